@@ -1,0 +1,178 @@
+"""
+ORACLE TOOLING -- TEST INFRASTRUCTURE ONLY.
+
+Generates tests/golden/*.npz by importing the UNMODIFIED reference from
+/root/reference/src (build container only; /root/reference does not exist on
+the GPU box, which is why the vectors are committed).  Run:
+
+    python oracle/make_golden.py
+
+`torchaudio` is absent from the image; the reference imports it transitively
+(models/filterbank.py:8 -> utils/audio.py:5) without using it on this path, so
+an empty stub module is injected before the import.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference/src"
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def import_reference():
+    sys.modules.setdefault("torchaudio", types.ModuleType("torchaudio"))
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from models.conv_tasnet import ConvTasNet
+    from criterion.sdr import NegSISDR, SISDR
+    from criterion.pit import PIT1d, SinkPIT
+    return ConvTasNet, NegSISDR, SISDR, PIT1d, SinkPIT
+
+
+CONFIGS = {
+    # BASELINE.json configs[0]: tiny, enc ReLU, 2 speakers
+    "tiny": dict(n_basis=64, kernel_size=16, stride=8, enc_basis="trainable", dec_basis="trainable", enc_nonlinear="relu",
+                 sep_hidden_channels=128, sep_bottleneck_channels=64, sep_skip_channels=64, sep_kernel_size=3,
+                 sep_num_blocks=1, sep_num_layers=2, dilated=True, separable=True, causal=False, sep_nonlinear="prelu",
+                 sep_norm=True, mask_nonlinear="sigmoid", n_sources=2),
+    # multi-block / dual-head logic, linear encoder, 3 speakers, skip != bottleneck width
+    "mid": dict(n_basis=128, kernel_size=16, stride=8, enc_basis="trainable", dec_basis="trainable", enc_nonlinear=None,
+                sep_hidden_channels=256, sep_bottleneck_channels=128, sep_skip_channels=64, sep_kernel_size=3,
+                sep_num_blocks=2, sep_num_layers=3, dilated=True, separable=True, causal=False, sep_nonlinear="prelu",
+                sep_norm=True, mask_nonlinear="sigmoid", n_sources=3),
+}
+SHAPES = {"tiny": (1, 4000), "mid": (2, 3203)}   # (batch, samples); 3203 exercises the input padding branch
+
+
+def perturb(model, seed):
+    """Default init has gamma=1, beta=0, alpha=0.25, which hides gamma/beta/alpha
+    indexing mistakes.  Perturb them (deterministically) so every parameter matters."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("norm.weight"):
+                p.add_(0.2 * torch.randn(p.shape, generator=g))
+            elif name.endswith("norm.bias"):
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+            elif name.endswith("nonlinear1d.weight") or name.endswith("prelu.weight"):
+                p.add_(0.1 * torch.rand(p.shape, generator=g))
+
+
+def model_golden(name, ConvTasNet, NegSISDR, PIT1d):
+    cfg = CONFIGS[name]
+    B, T = SHAPES[name]
+    torch.manual_seed(111)
+    model = ConvTasNet(**cfg)
+    perturb(model, 7)
+    g = torch.Generator().manual_seed(222)
+    sources = 0.1 * torch.randn(B, cfg["n_sources"], T, generator=g)
+    mixture = sources.sum(dim=1, keepdim=True)
+    crit = PIT1d(NegSISDR(), n_sources=cfg["n_sources"])
+
+    # fp32: the reference exactly as shipped
+    out32, latent32 = model.extract_latent(mixture)
+    loss32, pattern = crit(out32, sources)
+    # fp64 run of the same module tree: ground truth for gradients (SURVEY 8c noise-floor note)
+    import copy
+    m64 = copy.deepcopy(model).double()
+    out64, latent64 = m64.extract_latent(mixture.double())
+    loss64, pattern64 = crit(out64, sources.double())
+    loss64.backward()
+    assert torch.equal(pattern, pattern64)
+
+    blob = {"mixture": mixture.numpy(), "sources": sources.numpy(),
+            "output_f32": out32.detach().numpy(), "output_f64": out64.detach().numpy(),
+            "latent_f64_sum": np.array(latent64.detach().sum().item()),
+            "latent_f64_abs_sum": np.array(latent64.detach().abs().sum().item()),
+            "loss_f32": np.array(loss32.item()), "loss_f64": np.array(loss64.item()),
+            "pattern": pattern.numpy()}
+    for k, v in model.state_dict().items():
+        blob["param/" + k] = v.numpy()
+    for k, p in m64.named_parameters():
+        blob["grad/" + k] = p.grad.numpy().astype(np.float32)  # fp64 truth, stored as f32 to keep the fixture small
+    blob["num_parameters"] = np.array(model.num_parameters)
+    np.savez_compressed(os.path.join(OUT, "convtasnet_{}.npz".format(name)), **blob)
+    print(name, "params", model.num_parameters, "loss", loss64.item(), "pattern", pattern.tolist())
+
+
+def pit_kat(NegSISDR, SISDR, PIT1d, SinkPIT):
+    """The reference's own deterministic self-test, criterion/pit.py:226-263 and :331-361."""
+    import random
+    blob = {}
+    torch.manual_seed(111)
+    x = torch.randint(2, (4, 2, 1024), dtype=torch.float)
+    t = torch.randint(2, (4, 2, 1024), dtype=torch.float)
+    loss, pattern = PIT1d(SISDR(), n_sources=2)(x, t)
+    blob.update(pit_x=x.numpy(), pit_t=t.numpy(), pit_sisdr_loss=np.array(loss.item()), pit_sisdr_pattern=pattern.numpy())
+    print("PIT SI-SDR", loss.item(), pattern.tolist())
+
+    random.seed(111)
+    torch.manual_seed(111)
+    x = torch.randint(2, (4, 3, 1024), dtype=torch.float)
+    t = torch.randint(2, (4, 3, 1024), dtype=torch.float)
+    loss, pattern = PIT1d(NegSISDR(), n_sources=3)(x, t)
+    blob.update(sink_x=x.numpy(), sink_t=t.numpy(), pit3_negsisdr_loss=np.array(loss.item()), pit3_negsisdr_pattern=pattern.numpy())
+    print("PIT NegSI-SDR", loss.item(), pattern.tolist())
+    loss, pattern = SinkPIT(NegSISDR(), n_sources=3, coldness=1)(x, t, batch_mean=False)
+    blob.update(sinkpit_neg_loss=loss.numpy(), sinkpit_neg_pattern=pattern.numpy())
+    print("SinkPIT NegSI-SDR", loss.tolist(), pattern.tolist())
+    loss, pattern = SinkPIT(SISDR(), n_sources=3, coldness=1)(x, t, batch_mean=False)
+    blob.update(sinkpit_pos_loss=loss.numpy(), sinkpit_pos_pattern=pattern.numpy())
+    print("SinkPIT SI-SDR", loss.tolist(), pattern.tolist())
+
+    # gradient of SinkPIT through all iterations (fp64), continuous inputs, 4 sources, k=20, beta=2
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 4, 777, generator=g, dtype=torch.float64).requires_grad_(True)
+    t = torch.randn(3, 4, 777, generator=g, dtype=torch.float64)
+    x.data += 0.7 * t[:, [2, 0, 3, 1]]
+    loss, pattern = SinkPIT(NegSISDR(), n_sources=4, coldness=2.0, iteration=20)(x, t)
+    loss.backward()
+    blob.update(sg_x=x.detach().numpy(), sg_t=t.numpy(), sg_loss=np.array(loss.item()), sg_pattern=pattern.numpy(),
+                sg_grad=x.grad.numpy())
+    np.savez_compressed(os.path.join(OUT, "pit_kat.npz"), **blob)
+
+
+def op_golden(NegSISDR):
+    """Module-level vectors for the building blocks (reference modules run directly)."""
+    from modules.norm import GlobalLayerNorm
+    from models.tdcn import TimeDilatedConvNet
+    from models.filterbank import Encoder, Decoder
+    blob = {}
+    torch.manual_seed(3)
+    x = torch.randn(2, 6, 50, dtype=torch.float64) * 2 + 0.5
+    norm = GlobalLayerNorm(6).double()
+    with torch.no_grad():
+        norm.norm.weight.copy_(torch.randn(6)); norm.norm.bias.copy_(torch.randn(6))
+    blob.update(gln_x=x.numpy(), gln_w=norm.norm.weight.detach().numpy(), gln_b=norm.norm.bias.detach().numpy(),
+                gln_y=norm(x).detach().numpy())
+    net = TimeDilatedConvNet(8, hidden_channels=12, skip_channels=10, kernel_size=3, num_blocks=2, num_layers=3,
+                             dilated=True, separable=True, causal=False, nonlinear="prelu", norm=True).double()
+    x = torch.randn(2, 8, 37, dtype=torch.float64)
+    blob.update(tdcn_x=x.numpy(), tdcn_y=net(x).detach().numpy())
+    for k, v in net.state_dict().items():
+        blob["tdcn/" + k] = v.numpy()
+    enc = Encoder(2, 7, kernel_size=6, stride=3, nonlinear="relu").double()
+    x = torch.randn(2, 2, 33, dtype=torch.float64)
+    blob.update(enc_x=x.numpy(), enc_w=enc.conv1d.weight.detach().numpy(), enc_y=enc(x).detach().numpy())
+    dec = Decoder(7, 2, kernel_size=6, stride=3).double()
+    w = torch.randn(3, 7, 10, dtype=torch.float64)
+    blob.update(dec_x=w.numpy(), dec_w=dec.conv_transpose1d.weight.detach().numpy(), dec_y=dec(w).detach().numpy())
+    a = torch.randn(3, 2, 100, dtype=torch.float64)
+    b = torch.randn(3, 2, 100, dtype=torch.float64)
+    blob.update(sdr_x=a.numpy(), sdr_t=b.numpy(), sdr_negsisdr=NegSISDR()(a, b, batch_mean=False).numpy())
+    np.savez_compressed(os.path.join(OUT, "ops.npz"), **blob)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    ConvTasNet, NegSISDR, SISDR, PIT1d, SinkPIT = import_reference()
+    for name in CONFIGS:
+        model_golden(name, ConvTasNet, NegSISDR, PIT1d)
+    pit_kat(NegSISDR, SISDR, PIT1d, SinkPIT)
+    op_golden(NegSISDR)
+    print("golden vectors written to", OUT)
