@@ -1,0 +1,69 @@
+// Shared device/host helpers for libsepkernels (gfx950 / wave64 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/sepkernels.h"
+
+#define SEP_WAVE 64
+
+// ---- error plumbing (thread-local, never throws across the ABI) -------------------
+void sep_set_error(const char* fmt, ...);
+
+#define SEP_REQUIRE(cond, ...)            \
+    do {                                  \
+        if (!(cond)) {                    \
+            sep_set_error(__VA_ARGS__);   \
+            return -1;                    \
+        }                                 \
+    } while (0)
+
+#define SEP_CHECK_LAUNCH(name)                                                       \
+    do {                                                                             \
+        hipError_t e__ = hipGetLastError();                                          \
+        if (e__ != hipSuccess) {                                                     \
+            sep_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));    \
+            return -2;                                                               \
+        }                                                                            \
+    } while (0)
+
+// ---- wave / block reductions --------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Sum over a 256-thread block (4 waves). `sm` must hold >= 4 elements of T. Result valid in thread 0
+// (and in every thread of wave 0).  Ends with a barrier so `sm` can be reused.
+template <typename T>
+__device__ __forceinline__ T block_sum_256(T v, T* sm) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sm[w] = v;
+    __syncthreads();
+    T r = sm[0] + sm[1] + sm[2] + sm[3];
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ float prelu_f(float x, float a) { return x > 0.f ? x : a * x; }
+__device__ __forceinline__ float prelu_grad(float x, float a) { return x > 0.f ? 1.f : a; }
+
+// mean / rstd of a gLN from its {sum, sumsq} (double) -- biased variance like nn.GroupNorm
+__device__ __forceinline__ void gln_mu_rstd(const double* st, double count, float eps, float& mu, float& rstd) {
+    const double m = st[0] / count;
+    double var = st[1] / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mu = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

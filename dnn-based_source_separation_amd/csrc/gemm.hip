@@ -1,0 +1,566 @@
+// Pointwise (1x1) convolutions of the Conv-TasNet separator as fp32 MFMA GEMMs for gfx950.
+//
+//   forward / input-gradient :  Y[b][m][t] = epi( sum_k A[m][k] * pro(X[b][k][t]) + bias[m] )     (sep_pw_gemm)
+//   weight gradient          :  dW[m][n]   = sum_{b,t} G[b][m][t] * pro(X[b][n][t])               (sep_pw_wgrad)
+//
+// Replaces nn.Conv1d(kernel_size=1) of reference src/models/tdcn.py:86,173,175 and
+// src/models/conv_tasnet.py:335,341 together with the elementwise ops the reference runs as separate
+// ATen kernels around them (PReLU, gLN apply, residual/skip adds, sigmoid, their backward forms).
+//
+// Design (CDNA4): 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each wave a 64x64 tile =
+// 2x2 v_mfma_f32_32x32x2_f32 accumulators = 64 VGPRs), K staged through LDS in k-major order so that both
+// MFMA operands are read with conflict-free ds_read_b32 (lane l reads element [k = l>>5][l&31]).
+// Global->register->LDS staging is software pipelined one chunk ahead; the elementwise prologue
+// (PReLU / gLN scale+shift / gLN backward) runs on the values while they sit in registers, so the
+// normalised tensors v1, v2 of the reference never exist in HBM.  Blocks that share an X column tile are
+// placed on the same XCD (blockIdx % 8) so the tile is fetched from HBM once and re-read from that L2.
+#include "common.hpp"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+constexpr int BK = 16;       // contraction rows per chunk (forward / dgrad)
+constexpr int LDA_S = 132;   // As[k][m] row stride (floats): 16B aligned rows, 2-way max on the transposing scalar writes
+constexpr int LDB_S = 128;
+
+struct __attribute__((aligned(16))) GemmSmem {
+    float As[2][BK][LDA_S];
+    float Bs[2][BK][LDB_S];
+    double red[8];
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+__global__ __launch_bounds__(256) void pw_gemm_kernel(const sep_gemm_desc d) {
+    __shared__ GemmSmem sm;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+
+    const int NR = (d.M + BM - 1) / BM;
+    const int ntile_t = d.ldt / BN;
+    const int NC = d.B * ntile_t;
+    // XCD-aware decode: all row tiles of one column tile land on the same XCD (blockIdx % 8)
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, j = bid >> 3;
+    const int rt = j % NR;
+    const int ct = (j / NR) * 8 + xcd;
+    if (ct >= NC) return;
+    const int b = ct / ntile_t;
+    const int t0 = (ct % ntile_t) * BN;
+    const int m0 = rt * BM;
+    if (t0 >= d.T && d.pro_mode != SEP_PRO_GLN_BWD) {
+        // whole tile lies in the pad region: outputs are zero there (never read-modify-written)
+        for (int i = tid; i < BM * (BN / 4); i += 256) {
+            const int r = i / (BN / 4), c4 = i % (BN / 4);
+            const int row = m0 + r;
+            if (row >= d.M) continue;
+            float* dst;
+            size_t idx;
+            if (d.m_split && row >= d.m_split) {
+                dst = d.Y2; idx = ((size_t)b * (d.M - d.m_split) + (row - d.m_split)) * d.ldt;
+            } else {
+                dst = d.Y; idx = ((size_t)b * (d.m_split ? d.m_split : d.M) + row) * d.ldt;
+            }
+            st4(dst + idx + t0 + 4 * c4, make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+        if (d.epi_flags & SEP_EPI_ROWSUMS) {
+            for (int i = tid; i < BM * 2; i += 256) {
+                const int row = m0 + (i >> 1);
+                if (row < d.M) {
+                    float* rp = d.epi_rowpart + (((size_t)b * d.M + row) * (d.ldt / 64) + (t0 / 64) + (i & 1)) * 2;
+                    rp[0] = 0.f; rp[1] = 0.f;
+                }
+            }
+        }
+        return;
+    }
+
+    // ---- per-block prologue constants ------------------------------------------------
+    float mu = 0.f, rstd = 1.f, alpha_p = 0.f, mg = 0.f, mgx = 0.f;
+    const int pro = d.pro_mode;
+    if (pro == SEP_PRO_GLN || pro == SEP_PRO_GLN_PRELU || pro == SEP_PRO_GLN_BWD) gln_mu_rstd(d.pro_stats + 2 * b, d.count, d.eps, mu, rstd);
+    if (pro == SEP_PRO_PRELU || pro == SEP_PRO_GLN_PRELU || pro == SEP_PRO_GLN_BWD) alpha_p = d.pro_alpha[0];
+    if (pro == SEP_PRO_GLN_BWD) { mg = d.pro_bsum[2 * b]; mgx = d.pro_bsum[2 * b + 1]; }
+    float dalpha_pro = 0.f;
+
+    // ---- thread -> staging coordinates -------------------------------------------------
+    const int br = tid >> 5, bc4 = tid & 31;   // B tile: rows br, br+8 ; float4 column bc4
+    const int am = tid >> 2, ak4 = tid & 3;    // A tile (non-trans): rows am, am+64 ; float4 along k
+    const int nk = d.K / BK;
+
+    float4 ra[2], rb[2], rx[2];
+
+    auto load_global = [&](int kc) {
+        const int k0 = kc * BK;
+        const float* Xs = d.X;
+        const float* As_ = d.A;
+        int krow = k0, Ksrc = d.K;
+        bool second = false;
+        if (d.k_split) {
+            if (k0 >= d.k_split) { Xs = d.X2; As_ = d.A2; krow = k0 - d.k_split; Ksrc = d.K - d.k_split; second = true; }
+            else { Ksrc = d.k_split; }
+        }
+        (void)second;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const size_t off = ((size_t)b * Ksrc + krow + br + 8 * i) * d.ldt + t0 + 4 * bc4;
+            rb[i] = ld4(Xs + off);
+            if (pro == SEP_PRO_GLN_BWD) rx[i] = ld4(d.pro_aux + off);
+        }
+        if (d.trans_a) {
+            // A is [K][M]: row k, float4 along m
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int mm = m0 + 4 * bc4;
+                if (mm < d.M) ra[i] = ld4(As_ + (size_t)(krow + br + 8 * i) * d.M + mm);
+                else ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int mm = m0 + am + 64 * i;
+                if (mm < d.M) ra[i] = ld4(As_ + (size_t)mm * Ksrc + krow + 4 * ak4);
+                else ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+
+    auto store_lds = [&](int kc, int buf) {
+        const int k0 = kc * BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float v[4] = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
+            const int kg = k0 + br + 8 * i;   // global contraction row (parameter index of gamma/beta)
+            if (pro == SEP_PRO_PRELU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = prelu_f(v[q], alpha_p);
+            } else if (pro == SEP_PRO_GLN || pro == SEP_PRO_GLN_PRELU) {
+                const float sc = d.pro_gamma[kg] * rstd;
+                const float sh = d.pro_beta[kg] - mu * sc;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float u = (pro == SEP_PRO_GLN_PRELU) ? prelu_f(v[q], alpha_p) : v[q];
+                    v[q] = u * sc + sh;
+                }
+            } else if (pro == SEP_PRO_GLN_BWD) {
+                const float a4[4] = {rx[i].x, rx[i].y, rx[i].z, rx[i].w};
+                const float gk = d.pro_gamma[kg];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int t = t0 + 4 * bc4 + q;
+                    const float a = a4[q];
+                    const float u = prelu_f(a, alpha_p);
+                    const float xh = (u - mu) * rstd;
+                    const float du = rstd * (gk * v[q] - mg - xh * mgx);
+                    float da = du * prelu_grad(a, alpha_p);
+                    if (t >= d.T) da = 0.f;
+                    else if (a <= 0.f && rt == 0) dalpha_pro += du * a;
+                    v[q] = da;
+                }
+                if (rt == 0) {
+                    const size_t off = ((size_t)b * d.K + kg) * d.ldt + t0 + 4 * bc4;
+                    st4(d.pro_store + off, make_float4(v[0], v[1], v[2], v[3]));
+                }
+            }
+            st4(&sm.Bs[buf][br + 8 * i][4 * bc4], make_float4(v[0], v[1], v[2], v[3]));
+        }
+        if (d.trans_a) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) st4(&sm.As[buf][br + 8 * i][4 * bc4], ra[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int mm = am + 64 * i;
+                sm.As[buf][4 * ak4 + 0][mm] = ra[i].x;
+                sm.As[buf][4 * ak4 + 1][mm] = ra[i].y;
+                sm.As[buf][4 * ak4 + 2][mm] = ra[i].z;
+                sm.As[buf][4 * ak4 + 3][mm] = ra[i].w;
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    load_global(0);
+    store_lds(0, 0);
+    __syncthreads();
+
+    const int lk = lane >> 5, l31 = lane & 31;
+    for (int kc = 0; kc < nk; ++kc) {
+        const int cur = kc & 1;
+        if (kc + 1 < nk) load_global(kc + 1);
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            const int ka = 2 * kk + lk;
+            const float a0 = sm.As[cur][ka][wr * 64 + l31];
+            const float a1 = sm.As[cur][ka][wr * 64 + 32 + l31];
+            const float b0 = sm.Bs[cur][ka][wc * 64 + l31];
+            const float b1 = sm.Bs[cur][ka][wc * 64 + 32 + l31];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (kc + 1 < nk) store_lds(kc + 1, cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------
+    const int ef = d.epi_flags;
+    const float alpha_e = (ef & (SEP_EPI_STATS_PRELU | SEP_EPI_PRELU_BWD | SEP_EPI_ROWSUMS_PRELU)) ? d.epi_alpha[0] : 0.f;
+    float st_s = 0.f, st_ss = 0.f, dalpha_e = 0.f;
+    const int Mfirst = d.m_split ? d.m_split : d.M;
+
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            float rs1 = 0.f, rs2 = 0.f;
+            if (row < d.M) {
+                const float bias = d.bias ? d.bias[row] : 0.f;
+                const bool second = d.m_split && row >= d.m_split;
+                float* dst = second ? d.Y2 : d.Y;
+                const size_t rbase = second ? ((size_t)b * (d.M - d.m_split) + (row - d.m_split)) * d.ldt
+                                            : ((size_t)b * Mfirst + row) * d.ldt;
+                const size_t abase = ((size_t)b * d.M + row) * d.ldt;   // aux / residual tensors have M rows
+                const bool acc_this = d.accumulate && (second || !d.m_split);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int t = t0 + wc * 64 + ni * 32 + l31;
+                    const bool valid = t < d.T;
+                    float v = acc[mi][ni][r] + bias;
+                    if (ef & SEP_EPI_STATS_PRELU) {
+                        const float u = prelu_f(v, alpha_e);
+                        if (valid) { st_s += u; st_ss += u * u; }
+                    }
+                    if ((ef & SEP_EPI_RESIDUAL) && !second) v += d.epi_res[abase + t];
+                    if (ef & SEP_EPI_SIGMOID) v = 1.f / (1.f + expf(-v));
+                    if (ef & SEP_EPI_PRELU_BWD) {
+                        const float s = d.epi_aux[abase + t];
+                        if (valid && s <= 0.f) dalpha_e += v * s;
+                        v *= prelu_grad(s, alpha_e);
+                    }
+                    if (ef & SEP_EPI_ROWSUMS) {
+                        float u = d.epi_aux[abase + t];
+                        if (ef & SEP_EPI_ROWSUMS_PRELU) u = prelu_f(u, alpha_e);
+                        if (valid) { rs1 += v; rs2 += v * u; }
+                    }
+                    if (acc_this) v += dst[rbase + t];
+                    dst[rbase + t] = valid ? v : 0.f;
+                }
+            }
+            if (ef & SEP_EPI_ROWSUMS) {
+                // reduce over the 32 lanes that share (row): xor stays inside a 32-lane half
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) {
+                    rs1 += __shfl_xor(rs1, o, 64);
+                    rs2 += __shfl_xor(rs2, o, 64);
+                }
+                if (l31 == 0 && row < d.M) {
+                    float* rp = d.epi_rowpart + (((size_t)b * d.M + row) * (d.ldt / 64) + (t0 + wc * 64) / 64) * 2;
+                    rp[0] = rs1; rp[1] = rs2;
+                }
+            }
+        }
+    }
+    if (ef & SEP_EPI_STATS_PRELU) {
+        const double s = block_sum_256<double>((double)st_s, sm.red);
+        const double ss = block_sum_256<double>((double)st_ss, sm.red);
+        if (tid == 0) { atomicAdd(d.epi_stats + 2 * b, s); atomicAdd(d.epi_stats + 2 * b + 1, ss); }
+    }
+    if (ef & SEP_EPI_PRELU_BWD) {
+        const double s = block_sum_256<double>((double)dalpha_e, sm.red);
+        if (tid == 0) atomicAdd(d.epi_dalpha, s);
+    }
+    if (pro == SEP_PRO_GLN_BWD && rt == 0) {
+        const double s = block_sum_256<double>((double)dalpha_pro, sm.red);
+        if (tid == 0) atomicAdd(d.pro_dalpha, s);
+    }
+}
+
+// ======================================================================================
+// weight gradient: reduction over (batch, frame) columns, split into nsplit slabs
+// ======================================================================================
+constexpr int WK = 32;      // frames per chunk (one 128-byte line per operand row)
+constexpr int LDW_S = 129;  // k-major LDS row stride: odd -> conflict-free transposing writes AND fragment reads
+
+struct __attribute__((aligned(16))) WgradSmem {
+    float Gs[2][WK][LDW_S];
+    float Xs[2][WK][LDW_S];
+};
+
+__global__ __launch_bounds__(256) void pw_wgrad_kernel(const sep_wgrad_desc d) {
+    __shared__ WgradSmem sm;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
+    const int ntiles = ntm * ntn;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, j = bid >> 3;
+    const int tile = j % ntiles;
+    const int s = (j / ntiles) * 8 + xcd;
+    if (s >= d.nsplit) return;
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+
+    const int cps_t = d.ldt / WK;                 // chunks per sample
+    const long chunks_total = (long)d.B * cps_t;
+    const long cper = (chunks_total + d.nsplit - 1) / d.nsplit;
+    const long c_begin = (long)s * cper;
+    long c_end = c_begin + cper;
+    if (c_end > chunks_total) c_end = chunks_total;
+
+    const int lr = tid >> 3, lc4 = tid & 7;       // staging: rows lr + 32*i (i<4), float4 column lc4
+    const bool do_bias = d.partial_bias != nullptr && (tile % ntn) == 0;
+    float bias_acc = 0.f;
+
+    const float alpha_x = (d.x_mode == SEP_PRO_PRELU || d.x_mode == SEP_PRO_GLN_PRELU) ? d.x_alpha[0] : 0.f;
+    float4 rg[4], rx[4];
+    float xsc[4], xsh[4];
+
+    auto chunk_valid = [&](long c) -> bool { return (int)(c % cps_t) * WK < d.T; };
+
+    auto load_global = [&](long c) {
+        const int b = (int)(c / cps_t);
+        const int t0 = (int)(c % cps_t) * WK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + lr + 32 * i;
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < d.M) {
+                const float* src;
+                size_t off;
+                if (d.g_split && m >= d.g_split) { src = d.G2; off = ((size_t)b * (d.M - d.g_split) + (m - d.g_split)) * d.ldt; }
+                else { src = d.G; off = ((size_t)b * (d.g_split ? d.g_split : d.M) + m) * d.ldt; }
+                g = ld4(src + off + t0 + 4 * lc4);
+                if (d.g_mul) {
+                    const float4 w = ld4(d.Gaux + ((size_t)(b / d.g_div) * d.M + m) * d.ldt + t0 + 4 * lc4);
+                    g.x *= w.x; g.y *= w.y; g.z *= w.z; g.w *= w.w;
+                }
+            }
+            rg[i] = g;
+            const int n = n0 + lr + 32 * i;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            xsc[i] = 0.f; xsh[i] = 0.f;
+            if (n < d.N) {
+                const int bx = b / d.x_div;
+                x = ld4(d.X + ((size_t)bx * d.N + n) * d.ldt + t0 + 4 * lc4);
+                if (d.x_mode == SEP_PRO_GLN || d.x_mode == SEP_PRO_GLN_PRELU) {
+                    float mu, rstd;
+                    gln_mu_rstd(d.x_stats + 2 * bx, d.count, d.eps, mu, rstd);
+                    xsc[i] = d.x_gamma[n] * rstd;
+                    xsh[i] = d.x_beta[n] - mu * xsc[i];
+                }
+            }
+            rx[i] = x;
+        }
+    };
+
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int mm = lr + 32 * i;
+            sm.Gs[buf][4 * lc4 + 0][mm] = rg[i].x;
+            sm.Gs[buf][4 * lc4 + 1][mm] = rg[i].y;
+            sm.Gs[buf][4 * lc4 + 2][mm] = rg[i].z;
+            sm.Gs[buf][4 * lc4 + 3][mm] = rg[i].w;
+            float v[4] = {rx[i].x, rx[i].y, rx[i].z, rx[i].w};
+            const bool row_ok = (n0 + mm) < d.N;
+            if (d.x_mode == SEP_PRO_PRELU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = prelu_f(v[q], alpha_x);
+            } else if (d.x_mode == SEP_PRO_GLN || d.x_mode == SEP_PRO_GLN_PRELU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float u = (d.x_mode == SEP_PRO_GLN_PRELU) ? prelu_f(v[q], alpha_x) : v[q];
+                    v[q] = row_ok ? (u * xsc[i] + xsh[i]) : 0.f;
+                }
+            }
+            sm.Xs[buf][4 * lc4 + 0][mm] = v[0];
+            sm.Xs[buf][4 * lc4 + 1][mm] = v[1];
+            sm.Xs[buf][4 * lc4 + 2][mm] = v[2];
+            sm.Xs[buf][4 * lc4 + 3][mm] = v[3];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    // skip chunks that lie entirely in the zero pad (G is exactly 0 there)
+    long c = c_begin;
+    while (c < c_end && !chunk_valid(c)) ++c;
+    const int lk = lane >> 5, l31 = lane & 31;
+    int cur = 0;
+    if (c < c_end) {
+        load_global(c);
+        store_lds(0);
+    }
+    __syncthreads();
+    while (c < c_end) {
+        long cn = c + 1;
+        while (cn < c_end && !chunk_valid(cn)) ++cn;
+        if (cn < c_end) load_global(cn);
+#pragma unroll 4
+        for (int kk = 0; kk < WK / 2; ++kk) {
+            const int ka = 2 * kk + lk;
+            const float a0 = sm.Gs[cur][ka][wr * 64 + l31];
+            const float a1 = sm.Gs[cur][ka][wr * 64 + 32 + l31];
+            const float b0 = sm.Xs[cur][ka][wc * 64 + l31];
+            const float b1 = sm.Xs[cur][ka][wc * 64 + 32 + l31];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (do_bias && tid < BM) {
+            float sacc = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < WK; ++k) sacc += sm.Gs[cur][k][tid];
+            bias_acc += sacc;
+        }
+        if (cn < c_end) store_lds(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+        c = cn;
+    }
+
+    float* out = d.partial + (size_t)s * d.M * d.N;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (row < d.M) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int col = n0 + wc * 64 + ni * 32 + l31;
+                    if (col < d.N) out[(size_t)row * d.N + col] = acc[mi][ni][r];
+                }
+            }
+        }
+    if (do_bias && tid < BM && (m0 + tid) < d.M) d.partial_bias[(size_t)s * d.M + m0 + tid] = bias_acc;
+}
+
+// ======================================================================================
+struct ReduceArgs {
+    sep_reduce_seg seg[8];
+    int blk_start[9];
+    int nseg;
+};
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceArgs a) {
+    int sgi = 0;
+    while (sgi + 1 < a.nseg && (int)blockIdx.x >= a.blk_start[sgi + 1]) ++sgi;
+    const sep_reduce_seg sg = a.seg[sgi];
+    const int i = ((int)blockIdx.x - a.blk_start[sgi]) * 256 + threadIdx.x;
+    if (i >= sg.n) return;
+    // fixed summation order -> bit-stable run to run; 4 independent chains hide load latency
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < sg.nslab; k += 4) {
+        s0 += sg.src[(size_t)(k + 0) * sg.stride + i];
+        s1 += sg.src[(size_t)(k + 1) * sg.stride + i];
+        s2 += sg.src[(size_t)(k + 2) * sg.stride + i];
+        s3 += sg.src[(size_t)(k + 3) * sg.stride + i];
+    }
+    for (; k < sg.nslab; ++k) s0 += sg.src[(size_t)k * sg.stride + i];
+    float v = ((s0 + s1) + (s2 + s3)) * sg.scale;
+    if (sg.accumulate) v += sg.dst[i];
+    sg.dst[i] = v;
+}
+
+__global__ void f64_to_f32_kernel(const double* src, float* dst, int n, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (accumulate ? dst[i] : 0.f) + (float)src[i];
+}
+
+}  // namespace
+
+extern "C" int sep_pw_gemm(const sep_gemm_desc* d, sep_stream_t stream) {
+    SEP_REQUIRE(d != nullptr, "sep_pw_gemm: null descriptor");
+    SEP_REQUIRE(d->B > 0 && d->M > 0 && d->K > 0 && d->T > 0, "sep_pw_gemm: empty problem (B=%d M=%d K=%d T=%d)", d->B, d->M, d->K, d->T);
+    SEP_REQUIRE(d->ldt % 128 == 0 && d->ldt >= d->T, "sep_pw_gemm: ldt=%d must be a multiple of 128 and >= T=%d", d->ldt, d->T);
+    SEP_REQUIRE(d->K % BK == 0, "sep_pw_gemm: K=%d must be a multiple of %d", d->K, BK);
+    SEP_REQUIRE(d->k_split % BK == 0 && d->k_split < d->K, "sep_pw_gemm: bad k_split=%d", d->k_split);
+    SEP_REQUIRE(d->m_split % BM == 0 && d->m_split < d->M, "sep_pw_gemm: bad m_split=%d (M=%d)", d->m_split, d->M);
+    SEP_REQUIRE(!d->trans_a || d->M % 4 == 0, "sep_pw_gemm: transposed A needs M %% 4 == 0 (M=%d)", d->M);
+    SEP_REQUIRE(d->A && d->X && d->Y, "sep_pw_gemm: null operand");
+    SEP_REQUIRE(!d->k_split || (d->A2 && d->X2), "sep_pw_gemm: k_split without A2/X2");
+    SEP_REQUIRE(!d->m_split || d->Y2, "sep_pw_gemm: m_split without Y2");
+    SEP_REQUIRE(d->pro_mode >= 0 && d->pro_mode <= SEP_PRO_GLN_BWD, "sep_pw_gemm: bad pro_mode %d", d->pro_mode);
+    if (d->pro_mode == SEP_PRO_PRELU || d->pro_mode == SEP_PRO_GLN_PRELU || d->pro_mode == SEP_PRO_GLN_BWD)
+        SEP_REQUIRE(d->pro_alpha, "sep_pw_gemm: prologue needs pro_alpha");
+    if (d->pro_mode >= SEP_PRO_GLN)
+        SEP_REQUIRE(d->pro_stats && d->pro_gamma && (d->pro_mode == SEP_PRO_GLN_BWD || d->pro_beta) && d->count > 0, "sep_pw_gemm: gLN prologue needs stats/gamma/beta/count");
+    if (d->pro_mode == SEP_PRO_GLN_BWD)
+        SEP_REQUIRE(d->pro_aux && d->pro_bsum && d->pro_store && d->pro_dalpha && !d->k_split, "sep_pw_gemm: GLN_BWD prologue needs aux/bsum/store/dalpha");
+    if (d->epi_flags & SEP_EPI_STATS_PRELU) SEP_REQUIRE(d->epi_stats && d->epi_alpha, "sep_pw_gemm: STATS_PRELU needs epi_stats/epi_alpha");
+    if (d->epi_flags & SEP_EPI_RESIDUAL) SEP_REQUIRE(d->epi_res, "sep_pw_gemm: RESIDUAL needs epi_res");
+    if (d->epi_flags & SEP_EPI_PRELU_BWD) SEP_REQUIRE(d->epi_aux && d->epi_alpha && d->epi_dalpha, "sep_pw_gemm: PRELU_BWD needs aux/alpha/dalpha");
+    if (d->epi_flags & SEP_EPI_ROWSUMS) SEP_REQUIRE(d->epi_aux && d->epi_rowpart && !d->m_split, "sep_pw_gemm: ROWSUMS needs aux/rowpart");
+    if (d->epi_flags & SEP_EPI_ROWSUMS_PRELU) SEP_REQUIRE(d->epi_alpha, "sep_pw_gemm: ROWSUMS_PRELU needs epi_alpha");
+    const int NR = ceil_div(d->M, BM);
+    const int NC = d->B * (d->ldt / BN);
+    const int grid = 8 * NR * ceil_div(NC, 8);
+    hipLaunchKernelGGL(pw_gemm_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
+    SEP_CHECK_LAUNCH("sep_pw_gemm");
+    return 0;
+}
+
+extern "C" int sep_pw_wgrad(const sep_wgrad_desc* d, sep_stream_t stream) {
+    SEP_REQUIRE(d != nullptr, "sep_pw_wgrad: null descriptor");
+    SEP_REQUIRE(d->B > 0 && d->M > 0 && d->N > 0 && d->T > 0, "sep_pw_wgrad: empty problem");
+    SEP_REQUIRE(d->ldt % 128 == 0 && d->ldt >= d->T, "sep_pw_wgrad: ldt=%d must be a multiple of 128 and >= T=%d", d->ldt, d->T);
+    SEP_REQUIRE(d->nsplit > 0 && (long)d->nsplit <= (long)d->B * (d->ldt / WK), "sep_pw_wgrad: bad nsplit=%d", d->nsplit);
+    SEP_REQUIRE(d->g_split % BM == 0 && d->g_split < d->M, "sep_pw_wgrad: bad g_split=%d", d->g_split);
+    SEP_REQUIRE(d->G && d->X && d->partial, "sep_pw_wgrad: null operand");
+    SEP_REQUIRE(!d->g_split || d->G2, "sep_pw_wgrad: g_split without G2");
+    SEP_REQUIRE(!d->g_mul || (d->Gaux && d->g_div > 0 && !d->g_split), "sep_pw_wgrad: g_mul needs Gaux/g_div");
+    SEP_REQUIRE(d->x_div > 0, "sep_pw_wgrad: x_div must be >= 1");
+    SEP_REQUIRE(d->x_mode >= 0 && d->x_mode <= SEP_PRO_GLN_PRELU, "sep_pw_wgrad: bad x_mode %d", d->x_mode);
+    if (d->x_mode == SEP_PRO_PRELU || d->x_mode == SEP_PRO_GLN_PRELU) SEP_REQUIRE(d->x_alpha, "sep_pw_wgrad: needs x_alpha");
+    if (d->x_mode >= SEP_PRO_GLN) SEP_REQUIRE(d->x_stats && d->x_gamma && d->x_beta && d->count > 0, "sep_pw_wgrad: gLN prologue needs stats/gamma/beta/count");
+    const int ntiles = ceil_div(d->M, BM) * ceil_div(d->N, BN);
+    const int grid = 8 * ntiles * ceil_div(d->nsplit, 8);
+    hipLaunchKernelGGL(pw_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
+    SEP_CHECK_LAUNCH("sep_pw_wgrad");
+    return 0;
+}
+
+extern "C" int sep_reduce_slabs(const sep_reduce_seg* segs, int nseg, sep_stream_t stream) {
+    SEP_REQUIRE(segs && nseg >= 1 && nseg <= 8, "sep_reduce_slabs: 1..8 segments per launch (got %d)", nseg);
+    ReduceArgs a;
+    int blocks = 0;
+    for (int i = 0; i < nseg; ++i) {
+        SEP_REQUIRE(segs[i].src && segs[i].dst && segs[i].n > 0 && segs[i].nslab > 0, "sep_reduce_slabs: bad segment %d", i);
+        a.seg[i] = segs[i];
+        a.blk_start[i] = blocks;
+        blocks += ceil_div(segs[i].n, 256);
+    }
+    a.blk_start[nseg] = blocks;
+    a.nseg = nseg;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    SEP_CHECK_LAUNCH("sep_reduce_slabs");
+    return 0;
+}
+
+extern "C" int sep_f64_to_f32(const double* src, float* dst, int n, int accumulate, sep_stream_t stream) {
+    SEP_REQUIRE(src && dst && n > 0, "sep_f64_to_f32: bad arguments");
+    hipLaunchKernelGGL(f64_to_f32_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, n, accumulate);
+    SEP_CHECK_LAUNCH("sep_f64_to_f32");
+    return 0;
+}

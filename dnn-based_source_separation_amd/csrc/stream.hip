@@ -1,0 +1,747 @@
+// HBM-bound (streaming) kernels of the Conv-TasNet path for gfx950: learned encoder / decoder with
+// overlap-add, dilated depthwise conv with the gLN + PReLU of its input fused on load (LDS-staged
+// receptive field), their backward forms, the second stage of the gLN backward reductions, and a
+// stand-alone gLN.  All tensors (batch, channel, frame) fp32 with padded row stride ldt; frames [T, ldt)
+// of every written tensor are zero.
+//
+// Reference arithmetic replaced (under /root/reference/src): models/filterbank.py:205-251 (Encoder/Decoder),
+// models/conv_tasnet.py:145-169 (pad, mask*w, crop), models/tdcn.py:113-132,177-186 (PReLU -> gLN -> zero pad ->
+// depthwise conv -> PReLU), modules/norm.py:11-35 (gLN = GroupNorm(1, C)).
+#include "common.hpp"
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// =====================================================================================
+// Encoder: w[b][n][f] = sum_{c,k} E[n][c][k] * xpad[b][c][S f + k]   (+ReLU), + gLN statistics of w
+// One block = 128 frames x all N basis rows.  Thread = (frame, n parity); the basis row is wave-uniform
+// (scalar loads), the frame's samples sit in registers (LC = Cin*L <= 16) or LDS (generic).
+// =====================================================================================
+constexpr int ENC_FT = 128;
+
+template <int LC_REG>
+__global__ __launch_bounds__(256) void encoder_fwd_kernel(const float* __restrict__ x, const float* __restrict__ E,
+                                                          float* __restrict__ w, double* __restrict__ stats, int B,
+                                                          int Cin, int Tin, int N, int L, int S, int F, int ldt,
+                                                          int pad_left, int relu) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [Cin][span]
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int f0 = blockIdx.x * ENC_FT;
+    const int span = ENC_FT * S + L - S;
+    for (int i = tid; i < Cin * span; i += 256) {
+        const int c = i / span, o = i % span;
+        const int tau = S * f0 + o - pad_left;
+        xs[i] = (tau >= 0 && tau < Tin) ? x[((size_t)b * Cin + c) * Tin + tau] : 0.f;
+    }
+    __syncthreads();
+    const int fl = tid & (ENC_FT - 1);
+    const int f = f0 + fl;
+    const int nh = __builtin_amdgcn_readfirstlane(tid >> 7);   // wave-uniform
+    const bool fvalid = f < F;
+    const int LC = Cin * L;
+    float xr[LC_REG > 0 ? LC_REG : 1];
+    if (LC_REG > 0) {
+#pragma unroll
+        for (int q = 0; q < LC_REG; ++q) {
+            const int c = q / L, k = q % L;
+            xr[q] = xs[c * span + S * fl + k];
+        }
+    }
+    float s = 0.f, ss = 0.f;
+    for (int n = nh; n < N; n += 2) {
+        const float* En = E + (size_t)n * LC;
+        float acc = 0.f;
+        if (LC_REG > 0) {
+#pragma unroll
+            for (int q = 0; q < LC_REG; ++q) acc = fmaf(En[q], xr[q], acc);
+        } else {
+            for (int c = 0; c < Cin; ++c)
+                for (int k = 0; k < L; ++k) acc = fmaf(En[c * L + k], xs[c * span + S * fl + k], acc);
+        }
+        if (relu) acc = fmaxf(acc, 0.f);
+        if (!fvalid) acc = 0.f;
+        s += acc; ss += acc * acc;
+        if (f < ldt) w[((size_t)b * N + n) * ldt + f] = acc;
+    }
+    const double ds = block_sum_256<double>((double)s, red);
+    const double dss = block_sum_256<double>((double)ss, red);
+    if (tid == 0) { atomicAdd(stats + 2 * b, ds); atomicAdd(stats + 2 * b + 1, dss); }
+}
+
+// frames[bp][c*L+k][f] = xpad[bp][c][S f + k] (f < F), 0 for F <= f < ldt
+__global__ __launch_bounds__(256) void unfold_kernel(const float* __restrict__ x, float* __restrict__ frames, int C,
+                                                     int Tin, int L, int S, int F, int ldt, int pad_left) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    const int row = blockIdx.y;           // c*L + k
+    const int bp = blockIdx.z;
+    if (f >= ldt) return;
+    const int c = row / L, k = row % L;
+    const int tau = S * f + k - pad_left;
+    float v = 0.f;
+    if (f < F && tau >= 0 && tau < Tin) v = x[((size_t)bp * C + c) * Tin + tau];
+    frames[((size_t)bp * C * L + row) * ldt + f] = v;
+}
+
+// =====================================================================================
+// Depthwise dilated conv, forward.  One wave = one (b, c, 1024-frame tile): the tile plus a halo of
+// round_up(d,4) frames each side is loaded with float4, normalised (gLN o PReLU) and zero-masked on the
+// way into wave-private LDS; outputs are computed lane-consecutive (conflict-free ds_read_b32).
+// =====================================================================================
+constexpr int DW_TT = 1024;
+
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict__ a, const double* __restrict__ stats1,
+                                                         const float* __restrict__ gamma1, const float* __restrict__ beta1,
+                                                         const float* __restrict__ alpha1, const float* __restrict__ wd,
+                                                         const float* __restrict__ bd, const float* __restrict__ alpha2,
+                                                         float* __restrict__ z, double* __restrict__ stats2, int B, int C,
+                                                         int T, int ldt, int d, int dpad, float eps) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ double wred[4][2];
+    __shared__ int wb[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ntile = (ldt + DW_TT - 1) / DW_TT;
+    const long total = (long)B * C * ntile;
+    const long g = (long)blockIdx.x * 4 + wv;
+    const bool active = g < total;
+    const int wlen = DW_TT + 2 * dpad;
+    float* vs = lds + (size_t)wv * wlen;
+
+    int b = 0, c = 0, t0 = 0;
+    float s = 0.f, ss = 0.f;
+    if (active) {
+        const int tile = (int)(g % ntile);
+        c = (int)((g / ntile) % C);
+        b = (int)(g / ((long)ntile * C));
+        t0 = tile * DW_TT;
+        float mu, rstd;
+        gln_mu_rstd(stats1 + 2 * b, (double)C * T, eps, mu, rstd);
+        const float a1 = alpha1[0];
+        const float sc = gamma1[c] * rstd, sh = beta1[c] - mu * sc;
+        const float* arow = a + ((size_t)b * C + c) * ldt;
+        for (int q = lane; q < wlen / 4; q += 64) {
+            const int tp = t0 - dpad + 4 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tp >= 0 && tp < ldt) {
+                const float4 r = ld4(arow + tp);
+                v.x = (tp + 0 < T) ? prelu_f(r.x, a1) * sc + sh : 0.f;
+                v.y = (tp + 1 < T) ? prelu_f(r.y, a1) * sc + sh : 0.f;
+                v.z = (tp + 2 < T) ? prelu_f(r.z, a1) * sc + sh : 0.f;
+                v.w = (tp + 3 < T) ? prelu_f(r.w, a1) * sc + sh : 0.f;
+            }
+            st4(vs + 4 * q, v);
+        }
+    }
+    __syncthreads();
+    if (active) {
+        const float w0 = wd[c * 3 + 0], w1 = wd[c * 3 + 1], w2 = wd[c * 3 + 2], bb = bd[c];
+        const float a2 = alpha2[0];
+        float* zrow = z + ((size_t)b * C + c) * ldt;
+#pragma unroll 4
+        for (int i = 0; i < DW_TT / 64; ++i) {
+            const int o = lane + 64 * i;
+            const int t = t0 + o;
+            if (t >= ldt) break;
+            float zz = 0.f;
+            if (t < T) {
+                zz = bb + w0 * vs[dpad + o - d] + w1 * vs[dpad + o] + w2 * vs[dpad + o + d];
+                const float u = prelu_f(zz, a2);
+                s += u; ss += u * u;
+            }
+            zrow[t] = zz;
+        }
+    }
+    const double dsum = wave_sum((double)s), dss = wave_sum((double)ss);
+    if (lane == 0) { wred[wv][0] = dsum; wred[wv][1] = dss; wb[wv] = active ? b : -1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // merge waves that belong to the same sample -> at most one atomic pair per sample per block
+        for (int i = 0; i < 4; ++i) {
+            if (wb[i] < 0) continue;
+            double x0 = wred[i][0], x1 = wred[i][1];
+            for (int k = i + 1; k < 4; ++k)
+                if (wb[k] == wb[i]) { x0 += wred[k][0]; x1 += wred[k][1]; wb[k] = -1; }
+            atomicAdd(stats2 + 2 * wb[i], x0);
+            atomicAdd(stats2 + 2 * wb[i] + 1, x1);
+        }
+    }
+}
+
+// =====================================================================================
+// Backward of [gLN2 o PReLU2 o depthwise]: dv2 -> dv1 plus the per-row partial sums every downstream
+// reduction needs (gLN1 backward, depthwise weight/bias gradient, PReLU2 slope gradient).
+// rowpart[b][c][tile][8] = {sum dv1, sum dv1*u1, sum dz, sum dz*v1(t-d), sum dz*v1(t), sum dz*v1(t+d), dalpha2, 0}
+// =====================================================================================
+__global__ __launch_bounds__(256) void dwconv_bwd_kernel(
+    const float* __restrict__ dv2, const float* __restrict__ z, const float* __restrict__ a,
+    const double* __restrict__ stats1, const float* __restrict__ gamma1, const float* __restrict__ beta1,
+    const float* __restrict__ alpha1, const double* __restrict__ stats2, const float* __restrict__ gamma2,
+    const float* __restrict__ alpha2, const float* __restrict__ bsum2, const float* __restrict__ wd,
+    float* __restrict__ dv1, float* __restrict__ rowpart, int B, int C, int T, int ldt, int d, int dpad, float eps) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ntile = (ldt + DW_TT - 1) / DW_TT;
+    const long total = (long)B * C * ntile;
+    const long g = (long)blockIdx.x * 4 + wv;
+    const bool active = g < total;
+    const int wlen = DW_TT + 2 * dpad;
+    float* dzs = lds + (size_t)wv * 2 * wlen;
+    float* us = dzs + wlen;
+
+    int b = 0, c = 0, t0 = 0, tile = 0;
+    float sc1 = 0.f, sh1 = 0.f;
+    float q_dal = 0.f;
+    if (active) {
+        tile = (int)(g % ntile);
+        c = (int)((g / ntile) % C);
+        b = (int)(g / ((long)ntile * C));
+        t0 = tile * DW_TT;
+        float mu1, r1, mu2, r2;
+        gln_mu_rstd(stats1 + 2 * b, (double)C * T, eps, mu1, r1);
+        gln_mu_rstd(stats2 + 2 * b, (double)C * T, eps, mu2, r2);
+        const float a1 = alpha1[0], a2 = alpha2[0];
+        sc1 = gamma1[c] * r1; sh1 = beta1[c] - mu1 * sc1;
+        const float g2 = gamma2[c];
+        const float mg = bsum2[2 * b], mgx = bsum2[2 * b + 1];
+        const size_t rowoff = ((size_t)b * C + c) * ldt;
+        for (int q = lane; q < wlen / 4; q += 64) {
+            const int tp = t0 - dpad + 4 * q;
+            float dzv[4] = {0.f, 0.f, 0.f, 0.f}, uv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (tp >= 0 && tp < ldt) {
+                const float4 gv = ld4(dv2 + rowoff + tp);
+                const float4 zv = ld4(z + rowoff + tp);
+                const float4 av = ld4(a + rowoff + tp);
+                const float g4[4] = {gv.x, gv.y, gv.z, gv.w};
+                const float z4[4] = {zv.x, zv.y, zv.z, zv.w};
+                const float a4[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int t = tp + e;
+                    if (t < T) {
+                        const float u2 = prelu_f(z4[e], a2);
+                        const float xh = (u2 - mu2) * r2;
+                        const float du2 = r2 * (g2 * g4[e] - mg - xh * mgx);
+                        dzv[e] = du2 * prelu_grad(z4[e], a2);
+                        uv[e] = prelu_f(a4[e], a1);
+                        if (z4[e] <= 0.f && t >= t0 && t < t0 + DW_TT) q_dal += du2 * z4[e];
+                    }
+                }
+            }
+            st4(dzs + 4 * q, make_float4(dzv[0], dzv[1], dzv[2], dzv[3]));
+            st4(us + 4 * q, make_float4(uv[0], uv[1], uv[2], uv[3]));
+        }
+    }
+    __syncthreads();
+    float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f, q4 = 0.f, q5 = 0.f;
+    if (active) {
+        const float w0 = wd[c * 3 + 0], w1 = wd[c * 3 + 1], w2 = wd[c * 3 + 2];
+        float* orow = dv1 + ((size_t)b * C + c) * ldt;
+#pragma unroll 4
+        for (int i = 0; i < DW_TT / 64; ++i) {
+            const int o = lane + 64 * i;
+            const int t = t0 + o;
+            if (t >= ldt) break;
+            float dv = 0.f;
+            if (t < T) {
+                const int p = dpad + o;
+                // dv1[t] = sum_k w[k] * dz[t - (k-1) d]
+                dv = w0 * dzs[p + d] + w1 * dzs[p] + w2 * dzs[p - d];
+                const float dzt = dzs[p];
+                // v1 = gLN1(u1) inside [0,T), literal zero outside (padding is applied after the norm)
+                const float vm = (t - d >= 0) ? us[p - d] * sc1 + sh1 : 0.f;
+                const float v0 = us[p] * sc1 + sh1;
+                const float vp = (t + d < T) ? us[p + d] * sc1 + sh1 : 0.f;
+                q0 += dv; q1 += dv * us[p];
+                q2 += dzt; q3 += dzt * vm; q4 += dzt * v0; q5 += dzt * vp;
+            }
+            orow[t] = dv;
+        }
+    }
+    q0 = wave_sum(q0); q1 = wave_sum(q1); q2 = wave_sum(q2); q3 = wave_sum(q3);
+    q4 = wave_sum(q4); q5 = wave_sum(q5); q_dal = wave_sum(q_dal);
+    if (active && lane == 0) {
+        float* rp = rowpart + (((size_t)b * C + c) * ntile + tile) * 8;
+        rp[0] = q0; rp[1] = q1; rp[2] = q2; rp[3] = q3; rp[4] = q4; rp[5] = q5; rp[6] = q_dal; rp[7] = 0.f;
+    }
+}
+
+// =====================================================================================
+// gLN backward, second stage.  One block per sample; one wave reduces one (b, c) row of partials at a time.
+// nq in {2, 8}.  Outputs: pbeta[b][c], pgamma[b][c], bsum[b][2]; nq == 8: pextra[b] = [db[C] | dw[C][3]], palpha[b].
+// =====================================================================================
+__global__ __launch_bounds__(256) void gln_bwd_finalize_kernel(const float* __restrict__ rowpart, int ntile, int nq,
+                                                               const double* __restrict__ stats,
+                                                               const float* __restrict__ gamma, double count, float eps,
+                                                               float* __restrict__ bsum, float* __restrict__ pbeta,
+                                                               float* __restrict__ pgamma, float* __restrict__ pextra,
+                                                               float* __restrict__ palpha, int C) {
+    __shared__ float red[4][3];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float mu, rstd;
+    gln_mu_rstd(stats + 2 * b, count, eps, mu, rstd);
+    const int rowlen = ntile * nq;
+    float sg = 0.f, sgx = 0.f, sal = 0.f;
+    for (int c = wv; c < C; c += 4) {
+        const float* rp = rowpart + ((size_t)b * C + c) * rowlen;
+        float acc = 0.f;
+        for (int i = lane; i < rowlen; i += 64) acc += rp[i];     // i % nq == lane % nq (nq divides 64)
+        for (int o = nq; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
+        // lanes 0..nq-1 now hold the totals of quantity q = lane
+        const float R1 = __shfl(acc, 0, 64), R2 = __shfl(acc, 1, 64);
+        const float pg = rstd * (R2 - mu * R1);
+        if (lane == 0) {
+            pbeta[(size_t)b * C + c] = R1;
+            pgamma[(size_t)b * C + c] = pg;
+            const float gc = gamma[c];
+            sg += gc * R1; sgx += gc * pg;
+        }
+        if (nq == 8) {
+            // per-sample slab of 4C floats: [ db[C] | dw[C][3] ]
+            if (lane == 2) pextra[(size_t)b * 4 * C + c] = acc;
+            if (lane >= 3 && lane < 6) pextra[(size_t)b * 4 * C + C + (size_t)c * 3 + (lane - 3)] = acc;
+            if (lane == 6) sal += acc;
+        }
+    }
+    // combine the 4 waves (lane 0 holds sg/sgx, lane 6 holds sal)
+    const float sal0 = __shfl(sal, 6, 64);
+    if (lane == 0) { red[wv][0] = sg; red[wv][1] = sgx; red[wv][2] = sal0; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tg = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+        const float tgx = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+        bsum[2 * b] = (float)((double)tg / count);
+        bsum[2 * b + 1] = (float)((double)tgx / count);
+        if (nq == 8 && palpha) palpha[b] = red[0][2] + red[1][2] + red[2][2] + red[3][2];
+    }
+}
+
+// dw = r0*(gamma*dvw - mg - xhat*mgx) + dwm  [* (w>0)]   in place on dvw
+__global__ __launch_bounds__(256) void head_bwd_kernel(float* __restrict__ dvw, const float* __restrict__ w,
+                                                       const float* __restrict__ dwm, const double* __restrict__ stats0,
+                                                       const float* __restrict__ gamma0, const float* __restrict__ bsum0,
+                                                       int C, int T, int ldt, double count, float eps, int relu) {
+    const int row = blockIdx.y;            // b*C + c
+    const int b = row / C, c = row % C;
+    const int t4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (t4 >= ldt) return;
+    float mu, rstd;
+    gln_mu_rstd(stats0 + 2 * b, count, eps, mu, rstd);
+    const float gc = gamma0[c], mg = bsum0[2 * b], mgx = bsum0[2 * b + 1];
+    const size_t off = (size_t)row * ldt + t4;
+    const float4 g = ld4(dvw + off), ww = ld4(w + off), dm = ld4(dwm + off);
+    const float g4[4] = {g.x, g.y, g.z, g.w}, w4[4] = {ww.x, ww.y, ww.z, ww.w}, m4[4] = {dm.x, dm.y, dm.z, dm.w};
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float xh = (w4[e] - mu) * rstd;
+        float v = rstd * (gc * g4[e] - mg - xh * mgx) + m4[e];
+        if (relu && !(w4[e] > 0.f)) v = 0.f;
+        o[e] = (t4 + e < T) ? v : 0.f;
+    }
+    st4(dvw + off, make_float4(o[0], o[1], o[2], o[3]));
+}
+
+// =====================================================================================
+// Decoder forward: mask*w, basis synthesis, overlap-add, crop.  Thread = frame; loop over basis rows n
+// with the decoder row D[n][:] wave-uniform.  LC = Cout*L; frames exchanged through LDS for the OLA.
+// Block covers FB = 256-(R-1) output frames, computing R-1 halo frames redundantly (R = L/S).
+// =====================================================================================
+template <int LC_REG>
+__global__ __launch_bounds__(256) void decoder_fwd_kernel(const float* __restrict__ w, const float* __restrict__ m,
+                                                          const float* __restrict__ D, float* __restrict__ est,
+                                                          float* __restrict__ latent, int n_src, int N, int Cout, int L,
+                                                          int S, int F, int ldt, int Tout, int pad_left) {
+    extern __shared__ __attribute__((aligned(16))) float ys[];     // [256][LC+1]
+    const int LC = Cout * L;
+    const int R = L / S;
+    const int FB = 256 - (R - 1);
+    const int bs = blockIdx.y;            // b*n_src + s
+    const int b = bs / n_src;
+    const int f0 = blockIdx.x * FB;
+    const int i = threadIdx.x;
+    const int f = f0 - (R - 1) + i;
+    const bool fvalid = f >= 0 && f < F;
+    const bool owner = i >= R - 1 && f < ldt;       // this block owns latent[f]
+    const float* wrow = w + (size_t)b * N * ldt;
+    const float* mrow = m + (size_t)bs * N * ldt;
+    float* lrow = latent ? latent + (size_t)bs * N * ldt : nullptr;
+    const int fc = fvalid ? f : 0;
+
+    if (LC_REG > 0) {
+        float acc[LC_REG > 0 ? LC_REG : 1];
+#pragma unroll
+        for (int q = 0; q < LC_REG; ++q) acc[q] = 0.f;
+        for (int n = 0; n < N; ++n) {
+            float wh = wrow[(size_t)n * ldt + fc] * mrow[(size_t)n * ldt + fc];
+            if (!fvalid) wh = 0.f;
+            if (lrow && owner) lrow[(size_t)n * ldt + f] = wh;
+            const float* Dn = D + (size_t)n * LC;
+#pragma unroll
+            for (int q = 0; q < LC_REG; ++q) acc[q] = fmaf(wh, Dn[q], acc[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < LC_REG; ++q) ys[i * (LC + 1) + q] = acc[q];
+    } else {
+        for (int q0 = 0; q0 < LC; q0 += 16) {
+            float acc[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+            for (int n = 0; n < N; ++n) {
+                float wh = wrow[(size_t)n * ldt + fc] * mrow[(size_t)n * ldt + fc];
+                if (!fvalid) wh = 0.f;
+                if (q0 == 0 && lrow && owner) lrow[(size_t)n * ldt + f] = wh;
+                const float* Dn = D + (size_t)n * LC + q0;
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    if (q0 + q < LC) acc[q] = fmaf(wh, Dn[q], acc[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (q0 + q < LC) ys[i * (LC + 1) + q0 + q] = acc[q];
+        }
+    }
+    __syncthreads();
+    // overlap-add: padded sample tp = S*fo + k0 gets frames fo - r at tap k0 + r*S
+    const int nsamp = FB * S;
+    for (int j = i; j < nsamp * Cout; j += 256) {
+        const int c = j / nsamp, o = j % nsamp;
+        const int fo = o / S, k0 = o % S;            // frame offset inside the block's owned range
+        const int tau = S * (f0 + fo) + k0 - pad_left;
+        if (tau < 0 || tau >= Tout) continue;
+        float v = 0.f;
+        for (int r = 0; r < R; ++r) v += ys[(fo + (R - 1) - r) * (LC + 1) + c * L + k0 + r * S];
+        est[((size_t)bs * Cout + c) * Tout + tau] = v;
+    }
+}
+
+// Decoder + mask backward (sigmoid mask).  Thread = frame, every source handled by the same thread so that
+// dwm = sum_s dlatent*m needs no atomics.
+template <int LC_REG, int NS_REG>
+__global__ __launch_bounds__(256) void decoder_bwd_kernel(const float* __restrict__ d_est, const float* __restrict__ w,
+                                                          const float* __restrict__ m, const float* __restrict__ D,
+                                                          float* __restrict__ dpre, float* __restrict__ dwm, int n_src,
+                                                          int N, int Cout, int L, int S, int F, int ldt, int Tout,
+                                                          int pad_left) {
+    const int LC = Cout * L;
+    const int b = blockIdx.y;
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= ldt) return;
+    const bool fvalid = f < F;
+    const float* wrow = w + (size_t)b * N * ldt;
+    float* dwrow = dwm + (size_t)b * N * ldt;
+
+    auto dsample = [&](int s, int q) -> float {
+        const int c = q / L, k = q % L;
+        const int tau = S * f + k - pad_left;
+        return (fvalid && tau >= 0 && tau < Tout) ? d_est[(((size_t)b * n_src + s) * Cout + c) * Tout + tau] : 0.f;
+    };
+
+    if (LC_REG > 0 && NS_REG > 0) {
+        float ds[(NS_REG > 0 ? NS_REG : 1)][(LC_REG > 0 ? LC_REG : 1)];
+#pragma unroll
+        for (int s = 0; s < NS_REG; ++s)
+#pragma unroll
+            for (int q = 0; q < LC_REG; ++q) ds[s][q] = (s < n_src) ? dsample(s, q) : 0.f;
+        for (int n = 0; n < N; ++n) {
+            const float wv = wrow[(size_t)n * ldt + f];
+            const float* Dn = D + (size_t)n * LC;
+            float dacc = 0.f;
+#pragma unroll
+            for (int s = 0; s < NS_REG; ++s) {
+                if (s < n_src) {
+                    const size_t off = ((size_t)(b * n_src + s) * N + n) * ldt + f;
+                    const float mv = m[off];
+                    float dl = 0.f;
+#pragma unroll
+                    for (int q = 0; q < LC_REG; ++q) dl = fmaf(ds[s][q], Dn[q], dl);
+                    dpre[off] = fvalid ? dl * wv * mv * (1.f - mv) : 0.f;
+                    dacc += dl * mv;
+                }
+            }
+            dwrow[(size_t)n * ldt + f] = fvalid ? dacc : 0.f;
+        }
+    } else {
+        for (int n = 0; n < N; ++n) {
+            const float wv = wrow[(size_t)n * ldt + f];
+            const float* Dn = D + (size_t)n * LC;
+            float dacc = 0.f;
+            for (int s = 0; s < n_src; ++s) {
+                const size_t off = ((size_t)(b * n_src + s) * N + n) * ldt + f;
+                const float mv = m[off];
+                float dl = 0.f;
+                for (int q = 0; q < LC; ++q) dl = fmaf(dsample(s, q), Dn[q], dl);
+                dpre[off] = fvalid ? dl * wv * mv * (1.f - mv) : 0.f;
+                dacc += dl * mv;
+            }
+            dwrow[(size_t)n * ldt + f] = fvalid ? dacc : 0.f;
+        }
+    }
+}
+
+// =====================================================================================
+// Stand-alone gLN (for callers outside the fused network)
+// =====================================================================================
+__global__ __launch_bounds__(256) void gln_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int C,
+                                                        int T, int ldt) {
+    __shared__ double red[4];
+    const int row = blockIdx.y;
+    const int b = row / C;
+    const int t4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    float s = 0.f, ss = 0.f;
+    if (t4 < ldt) {
+        const float4 v = ld4(x + (size_t)row * ldt + t4);
+        const float v4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (t4 + e < T) { s += v4[e]; ss += v4[e] * v4[e]; }
+    }
+    const double ds = block_sum_256<double>((double)s, red);
+    const double dss = block_sum_256<double>((double)ss, red);
+    if (threadIdx.x == 0) { atomicAdd(stats + 2 * b, ds); atomicAdd(stats + 2 * b + 1, dss); }
+}
+
+__global__ __launch_bounds__(256) void gln_apply_kernel(const float* __restrict__ x, const double* __restrict__ stats,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ y, int C, int T, int ldt, double count,
+                                                        float eps) {
+    const int row = blockIdx.y;
+    const int b = row / C, c = row % C;
+    const int t4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (t4 >= ldt) return;
+    float mu, rstd;
+    gln_mu_rstd(stats + 2 * b, count, eps, mu, rstd);
+    const float sc = gamma[c] * rstd, sh = beta[c] - mu * sc;
+    const float4 v = ld4(x + (size_t)row * ldt + t4);
+    float4 o;
+    o.x = (t4 + 0 < T) ? v.x * sc + sh : 0.f;
+    o.y = (t4 + 1 < T) ? v.y * sc + sh : 0.f;
+    o.z = (t4 + 2 < T) ? v.z * sc + sh : 0.f;
+    o.w = (t4 + 3 < T) ? v.w * sc + sh : 0.f;
+    st4(y + (size_t)row * ldt + t4, o);
+}
+
+// rowpart[b][c][tile][2] = {sum dy, sum dy*x} over a 1024-frame tile (one block per tile)
+__global__ __launch_bounds__(256) void gln_bwd_rowsums_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                              float* __restrict__ rowpart, int T, int ldt, int ntile) {
+    __shared__ float red[4];
+    const int row = blockIdx.y;
+    const int tile = blockIdx.x;
+    const int t4 = tile * 1024 + threadIdx.x * 4;
+    float s1 = 0.f, s2 = 0.f;
+    if (t4 < ldt) {
+        const float4 g = ld4(dy + (size_t)row * ldt + t4), v = ld4(x + (size_t)row * ldt + t4);
+        const float g4[4] = {g.x, g.y, g.z, g.w}, v4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (t4 + e < T) { s1 += g4[e]; s2 += g4[e] * v4[e]; }
+    }
+    const float r1 = block_sum_256<float>(s1, red);
+    const float r2 = block_sum_256<float>(s2, red);
+    if (threadIdx.x == 0) {
+        float* rp = rowpart + ((size_t)row * ntile + tile) * 2;
+        rp[0] = r1; rp[1] = r2;
+    }
+}
+
+__global__ __launch_bounds__(256) void gln_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const double* __restrict__ stats, const float* __restrict__ gamma,
+                                                            const float* __restrict__ bsum, float* __restrict__ dx, int C,
+                                                            int T, int ldt, double count, float eps) {
+    const int row = blockIdx.y;
+    const int b = row / C, c = row % C;
+    const int t4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (t4 >= ldt) return;
+    float mu, rstd;
+    gln_mu_rstd(stats + 2 * b, count, eps, mu, rstd);
+    const float gc = gamma[c], mg = bsum[2 * b], mgx = bsum[2 * b + 1];
+    const size_t off = (size_t)row * ldt + t4;
+    const float4 g = ld4(dy + off), v = ld4(x + off);
+    const float g4[4] = {g.x, g.y, g.z, g.w}, v4[4] = {v.x, v.y, v.z, v.w};
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float xh = (v4[e] - mu) * rstd;
+        o[e] = (t4 + e < T) ? rstd * (gc * g4[e] - mg - xh * mgx) : 0.f;
+    }
+    st4(dx + off, make_float4(o[0], o[1], o[2], o[3]));
+}
+
+__global__ __launch_bounds__(256) void repack_kernel(const float* __restrict__ src, int ld_src, float* __restrict__ dst,
+                                                     int ld_dst, int T) {
+    const int row = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= ld_dst) return;
+    dst[(size_t)row * ld_dst + t] = (t < T) ? src[(size_t)row * ld_src + t] : 0.f;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+extern "C" int sep_encoder_fwd(const float* x, const float* E, float* w, double* stats, int B, int Cin, int Tin, int N,
+                               int L, int S, int F, int ldt, int pad_left, int relu, sep_stream_t stream) {
+    SEP_REQUIRE(x && E && w && stats, "sep_encoder_fwd: null pointer");
+    SEP_REQUIRE(B > 0 && Cin > 0 && N > 0 && L > 0 && S > 0 && F > 0 && F <= ldt && ldt % 128 == 0, "sep_encoder_fwd: bad sizes (F=%d ldt=%d)", F, ldt);
+    const int span = ENC_FT * S + L - S;
+    const size_t smem = (size_t)Cin * span * sizeof(float);
+    SEP_REQUIRE(smem <= 150 * 1024, "sep_encoder_fwd: Cin*(128*S+L-S) floats exceed LDS (Cin=%d L=%d S=%d)", Cin, L, S);
+    dim3 grid(ldt / ENC_FT, B);
+    if (Cin * L == 16)
+        hipLaunchKernelGGL(encoder_fwd_kernel<16>, grid, dim3(256), smem, (hipStream_t)stream, x, E, w, stats, B, Cin, Tin, N, L, S, F, ldt, pad_left, relu);
+    else
+        hipLaunchKernelGGL(encoder_fwd_kernel<0>, grid, dim3(256), smem, (hipStream_t)stream, x, E, w, stats, B, Cin, Tin, N, L, S, F, ldt, pad_left, relu);
+    SEP_CHECK_LAUNCH("sep_encoder_fwd");
+    return 0;
+}
+
+extern "C" int sep_unfold(const float* x, float* frames, int Bp, int C, int Tin, int L, int S, int F, int ldt,
+                          int pad_left, sep_stream_t stream) {
+    SEP_REQUIRE(x && frames && Bp > 0 && C > 0 && L > 0 && S > 0 && F > 0 && F <= ldt, "sep_unfold: bad arguments");
+    SEP_REQUIRE(Bp <= 65535 && C * L <= 65535, "sep_unfold: grid too large");
+    dim3 grid(ceil_div(ldt, 256), C * L, Bp);
+    hipLaunchKernelGGL(unfold_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, frames, C, Tin, L, S, F, ldt, pad_left);
+    SEP_CHECK_LAUNCH("sep_unfold");
+    return 0;
+}
+
+extern "C" int sep_dwconv_fwd(const float* a, const double* stats1, const float* gamma1, const float* beta1,
+                              const float* alpha1, const float* wd, const float* bd, const float* alpha2, float* z,
+                              double* stats2, int B, int C, int T, int ldt, int dilation, float eps, sep_stream_t stream) {
+    SEP_REQUIRE(a && stats1 && gamma1 && beta1 && alpha1 && wd && bd && alpha2 && z && stats2, "sep_dwconv_fwd: null pointer");
+    SEP_REQUIRE(B > 0 && C > 0 && T > 0 && ldt % 128 == 0 && ldt >= T, "sep_dwconv_fwd: bad sizes");
+    SEP_REQUIRE(dilation >= 1 && dilation <= 4096, "sep_dwconv_fwd: dilation %d out of range [1, 4096]", dilation);
+    const int dpad = (dilation + 3) & ~3;
+    const size_t smem = 4 * (size_t)(DW_TT + 2 * dpad) * sizeof(float);
+    const long total = (long)B * C * ceil_div(ldt, DW_TT);
+    hipLaunchKernelGGL(dwconv_fwd_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), smem, (hipStream_t)stream, a, stats1, gamma1, beta1, alpha1, wd, bd, alpha2, z, stats2, B, C, T, ldt, dilation, dpad, eps);
+    SEP_CHECK_LAUNCH("sep_dwconv_fwd");
+    return 0;
+}
+
+extern "C" int sep_dwconv_bwd(const float* dv2, const float* z, const float* a, const double* stats1, const float* gamma1,
+                              const float* beta1, const float* alpha1, const double* stats2, const float* gamma2,
+                              const float* alpha2, const float* bsum2, const float* wd, float* dv1, float* rowpart,
+                              int B, int C, int T, int ldt, int dilation, float eps, sep_stream_t stream) {
+    SEP_REQUIRE(dv2 && z && a && stats1 && gamma1 && beta1 && alpha1 && stats2 && gamma2 && alpha2 && bsum2 && wd && dv1 && rowpart, "sep_dwconv_bwd: null pointer");
+    SEP_REQUIRE(B > 0 && C > 0 && T > 0 && ldt % 128 == 0 && ldt >= T, "sep_dwconv_bwd: bad sizes");
+    SEP_REQUIRE(dilation >= 1 && dilation <= 2048, "sep_dwconv_bwd: dilation %d out of range [1, 2048]", dilation);
+    const int dpad = (dilation + 3) & ~3;
+    const size_t smem = 4 * 2 * (size_t)(DW_TT + 2 * dpad) * sizeof(float);
+    const long total = (long)B * C * ceil_div(ldt, DW_TT);
+    hipLaunchKernelGGL(dwconv_bwd_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), smem, (hipStream_t)stream, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bsum2, wd, dv1, rowpart, B, C, T, ldt, dilation, dpad, eps);
+    SEP_CHECK_LAUNCH("sep_dwconv_bwd");
+    return 0;
+}
+
+extern "C" int sep_gln_bwd_finalize(const float* rowpart, int ntile, int nq, const double* stats, const float* gamma,
+                                    double count, float eps, float* bsum, float* pbeta, float* pgamma, float* pextra,
+                                    int B, int C, sep_stream_t stream) {
+    SEP_REQUIRE(rowpart && stats && gamma && bsum && pbeta && pgamma, "sep_gln_bwd_finalize: null pointer");
+    SEP_REQUIRE(nq == 2 || nq == 8, "sep_gln_bwd_finalize: nq must be 2 or 8 (got %d)", nq);
+    SEP_REQUIRE(nq == 2 || pextra, "sep_gln_bwd_finalize: nq == 8 needs pextra");
+    // pextra layout for nq == 8: B slabs of 4C floats [db[C] | dw[C][3]] followed by palpha[B]
+    float* palpha = (nq == 8) ? pextra + (size_t)B * C * 4 : nullptr;
+    hipLaunchKernelGGL(gln_bwd_finalize_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, rowpart, ntile, nq, stats, gamma, count, eps, bsum, pbeta, pgamma, pextra, palpha, C);
+    SEP_CHECK_LAUNCH("sep_gln_bwd_finalize");
+    return 0;
+}
+
+extern "C" int sep_head_bwd(float* dvw, const float* w, const float* dwm, const double* stats0, const float* gamma0,
+                            const float* bsum0, int B, int C, int T, int ldt, double count, float eps, int relu,
+                            sep_stream_t stream) {
+    SEP_REQUIRE(dvw && w && dwm && stats0 && gamma0 && bsum0 && ldt % 4 == 0, "sep_head_bwd: bad arguments");
+    SEP_REQUIRE((long)B * C <= 65535, "sep_head_bwd: B*C too large for grid.y");
+    dim3 grid(ceil_div(ldt, 1024), B * C);
+    hipLaunchKernelGGL(head_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dvw, w, dwm, stats0, gamma0, bsum0, C, T, ldt, count, eps, relu);
+    SEP_CHECK_LAUNCH("sep_head_bwd");
+    return 0;
+}
+
+extern "C" int sep_decoder_fwd(const float* w, const float* m, const float* D, float* est, float* latent, int B, int n_src,
+                               int N, int Cout, int L, int S, int F, int ldt, int Tout, int pad_left, sep_stream_t stream) {
+    SEP_REQUIRE(w && m && D && est, "sep_decoder_fwd: null pointer");
+    SEP_REQUIRE(L % S == 0 && L / S <= 64, "sep_decoder_fwd: kernel_size %d must be a multiple of stride %d", L, S);
+    const int LC = Cout * L;
+    SEP_REQUIRE(LC <= 144, "sep_decoder_fwd: Cout*L=%d too large for the LDS frame buffer", LC);
+    SEP_REQUIRE((long)B * n_src <= 65535, "sep_decoder_fwd: B*n_src too large");
+    const int R = L / S, FB = 256 - (R - 1);
+    dim3 grid(ceil_div(ldt + R - 1, FB), B * n_src);
+    const size_t smem = (size_t)256 * (LC + 1) * sizeof(float);
+    if (LC == 16)
+        hipLaunchKernelGGL(decoder_fwd_kernel<16>, grid, dim3(256), smem, (hipStream_t)stream, w, m, D, est, latent, n_src, N, Cout, L, S, F, ldt, Tout, pad_left);
+    else
+        hipLaunchKernelGGL(decoder_fwd_kernel<0>, grid, dim3(256), smem, (hipStream_t)stream, w, m, D, est, latent, n_src, N, Cout, L, S, F, ldt, Tout, pad_left);
+    SEP_CHECK_LAUNCH("sep_decoder_fwd");
+    return 0;
+}
+
+extern "C" int sep_decoder_bwd(const float* d_est, const float* w, const float* m, const float* D, float* dpre, float* dwm,
+                               int B, int n_src, int N, int Cout, int L, int S, int F, int ldt, int Tout, int pad_left,
+                               sep_stream_t stream) {
+    SEP_REQUIRE(d_est && w && m && D && dpre && dwm, "sep_decoder_bwd: null pointer");
+    SEP_REQUIRE(B <= 65535, "sep_decoder_bwd: B too large");
+    dim3 grid(ceil_div(ldt, 256), B);
+    const int LC = Cout * L;
+    if (LC == 16 && n_src <= 2)
+        hipLaunchKernelGGL((decoder_bwd_kernel<16, 2>), grid, dim3(256), 0, (hipStream_t)stream, d_est, w, m, D, dpre, dwm, n_src, N, Cout, L, S, F, ldt, Tout, pad_left);
+    else if (LC == 16 && n_src <= 4)
+        hipLaunchKernelGGL((decoder_bwd_kernel<16, 4>), grid, dim3(256), 0, (hipStream_t)stream, d_est, w, m, D, dpre, dwm, n_src, N, Cout, L, S, F, ldt, Tout, pad_left);
+    else
+        hipLaunchKernelGGL((decoder_bwd_kernel<0, 0>), grid, dim3(256), 0, (hipStream_t)stream, d_est, w, m, D, dpre, dwm, n_src, N, Cout, L, S, F, ldt, Tout, pad_left);
+    SEP_CHECK_LAUNCH("sep_decoder_bwd");
+    return 0;
+}
+
+extern "C" int sep_gln_stats(const float* x, double* stats, int B, int C, int T, int ldt, sep_stream_t stream) {
+    SEP_REQUIRE(x && stats && ldt % 4 == 0 && (long)B * C <= 65535, "sep_gln_stats: bad arguments");
+    dim3 grid(ceil_div(ldt, 1024), B * C);
+    hipLaunchKernelGGL(gln_stats_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, stats, C, T, ldt);
+    SEP_CHECK_LAUNCH("sep_gln_stats");
+    return 0;
+}
+
+extern "C" int sep_gln_apply(const float* x, const double* stats, const float* gamma, const float* beta, float* y, int B,
+                             int C, int T, int ldt, double count, float eps, sep_stream_t stream) {
+    SEP_REQUIRE(x && stats && gamma && beta && y && ldt % 4 == 0 && (long)B * C <= 65535, "sep_gln_apply: bad arguments");
+    dim3 grid(ceil_div(ldt, 1024), B * C);
+    hipLaunchKernelGGL(gln_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, stats, gamma, beta, y, C, T, ldt, count, eps);
+    SEP_CHECK_LAUNCH("sep_gln_apply");
+    return 0;
+}
+
+extern "C" int sep_gln_bwd_rowsums(const float* dy, const float* x, float* rowpart, int B, int C, int T, int ldt,
+                                   sep_stream_t stream) {
+    SEP_REQUIRE(dy && x && rowpart && ldt % 4 == 0 && (long)B * C <= 65535, "sep_gln_bwd_rowsums: bad arguments");
+    const int ntile = ceil_div(ldt, 1024);
+    dim3 grid(ntile, B * C);
+    hipLaunchKernelGGL(gln_bwd_rowsums_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, x, rowpart, T, ldt, ntile);
+    SEP_CHECK_LAUNCH("sep_gln_bwd_rowsums");
+    return 0;
+}
+
+extern "C" int sep_gln_bwd_apply(const float* dy, const float* x, const double* stats, const float* gamma, const float* bsum,
+                                 float* dx, int B, int C, int T, int ldt, double count, float eps, sep_stream_t stream) {
+    SEP_REQUIRE(dy && x && stats && gamma && bsum && dx && ldt % 4 == 0 && (long)B * C <= 65535, "sep_gln_bwd_apply: bad arguments");
+    dim3 grid(ceil_div(ldt, 1024), B * C);
+    hipLaunchKernelGGL(gln_bwd_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma, bsum, dx, C, T, ldt, count, eps);
+    SEP_CHECK_LAUNCH("sep_gln_bwd_apply");
+    return 0;
+}
+
+extern "C" int sep_repack(const float* src, int ld_src, float* dst, int ld_dst, int rows, int T, sep_stream_t stream) {
+    SEP_REQUIRE(src && dst && rows > 0 && T > 0 && ld_src >= T && ld_dst >= T, "sep_repack: bad arguments");
+    SEP_REQUIRE(rows <= 65535 * 64, "sep_repack: too many rows");
+    // grid.y limited to 65535: fold rows
+    int done = 0;
+    while (done < rows) {
+        const int chunk = (rows - done) > 65535 ? 65535 : (rows - done);
+        dim3 grid(ceil_div(ld_dst, 256), chunk);
+        hipLaunchKernelGGL(repack_kernel, grid, dim3(256), 0, (hipStream_t)stream, src + (size_t)done * ld_src, ld_src, dst + (size_t)done * ld_dst, ld_dst, T);
+        done += chunk;
+    }
+    SEP_CHECK_LAUNCH("sep_repack");
+    return 0;
+}

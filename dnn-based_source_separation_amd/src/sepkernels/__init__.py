@@ -1,0 +1,271 @@
+"""
+sepkernels -- ctypes binding of libsepkernels.so (include/sepkernels.h), the MI355X/gfx950 kernels of the
+Conv-TasNet separation path.
+
+This package is plumbing only: it marshals torch tensors (device memory + the current HIP stream) into the
+plain-pointer C ABI.  There is NO CPU implementation behind it: every entry point raises if the shared
+library is missing or if it is handed a non-GPU tensor.
+"""
+import ctypes
+import os
+
+import torch  # imported first on purpose: libsepkernels must bind to the HIP runtime torch already loaded
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("SEPKERNELS_LIB", os.path.normpath(os.path.join(_HERE, "..", "..", "libsepkernels.so")))
+
+# ---- constants mirrored from include/sepkernels.h -------------------------------------------------
+PRO_NONE, PRO_PRELU, PRO_GLN, PRO_GLN_PRELU, PRO_GLN_BWD = 0, 1, 2, 3, 4
+EPI_STATS_PRELU, EPI_RESIDUAL, EPI_SIGMOID, EPI_PRELU_BWD, EPI_ROWSUMS, EPI_ROWSUMS_PRELU = 1, 2, 4, 8, 16, 32
+ABI_VERSION = 1
+
+_vp = ctypes.c_void_p
+_i32 = ctypes.c_int32
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = [(n, _i32) for n in ("B", "M", "K", "T", "ldt", "trans_a", "k_split", "m_split", "pro_mode", "epi_flags",
+                                    "accumulate")] + [("eps", ctypes.c_float), ("count", ctypes.c_double)] + \
+               [(n, _vp) for n in ("A", "A2", "X", "X2", "Y", "Y2", "bias", "pro_alpha", "pro_stats", "pro_gamma", "pro_beta",
+                                   "pro_aux", "pro_bsum", "pro_store", "pro_dalpha", "epi_alpha", "epi_stats", "epi_res",
+                                   "epi_aux", "epi_dalpha", "epi_rowpart")]
+
+
+class WgradDesc(ctypes.Structure):
+    _fields_ = [(n, _i32) for n in ("B", "M", "N", "T", "ldt", "g_split", "g_mul", "g_div", "x_mode", "x_div", "nsplit")] + \
+               [("eps", ctypes.c_float), ("count", ctypes.c_double)] + \
+               [(n, _vp) for n in ("G", "G2", "Gaux", "X", "x_alpha", "x_stats", "x_gamma", "x_beta", "partial", "partial_bias")]
+
+
+class ReduceSeg(ctypes.Structure):
+    _fields_ = [("src", _vp), ("dst", _vp), ("n", _i32), ("nslab", _i32), ("stride", ctypes.c_int64),
+                ("accumulate", _i32), ("scale", ctypes.c_float)]
+
+
+# name -> argtypes (restype is always int unless noted); also the list the symbol-export test checks
+_I, _F, _D, _L = ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_int64
+SIGNATURES = {
+    "sep_version": [],
+    "sep_last_error": [],
+    "sep_pw_gemm": [ctypes.POINTER(GemmDesc), _vp],
+    "sep_pw_wgrad": [ctypes.POINTER(WgradDesc), _vp],
+    "sep_reduce_slabs": [ctypes.POINTER(ReduceSeg), _I, _vp],
+    "sep_f64_to_f32": [_vp, _vp, _I, _I, _vp],
+    "sep_encoder_fwd": [_vp, _vp, _vp, _vp] + [_I] * 10 + [_vp],
+    "sep_unfold": [_vp, _vp] + [_I] * 8 + [_vp],
+    "sep_dwconv_fwd": [_vp] * 10 + [_I] * 5 + [_F, _vp],
+    "sep_dwconv_bwd": [_vp] * 14 + [_I] * 5 + [_F, _vp],
+    "sep_gln_bwd_finalize": [_vp, _I, _I, _vp, _vp, _D, _F, _vp, _vp, _vp, _vp, _I, _I, _vp],
+    "sep_head_bwd": [_vp] * 6 + [_I] * 4 + [_D, _F, _I, _vp],
+    "sep_decoder_fwd": [_vp] * 5 + [_I] * 10 + [_vp],
+    "sep_decoder_bwd": [_vp] * 6 + [_I] * 10 + [_vp],
+    "sep_gln_stats": [_vp, _vp, _I, _I, _I, _I, _vp],
+    "sep_gln_apply": [_vp] * 5 + [_I] * 4 + [_D, _F, _vp],
+    "sep_gln_bwd_rowsums": [_vp, _vp, _vp, _I, _I, _I, _I, _vp],
+    "sep_gln_bwd_apply": [_vp] * 6 + [_I] * 4 + [_D, _F, _vp],
+    "sep_repack": [_vp, _I, _vp, _I, _I, _I, _vp],
+    "sep_sisdr_dots": [_vp] * 5 + [_I] * 4 + [_vp],
+    "sep_sisdr_from_dots": [_vp] * 4 + [_I] * 3 + [_F, _vp],
+    "sep_sisdr_bwd": [_vp] * 7 + [_I] * 4 + [_F, _vp],
+    "sep_pit_search": [_vp, _vp, _I, _I, _I, _I, _I, _vp, _vp, _vp],
+    "sep_sinkhorn_fwd": [_vp] * 4 + [_I, _I, _F, _I, _vp],
+    "sep_sinkhorn_bwd": [_vp] * 4 + [_I, _I, _F, _I, _vp],
+    "sep_sqnorm": [_vp, _vp, _L, _vp],
+    "sep_adam_step": [_vp] * 5 + [_L] + [_F] * 7 + [_I, _vp],
+}
+
+_lib = None
+
+
+class SepKernelsError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libsepkernels.so (once).  Fails loudly -- there is no fallback implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SepKernelsError(
+            "libsepkernels.so not found at {} -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). The HIP extension is mandatory; there is no CPU/PyTorch fallback.".format(LIB_PATH))
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_char_p if name == "sep_last_error" else ctypes.c_int
+    if lib.sep_version() != ABI_VERSION:
+        raise SepKernelsError("libsepkernels ABI {} != binding ABI {}".format(lib.sep_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def _ptr(t, dtype=None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise SepKernelsError("sepkernels is HIP-only: got a {} tensor (no CPU fallback exists)".format(t.device))
+    if dtype is not None and t.dtype != dtype:
+        raise SepKernelsError("expected dtype {}, got {}".format(dtype, t.dtype))
+    if not t.is_contiguous():
+        raise SepKernelsError("non-contiguous tensor passed to a kernel")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check(rc, name):
+    if rc != 0:
+        raise SepKernelsError("{} failed ({}): {}".format(name, rc, load().sep_last_error().decode()))
+
+
+_f32, _f64 = torch.float32, torch.float64
+
+
+class HipBackend:
+    """Tensor-level facade over the C ABI.  tests/emulator.py implements the same interface with CPU torch
+    arithmetic so that the host-side orchestration can be exercised without a GPU (test infrastructure only)."""
+
+    name = "hip"
+
+    def pw_gemm(self, *, B, M, K, T, ldt, A, X, Y, trans_a=0, A2=None, X2=None, k_split=0, Y2=None, m_split=0,
+                pro_mode=PRO_NONE, epi_flags=0, accumulate=0, eps=1e-12, count=0.0, bias=None, pro_alpha=None,
+                pro_stats=None, pro_gamma=None, pro_beta=None, pro_aux=None, pro_bsum=None, pro_store=None,
+                pro_dalpha=None, epi_alpha=None, epi_stats=None, epi_res=None, epi_aux=None, epi_dalpha=None,
+                epi_rowpart=None):
+        d = GemmDesc(B=B, M=M, K=K, T=T, ldt=ldt, trans_a=trans_a, k_split=k_split, m_split=m_split, pro_mode=pro_mode,
+                     epi_flags=epi_flags, accumulate=accumulate, eps=eps, count=float(count),
+                     A=_ptr(A, _f32), A2=_ptr(A2, _f32), X=_ptr(X, _f32), X2=_ptr(X2, _f32), Y=_ptr(Y, _f32), Y2=_ptr(Y2, _f32),
+                     bias=_ptr(bias, _f32), pro_alpha=_ptr(pro_alpha, _f32), pro_stats=_ptr(pro_stats, _f64),
+                     pro_gamma=_ptr(pro_gamma, _f32), pro_beta=_ptr(pro_beta, _f32), pro_aux=_ptr(pro_aux, _f32),
+                     pro_bsum=_ptr(pro_bsum, _f32), pro_store=_ptr(pro_store, _f32), pro_dalpha=_ptr(pro_dalpha, _f64),
+                     epi_alpha=_ptr(epi_alpha, _f32), epi_stats=_ptr(epi_stats, _f64), epi_res=_ptr(epi_res, _f32),
+                     epi_aux=_ptr(epi_aux, _f32), epi_dalpha=_ptr(epi_dalpha, _f64), epi_rowpart=_ptr(epi_rowpart, _f32))
+        _check(load().sep_pw_gemm(ctypes.byref(d), _stream()), "sep_pw_gemm")
+
+    def pw_wgrad(self, *, B, M, N, T, ldt, G, X, partial, nsplit, G2=None, g_split=0, Gaux=None, g_mul=0, g_div=1,
+                 x_mode=PRO_NONE, x_div=1, eps=1e-12, count=0.0, x_alpha=None, x_stats=None, x_gamma=None, x_beta=None,
+                 partial_bias=None):
+        d = WgradDesc(B=B, M=M, N=N, T=T, ldt=ldt, g_split=g_split, g_mul=g_mul, g_div=g_div, x_mode=x_mode, x_div=x_div,
+                      nsplit=nsplit, eps=eps, count=float(count), G=_ptr(G, _f32), G2=_ptr(G2, _f32), Gaux=_ptr(Gaux, _f32),
+                      X=_ptr(X, _f32), x_alpha=_ptr(x_alpha, _f32), x_stats=_ptr(x_stats, _f64), x_gamma=_ptr(x_gamma, _f32),
+                      x_beta=_ptr(x_beta, _f32), partial=_ptr(partial, _f32), partial_bias=_ptr(partial_bias, _f32))
+        _check(load().sep_pw_wgrad(ctypes.byref(d), _stream()), "sep_pw_wgrad")
+
+    def reduce_slabs(self, segs):
+        """segs: list of (src, src_offset_elems, dst, n, nslab, stride, accumulate, scale)"""
+        lib = load()
+        for i in range(0, len(segs), 8):
+            chunk = segs[i:i + 8]
+            arr = (ReduceSeg * len(chunk))()
+            for k, (src, off, dst, n, nslab, stride, acc, scale) in enumerate(chunk):
+                arr[k] = ReduceSeg(src=_ptr(src, _f32) + 4 * off, dst=_ptr(dst, _f32), n=n, nslab=nslab, stride=stride,
+                                   accumulate=acc, scale=scale)
+            _check(lib.sep_reduce_slabs(arr, len(chunk), _stream()), "sep_reduce_slabs")
+
+    def f64_to_f32(self, src, dst, n, accumulate=0):
+        _check(load().sep_f64_to_f32(_ptr(src, _f64), _ptr(dst, _f32), n, accumulate, _stream()), "sep_f64_to_f32")
+
+    def encoder_fwd(self, x, E, w, stats, B, Cin, Tin, N, L, S, F, ldt, pad_left, relu):
+        _check(load().sep_encoder_fwd(_ptr(x, _f32), _ptr(E, _f32), _ptr(w, _f32), _ptr(stats, _f64), B, Cin, Tin, N, L, S, F,
+                                      ldt, pad_left, int(relu), _stream()), "sep_encoder_fwd")
+
+    def unfold(self, x, frames, Bp, C, Tin, L, S, F, ldt, pad_left):
+        _check(load().sep_unfold(_ptr(x, _f32), _ptr(frames, _f32), Bp, C, Tin, L, S, F, ldt, pad_left, _stream()), "sep_unfold")
+
+    def dwconv_fwd(self, a, stats1, gamma1, beta1, alpha1, wd, bd, alpha2, z, stats2, B, C, T, ldt, dilation, eps):
+        _check(load().sep_dwconv_fwd(_ptr(a, _f32), _ptr(stats1, _f64), _ptr(gamma1, _f32), _ptr(beta1, _f32), _ptr(alpha1, _f32),
+                                     _ptr(wd, _f32), _ptr(bd, _f32), _ptr(alpha2, _f32), _ptr(z, _f32), _ptr(stats2, _f64),
+                                     B, C, T, ldt, dilation, eps, _stream()), "sep_dwconv_fwd")
+
+    def dwconv_bwd(self, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bsum2, wd, dv1, rowpart, B, C, T,
+                   ldt, dilation, eps):
+        _check(load().sep_dwconv_bwd(_ptr(dv2, _f32), _ptr(z, _f32), _ptr(a, _f32), _ptr(stats1, _f64), _ptr(gamma1, _f32),
+                                     _ptr(beta1, _f32), _ptr(alpha1, _f32), _ptr(stats2, _f64), _ptr(gamma2, _f32),
+                                     _ptr(alpha2, _f32), _ptr(bsum2, _f32), _ptr(wd, _f32), _ptr(dv1, _f32), _ptr(rowpart, _f32),
+                                     B, C, T, ldt, dilation, eps, _stream()), "sep_dwconv_bwd")
+
+    def gln_bwd_finalize(self, rowpart, ntile, nq, stats, gamma, count, eps, bsum, pbeta, pgamma, pextra, B, C):
+        _check(load().sep_gln_bwd_finalize(_ptr(rowpart, _f32), ntile, nq, _ptr(stats, _f64), _ptr(gamma, _f32), float(count), eps,
+                                           _ptr(bsum, _f32), _ptr(pbeta, _f32), _ptr(pgamma, _f32), _ptr(pextra, _f32), B, C,
+                                           _stream()), "sep_gln_bwd_finalize")
+
+    def head_bwd(self, dvw, w, dwm, stats0, gamma0, bsum0, B, C, T, ldt, count, eps, relu):
+        _check(load().sep_head_bwd(_ptr(dvw, _f32), _ptr(w, _f32), _ptr(dwm, _f32), _ptr(stats0, _f64), _ptr(gamma0, _f32),
+                                   _ptr(bsum0, _f32), B, C, T, ldt, float(count), eps, int(relu), _stream()), "sep_head_bwd")
+
+    def decoder_fwd(self, w, m, D, est, latent, B, n_src, N, Cout, L, S, F, ldt, Tout, pad_left):
+        _check(load().sep_decoder_fwd(_ptr(w, _f32), _ptr(m, _f32), _ptr(D, _f32), _ptr(est, _f32), _ptr(latent, _f32), B, n_src,
+                                      N, Cout, L, S, F, ldt, Tout, pad_left, _stream()), "sep_decoder_fwd")
+
+    def decoder_bwd(self, d_est, w, m, D, dpre, dwm, B, n_src, N, Cout, L, S, F, ldt, Tout, pad_left):
+        _check(load().sep_decoder_bwd(_ptr(d_est, _f32), _ptr(w, _f32), _ptr(m, _f32), _ptr(D, _f32), _ptr(dpre, _f32),
+                                      _ptr(dwm, _f32), B, n_src, N, Cout, L, S, F, ldt, Tout, pad_left, _stream()), "sep_decoder_bwd")
+
+    def gln_stats(self, x, stats, B, C, T, ldt):
+        _check(load().sep_gln_stats(_ptr(x, _f32), _ptr(stats, _f64), B, C, T, ldt, _stream()), "sep_gln_stats")
+
+    def gln_apply(self, x, stats, gamma, beta, y, B, C, T, ldt, count, eps):
+        _check(load().sep_gln_apply(_ptr(x, _f32), _ptr(stats, _f64), _ptr(gamma, _f32), _ptr(beta, _f32), _ptr(y, _f32), B, C, T,
+                                    ldt, float(count), eps, _stream()), "sep_gln_apply")
+
+    def gln_bwd_rowsums(self, dy, x, rowpart, B, C, T, ldt):
+        _check(load().sep_gln_bwd_rowsums(_ptr(dy, _f32), _ptr(x, _f32), _ptr(rowpart, _f32), B, C, T, ldt, _stream()),
+               "sep_gln_bwd_rowsums")
+
+    def gln_bwd_apply(self, dy, x, stats, gamma, bsum, dx, B, C, T, ldt, count, eps):
+        _check(load().sep_gln_bwd_apply(_ptr(dy, _f32), _ptr(x, _f32), _ptr(stats, _f64), _ptr(gamma, _f32), _ptr(bsum, _f32),
+                                        _ptr(dx, _f32), B, C, T, ldt, float(count), eps, _stream()), "sep_gln_bwd_apply")
+
+    def repack(self, src, ld_src, dst, ld_dst, rows, T):
+        _check(load().sep_repack(_ptr(src, _f32), ld_src, _ptr(dst, _f32), ld_dst, rows, T, _stream()), "sep_repack")
+
+    def sisdr_dots(self, est, tgt, dots, tt, xx, B, n, T, all_pairs):
+        _check(load().sep_sisdr_dots(_ptr(est, _f32), _ptr(tgt, _f32), _ptr(dots, _f64), _ptr(tt, _f64), _ptr(xx, _f64), B, n, T,
+                                     int(all_pairs), _stream()), "sep_sisdr_dots")
+
+    def sisdr_from_dots(self, dots, tt, xx, out, B, n, all_pairs, eps):
+        _check(load().sep_sisdr_from_dots(_ptr(dots, _f64), _ptr(tt, _f64), _ptr(xx, _f64), _ptr(out, _f32), B, n, int(all_pairs),
+                                          eps, _stream()), "sep_sisdr_from_dots")
+
+    def sisdr_bwd(self, est, tgt, dots, tt, xx, gw, d_est, B, n, T, all_pairs, eps):
+        _check(load().sep_sisdr_bwd(_ptr(est, _f32), _ptr(tgt, _f32), _ptr(dots, _f64), _ptr(tt, _f64), _ptr(xx, _f64),
+                                    _ptr(gw, _f32), _ptr(d_est, _f32), B, n, T, int(all_pairs), eps, _stream()), "sep_sisdr_bwd")
+
+    def pit_search(self, val, perms, P, n, B, maximize, use_mean, best_val, best_idx):
+        _check(load().sep_pit_search(_ptr(val, _f32), _ptr(perms, torch.int32), P, n, B, int(maximize), int(use_mean),
+                                     _ptr(best_val, _f32), _ptr(best_idx, torch.int64), _stream()), "sep_pit_search")
+
+    def sinkhorn_fwd(self, C, zwork, loss, P, B, n, coldness, iters):
+        _check(load().sep_sinkhorn_fwd(_ptr(C, _f32), _ptr(zwork, _f64), _ptr(loss, _f32), _ptr(P, _f32), B, n, coldness, iters,
+                                       _stream()), "sep_sinkhorn_fwd")
+
+    def sinkhorn_bwd(self, C, zwork, dloss, dC, B, n, coldness, iters):
+        _check(load().sep_sinkhorn_bwd(_ptr(C, _f32), _ptr(zwork, _f64), _ptr(dloss, _f32), _ptr(dC, _f32), B, n, coldness, iters,
+                                       _stream()), "sep_sinkhorn_bwd")
+
+    def sqnorm(self, g, out, n):
+        _check(load().sep_sqnorm(_ptr(g, _f32), _ptr(out, _f64), n, _stream()), "sep_sqnorm")
+
+    def adam_step(self, p, g, m, v, sqnorm, n, lr, beta1, beta2, eps, weight_decay, max_norm, grad_scale, step):
+        _check(load().sep_adam_step(_ptr(p, _f32), _ptr(g, _f32), _ptr(m, _f32), _ptr(v, _f32), _ptr(sqnorm, _f64), n, lr, beta1,
+                                    beta2, eps, weight_decay, max_norm, grad_scale, step, _stream()), "sep_adam_step")
+
+
+_backend = HipBackend()
+
+
+def backend():
+    return _backend
+
+
+def _set_backend_for_tests(b):
+    """Test hook (tests/emulator.py): swap the kernel facade for the CPU emulator so the host-side orchestration
+    can be checked without a GPU.  Never called by product code."""
+    global _backend
+    old = _backend
+    _backend = b
+    return old

@@ -1,0 +1,315 @@
+"""
+Host-side orchestration of the fused Conv-TasNet forward/backward on the sepkernels C ABI.
+
+The phase structure is dictated by gLN: its statistic spans a whole sample (C x T'), so every gLN is a
+grid-wide dependency.  Per TCN layer (reference src/models/tdcn.py:107-147,177-196) the forward is three
+kernels, none of which writes a normalised tensor to HBM:
+
+   F2  a  = W1 x + b1                      (MFMA GEMM; epilogue accumulates stats of PReLU(a))
+   DW  z  = dw(gLN(PReLU(a))) + bd         (LDS-staged dilated depthwise; accumulates stats of PReLU(z))
+   F3  out = Wo v2 + bo + x ; S += Ws v2   (one MFMA GEMM over [Wo;Ws], v2 = gLN(PReLU(z)) applied on load)
+
+and the backward mirrors it (dgrad GEMM -> row-sum finalize -> depthwise^T -> finalize -> dgrad GEMM, plus two
+split-K weight-gradient GEMMs).  Only the pre-activations a, z and the layer input x are kept for backward.
+
+Everything here is plumbing: buffer allocation through torch, descriptor filling, launch order.
+"""
+import math
+
+import torch
+
+from . import (EPI_PRELU_BWD, EPI_RESIDUAL, EPI_ROWSUMS, EPI_ROWSUMS_PRELU, EPI_SIGMOID, EPI_STATS_PRELU, PRO_GLN,
+               PRO_GLN_BWD, PRO_GLN_PRELU, PRO_NONE, PRO_PRELU, backend)
+
+
+def round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+class Geometry:
+    """Frame geometry of conv_tasnet.py:145-149 (input padding) + the padded row stride of the workspaces."""
+
+    def __init__(self, T_in, L, S):
+        self.T_in = T_in
+        self.padding = (S - (T_in - L) % S) % S
+        self.pad_left = self.padding // 2
+        self.pad_right = self.padding - self.pad_left
+        self.F = (T_in + self.padding - L) // S + 1
+        self.ldt = round_up(self.F, 128)
+
+
+def layer_names(cfg):
+    out = []
+    R, X = cfg["sep_num_blocks"], cfg["sep_num_layers"]
+    for r in range(R):
+        for x in range(X):
+            out.append(("separator.tdcn.net.{}.net.{}.".format(r, x), 2 ** x, not (r == R - 1 and x == X - 1)))
+    return out
+
+
+def check_supported(cfg):
+    """The fused HIP path covers the north-star configuration family; anything else fails loudly
+    (there is deliberately no silent PyTorch fallback)."""
+    problems = []
+    if cfg.get("enc_basis") != "trainable" or cfg.get("dec_basis") != "trainable":
+        problems.append("enc_basis/dec_basis must be 'trainable'")
+    if cfg.get("enc_nonlinear") not in (None, "", "relu"):
+        problems.append("enc_nonlinear must be None or 'relu'")
+    if cfg.get("causal"):
+        problems.append("causal=True (cLN) is not implemented")
+    if not cfg.get("separable", True) or not cfg.get("dilated", True):
+        problems.append("separable=True and dilated=True are required")
+    if cfg.get("sep_nonlinear") != "prelu" or not cfg.get("sep_norm", True):
+        problems.append("sep_nonlinear='prelu' and sep_norm=True are required")
+    if cfg.get("mask_nonlinear") != "sigmoid":
+        problems.append("mask_nonlinear must be 'sigmoid'")
+    if cfg.get("sep_kernel_size") != 3:
+        problems.append("sep_kernel_size must be 3")
+    for k in ("n_basis", "sep_hidden_channels", "sep_bottleneck_channels", "sep_skip_channels"):
+        if cfg[k] % 16:
+            problems.append("{} must be a multiple of 16".format(k))
+    if (cfg["n_sources"] * cfg["n_basis"]) % 16:
+        problems.append("n_sources*n_basis must be a multiple of 16")
+    if cfg["kernel_size"] % cfg["stride"]:
+        problems.append("kernel_size must be divisible by stride")
+    if problems:
+        raise NotImplementedError("sepkernels fused Conv-TasNet path: " + "; ".join(problems))
+
+
+def _adjacent(t1, t2):
+    return t1.data_ptr() + t1.numel() * t1.element_size() == t2.data_ptr()
+
+
+def _nsplit(M, N, chunks_total, target_blocks=512):
+    ntiles = ((M + 127) // 128) * ((N + 127) // 128)
+    return max(1, min(chunks_total, max(1, target_blocks // ntiles)))
+
+
+class Saved:
+    """Activations kept between forward and backward (plain attribute bag)."""
+    pass
+
+
+def forward(cfg, P, mixture, want_latent=False, save=True):
+    """cfg: model config dict; P: dict name -> parameter tensor; mixture (B, Cin, T) fp32 contiguous.
+    Returns (est (B, n_src, Cin, T), latent or None, Saved or None)."""
+    K = backend()
+    dev = mixture.device
+    B, Cin, T_in = mixture.shape
+    N, L, S = cfg["n_basis"], cfg["kernel_size"], cfg["stride"]
+    Bn, H, Sc = cfg["sep_bottleneck_channels"], cfg["sep_hidden_channels"], cfg["sep_skip_channels"]
+    n_src = cfg["n_sources"]
+    eps = float(cfg.get("eps", 1e-12))
+    relu = cfg.get("enc_nonlinear") == "relu"
+    geo = Geometry(T_in, L, S)
+    F, ldt = geo.F, geo.ldt
+    layers = layer_names(cfg)
+    nl = len(layers)
+    f32 = dict(device=dev, dtype=mixture.dtype)   # always fp32 in the product; the CPU emulator tests also run fp64
+
+    stats = torch.zeros(2 * nl + 1, B, 2, device=dev, dtype=torch.float64)
+    w = torch.empty(B, N, ldt, **f32)
+    K.encoder_fwd(mixture, P["encoder.conv1d.weight"], w, stats[0], B, Cin, T_in, N, L, S, F, ldt, geo.pad_left, relu)
+
+    x = torch.empty(B, Bn, ldt, **f32)
+    K.pw_gemm(B=B, M=Bn, K=N, T=F, ldt=ldt, A=P["separator.bottleneck_conv1d.weight"], X=w, Y=x,
+              bias=P["separator.bottleneck_conv1d.bias"], pro_mode=PRO_GLN, pro_stats=stats[0],
+              pro_gamma=P["separator.norm1d.norm.weight"], pro_beta=P["separator.norm1d.norm.bias"], count=N * F, eps=eps)
+
+    skip = torch.empty(B, Sc, ldt, **f32)
+    acts = []
+    for li, (pre, dil, dual) in enumerate(layers):
+        sp = pre + "separable_conv1d."
+        st1, st2 = stats[1 + 2 * li], stats[2 + 2 * li]
+        a = torch.empty(B, H, ldt, **f32)
+        K.pw_gemm(B=B, M=H, K=Bn, T=F, ldt=ldt, A=P[pre + "bottleneck_conv1d.weight"], X=x, Y=a,
+                  bias=P[pre + "bottleneck_conv1d.bias"], epi_flags=EPI_STATS_PRELU, epi_alpha=P[pre + "nonlinear1d.weight"],
+                  epi_stats=st1, eps=eps)
+        z = torch.empty(B, H, ldt, **f32)
+        K.dwconv_fwd(a, st1, P[pre + "norm1d.norm.weight"], P[pre + "norm1d.norm.bias"], P[pre + "nonlinear1d.weight"],
+                     P[sp + "depthwise_conv1d.weight"], P[sp + "depthwise_conv1d.bias"], P[sp + "nonlinear1d.weight"],
+                     z, st2, B, H, F, ldt, dil, eps)
+        pro = dict(pro_mode=PRO_GLN_PRELU, pro_stats=st2, pro_gamma=P[sp + "norm1d.norm.weight"],
+                   pro_beta=P[sp + "norm1d.norm.bias"], pro_alpha=P[sp + "nonlinear1d.weight"], count=H * F, eps=eps)
+        Ws, bs = P[sp + "skip_pointwise_conv1d.weight"], P[sp + "skip_pointwise_conv1d.bias"]
+        if dual:
+            Wo, bo = P[sp + "output_pointwise_conv1d.weight"], P[sp + "output_pointwise_conv1d.bias"]
+            xo = torch.empty(B, Bn, ldt, **f32)
+            if Bn % 128 == 0 and _adjacent(Wo, Ws) and _adjacent(bo, bs):
+                # [Wo;Ws] contiguous (flat parameter layout): one GEMM reads the H-tensor z once for both heads
+                K.pw_gemm(B=B, M=Bn + Sc, K=H, T=F, ldt=ldt, A=Wo, X=z, Y=xo, Y2=skip, m_split=Bn, bias=bo,
+                          accumulate=int(li > 0), epi_flags=EPI_RESIDUAL, epi_res=x, **pro)
+            else:
+                K.pw_gemm(B=B, M=Bn, K=H, T=F, ldt=ldt, A=Wo, X=z, Y=xo, bias=bo, epi_flags=EPI_RESIDUAL, epi_res=x, **pro)
+                K.pw_gemm(B=B, M=Sc, K=H, T=F, ldt=ldt, A=Ws, X=z, Y=skip, bias=bs, accumulate=int(li > 0), **pro)
+        else:
+            xo = None
+            K.pw_gemm(B=B, M=Sc, K=H, T=F, ldt=ldt, A=Ws, X=z, Y=skip, bias=bs, accumulate=int(li > 0), **pro)
+        acts.append((x, a, z))
+        x = xo
+
+    m = torch.empty(B, n_src * N, ldt, **f32)
+    K.pw_gemm(B=B, M=n_src * N, K=Sc, T=F, ldt=ldt, A=P["separator.mask_conv1d.weight"], X=skip, Y=m,
+              bias=P["separator.mask_conv1d.bias"], pro_mode=PRO_PRELU, pro_alpha=P["separator.prelu.weight"],
+              epi_flags=EPI_SIGMOID, eps=eps)
+
+    est = torch.empty(B, n_src, Cin, T_in, **f32)
+    latent = torch.empty(B, n_src, N, ldt, **f32) if want_latent else None
+    K.decoder_fwd(w, m, P["decoder.conv_transpose1d.weight"], est, latent, B, n_src, N, Cin, L, S, F, ldt, T_in, geo.pad_left)
+
+    sv = None
+    if save:
+        sv = Saved()
+        sv.geo, sv.stats, sv.w, sv.acts, sv.skip, sv.m, sv.mixture = geo, stats, w, acts, skip, m, mixture
+    return est, latent, sv
+
+
+def backward(cfg, P, sv, d_est, G):
+    """Writes the gradient of every parameter into G[name] (overwrites; G tensors have the parameter shapes)."""
+    K = backend()
+    mixture = sv.mixture
+    dev = mixture.device
+    B, Cin, T_in = mixture.shape
+    N, L, S = cfg["n_basis"], cfg["kernel_size"], cfg["stride"]
+    Bn, H, Sc = cfg["sep_bottleneck_channels"], cfg["sep_hidden_channels"], cfg["sep_skip_channels"]
+    n_src = cfg["n_sources"]
+    eps = float(cfg.get("eps", 1e-12))
+    relu = cfg.get("enc_nonlinear") == "relu"
+    geo, stats, w, skip, m = sv.geo, sv.stats, sv.w, sv.skip, sv.m
+    F, ldt = geo.F, geo.ldt
+    layers = layer_names(cfg)
+    nl = len(layers)
+    f32 = dict(device=dev, dtype=mixture.dtype)   # always fp32 in the product; the CPU emulator tests also run fp64
+    chunks = B * (ldt // 32)
+    nt64, nt1024 = ldt // 64, (ldt + 1023) // 1024
+    dalpha = torch.zeros(nl + 1, device=dev, dtype=torch.float64)   # [layer alpha1 ..., mask prelu]
+
+    def wgrad(M, Nn, Gt, Xt, dW, dbias=None, Bq=B, **kw):
+        ch = Bq * (ldt // 32)
+        ns = _nsplit(M, Nn, ch)
+        part = torch.empty(ns, M, Nn, **f32)
+        pb = torch.empty(ns, M, **f32) if dbias is not None else None
+        K.pw_wgrad(B=Bq, M=M, N=Nn, T=F, ldt=ldt, G=Gt, X=Xt, partial=part, partial_bias=pb, nsplit=ns, eps=eps, **kw)
+        return part, pb, ns
+
+    # ---- tail: decoder / mask ---------------------------------------------------------------------
+    d_est = d_est.contiguous()
+    D = P["decoder.conv_transpose1d.weight"]
+    Fd = torch.empty(B * n_src, Cin * L, ldt, **f32)
+    K.unfold(d_est, Fd, B * n_src, Cin, T_in, L, S, F, ldt, geo.pad_left)
+    part, _, ns = wgrad(N, Cin * L, m, Fd, True, None, Bq=B * n_src, Gaux=w, g_mul=1, g_div=n_src)
+    K.reduce_slabs([(part, 0, G["decoder.conv_transpose1d.weight"], N * Cin * L, ns, N * Cin * L, 0, 1.0)])
+    dpre = torch.empty(B, n_src * N, ldt, **f32)
+    dwm = torch.empty(B, N, ldt, **f32)
+    K.decoder_bwd(d_est, w, m, D, dpre, dwm, B, n_src, N, Cin, L, S, F, ldt, T_in, geo.pad_left)
+
+    Wm = P["separator.mask_conv1d.weight"]
+    alpha_m = P["separator.prelu.weight"]
+    dS = torch.empty(B, Sc, ldt, **f32)
+    K.pw_gemm(B=B, M=Sc, K=n_src * N, T=F, ldt=ldt, trans_a=1, A=Wm, X=dpre, Y=dS, epi_flags=EPI_PRELU_BWD, epi_aux=skip,
+              epi_alpha=alpha_m, epi_dalpha=dalpha[nl:nl + 1], eps=eps)
+    part, pb, ns = wgrad(n_src * N, Sc, dpre, skip, True, True, x_mode=PRO_PRELU, x_alpha=alpha_m)
+    K.reduce_slabs([(part, 0, G["separator.mask_conv1d.weight"], n_src * N * Sc, ns, n_src * N * Sc, 0, 1.0),
+                    (pb, 0, G["separator.mask_conv1d.bias"], n_src * N, ns, n_src * N, 0, 1.0)])
+
+    # ---- TCN layers, reversed -----------------------------------------------------------------------
+    dout = None
+    for li in range(nl - 1, -1, -1):
+        pre, dil, dual = layers[li]
+        sp = pre + "separable_conv1d."
+        x, a, z = sv.acts[li]
+        st1, st2 = stats[1 + 2 * li], stats[2 + 2 * li]
+        g1, b1, al1 = P[pre + "norm1d.norm.weight"], P[pre + "norm1d.norm.bias"], P[pre + "nonlinear1d.weight"]
+        g2, b2, al2 = P[sp + "norm1d.norm.weight"], P[sp + "norm1d.norm.bias"], P[sp + "nonlinear1d.weight"]
+        Ws = P[sp + "skip_pointwise_conv1d.weight"]
+        cnt = H * F
+
+        # dv2 = Wo^T dout + Ws^T dS, with the row sums the gLN2 backward needs
+        dv2 = torch.empty(B, H, ldt, **f32)
+        rp2 = torch.empty(B, H, nt64, 2, **f32)
+        epi = dict(epi_flags=EPI_ROWSUMS | EPI_ROWSUMS_PRELU, epi_aux=z, epi_alpha=al2, epi_rowpart=rp2, eps=eps)
+        if dual:
+            Wo = P[sp + "output_pointwise_conv1d.weight"]
+            K.pw_gemm(B=B, M=H, K=Bn + Sc, T=F, ldt=ldt, trans_a=1, A=Wo, A2=Ws, X=dout, X2=dS, k_split=Bn, Y=dv2, **epi)
+        else:
+            K.pw_gemm(B=B, M=H, K=Sc, T=F, ldt=ldt, trans_a=1, A=Ws, X=dS, Y=dv2, **epi)
+        bsum2 = torch.empty(B, 2, **f32)
+        pbeta2 = torch.empty(B, H, **f32)
+        pgamma2 = torch.empty(B, H, **f32)
+        K.gln_bwd_finalize(rp2, nt64, 2, st2, g2, cnt, eps, bsum2, pbeta2, pgamma2, None, B, H)
+
+        # head weight gradients: dWo = sum dout v2^T, dWs = sum dS v2^T   (v2 = gLN2(PReLU(z)) rebuilt on load)
+        xkw = dict(x_mode=PRO_GLN_PRELU, x_stats=st2, x_gamma=g2, x_beta=b2, x_alpha=al2, count=cnt)
+        segs = []
+        if dual and Bn % 128 == 0:
+            part, pb, ns = wgrad(Bn + Sc, H, dout, z, True, True, G2=dS, g_split=Bn, **xkw)
+            st = (Bn + Sc) * H
+            segs += [(part, 0, G[sp + "output_pointwise_conv1d.weight"], Bn * H, ns, st, 0, 1.0),
+                     (part, Bn * H, G[sp + "skip_pointwise_conv1d.weight"], Sc * H, ns, st, 0, 1.0),
+                     (pb, 0, G[sp + "output_pointwise_conv1d.bias"], Bn, ns, Bn + Sc, 0, 1.0),
+                     (pb, Bn, G[sp + "skip_pointwise_conv1d.bias"], Sc, ns, Bn + Sc, 0, 1.0)]
+        else:
+            if dual:
+                part, pb, ns = wgrad(Bn, H, dout, z, True, True, **xkw)
+                segs += [(part, 0, G[sp + "output_pointwise_conv1d.weight"], Bn * H, ns, Bn * H, 0, 1.0),
+                         (pb, 0, G[sp + "output_pointwise_conv1d.bias"], Bn, ns, Bn, 0, 1.0)]
+            part, pb, ns = wgrad(Sc, H, dS, z, True, True, **xkw)
+            segs += [(part, 0, G[sp + "skip_pointwise_conv1d.weight"], Sc * H, ns, Sc * H, 0, 1.0),
+                     (pb, 0, G[sp + "skip_pointwise_conv1d.bias"], Sc, ns, Sc, 0, 1.0)]
+        K.reduce_slabs(segs)
+
+        # depthwise^T and everything hanging off it
+        dv1 = torch.empty(B, H, ldt, **f32)
+        rp1 = torch.empty(B, H, nt1024, 8, **f32)
+        K.dwconv_bwd(dv2, z, a, st1, g1, b1, al1, st2, g2, al2, bsum2, P[sp + "depthwise_conv1d.weight"], dv1, rp1,
+                     B, H, F, ldt, dil, eps)
+        bsum1 = torch.empty(B, 2, **f32)
+        pbeta1 = torch.empty(B, H, **f32)
+        pgamma1 = torch.empty(B, H, **f32)
+        pextra = torch.empty(B * 4 * H + B, **f32)
+        K.gln_bwd_finalize(rp1, nt1024, 8, st1, g1, cnt, eps, bsum1, pbeta1, pgamma1, pextra, B, H)
+        K.reduce_slabs([
+            (pbeta2, 0, G[sp + "norm1d.norm.bias"], H, B, H, 0, 1.0),
+            (pgamma2, 0, G[sp + "norm1d.norm.weight"], H, B, H, 0, 1.0),
+            (pbeta1, 0, G[pre + "norm1d.norm.bias"], H, B, H, 0, 1.0),
+            (pgamma1, 0, G[pre + "norm1d.norm.weight"], H, B, H, 0, 1.0),
+            (pextra, 0, G[sp + "depthwise_conv1d.bias"], H, B, 4 * H, 0, 1.0),
+            (pextra, H, G[sp + "depthwise_conv1d.weight"], 3 * H, B, 4 * H, 0, 1.0),
+            (pextra, B * 4 * H, G[sp + "nonlinear1d.weight"], 1, B, 1, 0, 1.0),
+        ])
+
+        # dx = W1^T da (+ dout through the residual); da = gLN1/PReLU1 backward of dv1, formed in the GEMM prologue
+        dx = torch.empty(B, Bn, ldt, **f32)
+        K.pw_gemm(B=B, M=Bn, K=H, T=F, ldt=ldt, trans_a=1, A=P[pre + "bottleneck_conv1d.weight"], X=dv1, Y=dx,
+                  pro_mode=PRO_GLN_BWD, pro_stats=st1, pro_gamma=g1, pro_alpha=al1, pro_aux=a, pro_bsum=bsum1,
+                  pro_store=dv1, pro_dalpha=dalpha[li:li + 1], count=cnt, eps=eps,
+                  epi_flags=(EPI_RESIDUAL if dout is not None else 0), epi_res=dout)
+        part, pb, ns = wgrad(H, Bn, dv1, x, True, True)
+        K.reduce_slabs([(part, 0, G[pre + "bottleneck_conv1d.weight"], H * Bn, ns, H * Bn, 0, 1.0),
+                        (pb, 0, G[pre + "bottleneck_conv1d.bias"], H, ns, H, 0, 1.0)])
+        K.f64_to_f32(dalpha[li:li + 1], G[pre + "nonlinear1d.weight"], 1, 0)
+        dout = dx
+    K.f64_to_f32(dalpha[nl:nl + 1], G["separator.prelu.weight"], 1, 0)
+
+    # ---- head: bottleneck conv, first gLN, encoder ------------------------------------------------------
+    g0, b0 = P["separator.norm1d.norm.weight"], P["separator.norm1d.norm.bias"]
+    Wb = P["separator.bottleneck_conv1d.weight"]
+    cnt0 = N * F
+    part, pb, ns = wgrad(Bn, N, dout, w, True, True, x_mode=PRO_GLN, x_stats=stats[0], x_gamma=g0, x_beta=b0, count=cnt0)
+    dvw = torch.empty(B, N, ldt, **f32)
+    rp0 = torch.empty(B, N, nt64, 2, **f32)
+    K.pw_gemm(B=B, M=N, K=Bn, T=F, ldt=ldt, trans_a=1, A=Wb, X=dout, Y=dvw, epi_flags=EPI_ROWSUMS, epi_aux=w,
+              epi_rowpart=rp0, eps=eps)
+    bsum0 = torch.empty(B, 2, **f32)
+    pbeta0 = torch.empty(B, N, **f32)
+    pgamma0 = torch.empty(B, N, **f32)
+    K.gln_bwd_finalize(rp0, nt64, 2, stats[0], g0, cnt0, eps, bsum0, pbeta0, pgamma0, None, B, N)
+    K.reduce_slabs([(part, 0, G["separator.bottleneck_conv1d.weight"], Bn * N, ns, Bn * N, 0, 1.0),
+                    (pb, 0, G["separator.bottleneck_conv1d.bias"], Bn, ns, Bn, 0, 1.0),
+                    (pbeta0, 0, G["separator.norm1d.norm.bias"], N, B, N, 0, 1.0),
+                    (pgamma0, 0, G["separator.norm1d.norm.weight"], N, B, N, 0, 1.0)])
+    K.head_bwd(dvw, w, dwm, stats[0], g0, bsum0, B, N, F, ldt, cnt0, eps, relu)
+    Fx = torch.empty(B, Cin * L, ldt, **f32)
+    K.unfold(mixture, Fx, B, Cin, T_in, L, S, F, ldt, geo.pad_left)
+    part, _, ns = wgrad(N, Cin * L, dvw, Fx, True, None)
+    K.reduce_slabs([(part, 0, G["encoder.conv1d.weight"], N * Cin * L, ns, N * Cin * L, 0, 1.0)])

@@ -1,0 +1,248 @@
+/*
+ * sepkernels.h -- C ABI of libsepkernels.so: the MI355X (gfx950) kernels behind the
+ * Conv-TasNet separation path of tky823/DNN-based_source_separation.
+ *
+ * The reference is pure PyTorch and has NO FFI for this path; each entry
+ * point below therefore names the reference *Python* interface whose arithmetic it replaces
+ * (file:line under /root/reference/src).  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference adds to route those interfaces here.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch types; every pointer is a DEVICE pointer
+ *     unless the name ends in _host.
+ *   - activations are fp32, layout (batch, channel, frame) as in the reference, frame
+ *     contiguous, with a padded row stride `ldt` (floats, multiple of 128).  Frames
+ *     [T, ldt) of every tensor a kernel WRITES are set to 0.
+ *   - gLN statistics are carried as double[B][2] = {sum, sum of squares} over the valid
+ *     (C, T) region of a sample; accumulated with fp64 atomics, so the caller zeroes them.
+ *   - the caller owns every buffer (inputs, outputs, saved activations, workspaces).
+ *     The library keeps no global mutable state, is re-entrant, never synchronises the
+ *     device and launches only on the stream it is given (the caller selects the device).
+ *   - return 0 on success, <0 on error; sep_last_error() gives the thread-local message.
+ */
+#ifndef SEPKERNELS_H
+#define SEPKERNELS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sep_stream_t; /* hipStream_t */
+
+#define SEP_ABI_VERSION 1
+
+int sep_version(void);
+const char* sep_last_error(void);
+
+/* ---- prologue modes applied to the X operand while it is staged into LDS ---------- */
+#define SEP_PRO_NONE 0
+#define SEP_PRO_PRELU 1     /* x -> PReLU(x; alpha)                         conv_tasnet.py:373 */
+#define SEP_PRO_GLN 2       /* x -> gLN(x)                                  modules/norm.py:27 */
+#define SEP_PRO_GLN_PRELU 3 /* x -> gLN(PReLU(x; alpha))                    tdcn.py:113-116,182-186 */
+#define SEP_PRO_GLN_BWD 4   /* X = d(gLN out); uses pro_aux = pre-activation a:
+                               da = rstd*(gamma*X - mg - xhat*mgx) * PReLU'(a); da is also stored to pro_store
+                               and sum(du * a * [a<=0]) is accumulated into pro_dalpha */
+
+/* ---- epilogue flags ----------------------------------------------------------------- */
+#define SEP_EPI_STATS_PRELU 1 /* accumulate sum/sumsq of PReLU(y; epi_alpha) into epi_stats (y itself is stored) */
+#define SEP_EPI_RESIDUAL 2    /* y += epi_res                                tdcn.py:144-145 */
+#define SEP_EPI_SIGMOID 4     /* y = 1/(1+exp(-y))                           conv_tasnet.py:375 */
+#define SEP_EPI_PRELU_BWD 8   /* y = y * PReLU'(epi_aux); epi_dalpha += sum(y_in * epi_aux * [epi_aux<=0]) */
+#define SEP_EPI_ROWSUMS 16    /* epi_rowpart[b][m][t/64][0..1] = sum_t y, sum_t y*u, u = epi_aux (or PReLU(epi_aux)) */
+#define SEP_EPI_ROWSUMS_PRELU 32
+
+/* Pointwise (1x1) convolution as a GEMM on MFMA (fp32 in / fp32 accumulate):
+ *     Y[b][m][t] = epilogue( sum_k A[m][k] * prologue(X[b][k][t]) + bias[m] )
+ * Replaces nn.Conv1d(kernel_size=1) at tdcn.py:86,173,175 and conv_tasnet.py:335,341 in the
+ * forward direction, and the same layers' input-gradient (A transposed) in backward.
+ * M and K must be multiples of 16 (K) / any (M); ldt multiple of 128. */
+typedef struct sep_gemm_desc {
+    int32_t B, M, K, T, ldt;
+    int32_t trans_a;    /* 0: A is [M][K] row-major ; 1: A is [K][M] row-major (input-gradient form) */
+    int32_t k_split;    /* 0, or multiple of 16: contraction rows k >= k_split are read from (A2, X2) at row k-k_split */
+    int32_t m_split;    /* 0, or multiple of 128: output rows m >= m_split are written to Y2 (row m-m_split) */
+    int32_t pro_mode;   /* SEP_PRO_* */
+    int32_t epi_flags;  /* SEP_EPI_* bitmask; RESIDUAL applies to Y rows only */
+    int32_t accumulate; /* 1: Y2 (or Y when m_split==0) += result instead of = */
+    float eps;
+    double count; /* number of valid elements per sample (C*T) of the gLN used by the prologue */
+    const float* A;
+    const float* A2;
+    const float* X;
+    const float* X2;
+    float* Y;
+    float* Y2;
+    const float* bias; /* [M] or NULL */
+    const float* pro_alpha;
+    const double* pro_stats;
+    const float* pro_gamma;
+    const float* pro_beta;
+    const float* pro_aux;
+    const float* pro_bsum; /* [B][2] = mean(g), mean(g*xhat) of the gLN being back-propagated */
+    float* pro_store;
+    double* pro_dalpha;
+    const float* epi_alpha;
+    double* epi_stats;
+    const float* epi_res;
+    const float* epi_aux;
+    double* epi_dalpha;
+    float* epi_rowpart;
+} sep_gemm_desc;
+
+int sep_pw_gemm(const sep_gemm_desc* d, sep_stream_t stream);
+
+/* Weight gradient of a pointwise convolution (reduction over batch and frames) on MFMA:
+ *     partial[s][m][n] = sum over the (b,t) columns of slab s of  Gp[b][m][t] * Xp[b][n][t]
+ *     partial_bias[s][m] = sum of Gp[b][m][t]
+ * followed by sep_reduce_slabs.  Replaces autograd's conv weight/bias gradient for the same
+ * nn.Conv1d layers, and (with unfolded frames as X) for Encoder.conv1d (filterbank.py:212)
+ * and Decoder.conv_transpose1d (filterbank.py:243). */
+typedef struct sep_wgrad_desc {
+    int32_t B, M, N, T, ldt;
+    int32_t g_split; /* 0, or multiple of 128: rows m >= g_split of G are read from G2 */
+    int32_t g_mul;   /* 1: Gp = G * Gaux[b / g_div] (latent = mask * w) */
+    int32_t g_div;
+    int32_t x_mode; /* SEP_PRO_NONE / PRELU / GLN / GLN_PRELU */
+    int32_t x_div;  /* X (and its gLN stats) are indexed with b / x_div */
+    int32_t nsplit; /* number of partial slabs, <= B*ldt/32 */
+    float eps;
+    double count;
+    const float* G;
+    const float* G2;
+    const float* Gaux;
+    const float* X;
+    const float* x_alpha;
+    const double* x_stats;
+    const float* x_gamma;
+    const float* x_beta;
+    float* partial;      /* [nsplit][M][N] */
+    float* partial_bias; /* [nsplit][M] or NULL */
+} sep_wgrad_desc;
+
+int sep_pw_wgrad(const sep_wgrad_desc* d, sep_stream_t stream);
+
+/* dst[i] (+)= scale * sum_s src[s*stride + i] for up to 8 independent segments in one launch
+ * (deterministic second stage of every split reduction). */
+typedef struct sep_reduce_seg {
+    const float* src;
+    float* dst;
+    int32_t n, nslab;
+    int64_t stride;
+    int32_t accumulate;
+    float scale;
+} sep_reduce_seg;
+int sep_reduce_slabs(const sep_reduce_seg* segs_host, int nseg, sep_stream_t stream);
+
+/* dst(double scalar partials) -> float parameter gradient: dst[i] (+)= (float)src[i] */
+int sep_f64_to_f32(const double* src, float* dst, int n, int accumulate, sep_stream_t stream);
+
+/* Encoder.forward (filterbank.py:222-230) with ConvTasNet's input padding (conv_tasnet.py:145-149):
+ *   w[b][n][f] = sum_{c,k} E[n][c][k] * xpad[b][c][S*f+k] (+ReLU), xpad = x shifted right by pad_left, zero elsewhere.
+ * Also accumulates the gLN statistics of w (separator.norm1d, conv_tasnet.py:370). */
+int sep_encoder_fwd(const float* x, const float* E, float* w, double* stats, int B, int Cin, int Tin, int N, int L,
+                    int S, int F, int ldt, int pad_left, int relu, sep_stream_t stream);
+
+/* frames[b][c*L+k][f] = xpad[b][c][S*f+k]  (the im2col operand of the encoder/decoder weight gradients) */
+int sep_unfold(const float* x, float* frames, int Bp, int C, int Tin, int L, int S, int F, int ldt, int pad_left,
+               sep_stream_t stream);
+
+/* Depthwise dilated conv of ResidualBlock1d/DepthwiseSeparableConv1d (tdcn.py:113-132,177-186), forward:
+ *   v = gLN(PReLU(a; alpha1)) ; v = 0 outside [0,T) ; z[c][t] = bd[c] + sum_k wd[c][k] * v[c][t+(k-1)*d]
+ * and accumulation of the statistics of PReLU(z; alpha2) for the following gLN.  P = 3 only. */
+int sep_dwconv_fwd(const float* a, const double* stats1, const float* gamma1, const float* beta1, const float* alpha1,
+                   const float* wd, const float* bd, const float* alpha2, float* z, double* stats2, int B, int C, int T,
+                   int ldt, int dilation, float eps, sep_stream_t stream);
+
+/* Backward of [gLN2 o PReLU2 o depthwise] given dv2 = d(gLN2 output):
+ *   du2 = r2*(gamma2*dv2 - mg2 - xhat2*mgx2) ; dz = du2*PReLU'(z) ; dv1 = depthwise^T(dz)
+ * Writes dv1 and, per (b, c, 1024-frame tile), 8 partial row sums into rowpart[b][c][ntile][8]:
+ *   {sum dv1, sum dv1*u1, sum dz, sum dz*v1[t-d], sum dz*v1[t], sum dz*v1[t+d], sum du2*z*[z<=0], 0}
+ * (u1 = PReLU(a), v1 = gLN1(u1) inside [0,T) and 0 outside; ntile = ceil(ldt/1024)). */
+int sep_dwconv_bwd(const float* dv2, const float* z, const float* a, const double* stats1, const float* gamma1,
+                   const float* beta1, const float* alpha1, const double* stats2, const float* gamma2,
+                   const float* alpha2, const float* bsum2, const float* wd, float* dv1, float* rowpart, int B, int C,
+                   int T, int ldt, int dilation, float eps, sep_stream_t stream);
+
+/* Second stage of every gLN backward (Appendix A of SURVEY.md).  rowpart is [B][C][ntile][nq], nq in {2, 8}:
+ *   R1 = sum_tiles rowpart[..][0], R2 = sum_tiles rowpart[..][1]
+ *   pbeta[b][c] = R1 ; pgamma[b][c] = r_b*(R2 - mu_b*R1)
+ *   bsum[b] = { sum_c gamma_c*R1 / count , sum_c gamma_c*pgamma[b][c] / count }
+ *   nq == 8 additionally (pextra holds B*C*4 + B floats):
+ *     pextra[b*4C + c]           = sum_tiles rowpart[..][2]      (depthwise bias gradient, per sample)
+ *     pextra[b*4C + C + 3c + k]  = sum_tiles rowpart[..][3+k]    (depthwise weight gradient [C][3], per sample)
+ *     pextra[B*4C + b]           = sum_{c,tiles} rowpart[..][6]  (PReLU slope gradient, per sample) */
+int sep_gln_bwd_finalize(const float* rowpart, int ntile, int nq, const double* stats, const float* gamma, double count,
+                         float eps, float* bsum, float* pbeta, float* pgamma, float* pextra, int B, int C,
+                         sep_stream_t stream);
+
+/* Backward tail of the separator head: dw = r0*(gamma0*dvw - mg - xhat*mgx) + dwm, times [w>0] if the encoder has ReLU.
+ * In place on dvw. (conv_tasnet.py:370 gLN backward + conv_tasnet.py:159-160 product rule + filterbank.py:227) */
+int sep_head_bwd(float* dvw, const float* w, const float* dwm, const double* stats0, const float* gamma0,
+                 const float* bsum0, int B, int C, int T, int ldt, double count, float eps, int relu,
+                 sep_stream_t stream);
+
+/* mask * w, Decoder.forward = basis synthesis + overlap-add, and the crop (conv_tasnet.py:159-169, filterbank.py:245-247):
+ *   est[b][s][c][tau] = sum_{n,f,k: S*f+k = tau+pad_left} w[b][n][f] * m[b][s][n][f] * D[n][c][k]
+ * latent (may be NULL) receives w*m as (B, n_src, N, ldt). */
+int sep_decoder_fwd(const float* w, const float* m, const float* D, float* est, float* latent, int B, int n_src, int N,
+                    int Cout, int L, int S, int F, int ldt, int Tout, int pad_left, sep_stream_t stream);
+
+/* Backward of the same: given d_est, writes dpre = d(mask pre-activation) (sigmoid) as (B, n_src*N, ldt)
+ * and dwm[b][n][f] = sum_s dlatent*m. */
+int sep_decoder_bwd(const float* d_est, const float* w, const float* m, const float* D, float* dpre, float* dwm, int B,
+                    int n_src, int N, int Cout, int L, int S, int F, int ldt, int Tout, int pad_left,
+                    sep_stream_t stream);
+
+/* Stand-alone gLN (modules/norm.py:11-35) for callers outside the fused network. */
+int sep_gln_stats(const float* x, double* stats, int B, int C, int T, int ldt, sep_stream_t stream);
+int sep_gln_apply(const float* x, const double* stats, const float* gamma, const float* beta, float* y, int B, int C,
+                  int T, int ldt, double count, float eps, sep_stream_t stream);
+/* rowpart[b][c][ntile][2] = {sum_t dy, sum_t dy*x} per 1024-frame tile */
+int sep_gln_bwd_rowsums(const float* dy, const float* x, float* rowpart, int B, int C, int T, int ldt,
+                        sep_stream_t stream);
+int sep_gln_bwd_apply(const float* dy, const float* x, const double* stats, const float* gamma, const float* bsum,
+                      float* dx, int B, int C, int T, int ldt, double count, float eps, sep_stream_t stream);
+
+/* (B, C, T) <-> (B, C, ldt) repack with zero fill of the pad frames */
+int sep_repack(const float* src, int ld_src, float* dst, int ld_dst, int rows, int T, sep_stream_t stream);
+
+/* SI-SDR (criterion/sdr.py:122-139): per batch item and per (i, j) pair the three dot products
+ *   dots[b][i][j] = <est_i, tgt_j>, tt[b][j] = |tgt_j|^2, xx[b][i] = |est_i|^2      (double)
+ * all_pairs = 0 computes only i == j. */
+int sep_sisdr_dots(const float* est, const float* tgt, double* dots, double* tt, double* xx, int B, int n, int T,
+                   int all_pairs, sep_stream_t stream);
+/* sisdr[b][i][j] (float) from the dot products, reference formula with eps. */
+int sep_sisdr_from_dots(const double* dots, const double* tt, const double* xx, float* sisdr, int B, int n,
+                        int all_pairs, float eps, sep_stream_t stream);
+/* d_est[b][i][:] = sum_j gw[b][i][j] * d sisdr_ij / d est_i ; gw = dL/d sisdr (float, [B][n][n]; diagonal only if !all_pairs) */
+int sep_sisdr_bwd(const float* est, const float* tgt, const double* dots, const double* tt, const double* xx,
+                  const float* gw, float* d_est, int B, int n, int T, int all_pairs, float eps, sep_stream_t stream);
+
+/* PIT search (criterion/pit.py:9-44) on the pair matrix: score[b][p] = reduce_s val[b][s][perm_p(s)] with
+ * reduce = mean (or sum); picks min (maximize=0) or max; ties resolve to the first permutation in
+ * itertools.permutations order like torch.min/max.  perms is [P][n] int32.  best_idx int64 [B], best_val float [B]. */
+int sep_pit_search(const float* val, const int32_t* perms, int P, int n, int B, int maximize, int use_mean,
+                   float* best_val, int64_t* best_idx, sep_stream_t stream);
+
+/* Sinkhorn PIT (criterion/pit.py:163-193) on the cost matrix C[b][n][n] (float):
+ * forward keeps every iterate in zwork (double [B][2*iters+1][n][n]) for the reverse sweep. */
+int sep_sinkhorn_fwd(const float* C, double* zwork, float* loss, float* P, int B, int n, float coldness, int iters,
+                     sep_stream_t stream);
+int sep_sinkhorn_bwd(const float* C, const double* zwork, const float* dloss, float* dC, int B, int n, float coldness,
+                     int iters, sep_stream_t stream);
+
+/* clip_grad_norm_ + Adam of the train step (egs/wsj0-mix/common/src/driver.py:152-155), fused on a flat buffer:
+ *   sqnorm[0] += sum g^2  (double, caller zeroes) ; then
+ *   g *= min(1, max_norm/(sqrt(sqnorm)+1e-6)) (if max_norm > 0) ; Adam(lr, b1, b2, eps, weight_decay), step t. */
+int sep_sqnorm(const float* g, double* sqnorm, int64_t n, sep_stream_t stream);
+int sep_adam_step(float* p, float* g, float* m, float* v, const double* sqnorm, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, float max_norm, float grad_scale, int step,
+                  sep_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

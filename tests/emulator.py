@@ -1,0 +1,415 @@
+"""
+TEST INFRASTRUCTURE ONLY -- a CPU emulation of every entry point of include/sepkernels.h with plain torch
+arithmetic, operating on the same padded (batch, channel, ldt) buffers and honouring the same contracts
+(zeroed pad frames, partial-slab outputs, accumulated statistics).
+
+Purpose: (1) check the host-side orchestration (sepkernels/net.py, the autograd wrappers, the criteria) against
+the oracle in this GPU-less container; (2) serve as the per-kernel expected value in the `-m gpu` tests, where
+each HIP kernel is compared against its emulation on identical buffers.
+
+It is injected with sepkernels._set_backend_for_tests() by tests only; the product never imports it.
+"""
+import math
+
+import torch
+
+PRO_NONE, PRO_PRELU, PRO_GLN, PRO_GLN_PRELU, PRO_GLN_BWD = 0, 1, 2, 3, 4
+EPI_STATS_PRELU, EPI_RESIDUAL, EPI_SIGMOID, EPI_PRELU_BWD, EPI_ROWSUMS, EPI_ROWSUMS_PRELU = 1, 2, 4, 8, 16, 32
+
+
+def _prelu(x, a):
+    return torch.where(x > 0, x, a.reshape(()).to(x.dtype) * x)
+
+
+def _prelu_grad(x, a):
+    return torch.where(x > 0, torch.ones_like(x), a.reshape(()).to(x.dtype) * torch.ones_like(x))
+
+
+def _mu_rstd(stats, count, eps, dtype):
+    m = stats[:, 0] / count
+    var = (stats[:, 1] / count - m * m).clamp_min(0.0)
+    return m.to(dtype).view(-1, 1, 1), (1.0 / torch.sqrt(var + eps)).to(dtype).view(-1, 1, 1)
+
+
+class EmuBackend:
+    name = "emulator"
+
+    # ------------------------------------------------------------------ GEMMs
+    def pw_gemm(self, *, B, M, K, T, ldt, A, X, Y, trans_a=0, A2=None, X2=None, k_split=0, Y2=None, m_split=0,
+                pro_mode=PRO_NONE, epi_flags=0, accumulate=0, eps=1e-12, count=0.0, bias=None, pro_alpha=None,
+                pro_stats=None, pro_gamma=None, pro_beta=None, pro_aux=None, pro_bsum=None, pro_store=None,
+                pro_dalpha=None, epi_alpha=None, epi_stats=None, epi_res=None, epi_aux=None, epi_dalpha=None,
+                epi_rowpart=None):
+        dt = X.dtype
+        k1 = k_split if k_split else K
+        if trans_a:
+            Am = A.reshape(k1, M)
+            if k_split:
+                Am = torch.cat([Am, A2.reshape(K - k1, M)], 0)
+            Am = Am.t()
+        else:
+            Am = A.reshape(M, k1)
+            if k_split:
+                Am = torch.cat([Am, A2.reshape(M, K - k1)], 1)
+        Xf = X.reshape(B, k1, ldt)
+        if k_split:
+            Xf = torch.cat([Xf, X2.reshape(B, K - k1, ldt)], 1)
+        valid = (torch.arange(ldt) < T).view(1, 1, ldt)
+        if pro_mode in (PRO_GLN, PRO_GLN_PRELU, PRO_GLN_BWD):
+            mu, rstd = _mu_rstd(pro_stats, count, eps, dt)
+        if pro_mode == PRO_PRELU:
+            Xp = _prelu(Xf, pro_alpha)
+        elif pro_mode in (PRO_GLN, PRO_GLN_PRELU):
+            u = _prelu(Xf, pro_alpha) if pro_mode == PRO_GLN_PRELU else Xf
+            sc = pro_gamma.view(1, K, 1) * rstd
+            sh = pro_beta.view(1, K, 1) - mu * sc
+            Xp = u * sc + sh
+        elif pro_mode == PRO_GLN_BWD:
+            a = pro_aux.reshape(B, K, ldt)
+            u = _prelu(a, pro_alpha)
+            xh = (u - mu) * rstd
+            mg, mgx = pro_bsum[:, 0].view(B, 1, 1), pro_bsum[:, 1].view(B, 1, 1)
+            du = rstd * (pro_gamma.view(1, K, 1) * Xf - mg - xh * mgx)
+            da = torch.where(valid, du * _prelu_grad(a, pro_alpha), torch.zeros_like(du))
+            pro_dalpha += torch.where(valid & (a <= 0), du * a, torch.zeros_like(du)).sum().double()
+            Xp = da
+            pro_store.reshape(B, K, ldt).copy_(da)
+        else:
+            Xp = Xf
+        y = torch.einsum("mk,bkt->bmt", Am, Xp)
+        if bias is not None:
+            y = y + bias.reshape(1, M, 1)
+        Mf = m_split if m_split else M
+        if epi_flags & EPI_STATS_PRELU:
+            u = torch.where(valid, _prelu(y, epi_alpha), torch.zeros_like(y))
+            epi_stats[:, 0] += u.sum((1, 2)).double()
+            epi_stats[:, 1] += (u * u).sum((1, 2)).double()
+        if epi_flags & EPI_RESIDUAL:
+            y = torch.cat([y[:, :Mf] + epi_res.reshape(B, -1, ldt)[:, :Mf], y[:, Mf:]], 1)
+        if epi_flags & EPI_SIGMOID:
+            y = 1.0 / (1.0 + torch.exp(-y))
+        if epi_flags & EPI_PRELU_BWD:
+            s = epi_aux.reshape(B, M, ldt)
+            epi_dalpha += torch.where(valid & (s <= 0), y * s, torch.zeros_like(y)).sum().double()
+            y = y * _prelu_grad(s, epi_alpha)
+        if epi_flags & EPI_ROWSUMS:
+            u = epi_aux.reshape(B, M, ldt)
+            if epi_flags & EPI_ROWSUMS_PRELU:
+                u = _prelu(u, epi_alpha)
+            yv = torch.where(valid, y, torch.zeros_like(y))
+            rp = epi_rowpart.reshape(B, M, ldt // 64, 2)
+            rp[..., 0] = yv.reshape(B, M, ldt // 64, 64).sum(-1)
+            rp[..., 1] = (yv * u).reshape(B, M, ldt // 64, 64).sum(-1)
+        y = torch.where(valid, y, torch.zeros_like(y))
+        if m_split:
+            Y.reshape(B, Mf, ldt).copy_(y[:, :Mf])
+            y2 = Y2.reshape(B, M - Mf, ldt)
+            y2.copy_(y2 + y[:, Mf:] if accumulate else y[:, Mf:])
+        else:
+            yv = Y.reshape(B, M, ldt)
+            yv.copy_(yv + y if accumulate else y)
+
+    def pw_wgrad(self, *, B, M, N, T, ldt, G, X, partial, nsplit, G2=None, g_split=0, Gaux=None, g_mul=0, g_div=1,
+                 x_mode=PRO_NONE, x_div=1, eps=1e-12, count=0.0, x_alpha=None, x_stats=None, x_gamma=None, x_beta=None,
+                 partial_bias=None):
+        dt = G.dtype
+        m1 = g_split if g_split else M
+        Gf = G.reshape(B, m1, ldt)
+        if g_split:
+            Gf = torch.cat([Gf, G2.reshape(B, M - m1, ldt)], 1)
+        if g_mul:
+            Gf = Gf * Gaux.reshape(B // g_div, M, ldt).repeat_interleave(g_div, 0)
+        Xf = X.reshape(B // x_div, N, ldt).repeat_interleave(x_div, 0)
+        if x_mode == PRO_PRELU:
+            Xp = _prelu(Xf, x_alpha)
+        elif x_mode in (PRO_GLN, PRO_GLN_PRELU):
+            mu, rstd = _mu_rstd(x_stats, count, eps, dt)
+            mu, rstd = mu.repeat_interleave(x_div, 0), rstd.repeat_interleave(x_div, 0)
+            u = _prelu(Xf, x_alpha) if x_mode == PRO_GLN_PRELU else Xf
+            sc = x_gamma.view(1, N, 1) * rstd
+            Xp = u * sc + (x_beta.view(1, N, 1) - mu * sc)
+        else:
+            Xp = Xf
+        partial.zero_()
+        partial.reshape(nsplit, M, N)[0] = torch.einsum("bmt,bnt->mn", Gf, Xp)
+        if partial_bias is not None:
+            partial_bias.zero_()
+            partial_bias.reshape(nsplit, M)[0] = Gf.sum((0, 2))
+
+    def reduce_slabs(self, segs):
+        for (src, off, dst, n, nslab, stride, acc, scale) in segs:
+            flat = src.reshape(-1)
+            tot = torch.zeros(n, dtype=src.dtype)
+            for s in range(nslab):
+                tot += flat[off + s * stride: off + s * stride + n]
+            tot = tot * scale
+            d = dst.reshape(-1)
+            d.copy_(d + tot if acc else tot)
+
+    def f64_to_f32(self, src, dst, n, accumulate=0):
+        d = dst.reshape(-1)
+        v = src.reshape(-1)[:n].to(dst.dtype)
+        d[:n] = d[:n] + v if accumulate else v
+
+    # ------------------------------------------------------------------ encoder / decoder
+    @staticmethod
+    def _xpad(x, pad_left, total):
+        Bp, C, Tin = x.shape
+        xp = torch.zeros(Bp, C, total, dtype=x.dtype)
+        xp[:, :, pad_left:pad_left + Tin] = x
+        return xp
+
+    def unfold(self, x, frames, Bp, C, Tin, L, S, F, ldt, pad_left):
+        xp = self._xpad(x.reshape(Bp, C, Tin), pad_left, S * (F - 1) + L + S)
+        idx = (torch.arange(F) * S).view(1, F) + torch.arange(L).view(L, 1)      # (L, F)
+        fr = xp[:, :, idx]                                                       # (Bp, C, L, F)
+        out = frames.reshape(Bp, C * L, ldt)
+        out.zero_()
+        out[:, :, :F] = fr.reshape(Bp, C * L, F)
+
+    def encoder_fwd(self, x, E, w, stats, B, Cin, Tin, N, L, S, F, ldt, pad_left, relu):
+        fr = torch.zeros(B, Cin * L, ldt, dtype=x.dtype)
+        self.unfold(x, fr, B, Cin, Tin, L, S, F, ldt, pad_left)
+        y = torch.einsum("nq,bqf->bnf", E.reshape(N, Cin * L), fr)
+        if relu:
+            y = y.clamp_min(0)
+        y[:, :, F:] = 0
+        w.reshape(B, N, ldt).copy_(y)
+        stats[:, 0] += y.sum((1, 2)).double()
+        stats[:, 1] += (y * y).sum((1, 2)).double()
+
+    def decoder_fwd(self, w, m, D, est, latent, B, n_src, N, Cout, L, S, F, ldt, Tout, pad_left):
+        wh = w.reshape(B, 1, N, ldt) * m.reshape(B, n_src, N, ldt)
+        wh[..., F:] = 0
+        if latent is not None:
+            latent.reshape(B, n_src, N, ldt).copy_(wh)
+        fr = torch.einsum("bsnf,nck->bsckf", wh[..., :F], D.reshape(N, Cout, L))
+        total = S * (F - 1) + L
+        out = torch.zeros(B, n_src, Cout, total, dtype=w.dtype)
+        idx = ((torch.arange(F) * S).view(1, F) + torch.arange(L).view(L, 1)).reshape(-1)
+        out.index_add_(3, idx, fr.reshape(B, n_src, Cout, L * F))
+        est.reshape(B, n_src, Cout, Tout).copy_(out[..., pad_left:pad_left + Tout])
+
+    def decoder_bwd(self, d_est, w, m, D, dpre, dwm, B, n_src, N, Cout, L, S, F, ldt, Tout, pad_left):
+        fr = torch.zeros(B * n_src, Cout * L, ldt, dtype=w.dtype)
+        self.unfold(d_est.reshape(B * n_src, Cout, Tout), fr, B * n_src, Cout, Tout, L, S, F, ldt, pad_left)
+        dl = torch.einsum("nq,bqf->bnf", D.reshape(N, Cout * L), fr).reshape(B, n_src, N, ldt)
+        mv = m.reshape(B, n_src, N, ldt)
+        wv = w.reshape(B, 1, N, ldt)
+        dp = dl * wv * mv * (1 - mv)
+        dp[..., F:] = 0
+        dpre.reshape(B, n_src, N, ldt).copy_(dp)
+        dw = (dl * mv).sum(1)
+        dw[..., F:] = 0
+        dwm.reshape(B, N, ldt).copy_(dw)
+
+    # ------------------------------------------------------------------ depthwise
+    def dwconv_fwd(self, a, stats1, gamma1, beta1, alpha1, wd, bd, alpha2, z, stats2, B, C, T, ldt, dilation, eps):
+        dt = a.dtype
+        mu, rstd = _mu_rstd(stats1, float(C * T), eps, dt)
+        sc = gamma1.view(1, C, 1) * rstd
+        v = _prelu(a.reshape(B, C, ldt), alpha1) * sc + (beta1.view(1, C, 1) - mu * sc)
+        d = dilation
+        vp = torch.zeros(B, C, T + 2 * d, dtype=dt)
+        vp[:, :, d:d + T] = v[:, :, :T]
+        wk = wd.reshape(C, 3)
+        zz = bd.view(1, C, 1) + wk[:, 0].view(1, C, 1) * vp[:, :, 0:T] + wk[:, 1].view(1, C, 1) * vp[:, :, d:d + T] \
+            + wk[:, 2].view(1, C, 1) * vp[:, :, 2 * d:2 * d + T]
+        out = z.reshape(B, C, ldt)
+        out.zero_()
+        out[:, :, :T] = zz
+        u = _prelu(zz, alpha2)
+        stats2[:, 0] += u.sum((1, 2)).double()
+        stats2[:, 1] += (u * u).sum((1, 2)).double()
+
+    def dwconv_bwd(self, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bsum2, wd, dv1, rowpart, B, C, T,
+                   ldt, dilation, eps):
+        dt = a.dtype
+        d = dilation
+        cnt = float(C * T)
+        mu1, r1 = _mu_rstd(stats1, cnt, eps, dt)
+        mu2, r2 = _mu_rstd(stats2, cnt, eps, dt)
+        zz = z.reshape(B, C, ldt)[:, :, :T]
+        aa = a.reshape(B, C, ldt)[:, :, :T]
+        g = dv2.reshape(B, C, ldt)[:, :, :T]
+        u2 = _prelu(zz, alpha2)
+        xh = (u2 - mu2) * r2
+        du2 = r2 * (gamma2.view(1, C, 1) * g - bsum2[:, 0].view(B, 1, 1) - xh * bsum2[:, 1].view(B, 1, 1))
+        dz = du2 * _prelu_grad(zz, alpha2)
+        dal = torch.where(zz <= 0, du2 * zz, torch.zeros_like(zz)).sum(2)
+        u1 = _prelu(aa, alpha1)
+        sc1 = gamma1.view(1, C, 1) * r1
+        v1 = u1 * sc1 + (beta1.view(1, C, 1) - mu1 * sc1)
+        dzp = torch.zeros(B, C, T + 2 * d, dtype=dt)
+        dzp[:, :, d:d + T] = dz
+        v1p = torch.zeros(B, C, T + 2 * d, dtype=dt)
+        v1p[:, :, d:d + T] = v1
+        wk = wd.reshape(C, 3)
+        # dv1[t] = w0 dz[t+d] + w1 dz[t] + w2 dz[t-d]
+        dv = wk[:, 0].view(1, C, 1) * dzp[:, :, 2 * d:2 * d + T] + wk[:, 1].view(1, C, 1) * dz + wk[:, 2].view(1, C, 1) * dzp[:, :, 0:T]
+        out = dv1.reshape(B, C, ldt)
+        out.zero_()
+        out[:, :, :T] = dv
+        ntile = (ldt + 1023) // 1024
+        rp = rowpart.reshape(B, C, ntile, 8)
+        rp.zero_()
+        rp[:, :, 0, 0] = dv.sum(2)
+        rp[:, :, 0, 1] = (dv * u1).sum(2)
+        rp[:, :, 0, 2] = dz.sum(2)
+        rp[:, :, 0, 3] = (dz * v1p[:, :, 0:T]).sum(2)
+        rp[:, :, 0, 4] = (dz * v1).sum(2)
+        rp[:, :, 0, 5] = (dz * v1p[:, :, 2 * d:2 * d + T]).sum(2)
+        rp[:, :, 0, 6] = dal
+
+    def gln_bwd_finalize(self, rowpart, ntile, nq, stats, gamma, count, eps, bsum, pbeta, pgamma, pextra, B, C):
+        dt = rowpart.dtype
+        rp = rowpart.reshape(B, C, ntile, nq).sum(2)
+        mu, rstd = _mu_rstd(stats, count, eps, dt)
+        R1, R2 = rp[..., 0], rp[..., 1]
+        pg = rstd.view(B, 1) * (R2 - mu.view(B, 1) * R1)
+        pbeta.reshape(B, C).copy_(R1)
+        pgamma.reshape(B, C).copy_(pg)
+        bsum.reshape(B, 2)[:, 0] = (gamma.view(1, C) * R1).sum(1) / count
+        bsum.reshape(B, 2)[:, 1] = (gamma.view(1, C) * pg).sum(1) / count
+        if nq == 8:
+            pe = pextra.reshape(-1)
+            slab = pe[:B * 4 * C].reshape(B, 4 * C)
+            slab[:, :C] = rp[..., 2]
+            slab[:, C:] = rp[..., 3:6].reshape(B, 3 * C)
+            pe[B * 4 * C:B * 4 * C + B] = rp[..., 6].sum(1)
+
+    def head_bwd(self, dvw, w, dwm, stats0, gamma0, bsum0, B, C, T, ldt, count, eps, relu):
+        dt = w.dtype
+        mu, rstd = _mu_rstd(stats0, count, eps, dt)
+        g = dvw.reshape(B, C, ldt)
+        wv = w.reshape(B, C, ldt)
+        xh = (wv - mu) * rstd
+        v = rstd * (gamma0.view(1, C, 1) * g - bsum0[:, 0].view(B, 1, 1) - xh * bsum0[:, 1].view(B, 1, 1)) + dwm.reshape(B, C, ldt)
+        if relu:
+            v = torch.where(wv > 0, v, torch.zeros_like(v))
+        v[:, :, T:] = 0
+        g.copy_(v)
+
+    # ------------------------------------------------------------------ stand-alone gLN
+    def gln_stats(self, x, stats, B, C, T, ldt):
+        v = x.reshape(B, C, ldt)[:, :, :T]
+        stats[:, 0] += v.sum((1, 2)).double()
+        stats[:, 1] += (v * v).sum((1, 2)).double()
+
+    def gln_apply(self, x, stats, gamma, beta, y, B, C, T, ldt, count, eps):
+        mu, rstd = _mu_rstd(stats, count, eps, x.dtype)
+        sc = gamma.view(1, C, 1) * rstd
+        v = x.reshape(B, C, ldt) * sc + (beta.view(1, C, 1) - mu * sc)
+        v[:, :, T:] = 0
+        y.reshape(B, C, ldt).copy_(v)
+
+    def gln_bwd_rowsums(self, dy, x, rowpart, B, C, T, ldt):
+        ntile = (ldt + 1023) // 1024
+        rp = rowpart.reshape(B, C, ntile, 2)
+        rp.zero_()
+        g = dy.reshape(B, C, ldt)[:, :, :T]
+        rp[:, :, 0, 0] = g.sum(2)
+        rp[:, :, 0, 1] = (g * x.reshape(B, C, ldt)[:, :, :T]).sum(2)
+
+    def gln_bwd_apply(self, dy, x, stats, gamma, bsum, dx, B, C, T, ldt, count, eps):
+        mu, rstd = _mu_rstd(stats, count, eps, x.dtype)
+        xh = (x.reshape(B, C, ldt) - mu) * rstd
+        v = rstd * (gamma.view(1, C, 1) * dy.reshape(B, C, ldt) - bsum[:, 0].view(B, 1, 1) - xh * bsum[:, 1].view(B, 1, 1))
+        v[:, :, T:] = 0
+        dx.reshape(B, C, ldt).copy_(v)
+
+    def repack(self, src, ld_src, dst, ld_dst, rows, T):
+        d = dst.reshape(rows, ld_dst)
+        d.zero_()
+        d[:, :T] = src.reshape(rows, ld_src)[:, :T]
+
+    # ------------------------------------------------------------------ losses
+    def sisdr_dots(self, est, tgt, dots, tt, xx, B, n, T, all_pairs):
+        e, t = est.reshape(B, n, T).double(), tgt.reshape(B, n, T).double()
+        full = torch.einsum("bit,bjt->bij", e, t)
+        if not all_pairs:
+            full = torch.diag_embed(torch.diagonal(full, dim1=1, dim2=2))
+        dots.reshape(B, n, n).add_(full)
+        tt.reshape(B, n).add_((t * t).sum(2))
+        xx.reshape(B, n).add_((e * e).sum(2))
+
+    @staticmethod
+    def _terms(a, ttv, xxv, eps):
+        c = ttv + eps
+        alpha = a / c
+        S = alpha * alpha * ttv + eps
+        Nn = (alpha * alpha * ttv - 2 * alpha * a + xxv).clamp_min(0) + eps
+        return alpha, c, S, Nn
+
+    def sisdr_from_dots(self, dots, tt, xx, out, B, n, all_pairs, eps):
+        a = dots.reshape(B, n, n)
+        alpha, c, S, Nn = self._terms(a, tt.reshape(B, 1, n), xx.reshape(B, n, 1), eps)
+        v = 10.0 * torch.log10(S / Nn)
+        if not all_pairs:
+            v = torch.diag_embed(torch.diagonal(v, dim1=1, dim2=2))
+        out.reshape(B, n, n).copy_(v.to(out.dtype))
+
+    def sisdr_bwd(self, est, tgt, dots, tt, xx, gw, d_est, B, n, T, all_pairs, eps):
+        a = dots.reshape(B, n, n)
+        ttv, xxv = tt.reshape(B, 1, n), xx.reshape(B, n, 1)
+        alpha, c, S, Nn = self._terms(a, ttv, xxv, eps)
+        Kc = 10.0 / math.log(10.0)
+        ct = Kc * (2 * alpha * ttv / (c * S) - ((2 * alpha * ttv - 2 * a) / c - 2 * alpha) / Nn)
+        ce = Kc * (-2.0 / Nn)
+        g = gw.reshape(B, n, n).double()
+        if not all_pairs:
+            g = torch.diag_embed(torch.diagonal(g, dim1=1, dim2=2))
+        cT = g * ct
+        cE = (g * ce).sum(2)
+        out = torch.einsum("bij,bjt->bit", cT, tgt.reshape(B, n, T).double()) + cE.view(B, n, 1) * est.reshape(B, n, T).double()
+        d_est.reshape(B, n, T).copy_(out.to(d_est.dtype))
+
+    def pit_search(self, val, perms, P, n, B, maximize, use_mean, best_val, best_idx):
+        v = val.reshape(B, n, n)
+        sc = torch.stack([sum(v[:, k, int(perms[p, k])] for k in range(n)) for p in range(P)], 1)
+        if use_mean:
+            sc = sc / n
+        bv, bi = (sc.max(1) if maximize else sc.min(1))
+        best_val.copy_(bv)
+        best_idx.copy_(bi)
+
+    def sinkhorn_fwd(self, C, zwork, loss, P, B, n, coldness, iters):
+        Cd = C.reshape(B, n, n).double()
+        Z = -coldness * Cd
+        zw = zwork.reshape(B, 2 * iters + 1, n, n)
+        zw[:, 0] = Z
+        for h in range(1, 2 * iters + 1):
+            Z = Z - torch.logsumexp(Z, dim=1 if (h & 1) else 2, keepdim=True)
+            zw[:, h] = Z
+        Pm = torch.exp(Z)
+        P.reshape(B, n, n).copy_(Pm.to(P.dtype))
+        loss.copy_(((Cd + Z / coldness) * Pm).sum((1, 2)).to(loss.dtype))
+
+    def sinkhorn_bwd(self, C, zwork, dloss, dC, B, n, coldness, iters):
+        Cd = C.reshape(B, n, n).double()
+        zw = zwork.reshape(B, 2 * iters + 1, n, n)
+        Zf = zw[:, 2 * iters]
+        g = dloss.reshape(B, 1, 1).double()
+        Pm = torch.exp(Zf)
+        dZ = g * Pm * (1.0 / coldness + Cd + Zf / coldness)
+        for h in range(2 * iters, 0, -1):
+            dim = 1 if (h & 1) else 2
+            dZ = dZ - torch.exp(zw[:, h]) * dZ.sum(dim, keepdim=True)
+        dC.reshape(B, n, n).copy_((g * Pm - coldness * dZ).to(dC.dtype))
+
+    # ------------------------------------------------------------------ optimiser
+    def sqnorm(self, g, out, n):
+        out += (g.reshape(-1)[:n].double() ** 2).sum()
+
+    def adam_step(self, p, g, m, v, sqnorm, n, lr, beta1, beta2, eps, weight_decay, max_norm, grad_scale, step):
+        coef = grad_scale
+        if max_norm > 0:
+            total = grad_scale * float(torch.sqrt(sqnorm.reshape(-1)[0]))
+            coef *= min(1.0, max_norm / (total + 1e-6))
+        g.mul_(coef)
+        gi = g + weight_decay * p if weight_decay != 0 else g
+        m.mul_(beta1).add_(gi, alpha=1 - beta1)
+        v.mul_(beta2).addcmul_(gi, gi, value=1 - beta2)
+        bc1 = 1 - beta1 ** step
+        bc2s = math.sqrt(1 - beta2 ** step)
+        p.sub_((lr / bc1) * (m / (v.sqrt() / bc2s + eps)))
