@@ -1,0 +1,197 @@
+"""
+bench.py -- separated audio frames/sec (fwd + SI-SDR/PIT + bwd [+ all-reduce] + clip + Adam) of Conv-TasNet paper-best
+(N512 L16 B128 H512 Sc128 P3 X8 R3, 2 speakers) on synthetic 4 s @ 8 kHz mixtures, 16 utterances per GPU.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One JSON line on rank 0.  A "step" is one pass of the hot path over one batch resident in HBM.  `roofline` is for the
+dominant kernel (the fp32-MFMA pointwise GEMM `pw_gemm_kernel`): its launches are bracketed with HIP events on the
+launch stream during the timed steps; achieved = algorithmic FLOPs of those launches / their summed duration.
+`cpu_baseline` is the oracle's functional port (oracle/fast_port.py, same ATen CPU kernels as the reference) timed
+on this box's host cores on a bounded sample (N=1 runs only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "dnn-based_source_separation_amd", "src")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PAPER = dict(n_basis=512, kernel_size=16, stride=8, enc_basis="trainable", dec_basis="trainable", enc_nonlinear=None,
+             sep_hidden_channels=512, sep_bottleneck_channels=128, sep_skip_channels=128, sep_kernel_size=3,
+             sep_num_blocks=3, sep_num_layers=8, dilated=True, separable=True, causal=False, sep_nonlinear="prelu",
+             sep_norm=True, mask_nonlinear="sigmoid", n_sources=2)
+T_SAMPLES = 32000            # 4 s @ 8 kHz
+PER_GPU_BATCH = 16
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_TBS = 8.0
+
+
+class TimedBackend:
+    """Wraps the kernel facade: brackets every launch of the two MFMA kernels with HIP events (recorded on the
+    current stream = the launch stream) and tallies their algorithmic FLOPs."""
+
+    def __init__(self, inner):
+        self._inner = inner
+        self.enabled = False
+        self.records = {"pw_gemm": [], "pw_wgrad": []}
+        self.name = inner.name
+
+    def __getattr__(self, item):
+        return getattr(self._inner, item)
+
+    def _timed(self, key, flops, fn, kw):
+        if not self.enabled:
+            return fn(**kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn(**kw)
+        e1.record()
+        self.records[key].append((e0, e1, flops))
+
+    def pw_gemm(self, **kw):
+        self._timed("pw_gemm", 2.0 * kw["M"] * kw["K"] * kw["B"] * kw["T"], self._inner.pw_gemm, kw)
+
+    def pw_wgrad(self, **kw):
+        self._timed("pw_wgrad", 2.0 * kw["M"] * kw["N"] * kw["B"] * kw["T"], self._inner.pw_wgrad, kw)
+
+    def summary(self, key):
+        ms = sum(a.elapsed_time(b) for a, b, _ in self.records[key])
+        fl = sum(f for _, _, f in self.records[key])
+        return len(self.records[key]), ms, fl
+
+
+def cpu_baseline(sample_steps=2):
+    """Reference-equivalent CPU path (oracle/fast_port.py) on the host cores, bounded sample: B=2 utterances/step."""
+    from oracle import fast_port as FP
+    from oracle.convtasnet_oracle import num_frames
+    from models.conv_tasnet import ConvTasNet
+    torch.manual_seed(111)
+    model = ConvTasNet(**PAPER)
+    p = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    B = 2
+    g = torch.Generator().manual_seed(111)
+    sources = 0.1 * torch.randn(B, 2, T_SAMPLES, generator=g)
+    mixture = sources.sum(1, keepdim=True)
+    cores = torch.get_num_threads()
+    for _ in range(2):                      # oneDNN primitive caches / allocator warm-up
+        FP.train_step(p, PAPER, mixture, sources, dtype=torch.float32)
+    t0 = time.perf_counter()
+    for _ in range(sample_steps):
+        FP.train_step(p, PAPER, mixture, sources, dtype=torch.float32)
+    dt = (time.perf_counter() - t0) / sample_steps
+    frames = B * num_frames(T_SAMPLES, 16, 8)
+    return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "{} timed fwd+PIT+bwd steps (after 2 warm-up) of B={} paper-best utterances, fp32, torch CPU "
+                      "(oracle/fast_port.py: same ATen conv/GroupNorm kernels as the reference modules), {:.2f} s/step".format(
+                          sample_steps, B, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="utterances per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus {} but WORLD_SIZE {}".format(args.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import sepkernels
+    from sepkernels.train import FusedTrainStep
+    from models.conv_tasnet import ConvTasNet
+    from criterion.sdr import NegSISDR
+    from criterion.pit import PIT1d
+    from oracle.convtasnet_oracle import num_frames, flops_per_frame, bytes_per_frame
+
+    sepkernels.load()          # fail loudly if the HIP library is missing
+    timed = TimedBackend(sepkernels.backend())
+    sepkernels._backend = timed
+
+    torch.manual_seed(111)
+    model = ConvTasNet(**PAPER).to(dev)
+    crit = PIT1d(NegSISDR(), n_sources=2)
+    step = FusedTrainStep(model, crit, lr=1e-3, max_norm=5.0)   # recipe defaults: adam 1e-3, clip 5 (train.sh:50-57)
+    g = torch.Generator().manual_seed(111 + rank)
+    sources = (0.1 * torch.randn(args.batch, 2, T_SAMPLES, generator=g)).to(dev)
+    mixture = sources.sum(1, keepdim=True).contiguous()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step(mixture, sources)
+    sync()
+    timed.enabled = not args.no_kernel_timing
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(mixture, sources)
+    sync()
+    elapsed = time.perf_counter() - t0
+    timed.enabled = False
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+
+    F = num_frames(T_SAMPLES, PAPER["kernel_size"], PAPER["stride"])
+    frames_per_step = world * args.batch * F
+    value = frames_per_step * args.steps / elapsed
+    fl_frame, by_frame = 3 * flops_per_frame(PAPER), 3 * bytes_per_frame(PAPER)
+
+    if rank == 0:
+        out = {
+            "metric": "separated audio frames/sec (fwd+bwd), Conv-TasNet 2-spk 4s@8kHz", "value": value, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Conv-TasNet paper-best (N=512,L=16,B=128,H=512,Sc=128,P=3,X=8,R=3) 2-spk, 4 s @ 8 kHz "
+                                   "synthetic mixtures, {} utterances/GPU, fwd + PIT(NegSI-SDR) + bwd + clip(5) + Adam".format(args.batch),
+                       "global_batch": world * args.batch, "frames_per_utterance": F, "parallelism": "dp{}".format(world),
+                       "utt_per_s": value / F, "samples_per_s": value / F * T_SAMPLES, "final_loss": float(loss)},
+            "step_roofline": {"mfma_frac": value / world * fl_frame / (FP32_MFMA_PEAK_TFLOPS * 1e12),
+                              "hbm_frac": value / world * by_frame / (HBM_PEAK_TBS * 1e12),
+                              "algorithmic_flop_per_frame": fl_frame, "algorithmic_bytes_per_frame": by_frame},
+        }
+        if not args.no_kernel_timing:
+            n, ms, fl = timed.summary("pw_gemm")
+            nw, msw, flw = timed.summary("pw_wgrad")
+            ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            out["roofline"] = {"bound": "mfma", "kernel": "pw_gemm_kernel", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "launches_per_step": n / args.steps, "avg_launch_ms": ms / max(n, 1),
+                               "flop_per_launch_avg": fl / max(n, 1), "share_of_step": ms / (1e3 * elapsed)}
+            achw = flw / (msw * 1e-3) / 1e12 if msw > 0 else 0.0
+            out["roofline_wgrad"] = {"bound": "mfma", "kernel": "pw_wgrad_kernel", "achieved": achw, "peak": FP32_MFMA_PEAK_TFLOPS,
+                                     "unit": "TFLOP/s", "frac": achw / FP32_MFMA_PEAK_TFLOPS, "launches_per_step": nw / args.steps,
+                                     "avg_launch_ms": msw / max(nw, 1), "share_of_step": msw / (1e3 * elapsed)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

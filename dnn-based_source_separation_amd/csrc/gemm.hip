@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const sep_gemm_desc d) {
                         const float u = prelu_f(v, alpha_e);
                         if (valid) { st_s += u; st_ss += u * u; }
                     }
-                    if ((ef & SEP_EPI_RESIDUAL) && !second) v += d.epi_res[abase + t];
+                    if ((ef & SEP_EPI_RESIDUAL) && !second) v += d.epi_res[((size_t)b * Mfirst + row) * d.ldt + t];   // residual has the Y-part's row count
                     if (ef & SEP_EPI_SIGMOID) v = 1.f / (1.f + expf(-v));
                     if (ef & SEP_EPI_PRELU_BWD) {
                         const float s = d.epi_aux[abase + t];

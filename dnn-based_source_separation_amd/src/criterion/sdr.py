@@ -1,0 +1,114 @@
+"""
+Scale-invariant SDR on MI355X.  API of reference src/criterion/sdr.py:122-231 (`sisdr`, `SISDR`, `NegSISDR`
+with `reduction`, `eps`, `forward(input, target, batch_mean=True)`, `.maximize`).
+
+The O(T) work is two kernels of libsepkernels: sep_sisdr_dots (the three dot products per pair, fp64
+accumulation) and sep_sisdr_bwd (analytic gradient applied elementwise); the value itself is formed from the
+dot products exactly as the reference formula states (eps placement included).
+"""
+import torch
+import torch.nn as nn
+
+import sepkernels
+
+EPS = 1e-12
+
+
+class _SISDRPairsFn(torch.autograd.Function):
+    """est, tgt (B, n, T) -> sisdr (B, n, n): entry [b, i, j] = SI-SDR(est_i, tgt_j); only the diagonal is computed
+    (others 0) when all_pairs is False."""
+
+    @staticmethod
+    def forward(ctx, est, tgt, all_pairs, eps):
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError("gradient w.r.t. the SI-SDR target is not implemented")
+        K = sepkernels.backend()
+        est, tgt = est.contiguous(), tgt.contiguous()
+        B, n, T = est.shape
+        dev = est.device
+        dots = torch.zeros(B, n, n, device=dev, dtype=torch.float64)
+        tt = torch.zeros(B, n, device=dev, dtype=torch.float64)
+        xx = torch.zeros(B, n, device=dev, dtype=torch.float64)
+        K.sisdr_dots(est, tgt, dots, tt, xx, B, n, T, all_pairs)
+        out = torch.empty(B, n, n, device=dev, dtype=est.dtype)
+        K.sisdr_from_dots(dots, tt, xx, out, B, n, all_pairs, eps)
+        ctx.save_for_backward(est, tgt, dots, tt, xx)
+        ctx.meta = (all_pairs, eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        K = sepkernels.backend()
+        est, tgt, dots, tt, xx = ctx.saved_tensors
+        all_pairs, eps = ctx.meta
+        B, n, T = est.shape
+        d_est = torch.empty_like(est)
+        K.sisdr_bwd(est, tgt, dots, tt, xx, gout.contiguous().to(est.dtype), d_est, B, n, T, all_pairs, eps)
+        return d_est, None, None, None
+
+
+def _prep(input, target):
+    if input.dtype != torch.float32 and sepkernels.backend().name == "hip":
+        input = input.float()
+    return input, target.to(input.dtype)
+
+
+def sisdr_pairs(input, target, eps=EPS):
+    """(B, n, T) x (B, n, T) -> (B, n, n) matrix of SI-SDR(input_i, target_j)."""
+    input, target = _prep(input, target)
+    return _SISDRPairsFn.apply(input, target, True, eps)
+
+
+def sisdr(input, target, eps=EPS):
+    """
+    Args:
+        input, target: (batch_size, T) or (batch_size, n_sources, T) or (batch_size, n_sources, n_mics, T)
+    Returns:
+        SI-SDR over the last axis, shape input.shape[:-1]
+    """
+    n_dims = input.dim()
+    assert n_dims in [2, 3, 4], "Only 2D or 3D or 4D tensor is acceptable, but given {}D tensor.".format(n_dims)
+    input, target = _prep(input, target)
+    lead, T = input.shape[:-1], input.shape[-1]
+    rows = input.numel() // T
+    out = _SISDRPairsFn.apply(input.reshape(rows, 1, T), target.reshape(rows, 1, T), False, eps)
+    return out.view(lead)
+
+
+class _SISDRBase(nn.Module):
+    _sign = 1.0
+
+    def __init__(self, reduction="mean", eps=EPS):
+        super().__init__()
+        if reduction not in ["mean", "sum", None]:
+            raise ValueError("Invalid reduction type")
+        self.reduction = reduction
+        self.eps = eps
+
+    def forward(self, input, target, batch_mean=True):
+        n_dims = input.dim()
+        assert n_dims in [2, 3, 4], "Only 2D or 3D or 4D tensor is acceptable, but given {}D tensor.".format(n_dims)
+        loss = self._sign * sisdr(input, target, eps=self.eps)
+        if self.reduction:
+            dims = {3: 1, 4: (1, 2)}.get(n_dims)
+            if dims is not None:
+                loss = loss.mean(dim=dims) if self.reduction == "mean" else loss.sum(dim=dims)
+        if batch_mean:
+            loss = loss.mean(dim=0)
+        return loss
+
+
+class SISDR(_SISDRBase):
+    _sign = 1.0
+
+    @property
+    def maximize(self):
+        return True
+
+
+class NegSISDR(_SISDRBase):
+    _sign = -1.0
+
+    @property
+    def maximize(self):
+        return False

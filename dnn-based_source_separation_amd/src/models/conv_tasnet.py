@@ -1,0 +1,355 @@
+"""
+Conv-TasNet on MI355X.
+
+Drop-in for reference src/models/conv_tasnet.py:16-378: same constructor keywords, `forward` /
+`extract_latent` / `get_config` / `get_package` / `build_model` / `build_from_pretrained` / `num_parameters`,
+same module tree and state_dict keys, same exception types for bad configurations.
+The arithmetic of the whole network is the fused kernel sequence of sepkernels/net.py behind one
+torch.autograd.Function; parameters live as views of one flat fp32 buffer laid out so that the output- and
+skip-head weights of every TCN layer are adjacent ([Wo;Ws] is then a single GEMM operand) and so that the
+data-parallel gradient all-reduce is a single RCCL call on one buffer.
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from utils.filterbank import choose_filterbank
+from utils.tasnet import choose_layer_norm
+from models.tdcn import TimeDilatedConvNet
+from sepkernels import net as _net
+
+SAMPLE_RATE_MUSDB18 = 44100
+SAMPLE_RATE_LIBRISPEECH = 16000
+EPS = 1e-12
+
+
+class _FusedConvTasNetFn(torch.autograd.Function):
+    """forward(mixture, cfg, names, want_latent, *params) -> est[, latent]; backward runs the hand-written
+    backward kernel sequence and returns one gradient per parameter (views of a single flat buffer)."""
+
+    @staticmethod
+    def forward(ctx, mixture, cfg, names, want_latent, grad_sink, *params):
+        ctx.set_materialize_grads(False)
+        ctx.grad_sink = grad_sink
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("gradient w.r.t. the input mixture is not implemented on the fused path")
+        need_bwd = any(ctx.needs_input_grad[5:])
+        P = dict(zip(names, params))
+        est, latent, sv = _net.forward(cfg, P, mixture, want_latent=want_latent, save=need_bwd)
+        ctx.cfg, ctx.names, ctx.sv = cfg, names, sv
+        ctx.save_for_backward(*params)
+        if want_latent:
+            ctx.mark_non_differentiable(latent)
+            return est, latent
+        return est
+
+    @staticmethod
+    def backward(ctx, d_est, *unused):
+        params = ctx.saved_tensors
+        names = ctx.names
+        if d_est is None:
+            return (None, None, None, None, None) + tuple(None for _ in params)
+        # one flat gradient buffer with the same packing as ConvTasNet._flatten_parameters
+        offs, total = _layout([(n, p.numel()) for n, p in zip(names, params)])
+        flat = ctx.grad_sink
+        if flat is None or flat.numel() != total:
+            flat = torch.empty(total, device=d_est.device, dtype=d_est.dtype)
+        G = {n: flat[offs[n]:offs[n] + p.numel()].view(p.shape) for n, p in zip(names, params)}
+        _net.backward(ctx.cfg, dict(zip(names, params)), ctx.sv, d_est, G)
+        ctx.sv = None
+        grads = tuple(G[n] for n in names)
+        G = None
+        return (None, None, None, None, None) + grads
+
+
+def _layout(named_sizes):
+    """Offsets (in floats) of every parameter inside the flat buffer.  Every tensor starts 16-byte aligned; for each
+    TCN layer the pair (output_pointwise.weight, skip_pointwise.weight) and the pair of their biases are adjacent."""
+    sizes = dict(named_sizes)
+    order, seen = [], set()
+    for n, _ in named_sizes:
+        if n in seen:
+            continue
+        if n.endswith("output_pointwise_conv1d.weight"):
+            base = n[:-len("output_pointwise_conv1d.weight")]
+            group = [base + "output_pointwise_conv1d.weight", base + "skip_pointwise_conv1d.weight",
+                     base + "output_pointwise_conv1d.bias", base + "skip_pointwise_conv1d.bias"]
+            group = [g for g in group if g in sizes]
+        else:
+            group = [n]
+        for g in group:
+            if g not in seen:
+                order.append(g)
+                seen.add(g)
+    offs, cur = {}, 0
+    for n in order:
+        cur = (cur + 3) // 4 * 4
+        offs[n] = cur
+        cur += sizes[n]
+    return offs, (cur + 3) // 4 * 4
+
+
+class ConvTasNet(nn.Module):
+    pretrained_model_ids = {
+        "wsj0-mix": {8000: {2: {"enc_relu": "1yy-o7TyS1EcBWZ41rskMAVavtuEi4fMe"}, 3: {"enc_relu": "1-4Abl7LnEtwqMnAFQOcNLUOaDbgp3NoG"}},
+                     16000: {2: "", 3: ""}},
+        "wham/enhance-single": {8000: "1-6oiSK_CEE5Vl4OCy8TinA0cKsFFfGUg", 16000: ""},
+        "wham/enhance-both": {8000: "1-GISUVcWjMeP3GLvojz9b0svw6gkmd2G", 16000: ""},
+        "wham/separate-noisy": {8000: "1-0ckoPjaIiTJwv9Qotz6fkY2xeC77xdi", 16000: ""},
+        "musdb18": {SAMPLE_RATE_MUSDB18: {"4sec_L20": "1A6dIofHZJQCUkyq-vxZ6KbPmEHLcf4WK", "8sec_L20": "1C4uv2z0w1s4rudIMaErLyEccNprJQWSZ",
+                                          "8sec_L64": "1paXNGgH8m0kiJTQnn1WH-jEIurCKXwtw"}},
+        "librispeech": {SAMPLE_RATE_LIBRISPEECH: {2: "1NI6Q_WZHiTKkgkNTEcZE1yHskHgYUHpy"}},
+    }
+
+    def __init__(self, n_basis, kernel_size, stride=None, enc_basis=None, dec_basis=None,
+                 sep_hidden_channels=256, sep_bottleneck_channels=128, sep_skip_channels=128, sep_kernel_size=3,
+                 sep_num_blocks=3, sep_num_layers=8, dilated=True, separable=True, sep_nonlinear="prelu", sep_norm=True,
+                 mask_nonlinear="sigmoid", causal=True, n_sources=2, eps=EPS, **kwargs):
+        super().__init__()
+        if stride is None:
+            stride = kernel_size // 2
+        assert kernel_size % stride == 0, "kernel_size is expected divisible by stride"
+
+        self.in_channels = kwargs.get("in_channels", 1)
+        self.n_basis = n_basis
+        self.kernel_size, self.stride = kernel_size, stride
+        self.enc_basis, self.dec_basis = enc_basis, dec_basis
+        if enc_basis == "trainable" and not dec_basis == "pinv":
+            self.enc_nonlinear = kwargs["enc_nonlinear"]
+        else:
+            self.enc_nonlinear = None
+        if enc_basis in ["Fourier", "trainableFourier", "trainableFourierTrainablePhase"] or \
+                dec_basis in ["Fourier", "trainableFourier", "trainableFourierTrainablePhase"]:
+            self.window_fn = kwargs["window_fn"]
+            self.enc_onesided, self.enc_return_complex = kwargs["enc_onesided"], kwargs["enc_return_complex"]
+        else:
+            self.window_fn = None
+            self.enc_onesided, self.enc_return_complex = None, None
+
+        self.sep_hidden_channels, self.sep_bottleneck_channels, self.sep_skip_channels = \
+            sep_hidden_channels, sep_bottleneck_channels, sep_skip_channels
+        self.sep_kernel_size = sep_kernel_size
+        self.sep_num_blocks, self.sep_num_layers = sep_num_blocks, sep_num_layers
+        self.dilated, self.separable, self.causal = dilated, separable, causal
+        self.sep_nonlinear, self.sep_norm = sep_nonlinear, sep_norm
+        self.mask_nonlinear = mask_nonlinear
+        self.n_sources = n_sources
+        self.eps = eps
+
+        # same construction order as the reference -> identical RNG consumption -> identical default weights per seed
+        encoder, decoder = choose_filterbank(n_basis, kernel_size=kernel_size, stride=stride, enc_basis=enc_basis,
+                                             dec_basis=dec_basis, **kwargs)
+        self.encoder = encoder
+        self.separator = Separator(n_basis, bottleneck_channels=sep_bottleneck_channels, hidden_channels=sep_hidden_channels,
+                                   skip_channels=sep_skip_channels, kernel_size=sep_kernel_size, num_blocks=sep_num_blocks,
+                                   num_layers=sep_num_layers, dilated=dilated, separable=separable, causal=causal,
+                                   nonlinear=sep_nonlinear, norm=sep_norm, mask_nonlinear=mask_nonlinear, n_sources=n_sources, eps=eps)
+        self.decoder = decoder
+
+        self._flat = None
+        self._names = None
+        self._grad_sink = None      # optional flat buffer the backward pass writes into (sepkernels.train.FusedTrainStep)
+        self._flatten_parameters()
+
+    # ------------------------------------------------------------------ parameter storage
+    def _flatten_parameters(self):
+        """Re-home every parameter as a view of one flat buffer (see _layout).  Idempotent; called after
+        construction and after every .to()/.cuda()/.float() (nn.Module._apply)."""
+        named = [(n, p) for n, p in self.named_parameters()]
+        if not named:
+            return
+        dev, dt = named[0][1].device, named[0][1].dtype
+        if any(p.device != dev or p.dtype != dt for _, p in named):
+            self._flat = None
+            return
+        offs, total = _layout([(n, p.numel()) for n, p in named])
+        flat = torch.zeros(total, device=dev, dtype=dt)
+        with torch.no_grad():
+            for n, p in named:
+                v = flat[offs[n]:offs[n] + p.numel()].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+        self._flat = flat
+        self._names = [n for n, _ in named]
+        self._offsets = offs
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._flatten_parameters()
+        return out
+
+    def flat_parameters(self):
+        """The flat fp32 buffer all parameters are views of (None if they are not co-located)."""
+        if self._flat is None:
+            return None
+        for n, p in self.named_parameters():   # cheap sanity: views still intact?
+            if p.data_ptr() != self._flat.data_ptr() + 4 * self._offsets[n]:
+                self._flatten_parameters()
+                break
+        return self._flat
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, input):
+        output, _ = self._run(input, want_latent=False)
+        return output
+
+    def extract_latent(self, input):
+        """
+        Args:
+            input (batch_size, 1, T) or (batch_size, 1, n_mics, T)
+        Returns:
+            output (batch_size, n_sources, T) or (batch_size, n_sources, n_mics, T)
+            latent (batch_size, n_sources, n_basis, T'), where T' = (T-K)//S+1
+        """
+        return self._run(input, want_latent=True)
+
+    def _run(self, input, want_latent):
+        n_dims = input.dim()
+        if n_dims == 3:
+            batch_size, C_in, T = input.size()
+            assert C_in == 1, "input.size() is expected (?, 1, ?), but given {}".format(input.size())
+            mixture = input
+        elif n_dims == 4:
+            batch_size, C_in, n_mics, T = input.size()
+            assert C_in == 1, "input.size() is expected (?, 1, ?, ?), but given {}".format(input.size())
+            mixture = input.view(batch_size, n_mics, T)
+        else:
+            raise ValueError("Not support {} dimension input".format(n_dims))
+        cfg = self.get_config()
+        _net.check_supported(cfg)
+        if mixture.size(1) != self.in_channels:
+            raise ValueError("input has {} channels, the model was built with in_channels={}".format(mixture.size(1), self.in_channels))
+        if not mixture.is_cuda and _net.backend().name == "hip":
+            raise RuntimeError("ConvTasNet (MI355X build) runs on the GPU only: move the model and the input to 'cuda'. "
+                               "There is no CPU fallback.")
+        mixture = mixture.contiguous()
+        if mixture.dtype != torch.float32 and _net.backend().name == "hip":
+            mixture = mixture.float()
+        named = list(self.named_parameters())
+        names = tuple(n for n, _ in named)
+        params = tuple(p for _, p in named)
+        out = _FusedConvTasNetFn.apply(mixture, cfg, names, want_latent, getattr(self, "_grad_sink", None), *params)
+        if want_latent:
+            est, latent = out
+            F = _net.Geometry(T, self.kernel_size, self.stride).F
+            latent = latent[..., :F]
+        else:
+            est, latent = out, None
+        if n_dims == 3:
+            est = est.view(batch_size, self.n_sources, T)
+        return est, latent
+
+    # ------------------------------------------------------------------ config / checkpoints
+    def get_config(self):
+        return {
+            "in_channels": self.in_channels, "n_basis": self.n_basis, "kernel_size": self.kernel_size, "stride": self.stride,
+            "enc_basis": self.enc_basis, "dec_basis": self.dec_basis, "enc_nonlinear": self.enc_nonlinear,
+            "window_fn": self.window_fn, "enc_onesided": self.enc_onesided, "enc_return_complex": self.enc_return_complex,
+            "sep_hidden_channels": self.sep_hidden_channels, "sep_bottleneck_channels": self.sep_bottleneck_channels,
+            "sep_skip_channels": self.sep_skip_channels, "sep_kernel_size": self.sep_kernel_size,
+            "sep_num_blocks": self.sep_num_blocks, "sep_num_layers": self.sep_num_layers,
+            "dilated": self.dilated, "separable": self.separable, "causal": self.causal,
+            "sep_nonlinear": self.sep_nonlinear, "sep_norm": self.sep_norm, "mask_nonlinear": self.mask_nonlinear,
+            "n_sources": self.n_sources, "eps": self.eps,
+        }
+
+    def get_package(self):
+        return self.get_config()
+
+    @classmethod
+    def build_model(cls, model_path, load_state_dict=False):
+        config = torch.load(model_path, map_location=lambda storage, loc: storage, weights_only=False)
+        return cls._from_config(config, load_state_dict)
+
+    @classmethod
+    def _from_config(cls, config, load_state_dict=False):
+        model = cls(
+            config.get("n_bases") or config["n_basis"], in_channels=config.get("in_channels") or 1,
+            kernel_size=config["kernel_size"], stride=config["stride"],
+            enc_basis=config.get("enc_bases") or config["enc_basis"], dec_basis=config.get("dec_bases") or config["dec_basis"],
+            enc_nonlinear=config["enc_nonlinear"], window_fn=config["window_fn"],
+            enc_onesided=config.get("enc_onesided") or None, enc_return_complex=config.get("enc_return_complex") or None,
+            sep_hidden_channels=config["sep_hidden_channels"], sep_bottleneck_channels=config["sep_bottleneck_channels"],
+            sep_skip_channels=config["sep_skip_channels"], sep_kernel_size=config["sep_kernel_size"],
+            sep_num_blocks=config["sep_num_blocks"], sep_num_layers=config["sep_num_layers"],
+            dilated=config["dilated"], separable=config["separable"], causal=config["causal"],
+            sep_nonlinear=config["sep_nonlinear"], sep_norm=config["sep_norm"], mask_nonlinear=config["mask_nonlinear"],
+            n_sources=config["n_sources"], eps=config["eps"])
+        if load_state_dict:
+            model.load_state_dict(config["state_dict"])
+        return model
+
+    @classmethod
+    def build_from_pretrained(cls, root="./pretrained", quiet=False, load_state_dict=True, **kwargs):
+        """Same task table and directory convention as the reference (conv_tasnet.py:238-310).  The download itself
+        needs the reference's gdown helper (utils.utils); an already-downloaded checkpoint is loaded directly."""
+        task = kwargs.get("task")
+        if task not in cls.pretrained_model_ids:
+            raise KeyError("Invalid task ({}) is specified.".format(task))
+        ids = cls.pretrained_model_ids[task]
+        extra = {}
+        model_choice = kwargs.get("model_choice") or "best"
+        if task in ["wsj0-mix", "wsj0"]:
+            sample_rate, n_sources = kwargs.get("sample_rate") or 8000, kwargs.get("n_sources") or 2
+            config = kwargs.get("config") or "enc_relu"
+            model_id = ids[sample_rate][n_sources][config]
+            download_dir = os.path.join(root, cls.__name__, task, "sr{}/{}speakers/{}".format(sample_rate, n_sources, config))
+            extra["n_sources"] = n_sources
+        elif task == "musdb18":
+            sample_rate = kwargs.get("sample_rate") or SAMPLE_RATE_MUSDB18
+            config = kwargs.get("config") or "4sec_L20"
+            model_id = ids[sample_rate][config]
+            download_dir = os.path.join(root, cls.__name__, task, "sr{}".format(sample_rate), config)
+        elif task in ["wham/separate-noisy", "wham/enhance-single", "wham/enhance-both"]:
+            sample_rate = kwargs.get("sample_rate") or 8000
+            model_id = ids[sample_rate]
+            download_dir = os.path.join(root, cls.__name__, task, "sr{}".format(sample_rate))
+        elif task == "librispeech":
+            sample_rate, n_sources = kwargs.get("sample_rate") or SAMPLE_RATE_LIBRISPEECH, kwargs.get("n_sources") or 2
+            model_id = ids[sample_rate][n_sources]
+            download_dir = os.path.join(root, cls.__name__, task, "sr{}/{}speakers".format(sample_rate, n_sources))
+            extra["n_sources"] = n_sources
+        else:
+            raise NotImplementedError("Not support task={}.".format(task))
+        extra["sample_rate"] = sample_rate
+        model_path = os.path.join(download_dir, "model", "{}.pth".format(model_choice))
+        if not os.path.exists(model_path):
+            from utils.utils import download_pretrained_model_from_google_drive   # reference helper (gdown), reused as-is
+            download_pretrained_model_from_google_drive(model_id, download_dir, quiet=quiet)
+        config = torch.load(model_path, map_location=lambda storage, loc: storage, weights_only=False)
+        model = cls._from_config(config, load_state_dict=load_state_dict)
+        if task == "musdb18":
+            extra.update({"sources": config["sources"], "n_sources": len(config["sources"])})
+        for key, value in extra.items():
+            setattr(model, key, value)
+        return model
+
+    @property
+    def num_parameters(self):
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)
+
+
+class Separator(nn.Module):
+    """gLN -> 1x1 bottleneck -> TCN -> PReLU -> 1x1 mask conv -> sigmoid (reference conv_tasnet.py:322-378):
+    parameter container; executed by the fused sequence of ConvTasNet."""
+
+    def __init__(self, num_features, bottleneck_channels=128, hidden_channels=256, skip_channels=128, kernel_size=3,
+                 num_blocks=3, num_layers=8, dilated=True, separable=True, causal=True, nonlinear="prelu", norm=True,
+                 mask_nonlinear="sigmoid", n_sources=2, eps=EPS):
+        super().__init__()
+        self.num_features, self.n_sources = num_features, n_sources
+        norm_name = "cLN" if causal else "gLN"
+        self.norm1d = choose_layer_norm(norm_name, num_features, causal=causal, eps=eps)
+        self.bottleneck_conv1d = nn.Conv1d(num_features, bottleneck_channels, kernel_size=1, stride=1)
+        self.tdcn = TimeDilatedConvNet(bottleneck_channels, hidden_channels=hidden_channels, skip_channels=skip_channels,
+                                       kernel_size=kernel_size, num_blocks=num_blocks, num_layers=num_layers, dilated=dilated,
+                                       separable=separable, causal=causal, nonlinear=nonlinear, norm=norm)
+        self.prelu = nn.PReLU()
+        self.mask_conv1d = nn.Conv1d(skip_channels, n_sources * num_features, kernel_size=1, stride=1)
+        if mask_nonlinear not in ("sigmoid", "softmax"):
+            raise ValueError("Cannot support {}".format(mask_nonlinear))
+        self.mask_nonlinear = nn.Sigmoid() if mask_nonlinear == "sigmoid" else nn.Softmax(dim=1)
+
+    def forward(self, input):
+        raise NotImplementedError("Separator is executed as part of the fused ConvTasNet kernel sequence (sepkernels/net.py)")

@@ -99,7 +99,8 @@ def forward(cfg, P, mixture, want_latent=False, save=True):
     N, L, S = cfg["n_basis"], cfg["kernel_size"], cfg["stride"]
     Bn, H, Sc = cfg["sep_bottleneck_channels"], cfg["sep_hidden_channels"], cfg["sep_skip_channels"]
     n_src = cfg["n_sources"]
-    eps = float(cfg.get("eps", 1e-12))
+    eps = float(cfg.get("eps", 1e-12))          # separator.norm1d
+    teps = float(cfg.get("tcn_eps", 1e-12))     # TCN norms keep tdcn.EPS: the reference never forwards eps to the TCN (conv_tasnet.py:336-339)
     relu = cfg.get("enc_nonlinear") == "relu"
     geo = Geometry(T_in, L, S)
     F, ldt = geo.F, geo.ldt
@@ -124,20 +125,22 @@ def forward(cfg, P, mixture, want_latent=False, save=True):
         a = torch.empty(B, H, ldt, **f32)
         K.pw_gemm(B=B, M=H, K=Bn, T=F, ldt=ldt, A=P[pre + "bottleneck_conv1d.weight"], X=x, Y=a,
                   bias=P[pre + "bottleneck_conv1d.bias"], epi_flags=EPI_STATS_PRELU, epi_alpha=P[pre + "nonlinear1d.weight"],
-                  epi_stats=st1, eps=eps)
+                  epi_stats=st1, eps=teps)
         z = torch.empty(B, H, ldt, **f32)
         K.dwconv_fwd(a, st1, P[pre + "norm1d.norm.weight"], P[pre + "norm1d.norm.bias"], P[pre + "nonlinear1d.weight"],
                      P[sp + "depthwise_conv1d.weight"], P[sp + "depthwise_conv1d.bias"], P[sp + "nonlinear1d.weight"],
-                     z, st2, B, H, F, ldt, dil, eps)
+                     z, st2, B, H, F, ldt, dil, teps)
         pro = dict(pro_mode=PRO_GLN_PRELU, pro_stats=st2, pro_gamma=P[sp + "norm1d.norm.weight"],
-                   pro_beta=P[sp + "norm1d.norm.bias"], pro_alpha=P[sp + "nonlinear1d.weight"], count=H * F, eps=eps)
+                   pro_beta=P[sp + "norm1d.norm.bias"], pro_alpha=P[sp + "nonlinear1d.weight"], count=H * F, eps=teps)
         Ws, bs = P[sp + "skip_pointwise_conv1d.weight"], P[sp + "skip_pointwise_conv1d.bias"]
         if dual:
             Wo, bo = P[sp + "output_pointwise_conv1d.weight"], P[sp + "output_pointwise_conv1d.bias"]
             xo = torch.empty(B, Bn, ldt, **f32)
             if Bn % 128 == 0 and _adjacent(Wo, Ws) and _adjacent(bo, bs):
                 # [Wo;Ws] contiguous (flat parameter layout): one GEMM reads the H-tensor z once for both heads
-                K.pw_gemm(B=B, M=Bn + Sc, K=H, T=F, ldt=ldt, A=Wo, X=z, Y=xo, Y2=skip, m_split=Bn, bias=bo,
+                Wcat = Wo.as_strided((Bn + Sc, H), (H, 1))      # views over the flat parameter buffer
+                bcat = bo.as_strided((Bn + Sc,), (1,))
+                K.pw_gemm(B=B, M=Bn + Sc, K=H, T=F, ldt=ldt, A=Wcat, X=z, Y=xo, Y2=skip, m_split=Bn, bias=bcat,
                           accumulate=int(li > 0), epi_flags=EPI_RESIDUAL, epi_res=x, **pro)
             else:
                 K.pw_gemm(B=B, M=Bn, K=H, T=F, ldt=ldt, A=Wo, X=z, Y=xo, bias=bo, epi_flags=EPI_RESIDUAL, epi_res=x, **pro)
@@ -174,6 +177,7 @@ def backward(cfg, P, sv, d_est, G):
     Bn, H, Sc = cfg["sep_bottleneck_channels"], cfg["sep_hidden_channels"], cfg["sep_skip_channels"]
     n_src = cfg["n_sources"]
     eps = float(cfg.get("eps", 1e-12))
+    teps = float(cfg.get("tcn_eps", 1e-12))
     relu = cfg.get("enc_nonlinear") == "relu"
     geo, stats, w, skip, m = sv.geo, sv.stats, sv.w, sv.skip, sv.m
     F, ldt = geo.F, geo.ldt
@@ -184,12 +188,12 @@ def backward(cfg, P, sv, d_est, G):
     nt64, nt1024 = ldt // 64, (ldt + 1023) // 1024
     dalpha = torch.zeros(nl + 1, device=dev, dtype=torch.float64)   # [layer alpha1 ..., mask prelu]
 
-    def wgrad(M, Nn, Gt, Xt, dW, dbias=None, Bq=B, **kw):
+    def wgrad(M, Nn, Gt, Xt, dW, dbias=None, Bq=B, weps=None, **kw):
         ch = Bq * (ldt // 32)
         ns = _nsplit(M, Nn, ch)
         part = torch.empty(ns, M, Nn, **f32)
         pb = torch.empty(ns, M, **f32) if dbias is not None else None
-        K.pw_wgrad(B=Bq, M=M, N=Nn, T=F, ldt=ldt, G=Gt, X=Xt, partial=part, partial_bias=pb, nsplit=ns, eps=eps, **kw)
+        K.pw_wgrad(B=Bq, M=M, N=Nn, T=F, ldt=ldt, G=Gt, X=Xt, partial=part, partial_bias=pb, nsplit=ns, eps=(eps if weps is None else weps), **kw)
         return part, pb, ns
 
     # ---- tail: decoder / mask ---------------------------------------------------------------------
@@ -227,7 +231,7 @@ def backward(cfg, P, sv, d_est, G):
         # dv2 = Wo^T dout + Ws^T dS, with the row sums the gLN2 backward needs
         dv2 = torch.empty(B, H, ldt, **f32)
         rp2 = torch.empty(B, H, nt64, 2, **f32)
-        epi = dict(epi_flags=EPI_ROWSUMS | EPI_ROWSUMS_PRELU, epi_aux=z, epi_alpha=al2, epi_rowpart=rp2, eps=eps)
+        epi = dict(epi_flags=EPI_ROWSUMS | EPI_ROWSUMS_PRELU, epi_aux=z, epi_alpha=al2, epi_rowpart=rp2, eps=teps)
         if dual:
             Wo = P[sp + "output_pointwise_conv1d.weight"]
             K.pw_gemm(B=B, M=H, K=Bn + Sc, T=F, ldt=ldt, trans_a=1, A=Wo, A2=Ws, X=dout, X2=dS, k_split=Bn, Y=dv2, **epi)
@@ -236,10 +240,10 @@ def backward(cfg, P, sv, d_est, G):
         bsum2 = torch.empty(B, 2, **f32)
         pbeta2 = torch.empty(B, H, **f32)
         pgamma2 = torch.empty(B, H, **f32)
-        K.gln_bwd_finalize(rp2, nt64, 2, st2, g2, cnt, eps, bsum2, pbeta2, pgamma2, None, B, H)
+        K.gln_bwd_finalize(rp2, nt64, 2, st2, g2, cnt, teps, bsum2, pbeta2, pgamma2, None, B, H)
 
         # head weight gradients: dWo = sum dout v2^T, dWs = sum dS v2^T   (v2 = gLN2(PReLU(z)) rebuilt on load)
-        xkw = dict(x_mode=PRO_GLN_PRELU, x_stats=st2, x_gamma=g2, x_beta=b2, x_alpha=al2, count=cnt)
+        xkw = dict(x_mode=PRO_GLN_PRELU, x_stats=st2, x_gamma=g2, x_beta=b2, x_alpha=al2, count=cnt, weps=teps)
         segs = []
         if dual and Bn % 128 == 0:
             part, pb, ns = wgrad(Bn + Sc, H, dout, z, True, True, G2=dS, g_split=Bn, **xkw)
@@ -262,12 +266,12 @@ def backward(cfg, P, sv, d_est, G):
         dv1 = torch.empty(B, H, ldt, **f32)
         rp1 = torch.empty(B, H, nt1024, 8, **f32)
         K.dwconv_bwd(dv2, z, a, st1, g1, b1, al1, st2, g2, al2, bsum2, P[sp + "depthwise_conv1d.weight"], dv1, rp1,
-                     B, H, F, ldt, dil, eps)
+                     B, H, F, ldt, dil, teps)
         bsum1 = torch.empty(B, 2, **f32)
         pbeta1 = torch.empty(B, H, **f32)
         pgamma1 = torch.empty(B, H, **f32)
         pextra = torch.empty(B * 4 * H + B, **f32)
-        K.gln_bwd_finalize(rp1, nt1024, 8, st1, g1, cnt, eps, bsum1, pbeta1, pgamma1, pextra, B, H)
+        K.gln_bwd_finalize(rp1, nt1024, 8, st1, g1, cnt, teps, bsum1, pbeta1, pgamma1, pextra, B, H)
         K.reduce_slabs([
             (pbeta2, 0, G[sp + "norm1d.norm.bias"], H, B, H, 0, 1.0),
             (pgamma2, 0, G[sp + "norm1d.norm.weight"], H, B, H, 0, 1.0),
@@ -280,11 +284,14 @@ def backward(cfg, P, sv, d_est, G):
 
         # dx = W1^T da (+ dout through the residual); da = gLN1/PReLU1 backward of dv1, formed in the GEMM prologue
         dx = torch.empty(B, Bn, ldt, **f32)
+        # da overwrites dv1 in place when a single row tile covers all outputs (each X element is then read once);
+        # with several row tiles the other tiles still need the untouched dv1, so da goes to its own buffer
+        da = dv1 if Bn <= 128 else torch.empty_like(dv1)
         K.pw_gemm(B=B, M=Bn, K=H, T=F, ldt=ldt, trans_a=1, A=P[pre + "bottleneck_conv1d.weight"], X=dv1, Y=dx,
                   pro_mode=PRO_GLN_BWD, pro_stats=st1, pro_gamma=g1, pro_alpha=al1, pro_aux=a, pro_bsum=bsum1,
-                  pro_store=dv1, pro_dalpha=dalpha[li:li + 1], count=cnt, eps=eps,
+                  pro_store=da, pro_dalpha=dalpha[li:li + 1], count=cnt, eps=teps,
                   epi_flags=(EPI_RESIDUAL if dout is not None else 0), epi_res=dout)
-        part, pb, ns = wgrad(H, Bn, dv1, x, True, True)
+        part, pb, ns = wgrad(H, Bn, da, x, True, True)
         K.reduce_slabs([(part, 0, G[pre + "bottleneck_conv1d.weight"], H * Bn, ns, H * Bn, 0, 1.0),
                         (pb, 0, G[pre + "bottleneck_conv1d.bias"], H, ns, H, 0, 1.0)])
         K.f64_to_f32(dalpha[li:li + 1], G[pre + "nonlinear1d.weight"], 1, 0)

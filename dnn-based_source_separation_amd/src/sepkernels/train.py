@@ -1,0 +1,62 @@
+"""
+Data-parallel train step for the fused Conv-TasNet path: one process per GPU, utterances sharded across ranks,
+every rank runs forward + SI-SDR/PIT + backward locally, then ONE all-reduce (RCCL over xGMI; `nccl` backend on
+ROCm) of the flat fp32 gradient buffer, then global-norm clip + Adam fused in two kernels on the flat buffers.
+
+Replaces the single-process nn.DataParallel step of reference egs/wsj0-mix/common/src/driver.py:141-157
+(scatter / per-forward parameter broadcast / gather / loss+clip+Adam on GPU 0) -- SURVEY.md section 8(e).
+Equal per-rank batches make mean-of-rank-means the global batch mean, so the averaged gradient equals the
+reference's single-process result.  The collective is 19.9 MB per step (4,984,881 floats): latency-, not
+bandwidth-bound on 7 x 153 GB/s xGMI links, so it is issued once, un-bucketed, after backward.
+"""
+import torch
+import torch.distributed as dist
+
+import sepkernels
+
+
+class FusedTrainStep:
+    def __init__(self, model, criterion, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=5.0,
+                 process_group=None, distributed=None):
+        self.model, self.criterion = model, criterion
+        self.lr, self.betas, self.eps, self.weight_decay, self.max_norm = lr, betas, eps, weight_decay, max_norm
+        self.group = process_group
+        self.distributed = dist.is_available() and dist.is_initialized() if distributed is None else distributed
+        self.world = dist.get_world_size(process_group) if self.distributed else 1
+        flat = model.flat_parameters()
+        if flat is None:
+            raise RuntimeError("FusedTrainStep needs the model's parameters co-located in one flat buffer")
+        self.flat = flat
+        if self.distributed and self.world > 1:
+            dist.broadcast(self.flat, src=0, group=process_group)      # replaces DataParallel's per-forward replicate
+        self.gflat = torch.zeros_like(flat)
+        self.m = torch.zeros_like(flat)
+        self.v = torch.zeros_like(flat)
+        self.sqnorm = torch.zeros(1, device=flat.device, dtype=torch.float64)
+        self.step_count = 0
+
+    def zero_grad(self):
+        for p in self.model.parameters():
+            p.grad = None
+
+    def __call__(self, mixture, sources):
+        K = sepkernels.backend()
+        model = self.model
+        self.zero_grad()
+        model._grad_sink = self.gflat                 # backward writes every gradient straight into the flat buffer
+        try:
+            est = model(mixture)
+            loss, _ = self.criterion(est, sources)
+            loss.backward()
+        finally:
+            model._grad_sink = None
+        if self.world > 1:
+            dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM, group=self.group)
+        self.step_count += 1
+        n = self.gflat.numel()
+        self.sqnorm.zero_()
+        if self.max_norm and self.max_norm > 0:
+            K.sqnorm(self.gflat, self.sqnorm, n)
+        K.adam_step(self.flat, self.gflat, self.m, self.v, self.sqnorm, n, self.lr, self.betas[0], self.betas[1], self.eps,
+                    self.weight_decay, float(self.max_norm or 0.0), 1.0 / self.world, self.step_count)
+        return loss.detach()

@@ -1,0 +1,351 @@
+"""GPU: every entry point of the C ABI (called through ctypes, i.e. through libsepkernels.so) against its CPU
+emulation (tests/emulator.py) on identical seeded buffers.  The emulator itself is pinned to the oracle / the
+reference golden vectors by the CPU tests, so agreement here chains each HIP kernel to the reference.
+Pure outputs are pre-filled with NaN so that an element the kernel forgets to write is caught."""
+import copy
+import itertools
+import math
+
+import pytest
+import torch
+
+import sepkernels
+from sepkernels import (EPI_PRELU_BWD, EPI_RESIDUAL, EPI_ROWSUMS, EPI_ROWSUMS_PRELU, EPI_SIGMOID, EPI_STATS_PRELU, PRO_GLN,
+                        PRO_GLN_BWD, PRO_GLN_PRELU, PRO_NONE, PRO_PRELU)
+from emulator import EmuBackend
+
+pytestmark = pytest.mark.gpu
+
+EMU = EmuBackend()
+HIP = sepkernels.HipBackend()
+G = torch.Generator().manual_seed(1234)
+
+
+def rnd(*shape, scale=1.0):
+    return (torch.randn(*shape, generator=G) * scale).float()
+
+
+def nan(*shape):
+    return torch.full(shape, float("nan"))
+
+
+def padded(B, C, T, ldt, scale=1.0):
+    x = rnd(B, C, ldt, scale=scale)
+    x[..., T:] = 0
+    return x
+
+
+def stats_of(x, T):
+    v = x[..., :T].double()
+    return torch.stack([v.sum((1, 2)), (v * v).sum((1, 2))], 1)
+
+
+def both(op, args, kwargs=None, tol=2e-4, names=None):
+    """Run `op` on the emulator (CPU tensors) and on HIP (cuda clones); compare every tensor argument afterwards."""
+    kwargs = kwargs or {}
+    memo = {}
+
+    def to_gpu(v):   # aliasing arguments (in-place ops) must stay aliased on the device
+        if not torch.is_tensor(v):
+            return v
+        if id(v) not in memo:
+            memo[id(v)] = v.cuda()
+        return memo[id(v)]
+    gargs = [to_gpu(a) for a in args]
+    gkw = {k: to_gpu(v) for k, v in kwargs.items()}
+    getattr(EMU, op)(*args, **kwargs)
+    getattr(HIP, op)(*gargs, **gkw)
+    torch.cuda.synchronize()
+    items = list(enumerate(zip(args, gargs))) + [(k, (kwargs[k], gkw[k])) for k in kwargs]
+    for key, (c, g) in items:
+        if not torch.is_tensor(c):
+            continue
+        gc = g.cpu()
+        if c.dtype in (torch.int64, torch.int32):
+            assert torch.equal(c, gc), "{}: integer output {} differs".format(op, key)
+            continue
+        assert torch.isfinite(gc).all() == torch.isfinite(c).all(), "{}: arg {} finite-ness differs (unwritten output?)".format(op, key)
+        assert torch.isfinite(gc).all(), "{}: arg {} has non-finite values".format(op, key)
+        ref = c.double()
+        err = (gc.double() - ref).abs().max().item()
+        den = ref.abs().max().item() + 1e-30
+        assert err <= tol * den, "{}: arg {} max err {:.3e} vs scale {:.3e}".format(op, key, err, den)
+
+
+# ------------------------------------------------------------------------------------------- encoder / unfold
+@pytest.mark.parametrize("Cin,L,S,relu,pad_left", [(1, 16, 8, 0, 0), (1, 16, 8, 1, 3), (2, 20, 10, 1, 4), (1, 2, 1, 0, 0)])
+def test_encoder_and_unfold(Cin, L, S, relu, pad_left):
+    B, N, Tin = 2, 64, 1999
+    F = (Tin + 2 * pad_left - L) // S + 1
+    ldt = (F + 127) // 128 * 128
+    x, E = rnd(B, Cin, Tin), rnd(N, Cin, L)
+    both("encoder_fwd", [x, E, nan(B, N, ldt), torch.zeros(B, 2, dtype=torch.float64), B, Cin, Tin, N, L, S, F, ldt, pad_left, relu])
+    both("unfold", [x, nan(B, Cin * L, ldt), B, Cin, Tin, L, S, F, ldt, pad_left])
+
+
+# ------------------------------------------------------------------------------------------- pointwise GEMM
+def _gemm_common(B, M, K, T):
+    ldt = (T + 127) // 128 * 128
+    return ldt, padded(B, K, T, ldt), rnd(M, K, scale=K ** -0.5), rnd(M)
+
+
+@pytest.mark.parametrize("B,M,K,T", [(2, 64, 128, 300), (1, 512, 128, 3999), (3, 128, 64, 129)])
+def test_gemm_plain_bias(B, M, K, T):
+    ldt, X, A, bias = _gemm_common(B, M, K, T)
+    both("pw_gemm", [], dict(B=B, M=M, K=K, T=T, ldt=ldt, A=A, X=X, Y=nan(B, M, ldt), bias=bias))
+
+
+def test_gemm_gln_prologue_and_stats_epilogue():
+    B, M, K, T = 2, 128, 256, 777
+    ldt, X, A, bias = _gemm_common(B, M, K, T)
+    X = X * 2 + 0.3
+    X[..., T:] = 0
+    st = stats_of(X, T)
+    gamma, beta, alpha = rnd(K) + 1, rnd(K), torch.tensor([0.2])
+    both("pw_gemm", [], dict(B=B, M=M, K=K, T=T, ldt=ldt, A=A, X=X, Y=nan(B, M, ldt), bias=bias, pro_mode=PRO_GLN, pro_stats=st,
+                             pro_gamma=gamma, pro_beta=beta, count=K * T, eps=1e-12, epi_flags=EPI_STATS_PRELU,
+                             epi_alpha=alpha, epi_stats=torch.zeros(B, 2, dtype=torch.float64)))
+
+
+def test_gemm_packed_heads_residual_accumulate():
+    """[Wo;Ws] as one operand: rows < m_split -> Y (+residual), rows >= m_split -> Y2 (+=)."""
+    B, Bn, Sc, H, T = 2, 128, 128, 256, 500
+    ldt = 512
+    z = padded(B, H, T, ldt) * 1.5 + 0.2
+    z[..., T:] = 0
+    u = torch.where(z > 0, z, 0.3 * z)
+    st = stats_of(u, T)
+    A, bias = rnd(Bn + Sc, H, scale=H ** -0.5), rnd(Bn + Sc)
+    res, skip0 = padded(B, Bn, T, ldt), padded(B, Sc, T, ldt)
+    kw = dict(B=B, M=Bn + Sc, K=H, T=T, ldt=ldt, A=A, X=z, Y=nan(B, Bn, ldt), Y2=skip0, m_split=Bn, bias=bias, accumulate=1,
+              epi_flags=EPI_RESIDUAL, epi_res=res, pro_mode=PRO_GLN_PRELU, pro_stats=st, pro_gamma=rnd(H) + 1, pro_beta=rnd(H),
+              pro_alpha=torch.tensor([0.3]), count=H * T, eps=1e-12)
+    both("pw_gemm", [], kw)
+
+
+def test_gemm_prelu_prologue_sigmoid():
+    B, M, K, T = 2, 384, 64, 260
+    ldt, X, A, bias = _gemm_common(B, M, K, T)
+    both("pw_gemm", [], dict(B=B, M=M, K=K, T=T, ldt=ldt, A=A, X=X, Y=nan(B, M, ldt), bias=bias, pro_mode=PRO_PRELU,
+                             pro_alpha=torch.tensor([0.25]), epi_flags=EPI_SIGMOID))
+
+
+def test_gemm_dgrad_two_sources_rowsums():
+    """dv2 = Wo^T dout + Ws^T dS with the gLN-backward row sums in the epilogue."""
+    B, Bn, Sc, H, T = 2, 128, 64, 256, 700
+    ldt = 768
+    Wo, Ws = rnd(Bn, H, scale=0.1), rnd(Sc, H, scale=0.1)
+    dout, dS, z = padded(B, Bn, T, ldt), padded(B, Sc, T, ldt), padded(B, H, T, ldt)
+    kw = dict(B=B, M=H, K=Bn + Sc, T=T, ldt=ldt, trans_a=1, A=Wo, A2=Ws, X=dout, X2=dS, k_split=Bn, Y=nan(B, H, ldt),
+              epi_flags=EPI_ROWSUMS | EPI_ROWSUMS_PRELU, epi_aux=z, epi_alpha=torch.tensor([0.15]),
+              epi_rowpart=nan(B, H, ldt // 64, 2))
+    both("pw_gemm", [], kw)
+
+
+def test_gemm_dgrad_prelu_bwd():
+    B, M, K, T = 2, 64, 384, 333
+    ldt = 384
+    Wm = rnd(K, M, scale=0.1)
+    dpre, S = padded(B, K, T, ldt), padded(B, M, T, ldt)
+    both("pw_gemm", [], dict(B=B, M=M, K=K, T=T, ldt=ldt, trans_a=1, A=Wm, X=dpre, Y=nan(B, M, ldt), epi_flags=EPI_PRELU_BWD,
+                             epi_aux=S, epi_alpha=torch.tensor([0.25]), epi_dalpha=torch.zeros(1, dtype=torch.float64)))
+
+
+@pytest.mark.parametrize("residual", [0, 1])
+def test_gemm_gln_bwd_prologue(residual):
+    B, M, K, T = 2, 128, 256, 450
+    ldt = 512
+    W1 = rnd(K, M, scale=0.1)
+    a = padded(B, K, T, ldt)
+    u = torch.where(a > 0, a, 0.2 * a)
+    st = stats_of(u, T)
+    dv = padded(B, K, T, ldt)
+    kw = dict(B=B, M=M, K=K, T=T, ldt=ldt, trans_a=1, A=W1, X=dv, Y=nan(B, M, ldt), pro_mode=PRO_GLN_BWD, pro_stats=st,
+              pro_gamma=rnd(K) + 1, pro_alpha=torch.tensor([0.2]), pro_aux=a, pro_bsum=rnd(B, 2, scale=0.01), pro_store=dv,
+              pro_dalpha=torch.zeros(1, dtype=torch.float64), count=K * T, eps=1e-12)
+    if residual:
+        kw.update(epi_flags=EPI_RESIDUAL, epi_res=padded(B, M, T, ldt))
+    both("pw_gemm", [], kw)
+
+
+# ------------------------------------------------------------------------------------------- weight gradient
+def _wg_out(ns, M, N):
+    return nan(ns, M, N), nan(ns, M)
+
+
+def _reduce_check(part_c, part_g, tol=3e-4):
+    a, b = part_c.double().sum(0), part_g.double().cpu().sum(0)
+    assert (a - b).abs().max() <= tol * (a.abs().max() + 1e-30)
+
+
+def _wgrad_both(kw, tol=3e-4):
+    """Slab contents differ by construction (the emulator puts everything in slab 0): compare the slab sums."""
+    ck = dict(kw)
+    gk = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in kw.items()}
+    EMU.pw_wgrad(**ck)
+    HIP.pw_wgrad(**gk)
+    torch.cuda.synchronize()
+    assert torch.isfinite(gk["partial"]).all()
+    _reduce_check(ck["partial"], gk["partial"], tol)
+    if kw.get("partial_bias") is not None:
+        assert torch.isfinite(gk["partial_bias"]).all()
+        _reduce_check(ck["partial_bias"], gk["partial_bias"], tol)
+
+
+@pytest.mark.parametrize("B,M,N,T,ns", [(2, 256, 128, 999, 7), (1, 128, 16, 300, 3), (3, 64, 64, 130, 1), (2, 512, 128, 3999, 64)])
+def test_wgrad_plain(B, M, N, T, ns):
+    ldt = (T + 127) // 128 * 128
+    part, pb = _wg_out(ns, M, N)
+    _wgrad_both(dict(B=B, M=M, N=N, T=T, ldt=ldt, G=padded(B, M, T, ldt), X=padded(B, N, T, ldt), partial=part, partial_bias=pb, nsplit=ns))
+
+
+def test_wgrad_two_sources_gln_prelu():
+    B, Bn, Sc, H, T, ns = 2, 128, 64, 256, 640, 5
+    ldt = 640
+    z = padded(B, H, T, ldt)
+    u = torch.where(z > 0, z, 0.1 * z)
+    part, pb = _wg_out(ns, Bn + Sc, H)
+    _wgrad_both(dict(B=B, M=Bn + Sc, N=H, T=T, ldt=ldt, G=padded(B, Bn, T, ldt), G2=padded(B, Sc, T, ldt), g_split=Bn, X=z,
+                     x_mode=PRO_GLN_PRELU, x_stats=stats_of(u, T), x_gamma=rnd(H) + 1, x_beta=rnd(H), x_alpha=torch.tensor([0.1]),
+                     count=H * T, eps=1e-12, partial=part, partial_bias=pb, nsplit=ns))
+
+
+def test_wgrad_latent_product_and_prelu():
+    B, n_src, N, LC, T, ns = 2, 3, 64, 16, 500, 4
+    ldt = 512
+    m, w = padded(B * n_src, N, T, ldt), padded(B, N, T, ldt)
+    part, _ = _wg_out(ns, N, LC)
+    _wgrad_both(dict(B=B * n_src, M=N, N=LC, T=T, ldt=ldt, G=m, Gaux=w, g_mul=1, g_div=n_src, X=padded(B * n_src, LC, T, ldt),
+                     partial=part, nsplit=ns))
+    part, pb = _wg_out(ns, 192, 64)
+    _wgrad_both(dict(B=B, M=192, N=64, T=T, ldt=ldt, G=padded(B, 192, T, ldt), X=padded(B, 64, T, ldt), x_mode=PRO_PRELU,
+                     x_alpha=torch.tensor([0.3]), partial=part, partial_bias=pb, nsplit=ns))
+    part, pb = _wg_out(ns, 64, 128)
+    Xw = padded(B, 128, T, ldt)
+    _wgrad_both(dict(B=B, M=64, N=128, T=T, ldt=ldt, G=padded(B, 64, T, ldt), X=Xw, x_mode=PRO_GLN, x_stats=stats_of(Xw, T),
+                     x_gamma=rnd(128) + 1, x_beta=rnd(128), count=128 * T, eps=1e-12, partial=part, partial_bias=pb, nsplit=ns))
+
+
+def test_reduce_slabs_and_f64():
+    src = rnd(6, 1000)
+    segs_c = [(src, 0, nan(300), 300, 6, 1000, 0, 1.0), (src, 300, torch.ones(700), 700, 5, 1000, 1, 0.5)]
+    segs_g = [(s.cuda(), o, d.cuda(), n, k, st, a, sc) for (s, o, d, n, k, st, a, sc) in segs_c]
+    EMU.reduce_slabs(segs_c)
+    HIP.reduce_slabs(segs_g)
+    for c, g in zip(segs_c, segs_g):
+        assert torch.allclose(c[2], g[2].cpu(), rtol=1e-5, atol=1e-6)
+    both("f64_to_f32", [torch.tensor([1.25, -3.5], dtype=torch.float64), torch.tensor([1.0, 1.0]), 2, 1])
+
+
+# ------------------------------------------------------------------------------------------- depthwise
+@pytest.mark.parametrize("T,d", [(3999, 1), (3999, 2), (3999, 128), (300, 8), (1030, 64), (2100, 256)])
+def test_dwconv_fwd_bwd(T, d):
+    B, C = 2, 8
+    ldt = (T + 127) // 128 * 128
+    a = padded(B, C, T, ldt)
+    a1, a2 = torch.tensor([0.25]), torch.tensor([0.1])
+    u1 = torch.where(a > 0, a, a1 * a)
+    st1 = stats_of(u1, T)
+    g1, b1, wd, bd = rnd(C) + 1, rnd(C), rnd(C, 1, 3), rnd(C)
+    z = nan(B, C, ldt)
+    st2 = torch.zeros(B, 2, dtype=torch.float64)
+    both("dwconv_fwd", [a, st1, g1, b1, a1, wd, bd, a2, z, st2, B, C, T, ldt, d, 1e-12])
+    # backward on the emulator's z / stats2 (identical inputs for both)
+    dv2 = padded(B, C, T, ldt)
+    ntile = (ldt + 1023) // 1024
+    args = [dv2, z, a, st1, g1, b1, a1, st2, rnd(C) + 1, a2, rnd(B, 2, scale=0.01), wd, nan(B, C, ldt), nan(B, C, ntile, 8), B, C, T, ldt, d, 1e-12]
+    gargs = [v.cuda() if torch.is_tensor(v) else v for v in args]
+    EMU.dwconv_bwd(*args)
+    HIP.dwconv_bwd(*gargs)
+    torch.cuda.synchronize()
+    assert torch.isfinite(gargs[12]).all() and torch.isfinite(gargs[13]).all()
+    assert (args[12] - gargs[12].cpu()).abs().max() <= 2e-4 * args[12].abs().max()
+    rc, rg = args[13].double().sum(2), gargs[13].cpu().double().sum(2)          # per-tile partials -> per-row totals
+    assert (rc - rg).abs().max() <= 3e-4 * rc.abs().max()
+
+
+@pytest.mark.parametrize("nq,ntile", [(2, 8), (8, 4), (8, 1), (2, 64)])
+def test_gln_bwd_finalize(nq, ntile):
+    B, C = 3, 96
+    rp = rnd(B, C, ntile, nq)
+    x = rnd(B, C, 50)
+    st = stats_of(x, 50)
+    pextra = nan(B * 4 * C + B) if nq == 8 else None
+    both("gln_bwd_finalize", [rp, ntile, nq, st, rnd(C) + 1, C * 50.0, 1e-12, nan(B, 2), nan(B, C), nan(B, C), pextra, B, C])
+
+
+@pytest.mark.parametrize("relu", [0, 1])
+def test_head_bwd(relu):
+    B, C, T, ldt = 2, 64, 300, 384
+    w = padded(B, C, T, ldt)
+    both("head_bwd", [padded(B, C, T, ldt), w, padded(B, C, T, ldt), stats_of(w, T), rnd(C) + 1, rnd(B, 2, scale=0.01), B, C, T, ldt, C * float(T), 1e-12, relu])
+
+
+# ------------------------------------------------------------------------------------------- decoder
+@pytest.mark.parametrize("n_src,Cout,L,S,pad_left,latent", [(2, 1, 16, 8, 0, True), (3, 1, 16, 8, 3, False), (5, 1, 16, 8, 0, False),
+                                                            (2, 2, 20, 10, 4, True), (2, 1, 2, 1, 0, False), (1, 1, 64, 16, 0, False)])
+def test_decoder_fwd_bwd(n_src, Cout, L, S, pad_left, latent):
+    B, N, F = 2, 64, 300
+    ldt = 384
+    Tpad = S * (F - 1) + L
+    Tout = Tpad - 2 * pad_left - (1 if pad_left else 0)
+    w = padded(B, N, F, ldt)
+    m = torch.sigmoid(padded(B, n_src * N, F, ldt))
+    m[..., F:] = 0
+    D = rnd(N, Cout, L)
+    both("decoder_fwd", [w, m, D, nan(B, n_src, Cout, Tout), nan(B, n_src, N, ldt) if latent else None, B, n_src, N, Cout, L, S, F, ldt, Tout, pad_left])
+    both("decoder_bwd", [rnd(B, n_src, Cout, Tout), w, m, D, nan(B, n_src * N, ldt), nan(B, N, ldt), B, n_src, N, Cout, L, S, F, ldt, Tout, pad_left])
+
+
+# ------------------------------------------------------------------------------------------- stand-alone gLN / repack
+def test_gln_standalone_and_repack():
+    B, C, T, ldt = 3, 20, 1501, 1504
+    x = padded(B, C, T, ldt) + 0.5
+    x[..., T:] = 0
+    st = torch.zeros(B, 2, dtype=torch.float64)
+    both("gln_stats", [x, st, B, C, T, ldt])
+    gamma, beta = rnd(C) + 1, rnd(C)
+    both("gln_apply", [x, st, gamma, beta, nan(B, C, ldt), B, C, T, ldt, C * float(T), 1e-12])
+    dy = padded(B, C, T, ldt)
+    ntile = (ldt + 1023) // 1024
+    rp = nan(B, C, ntile, 2)
+    both("gln_bwd_rowsums", [dy, x, rp, B, C, T, ldt])
+    both("gln_bwd_apply", [dy, x, st, gamma, rnd(B, 2, scale=0.01), nan(B, C, ldt), B, C, T, ldt, C * float(T), 1e-12])
+    both("repack", [rnd(B * C, T), T, nan(B * C, ldt), ldt, B * C, T])
+
+
+# ------------------------------------------------------------------------------------------- losses / optimiser
+@pytest.mark.parametrize("n,all_pairs", [(1, 0), (2, 1), (4, 1), (3, 0)])
+def test_sisdr_kernels(n, all_pairs):
+    B, T = 3, 32000
+    tgt = rnd(B, n, T)
+    est = 0.8 * tgt[:, torch.randperm(n, generator=G)] + 0.3 * rnd(B, n, T)
+    dots, tt, xx = (torch.zeros(B, n, n, dtype=torch.float64), torch.zeros(B, n, dtype=torch.float64), torch.zeros(B, n, dtype=torch.float64))
+    both("sisdr_dots", [est, tgt, dots, tt, xx, B, n, T, all_pairs], tol=1e-6)
+    both("sisdr_from_dots", [dots, tt, xx, nan(B, n, n), B, n, all_pairs, 1e-12], tol=1e-5)
+    both("sisdr_bwd", [est, tgt, dots, tt, xx, rnd(B, n, n), nan(B, n, T), B, n, T, all_pairs, 1e-12], tol=1e-5)
+
+
+@pytest.mark.parametrize("n,maximize,use_mean", [(2, 0, 1), (3, 1, 1), (4, 0, 0)])
+def test_pit_search(n, maximize, use_mean):
+    B = 9
+    perms = torch.tensor(list(itertools.permutations(range(n))), dtype=torch.int32)
+    both("pit_search", [rnd(B, n, n), perms, perms.size(0), n, B, maximize, use_mean, nan(B), torch.zeros(B, dtype=torch.int64)])
+
+
+@pytest.mark.parametrize("n,iters,beta", [(3, 10, 1.0), (5, 200, 1.0), (4, 20, 2.0), (10, 5, 0.5)])
+def test_sinkhorn(n, iters, beta):
+    B = 4
+    C = rnd(B, n, n, scale=3.0)
+    zw = torch.full((B, 2 * iters + 1, n, n), float("nan"), dtype=torch.float64)
+    both("sinkhorn_fwd", [C, zw, nan(B), nan(B, n, n), B, n, beta, iters], tol=1e-5)
+    both("sinkhorn_bwd", [C, zw, rnd(B), nan(B, n, n), B, n, beta, iters], tol=1e-5)
+
+
+def test_sqnorm_and_adam():
+    n = 100003
+    p, g, m, v = rnd(n), rnd(n, scale=3.0), rnd(n, scale=0.1), rnd(n, scale=0.1).abs()
+    sq = torch.zeros(1, dtype=torch.float64)
+    both("sqnorm", [g, sq, n], tol=1e-6)
+    both("adam_step", [p, g, m, v, sq, n, 1e-3, 0.9, 0.999, 1e-8, 0.0, 5.0, 0.5, 3], tol=1e-5)
+    both("adam_step", [p, g, m, v, sq, n, 1e-3, 0.9, 0.999, 1e-8, 0.01, 0.0, 1.0, 4], tol=1e-5)

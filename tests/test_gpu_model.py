@@ -1,0 +1,184 @@
+"""GPU: the drop-in ConvTasNet / criterion API running on libsepkernels.so against (a) the committed golden vectors
+produced by the real reference, (b) the oracle on the same seeded inputs at the paper-best configuration, and
+(c) size-independent properties at BASELINE.json's full size (B=16, 4 s @ 8 kHz).
+Tolerance: 1e-3 relative (north_star: "within 1e-3 relative fp32") on the forward; gradients are judged on the
+flat-vector rel-inf norm against an fp64 reference run (SURVEY.md section 8c noise-floor note)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.make_golden import CONFIGS
+from oracle import fast_port as FP
+from models.conv_tasnet import ConvTasNet
+from criterion.sdr import NegSISDR, SISDR
+from criterion.pit import PIT1d, SinkPIT
+from modules.norm import GlobalLayerNorm
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+PAPER = dict(n_basis=512, kernel_size=16, stride=8, enc_basis="trainable", dec_basis="trainable", enc_nonlinear=None,
+             sep_hidden_channels=512, sep_bottleneck_channels=128, sep_skip_channels=128, sep_kernel_size=3,
+             sep_num_blocks=3, sep_num_layers=8, dilated=True, separable=True, causal=False, sep_nonlinear="prelu",
+             sep_norm=True, mask_nonlinear="sigmoid", n_sources=2)
+
+
+def _rel(a, b):
+    return (a.double().cpu() - b.double()).abs().max().item() / (b.double().abs().max().item() + 1e-30)
+
+
+def _grad_report(model, ref_grads):
+    num = den = 0.0
+    worst = ("", 0.0)
+    for k, p in model.named_parameters():
+        r = ref_grads[k].double()
+        e = (p.grad.double().cpu() - r).abs().max().item()
+        num, den = max(num, e), max(den, r.abs().max().item())
+        rel = e / (r.abs().max().item() + 1e-30)
+        if rel > worst[1]:
+            worst = (k, rel)
+    return num / den, worst
+
+
+@pytest.mark.parametrize("name", ["tiny", "mid"])
+def test_golden_forward_loss_grads(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, "convtasnet_{}.npz".format(name)))
+    model = ConvTasNet(**CONFIGS[name])
+    model.load_state_dict({k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param/")})
+    model.cuda()
+    mixture, sources = torch.from_numpy(g["mixture"]).cuda(), torch.from_numpy(g["sources"]).cuda()
+    est, latent = model.extract_latent(mixture)
+    ref = torch.from_numpy(g["output_f64"])
+    assert est.shape == ref.shape
+    assert _rel(est, ref) <= TOL
+    assert abs(latent.double().sum().item() - float(g["latent_f64_sum"])) <= TOL * float(g["latent_f64_abs_sum"])
+    loss, pattern = PIT1d(NegSISDR(), n_sources=CONFIGS[name]["n_sources"])(est, sources)
+    assert abs(loss.item() - float(g["loss_f64"])) <= TOL * abs(float(g["loss_f64"]))
+    assert np.array_equal(pattern.cpu().numpy(), g["pattern"])
+    loss.backward()
+    flat_rel, worst = _grad_report(model, {k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("grad/")})
+    assert flat_rel <= TOL, "flat gradient rel-inf {:.3e}, worst tensor {}".format(flat_rel, worst)
+    assert worst[1] <= 2e-2, "per-tensor worst {}".format(worst)
+
+
+def test_paper_best_against_oracle():
+    """Paper-best (N512 L16 B128 H512 Sc128 P3 X8 R3), 1 utterance of 4 s @ 8 kHz: the fp64 CPU port is the truth."""
+    torch.manual_seed(111)
+    model = ConvTasNet(**PAPER)
+    p = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    sources = 0.1 * torch.randn(1, 2, 32000, generator=g)
+    mixture = sources.sum(1, keepdim=True)
+    ref_out, ref_loss, ref_pat, ref_grads = FP.train_step(p, PAPER, mixture, sources, dtype=torch.float64)
+    model.cuda()
+    est = model(mixture.cuda())
+    assert _rel(est, ref_out) <= TOL
+    loss, pattern = PIT1d(NegSISDR(), n_sources=2)(est, sources.cuda())
+    assert abs(loss.item() - ref_loss.item()) <= TOL * abs(ref_loss.item())
+    assert torch.equal(pattern.cpu(), ref_pat)
+    loss.backward()
+    flat_rel, worst = _grad_report(model, ref_grads)
+    assert flat_rel <= TOL, "flat gradient rel-inf {:.3e}, worst tensor {}".format(flat_rel, worst)
+
+
+def test_full_size_properties():
+    """BASELINE.json configs[1] size (B=16, T=32000): properties that need no oracle."""
+    torch.manual_seed(111)
+    model = ConvTasNet(**PAPER).cuda()
+    g = torch.Generator().manual_seed(9)
+    sources = (0.1 * torch.randn(16, 2, 32000, generator=g)).cuda()
+    mixture = sources.sum(1, keepdim=True)
+    crit = PIT1d(NegSISDR(), n_sources=2)
+    with torch.no_grad():
+        est = model(mixture)
+        # (1) utterances are independent: a sample processed alone gives the same answer as inside the batch
+        for b in (0, 15):
+            alone = model(mixture[b:b + 1])
+            assert _rel(alone[0], est[b].cpu()) <= 1e-4
+        # (2) linear encoder + gLN => the network is scale-equivariant (eps negligible at this level)
+        est2 = model(3.0 * mixture)
+        assert _rel(est2, (3.0 * est).cpu()) <= 1e-3
+        # (3) PIT is invariant to relabelling the sources and returns the relabelled pattern
+        loss, pattern = crit(est, sources)
+        loss_sw, pattern_sw = crit(est, sources[:, [1, 0]])
+        assert abs(loss.item() - loss_sw.item()) <= 1e-5 * abs(loss.item())
+        assert torch.equal(pattern_sw, 1 - pattern)
+    # (4) directional derivative: <grad, d> matches a central finite difference of the loss along d
+    est = model(mixture)
+    loss, _ = crit(est, sources)
+    loss.backward()
+    params = [p for p in model.parameters()]
+    torch.manual_seed(3)
+    dirs = [torch.randn_like(p) * p.detach().abs().mean().clamp_min(1e-3) for p in params]
+    analytic = sum((p.grad.double() * d.double()).sum().item() for p, d in zip(params, dirs))
+    h = 2e-3
+    vals = []
+    with torch.no_grad():
+        for sgn in (+1, -1):
+            for p, d in zip(params, dirs):
+                p.add_(sgn * h * d)
+            vals.append(crit(model(mixture), sources)[0].double().item())
+            for p, d in zip(params, dirs):
+                p.sub_(sgn * h * d)
+    numeric = (vals[0] - vals[1]) / (2 * h)
+    assert abs(analytic - numeric) <= 3e-2 * abs(numeric) + 1e-3, (analytic, numeric)
+
+
+def test_multichannel_relu_encoder_and_validation_length():
+    """in_channels=2 (4-D input), enc ReLU, a length that needs input padding, B=1 (the validation/test regime)."""
+    cfg = dict(CONFIGS["tiny"], in_channels=2, n_sources=3)
+    torch.manual_seed(1)
+    model = ConvTasNet(**cfg)
+    p = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    x = 0.1 * torch.randn(1, 1, 2, 5003)
+    ref_out, _ = FP.conv_tasnet(x.view(1, 2, 5003).double(), {k: v.double() for k, v in p.items()}, cfg)
+    model.cuda()
+    with torch.no_grad():
+        out = model(x.cuda())
+    assert out.shape == (1, 3, 2, 5003)
+    # reference view semantics: decoder output (B*n_src, in_channels, T) -> (B, n_src, n_mics, T)
+    F_ref = torch.nn.functional
+    assert _rel(out.view(1, 3, 2, 5003), ref_out.view(1, 3, 2, 5003)) <= TOL
+
+
+def test_criteria_on_gpu(golden_dir):
+    g = np.load(os.path.join(golden_dir, "pit_kat.npz"))
+    x, t = torch.from_numpy(g["pit_x"]).cuda(), torch.from_numpy(g["pit_t"]).cuda()
+    loss, pattern = PIT1d(SISDR(), n_sources=2)(x, t)
+    assert abs(loss.item() - (-4.6058)) < 1e-3 and pattern.tolist() == [[1, 0], [1, 0], [0, 1], [0, 1]]
+    x, t = torch.from_numpy(g["sink_x"]).cuda(), torch.from_numpy(g["sink_t"]).cuda()
+    loss, pattern = PIT1d(NegSISDR(), n_sources=3)(x, t)
+    assert abs(loss.item() - 4.4252) < 1e-3 and pattern.tolist() == [[1, 0, 2], [2, 1, 0], [0, 1, 2], [2, 1, 0]]
+    loss, pattern = SinkPIT(NegSISDR(), n_sources=3, coldness=1)(x, t, batch_mean=False)
+    assert np.allclose(loss.cpu().numpy(), [11.1611, 10.4200, 10.5582, 9.9728], atol=1e-3)
+    assert pattern.tolist() == [[2, 0, 2], [0, 1, 0], [0, 1, 2], [2, 1, 0]]
+    x = torch.from_numpy(g["sg_x"]).float().cuda().requires_grad_(True)
+    t = torch.from_numpy(g["sg_t"]).float().cuda()
+    loss, pattern = SinkPIT(NegSISDR(), n_sources=4, coldness=2.0, iteration=20)(x, t)
+    loss.backward()
+    assert abs(loss.item() - float(g["sg_loss"])) < 1e-4 * abs(float(g["sg_loss"])) + 1e-4
+    assert _rel(x.grad, torch.from_numpy(g["sg_grad"])) <= 1e-3
+    assert np.array_equal(pattern.cpu().numpy(), g["sg_pattern"])
+
+
+def test_global_layer_norm_module_on_gpu():
+    torch.manual_seed(0)
+    x = (torch.randn(3, 24, 777) * 2 + 0.3)
+    norm = GlobalLayerNorm(24)
+    with torch.no_grad():
+        norm.norm.weight.add_(0.3 * torch.randn(24)); norm.norm.bias.add_(0.2 * torch.randn(24))
+    ref = torch.nn.GroupNorm(1, 24, eps=1e-12).double()
+    ref.load_state_dict({k: v.double() for k, v in norm.norm.state_dict().items()})
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    (yr ** 2).sum().backward()
+    norm.cuda()
+    xg = x.cuda().requires_grad_(True)
+    y = norm(xg)
+    (y ** 2).sum().backward()
+    assert _rel(y, yr.detach()) <= 1e-4
+    assert _rel(xg.grad, xr.grad) <= 1e-3
+    assert _rel(norm.norm.weight.grad, ref.weight.grad) <= 1e-3
+    assert _rel(norm.norm.bias.grad, ref.bias.grad) <= 1e-3

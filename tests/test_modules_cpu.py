@@ -1,0 +1,162 @@
+"""CPU: the drop-in module layer (models/, criterion/) -- state_dict contract, default initialisation, config round
+trip, error behaviour -- and, through the CPU emulator of the C ABI, forward/loss/gradient agreement with the
+reference golden vectors when driven through the public nn.Module / criterion API."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import sepkernels
+from emulator import EmuBackend
+from oracle.make_golden import CONFIGS
+from models.conv_tasnet import ConvTasNet
+from criterion.sdr import NegSISDR, SISDR, sisdr
+from criterion.pit import PIT1d, SinkPIT, pit
+from modules.norm import GlobalLayerNorm
+
+
+@pytest.fixture()
+def emu():
+    old = sepkernels._set_backend_for_tests(EmuBackend())
+    yield
+    sepkernels._set_backend_for_tests(old)
+
+
+def _golden(golden_dir, name):
+    return np.load(os.path.join(golden_dir, "convtasnet_{}.npz".format(name)))
+
+
+@pytest.mark.parametrize("name", ["tiny", "mid"])
+def test_state_dict_contract_and_default_init(golden_dir, name):
+    g = _golden(golden_dir, name)
+    torch.manual_seed(111)
+    model = ConvTasNet(**CONFIGS[name])
+    sd = model.state_dict()
+    keys = [k[6:] for k in g.files if k.startswith("param/")]
+    assert list(sd.keys()) == keys                      # same names, same order as the reference
+    for k in keys:
+        assert tuple(sd[k].shape) == g["param/" + k].shape, k
+    assert model.num_parameters == int(g["num_parameters"])
+    # same seed -> same default weights as the reference (conv weights were not perturbed in the fixture)
+    for k in ["encoder.conv1d.weight", "separator.bottleneck_conv1d.weight", "separator.mask_conv1d.bias",
+              "separator.tdcn.net.0.net.1.separable_conv1d.depthwise_conv1d.weight", "decoder.conv_transpose1d.weight"]:
+        assert np.array_equal(sd[k].numpy(), g["param/" + k]), k
+    # parameters are views of one flat buffer, [Wo;Ws] adjacent
+    flat = model.flat_parameters()
+    assert flat is not None
+    p = dict(model.named_parameters())
+    pre = "separator.tdcn.net.0.net.0.separable_conv1d."
+    wo, ws = p[pre + "output_pointwise_conv1d.weight"], p[pre + "skip_pointwise_conv1d.weight"]
+    assert wo.data_ptr() + 4 * wo.numel() == ws.data_ptr()
+    assert all(q.data_ptr() % 16 == 0 for q in p.values())
+
+
+def test_config_roundtrip_and_checkpoint(tmp_path):
+    model = ConvTasNet(**CONFIGS["tiny"])
+    cfg = model.get_config()
+    assert cfg["n_basis"] == 64 and cfg["enc_nonlinear"] == "relu" and cfg["n_sources"] == 2 and cfg["in_channels"] == 1
+    package = model.get_package()
+    package["state_dict"] = model.state_dict()
+    path = os.path.join(tmp_path, "best.pth")
+    torch.save(package, path)
+    again = ConvTasNet.build_model(path, load_state_dict=True)
+    for (k1, v1), (k2, v2) in zip(model.state_dict().items(), again.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+
+
+def test_error_behaviour():
+    model = ConvTasNet(**CONFIGS["tiny"])
+    with pytest.raises(ValueError):
+        model(torch.zeros(4000))                                  # bad rank -> ValueError like the reference
+    with pytest.raises(AssertionError):
+        model(torch.zeros(1, 2, 4000))                            # C_in must be 1
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(1, 1, 4000))                            # CPU tensor on the HIP build: loud failure, no fallback
+    with pytest.raises(NotImplementedError):
+        ConvTasNet(64, 16, enc_basis="Fourier", dec_basis="Fourier", enc_nonlinear=None, window_fn="hann",
+                   enc_onesided=True, enc_return_complex=True)
+    with pytest.raises(ValueError):
+        ConvTasNet(**dict(CONFIGS["tiny"], mask_nonlinear="tanh"))
+    with pytest.raises(ValueError):
+        NegSISDR(reduction="max")
+
+
+@pytest.mark.parametrize("name", ["tiny", "mid"])
+def test_module_forward_backward_via_emulator(golden_dir, emu, name):
+    g = _golden(golden_dir, name)
+    model = ConvTasNet(**CONFIGS[name])
+    model.load_state_dict({k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param/")})
+    mixture, sources = torch.from_numpy(g["mixture"]), torch.from_numpy(g["sources"])
+    est, latent = model.extract_latent(mixture)
+    ref = torch.from_numpy(g["output_f64"])
+    assert est.shape == ref.shape
+    assert (est.double() - ref).abs().max() <= 1e-3 * ref.abs().max()          # north-star tolerance
+    assert latent.shape[-1] == (mixture.shape[-1] + (8 - (mixture.shape[-1] - 16) % 8) % 8 - 16) // 8 + 1
+    crit = PIT1d(NegSISDR(), n_sources=CONFIGS[name]["n_sources"])
+    loss, pattern = crit(est, sources)
+    assert abs(loss.item() - float(g["loss_f64"])) <= 1e-3 * abs(float(g["loss_f64"]))
+    assert np.array_equal(pattern.numpy(), g["pattern"])
+    loss.backward()
+    num, den = 0.0, 0.0
+    for k, p in model.named_parameters():
+        r = torch.from_numpy(g["grad/" + k]).double()
+        assert p.grad is not None and p.grad.shape == p.shape, k
+        num = max(num, (p.grad.double() - r).abs().max().item())
+        den = max(den, r.abs().max().item())
+    assert num <= 1e-3 * den
+
+
+def test_pit_and_sinkpit_known_answers(golden_dir, emu):
+    g = np.load(os.path.join(golden_dir, "pit_kat.npz"))
+    x, t = torch.from_numpy(g["pit_x"]), torch.from_numpy(g["pit_t"])
+    loss, pattern = PIT1d(SISDR(), n_sources=2)(x, t)
+    assert abs(loss.item() - (-4.6058)) < 1e-3 and pattern.tolist() == [[1, 0], [1, 0], [0, 1], [0, 1]]
+    x, t = torch.from_numpy(g["sink_x"]), torch.from_numpy(g["sink_t"])
+    loss, pattern = PIT1d(NegSISDR(), n_sources=3)(x, t)
+    assert abs(loss.item() - 4.4252) < 1e-3 and pattern.tolist() == [[1, 0, 2], [2, 1, 0], [0, 1, 2], [2, 1, 0]]
+    loss, pattern = SinkPIT(NegSISDR(), n_sources=3, coldness=1)(x, t, batch_mean=False)
+    assert np.allclose(loss.numpy(), [11.1611, 10.4200, 10.5582, 9.9728], atol=1e-3)
+    assert pattern.tolist() == [[2, 0, 2], [0, 1, 0], [0, 1, 2], [2, 1, 0]]
+    loss, pattern = SinkPIT(SISDR(), n_sources=3, coldness=1)(x, t, batch_mean=False)
+    assert np.allclose(loss.numpy(), g["sinkpit_pos_loss"], atol=1e-3)
+    # generic (non SI-SDR) criterion goes through the per-permutation route
+    def squared_error(a, b, batch_mean=True):
+        l = ((a - b) ** 2).sum(-1).mean(1)
+        return l.mean(0) if batch_mean else l
+    x, t = torch.from_numpy(g["pit_x"]), torch.from_numpy(g["pit_t"])
+    loss, pattern = pit(squared_error, x, t)
+    assert abs(loss.item() - 507.3750) < 1e-3 and pattern.tolist() == [[1, 0], [1, 0], [0, 1], [0, 1]]
+
+
+def test_sinkpit_gradient_via_emulator(golden_dir, emu):
+    g = np.load(os.path.join(golden_dir, "pit_kat.npz"))
+    x = torch.from_numpy(g["sg_x"]).requires_grad_(True)
+    t = torch.from_numpy(g["sg_t"])
+    loss, pattern = SinkPIT(NegSISDR(), n_sources=4, coldness=2.0, iteration=20)(x, t)
+    loss.backward()
+    assert abs(loss.item() - float(g["sg_loss"])) < 1e-6
+    assert np.allclose(x.grad.numpy(), g["sg_grad"], rtol=1e-5, atol=1e-9)
+    assert np.array_equal(pattern.numpy(), g["sg_pattern"])
+
+
+def test_sisdr_shapes_and_gln_via_emulator(golden_dir, emu):
+    g = np.load(os.path.join(golden_dir, "ops.npz"))
+    a, b = torch.from_numpy(g["sdr_x"]), torch.from_numpy(g["sdr_t"])
+    assert np.allclose(NegSISDR()(a, b, batch_mean=False).numpy(), g["sdr_negsisdr"], atol=1e-9)
+    assert sisdr(a[:, 0], b[:, 0]).shape == (3,)
+    assert sisdr(a.unsqueeze(2), b.unsqueeze(2)).shape == (3, 2, 1)
+    norm = GlobalLayerNorm(6).double()
+    with torch.no_grad():
+        norm.norm.weight.copy_(torch.from_numpy(g["gln_w"])); norm.norm.bias.copy_(torch.from_numpy(g["gln_b"]))
+    x = torch.from_numpy(g["gln_x"]).requires_grad_(True)
+    y = norm(x)
+    assert np.allclose(y.detach().numpy(), g["gln_y"], atol=1e-10)
+    ref = torch.nn.GroupNorm(1, 6, eps=1e-12).double()
+    ref.load_state_dict(norm.norm.state_dict())
+    x2 = x.detach().clone().requires_grad_(True)
+    (ref(x2) ** 2).sum().backward()
+    (y ** 2).sum().backward()
+    assert torch.allclose(x.grad, x2.grad, atol=1e-9)
+    assert torch.allclose(norm.norm.weight.grad, ref.weight.grad, atol=1e-9)
+    assert torch.allclose(norm.norm.bias.grad, ref.bias.grad, atol=1e-9)

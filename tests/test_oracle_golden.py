@@ -95,3 +95,21 @@ def test_roofline_constants():
     assert 3 * O.flops_per_frame(cfg) == 29466624
     assert 3 * O.bytes_per_frame(cfg) == 775872
     assert O.num_frames(32000, 16, 8) == 3999
+
+
+@pytest.mark.parametrize("name", ["tiny", "mid"])
+def test_fast_port_matches_reference_and_algebra_oracle(golden_dir, name):
+    """oracle/fast_port.py (what bench.py times as cpu_baseline) against the reference golden vectors."""
+    from oracle import fast_port as FP
+    g = _load(golden_dir, "convtasnet_{}.npz".format(name))
+    cfg = CONFIGS[name]
+    p = _params(g)
+    mixture, sources = torch.from_numpy(g["mixture"]), torch.from_numpy(g["sources"])
+    out, loss, pattern, grads = FP.train_step(p, cfg, mixture, sources, dtype=torch.float64)
+    ref = torch.from_numpy(g["output_f64"])
+    assert (out - ref).abs().max() <= 1e-9 * ref.abs().max()
+    assert abs(loss.item() - float(g["loss_f64"])) < 1e-8
+    assert np.array_equal(pattern.numpy(), g["pattern"])
+    for k, gr in grads.items():
+        r = torch.from_numpy(g["grad/" + k]).double()
+        assert (gr - r).abs().max() <= 2e-6 * r.abs().max() + 1e-12, k
