@@ -81,13 +81,20 @@ def cpu_baseline(sample_steps=2):
     g = torch.Generator().manual_seed(111)
     sources = 0.1 * torch.randn(B, 2, T_SAMPLES, generator=g)
     mixture = sources.sum(1, keepdim=True)
-    cores = torch.get_num_threads()
-    for _ in range(2):                      # oneDNN primitive caches / allocator warm-up
-        FP.train_step(p, PAPER, mixture, sources, dtype=torch.float32)
-    t0 = time.perf_counter()
-    for _ in range(sample_steps):
-        FP.train_step(p, PAPER, mixture, sources, dtype=torch.float32)
-    dt = (time.perf_counter() - t0) / sample_steps
+    all_cores = torch.get_num_threads()
+    best = None
+    for cores in sorted({all_cores, min(all_cores, 32)}, reverse=True):   # oneDNN often peaks below the full core count
+        torch.set_num_threads(cores)
+        for _ in range(2):                  # oneDNN primitive caches / allocator warm-up
+            FP.train_step(p, PAPER, mixture, sources, dtype=torch.float32)
+        t0 = time.perf_counter()
+        for _ in range(sample_steps):
+            FP.train_step(p, PAPER, mixture, sources, dtype=torch.float32)
+        dt_c = (time.perf_counter() - t0) / sample_steps
+        if best is None or dt_c < best[0]:
+            best = (dt_c, cores)
+    torch.set_num_threads(all_cores)
+    dt, cores = best
     frames = B * num_frames(T_SAMPLES, 16, 8)
     return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": "{} timed fwd+PIT+bwd steps (after 2 warm-up) of B={} paper-best utterances, fp32, torch CPU "

@@ -61,8 +61,8 @@ def conv_tasnet(x, p, cfg):
     mask = torch.sigmoid(F.conv1d(h, p["separator.mask_conv1d.weight"], p["separator.mask_conv1d.bias"]))
     latent = w.unsqueeze(1) * mask.view(B, n_src, N, -1)
     xh = F.conv_transpose1d(latent.view(B * n_src, N, -1), p["decoder.conv_transpose1d.weight"], stride=S)
-    xh = xh.view(B, n_src, -1)
-    return F.pad(xh, (-pl, -pr)), latent
+    xh = F.pad(xh.view(B, n_src, Cin, -1), (-pl, -pr))        # crop per channel, then the reference's views
+    return (xh.view(B, n_src, -1) if Cin == 1 else xh), latent
 
 
 def neg_sisdr_pit(est, src, eps=EPS):
