@@ -57,10 +57,19 @@ __device__ __forceinline__ T block_sum_256(T v, T* sm) {
 __device__ __forceinline__ float prelu_f(float x, float a) { return x > 0.f ? x : a * x; }
 __device__ __forceinline__ float prelu_grad(float x, float a) { return x > 0.f ? 1.f : a; }
 
-// mean / rstd of a gLN from its {sum, sumsq} (double) -- biased variance like nn.GroupNorm
+// gLN statistics are accumulated with fp64 atomics into SEP_STATS_SLOTS independent {sum, sumsq} slots per sample
+// (slot = blockIdx & 15) so that the ~10^4 producer blocks of one tensor do not serialise on two addresses.
+#ifndef SEP_STATS_SLOTS
+#define SEP_STATS_SLOTS 16
+#endif
+
+// mean / rstd of a gLN from its slots -- biased variance like nn.GroupNorm.  st points at the sample's first slot.
 __device__ __forceinline__ void gln_mu_rstd(const double* st, double count, float eps, float& mu, float& rstd) {
-    const double m = st[0] / count;
-    double var = st[1] / count - m * m;
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < SEP_STATS_SLOTS; ++k) { s0 += st[2 * k]; s1 += st[2 * k + 1]; }
+    const double m = s0 / count;
+    double var = s1 / count - m * m;
     if (var < 0.0) var = 0.0;
     mu = (float)m;
     rstd = (float)(1.0 / sqrt(var + (double)eps));

@@ -21,20 +21,56 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int BM = 128, BN = 128;
-constexpr int BK = 16;       // contraction rows per chunk (forward / dgrad)
-constexpr int LDA_S = 132;   // As[k][m] row stride (floats): 16B aligned rows, 2-way max on the transposing scalar writes
+constexpr int BK = 32;       // contraction rows per chunk (forward / dgrad): 64 MFMAs per wave between barriers
+constexpr int LDA_S = 132;   // allocated As[k][m] row stride (floats); 16B aligned rows for the float4 (transposed-A) writes
+constexpr int LDA_NT = 129;  // row stride actually used by the non-transposed path: odd -> conflict-free transposing scalar writes
 constexpr int LDB_S = 128;
 
 struct __attribute__((aligned(16))) GemmSmem {
-    float As[2][BK][LDA_S];
-    float Bs[2][BK][LDB_S];
+    float As[2][BK * LDA_S];
+    float Bs[2][BK * LDB_S];
     double red[8];
 };
+
+// One 32-deep chunk of the contraction for a wave's 64x64 tile: 16 k-steps x 4 v_mfma_f32_32x32x2_f32.
+// Operand fragments are fetched from LDS in groups of 4 k-steps, one group ahead of the MFMAs that consume
+// them (two static register sets), so the LDS latency is paid once per chunk instead of once per k-step and
+// the matrix pipe sees 64 back-to-back MFMAs.  A/B are k-major: element (k, i) at base[k*ld + i].
+__device__ __forceinline__ void mfma_chunk32(const float* __restrict__ Ab, const int lda, const float* __restrict__ Bb,
+                                             const int ldb, const int aoff, const int boff, const int lk,
+                                             f32x16& c00, f32x16& c01, f32x16& c10, f32x16& c11) {
+    float fa0[4][2], fb0[4][2], fa1[4][2], fb1[4][2];
+#define SEP_LOAD_FRAGS(FA, FB, g)                                         \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                    \
+        const int ka = 2 * (4 * (g) + ks) + lk;                           \
+        FA[ks][0] = Ab[ka * lda + aoff];                                  \
+        FA[ks][1] = Ab[ka * lda + aoff + 32];                             \
+        FB[ks][0] = Bb[ka * ldb + boff];                                  \
+        FB[ks][1] = Bb[ka * ldb + boff + 32];                             \
+    }
+#define SEP_MFMA_GROUP(FA, FB)                                                            \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                    \
+        c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[ks][0], FB[ks][0], c00, 0, 0, 0);   \
+        c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[ks][0], FB[ks][1], c01, 0, 0, 0);   \
+        c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[ks][1], FB[ks][0], c10, 0, 0, 0);   \
+        c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[ks][1], FB[ks][1], c11, 0, 0, 0);   \
+    }
+    SEP_LOAD_FRAGS(fa0, fb0, 0)
+    SEP_LOAD_FRAGS(fa1, fb1, 1)
+    SEP_MFMA_GROUP(fa0, fb0)
+    SEP_LOAD_FRAGS(fa0, fb0, 2)
+    SEP_MFMA_GROUP(fa1, fb1)
+    SEP_LOAD_FRAGS(fa1, fb1, 3)
+    SEP_MFMA_GROUP(fa0, fb0)
+    SEP_MFMA_GROUP(fa1, fb1)
+#undef SEP_LOAD_FRAGS
+#undef SEP_MFMA_GROUP
+}
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
-__global__ __launch_bounds__(256) void pw_gemm_kernel(const sep_gemm_desc d) {
+__global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const sep_gemm_desc d) {
     __shared__ GemmSmem sm;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
@@ -81,17 +117,18 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const sep_gemm_desc d) {
     // ---- per-block prologue constants ------------------------------------------------
     float mu = 0.f, rstd = 1.f, alpha_p = 0.f, mg = 0.f, mgx = 0.f;
     const int pro = d.pro_mode;
-    if (pro == SEP_PRO_GLN || pro == SEP_PRO_GLN_PRELU || pro == SEP_PRO_GLN_BWD) gln_mu_rstd(d.pro_stats + 2 * b, d.count, d.eps, mu, rstd);
+    if (pro == SEP_PRO_GLN || pro == SEP_PRO_GLN_PRELU || pro == SEP_PRO_GLN_BWD) gln_mu_rstd(d.pro_stats + (size_t)b * SEP_STATS_SLOTS * 2, d.count, d.eps, mu, rstd);
     if (pro == SEP_PRO_PRELU || pro == SEP_PRO_GLN_PRELU || pro == SEP_PRO_GLN_BWD) alpha_p = d.pro_alpha[0];
     if (pro == SEP_PRO_GLN_BWD) { mg = d.pro_bsum[2 * b]; mgx = d.pro_bsum[2 * b + 1]; }
     float dalpha_pro = 0.f;
 
     // ---- thread -> staging coordinates -------------------------------------------------
-    const int br = tid >> 5, bc4 = tid & 31;   // B tile: rows br, br+8 ; float4 column bc4
-    const int am = tid >> 2, ak4 = tid & 3;    // A tile (non-trans): rows am, am+64 ; float4 along k
+    const int br = tid >> 5, bc4 = tid & 31;   // B tile: rows br + 8i (i<4) ; float4 column bc4
+    const int am = tid >> 3, ak4 = tid & 7;    // A tile (non-trans): rows am + 32i (i<4) ; float4 along k
     const int nk = d.K / BK;
+    const int lda_s = d.trans_a ? LDA_S : LDA_NT;
 
-    float4 ra[2], rb[2], rx[2];
+    float4 ra[4], rb[4], rx[4];
 
     auto load_global = [&](int kc) {
         const int k0 = kc * BK;
@@ -105,7 +142,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const sep_gemm_desc d) {
         }
         (void)second;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 4; ++i) {
             const size_t off = ((size_t)b * Ksrc + krow + br + 8 * i) * d.ldt + t0 + 4 * bc4;
             rb[i] = ld4(Xs + off);
             if (pro == SEP_PRO_GLN_BWD) rx[i] = ld4(d.pro_aux + off);
@@ -113,15 +150,15 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const sep_gemm_desc d) {
         if (d.trans_a) {
             // A is [K][M]: row k, float4 along m
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < 4; ++i) {
                 const int mm = m0 + 4 * bc4;
                 if (mm < d.M) ra[i] = ld4(As_ + (size_t)(krow + br + 8 * i) * d.M + mm);
                 else ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int mm = m0 + am + 64 * i;
+            for (int i = 0; i < 4; ++i) {
+                const int mm = m0 + am + 32 * i;
                 if (mm < d.M) ra[i] = ld4(As_ + (size_t)mm * Ksrc + krow + 4 * ak4);
                 else ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -131,7 +168,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const sep_gemm_desc d) {
     auto store_lds = [&](int kc, int buf) {
         const int k0 = kc * BK;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 4; ++i) {
             float v[4] = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
             const int kg = k0 + br + 8 * i;   // global contraction row (parameter index of gamma/beta)
             if (pro == SEP_PRO_PRELU) {
@@ -165,19 +202,19 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const sep_gemm_desc d) {
                     st4(d.pro_store + off, make_float4(v[0], v[1], v[2], v[3]));
                 }
             }
-            st4(&sm.Bs[buf][br + 8 * i][4 * bc4], make_float4(v[0], v[1], v[2], v[3]));
+            st4(&sm.Bs[buf][(br + 8 * i) * LDB_S + 4 * bc4], make_float4(v[0], v[1], v[2], v[3]));
         }
         if (d.trans_a) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) st4(&sm.As[buf][br + 8 * i][4 * bc4], ra[i]);
+            for (int i = 0; i < 4; ++i) st4(&sm.As[buf][(br + 8 * i) * LDA_S + 4 * bc4], ra[i]);
         } else {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int mm = am + 64 * i;
-                sm.As[buf][4 * ak4 + 0][mm] = ra[i].x;
-                sm.As[buf][4 * ak4 + 1][mm] = ra[i].y;
-                sm.As[buf][4 * ak4 + 2][mm] = ra[i].z;
-                sm.As[buf][4 * ak4 + 3][mm] = ra[i].w;
+            for (int i = 0; i < 4; ++i) {
+                const int mm = am + 32 * i;
+                sm.As[buf][(4 * ak4 + 0) * LDA_NT + mm] = ra[i].x;
+                sm.As[buf][(4 * ak4 + 1) * LDA_NT + mm] = ra[i].y;
+                sm.As[buf][(4 * ak4 + 2) * LDA_NT + mm] = ra[i].z;
+                sm.As[buf][(4 * ak4 + 3) * LDA_NT + mm] = ra[i].w;
             }
         }
     };
@@ -198,18 +235,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const sep_gemm_desc d) {
     for (int kc = 0; kc < nk; ++kc) {
         const int cur = kc & 1;
         if (kc + 1 < nk) load_global(kc + 1);
-#pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            const int ka = 2 * kk + lk;
-            const float a0 = sm.As[cur][ka][wr * 64 + l31];
-            const float a1 = sm.As[cur][ka][wr * 64 + 32 + l31];
-            const float b0 = sm.Bs[cur][ka][wc * 64 + l31];
-            const float b1 = sm.Bs[cur][ka][wc * 64 + 32 + l31];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
+        mfma_chunk32(sm.As[cur], lda_s, sm.Bs[cur], LDB_S, wr * 64 + l31, wc * 64 + l31, lk, acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
         if (kc + 1 < nk) store_lds(kc + 1, cur ^ 1);
         __syncthreads();
     }
@@ -276,7 +302,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const sep_gemm_desc d) {
     if (ef & SEP_EPI_STATS_PRELU) {
         const double s = block_sum_256<double>((double)st_s, sm.red);
         const double ss = block_sum_256<double>((double)st_ss, sm.red);
-        if (tid == 0) { atomicAdd(d.epi_stats + 2 * b, s); atomicAdd(d.epi_stats + 2 * b + 1, ss); }
+        if (tid == 0) { double* st = d.epi_stats + ((size_t)b * SEP_STATS_SLOTS + (blockIdx.x & (SEP_STATS_SLOTS - 1))) * 2; atomicAdd(st, s); atomicAdd(st + 1, ss); }
     }
     if (ef & SEP_EPI_PRELU_BWD) {
         const double s = block_sum_256<double>((double)dalpha_e, sm.red);
@@ -295,11 +321,11 @@ constexpr int WK = 32;      // frames per chunk (one 128-byte line per operand r
 constexpr int LDW_S = 129;  // k-major LDS row stride: odd -> conflict-free transposing writes AND fragment reads
 
 struct __attribute__((aligned(16))) WgradSmem {
-    float Gs[2][WK][LDW_S];
-    float Xs[2][WK][LDW_S];
+    float Gs[2][WK * LDW_S];
+    float Xs[2][WK * LDW_S];
 };
 
-__global__ __launch_bounds__(256) void pw_wgrad_kernel(const sep_wgrad_desc d) {
+__global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(const sep_wgrad_desc d) {
     __shared__ WgradSmem sm;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
@@ -326,6 +352,8 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const sep_wgrad_desc d) {
     const float alpha_x = (d.x_mode == SEP_PRO_PRELU || d.x_mode == SEP_PRO_GLN_PRELU) ? d.x_alpha[0] : 0.f;
     float4 rg[4], rx[4];
     float xsc[4], xsh[4];
+    int stat_b = -1;            // sample whose gLN constants are cached below
+    float stat_mu = 0.f, stat_rstd = 1.f;
 
     auto chunk_valid = [&](long c) -> bool { return (int)(c % cps_t) * WK < d.T; };
 
@@ -355,10 +383,9 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const sep_wgrad_desc d) {
                 const int bx = b / d.x_div;
                 x = ld4(d.X + ((size_t)bx * d.N + n) * d.ldt + t0 + 4 * lc4);
                 if (d.x_mode == SEP_PRO_GLN || d.x_mode == SEP_PRO_GLN_PRELU) {
-                    float mu, rstd;
-                    gln_mu_rstd(d.x_stats + 2 * bx, d.count, d.eps, mu, rstd);
-                    xsc[i] = d.x_gamma[n] * rstd;
-                    xsh[i] = d.x_beta[n] - mu * xsc[i];
+                    if (bx != stat_b) { gln_mu_rstd(d.x_stats + (size_t)bx * SEP_STATS_SLOTS * 2, d.count, d.eps, stat_mu, stat_rstd); stat_b = bx; }
+                    xsc[i] = d.x_gamma[n] * stat_rstd;
+                    xsh[i] = d.x_beta[n] - stat_mu * xsc[i];
                 }
             }
             rx[i] = x;
@@ -369,10 +396,10 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const sep_wgrad_desc d) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int mm = lr + 32 * i;
-            sm.Gs[buf][4 * lc4 + 0][mm] = rg[i].x;
-            sm.Gs[buf][4 * lc4 + 1][mm] = rg[i].y;
-            sm.Gs[buf][4 * lc4 + 2][mm] = rg[i].z;
-            sm.Gs[buf][4 * lc4 + 3][mm] = rg[i].w;
+            sm.Gs[buf][(4 * lc4 + 0) * LDW_S + mm] = rg[i].x;
+            sm.Gs[buf][(4 * lc4 + 1) * LDW_S + mm] = rg[i].y;
+            sm.Gs[buf][(4 * lc4 + 2) * LDW_S + mm] = rg[i].z;
+            sm.Gs[buf][(4 * lc4 + 3) * LDW_S + mm] = rg[i].w;
             float v[4] = {rx[i].x, rx[i].y, rx[i].z, rx[i].w};
             const bool row_ok = (n0 + mm) < d.N;
             if (d.x_mode == SEP_PRO_PRELU) {
@@ -385,10 +412,10 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const sep_wgrad_desc d) {
                     v[q] = row_ok ? (u * xsc[i] + xsh[i]) : 0.f;
                 }
             }
-            sm.Xs[buf][4 * lc4 + 0][mm] = v[0];
-            sm.Xs[buf][4 * lc4 + 1][mm] = v[1];
-            sm.Xs[buf][4 * lc4 + 2][mm] = v[2];
-            sm.Xs[buf][4 * lc4 + 3][mm] = v[3];
+            sm.Xs[buf][(4 * lc4 + 0) * LDW_S + mm] = v[0];
+            sm.Xs[buf][(4 * lc4 + 1) * LDW_S + mm] = v[1];
+            sm.Xs[buf][(4 * lc4 + 2) * LDW_S + mm] = v[2];
+            sm.Xs[buf][(4 * lc4 + 3) * LDW_S + mm] = v[3];
         }
     };
 
@@ -414,22 +441,11 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const sep_wgrad_desc d) {
         long cn = c + 1;
         while (cn < c_end && !chunk_valid(cn)) ++cn;
         if (cn < c_end) load_global(cn);
-#pragma unroll 4
-        for (int kk = 0; kk < WK / 2; ++kk) {
-            const int ka = 2 * kk + lk;
-            const float a0 = sm.Gs[cur][ka][wr * 64 + l31];
-            const float a1 = sm.Gs[cur][ka][wr * 64 + 32 + l31];
-            const float b0 = sm.Xs[cur][ka][wc * 64 + l31];
-            const float b1 = sm.Xs[cur][ka][wc * 64 + 32 + l31];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
+        mfma_chunk32(sm.Gs[cur], LDW_S, sm.Xs[cur], LDW_S, wr * 64 + l31, wc * 64 + l31, lk, acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
         if (do_bias && tid < BM) {
             float sacc = 0.f;
 #pragma unroll 8
-            for (int k = 0; k < WK; ++k) sacc += sm.Gs[cur][k][tid];
+            for (int k = 0; k < WK; ++k) sacc += sm.Gs[cur][k * LDW_S + tid];
             bias_acc += sacc;
         }
         if (cn < c_end) store_lds(cur ^ 1);

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void encoder_fwd_kernel(const float* __restric
     }
     const double ds = block_sum_256<double>((double)s, red);
     const double dss = block_sum_256<double>((double)ss, red);
-    if (tid == 0) { atomicAdd(stats + 2 * b, ds); atomicAdd(stats + 2 * b + 1, dss); }
+    if (tid == 0) { double* st = stats + ((size_t)b * SEP_STATS_SLOTS + (blockIdx.x & (SEP_STATS_SLOTS - 1))) * 2; atomicAdd(st, ds); atomicAdd(st + 1, dss); }
 }
 
 // frames[bp][c*L+k][f] = xpad[bp][c][S f + k] (f < F), 0 for F <= f < ldt
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
         b = (int)(g / ((long)ntile * C));
         t0 = tile * DW_TT;
         float mu, rstd;
-        gln_mu_rstd(stats1 + 2 * b, (double)C * T, eps, mu, rstd);
+        gln_mu_rstd(stats1 + (size_t)b * SEP_STATS_SLOTS * 2, (double)C * T, eps, mu, rstd);
         const float a1 = alpha1[0];
         const float sc = gamma1[c] * rstd, sh = beta1[c] - mu * sc;
         const float* arow = a + ((size_t)b * C + c) * ldt;
@@ -164,8 +164,9 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
             double x0 = wred[i][0], x1 = wred[i][1];
             for (int k = i + 1; k < 4; ++k)
                 if (wb[k] == wb[i]) { x0 += wred[k][0]; x1 += wred[k][1]; wb[k] = -1; }
-            atomicAdd(stats2 + 2 * wb[i], x0);
-            atomicAdd(stats2 + 2 * wb[i] + 1, x1);
+            double* st = stats2 + ((size_t)wb[i] * SEP_STATS_SLOTS + (blockIdx.x & (SEP_STATS_SLOTS - 1))) * 2;
+            atomicAdd(st, x0);
+            atomicAdd(st + 1, x1);
         }
     }
 }
@@ -200,8 +201,8 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(
         b = (int)(g / ((long)ntile * C));
         t0 = tile * DW_TT;
         float mu1, r1, mu2, r2;
-        gln_mu_rstd(stats1 + 2 * b, (double)C * T, eps, mu1, r1);
-        gln_mu_rstd(stats2 + 2 * b, (double)C * T, eps, mu2, r2);
+        gln_mu_rstd(stats1 + (size_t)b * SEP_STATS_SLOTS * 2, (double)C * T, eps, mu1, r1);
+        gln_mu_rstd(stats2 + (size_t)b * SEP_STATS_SLOTS * 2, (double)C * T, eps, mu2, r2);
         const float a1 = alpha1[0], a2 = alpha2[0];
         sc1 = gamma1[c] * r1; sh1 = beta1[c] - mu1 * sc1;
         const float g2 = gamma2[c];
@@ -269,53 +270,63 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(
 }
 
 // =====================================================================================
-// gLN backward, second stage.  One block per sample; one wave reduces one (b, c) row of partials at a time.
-// nq in {2, 8}.  Outputs: pbeta[b][c], pgamma[b][c], bsum[b][2]; nq == 8: pextra[b] = [db[C] | dw[C][3]], palpha[b].
+// gLN backward, second stage, in two small kernels.
+//  rows:   one WAVE per (b, c) row reduces that row's per-tile partials (nq in {2, 8}) and writes
+//          pbeta[b][c] = R1, pgamma[b][c] = r_b (R2 - mu_b R1), nq == 8: pextra[b] = [db[C] | dw[C][3]] and
+//          scratch[b][c] = rowpart[..][6] total (PReLU slope partial)
+//  sample: one block per sample sums over channels: bsum[b] = {sum_c gamma_c R1, sum_c gamma_c pgamma} / count,
+//          palpha[b] = sum_c scratch[b][c]
 // =====================================================================================
-__global__ __launch_bounds__(256) void gln_bwd_finalize_kernel(const float* __restrict__ rowpart, int ntile, int nq,
-                                                               const double* __restrict__ stats,
-                                                               const float* __restrict__ gamma, double count, float eps,
-                                                               float* __restrict__ bsum, float* __restrict__ pbeta,
-                                                               float* __restrict__ pgamma, float* __restrict__ pextra,
-                                                               float* __restrict__ palpha, int C) {
-    __shared__ float red[4][3];
-    const int b = blockIdx.x;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+__global__ __launch_bounds__(256) void gln_bwd_finalize_rows_kernel(const float* __restrict__ rowpart, int ntile, int nq,
+                                                                    const double* __restrict__ stats, double count, float eps,
+                                                                    float* __restrict__ pbeta, float* __restrict__ pgamma,
+                                                                    float* __restrict__ pextra, float* __restrict__ scratch,
+                                                                    int B, int C) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);      // b*C + c
+    if (row >= (long)B * C) return;
+    const int b = (int)(row / C), c = (int)(row % C);
     float mu, rstd;
-    gln_mu_rstd(stats + 2 * b, count, eps, mu, rstd);
+    gln_mu_rstd(stats + (size_t)b * SEP_STATS_SLOTS * 2, count, eps, mu, rstd);
     const int rowlen = ntile * nq;
-    float sg = 0.f, sgx = 0.f, sal = 0.f;
-    for (int c = wv; c < C; c += 4) {
-        const float* rp = rowpart + ((size_t)b * C + c) * rowlen;
-        float acc = 0.f;
-        for (int i = lane; i < rowlen; i += 64) acc += rp[i];     // i % nq == lane % nq (nq divides 64)
-        for (int o = nq; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
-        // lanes 0..nq-1 now hold the totals of quantity q = lane
-        const float R1 = __shfl(acc, 0, 64), R2 = __shfl(acc, 1, 64);
-        const float pg = rstd * (R2 - mu * R1);
-        if (lane == 0) {
-            pbeta[(size_t)b * C + c] = R1;
-            pgamma[(size_t)b * C + c] = pg;
-            const float gc = gamma[c];
-            sg += gc * R1; sgx += gc * pg;
-        }
-        if (nq == 8) {
-            // per-sample slab of 4C floats: [ db[C] | dw[C][3] ]
-            if (lane == 2) pextra[(size_t)b * 4 * C + c] = acc;
-            if (lane >= 3 && lane < 6) pextra[(size_t)b * 4 * C + C + (size_t)c * 3 + (lane - 3)] = acc;
-            if (lane == 6) sal += acc;
-        }
+    const float* rp = rowpart + (size_t)row * rowlen;
+    float acc = 0.f;
+    for (int i = lane; i < rowlen; i += 64) acc += rp[i];            // i % nq == lane % nq (nq divides 64)
+    for (int o = nq; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    // every lane now holds the total of quantity q = lane % nq
+    const float R1 = __shfl(acc, 0, 64), R2 = __shfl(acc, 1, 64);
+    if (lane == 0) {
+        pbeta[row] = R1;
+        pgamma[row] = rstd * (R2 - mu * R1);
     }
-    // combine the 4 waves (lane 0 holds sg/sgx, lane 6 holds sal)
-    const float sal0 = __shfl(sal, 6, 64);
-    if (lane == 0) { red[wv][0] = sg; red[wv][1] = sgx; red[wv][2] = sal0; }
-    __syncthreads();
+    if (nq == 8) {
+        // per-sample slab of 4C floats: [ db[C] | dw[C][3] ]
+        if (lane == 2) pextra[(size_t)b * 4 * C + c] = acc;
+        if (lane >= 3 && lane < 6) pextra[(size_t)b * 4 * C + C + (size_t)c * 3 + (lane - 3)] = acc;
+        if (lane == 6) scratch[row] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void gln_bwd_finalize_sample_kernel(const float* __restrict__ pbeta, const float* __restrict__ pgamma,
+                                                                      const float* __restrict__ gamma, const float* __restrict__ scratch,
+                                                                      double count, float* __restrict__ bsum,
+                                                                      float* __restrict__ palpha, int C) {
+    __shared__ double red[4];
+    const int b = blockIdx.x;
+    double sg = 0.0, sgx = 0.0, sal = 0.0;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float gc = gamma[c];
+        sg += (double)(gc * pbeta[(size_t)b * C + c]);
+        sgx += (double)(gc * pgamma[(size_t)b * C + c]);
+        if (palpha) sal += (double)scratch[(size_t)b * C + c];
+    }
+    const double tg = block_sum_256<double>(sg, red);
+    const double tgx = block_sum_256<double>(sgx, red);
+    const double tal = block_sum_256<double>(sal, red);
     if (threadIdx.x == 0) {
-        const float tg = red[0][0] + red[1][0] + red[2][0] + red[3][0];
-        const float tgx = red[0][1] + red[1][1] + red[2][1] + red[3][1];
-        bsum[2 * b] = (float)((double)tg / count);
-        bsum[2 * b + 1] = (float)((double)tgx / count);
-        if (nq == 8 && palpha) palpha[b] = red[0][2] + red[1][2] + red[2][2] + red[3][2];
+        bsum[2 * b] = (float)(tg / count);
+        bsum[2 * b + 1] = (float)(tgx / count);
+        if (palpha) palpha[b] = (float)tal;
     }
 }
 
@@ -329,7 +340,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(float* __restrict__ dvw, 
     const int t4 = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (t4 >= ldt) return;
     float mu, rstd;
-    gln_mu_rstd(stats0 + 2 * b, count, eps, mu, rstd);
+    gln_mu_rstd(stats0 + (size_t)b * SEP_STATS_SLOTS * 2, count, eps, mu, rstd);
     const float gc = gamma0[c], mg = bsum0[2 * b], mgx = bsum0[2 * b + 1];
     const size_t off = (size_t)row * ldt + t4;
     const float4 g = ld4(dvw + off), ww = ld4(w + off), dm = ld4(dwm + off);
@@ -501,7 +512,7 @@ __global__ __launch_bounds__(256) void gln_stats_kernel(const float* __restrict_
     }
     const double ds = block_sum_256<double>((double)s, red);
     const double dss = block_sum_256<double>((double)ss, red);
-    if (threadIdx.x == 0) { atomicAdd(stats + 2 * b, ds); atomicAdd(stats + 2 * b + 1, dss); }
+    if (threadIdx.x == 0) { double* st = stats + ((size_t)b * SEP_STATS_SLOTS + ((blockIdx.x + blockIdx.y) & (SEP_STATS_SLOTS - 1))) * 2; atomicAdd(st, ds); atomicAdd(st + 1, dss); }
 }
 
 __global__ __launch_bounds__(256) void gln_apply_kernel(const float* __restrict__ x, const double* __restrict__ stats,
@@ -513,7 +524,7 @@ __global__ __launch_bounds__(256) void gln_apply_kernel(const float* __restrict_
     const int t4 = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (t4 >= ldt) return;
     float mu, rstd;
-    gln_mu_rstd(stats + 2 * b, count, eps, mu, rstd);
+    gln_mu_rstd(stats + (size_t)b * SEP_STATS_SLOTS * 2, count, eps, mu, rstd);
     const float sc = gamma[c] * rstd, sh = beta[c] - mu * sc;
     const float4 v = ld4(x + (size_t)row * ldt + t4);
     float4 o;
@@ -556,7 +567,7 @@ __global__ __launch_bounds__(256) void gln_bwd_apply_kernel(const float* __restr
     const int t4 = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (t4 >= ldt) return;
     float mu, rstd;
-    gln_mu_rstd(stats + 2 * b, count, eps, mu, rstd);
+    gln_mu_rstd(stats + (size_t)b * SEP_STATS_SLOTS * 2, count, eps, mu, rstd);
     const float gc = gamma[c], mg = bsum[2 * b], mgx = bsum[2 * b + 1];
     const size_t off = (size_t)row * ldt + t4;
     const float4 g = ld4(dy + off), v = ld4(x + off);
@@ -642,9 +653,12 @@ extern "C" int sep_gln_bwd_finalize(const float* rowpart, int ntile, int nq, con
     SEP_REQUIRE(rowpart && stats && gamma && bsum && pbeta && pgamma, "sep_gln_bwd_finalize: null pointer");
     SEP_REQUIRE(nq == 2 || nq == 8, "sep_gln_bwd_finalize: nq must be 2 or 8 (got %d)", nq);
     SEP_REQUIRE(nq == 2 || pextra, "sep_gln_bwd_finalize: nq == 8 needs pextra");
-    // pextra layout for nq == 8: B slabs of 4C floats [db[C] | dw[C][3]] followed by palpha[B]
+    // pextra layout for nq == 8: B slabs of 4C floats [db[C] | dw[C][3]], then palpha[B], then B*C floats of scratch
     float* palpha = (nq == 8) ? pextra + (size_t)B * C * 4 : nullptr;
-    hipLaunchKernelGGL(gln_bwd_finalize_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, rowpart, ntile, nq, stats, gamma, count, eps, bsum, pbeta, pgamma, pextra, palpha, C);
+    float* scratch = (nq == 8) ? palpha + B : nullptr;
+    const long rows = (long)B * C;
+    hipLaunchKernelGGL(gln_bwd_finalize_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rowpart, ntile, nq, stats, count, eps, pbeta, pgamma, pextra, scratch, B, C);
+    hipLaunchKernelGGL(gln_bwd_finalize_sample_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pbeta, pgamma, gamma, scratch, count, bsum, palpha, C);
     SEP_CHECK_LAUNCH("sep_gln_bwd_finalize");
     return 0;
 }

@@ -38,7 +38,7 @@ class Encoder(nn.Module):
         F = (T - L) // S + 1
         ldt = _round_up(F, 128)
         w = torch.empty(B, N, ldt, device=x.device, dtype=x.dtype)
-        stats = torch.zeros(B, 2, device=x.device, dtype=torch.float64)
+        stats = torch.zeros(B, sepkernels.STATS_SLOTS, 2, device=x.device, dtype=torch.float64)
         K.encoder_fwd(x, self.conv1d.weight, w, stats, B, Cin, T, N, L, S, F, ldt, 0, self.nonlinear)
         out = torch.empty(B, N, F, device=x.device, dtype=x.dtype)
         K.repack(w, ldt, out, F, B * N, F)

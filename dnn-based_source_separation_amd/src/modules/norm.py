@@ -28,7 +28,7 @@ class _GlobalLayerNormFn(torch.autograd.Function):
             K.repack(x3, T, xp, ldt, B * C, T)
         else:
             xp = x3
-        stats = torch.zeros(B, 2, device=x.device, dtype=torch.float64)
+        stats = torch.zeros(B, sepkernels.STATS_SLOTS, 2, device=x.device, dtype=torch.float64)
         K.gln_stats(xp, stats, B, C, T, ldt)
         yp = torch.empty_like(xp)
         K.gln_apply(xp, stats, gamma, beta, yp, B, C, T, ldt, C * T, eps)

@@ -18,7 +18,7 @@ import math
 
 import torch
 
-from . import (EPI_PRELU_BWD, EPI_RESIDUAL, EPI_ROWSUMS, EPI_ROWSUMS_PRELU, EPI_SIGMOID, EPI_STATS_PRELU, PRO_GLN,
+from . import (STATS_SLOTS, EPI_PRELU_BWD, EPI_RESIDUAL, EPI_ROWSUMS, EPI_ROWSUMS_PRELU, EPI_SIGMOID, EPI_STATS_PRELU, PRO_GLN,
                PRO_GLN_BWD, PRO_GLN_PRELU, PRO_NONE, PRO_PRELU, backend)
 
 
@@ -108,7 +108,7 @@ def forward(cfg, P, mixture, want_latent=False, save=True):
     nl = len(layers)
     f32 = dict(device=dev, dtype=mixture.dtype)   # always fp32 in the product; the CPU emulator tests also run fp64
 
-    stats = torch.zeros(2 * nl + 1, B, 2, device=dev, dtype=torch.float64)
+    stats = torch.zeros(2 * nl + 1, B, STATS_SLOTS, 2, device=dev, dtype=torch.float64)
     w = torch.empty(B, N, ldt, **f32)
     K.encoder_fwd(mixture, P["encoder.conv1d.weight"], w, stats[0], B, Cin, T_in, N, L, S, F, ldt, geo.pad_left, relu)
 
@@ -270,7 +270,7 @@ def backward(cfg, P, sv, d_est, G):
         bsum1 = torch.empty(B, 2, **f32)
         pbeta1 = torch.empty(B, H, **f32)
         pgamma1 = torch.empty(B, H, **f32)
-        pextra = torch.empty(B * 4 * H + B, **f32)
+        pextra = torch.empty(B * 4 * H + B + B * H, **f32)
         K.gln_bwd_finalize(rp1, nt1024, 8, st1, g1, cnt, teps, bsum1, pbeta1, pgamma1, pextra, B, H)
         K.reduce_slabs([
             (pbeta2, 0, G[sp + "norm1d.norm.bias"], H, B, H, 0, 1.0),

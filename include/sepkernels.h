@@ -13,8 +13,9 @@
  *   - activations are fp32, layout (batch, channel, frame) as in the reference, frame
  *     contiguous, with a padded row stride `ldt` (floats, multiple of 128).  Frames
  *     [T, ldt) of every tensor a kernel WRITES are set to 0.
- *   - gLN statistics are carried as double[B][2] = {sum, sum of squares} over the valid
- *     (C, T) region of a sample; accumulated with fp64 atomics, so the caller zeroes them.
+ *   - gLN statistics are carried as double[B][SEP_STATS_SLOTS][2]: SEP_STATS_SLOTS independent
+ *     {sum, sum of squares} accumulators over the valid (C, T) region of a sample (producer blocks
+ *     spread their fp64 atomics over the slots; consumers add the slots up).  The caller zeroes them.
  *   - the caller owns every buffer (inputs, outputs, saved activations, workspaces).
  *     The library keeps no global mutable state, is re-entrant, never synchronises the
  *     device and launches only on the stream it is given (the caller selects the device).
@@ -32,7 +33,8 @@ extern "C" {
 
 typedef void* sep_stream_t; /* hipStream_t */
 
-#define SEP_ABI_VERSION 1
+#define SEP_ABI_VERSION 2
+#define SEP_STATS_SLOTS 16
 
 int sep_version(void);
 const char* sep_last_error(void);
@@ -170,7 +172,7 @@ int sep_dwconv_bwd(const float* dv2, const float* z, const float* a, const doubl
  *   R1 = sum_tiles rowpart[..][0], R2 = sum_tiles rowpart[..][1]
  *   pbeta[b][c] = R1 ; pgamma[b][c] = r_b*(R2 - mu_b*R1)
  *   bsum[b] = { sum_c gamma_c*R1 / count , sum_c gamma_c*pgamma[b][c] / count }
- *   nq == 8 additionally (pextra holds B*C*4 + B floats):
+ *   nq == 8 additionally (pextra holds B*C*4 + B + B*C floats; the last B*C are scratch):
  *     pextra[b*4C + c]           = sum_tiles rowpart[..][2]      (depthwise bias gradient, per sample)
  *     pextra[b*4C + C + 3c + k]  = sum_tiles rowpart[..][3+k]    (depthwise weight gradient [C][3], per sample)
  *     pextra[B*4C + b]           = sum_{c,tiles} rowpart[..][6]  (PReLU slope gradient, per sample) */

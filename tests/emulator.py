@@ -25,9 +25,24 @@ def _prelu_grad(x, a):
     return torch.where(x > 0, torch.ones_like(x), a.reshape(()).to(x.dtype) * torch.ones_like(x))
 
 
+SLOTS = 16
+
+
+def _tot(stats):
+    """(B, SLOTS, 2) slotted accumulators -> (B, 2) totals"""
+    return stats.reshape(-1, SLOTS, 2).sum(1)
+
+
+def _acc(stats, s, ss):
+    v = stats.reshape(-1, SLOTS, 2)
+    v[:, 0, 0] += s.double()
+    v[:, 0, 1] += ss.double()
+
+
 def _mu_rstd(stats, count, eps, dtype):
-    m = stats[:, 0] / count
-    var = (stats[:, 1] / count - m * m).clamp_min(0.0)
+    st = _tot(stats)
+    m = st[:, 0] / count
+    var = (st[:, 1] / count - m * m).clamp_min(0.0)
     return m.to(dtype).view(-1, 1, 1), (1.0 / torch.sqrt(var + eps)).to(dtype).view(-1, 1, 1)
 
 
@@ -82,8 +97,7 @@ class EmuBackend:
         Mf = m_split if m_split else M
         if epi_flags & EPI_STATS_PRELU:
             u = torch.where(valid, _prelu(y, epi_alpha), torch.zeros_like(y))
-            epi_stats[:, 0] += u.sum((1, 2)).double()
-            epi_stats[:, 1] += (u * u).sum((1, 2)).double()
+            _acc(epi_stats, u.sum((1, 2)), (u * u).sum((1, 2)))
         if epi_flags & EPI_RESIDUAL:
             y = torch.cat([y[:, :Mf] + epi_res.reshape(B, -1, ldt)[:, :Mf], y[:, Mf:]], 1)
         if epi_flags & EPI_SIGMOID:
@@ -175,8 +189,7 @@ class EmuBackend:
             y = y.clamp_min(0)
         y[:, :, F:] = 0
         w.reshape(B, N, ldt).copy_(y)
-        stats[:, 0] += y.sum((1, 2)).double()
-        stats[:, 1] += (y * y).sum((1, 2)).double()
+        _acc(stats, y.sum((1, 2)), (y * y).sum((1, 2)))
 
     def decoder_fwd(self, w, m, D, est, latent, B, n_src, N, Cout, L, S, F, ldt, Tout, pad_left):
         wh = w.reshape(B, 1, N, ldt) * m.reshape(B, n_src, N, ldt)
@@ -219,8 +232,7 @@ class EmuBackend:
         out.zero_()
         out[:, :, :T] = zz
         u = _prelu(zz, alpha2)
-        stats2[:, 0] += u.sum((1, 2)).double()
-        stats2[:, 1] += (u * u).sum((1, 2)).double()
+        _acc(stats2, u.sum((1, 2)), (u * u).sum((1, 2)))
 
     def dwconv_bwd(self, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bsum2, wd, dv1, rowpart, B, C, T,
                    ldt, dilation, eps):
@@ -277,6 +289,7 @@ class EmuBackend:
             slab[:, :C] = rp[..., 2]
             slab[:, C:] = rp[..., 3:6].reshape(B, 3 * C)
             pe[B * 4 * C:B * 4 * C + B] = rp[..., 6].sum(1)
+            pe[B * 4 * C + B:B * 4 * C + B + B * C] = rp[..., 6].reshape(-1)      # per-row scratch of the two-kernel finalize
 
     def head_bwd(self, dvw, w, dwm, stats0, gamma0, bsum0, B, C, T, ldt, count, eps, relu):
         dt = w.dtype
@@ -293,8 +306,7 @@ class EmuBackend:
     # ------------------------------------------------------------------ stand-alone gLN
     def gln_stats(self, x, stats, B, C, T, ldt):
         v = x.reshape(B, C, ldt)[:, :, :T]
-        stats[:, 0] += v.sum((1, 2)).double()
-        stats[:, 1] += (v * v).sum((1, 2)).double()
+        _acc(stats, v.sum((1, 2)), (v * v).sum((1, 2)))
 
     def gln_apply(self, x, stats, gamma, beta, y, B, C, T, ldt, count, eps):
         mu, rstd = _mu_rstd(stats, count, eps, x.dtype)
