@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const sep_gemm_desc d) 
     const int lda_s = d.trans_a ? LDA_S : LDA_NT;
 
     float4 ra[4], rb[4], rx[4];
+    float pgam[4], pbet[4];     // gLN affine of the rows being staged, fetched together with the tile (one chunk ahead)
 
     auto load_global = [&](int kc) {
         const int k0 = kc * BK;
@@ -146,6 +147,10 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const sep_gemm_desc d) 
             const size_t off = ((size_t)b * Ksrc + krow + br + 8 * i) * d.ldt + t0 + 4 * bc4;
             rb[i] = ld4(Xs + off);
             if (pro == SEP_PRO_GLN_BWD) rx[i] = ld4(d.pro_aux + off);
+            if (pro >= SEP_PRO_GLN) {
+                pgam[i] = d.pro_gamma[k0 + br + 8 * i];
+                pbet[i] = (pro == SEP_PRO_GLN_BWD) ? 0.f : d.pro_beta[k0 + br + 8 * i];
+            }
         }
         if (d.trans_a) {
             // A is [K][M]: row k, float4 along m
@@ -175,8 +180,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const sep_gemm_desc d) 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = prelu_f(v[q], alpha_p);
             } else if (pro == SEP_PRO_GLN || pro == SEP_PRO_GLN_PRELU) {
-                const float sc = d.pro_gamma[kg] * rstd;
-                const float sh = d.pro_beta[kg] - mu * sc;
+                const float sc = pgam[i] * rstd;
+                const float sh = pbet[i] - mu * sc;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float u = (pro == SEP_PRO_GLN_PRELU) ? prelu_f(v[q], alpha_p) : v[q];
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const sep_gemm_desc d) 
                 }
             } else if (pro == SEP_PRO_GLN_BWD) {
                 const float a4[4] = {rx[i].x, rx[i].y, rx[i].z, rx[i].w};
-                const float gk = d.pro_gamma[kg];
+                const float gk = pgam[i];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int t = t0 + 4 * bc4 + q;
@@ -241,49 +246,69 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const sep_gemm_desc d) 
     }
 
     // ---- epilogue ----------------------------------------------------------------------
+    // Every global READ the epilogue needs (bias, residual, accumulate-into, aux) is issued for a whole 32-row half
+    // before the first store of that half: a load placed after a store cannot be hoisted by the compiler (possible
+    // alias), and 64 dependent load->store round trips per thread were the dominant cost of the first version.
     const int ef = d.epi_flags;
     const float alpha_e = (ef & (SEP_EPI_STATS_PRELU | SEP_EPI_PRELU_BWD | SEP_EPI_ROWSUMS_PRELU)) ? d.epi_alpha[0] : 0.f;
     float st_s = 0.f, st_ss = 0.f, dalpha_e = 0.f;
     const int Mfirst = d.m_split ? d.m_split : d.M;
+    const bool second = d.m_split && m0 >= d.m_split;        // block-uniform: m_split is a multiple of BM
+    const int Mdst = second ? d.M - d.m_split : Mfirst;
+    const int rowoff = second ? d.m_split : 0;
+    float* __restrict__ dst = second ? d.Y2 : d.Y;
+    const bool acc_this = d.accumulate && (second || !d.m_split);
+    const bool use_res = (ef & SEP_EPI_RESIDUAL) && !second;
+    const bool use_aux = (ef & (SEP_EPI_PRELU_BWD | SEP_EPI_ROWSUMS)) != 0;
+    const int tcol = t0 + wc * 64 + l31;
 
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
+        float ext[16][2], aux[16][2], bs[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            float rs1 = 0.f, rs2 = 0.f;
-            if (row < d.M) {
-                const float bias = d.bias ? d.bias[row] : 0.f;
-                const bool second = d.m_split && row >= d.m_split;
-                float* dst = second ? d.Y2 : d.Y;
-                const size_t rbase = second ? ((size_t)b * (d.M - d.m_split) + (row - d.m_split)) * d.ldt
-                                            : ((size_t)b * Mfirst + row) * d.ldt;
-                const size_t abase = ((size_t)b * d.M + row) * d.ldt;   // aux / residual tensors have M rows
-                const bool acc_this = d.accumulate && (second || !d.m_split);
+            const bool ok = row < d.M;
+            bs[r] = (ok && d.bias) ? d.bias[row] : 0.f;
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const int t = t0 + wc * 64 + ni * 32 + l31;
-                    const bool valid = t < d.T;
-                    float v = acc[mi][ni][r] + bias;
-                    if (ef & SEP_EPI_STATS_PRELU) {
-                        const float u = prelu_f(v, alpha_e);
-                        if (valid) { st_s += u; st_ss += u * u; }
-                    }
-                    if ((ef & SEP_EPI_RESIDUAL) && !second) v += d.epi_res[((size_t)b * Mfirst + row) * d.ldt + t];   // residual has the Y-part's row count
-                    if (ef & SEP_EPI_SIGMOID) v = 1.f / (1.f + expf(-v));
-                    if (ef & SEP_EPI_PRELU_BWD) {
-                        const float s = d.epi_aux[abase + t];
-                        if (valid && s <= 0.f) dalpha_e += v * s;
-                        v *= prelu_grad(s, alpha_e);
-                    }
-                    if (ef & SEP_EPI_ROWSUMS) {
-                        float u = d.epi_aux[abase + t];
-                        if (ef & SEP_EPI_ROWSUMS_PRELU) u = prelu_f(u, alpha_e);
-                        if (valid) { rs1 += v; rs2 += v * u; }
-                    }
-                    if (acc_this) v += dst[rbase + t];
-                    dst[rbase + t] = valid ? v : 0.f;
+            for (int ni = 0; ni < 2; ++ni) {
+                const int t = tcol + 32 * ni;
+                float e = 0.f, a = 0.f;
+                if (ok) {
+                    if (use_res) e = d.epi_res[((size_t)b * Mfirst + row) * d.ldt + t];   // residual has the Y-part's row count
+                    if (acc_this) e += dst[((size_t)b * Mdst + (row - rowoff)) * d.ldt + t];
+                    if (use_aux) a = d.epi_aux[((size_t)b * d.M + row) * d.ldt + t];
                 }
+                ext[r][ni] = e; aux[r][ni] = a;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            const bool ok = row < d.M;
+            float rs1 = 0.f, rs2 = 0.f;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int t = tcol + 32 * ni;
+                const bool valid = t < d.T;
+                float v = acc[mi][ni][r] + bs[r];
+                if (ef & SEP_EPI_STATS_PRELU) {
+                    const float u = prelu_f(v, alpha_e);
+                    if (valid && ok) { st_s += u; st_ss += u * u; }
+                }
+                if (ef & SEP_EPI_SIGMOID) v = 1.f / (1.f + expf(-v));
+                if (ef & SEP_EPI_PRELU_BWD) {
+                    const float sv = aux[r][ni];
+                    if (valid && ok && sv <= 0.f) dalpha_e += v * sv;
+                    v *= prelu_grad(sv, alpha_e);
+                }
+                if (ef & SEP_EPI_ROWSUMS) {
+                    float u = aux[r][ni];
+                    if (ef & SEP_EPI_ROWSUMS_PRELU) u = prelu_f(u, alpha_e);
+                    if (valid && ok) { rs1 += v; rs2 += v * u; }
+                }
+                v += ext[r][ni];
+                if (ok) dst[((size_t)b * Mdst + (row - rowoff)) * d.ldt + t] = valid ? v : 0.f;
             }
             if (ef & SEP_EPI_ROWSUMS) {
                 // reduce over the 32 lanes that share (row): xor stays inside a 32-lane half
@@ -292,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const sep_gemm_desc d) 
                     rs1 += __shfl_xor(rs1, o, 64);
                     rs2 += __shfl_xor(rs2, o, 64);
                 }
-                if (l31 == 0 && row < d.M) {
+                if (l31 == 0 && ok) {
                     float* rp = d.epi_rowpart + (((size_t)b * d.M + row) * (d.ldt / 64) + (t0 + wc * 64) / 64) * 2;
                     rp[0] = rs1; rp[1] = rs2;
                 }
@@ -354,6 +379,14 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(const sep_wgrad_desc d
     float xsc[4], xsh[4];
     int stat_b = -1;            // sample whose gLN constants are cached below
     float stat_mu = 0.f, stat_rstd = 1.f;
+    float xgam[4] = {0.f, 0.f, 0.f, 0.f}, xbet[4] = {0.f, 0.f, 0.f, 0.f};   // rows are fixed per thread: fetch once
+    if (d.x_mode == SEP_PRO_GLN || d.x_mode == SEP_PRO_GLN_PRELU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + lr + 32 * i;
+            if (n < d.N) { xgam[i] = d.x_gamma[n]; xbet[i] = d.x_beta[n]; }
+        }
+    }
 
     auto chunk_valid = [&](long c) -> bool { return (int)(c % cps_t) * WK < d.T; };
 
@@ -384,8 +417,8 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(const sep_wgrad_desc d
                 x = ld4(d.X + ((size_t)bx * d.N + n) * d.ldt + t0 + 4 * lc4);
                 if (d.x_mode == SEP_PRO_GLN || d.x_mode == SEP_PRO_GLN_PRELU) {
                     if (bx != stat_b) { gln_mu_rstd(d.x_stats + (size_t)bx * SEP_STATS_SLOTS * 2, d.count, d.eps, stat_mu, stat_rstd); stat_b = bx; }
-                    xsc[i] = d.x_gamma[n] * stat_rstd;
-                    xsh[i] = d.x_beta[n] - stat_mu * xsc[i];
+                    xsc[i] = xgam[i] * stat_rstd;
+                    xsh[i] = xbet[i] - stat_mu * xsc[i];
                 }
             }
             rx[i] = x;
