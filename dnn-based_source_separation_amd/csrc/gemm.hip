@@ -15,6 +15,7 @@
 // normalised tensors v1, v2 of the reference never exist in HBM.  Blocks that share an X column tile are
 // placed on the same XCD (blockIdx % 8) so the tile is fetched from HBM once and re-read from that L2.
 #include "common.hpp"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -69,6 +70,126 @@ __device__ __forceinline__ void mfma_chunk32(const float* __restrict__ Ab, const
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// Shared epilogue of the GEMM kernels.  acc[mi][ni] are the wave's four 32x32 accumulators.
+//
+// The MFMA C layout gives a lane ONE column of 16 different rows, i.e. 4-byte stores.  Measured on the first
+// version: 64 dword stores per lane made the epilogue 40 % of the short-K GEMMs (store-issue bound, ~2 TB/s).
+// So each wave transposes its tile through LDS (32 rows at a time, wave-private region, conflict-free
+// ds_write_b32 / ds_read_b128) and every global access of the epilogue -- result stores, residual / accumulate /
+// aux reads -- is a float4 covering 256 contiguous bytes per 16 lanes.  All reads of a half tile are issued before
+// its first store (a load placed after a store cannot be hoisted: possible alias).
+constexpr int EPI_LD = 68;                         // floats per transposed row (64 + 4: keeps float4 alignment)
+constexpr int EPI_WAVE_FLOATS = 32 * EPI_LD;       // LDS floats one wave needs
+
+__device__ __forceinline__ void gemm_epilogue(const sep_gemm_desc& d, f32x16 (&acc)[2][2], const int b, const int m0,
+                                              const int t0, const int wr, const int wc, const int lk, const int l31,
+                                              const int tid, float* lds, double* red) {
+    const int lane = tid & 63, wid = tid >> 6;
+    const int ef = d.epi_flags;
+    const float alpha_e = (ef & (SEP_EPI_STATS_PRELU | SEP_EPI_PRELU_BWD | SEP_EPI_ROWSUMS_PRELU)) ? d.epi_alpha[0] : 0.f;
+    float st_s = 0.f, st_ss = 0.f, dalpha_e = 0.f;
+    const int Mfirst = d.m_split ? d.m_split : d.M;
+    const bool second = d.m_split && m0 >= d.m_split;        // block-uniform: m_split is a multiple of BM
+    const int Mdst = second ? d.M - d.m_split : Mfirst;
+    const int rowoff = second ? d.m_split : 0;
+    float* __restrict__ dst = second ? d.Y2 : d.Y;
+    const bool acc_this = d.accumulate && (second || !d.m_split);
+    const bool use_res = (ef & SEP_EPI_RESIDUAL) && !second;
+    const bool use_aux = (ef & (SEP_EPI_PRELU_BWD | SEP_EPI_ROWSUMS)) != 0;
+    float* Tw = lds + wid * EPI_WAVE_FLOATS;
+    const int rsub = lane >> 4, c4 = lane & 15;              // read-back: 4 rows x 16 float4 per pass
+    const int tc = t0 + wc * 64 + 4 * c4;
+
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        // ---- transpose: registers -> LDS (C layout) --------------------------------------------
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * lk;
+            Tw[rl * EPI_LD + l31] = acc[mi][0][r];
+            Tw[rl * EPI_LD + 32 + l31] = acc[mi][1][r];
+        }
+        __builtin_amdgcn_wave_barrier();       // LDS is in-order per wave; this only pins the compiler's order
+        // ---- gather every global read of this half ---------------------------------------------
+        float4 ext[8], aux[8];
+        float bs[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = m0 + wr * 64 + mi * 32 + it * 4 + rsub;
+            const bool ok = row < d.M;
+            bs[it] = (ok && d.bias) ? d.bias[row] : 0.f;
+            float4 e = make_float4(0.f, 0.f, 0.f, 0.f), a = e;
+            if (ok) {
+                if (use_res) e = ld4(d.epi_res + ((size_t)b * Mfirst + row) * d.ldt + tc);   // residual has the Y-part's row count
+                if (acc_this) {
+                    const float4 o = ld4(dst + ((size_t)b * Mdst + (row - rowoff)) * d.ldt + tc);
+                    e.x += o.x; e.y += o.y; e.z += o.z; e.w += o.w;
+                }
+                if (use_aux) a = ld4(d.epi_aux + ((size_t)b * d.M + row) * d.ldt + tc);
+            }
+            ext[it] = e; aux[it] = a;
+        }
+        // ---- compute + float4 stores -------------------------------------------------------------
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int rl = it * 4 + rsub;
+            const int row = m0 + wr * 64 + mi * 32 + rl;
+            const bool ok = row < d.M;
+            const float4 tv = ld4(Tw + rl * EPI_LD + 4 * c4);
+            float v[4] = {tv.x + bs[it], tv.y + bs[it], tv.z + bs[it], tv.w + bs[it]};
+            const float ex[4] = {ext[it].x, ext[it].y, ext[it].z, ext[it].w};
+            const float ax[4] = {aux[it].x, aux[it].y, aux[it].z, aux[it].w};
+            float rs1 = 0.f, rs2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool valid = (tc + e) < d.T;
+                if (ef & SEP_EPI_STATS_PRELU) {
+                    const float u = prelu_f(v[e], alpha_e);
+                    if (valid && ok) { st_s += u; st_ss += u * u; }
+                }
+                if (ef & SEP_EPI_SIGMOID) v[e] = 1.f / (1.f + expf(-v[e]));
+                if (ef & SEP_EPI_PRELU_BWD) {
+                    if (valid && ok && ax[e] <= 0.f) dalpha_e += v[e] * ax[e];
+                    v[e] *= prelu_grad(ax[e], alpha_e);
+                }
+                if (ef & SEP_EPI_ROWSUMS) {
+                    const float u = (ef & SEP_EPI_ROWSUMS_PRELU) ? prelu_f(ax[e], alpha_e) : ax[e];
+                    if (valid && ok) { rs1 += v[e]; rs2 += v[e] * u; }
+                }
+                v[e] = valid ? v[e] + ex[e] : 0.f;
+            }
+#ifdef SEP_ABL_NO_EPI_STORE
+            if (ok && v[0] == 123.456f)
+#else
+            if (ok)
+#endif
+                st4(dst + ((size_t)b * Mdst + (row - rowoff)) * d.ldt + tc, make_float4(v[0], v[1], v[2], v[3]));
+            if (ef & SEP_EPI_ROWSUMS) {
+                // the 16 lanes with equal (lane >> 4) share this row: xor offsets < 16 stay inside the group
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) {
+                    rs1 += __shfl_xor(rs1, o, 64);
+                    rs2 += __shfl_xor(rs2, o, 64);
+                }
+                if (c4 == 0 && ok) {
+                    float* rp = d.epi_rowpart + (((size_t)b * d.M + row) * (d.ldt / 64) + (t0 + wc * 64) / 64) * 2;
+                    rp[0] = rs1; rp[1] = rs2;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (ef & SEP_EPI_STATS_PRELU) {
+        const double s = block_sum_256<double>((double)st_s, red);
+        const double ss = block_sum_256<double>((double)st_ss, red);
+        if (tid == 0) { double* st = d.epi_stats + ((size_t)b * SEP_STATS_SLOTS + (blockIdx.x & (SEP_STATS_SLOTS - 1))) * 2; atomicAdd(st, s); atomicAdd(st + 1, ss); }
+    }
+    if (ef & SEP_EPI_PRELU_BWD) {
+        const double s = block_sum_256<double>((double)dalpha_e, red);
+        if (tid == 0) atomicAdd(d.epi_dalpha, s);
+    }
+}
 
 __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const sep_gemm_desc d) {
     __shared__ GemmSmem sm;
@@ -240,103 +361,201 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const sep_gemm_desc d) 
     for (int kc = 0; kc < nk; ++kc) {
         const int cur = kc & 1;
         if (kc + 1 < nk) load_global(kc + 1);
+#ifndef SEP_ABL_NO_MFMA
         mfma_chunk32(sm.As[cur], lda_s, sm.Bs[cur], LDB_S, wr * 64 + l31, wc * 64 + l31, lk, acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+#endif
         if (kc + 1 < nk) store_lds(kc + 1, cur ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue ----------------------------------------------------------------------
-    // Every global READ the epilogue needs (bias, residual, accumulate-into, aux) is issued for a whole 32-row half
-    // before the first store of that half: a load placed after a store cannot be hoisted by the compiler (possible
-    // alias), and 64 dependent load->store round trips per thread were the dominant cost of the first version.
-    const int ef = d.epi_flags;
-    const float alpha_e = (ef & (SEP_EPI_STATS_PRELU | SEP_EPI_PRELU_BWD | SEP_EPI_ROWSUMS_PRELU)) ? d.epi_alpha[0] : 0.f;
-    float st_s = 0.f, st_ss = 0.f, dalpha_e = 0.f;
-    const int Mfirst = d.m_split ? d.m_split : d.M;
-    const bool second = d.m_split && m0 >= d.m_split;        // block-uniform: m_split is a multiple of BM
-    const int Mdst = second ? d.M - d.m_split : Mfirst;
-    const int rowoff = second ? d.m_split : 0;
-    float* __restrict__ dst = second ? d.Y2 : d.Y;
-    const bool acc_this = d.accumulate && (second || !d.m_split);
-    const bool use_res = (ef & SEP_EPI_RESIDUAL) && !second;
-    const bool use_aux = (ef & (SEP_EPI_PRELU_BWD | SEP_EPI_ROWSUMS)) != 0;
-    const int tcol = t0 + wc * 64 + l31;
-
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        float ext[16][2], aux[16][2], bs[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            const bool ok = row < d.M;
-            bs[r] = (ok && d.bias) ? d.bias[row] : 0.f;
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int t = tcol + 32 * ni;
-                float e = 0.f, a = 0.f;
-                if (ok) {
-                    if (use_res) e = d.epi_res[((size_t)b * Mfirst + row) * d.ldt + t];   // residual has the Y-part's row count
-                    if (acc_this) e += dst[((size_t)b * Mdst + (row - rowoff)) * d.ldt + t];
-                    if (use_aux) a = d.epi_aux[((size_t)b * d.M + row) * d.ldt + t];
-                }
-                ext[r][ni] = e; aux[r][ni] = a;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            const bool ok = row < d.M;
-            float rs1 = 0.f, rs2 = 0.f;
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int t = tcol + 32 * ni;
-                const bool valid = t < d.T;
-                float v = acc[mi][ni][r] + bs[r];
-                if (ef & SEP_EPI_STATS_PRELU) {
-                    const float u = prelu_f(v, alpha_e);
-                    if (valid && ok) { st_s += u; st_ss += u * u; }
-                }
-                if (ef & SEP_EPI_SIGMOID) v = 1.f / (1.f + expf(-v));
-                if (ef & SEP_EPI_PRELU_BWD) {
-                    const float sv = aux[r][ni];
-                    if (valid && ok && sv <= 0.f) dalpha_e += v * sv;
-                    v *= prelu_grad(sv, alpha_e);
-                }
-                if (ef & SEP_EPI_ROWSUMS) {
-                    float u = aux[r][ni];
-                    if (ef & SEP_EPI_ROWSUMS_PRELU) u = prelu_f(u, alpha_e);
-                    if (valid && ok) { rs1 += v; rs2 += v * u; }
-                }
-                v += ext[r][ni];
-                if (ok) dst[((size_t)b * Mdst + (row - rowoff)) * d.ldt + t] = valid ? v : 0.f;
-            }
-            if (ef & SEP_EPI_ROWSUMS) {
-                // reduce over the 32 lanes that share (row): xor stays inside a 32-lane half
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) {
-                    rs1 += __shfl_xor(rs1, o, 64);
-                    rs2 += __shfl_xor(rs2, o, 64);
-                }
-                if (l31 == 0 && ok) {
-                    float* rp = d.epi_rowpart + (((size_t)b * d.M + row) * (d.ldt / 64) + (t0 + wc * 64) / 64) * 2;
-                    rp[0] = rs1; rp[1] = rs2;
-                }
-            }
-        }
-    }
-    if (ef & SEP_EPI_STATS_PRELU) {
-        const double s = block_sum_256<double>((double)st_s, sm.red);
-        const double ss = block_sum_256<double>((double)st_ss, sm.red);
-        if (tid == 0) { double* st = d.epi_stats + ((size_t)b * SEP_STATS_SLOTS + (blockIdx.x & (SEP_STATS_SLOTS - 1))) * 2; atomicAdd(st, s); atomicAdd(st + 1, ss); }
-    }
-    if (ef & SEP_EPI_PRELU_BWD) {
-        const double s = block_sum_256<double>((double)dalpha_e, sm.red);
-        if (tid == 0) atomicAdd(d.epi_dalpha, s);
-    }
+    __syncthreads();                                    // K-loop LDS reads are done: the staging area becomes the transpose buffer
+    gemm_epilogue(d, acc, b, m0, t0, wr, wc, lk, l31, tid, &sm.As[0][0], sm.red);
     if (pro == SEP_PRO_GLN_BWD && rt == 0) {
         const double s = block_sum_256<double>((double)dalpha_pro, sm.red);
         if (tid == 0) atomicAdd(d.pro_dalpha, s);
     }
+}
+
+
+// ======================================================================================
+// Direct-to-LDS pipelined GEMM (the fast path).
+//
+// The staged kernel above keeps ONE chunk of operands in flight (registers) per workgroup; with ~3 us of HBM latency
+// under load and 1.7 us of MFMA work per chunk it is latency-bound (measured: removing every MFMA changed its run
+// time by < 35 %).  Here both operands go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip) through a
+// ring of NST = 4 stages of 16 contraction rows: three chunks are always in flight per workgroup, waits are counted
+// (s_waitcnt vmcnt(8/4/0)) and the only barrier per chunk is a raw s_barrier, so the DMA queue is never drained
+// inside the loop.  The elementwise prologue (PReLU / gLN affine) moves from the staging registers to the B
+// fragments after the ds_read, with the per-row affine precomputed once per workgroup in LDS.
+//   A k-major ([K][M], input-gradient form): rows copied verbatim, fragments by conflict-free ds_read_b32.
+//   A row-major ([M][K], forward form): 16-byte granules copied with an XOR swizzle on the SOURCE address (the LDS
+//   image of a DMA is lane-linear), fragments by two ds_read_b128 per 32-row block; the contraction index is
+//   permuted (lane half lk owns k = 8*lk .. 8*lk+7 of the chunk) identically for A and B, which a sum allows.
+// ======================================================================================
+constexpr int DK = 16;
+constexpr int NST = 4;
+constexpr int DMAXK = 1024;
+
+struct __attribute__((aligned(16))) DirectSmem {
+    float As[NST][DK * 128];
+    float Bs[NST][DK * 128];
+    float sc[DMAXK];
+    float sh[DMAXK];
+    double red[8];
+};
+
+__device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <bool TRANS_A>
+__global__ __launch_bounds__(256, 2) void pw_gemm_direct_kernel(const sep_gemm_desc d) {
+    __shared__ DirectSmem sm;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: the DMA's LDS base goes to M0 without a waterfall loop
+    const int wr = wid >> 1, wc = wid & 1;
+    const int lk = lane >> 5, l31 = lane & 31;
+
+    const int NR = (d.M + BM - 1) / BM;
+    const int ntile_t = d.ldt / BN;
+    const int NC = d.B * ntile_t;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, j = bid >> 3;
+    const int rt = j % NR;
+    const int ct = (j / NR) * 8 + xcd;
+    if (ct >= NC) return;
+    const int b = ct / ntile_t;
+    const int t0 = (ct % ntile_t) * BN;
+    const int m0 = rt * BM;
+    const int pro = d.pro_mode;
+    const int nk = d.K / DK;
+
+    // per-row affine of the prologue, once per workgroup
+    float alpha_p = 0.f;
+    if (pro == SEP_PRO_PRELU || pro == SEP_PRO_GLN_PRELU) alpha_p = d.pro_alpha[0];
+    if (pro == SEP_PRO_GLN || pro == SEP_PRO_GLN_PRELU) {
+        float mu, rstd;
+        gln_mu_rstd(d.pro_stats + (size_t)b * SEP_STATS_SLOTS * 2, d.count, d.eps, mu, rstd);
+        for (int k = tid; k < d.K; k += 256) {
+            const float scv = d.pro_gamma[k] * rstd;
+            sm.sc[k] = scv;
+            sm.sh[k] = d.pro_beta[k] - mu * scv;
+        }
+    }
+
+    // this wave's share of one stage: 2 DMA instructions for A, 2 for B (1 KiB each)
+    auto issue = [&](int kc, int stage) {
+#ifdef SEP_ABL_NO_LOADS
+        if (kc >= 0) return;
+#endif
+        const int k0 = kc * DK;
+        const float* Xs = d.X;
+        const float* As_ = d.A;
+        int krow = k0, Ksrc = d.K;
+        if (d.k_split) {
+            if (k0 >= d.k_split) { Xs = d.X2; As_ = d.A2; krow = k0 - d.k_split; Ksrc = d.K - d.k_split; }
+            else { Ksrc = d.k_split; }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int r2 = 4 * wid + 2 * q;                       // first of the two k rows this instruction covers
+            const float* gB = Xs + ((size_t)b * Ksrc + krow + r2 + lk) * d.ldt + t0 + 4 * l31;
+            glds16(gB, &sm.Bs[stage][r2 * 128]);
+            if (TRANS_A) {
+                int mm = m0 + 4 * l31;
+                if (mm > d.M - 4) mm = d.M - 4;                   // rows past M are never stored; keep the read in bounds
+                const float* gA = As_ + (size_t)(krow + r2 + lk) * d.M + mm;
+                glds16(gA, &sm.As[stage][r2 * 128]);
+            } else {
+                // [128 m][16 k] image, 64-byte rows; instruction covers 16 rows; granule p of row r holds k-chunk p ^ ((r>>2)&3)
+                const int g16 = 2 * wid + q;
+                const int r = lane >> 2, pch = lane & 3;
+                int mm = m0 + 16 * g16 + r;
+                if (mm > d.M - 1) mm = d.M - 1;
+                const int c = pch ^ ((r >> 2) & 3);
+                const float* gA = As_ + (size_t)mm * Ksrc + krow + 4 * c;
+                glds16(gA, &sm.As[stage][g16 * 256]);
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < nk) issue(s, s);
+
+    for (int kc = 0; kc < nk; ++kc) {
+        const int stage = kc & (NST - 1);
+        const int rem = nk - 1 - kc;                              // chunks issued after this one that may stay in flight
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        // every wave is past the reads of stage kc-1 -> its buffer can be refilled with chunk kc+3
+        if (kc + NST - 1 < nk) issue(kc + NST - 1, (kc + NST - 1) & (NST - 1));
+
+        const float* Ab = sm.As[stage];
+        const float* Bb = sm.Bs[stage];
+        float fa[2][8], fb[2][8];
+        if (TRANS_A) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                fa[0][kk] = Ab[(8 * lk + kk) * 128 + wr * 64 + l31];
+                fa[1][kk] = Ab[(8 * lk + kk) * 128 + wr * 64 + 32 + l31];
+            }
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int m = wr * 64 + mi * 32 + l31;
+                const int sw = (m >> 2) & 3;
+                const float* p0 = Ab + m * 16 + 4 * ((2 * lk) ^ sw);
+                const float* p1 = Ab + m * 16 + 4 * ((2 * lk + 1) ^ sw);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { fa[mi][e] = p0[e]; fa[mi][4 + e] = p1[e]; }
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            fb[0][kk] = Bb[(8 * lk + kk) * 128 + wc * 64 + l31];
+            fb[1][kk] = Bb[(8 * lk + kk) * 128 + wc * 64 + 32 + l31];
+        }
+        if (pro != SEP_PRO_NONE) {
+            const int kbase = kc * DK + 8 * lk;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                float scv = 1.f, shv = 0.f;
+                if (pro >= SEP_PRO_GLN) { scv = sm.sc[kbase + kk]; shv = sm.sh[kbase + kk]; }
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    float v = fb[ni][kk];
+                    if (pro == SEP_PRO_PRELU || pro == SEP_PRO_GLN_PRELU) v = prelu_f(v, alpha_p);
+                    fb[ni][kk] = v * scv + shv;
+                }
+            }
+        }
+#ifndef SEP_ABL_NO_MFMA
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][kk], fb[0][kk], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][kk], fb[1][kk], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][kk], fb[0][kk], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][kk], fb[1][kk], acc[1][1], 0, 0, 0);
+        }
+#endif
+    }
+    __syncthreads();
+#ifdef SEP_ABL_NO_EPI
+    if (acc[0][0][0] + acc[0][1][3] + acc[1][0][5] + acc[1][1][7] == 123.456f) d.Y[tid] = 1.f;
+#else
+    gemm_epilogue(d, acc, b, m0, t0, wr, wc, lk, l31, tid, &sm.As[0][0], sm.red);
+#endif
 }
 
 // ======================================================================================
@@ -565,7 +784,17 @@ extern "C" int sep_pw_gemm(const sep_gemm_desc* d, sep_stream_t stream) {
     const int NR = ceil_div(d->M, BM);
     const int NC = d->B * (d->ldt / BN);
     const int grid = 8 * NR * ceil_div(NC, 8);
-    hipLaunchKernelGGL(pw_gemm_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
+    // fast path: direct-to-LDS pipelined kernel; the register-staged kernel remains for the gLN-backward prologue
+    // (it needs a second input tile and writes one back) and for shapes outside the fast path's limits
+    static const bool force_staged = getenv("SEPK_FORCE_STAGED") != nullptr;
+    const bool direct_ok = !force_staged && d->pro_mode != SEP_PRO_GLN_BWD && d->K % DK == 0 && d->k_split % DK == 0 &&
+                           (d->pro_mode < SEP_PRO_GLN || d->K <= DMAXK) && d->M >= 4 && d->M % 4 == 0;
+    if (direct_ok && d->trans_a)
+        hipLaunchKernelGGL(pw_gemm_direct_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
+    else if (direct_ok)
+        hipLaunchKernelGGL(pw_gemm_direct_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
+    else
+        hipLaunchKernelGGL(pw_gemm_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
     SEP_CHECK_LAUNCH("sep_pw_gemm");
     return 0;
 }
