@@ -1,0 +1,82 @@
+"""CPU, world_size 2, gloo: the data-parallel train step (sepkernels/train.py).  Utterances are sharded across ranks,
+each rank runs forward + PIT + backward locally, ONE all-reduce of the flat gradient buffer, then clip + Adam.
+Checked: (1) ranks end with bit-identical parameters; (2) they equal a single-process step on the concatenated
+batch (mean of equal-sized rank means == global mean), i.e. the reference's nn.DataParallel result.
+Kernels are the CPU emulator here (no GPU in this container); the collective logic is what is under test."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = dict(n_basis=64, kernel_size=16, stride=8, enc_basis="trainable", dec_basis="trainable", enc_nonlinear="relu",
+           sep_hidden_channels=128, sep_bottleneck_channels=64, sep_skip_channels=64, sep_kernel_size=3, sep_num_blocks=1,
+           sep_num_layers=2, dilated=True, separable=True, causal=False, sep_nonlinear="prelu", sep_norm=True,
+           mask_nonlinear="sigmoid", n_sources=2)
+
+
+def _setup_paths():
+    for p in (ROOT, os.path.join(ROOT, "dnn-based_source_separation_amd", "src"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _data():
+    g = torch.Generator().manual_seed(7)
+    sources = 0.1 * torch.randn(4, 2, 2000, generator=g)
+    return sources.sum(1, keepdim=True), sources
+
+
+def _run_steps(mixture, sources, nsteps, distributed):
+    import sepkernels
+    from emulator import EmuBackend
+    from sepkernels.train import FusedTrainStep
+    from models.conv_tasnet import ConvTasNet
+    from criterion.sdr import NegSISDR
+    from criterion.pit import PIT1d
+    sepkernels._set_backend_for_tests(EmuBackend())
+    torch.manual_seed(111)
+    model = ConvTasNet(**CFG)
+    step = FusedTrainStep(model, PIT1d(NegSISDR(), n_sources=2), lr=1e-3, max_norm=5.0, distributed=distributed)
+    losses = [step(mixture, sources).item() for _ in range(nsteps)]
+    return model.flat_parameters().clone(), losses
+
+
+def _worker(rank, world, port, out_dir):
+    _setup_paths()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    mixture, sources = _data()
+    per = mixture.shape[0] // world
+    sl = slice(rank * per, (rank + 1) * per)                       # utterance sharding
+    flat, losses = _run_steps(mixture[sl], sources[sl], 2, True)
+    torch.save({"flat": flat, "losses": losses}, os.path.join(out_dir, "rank{}.pt".format(rank)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_matches_single_process(tmp_path):
+    _setup_paths()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
+    assert torch.equal(r0["flat"], r1["flat"])                     # replicas stay in lock-step
+    import sepkernels
+    old = sepkernels.backend()
+    try:
+        mixture, sources = _data()
+        flat, losses = _run_steps(mixture, sources, 2, False)      # single process, global batch
+    finally:
+        sepkernels._set_backend_for_tests(old)
+    assert (r0["flat"] - flat).abs().max() <= 2e-5 * flat.abs().max()
+    # the global loss is the mean of the two rank losses
+    for k in range(2):
+        assert abs(0.5 * (r0["losses"][k] + r1["losses"][k]) - losses[k]) <= 1e-4 * abs(losses[k])
+    assert losses[1] < losses[0]                                   # and the optimiser actually descends

@@ -1,0 +1,36 @@
+"""Dump the per-kernel statistics of a rocprofv3 (rocpd sqlite) capture as CSV + markdown for profiles/.
+    python tools/export_profile.py gpurun_out/prof_xxx/bench_results.db profiles/r01_xxx [steps]"""
+import csv
+import sqlite3
+import sys
+
+db, out = sys.argv[1], sys.argv[2]
+steps = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
+con = sqlite3.connect(db)
+cur = con.cursor()
+rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+with open(out + "_kernel_stats.csv", "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "CallsPerStep", "MsPerStep"])
+    for name, calls, tot, avg, pct in rows:
+        w.writerow([name, calls, int(tot * 1000), int(avg * 1000), "%.4f" % pct, "%.2f" % (calls / steps), "%.4f" % (tot / 1e3 / steps)])
+tot_ms = sum(r[2] for r in rows) / 1e3 / steps
+with open(out + "_kernel_stats.md", "w") as f:
+    f.write("| kernel | calls/step | avg us | ms/step | % |\n|---|---:|---:|---:|---:|\n")
+    for name, calls, tot, avg, pct in rows[:25]:
+        short = name.replace("(anonymous namespace)::", "").split("(")[0][:70]
+        f.write("| `{}` | {:.1f} | {:.1f} | {:.3f} | {:.1f} |\n".format(short, calls / steps, avg, tot / 1e3 / steps, pct))
+    f.write("\nGPU kernel time per step: {:.2f} ms ({} steps in the capture)\n".format(tot_ms, int(steps)))
+try:
+    q = ("select kernel_name, grid_size_x, counter_name, count(*), avg(value) from counters_collection "
+         "group by kernel_name, grid_size_x, counter_name order by kernel_name, grid_size_x, counter_name")
+    prow = list(cur.execute(q))
+    if prow:
+        with open(out + "_pmc.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Kernel", "GridSizeX", "Counter", "Dispatches", "AvgValue"])
+            for r in prow:
+                w.writerow([r[0], r[1], r[2], r[3], "%.1f" % r[4]])
+except sqlite3.Error:
+    pass
+print("wrote", out + "_kernel_stats.{csv,md}", "total ms/step %.2f" % tot_ms)
