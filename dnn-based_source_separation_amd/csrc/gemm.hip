@@ -444,39 +444,42 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_direct_kernel(const sep_gemm_d
         }
     }
 
-    // this wave's share of one stage: 2 DMA instructions for A, 2 for B (1 KiB each)
+    // this wave's share of one stage: 2 DMA instructions for A, 2 for B (1 KiB each).  Chunks are issued strictly in
+    // order, so the per-lane source pointers are carried and bumped instead of being rebuilt with 64-bit multiplies.
+    const float* pA[2];
+    const float* pB[2];
+    size_t stepA, stepB = (size_t)DK * d.ldt;
+    auto rebase = [&](const float* As_, const float* Xs, int Ksrc) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int r2 = 4 * wid + 2 * q;                       // first of the two k rows this instruction covers
+            pB[q] = Xs + ((size_t)b * Ksrc + r2 + lk) * d.ldt + t0 + 4 * l31;
+            if (TRANS_A) {
+                int mm = m0 + 4 * l31;
+                if (mm > d.M - 4) mm = d.M - 4;                   // rows past M are never stored; keep the read in bounds
+                pA[q] = As_ + (size_t)(r2 + lk) * d.M + mm;
+            } else {
+                // [128 m][16 k] image, 64-byte rows; instruction covers 16 rows; granule p of row r holds k-chunk p ^ ((r>>2)&3)
+                const int r = lane >> 2, pch = lane & 3;
+                int mm = m0 + 16 * (2 * wid + q) + r;
+                if (mm > d.M - 1) mm = d.M - 1;
+                pA[q] = As_ + (size_t)mm * Ksrc + 4 * (pch ^ ((r >> 2) & 3));
+            }
+        }
+        stepA = TRANS_A ? (size_t)DK * d.M : (size_t)DK;
+    };
+    rebase(d.A, d.X, d.k_split ? d.k_split : d.K);
     auto issue = [&](int kc, int stage) {
 #ifdef SEP_ABL_NO_LOADS
         if (kc >= 0) return;
 #endif
-        const int k0 = kc * DK;
-        const float* Xs = d.X;
-        const float* As_ = d.A;
-        int krow = k0, Ksrc = d.K;
-        if (d.k_split) {
-            if (k0 >= d.k_split) { Xs = d.X2; As_ = d.A2; krow = k0 - d.k_split; Ksrc = d.K - d.k_split; }
-            else { Ksrc = d.k_split; }
-        }
+        if (d.k_split && kc * DK == d.k_split) rebase(d.A2, d.X2, d.K - d.k_split);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int r2 = 4 * wid + 2 * q;                       // first of the two k rows this instruction covers
-            const float* gB = Xs + ((size_t)b * Ksrc + krow + r2 + lk) * d.ldt + t0 + 4 * l31;
-            glds16(gB, &sm.Bs[stage][r2 * 128]);
-            if (TRANS_A) {
-                int mm = m0 + 4 * l31;
-                if (mm > d.M - 4) mm = d.M - 4;                   // rows past M are never stored; keep the read in bounds
-                const float* gA = As_ + (size_t)(krow + r2 + lk) * d.M + mm;
-                glds16(gA, &sm.As[stage][r2 * 128]);
-            } else {
-                // [128 m][16 k] image, 64-byte rows; instruction covers 16 rows; granule p of row r holds k-chunk p ^ ((r>>2)&3)
-                const int g16 = 2 * wid + q;
-                const int r = lane >> 2, pch = lane & 3;
-                int mm = m0 + 16 * g16 + r;
-                if (mm > d.M - 1) mm = d.M - 1;
-                const int c = pch ^ ((r >> 2) & 3);
-                const float* gA = As_ + (size_t)mm * Ksrc + krow + 4 * c;
-                glds16(gA, &sm.As[stage][g16 * 256]);
-            }
+            glds16(pB[q], &sm.Bs[stage][(4 * wid + 2 * q) * 128]);
+            glds16(pA[q], TRANS_A ? &sm.As[stage][(4 * wid + 2 * q) * 128] : &sm.As[stage][(2 * wid + q) * 256]);
+            pB[q] += stepB;
+            pA[q] += stepA;
         }
     };
 
@@ -488,68 +491,90 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_direct_kernel(const sep_gemm_d
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-#pragma unroll
-    for (int s = 0; s < NST - 1; ++s)
-        if (s < nk) issue(s, s);
-
-    for (int kc = 0; kc < nk; ++kc) {
-        const int stage = kc & (NST - 1);
-        const int rem = nk - 1 - kc;                              // chunks issued after this one that may stay in flight
-        if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        // every wave is past the reads of stage kc-1 -> its buffer can be refilled with chunk kc+3
-        if (kc + NST - 1 < nk) issue(kc + NST - 1, (kc + NST - 1) & (NST - 1));
-
-        const float* Ab = sm.As[stage];
-        const float* Bb = sm.Bs[stage];
-        float fa[2][8], fb[2][8];
-        if (TRANS_A) {
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                fa[0][kk] = Ab[(8 * lk + kk) * 128 + wr * 64 + l31];
-                fa[1][kk] = Ab[(8 * lk + kk) * 128 + wr * 64 + 32 + l31];
-            }
-        } else {
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                const int m = wr * 64 + mi * 32 + l31;
-                const int sw = (m >> 2) & 3;
-                const float* p0 = Ab + m * 16 + 4 * ((2 * lk) ^ sw);
-                const float* p1 = Ab + m * 16 + 4 * ((2 * lk + 1) ^ sw);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { fa[mi][e] = p0[e]; fa[mi][4 + e] = p1[e]; }
-            }
-        }
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            fb[0][kk] = Bb[(8 * lk + kk) * 128 + wc * 64 + l31];
-            fb[1][kk] = Bb[(8 * lk + kk) * 128 + wc * 64 + 32 + l31];
-        }
-        if (pro != SEP_PRO_NONE) {
-            const int kbase = kc * DK + 8 * lk;
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                float scv = 1.f, shv = 0.f;
-                if (pro >= SEP_PRO_GLN) { scv = sm.sc[kbase + kk]; shv = sm.sh[kbase + kk]; }
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    float v = fb[ni][kk];
-                    if (pro == SEP_PRO_PRELU || pro == SEP_PRO_GLN_PRELU) v = prelu_f(v, alpha_p);
-                    fb[ni][kk] = v * scv + shv;
-                }
-            }
-        }
-#ifndef SEP_ABL_NO_MFMA
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][kk], fb[0][kk], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][kk], fb[1][kk], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][kk], fb[0][kk], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][kk], fb[1][kk], acc[1][1], 0, 0, 0);
-        }
-#endif
+    // wait until chunk k has landed (this wave's DMAs: counted vmcnt; everyone's: barrier).  lgkmcnt(0) retires this
+    // wave's fragment reads of the previous chunk, so after the barrier that chunk's stage may be refilled.
+#define DG_WAIT_BARRIER(k)                                                                        \
+    {                                                                                             \
+        const int rem_ = nk - 1 - (k);                                                            \
+        if (rem_ >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");    \
+        else if (rem_ == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");              \
     }
+    // LDS -> registers for chunk kc (A and B fragments of all 8 k-steps) + the elementwise prologue on B
+#define DG_LOAD_FRAGS(kc_, FA, FB)                                                                \
+    {                                                                                             \
+        const float* Ab = sm.As[(kc_) & (NST - 1)];                                               \
+        const float* Bb = sm.Bs[(kc_) & (NST - 1)];                                               \
+        if (TRANS_A) {                                                                            \
+            _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                    \
+                FA[0][kk] = Ab[(8 * lk + kk) * 128 + wr * 64 + l31];                              \
+                FA[1][kk] = Ab[(8 * lk + kk) * 128 + wr * 64 + 32 + l31];                         \
+            }                                                                                     \
+        } else {                                                                                  \
+            _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) {                                    \
+                const int m = wr * 64 + mi * 32 + l31;                                            \
+                const int sw = (m >> 2) & 3;                                                      \
+                const float* p0 = Ab + m * 16 + 4 * ((2 * lk) ^ sw);                              \
+                const float* p1 = Ab + m * 16 + 4 * ((2 * lk + 1) ^ sw);                          \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) { FA[mi][e] = p0[e]; FA[mi][4 + e] = p1[e]; } \
+            }                                                                                     \
+        }                                                                                         \
+        _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                        \
+            FB[0][kk] = Bb[(8 * lk + kk) * 128 + wc * 64 + l31];                                  \
+            FB[1][kk] = Bb[(8 * lk + kk) * 128 + wc * 64 + 32 + l31];                             \
+        }                                                                                         \
+        if (pro != SEP_PRO_NONE) {                                                                \
+            const int kbase = (kc_) * DK + 8 * lk;                                                \
+            _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                    \
+                float scv = 1.f, shv = 0.f;                                                       \
+                if (pro >= SEP_PRO_GLN) { scv = sm.sc[kbase + kk]; shv = sm.sh[kbase + kk]; }     \
+                _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                                \
+                    float v = FB[ni][kk];                                                         \
+                    if (pro == SEP_PRO_PRELU || pro == SEP_PRO_GLN_PRELU) v = prelu_f(v, alpha_p); \
+                    FB[ni][kk] = v * scv + shv;                                                   \
+                }                                                                                 \
+            }                                                                                     \
+        }                                                                                         \
+    }
+#ifndef SEP_ABL_NO_MFMA
+#define DG_MFMA(FA, FB)                                                                           \
+    _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                            \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0][kk], FB[0][kk], acc[0][0], 0, 0, 0); \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0][kk], FB[1][kk], acc[0][1], 0, 0, 0); \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1][kk], FB[0][kk], acc[1][0], 0, 0, 0); \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1][kk], FB[1][kk], acc[1][1], 0, 0, 0); \
+    }
+#else
+#define DG_MFMA(FA, FB) { acc[0][0][0] += FA[0][0] * FB[0][0] + FA[1][7] * FB[1][7]; }
+#endif
+
+    // Software pipeline: while the matrix pipe works through chunk kc (fragments already in registers), the wave has
+    // already synchronised on chunk kc+1, re-armed the DMA ring (chunk kc+4) and issued the LDS reads of chunk kc+1.
+    float fa0[2][8], fb0[2][8], fa1[2][8], fb1[2][8];
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st)
+        if (st < nk) issue(st, st);
+    DG_WAIT_BARRIER(0)
+    if (NST - 1 < nk) issue(NST - 1, NST - 1);
+    DG_LOAD_FRAGS(0, fa0, fb0)
+    for (int kc = 0; kc < nk; kc += 2) {
+        if (kc + 1 < nk) {
+            DG_WAIT_BARRIER(kc + 1)
+            if (kc + 4 < nk) issue(kc + 4, (kc + 4) & (NST - 1));
+            DG_LOAD_FRAGS(kc + 1, fa1, fb1)
+        }
+        DG_MFMA(fa0, fb0)
+        if (kc + 1 >= nk) break;
+        if (kc + 2 < nk) {
+            DG_WAIT_BARRIER(kc + 2)
+            if (kc + 5 < nk) issue(kc + 5, (kc + 5) & (NST - 1));
+            DG_LOAD_FRAGS(kc + 2, fa0, fb0)
+        }
+        DG_MFMA(fa1, fb1)
+    }
+#undef DG_WAIT_BARRIER
+#undef DG_LOAD_FRAGS
+#undef DG_MFMA
     __syncthreads();
 #ifdef SEP_ABL_NO_EPI
     if (acc[0][0][0] + acc[0][1][3] + acc[1][0][5] + acc[1][1][7] == 123.456f) d.Y[tid] = 1.f;
@@ -723,6 +748,226 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(const sep_wgrad_desc d
     if (do_bias && tid < BM && (m0 + tid) < d.M) d.partial_bias[(size_t)s * d.M + m0 + tid] = bias_acc;
 }
 
+
+// ======================================================================================
+// Direct-to-LDS pipelined weight gradient:  partial[s][m][n] = sum over slab s of G[b][m][t] * pro(X[b][n][t]).
+// Both operands are row-major with the contraction index (frame t) contiguous, i.e. both take the "row-major A"
+// route of pw_gemm_direct_kernel: 16-frame chunks, 64-byte rows DMA'd with the XOR swizzle on the source address,
+// fragments by two ds_read_b128 per 32-row block, 4-stage ring, counted vmcnt.  The gLN / PReLU prologue of X is
+// applied to the B fragments (per-lane row affine x per-sample mean/rstd table in LDS); bias row sums fall out of
+// the A fragments.  Frames >= T need no mask: G is zero there by the layout contract.
+// ======================================================================================
+constexpr int WMAXB = 256;      // samples whose gLN constants fit the LDS table
+
+struct __attribute__((aligned(16))) WDirectSmem {
+    float Gs[NST][128 * DK];
+    float Xs[NST][128 * DK];
+    float mu[WMAXB];
+    float rstd[WMAXB];
+};
+
+__global__ __launch_bounds__(256, 2) void pw_wgrad_direct_kernel(const sep_wgrad_desc d) {
+    __shared__ WDirectSmem sm;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+    const int lk = lane >> 5, l31 = lane & 31;
+    const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
+    const int ntiles = ntm * ntn;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, j = bid >> 3;
+    const int tile = j % ntiles;
+    const int s = (j / ntiles) * 8 + xcd;
+    if (s >= d.nsplit) return;
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+
+    const int cps_t = d.ldt / DK;                  // chunks per sample
+    const long chunks_total = (long)d.B * cps_t;
+    const long cper = (chunks_total + d.nsplit - 1) / d.nsplit;
+    const long c_begin = (long)s * cper;
+    long c_end = c_begin + cper;
+    if (c_end > chunks_total) c_end = chunks_total;
+    const int nk = (int)(c_end > c_begin ? c_end - c_begin : 0);
+
+    const bool gln = d.x_mode == SEP_PRO_GLN || d.x_mode == SEP_PRO_GLN_PRELU;
+    const bool prelu = d.x_mode == SEP_PRO_PRELU || d.x_mode == SEP_PRO_GLN_PRELU;
+    const float alpha_x = prelu ? d.x_alpha[0] : 0.f;
+    if (gln) {
+        const int nb = d.B / d.x_div;
+        for (int bx = tid; bx < nb; bx += 256) {
+            float mu, rstd;
+            gln_mu_rstd(d.x_stats + (size_t)bx * SEP_STATS_SLOTS * 2, d.count, d.eps, mu, rstd);
+            sm.mu[bx] = mu; sm.rstd[bx] = rstd;
+        }
+    }
+    // this lane's two X rows (B operand) and their gLN affine
+    float xg[2] = {0.f, 0.f}, xb[2] = {0.f, 0.f};
+    if (gln) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int n = n0 + wc * 64 + ni * 32 + l31;
+            if (n < d.N) { xg[ni] = d.x_gamma[n]; xb[ni] = d.x_beta[n]; }
+        }
+    }
+    // G source of this row tile (g_split is a multiple of BM -> block-uniform)
+    const bool gsecond = d.g_split && m0 >= d.g_split;
+    const float* Gsrc = gsecond ? d.G2 : d.G;
+    const int Mg = gsecond ? d.M - d.g_split : (d.g_split ? d.g_split : d.M);
+    const int mg0 = gsecond ? m0 - d.g_split : m0;
+    const int Mg_lim = (d.M < m0 + BM ? d.M : m0 + BM) - (gsecond ? d.g_split : 0);   // rows of this tile that exist in Gsrc
+
+    // per-lane DMA sources, carried from chunk to chunk (chunks are issued strictly in order); rebuilt only when the
+    // chunk sequence crosses into the next sample
+    const int r16 = lane >> 2, cch = (lane & 3) ^ ((r16 >> 2) & 3);
+    int ib = (int)(c_begin / cps_t), itt = (int)(c_begin % cps_t) * DK;     // sample / first frame of the next chunk to issue
+    const float* pG[2];
+    const float* pX[2];
+    auto rebase = [&]() {
+        const int bx = ib / d.x_div;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int g16 = 2 * wid + q;                          // 16-row group of the 128-row tile
+            int mm = mg0 + 16 * g16 + r16;
+            if (mm > Mg_lim - 1) mm = Mg_lim - 1;                 // rows past M: in-bounds garbage, never stored
+            pG[q] = Gsrc + ((size_t)ib * Mg + mm) * d.ldt + itt + 4 * cch;
+            int nn = n0 + 16 * g16 + r16;
+            if (nn > d.N - 1) nn = d.N - 1;
+            pX[q] = d.X + ((size_t)bx * d.N + nn) * d.ldt + itt + 4 * cch;
+        }
+    };
+    rebase();
+    auto issue = [&](int stage) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            glds16(pG[q], &sm.Gs[stage][(2 * wid + q) * 256]);
+            glds16(pX[q], &sm.Xs[stage][(2 * wid + q) * 256]);
+            pG[q] += DK;
+            pX[q] += DK;
+        }
+        itt += DK;
+        if (itt >= d.ldt) { itt = 0; ++ib; rebase(); }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    float bias_acc[2] = {0.f, 0.f};
+    const bool do_bias = d.partial_bias != nullptr && (tile % ntn) == 0 && wc == 0;
+
+    // sample of the chunk whose fragments are loaded next (for the per-sample gLN constants)
+    int fb_b = (int)(c_begin / cps_t), fb_t = (int)(c_begin % cps_t);
+
+#define WD_WAIT_BARRIER(k)                                                                        \
+    {                                                                                             \
+        const int rem_ = nk - 1 - (k);                                                            \
+        if (rem_ >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");    \
+        else if (rem_ == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");              \
+    }
+#define WD_LOAD_FRAGS(kc_, FA, FB)                                                                \
+    {                                                                                             \
+        const float* Gb = sm.Gs[(kc_) & (NST - 1)];                                               \
+        const float* Xb = sm.Xs[(kc_) & (NST - 1)];                                               \
+        _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) {                                        \
+            const int m = wr * 64 + mi * 32 + l31;                                                \
+            const int sw = (m >> 2) & 3;                                                          \
+            const float* p0 = Gb + m * 16 + 4 * ((2 * lk) ^ sw);                                  \
+            const float* p1 = Gb + m * 16 + 4 * ((2 * lk + 1) ^ sw);                              \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) { FA[mi][e] = p0[e]; FA[mi][4 + e] = p1[e]; } \
+        }                                                                                         \
+        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                                        \
+            const int n = wc * 64 + ni * 32 + l31;                                                \
+            const int sw = (n >> 2) & 3;                                                          \
+            const float* p0 = Xb + n * 16 + 4 * ((2 * lk) ^ sw);                                  \
+            const float* p1 = Xb + n * 16 + 4 * ((2 * lk + 1) ^ sw);                              \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) { FB[ni][e] = p0[e]; FB[ni][4 + e] = p1[e]; } \
+        }                                                                                         \
+        if (d.x_mode != SEP_PRO_NONE) {                                                           \
+            float mu = 0.f, rstd = 1.f;                                                           \
+            if (gln) { mu = sm.mu[fb_b / d.x_div]; rstd = sm.rstd[fb_b / d.x_div]; }              \
+            _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                                    \
+                const float scv = gln ? xg[ni] * rstd : 1.f;                                      \
+                const float shv = gln ? xb[ni] - mu * scv : 0.f;                                  \
+                _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                \
+                    float v = FB[ni][kk];                                                         \
+                    if (prelu) v = prelu_f(v, alpha_x);                                           \
+                    FB[ni][kk] = v * scv + shv;                                                   \
+                }                                                                                 \
+            }                                                                                     \
+        }                                                                                         \
+        if (++fb_t >= cps_t) { fb_t = 0; ++fb_b; }                                                \
+    }
+#define WD_MFMA(FA, FB)                                                                           \
+    {                                                                                             \
+        if (do_bias) {                                                                            \
+            _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                      \
+                _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) bias_acc[mi] += FA[mi][kk];      \
+        }                                                                                         \
+        _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                        \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0][kk], FB[0][kk], acc[0][0], 0, 0, 0); \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0][kk], FB[1][kk], acc[0][1], 0, 0, 0); \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1][kk], FB[0][kk], acc[1][0], 0, 0, 0); \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1][kk], FB[1][kk], acc[1][1], 0, 0, 0); \
+        }                                                                                         \
+    }
+
+    __syncthreads();                                              // mu/rstd table visible; placed BEFORE the first DMA so it drains nothing
+    float fa0[2][8], fb0[2][8], fa1[2][8], fb1[2][8];
+    if (nk > 0) {
+#pragma unroll
+        for (int st = 0; st < NST - 1; ++st)
+            if (st < nk) issue(st);
+        WD_WAIT_BARRIER(0)
+        if (NST - 1 < nk) issue(NST - 1);
+        WD_LOAD_FRAGS(0, fa0, fb0)
+        for (int kc = 0; kc < nk; kc += 2) {
+            if (kc + 1 < nk) {
+                WD_WAIT_BARRIER(kc + 1)
+                if (kc + 4 < nk) issue((kc + 4) & (NST - 1));
+                WD_LOAD_FRAGS(kc + 1, fa1, fb1)
+            }
+            WD_MFMA(fa0, fb0)
+            if (kc + 1 >= nk) break;
+            if (kc + 2 < nk) {
+                WD_WAIT_BARRIER(kc + 2)
+                if (kc + 5 < nk) issue((kc + 5) & (NST - 1));
+                WD_LOAD_FRAGS(kc + 2, fa0, fb0)
+            }
+            WD_MFMA(fa1, fb1)
+        }
+    }
+#undef WD_WAIT_BARRIER
+#undef WD_LOAD_FRAGS
+#undef WD_MFMA
+
+    float* out = d.partial + (size_t)s * d.M * d.N;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (row < d.M) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int col = n0 + wc * 64 + ni * 32 + l31;
+                    if (col < d.N) out[(size_t)row * d.N + col] = acc[mi][ni][r];
+                }
+            }
+        }
+    if (do_bias) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const float tot = bias_acc[mi] + __shfl_xor(bias_acc[mi], 32, 64);     // the two lane halves own different frames
+            const int row = m0 + wr * 64 + mi * 32 + l31;
+            if (lk == 0 && row < d.M) d.partial_bias[(size_t)s * d.M + row] = tot;
+        }
+    }
+}
+
 // ======================================================================================
 struct ReduceArgs {
     sep_reduce_seg seg[8];
@@ -814,7 +1059,13 @@ extern "C" int sep_pw_wgrad(const sep_wgrad_desc* d, sep_stream_t stream) {
     if (d->x_mode >= SEP_PRO_GLN) SEP_REQUIRE(d->x_stats && d->x_gamma && d->x_beta && d->count > 0, "sep_pw_wgrad: gLN prologue needs stats/gamma/beta/count");
     const int ntiles = ceil_div(d->M, BM) * ceil_div(d->N, BN);
     const int grid = 8 * ntiles * ceil_div(d->nsplit, 8);
-    hipLaunchKernelGGL(pw_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
+    static const bool force_staged = getenv("SEPK_FORCE_STAGED") != nullptr;
+    const bool direct_ok = !force_staged && !d->g_mul && (d->x_mode < SEP_PRO_GLN || d->B / d->x_div <= WMAXB) &&
+                           (long)d->nsplit <= (long)d->B * (d->ldt / DK);
+    if (direct_ok)
+        hipLaunchKernelGGL(pw_wgrad_direct_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
+    else
+        hipLaunchKernelGGL(pw_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
     SEP_CHECK_LAUNCH("sep_pw_wgrad");
     return 0;
 }
