@@ -16,6 +16,7 @@
 // placed on the same XCD (blockIdx % 8) so the tile is fetched from HBM once and re-read from that L2.
 #include "common.hpp"
 #include <stdlib.h>
+#include <stddef.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -394,6 +395,27 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const sep_gemm_desc d) 
 // ======================================================================================
 constexpr int DK = 16;
 constexpr int NST = 4;
+
+// Interleave recipe for one pipeline step of the direct kernels.  A wave issues in order: if the ~100 non-MFMA
+// instructions of a step (DMA issue, fragment ds_reads of the NEXT chunk, prologue VALU) sit in front of its 32 MFMAs
+// the matrix pipe idles while they issue (measured: one wave per SIMD reached only 58 % of the MFMA rate).  Placed
+// between the MFMAs they are free: each v_mfma_f32_32x32x2_f32 occupies the pipe for 64 cycles.
+__device__ __forceinline__ void sched_interleave_step() {
+#ifndef SEP_NO_SCHED
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read (the DMA re-arm)
+        __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);   // its SALU (M0, base bump)
+    }
+#pragma unroll
+    for (int i = 0; i < 28; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // 4 VALU (prologue on the next fragments)
+    }
+#endif
+}
+
 constexpr int DMAXK = 1024;
 
 struct __attribute__((aligned(16))) DirectSmem {
@@ -402,6 +424,9 @@ struct __attribute__((aligned(16))) DirectSmem {
     float sc[DMAXK];
     float sh[DMAXK];
     double red[8];
+#ifdef SEP_LDS_PAD
+    float pad[SEP_LDS_PAD];      // occupancy experiment only
+#endif
 };
 
 __device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
@@ -409,7 +434,7 @@ __device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <bool TRANS_A>
+template <bool TRANS_A, int PRO, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void pw_gemm_direct_kernel(const sep_gemm_desc d) {
     __shared__ DirectSmem sm;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -428,13 +453,14 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_direct_kernel(const sep_gemm_d
     const int b = ct / ntile_t;
     const int t0 = (ct % ntile_t) * BN;
     const int m0 = rt * BM;
-    const int pro = d.pro_mode;
     const int nk = d.K / DK;
+    constexpr bool P_PRELU = PRO == SEP_PRO_PRELU || PRO == SEP_PRO_GLN_PRELU;
+    constexpr bool P_GLN = PRO == SEP_PRO_GLN || PRO == SEP_PRO_GLN_PRELU;
 
     // per-row affine of the prologue, once per workgroup
     float alpha_p = 0.f;
-    if (pro == SEP_PRO_PRELU || pro == SEP_PRO_GLN_PRELU) alpha_p = d.pro_alpha[0];
-    if (pro == SEP_PRO_GLN || pro == SEP_PRO_GLN_PRELU) {
+    if (P_PRELU) alpha_p = d.pro_alpha[0];
+    if (P_GLN) {
         float mu, rstd;
         gln_mu_rstd(d.pro_stats + (size_t)b * SEP_STATS_SLOTS * 2, d.count, d.eps, mu, rstd);
         for (int k = tid; k < d.K; k += 256) {
@@ -444,43 +470,63 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_direct_kernel(const sep_gemm_d
         }
     }
 
-    // this wave's share of one stage: 2 DMA instructions for A, 2 for B (1 KiB each).  Chunks are issued strictly in
-    // order, so the per-lane source pointers are carried and bumped instead of being rebuilt with 64-bit multiplies.
-    const float* pA[2];
-    const float* pB[2];
-    size_t stepA, stepB = (size_t)DK * d.ldt;
-    auto rebase = [&](const float* As_, const float* Xs, int Ksrc) {
+    // This wave's share of one stage: 2 DMA instructions for A, 2 for B (1 KiB each).  Every source address is a
+    // wave-uniform base (SGPR pair, advanced with scalar adds as chunks are issued strictly in order) plus a per-lane
+    // 32-bit offset fixed for the whole tile, so the per-chunk address work is SALU only.
+    const int Ks1 = SPLIT ? d.k_split : d.K;
+    const int split_chunk = SPLIT ? d.k_split / DK : -1;
+    const size_t stepB = (size_t)DK * d.ldt;
+    const size_t stepA = TRANS_A ? (size_t)DK * d.M : (size_t)DK;
+    const float* baseB[2];
+    const float* baseA[2];
+    int offB, offA[2];
+    offB = lk * d.ldt + 4 * l31;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int r2 = 4 * wid + 2 * q;                       // first of the two k rows this instruction covers
-            pB[q] = Xs + ((size_t)b * Ksrc + r2 + lk) * d.ldt + t0 + 4 * l31;
-            if (TRANS_A) {
-                int mm = m0 + 4 * l31;
-                if (mm > d.M - 4) mm = d.M - 4;                   // rows past M are never stored; keep the read in bounds
-                pA[q] = As_ + (size_t)(r2 + lk) * d.M + mm;
-            } else {
-                // [128 m][16 k] image, 64-byte rows; instruction covers 16 rows; granule p of row r holds k-chunk p ^ ((r>>2)&3)
-                const int r = lane >> 2, pch = lane & 3;
-                int mm = m0 + 16 * (2 * wid + q) + r;
-                if (mm > d.M - 1) mm = d.M - 1;
-                pA[q] = As_ + (size_t)mm * Ksrc + 4 * (pch ^ ((r >> 2) & 3));
+    for (int q = 0; q < 2; ++q) {
+        const int r2 = 4 * wid + 2 * q;                           // first of the two k rows this instruction covers
+        baseB[q] = d.X + ((size_t)b * Ks1 + r2) * d.ldt + t0;
+        if (TRANS_A) {
+            int mm = m0 + 4 * l31;
+            if (mm > d.M - 4) mm = d.M - 4;                       // rows past M are never stored; keep the read in bounds
+            baseA[q] = d.A + (size_t)r2 * d.M;
+            offA[q] = lk * d.M + mm;
+        } else {
+            // [128 m][16 k] image, 64-byte rows; instruction covers 16 rows; granule p of row r holds k-chunk p ^ ((r>>2)&3)
+            const int r = lane >> 2, pch = lane & 3;
+            int mm = m0 + 16 * (2 * wid + q) + r;
+            if (mm > d.M - 1) mm = d.M - 1;
+            baseA[q] = d.A;
+            offA[q] = mm * Ks1 + 4 * (pch ^ ((r >> 2) & 3));
+        }
+    }
+    int kci = 0;                                                  // next chunk to issue
+    auto issue = [&](const int stage) {
+        if (SPLIT && kci == split_chunk) {                        // uniform, taken once per tile: switch to the second source
+            const int Ks2 = d.K - d.k_split;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r2 = 4 * wid + 2 * q;
+                baseB[q] = d.X2 + ((size_t)b * Ks2 + r2) * d.ldt + t0;
+                if (TRANS_A) baseA[q] = d.A2 + (size_t)r2 * d.M;
+                else {
+                    const int r = lane >> 2, pch = lane & 3;
+                    int mm = m0 + 16 * (2 * wid + q) + r;
+                    if (mm > d.M - 1) mm = d.M - 1;
+                    baseA[q] = d.A2;
+                    offA[q] = mm * Ks2 + 4 * (pch ^ ((r >> 2) & 3));
+                }
             }
         }
-        stepA = TRANS_A ? (size_t)DK * d.M : (size_t)DK;
-    };
-    rebase(d.A, d.X, d.k_split ? d.k_split : d.K);
-    auto issue = [&](int kc, int stage) {
-#ifdef SEP_ABL_NO_LOADS
-        if (kc >= 0) return;
-#endif
-        if (d.k_split && kc * DK == d.k_split) rebase(d.A2, d.X2, d.K - d.k_split);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            glds16(pB[q], &sm.Bs[stage][(4 * wid + 2 * q) * 128]);
-            glds16(pA[q], TRANS_A ? &sm.As[stage][(4 * wid + 2 * q) * 128] : &sm.As[stage][(2 * wid + q) * 256]);
-            pB[q] += stepB;
-            pA[q] += stepA;
+#ifndef SEP_ABL_NO_LOADS
+            glds16(baseB[q] + offB, &sm.Bs[stage][(4 * wid + 2 * q) * 128]);
+            glds16(baseA[q] + offA[q], TRANS_A ? &sm.As[stage][(4 * wid + 2 * q) * 128] : &sm.As[stage][(2 * wid + q) * 256]);
+#endif
+            baseB[q] += stepB;
+            baseA[q] += stepA;
         }
+        ++kci;
     };
 
     f32x16 acc[2][2];
@@ -493,18 +539,19 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_direct_kernel(const sep_gemm_d
 
     // wait until chunk k has landed (this wave's DMAs: counted vmcnt; everyone's: barrier).  lgkmcnt(0) retires this
     // wave's fragment reads of the previous chunk, so after the barrier that chunk's stage may be refilled.
+#define DG_WAIT8 asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #define DG_WAIT_BARRIER(k)                                                                        \
     {                                                                                             \
         const int rem_ = nk - 1 - (k);                                                            \
-        if (rem_ >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");    \
+        if (rem_ >= 2) DG_WAIT8                                                                   \
         else if (rem_ == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");              \
     }
-    // LDS -> registers for chunk kc (A and B fragments of all 8 k-steps) + the elementwise prologue on B
-#define DG_LOAD_FRAGS(kc_, FA, FB)                                                                \
+    // LDS -> registers for one chunk (A and B fragments of all 8 k-steps), raw
+#define DG_LOAD_FRAGS(st_, FA, FB)                                                                \
     {                                                                                             \
-        const float* Ab = sm.As[(kc_) & (NST - 1)];                                               \
-        const float* Bb = sm.Bs[(kc_) & (NST - 1)];                                               \
+        const float* Ab = sm.As[st_];                                                             \
+        const float* Bb = sm.Bs[st_];                                                             \
         if (TRANS_A) {                                                                            \
             _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                    \
                 FA[0][kk] = Ab[(8 * lk + kk) * 128 + wr * 64 + l31];                              \
@@ -523,16 +570,18 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_direct_kernel(const sep_gemm_d
             FB[0][kk] = Bb[(8 * lk + kk) * 128 + wc * 64 + l31];                                  \
             FB[1][kk] = Bb[(8 * lk + kk) * 128 + wc * 64 + 32 + l31];                             \
         }                                                                                         \
-        if (pro != SEP_PRO_NONE) {                                                                \
-            const int kbase = (kc_) * DK + 8 * lk;                                                \
-            _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                    \
-                float scv = 1.f, shv = 0.f;                                                       \
-                if (pro >= SEP_PRO_GLN) { scv = sm.sc[kbase + kk]; shv = sm.sh[kbase + kk]; }     \
-                _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                                \
-                    float v = FB[ni][kk];                                                         \
-                    if (pro == SEP_PRO_PRELU || pro == SEP_PRO_GLN_PRELU) v = prelu_f(v, alpha_p); \
-                    FB[ni][kk] = v * scv + shv;                                                   \
-                }                                                                                 \
+    }
+    // the elementwise prologue on the B fragments of chunk kc_
+#define DG_PROLOGUE(kc_, FB)                                                                      \
+    if (PRO != SEP_PRO_NONE) {                                                                    \
+        const int kbase = (kc_) * DK + 8 * lk;                                                    \
+        _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                        \
+            const float scv = P_GLN ? sm.sc[kbase + kk] : 1.f;                                    \
+            const float shv = P_GLN ? sm.sh[kbase + kk] : 0.f;                                    \
+            _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                                    \
+                float v = FB[ni][kk];                                                             \
+                if (P_PRELU) v = prelu_f(v, alpha_p);                                             \
+                FB[ni][kk] = P_GLN ? v * scv + shv : v;                                           \
             }                                                                                     \
         }                                                                                         \
     }
@@ -547,33 +596,57 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_direct_kernel(const sep_gemm_d
 #else
 #define DG_MFMA(FA, FB) { acc[0][0][0] += FA[0][0] * FB[0][0] + FA[1][7] * FB[1][7]; }
 #endif
+    // One steady-state pipeline step: [chunk nxt has landed] -> its ds_reads go out first (pinned with a scheduling
+    // barrier), then the DMA re-arm, then the 32 MFMAs of the current chunk with the prologue VALU of the next chunk's
+    // fragments woven in behind the first few (whose 64-cycle slots also cover the LDS latency).
+#define DG_STEP(st_issue, st_next, kc_next, FAc, FBc, FAn, FBn)                                   \
+    DG_WAIT8                                                                                      \
+    DG_LOAD_FRAGS(st_next, FAn, FBn)                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    issue(st_issue);                                                                              \
+    DG_MFMA(FAc, FBc)                                                                             \
+    DG_PROLOGUE(kc_next, FBn)                                                                     \
+    sched_interleave_step();
 
-    // Software pipeline: while the matrix pipe works through chunk kc (fragments already in registers), the wave has
-    // already synchronised on chunk kc+1, re-armed the DMA ring (chunk kc+4) and issued the LDS reads of chunk kc+1.
     float fa0[2][8], fb0[2][8], fa1[2][8], fb1[2][8];
 #pragma unroll
     for (int st = 0; st < NST - 1; ++st)
-        if (st < nk) issue(st, st);
+        if (st < nk) issue(st);
     DG_WAIT_BARRIER(0)
-    if (NST - 1 < nk) issue(NST - 1, NST - 1);
+    if (NST - 1 < nk) issue(NST - 1);
     DG_LOAD_FRAGS(0, fa0, fb0)
-    for (int kc = 0; kc < nk; kc += 2) {
+    DG_PROLOGUE(0, fb0)
+    int kc = 0;
+    // Steady state, unrolled over the 4 ring stages so every LDS address is "lane base + immediate" and every M0 a
+    // constant; each step is one basic block.  kc % 4 == 0 here.
+    for (; kc + 7 < nk; kc += 4) {
+        DG_STEP(0, 1, kc + 1, fa0, fb0, fa1, fb1)
+        DG_STEP(1, 2, kc + 2, fa1, fb1, fa0, fb0)
+        DG_STEP(2, 3, kc + 3, fa0, fb0, fa1, fb1)
+        DG_STEP(3, 0, kc + 4, fa1, fb1, fa0, fb0)
+    }
+    for (; kc < nk; kc += 2) {
         if (kc + 1 < nk) {
             DG_WAIT_BARRIER(kc + 1)
-            if (kc + 4 < nk) issue(kc + 4, (kc + 4) & (NST - 1));
-            DG_LOAD_FRAGS(kc + 1, fa1, fb1)
+            if (kc + 4 < nk) issue((kc + 4) & (NST - 1));
+            DG_LOAD_FRAGS((kc + 1) & (NST - 1), fa1, fb1)
+            DG_PROLOGUE(kc + 1, fb1)
         }
         DG_MFMA(fa0, fb0)
         if (kc + 1 >= nk) break;
         if (kc + 2 < nk) {
             DG_WAIT_BARRIER(kc + 2)
-            if (kc + 5 < nk) issue(kc + 5, (kc + 5) & (NST - 1));
-            DG_LOAD_FRAGS(kc + 2, fa0, fb0)
+            if (kc + 5 < nk) issue((kc + 5) & (NST - 1));
+            DG_LOAD_FRAGS((kc + 2) & (NST - 1), fa0, fb0)
+            DG_PROLOGUE(kc + 2, fb0)
         }
         DG_MFMA(fa1, fb1)
     }
+#undef DG_STEP
+#undef DG_WAIT8
 #undef DG_WAIT_BARRIER
 #undef DG_LOAD_FRAGS
+#undef DG_PROLOGUE
 #undef DG_MFMA
     __syncthreads();
 #ifdef SEP_ABL_NO_EPI
@@ -931,6 +1004,8 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_direct_kernel(const sep_wgrad
                 WD_LOAD_FRAGS(kc + 1, fa1, fb1)
             }
             WD_MFMA(fa0, fb0)
+            sched_interleave_step();
+        sched_interleave_step();
             if (kc + 1 >= nk) break;
             if (kc + 2 < nk) {
                 WD_WAIT_BARRIER(kc + 2)
@@ -938,6 +1013,8 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_direct_kernel(const sep_wgrad
                 WD_LOAD_FRAGS(kc + 2, fa0, fb0)
             }
             WD_MFMA(fa1, fb1)
+            sched_interleave_step();
+        sched_interleave_step();
         }
     }
 #undef WD_WAIT_BARRIER
@@ -1034,11 +1111,24 @@ extern "C" int sep_pw_gemm(const sep_gemm_desc* d, sep_stream_t stream) {
     static const bool force_staged = getenv("SEPK_FORCE_STAGED") != nullptr;
     const bool direct_ok = !force_staged && d->pro_mode != SEP_PRO_GLN_BWD && d->K % DK == 0 && d->k_split % DK == 0 &&
                            (d->pro_mode < SEP_PRO_GLN || d->K <= DMAXK) && d->M >= 4 && d->M % 4 == 0;
-    if (direct_ok && d->trans_a)
-        hipLaunchKernelGGL(pw_gemm_direct_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
-    else if (direct_ok)
-        hipLaunchKernelGGL(pw_gemm_direct_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
-    else
+    if (direct_ok) {
+#define SEP_LAUNCH_DIRECT(T, P)                                                                                              \
+    do {                                                                                                                     \
+        if (d->k_split) hipLaunchKernelGGL((pw_gemm_direct_kernel<T, P, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);  \
+        else hipLaunchKernelGGL((pw_gemm_direct_kernel<T, P, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);            \
+    } while (0)
+        switch (d->pro_mode * 2 + (d->trans_a ? 1 : 0)) {
+            case 0: SEP_LAUNCH_DIRECT(false, SEP_PRO_NONE); break;
+            case 1: SEP_LAUNCH_DIRECT(true, SEP_PRO_NONE); break;
+            case 2: SEP_LAUNCH_DIRECT(false, SEP_PRO_PRELU); break;
+            case 3: SEP_LAUNCH_DIRECT(true, SEP_PRO_PRELU); break;
+            case 4: SEP_LAUNCH_DIRECT(false, SEP_PRO_GLN); break;
+            case 5: SEP_LAUNCH_DIRECT(true, SEP_PRO_GLN); break;
+            case 6: SEP_LAUNCH_DIRECT(false, SEP_PRO_GLN_PRELU); break;
+            default: SEP_LAUNCH_DIRECT(true, SEP_PRO_GLN_PRELU); break;
+        }
+#undef SEP_LAUNCH_DIRECT
+    } else
         hipLaunchKernelGGL(pw_gemm_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
     SEP_CHECK_LAUNCH("sep_pw_gemm");
     return 0;

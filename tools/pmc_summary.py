@@ -1,0 +1,19 @@
+"""Print per-kernel averages of the PMC counters in a rocprofv3 rocpd database (compact, one line per counter)."""
+import glob
+import sqlite3
+import sys
+
+path = sys.argv[1]
+dbs = glob.glob(path + "/**/*.db", recursive=True) if not path.endswith(".db") else [path]
+for db in dbs:
+    con = sqlite3.connect(db)
+    q = ("select kernel_name, grid_size_x, counter_name, count(*), avg(value) from counters_collection "
+         "where kernel_name like '%pw_%' group by kernel_name, grid_size_x, counter_name order by kernel_name, grid_size_x, counter_name")
+    last = None
+    for name, grid, ctr, n, avg in con.execute(q):
+        short = name.replace("(anonymous namespace)::", "").split("(")[0][-40:]
+        key = (short, grid)
+        if key != last:
+            print("== {} grid={} dispatches={}".format(short, grid, n))
+            last = key
+        print("   {:32s} {:16.0f}".format(ctr, avg))
