@@ -589,6 +589,40 @@ __global__ __launch_bounds__(256) void repack_kernel(const float* __restrict__ s
     dst[(size_t)row * ld_dst + t] = (t < T) ? src[(size_t)row * ld_src + t] : 0.f;
 }
 
+
+// =====================================================================================
+// Segment1d / OverlapAdd1d of the dual-path models (reference src/models/transform.py:6-65) as index maps, without
+// the unfold/fold materialisation + permute copies of the reference:
+//   segment:     out[b][c][s][k] = xpad[b][c][s*hop + k],  xpad = x (padded rows, T valid frames) shifted right by pad_left
+//   overlap-add: out[b][c][t]    = sum_{(s,k): s*hop + k == t + pad_left} y[b][c][s][k]   (t < T; zero for T <= t < ldt)
+// The two are adjoints, so each is the other's backward.
+// =====================================================================================
+__global__ __launch_bounds__(256) void segment_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int ldt,
+                                                      int S, int Kc, int hop, int pad_left) {
+    const int row = blockIdx.y;                                  // b*C + c
+    const int i = blockIdx.x * 256 + threadIdx.x;                // s*Kc + k
+    if (i >= S * Kc) return;
+    const int s = i / Kc, k = i % Kc;
+    const int t = s * hop + k - pad_left;
+    out[(size_t)row * S * Kc + i] = (t >= 0 && t < T) ? x[(size_t)row * ldt + t] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void overlap_add_kernel(const float* __restrict__ y, float* __restrict__ out, int T, int ldt,
+                                                          int S, int Kc, int hop, int pad_left) {
+    const int row = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= ldt) return;
+    float acc = 0.f;
+    if (t < T) {
+        const int tp = t + pad_left;
+        // chunks covering tp: s*hop <= tp < s*hop + Kc
+        int s_hi = tp / hop;
+        if (s_hi > S - 1) s_hi = S - 1;
+        for (int s = s_hi; s >= 0 && tp - s * hop < Kc; --s) acc += y[((size_t)row * S + s) * Kc + (tp - s * hop)];
+    }
+    out[(size_t)row * ldt + t] = acc;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------
@@ -757,5 +791,33 @@ extern "C" int sep_repack(const float* src, int ld_src, float* dst, int ld_dst, 
         done += chunk;
     }
     SEP_CHECK_LAUNCH("sep_repack");
+    return 0;
+}
+
+extern "C" int sep_segment(const float* x, float* out, int rows, int T, int ldt, int S, int chunk, int hop, int pad_left,
+                           sep_stream_t stream) {
+    SEP_REQUIRE(x && out && rows > 0 && T > 0 && ldt >= T && S > 0 && chunk > 0 && hop > 0, "sep_segment: bad arguments");
+    int done = 0;
+    while (done < rows) {
+        const int nr = (rows - done) > 65535 ? 65535 : (rows - done);
+        dim3 grid(ceil_div(S * chunk, 256), nr);
+        hipLaunchKernelGGL(segment_kernel, grid, dim3(256), 0, (hipStream_t)stream, x + (size_t)done * ldt, out + (size_t)done * S * chunk, T, ldt, S, chunk, hop, pad_left);
+        done += nr;
+    }
+    SEP_CHECK_LAUNCH("sep_segment");
+    return 0;
+}
+
+extern "C" int sep_overlap_add(const float* y, float* out, int rows, int T, int ldt, int S, int chunk, int hop, int pad_left,
+                               sep_stream_t stream) {
+    SEP_REQUIRE(y && out && rows > 0 && T > 0 && ldt >= T && S > 0 && chunk > 0 && hop > 0, "sep_overlap_add: bad arguments");
+    int done = 0;
+    while (done < rows) {
+        const int nr = (rows - done) > 65535 ? 65535 : (rows - done);
+        dim3 grid(ceil_div(ldt, 256), nr);
+        hipLaunchKernelGGL(overlap_add_kernel, grid, dim3(256), 0, (hipStream_t)stream, y + (size_t)done * S * chunk, out + (size_t)done * ldt, T, ldt, S, chunk, hop, pad_left);
+        done += nr;
+    }
+    SEP_CHECK_LAUNCH("sep_overlap_add");
     return 0;
 }

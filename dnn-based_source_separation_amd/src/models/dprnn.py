@@ -1,0 +1,84 @@
+"""
+Dual-path RNN blocks: module tree / parameter names of reference src/models/dprnn.py:9-148.
+
+Interim design: the recurrences run on torch.nn.LSTM (MIOpen on ROCm); the global layer
+norm after every path is the libsepkernels gLN; layout changes are torch views/permutes.  A persistent hand-written
+LSTM (weights in LDS, chunk loop in-kernel) is the planned replacement -- it is NOT part of this round.
+"""
+import torch.nn as nn
+
+from utils.model import choose_rnn
+from utils.tasnet import choose_layer_norm
+
+EPS = 1e-12
+
+
+class DPRNN(nn.Module):
+    def __init__(self, num_features, hidden_channels, num_blocks=6, norm=True, causal=False, rnn_type="lstm", eps=EPS):
+        super().__init__()
+        self.net = nn.Sequential(*[DPRNNBlock(num_features, hidden_channels, norm=norm, causal=causal, rnn_type=rnn_type, eps=eps)
+                                   for _ in range(num_blocks)])
+
+    def forward(self, input):
+        """(B, F, S, K) -> (B, F, S, K)"""
+        return self.net(input)
+
+
+class DPRNNBlock(nn.Module):
+    def __init__(self, num_features, hidden_channels, causal, norm=True, rnn_type="lstm", eps=EPS):
+        super().__init__()
+        self.intra_chunk_block = IntraChunkRNN(num_features, hidden_channels, norm=norm, rnn_type=rnn_type, eps=eps)
+        self.inter_chunk_block = InterChunkRNN(num_features, hidden_channels, norm=norm, causal=causal, rnn_type=rnn_type, eps=eps)
+
+    def forward(self, input):
+        return self.inter_chunk_block(self.intra_chunk_block(input))
+
+
+class _PathRNN(nn.Module):
+    """Shared body of the intra- and inter-chunk paths: sequence axis -> bi-LSTM -> Linear -> gLN -> + input."""
+
+    def __init__(self, num_features, hidden_channels, bidirectional, norm_name, norm, rnn_type, causal, eps):
+        super().__init__()
+        if rnn_type != "lstm":
+            raise NotImplementedError("Not support {}.".format(rnn_type))
+        self.num_features, self.hidden_channels = num_features, hidden_channels
+        self.norm = norm
+        self.rnn = choose_rnn(rnn_type, input_size=num_features, hidden_size=hidden_channels, batch_first=True, bidirectional=bidirectional)
+        self.fc = nn.Linear((2 if bidirectional else 1) * hidden_channels, num_features)
+        if norm:
+            self.norm1d = choose_layer_norm(norm_name, num_features, causal=causal, eps=eps)
+
+    def _run(self, input, seq_axis):
+        """input (B, F, S, K); seq_axis 3 -> recur over K for every (b, s); 2 -> over S for every (b, k)."""
+        B, F, S, K = input.shape
+        self.rnn.flatten_parameters()
+        if seq_axis == 3:
+            x = input.permute(0, 2, 3, 1).reshape(B * S, K, F)
+        else:
+            x = input.permute(0, 3, 2, 1).reshape(B * K, S, F)
+        x, _ = self.rnn(x)
+        x = self.fc(x)                                           # (B*S, K, F) or (B*K, S, F)
+        x = x.reshape(B, S * K, F).permute(0, 2, 1).contiguous()  # (B, F, S*K) [or (B, F, K*S)]
+        if self.norm:
+            x = self.norm1d(x)                                   # statistics over all of (F, S*K): order-free
+        if seq_axis == 3:
+            x = x.view(B, F, S, K)
+        else:
+            x = x.view(B, F, K, S).permute(0, 1, 3, 2)
+        return x + input
+
+
+class IntraChunkRNN(_PathRNN):
+    def __init__(self, num_features, hidden_channels, norm=True, rnn_type="lstm", eps=EPS):
+        super().__init__(num_features, hidden_channels, True, "gLN", norm, rnn_type, False, eps)
+
+    def forward(self, input):
+        return self._run(input, 3)
+
+
+class InterChunkRNN(_PathRNN):
+    def __init__(self, num_features, hidden_channels, causal, norm=True, rnn_type="lstm", eps=EPS):
+        super().__init__(num_features, hidden_channels, not causal, "cLN" if causal else "gLN", norm, rnn_type, causal, eps)
+
+    def forward(self, input):
+        return self._run(input, 2)

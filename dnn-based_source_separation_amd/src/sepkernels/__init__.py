@@ -65,6 +65,8 @@ SIGNATURES = {
     "sep_gln_bwd_rowsums": [_vp, _vp, _vp, _I, _I, _I, _I, _vp],
     "sep_gln_bwd_apply": [_vp] * 6 + [_I] * 4 + [_D, _F, _vp],
     "sep_repack": [_vp, _I, _vp, _I, _I, _I, _vp],
+    "sep_segment": [_vp, _vp] + [_I] * 7 + [_vp],
+    "sep_overlap_add": [_vp, _vp] + [_I] * 7 + [_vp],
     "sep_sisdr_dots": [_vp] * 5 + [_I] * 4 + [_vp],
     "sep_sisdr_from_dots": [_vp] * 4 + [_I] * 3 + [_F, _vp],
     "sep_sisdr_bwd": [_vp] * 7 + [_I] * 4 + [_F, _vp],
@@ -223,6 +225,12 @@ class HipBackend:
 
     def repack(self, src, ld_src, dst, ld_dst, rows, T):
         _check(load().sep_repack(_ptr(src, _f32), ld_src, _ptr(dst, _f32), ld_dst, rows, T, _stream()), "sep_repack")
+
+    def segment(self, x, out, rows, T, ldt, S, chunk, hop, pad_left):
+        _check(load().sep_segment(_ptr(x, _f32), _ptr(out, _f32), rows, T, ldt, S, chunk, hop, pad_left, _stream()), "sep_segment")
+
+    def overlap_add(self, y, out, rows, T, ldt, S, chunk, hop, pad_left):
+        _check(load().sep_overlap_add(_ptr(y, _f32), _ptr(out, _f32), rows, T, ldt, S, chunk, hop, pad_left, _stream()), "sep_overlap_add")
 
     def sisdr_dots(self, est, tgt, dots, tt, xx, B, n, T, all_pairs):
         _check(load().sep_sisdr_dots(_ptr(est, _f32), _ptr(tgt, _f32), _ptr(dots, _f64), _ptr(tt, _f64), _ptr(xx, _f64), B, n, T,

@@ -90,6 +90,121 @@ class Saved:
     pass
 
 
+def head_forward(cfg, P, mixture, stats0):
+    """Encoder (+input padding) and the separator's first gLN + 1x1 bottleneck.
+    Returns (geo, w (B,N,ldt), x0 (B,Bn,ldt)); stats0 (B,SLOTS,2) zeroed by the caller receives the statistics of w."""
+    K = backend()
+    B, Cin, T_in = mixture.shape
+    N, L, S = cfg["n_basis"], cfg["kernel_size"], cfg["stride"]
+    Bn = cfg["sep_bottleneck_channels"]
+    eps = float(cfg.get("eps", 1e-12))
+    relu = cfg.get("enc_nonlinear") == "relu"
+    geo = Geometry(T_in, L, S)
+    F, ldt = geo.F, geo.ldt
+    f32 = dict(device=mixture.device, dtype=mixture.dtype)
+    w = torch.empty(B, N, ldt, **f32)
+    K.encoder_fwd(mixture, P["encoder.conv1d.weight"], w, stats0, B, Cin, T_in, N, L, S, F, ldt, geo.pad_left, relu)
+    x = torch.empty(B, Bn, ldt, **f32)
+    K.pw_gemm(B=B, M=Bn, K=N, T=F, ldt=ldt, A=P["separator.bottleneck_conv1d.weight"], X=w, Y=x,
+              bias=P["separator.bottleneck_conv1d.bias"], pro_mode=PRO_GLN, pro_stats=stats0,
+              pro_gamma=P["separator.norm1d.norm.weight"], pro_beta=P["separator.norm1d.norm.bias"], count=N * F, eps=eps)
+    return geo, w, x
+
+
+def tail_forward(cfg, P, geo, w, core, mixture_shape, want_latent):
+    """PReLU -> 1x1 mask conv -> sigmoid -> mask*w -> decoder (overlap-add) -> crop.  core (B, C, ldt)."""
+    K = backend()
+    B, Cin, T_in = mixture_shape
+    N, L, S, n_src = cfg["n_basis"], cfg["kernel_size"], cfg["stride"], cfg["n_sources"]
+    eps = float(cfg.get("eps", 1e-12))
+    F, ldt = geo.F, geo.ldt
+    C = core.shape[1]
+    f32 = dict(device=w.device, dtype=w.dtype)
+    m = torch.empty(B, n_src * N, ldt, **f32)
+    K.pw_gemm(B=B, M=n_src * N, K=C, T=F, ldt=ldt, A=P["separator.mask_conv1d.weight"], X=core, Y=m,
+              bias=P["separator.mask_conv1d.bias"], pro_mode=PRO_PRELU, pro_alpha=P["separator.prelu.weight"],
+              epi_flags=EPI_SIGMOID, eps=eps)
+    est = torch.empty(B, n_src, Cin, T_in, **f32)
+    latent = torch.empty(B, n_src, N, ldt, **f32) if want_latent else None
+    K.decoder_fwd(w, m, P["decoder.conv_transpose1d.weight"], est, latent, B, n_src, N, Cin, L, S, F, ldt, T_in, geo.pad_left)
+    return est, latent, m
+
+
+def _wgrad(K, B, F, ldt, eps, f32, M, Nn, Gt, Xt, want_bias, Bq=None, weps=None, **kw):
+    Bq = B if Bq is None else Bq
+    ch = Bq * (ldt // 32)
+    ns = _nsplit(M, Nn, ch)
+    part = torch.empty(ns, M, Nn, **f32)
+    pb = torch.empty(ns, M, **f32) if want_bias else None
+    K.pw_wgrad(B=Bq, M=M, N=Nn, T=F, ldt=ldt, G=Gt, X=Xt, partial=part, partial_bias=pb, nsplit=ns,
+               eps=(eps if weps is None else weps), **kw)
+    return part, pb, ns
+
+
+def tail_backward(cfg, P, geo, w, core, m, mixture_shape, d_est, G, dalpha_slot):
+    """Backward of tail_forward.  Writes the gradients of decoder / mask conv; accumulates the PReLU slope gradient
+    into dalpha_slot (double, 1 element, zeroed by the caller).  Returns (dcore (B,C,ldt), dwm (B,N,ldt))."""
+    K = backend()
+    B, Cin, T_in = mixture_shape
+    N, L, S, n_src = cfg["n_basis"], cfg["kernel_size"], cfg["stride"], cfg["n_sources"]
+    eps = float(cfg.get("eps", 1e-12))
+    F, ldt = geo.F, geo.ldt
+    C = core.shape[1]
+    f32 = dict(device=w.device, dtype=w.dtype)
+    d_est = d_est.contiguous()
+    D = P["decoder.conv_transpose1d.weight"]
+    Fd = torch.empty(B * n_src, Cin * L, ldt, **f32)
+    K.unfold(d_est, Fd, B * n_src, Cin, T_in, L, S, F, ldt, geo.pad_left)
+    part, _, ns = _wgrad(K, B, F, ldt, eps, f32, N, Cin * L, m, Fd, False, Bq=B * n_src, Gaux=w, g_mul=1, g_div=n_src)
+    K.reduce_slabs([(part, 0, G["decoder.conv_transpose1d.weight"], N * Cin * L, ns, N * Cin * L, 0, 1.0)])
+    dpre = torch.empty(B, n_src * N, ldt, **f32)
+    dwm = torch.empty(B, N, ldt, **f32)
+    K.decoder_bwd(d_est, w, m, D, dpre, dwm, B, n_src, N, Cin, L, S, F, ldt, T_in, geo.pad_left)
+    Wm = P["separator.mask_conv1d.weight"]
+    alpha_m = P["separator.prelu.weight"]
+    dcore = torch.empty(B, C, ldt, **f32)
+    K.pw_gemm(B=B, M=C, K=n_src * N, T=F, ldt=ldt, trans_a=1, A=Wm, X=dpre, Y=dcore, epi_flags=EPI_PRELU_BWD, epi_aux=core,
+              epi_alpha=alpha_m, epi_dalpha=dalpha_slot, eps=eps)
+    part, pb, ns = _wgrad(K, B, F, ldt, eps, f32, n_src * N, C, dpre, core, True, x_mode=PRO_PRELU, x_alpha=alpha_m)
+    K.reduce_slabs([(part, 0, G["separator.mask_conv1d.weight"], n_src * N * C, ns, n_src * N * C, 0, 1.0),
+                    (pb, 0, G["separator.mask_conv1d.bias"], n_src * N, ns, n_src * N, 0, 1.0)])
+    return dcore, dwm
+
+
+def head_backward(cfg, P, geo, stats0, w, mixture, dx0, dwm, G):
+    """Backward of head_forward given dx0 = d(bottleneck output) and dwm = d(w) arriving through mask*w."""
+    K = backend()
+    B, Cin, T_in = mixture.shape
+    N, L, S = cfg["n_basis"], cfg["kernel_size"], cfg["stride"]
+    Bn = cfg["sep_bottleneck_channels"]
+    eps = float(cfg.get("eps", 1e-12))
+    relu = cfg.get("enc_nonlinear") == "relu"
+    F, ldt = geo.F, geo.ldt
+    f32 = dict(device=w.device, dtype=w.dtype)
+    nt64 = ldt // 64
+    g0, b0 = P["separator.norm1d.norm.weight"], P["separator.norm1d.norm.bias"]
+    Wb = P["separator.bottleneck_conv1d.weight"]
+    cnt0 = N * F
+    part, pb, ns = _wgrad(K, B, F, ldt, eps, f32, Bn, N, dx0, w, True, x_mode=PRO_GLN, x_stats=stats0, x_gamma=g0, x_beta=b0, count=cnt0)
+    dvw = torch.empty(B, N, ldt, **f32)
+    rp0 = torch.empty(B, N, nt64, 2, **f32)
+    K.pw_gemm(B=B, M=N, K=Bn, T=F, ldt=ldt, trans_a=1, A=Wb, X=dx0, Y=dvw, epi_flags=EPI_ROWSUMS, epi_aux=w,
+              epi_rowpart=rp0, eps=eps)
+    bsum0 = torch.empty(B, 2, **f32)
+    pbeta0 = torch.empty(B, N, **f32)
+    pgamma0 = torch.empty(B, N, **f32)
+    K.gln_bwd_finalize(rp0, nt64, 2, stats0, g0, cnt0, eps, bsum0, pbeta0, pgamma0, None, B, N)
+    K.reduce_slabs([(part, 0, G["separator.bottleneck_conv1d.weight"], Bn * N, ns, Bn * N, 0, 1.0),
+                    (pb, 0, G["separator.bottleneck_conv1d.bias"], Bn, ns, Bn, 0, 1.0),
+                    (pbeta0, 0, G["separator.norm1d.norm.bias"], N, B, N, 0, 1.0),
+                    (pgamma0, 0, G["separator.norm1d.norm.weight"], N, B, N, 0, 1.0)])
+    K.head_bwd(dvw, w, dwm, stats0, g0, bsum0, B, N, F, ldt, cnt0, eps, relu)
+    Fx = torch.empty(B, Cin * L, ldt, **f32)
+    K.unfold(mixture, Fx, B, Cin, T_in, L, S, F, ldt, geo.pad_left)
+    part, _, ns = _wgrad(K, B, F, ldt, eps, f32, N, Cin * L, dvw, Fx, False)
+    K.reduce_slabs([(part, 0, G["encoder.conv1d.weight"], N * Cin * L, ns, N * Cin * L, 0, 1.0)])
+
+
 def forward(cfg, P, mixture, want_latent=False, save=True):
     """cfg: model config dict; P: dict name -> parameter tensor; mixture (B, Cin, T) fp32 contiguous.
     Returns (est (B, n_src, Cin, T), latent or None, Saved or None)."""
@@ -109,13 +224,7 @@ def forward(cfg, P, mixture, want_latent=False, save=True):
     f32 = dict(device=dev, dtype=mixture.dtype)   # always fp32 in the product; the CPU emulator tests also run fp64
 
     stats = torch.zeros(2 * nl + 1, B, STATS_SLOTS, 2, device=dev, dtype=torch.float64)
-    w = torch.empty(B, N, ldt, **f32)
-    K.encoder_fwd(mixture, P["encoder.conv1d.weight"], w, stats[0], B, Cin, T_in, N, L, S, F, ldt, geo.pad_left, relu)
-
-    x = torch.empty(B, Bn, ldt, **f32)
-    K.pw_gemm(B=B, M=Bn, K=N, T=F, ldt=ldt, A=P["separator.bottleneck_conv1d.weight"], X=w, Y=x,
-              bias=P["separator.bottleneck_conv1d.bias"], pro_mode=PRO_GLN, pro_stats=stats[0],
-              pro_gamma=P["separator.norm1d.norm.weight"], pro_beta=P["separator.norm1d.norm.bias"], count=N * F, eps=eps)
+    geo, w, x = head_forward(cfg, P, mixture, stats[0])
 
     skip = torch.empty(B, Sc, ldt, **f32)
     acts = []
@@ -151,14 +260,7 @@ def forward(cfg, P, mixture, want_latent=False, save=True):
         acts.append((x, a, z))
         x = xo
 
-    m = torch.empty(B, n_src * N, ldt, **f32)
-    K.pw_gemm(B=B, M=n_src * N, K=Sc, T=F, ldt=ldt, A=P["separator.mask_conv1d.weight"], X=skip, Y=m,
-              bias=P["separator.mask_conv1d.bias"], pro_mode=PRO_PRELU, pro_alpha=P["separator.prelu.weight"],
-              epi_flags=EPI_SIGMOID, eps=eps)
-
-    est = torch.empty(B, n_src, Cin, T_in, **f32)
-    latent = torch.empty(B, n_src, N, ldt, **f32) if want_latent else None
-    K.decoder_fwd(w, m, P["decoder.conv_transpose1d.weight"], est, latent, B, n_src, N, Cin, L, S, F, ldt, T_in, geo.pad_left)
+    est, latent, m = tail_forward(cfg, P, geo, w, skip, mixture.shape, want_latent)
 
     sv = None
     if save:
@@ -189,32 +291,10 @@ def backward(cfg, P, sv, d_est, G):
     dalpha = torch.zeros(nl + 1, device=dev, dtype=torch.float64)   # [layer alpha1 ..., mask prelu]
 
     def wgrad(M, Nn, Gt, Xt, dW, dbias=None, Bq=B, weps=None, **kw):
-        ch = Bq * (ldt // 32)
-        ns = _nsplit(M, Nn, ch)
-        part = torch.empty(ns, M, Nn, **f32)
-        pb = torch.empty(ns, M, **f32) if dbias is not None else None
-        K.pw_wgrad(B=Bq, M=M, N=Nn, T=F, ldt=ldt, G=Gt, X=Xt, partial=part, partial_bias=pb, nsplit=ns, eps=(eps if weps is None else weps), **kw)
-        return part, pb, ns
+        return _wgrad(K, B, F, ldt, eps, f32, M, Nn, Gt, Xt, dbias is not None, Bq=Bq, weps=weps, **kw)
 
     # ---- tail: decoder / mask ---------------------------------------------------------------------
-    d_est = d_est.contiguous()
-    D = P["decoder.conv_transpose1d.weight"]
-    Fd = torch.empty(B * n_src, Cin * L, ldt, **f32)
-    K.unfold(d_est, Fd, B * n_src, Cin, T_in, L, S, F, ldt, geo.pad_left)
-    part, _, ns = wgrad(N, Cin * L, m, Fd, True, None, Bq=B * n_src, Gaux=w, g_mul=1, g_div=n_src)
-    K.reduce_slabs([(part, 0, G["decoder.conv_transpose1d.weight"], N * Cin * L, ns, N * Cin * L, 0, 1.0)])
-    dpre = torch.empty(B, n_src * N, ldt, **f32)
-    dwm = torch.empty(B, N, ldt, **f32)
-    K.decoder_bwd(d_est, w, m, D, dpre, dwm, B, n_src, N, Cin, L, S, F, ldt, T_in, geo.pad_left)
-
-    Wm = P["separator.mask_conv1d.weight"]
-    alpha_m = P["separator.prelu.weight"]
-    dS = torch.empty(B, Sc, ldt, **f32)
-    K.pw_gemm(B=B, M=Sc, K=n_src * N, T=F, ldt=ldt, trans_a=1, A=Wm, X=dpre, Y=dS, epi_flags=EPI_PRELU_BWD, epi_aux=skip,
-              epi_alpha=alpha_m, epi_dalpha=dalpha[nl:nl + 1], eps=eps)
-    part, pb, ns = wgrad(n_src * N, Sc, dpre, skip, True, True, x_mode=PRO_PRELU, x_alpha=alpha_m)
-    K.reduce_slabs([(part, 0, G["separator.mask_conv1d.weight"], n_src * N * Sc, ns, n_src * N * Sc, 0, 1.0),
-                    (pb, 0, G["separator.mask_conv1d.bias"], n_src * N, ns, n_src * N, 0, 1.0)])
+    dS, dwm = tail_backward(cfg, P, geo, w, skip, m, mixture.shape, d_est, G, dalpha[nl:nl + 1])
 
     # ---- TCN layers, reversed -----------------------------------------------------------------------
     dout = None
@@ -299,24 +379,4 @@ def backward(cfg, P, sv, d_est, G):
     K.f64_to_f32(dalpha[nl:nl + 1], G["separator.prelu.weight"], 1, 0)
 
     # ---- head: bottleneck conv, first gLN, encoder ------------------------------------------------------
-    g0, b0 = P["separator.norm1d.norm.weight"], P["separator.norm1d.norm.bias"]
-    Wb = P["separator.bottleneck_conv1d.weight"]
-    cnt0 = N * F
-    part, pb, ns = wgrad(Bn, N, dout, w, True, True, x_mode=PRO_GLN, x_stats=stats[0], x_gamma=g0, x_beta=b0, count=cnt0)
-    dvw = torch.empty(B, N, ldt, **f32)
-    rp0 = torch.empty(B, N, nt64, 2, **f32)
-    K.pw_gemm(B=B, M=N, K=Bn, T=F, ldt=ldt, trans_a=1, A=Wb, X=dout, Y=dvw, epi_flags=EPI_ROWSUMS, epi_aux=w,
-              epi_rowpart=rp0, eps=eps)
-    bsum0 = torch.empty(B, 2, **f32)
-    pbeta0 = torch.empty(B, N, **f32)
-    pgamma0 = torch.empty(B, N, **f32)
-    K.gln_bwd_finalize(rp0, nt64, 2, stats[0], g0, cnt0, eps, bsum0, pbeta0, pgamma0, None, B, N)
-    K.reduce_slabs([(part, 0, G["separator.bottleneck_conv1d.weight"], Bn * N, ns, Bn * N, 0, 1.0),
-                    (pb, 0, G["separator.bottleneck_conv1d.bias"], Bn, ns, Bn, 0, 1.0),
-                    (pbeta0, 0, G["separator.norm1d.norm.bias"], N, B, N, 0, 1.0),
-                    (pgamma0, 0, G["separator.norm1d.norm.weight"], N, B, N, 0, 1.0)])
-    K.head_bwd(dvw, w, dwm, stats[0], g0, bsum0, B, N, F, ldt, cnt0, eps, relu)
-    Fx = torch.empty(B, Cin * L, ldt, **f32)
-    K.unfold(mixture, Fx, B, Cin, T_in, L, S, F, ldt, geo.pad_left)
-    part, _, ns = wgrad(N, Cin * L, dvw, Fx, True, None)
-    K.reduce_slabs([(part, 0, G["encoder.conv1d.weight"], N * Cin * L, ns, N * Cin * L, 0, 1.0)])
+    head_backward(cfg, P, geo, stats[0], w, mixture, dout, dwm, G)

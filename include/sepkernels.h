@@ -208,6 +208,15 @@ int sep_gln_bwd_rowsums(const float* dy, const float* x, float* rowpart, int B, 
 int sep_gln_bwd_apply(const float* dy, const float* x, const double* stats, const float* gamma, const float* bsum,
                       float* dx, int B, int C, int T, int ldt, double count, float eps, sep_stream_t stream);
 
+/* Segment1d / OverlapAdd1d (models/transform.py:6-65) for rows = B*C padded rows of x (T valid frames, stride ldt):
+ *   segment:     out[row][s][k] = xpad[row][s*hop + k]   (xpad = x shifted right by pad_left, zero elsewhere)
+ *   overlap_add: out[row][t]    = sum_{s*hop + k == t + pad_left} y[row][s][k] for t < T, 0 for T <= t < ldt
+ * adjoint pair: each one is the other's backward. */
+int sep_segment(const float* x, float* out, int rows, int T, int ldt, int S, int chunk, int hop, int pad_left,
+                sep_stream_t stream);
+int sep_overlap_add(const float* y, float* out, int rows, int T, int ldt, int S, int chunk, int hop, int pad_left,
+                    sep_stream_t stream);
+
 /* (B, C, T) <-> (B, C, ldt) repack with zero fill of the pad frames */
 int sep_repack(const float* src, int ld_src, float* dst, int ld_dst, int rows, int T, sep_stream_t stream);
 

@@ -167,6 +167,36 @@ def op_golden(NegSISDR):
     np.savez_compressed(os.path.join(OUT, "ops.npz"), **blob)
 
 
+DPRNN_CFG = dict(n_basis=64, kernel_size=2, stride=1, enc_basis="trainable", dec_basis="trainable", enc_nonlinear=None,
+                 sep_hidden_channels=32, sep_bottleneck_channels=64, sep_chunk_size=20, sep_hop_size=10, sep_num_blocks=2,
+                 sep_norm=True, mask_nonlinear="sigmoid", causal=False, rnn_type="lstm", n_sources=2)
+
+
+def dprnn_golden(NegSISDR, PIT1d):
+    """DPRNN-TasNet (reference src/models/dprnn_tasnet.py), small configuration, fp64 module run as ground truth."""
+    import copy
+    from models.dprnn_tasnet import DPRNNTasNet
+    torch.manual_seed(111)
+    model = DPRNNTasNet(**DPRNN_CFG)
+    perturb(model, 11)
+    g = torch.Generator().manual_seed(333)
+    sources = 0.1 * torch.randn(2, 2, 813, generator=g)          # 812 frames -> exercises the chunk padding
+    mixture = sources.sum(dim=1, keepdim=True)
+    m64 = copy.deepcopy(model).double()
+    out64, latent64 = m64.extract_latent(mixture.double())
+    loss64, pattern = PIT1d(NegSISDR(), n_sources=2)(out64, sources.double())
+    loss64.backward()
+    blob = {"mixture": mixture.numpy(), "sources": sources.numpy(), "output_f64": out64.detach().numpy(),
+            "latent_f64_sum": np.array(latent64.detach().sum().item()), "loss_f64": np.array(loss64.item()),
+            "pattern": pattern.numpy(), "num_parameters": np.array(model.num_parameters)}
+    for k, v in model.state_dict().items():
+        blob["param/" + k] = v.numpy()
+    for k, p in m64.named_parameters():
+        blob["grad/" + k] = p.grad.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "dprnn_tasnet_small.npz"), **blob)
+    print("dprnn params", model.num_parameters, "loss", loss64.item(), "pattern", pattern.tolist())
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -175,4 +205,5 @@ if __name__ == "__main__":
         model_golden(name, ConvTasNet, NegSISDR, PIT1d)
     pit_kat(NegSISDR, SISDR, PIT1d, SinkPIT)
     op_golden(NegSISDR)
+    dprnn_golden(NegSISDR, PIT1d)
     print("golden vectors written to", OUT)

@@ -335,6 +335,22 @@ class EmuBackend:
         d.zero_()
         d[:, :T] = src.reshape(rows, ld_src)[:, :T]
 
+    def segment(self, x, out, rows, T, ldt, S, chunk, hop, pad_left):
+        total = (S - 1) * hop + chunk
+        xp = torch.zeros(rows, total + pad_left + T, dtype=x.dtype)
+        xp[:, pad_left:pad_left + T] = x.reshape(rows, ldt)[:, :T]
+        idx = (torch.arange(S) * hop).view(S, 1) + torch.arange(chunk).view(1, chunk)
+        out.reshape(rows, S, chunk).copy_(xp[:, idx])
+
+    def overlap_add(self, y, out, rows, T, ldt, S, chunk, hop, pad_left):
+        total = (S - 1) * hop + chunk
+        acc = torch.zeros(rows, total + T, dtype=y.dtype)
+        idx = ((torch.arange(S) * hop).view(S, 1) + torch.arange(chunk).view(1, chunk)).reshape(-1)
+        acc.index_add_(1, idx, y.reshape(rows, S * chunk))
+        o = out.reshape(rows, ldt)
+        o.zero_()
+        o[:, :T] = acc[:, pad_left:pad_left + T]
+
     # ------------------------------------------------------------------ losses
     def sisdr_dots(self, est, tgt, dots, tt, xx, B, n, T, all_pairs):
         e, t = est.reshape(B, n, T).double(), tgt.reshape(B, n, T).double()

@@ -365,3 +365,15 @@ def test_sqnorm_and_adam():
     both("sqnorm", [g, sq, n], tol=1e-6)
     both("adam_step", [p, g, m, v, sq, n, 1e-3, 0.9, 0.999, 1e-8, 0.0, 5.0, 0.5, 3], tol=1e-5)
     both("adam_step", [p, g, m, v, sq, n, 1e-3, 0.9, 0.999, 1e-8, 0.01, 0.0, 1.0, 4], tol=1e-5)
+
+
+@pytest.mark.parametrize("T,chunk,hop", [(812, 20, 10), (3999, 250, 125), (100, 16, 4), (64, 64, 64)])
+def test_segment_overlap_add(T, chunk, hop):
+    B, C = 2, 5
+    ldt = (T + 127) // 128 * 128
+    padding = (hop - (T - chunk) % hop) % hop
+    pad_left = padding // 2
+    S = (T + padding - chunk) // hop + 1
+    x = padded(B, C, T, ldt)
+    both("segment", [x, nan(B, C, S, chunk), B * C, T, ldt, S, chunk, hop, pad_left], tol=0.0)
+    both("overlap_add", [rnd(B, C, S, chunk), nan(B, C, ldt), B * C, T, ldt, S, chunk, hop, pad_left], tol=1e-6)

@@ -182,3 +182,23 @@ def test_global_layer_norm_module_on_gpu():
     assert _rel(xg.grad, xr.grad) <= 1e-3
     assert _rel(norm.norm.weight.grad, ref.weight.grad) <= 1e-3
     assert _rel(norm.norm.bias.grad, ref.bias.grad) <= 1e-3
+
+
+def test_dprnn_tasnet_golden(golden_dir):
+    """BASELINE.json configs[3] family (small instance): head/tail kernels + segment/overlap-add + interim torch LSTM."""
+    from oracle.make_golden import DPRNN_CFG
+    from models.dprnn_tasnet import DPRNNTasNet
+    g = np.load(os.path.join(golden_dir, "dprnn_tasnet_small.npz"))
+    model = DPRNNTasNet(**DPRNN_CFG)
+    model.load_state_dict({k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param/")})
+    model.cuda()
+    mixture, sources = torch.from_numpy(g["mixture"]).cuda(), torch.from_numpy(g["sources"]).cuda()
+    est, latent = model.extract_latent(mixture)
+    ref = torch.from_numpy(g["output_f64"])
+    assert _rel(est, ref) <= TOL
+    loss, pattern = PIT1d(NegSISDR(), n_sources=2)(est, sources)
+    assert abs(loss.item() - float(g["loss_f64"])) <= TOL * abs(float(g["loss_f64"]))
+    assert np.array_equal(pattern.cpu().numpy(), g["pattern"])
+    loss.backward()
+    flat_rel, worst = _grad_report(model, {k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("grad/")})
+    assert flat_rel <= 2e-3, "flat gradient rel-inf {:.3e}, worst tensor {}".format(flat_rel, worst)
