@@ -623,6 +623,64 @@ __global__ __launch_bounds__(256) void overlap_add_kernel(const float* __restric
     out[(size_t)row * ldt + t] = acc;
 }
 
+
+// =====================================================================================
+// Generic depthwise Conv1d (reference src/modules/conv.py:13-29, nn.Conv1d(groups=C) with any kernel size / stride /
+// padding / dilation).  Not on the Conv-TasNet hot path (its depthwise is dwconv_fwd above); plain streaming kernels.
+//   y[r][to] = bias[c] + sum_k w[c][k] * xpad[r][to*stride + k*dil - pad]           r = b*C + c
+// =====================================================================================
+__global__ __launch_bounds__(256) void depthwise_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ y, int C,
+                                                            int Tin, int Tout, int Kw, int stride, int pad, int dil) {
+    const int row = blockIdx.y, c = row % C;
+    const int to = blockIdx.x * 256 + threadIdx.x;
+    if (to >= Tout) return;
+    float acc = bias ? bias[c] : 0.f;
+    for (int k = 0; k < Kw; ++k) {
+        const int ti = to * stride + k * dil - pad;
+        if (ti >= 0 && ti < Tin) acc = fmaf(w[c * Kw + k], x[(size_t)row * Tin + ti], acc);
+    }
+    y[(size_t)row * Tout + to] = acc;
+}
+
+__global__ __launch_bounds__(256) void depthwise_bwd_input_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                  float* __restrict__ dx, int C, int Tin, int Tout, int Kw,
+                                                                  int stride, int pad, int dil) {
+    const int row = blockIdx.y, c = row % C;
+    const int ti = blockIdx.x * 256 + threadIdx.x;
+    if (ti >= Tin) return;
+    float acc = 0.f;
+    for (int k = 0; k < Kw; ++k) {
+        const int num = ti + pad - k * dil;
+        if (num >= 0 && num % stride == 0) {
+            const int to = num / stride;
+            if (to < Tout) acc = fmaf(w[c * Kw + k], dy[(size_t)row * Tout + to], acc);
+        }
+    }
+    dx[(size_t)row * Tin + ti] = acc;
+}
+
+// partial[b][c][0..Kw-1] = sum_to dy * xpad(tap k) ; partial[b][c][Kw] = sum_to dy     (one block per (b, c) row)
+__global__ __launch_bounds__(256) void depthwise_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                   float* __restrict__ partial, int C, int Tin, int Tout, int Kw,
+                                                                   int stride, int pad, int dil) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    for (int k = 0; k <= Kw; ++k) {
+        float acc = 0.f;
+        for (int to = threadIdx.x; to < Tout; to += 256) {
+            const float g = dy[(size_t)row * Tout + to];
+            if (k == Kw) acc += g;
+            else {
+                const int ti = to * stride + k * dil - pad;
+                if (ti >= 0 && ti < Tin) acc = fmaf(g, x[(size_t)row * Tin + ti], acc);
+            }
+        }
+        const float tot = block_sum_256<float>(acc, red);
+        if (threadIdx.x == 0) partial[(size_t)row * (Kw + 1) + k] = tot;
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------
@@ -819,5 +877,30 @@ extern "C" int sep_overlap_add(const float* y, float* out, int rows, int T, int 
         done += nr;
     }
     SEP_CHECK_LAUNCH("sep_overlap_add");
+    return 0;
+}
+
+extern "C" int sep_depthwise_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C, int Tin, int Tout,
+                                 int Kw, int stride, int pad, int dil, sep_stream_t stream) {
+    SEP_REQUIRE(x && w && y && B > 0 && C > 0 && Tin > 0 && Tout > 0 && Kw > 0 && stride > 0 && dil > 0 && pad >= 0, "sep_depthwise_fwd: bad arguments");
+    SEP_REQUIRE((long)B * C <= 65535, "sep_depthwise_fwd: B*C too large");
+    hipLaunchKernelGGL(depthwise_fwd_kernel, dim3(ceil_div(Tout, 256), B * C), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, C, Tin, Tout, Kw, stride, pad, dil);
+    SEP_CHECK_LAUNCH("sep_depthwise_fwd");
+    return 0;
+}
+
+extern "C" int sep_depthwise_bwd_input(const float* dy, const float* w, float* dx, int B, int C, int Tin, int Tout, int Kw,
+                                       int stride, int pad, int dil, sep_stream_t stream) {
+    SEP_REQUIRE(dy && w && dx && (long)B * C <= 65535 && stride > 0, "sep_depthwise_bwd_input: bad arguments");
+    hipLaunchKernelGGL(depthwise_bwd_input_kernel, dim3(ceil_div(Tin, 256), B * C), dim3(256), 0, (hipStream_t)stream, dy, w, dx, C, Tin, Tout, Kw, stride, pad, dil);
+    SEP_CHECK_LAUNCH("sep_depthwise_bwd_input");
+    return 0;
+}
+
+extern "C" int sep_depthwise_bwd_weight(const float* dy, const float* x, float* partial, int B, int C, int Tin, int Tout, int Kw,
+                                        int stride, int pad, int dil, sep_stream_t stream) {
+    SEP_REQUIRE(dy && x && partial && B > 0 && C > 0, "sep_depthwise_bwd_weight: bad arguments");
+    hipLaunchKernelGGL(depthwise_bwd_weight_kernel, dim3(B * C), dim3(256), 0, (hipStream_t)stream, dy, x, partial, C, Tin, Tout, Kw, stride, pad, dil);
+    SEP_CHECK_LAUNCH("sep_depthwise_bwd_weight");
     return 0;
 }

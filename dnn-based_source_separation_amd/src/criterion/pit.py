@@ -149,3 +149,63 @@ class SinkPIT(nn.Module):
         loss, permutation_matrix = sinkpit(self.criterion, input, target, n_sources=self.n_sources, coldness=self.coldness,
                                            iteration=self.iteration, batch_mean=batch_mean)
         return loss, torch.argmax(permutation_matrix, dim=2)
+
+
+class ORPIT(nn.Module):
+    """
+    One-and-Rest permutation invariant training (reference pit.py:87-161): for every item the "one" output is matched
+    against each source in turn and the "rest" output against the sum of the others,
+        loss_idx = criterion(input_one, target_idx) + criterion(input_rest, sum_{j != idx} target_j) / (n_sources - 1),
+    and the best candidate (min, or max if criterion.maximize) is kept.  The reference evaluates the criterion
+    2 * n_sources times per item inside a python loop over the batch; here all candidates of the whole batch go through
+    ONE criterion call on (n_candidates, T) tensors (with the SI-SDR criteria: one sep_sisdr_dots launch).
+    """
+
+    def __init__(self, criterion):
+        super().__init__()
+        self.criterion = criterion
+        self.patterns = torch.tensor(list(itertools.permutations(range(2))), dtype=torch.long)
+
+    def forward(self, input, target, batch_mean=True):
+        """
+        Args:
+            input (batch_size, 2, *)
+            target (batch_size, n_sources, *) tensor, or a PackedSequence when n_sources differs per item
+        Returns:
+            loss () or (batch_size,), indices (batch_size,)
+        """
+        assert input.size(1) == 2, "input.size() is expected (batch_size, 2, *), but given {}".format(input.size())
+        if isinstance(target, torch.Tensor):
+            lens = [target.size(1)] * target.size(0)
+        else:
+            target, lens = nn.utils.rnn.pad_packed_sequence(target, batch_first=True)
+            lens = [int(n) for n in lens]
+        B = input.size(0)
+        ones, rests, t_one, t_rest, owner, scale = [], [], [], [], [], []
+        for b in range(B):
+            n = lens[b]
+            tb = target[b, :n]                                   # (n, *)
+            total = tb.sum(dim=0, keepdim=True)
+            t_one.append(tb)
+            t_rest.append(total - tb)                            # sum of the others, for every candidate at once
+            ones.append(input[b, 0:1].expand(n, *input.shape[2:]))
+            rests.append(input[b, 1:2].expand(n, *input.shape[2:]))
+            owner += [b] * n
+            scale += [1.0 / (n - 1)] * n
+        ones, rests = torch.cat(ones, 0).contiguous(), torch.cat(rests, 0).contiguous()
+        t_one, t_rest = torch.cat(t_one, 0).contiguous(), torch.cat(t_rest, 0).contiguous()
+        loss_one = self.criterion(ones, t_one, batch_mean=False)
+        loss_rest = self.criterion(rests, t_rest, batch_mean=False)
+        cand = loss_one + loss_rest * torch.tensor(scale, device=loss_one.device, dtype=loss_one.dtype)
+        maximize = bool(getattr(self.criterion, "maximize", False))
+        losses, indices, start = [], [], 0
+        for b in range(B):
+            seg = cand[start:start + lens[b]]
+            val, idx = (seg.max(dim=0) if maximize else seg.min(dim=0))
+            losses.append(val)
+            indices.append(idx)
+            start += lens[b]
+        batch_loss, batch_indices = torch.stack(losses), torch.stack(indices)
+        if batch_mean:
+            batch_loss = batch_loss.mean(dim=0)
+        return batch_loss, batch_indices

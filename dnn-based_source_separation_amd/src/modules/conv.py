@@ -1,11 +1,12 @@
 """
 `DepthwiseSeparableConv1d` of reference src/modules/conv.py:13-29 (depthwise -> pointwise, no norm/activation).
 Conv-TasNet does NOT use this class (its separable block is models/tdcn.py's class of the same name); it is the
-`src/conv.py` the north-star text mentions.  Parameter container with the reference's names; the pointwise half
-runs on the MFMA GEMM of libsepkernels, the generic strided/padded depthwise half is not on the SURVEY section 8
-path and is not implemented yet.
+`src/conv.py` the north-star text mentions.  Parameter container with the reference's names; the depthwise half is a generic
+streaming kernel (sep_depthwise_*), the pointwise half runs on the MFMA GEMM of libsepkernels.
 """
 import torch.nn as nn
+
+from sepkernels.functional import DepthwiseConv1dFn, PointwiseConv1dFn
 
 
 class DepthwiseSeparableConv1d(nn.Module):
@@ -19,5 +20,7 @@ class DepthwiseSeparableConv1d(nn.Module):
         self.pointwise_conv1d = nn.Conv1d(in_channels, out_channels, kernel_size=1, stride=1, bias=bias)
 
     def forward(self, input):
-        raise NotImplementedError("modules.conv.DepthwiseSeparableConv1d: generic strided depthwise is not part of the "
-                                  "Conv-TasNet hot path (SURVEY.md section 8 row a14) and has no HIP kernel yet")
+        """input (B, in_channels, T) -> (B, out_channels, T')"""
+        dw, pw = self.depthwise_conv1d, self.pointwise_conv1d
+        x = DepthwiseConv1dFn.apply(input, dw.weight, dw.bias, dw.stride[0], dw.padding[0], dw.dilation[0])
+        return PointwiseConv1dFn.apply(x, pw.weight, pw.bias)

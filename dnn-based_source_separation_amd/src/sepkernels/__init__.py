@@ -66,6 +66,9 @@ SIGNATURES = {
     "sep_gln_bwd_apply": [_vp] * 6 + [_I] * 4 + [_D, _F, _vp],
     "sep_repack": [_vp, _I, _vp, _I, _I, _I, _vp],
     "sep_segment": [_vp, _vp] + [_I] * 7 + [_vp],
+    "sep_depthwise_fwd": [_vp] * 4 + [_I] * 8 + [_vp],
+    "sep_depthwise_bwd_input": [_vp] * 3 + [_I] * 8 + [_vp],
+    "sep_depthwise_bwd_weight": [_vp] * 3 + [_I] * 8 + [_vp],
     "sep_overlap_add": [_vp, _vp] + [_I] * 7 + [_vp],
     "sep_sisdr_dots": [_vp] * 5 + [_I] * 4 + [_vp],
     "sep_sisdr_from_dots": [_vp] * 4 + [_I] * 3 + [_F, _vp],
@@ -225,6 +228,18 @@ class HipBackend:
 
     def repack(self, src, ld_src, dst, ld_dst, rows, T):
         _check(load().sep_repack(_ptr(src, _f32), ld_src, _ptr(dst, _f32), ld_dst, rows, T, _stream()), "sep_repack")
+
+    def depthwise_fwd(self, x, w, bias, y, B, C, Tin, Tout, Kw, stride, pad, dil):
+        _check(load().sep_depthwise_fwd(_ptr(x, _f32), _ptr(w, _f32), _ptr(bias, _f32), _ptr(y, _f32), B, C, Tin, Tout, Kw, stride,
+                                        pad, dil, _stream()), "sep_depthwise_fwd")
+
+    def depthwise_bwd_input(self, dy, w, dx, B, C, Tin, Tout, Kw, stride, pad, dil):
+        _check(load().sep_depthwise_bwd_input(_ptr(dy, _f32), _ptr(w, _f32), _ptr(dx, _f32), B, C, Tin, Tout, Kw, stride, pad, dil,
+                                              _stream()), "sep_depthwise_bwd_input")
+
+    def depthwise_bwd_weight(self, dy, x, partial, B, C, Tin, Tout, Kw, stride, pad, dil):
+        _check(load().sep_depthwise_bwd_weight(_ptr(dy, _f32), _ptr(x, _f32), _ptr(partial, _f32), B, C, Tin, Tout, Kw, stride, pad,
+                                               dil, _stream()), "sep_depthwise_bwd_weight")
 
     def segment(self, x, out, rows, T, ldt, S, chunk, hop, pad_left):
         _check(load().sep_segment(_ptr(x, _f32), _ptr(out, _f32), rows, T, ldt, S, chunk, hop, pad_left, _stream()), "sep_segment")

@@ -125,3 +125,90 @@ class OverlapAddFn(torch.autograd.Function):
         dy = torch.empty(B, C, S, chunk, device=g.device, dtype=g.dtype)
         K.segment(g.contiguous(), dy, B * C, T, ldt, S, chunk, hop, pad_left)
         return dy, None, None, None
+
+
+def _round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+class PointwiseConv1dFn(torch.autograd.Function):
+    """nn.Conv1d(kernel_size=1) on the MFMA GEMM: x (B, Cin, T), weight (Cout, Cin, 1), bias (Cout) or None."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        K = backend()
+        B, Cin, T = x.shape
+        Cout = weight.shape[0]
+        if Cin % 16:
+            raise NotImplementedError("PointwiseConv1dFn: in_channels must be a multiple of 16")
+        ldt = _round_up(T, 128)
+        f32 = dict(device=x.device, dtype=x.dtype)
+        xp = torch.empty(B, Cin, ldt, **f32)
+        K.repack(x.contiguous(), T, xp, ldt, B * Cin, T)
+        yp = torch.empty(B, Cout, ldt, **f32)
+        K.pw_gemm(B=B, M=Cout, K=Cin, T=T, ldt=ldt, A=weight, X=xp, Y=yp, bias=bias)
+        y = torch.empty(B, Cout, T, **f32)
+        K.repack(yp, ldt, y, T, B * Cout, T)
+        ctx.save_for_backward(xp, weight)
+        ctx.meta = (B, Cin, Cout, T, ldt, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        K = backend()
+        xp, weight = ctx.saved_tensors
+        B, Cin, Cout, T, ldt, has_bias = ctx.meta
+        f32 = dict(device=xp.device, dtype=xp.dtype)
+        dyp = torch.empty(B, Cout, ldt, **f32)
+        K.repack(dy.contiguous(), T, dyp, ldt, B * Cout, T)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if Cout % 16 or Cin % 4:
+                raise NotImplementedError("PointwiseConv1dFn backward: out_channels must be a multiple of 16")
+            dxp = torch.empty(B, Cin, ldt, **f32)
+            K.pw_gemm(B=B, M=Cin, K=Cout, T=T, ldt=ldt, trans_a=1, A=weight, X=dyp, Y=dxp)
+            dx = torch.empty(B, Cin, T, **f32)
+            K.repack(dxp, ldt, dx, T, B * Cin, T)
+        ns = _net._nsplit(Cout, Cin, B * (ldt // 32))
+        part = torch.empty(ns, Cout, Cin, **f32)
+        pb = torch.empty(ns, Cout, **f32)
+        K.pw_wgrad(B=B, M=Cout, N=Cin, T=T, ldt=ldt, G=dyp, X=xp, partial=part, partial_bias=pb, nsplit=ns)
+        dW = torch.empty_like(weight)
+        db = torch.empty(Cout, **f32)
+        K.reduce_slabs([(part, 0, dW, Cout * Cin, ns, Cout * Cin, 0, 1.0), (pb, 0, db, Cout, ns, Cout, 0, 1.0)])
+        return dx, dW, (db if has_bias else None)
+
+
+class DepthwiseConv1dFn(torch.autograd.Function):
+    """nn.Conv1d(C, C, k, stride, padding, dilation, groups=C): x (B, C, T), weight (C, 1, k), bias (C) or None."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, dilation):
+        K = backend()
+        x = x.contiguous()
+        B, C, Tin = x.shape
+        Kw = weight.shape[-1]
+        Tout = (Tin + 2 * padding - dilation * (Kw - 1) - 1) // stride + 1
+        y = torch.empty(B, C, Tout, device=x.device, dtype=x.dtype)
+        K.depthwise_fwd(x, weight, bias, y, B, C, Tin, Tout, Kw, stride, padding, dilation)
+        ctx.save_for_backward(x, weight)
+        ctx.meta = (B, C, Tin, Tout, Kw, stride, padding, dilation, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        K = backend()
+        x, weight = ctx.saved_tensors
+        B, C, Tin, Tout, Kw, stride, padding, dilation, has_bias = ctx.meta
+        dy = dy.contiguous()
+        f32 = dict(device=x.device, dtype=x.dtype)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(B, C, Tin, **f32)
+            K.depthwise_bwd_input(dy, weight, dx, B, C, Tin, Tout, Kw, stride, padding, dilation)
+        part = torch.empty(B, C, Kw + 1, **f32)
+        K.depthwise_bwd_weight(dy, x, part, B, C, Tin, Tout, Kw, stride, padding, dilation)
+        dwb = torch.empty(C * (Kw + 1), **f32)
+        K.reduce_slabs([(part, 0, dwb, C * (Kw + 1), B, C * (Kw + 1), 0, 1.0)])
+        dwb = dwb.view(C, Kw + 1)
+        return dx, dwb[:, :Kw].reshape(C, 1, Kw).contiguous(), (dwb[:, Kw].contiguous() if has_bias else None), None, None, None

@@ -217,6 +217,17 @@ int sep_segment(const float* x, float* out, int rows, int T, int ldt, int S, int
 int sep_overlap_add(const float* y, float* out, int rows, int T, int ldt, int S, int chunk, int hop, int pad_left,
                     sep_stream_t stream);
 
+/* Generic depthwise Conv1d of modules.conv.DepthwiseSeparableConv1d (src/modules/conv.py:13-29; nn.Conv1d(groups=C) with
+ * kernel size Kw, stride, zero padding, dilation) on contiguous (B, C, T) tensors:
+ *   y[b][c][to] = bias[c] + sum_k w[c][k] * xpad[b][c][to*stride + k*dil - pad]
+ * bwd_weight writes partial[b][c][0..Kw-1] = dL/dw contributions and partial[b][c][Kw] = dL/dbias contribution of row (b,c). */
+int sep_depthwise_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C, int Tin, int Tout, int Kw,
+                      int stride, int pad, int dil, sep_stream_t stream);
+int sep_depthwise_bwd_input(const float* dy, const float* w, float* dx, int B, int C, int Tin, int Tout, int Kw, int stride,
+                            int pad, int dil, sep_stream_t stream);
+int sep_depthwise_bwd_weight(const float* dy, const float* x, float* partial, int B, int C, int Tin, int Tout, int Kw,
+                             int stride, int pad, int dil, sep_stream_t stream);
+
 /* (B, C, T) <-> (B, C, ldt) repack with zero fill of the pad frames */
 int sep_repack(const float* src, int ld_src, float* dst, int ld_dst, int rows, int T, sep_stream_t stream);
 

@@ -133,6 +133,21 @@ def pit_kat(NegSISDR, SISDR, PIT1d, SinkPIT):
     loss.backward()
     blob.update(sg_x=x.detach().numpy(), sg_t=t.numpy(), sg_loss=np.array(loss.item()), sg_pattern=pattern.numpy(),
                 sg_grad=x.grad.numpy())
+    # ORPIT (pit.py:87-161) with a variable number of sources per item (packed sequence), fp64
+    from criterion.pit import ORPIT
+    import torch.nn as nn
+    g = torch.Generator().manual_seed(17)
+    lens = [3, 2, 4]
+    tg = [torch.randn(n, 500, generator=g, dtype=torch.float64) for n in lens]
+    x = torch.stack([torch.stack([t[1 % len(t)] + 0.3 * torch.randn(500, generator=g, dtype=torch.float64),
+                                  t.sum(0) - t[1 % len(t)] + 0.3 * torch.randn(500, generator=g, dtype=torch.float64)]) for t in tg])
+    x.requires_grad_(True)
+    packed = nn.utils.rnn.pack_sequence(tg, enforce_sorted=False)
+    loss, idx = ORPIT(NegSISDR())(x, packed, batch_mean=False)
+    loss.sum().backward()
+    blob.update(orpit_x=x.detach().numpy(), orpit_loss=loss.detach().numpy(), orpit_idx=idx.numpy(), orpit_grad=x.grad.numpy(),
+                orpit_lens=np.array(lens), orpit_t=nn.utils.rnn.pad_sequence(tg, batch_first=True).numpy())
+    print("ORPIT", loss.tolist(), idx.tolist())
     np.savez_compressed(os.path.join(OUT, "pit_kat.npz"), **blob)
 
 

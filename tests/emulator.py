@@ -335,6 +335,28 @@ class EmuBackend:
         d.zero_()
         d[:, :T] = src.reshape(rows, ld_src)[:, :T]
 
+    def depthwise_fwd(self, x, w, bias, y, B, C, Tin, Tout, Kw, stride, pad, dil):
+        r = torch.nn.functional.conv1d(x.reshape(B, C, Tin), w.reshape(C, 1, Kw), None if bias is None else bias.reshape(C),
+                                       stride=stride, padding=pad, dilation=dil, groups=C)
+        y.reshape(B, C, Tout).copy_(r)
+
+    def depthwise_bwd_input(self, dy, w, dx, B, C, Tin, Tout, Kw, stride, pad, dil):
+        with torch.enable_grad():
+            x0 = torch.zeros(B, C, Tin, dtype=dy.dtype, requires_grad=True)
+            r = torch.nn.functional.conv1d(x0, w.detach().reshape(C, 1, Kw), None, stride=stride, padding=pad, dilation=dil, groups=C)
+            gx = torch.autograd.grad(r, x0, dy.detach().reshape(B, C, Tout))[0]
+        dx.reshape(B, C, Tin).copy_(gx)
+
+    def depthwise_bwd_weight(self, dy, x, partial, B, C, Tin, Tout, Kw, stride, pad, dil):
+        g = dy.reshape(B, C, Tout)
+        xp = torch.zeros(B, C, Tin + 2 * pad + Kw * dil + Tout * stride, dtype=x.dtype)
+        xp[:, :, pad:pad + Tin] = x.reshape(B, C, Tin)
+        out = partial.reshape(B, C, Kw + 1)
+        to = torch.arange(Tout)
+        for k in range(Kw):
+            out[:, :, k] = (g * xp[:, :, to * stride + k * dil]).sum(2)
+        out[:, :, Kw] = g.sum(2)
+
     def segment(self, x, out, rows, T, ldt, S, chunk, hop, pad_left):
         total = (S - 1) * hop + chunk
         xp = torch.zeros(rows, total + pad_left + T, dtype=x.dtype)

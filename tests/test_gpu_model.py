@@ -202,3 +202,17 @@ def test_dprnn_tasnet_golden(golden_dir):
     loss.backward()
     flat_rel, worst = _grad_report(model, {k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("grad/")})
     assert flat_rel <= 2e-3, "flat gradient rel-inf {:.3e}, worst tensor {}".format(flat_rel, worst)
+
+
+def test_orpit_and_dsconv_on_gpu(golden_dir):
+    from test_modules_cpu import _orpit_case, _dsconv_case
+    g, x, loss, idx = _orpit_case(golden_dir, "cuda")
+    assert np.allclose(loss.detach().cpu().numpy(), g["orpit_loss"], rtol=1e-4, atol=1e-4)
+    assert np.array_equal(idx.cpu().numpy(), g["orpit_idx"])
+    assert _rel(x.grad, torch.from_numpy(g["orpit_grad"])) <= 1e-3
+    mod, xg, y, ref_dw, ref_pw, xr, yr = _dsconv_case("cuda", torch.float32)
+    assert _rel(y, yr.detach()) <= 1e-4
+    assert _rel(xg.grad, xr.grad) <= 1e-3
+    assert _rel(mod.depthwise_conv1d.weight.grad, ref_dw.weight.grad) <= 1e-3
+    assert _rel(mod.pointwise_conv1d.weight.grad, ref_pw.weight.grad) <= 1e-3
+    assert _rel(mod.pointwise_conv1d.bias.grad, ref_pw.bias.grad) <= 1e-3

@@ -160,3 +160,49 @@ def test_sisdr_shapes_and_gln_via_emulator(golden_dir, emu):
     assert torch.allclose(x.grad, x2.grad, atol=1e-9)
     assert torch.allclose(norm.norm.weight.grad, ref.weight.grad, atol=1e-9)
     assert torch.allclose(norm.norm.bias.grad, ref.bias.grad, atol=1e-9)
+
+
+def _orpit_case(golden_dir, device):
+    from criterion.pit import ORPIT
+    g = np.load(os.path.join(golden_dir, "pit_kat.npz"))
+    lens = [int(n) for n in g["orpit_lens"]]
+    tg = [torch.from_numpy(g["orpit_t"][i, :n]).to(device) for i, n in enumerate(lens)]
+    x = torch.from_numpy(g["orpit_x"]).to(device).requires_grad_(True)
+    packed = torch.nn.utils.rnn.pack_sequence(tg, enforce_sorted=False)
+    loss, idx = ORPIT(NegSISDR())(x, packed, batch_mean=False)
+    loss.sum().backward()
+    return g, x, loss, idx
+
+
+def test_orpit_against_reference(golden_dir, emu):
+    g, x, loss, idx = _orpit_case(golden_dir, "cpu")
+    assert np.allclose(loss.detach().numpy(), g["orpit_loss"], atol=1e-8)
+    assert np.array_equal(idx.numpy(), g["orpit_idx"])
+    assert np.allclose(x.grad.numpy(), g["orpit_grad"], rtol=1e-6, atol=1e-10)
+
+
+def _dsconv_case(device, dtype):
+    from modules.conv import DepthwiseSeparableConv1d
+    torch.manual_seed(5)
+    mod = DepthwiseSeparableConv1d(32, 48, kernel_size=5, stride=2, padding=3, dilation=2).to(dtype)
+    ref_dw = torch.nn.Conv1d(32, 32, 5, stride=2, padding=3, dilation=2, groups=32).to(dtype)
+    ref_pw = torch.nn.Conv1d(32, 48, 1).to(dtype)
+    ref_dw.load_state_dict(mod.depthwise_conv1d.state_dict()); ref_pw.load_state_dict(mod.pointwise_conv1d.state_dict())
+    x = torch.randn(3, 32, 101, dtype=dtype)
+    xr = x.clone().requires_grad_(True)
+    yr = ref_pw(ref_dw(xr))
+    (yr ** 2).sum().backward()
+    mod.to(device)
+    xg = x.to(device).requires_grad_(True)
+    y = mod(xg)
+    (y ** 2).sum().backward()
+    return mod, xg, y, ref_dw, ref_pw, xr, yr
+
+
+def test_depthwise_separable_conv1d_module(emu):
+    mod, xg, y, ref_dw, ref_pw, xr, yr = _dsconv_case("cpu", torch.float64)
+    assert torch.allclose(y, yr, atol=1e-10)
+    assert torch.allclose(xg.grad, xr.grad, atol=1e-9)
+    for a, b in [(mod.depthwise_conv1d.weight, ref_dw.weight), (mod.depthwise_conv1d.bias, ref_dw.bias),
+                 (mod.pointwise_conv1d.weight, ref_pw.weight), (mod.pointwise_conv1d.bias, ref_pw.bias)]:
+        assert torch.allclose(a.grad, b.grad, atol=1e-8)
