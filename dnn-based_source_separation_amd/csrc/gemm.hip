@@ -1084,8 +1084,8 @@ extern "C" int sep_pw_gemm(const sep_gemm_desc* d, sep_stream_t stream) {
     SEP_REQUIRE(d != nullptr, "sep_pw_gemm: null descriptor");
     SEP_REQUIRE(d->B > 0 && d->M > 0 && d->K > 0 && d->T > 0, "sep_pw_gemm: empty problem (B=%d M=%d K=%d T=%d)", d->B, d->M, d->K, d->T);
     SEP_REQUIRE(d->ldt % 128 == 0 && d->ldt >= d->T, "sep_pw_gemm: ldt=%d must be a multiple of 128 and >= T=%d", d->ldt, d->T);
-    SEP_REQUIRE(d->K % BK == 0, "sep_pw_gemm: K=%d must be a multiple of %d", d->K, BK);
-    SEP_REQUIRE(d->k_split % BK == 0 && d->k_split < d->K, "sep_pw_gemm: bad k_split=%d", d->k_split);
+    SEP_REQUIRE(d->K % 16 == 0, "sep_pw_gemm: K=%d must be a multiple of 16", d->K);
+    SEP_REQUIRE(d->k_split % 16 == 0 && d->k_split < d->K, "sep_pw_gemm: bad k_split=%d", d->k_split);
     SEP_REQUIRE(d->m_split % BM == 0 && d->m_split < d->M, "sep_pw_gemm: bad m_split=%d (M=%d)", d->m_split, d->M);
     SEP_REQUIRE(!d->trans_a || d->M % 4 == 0, "sep_pw_gemm: transposed A needs M %% 4 == 0 (M=%d)", d->M);
     SEP_REQUIRE(d->A && d->X && d->Y, "sep_pw_gemm: null operand");
@@ -1111,6 +1111,7 @@ extern "C" int sep_pw_gemm(const sep_gemm_desc* d, sep_stream_t stream) {
     static const bool force_staged = getenv("SEPK_FORCE_STAGED") != nullptr;
     const bool direct_ok = !force_staged && d->pro_mode != SEP_PRO_GLN_BWD && d->K % DK == 0 && d->k_split % DK == 0 &&
                            (d->pro_mode < SEP_PRO_GLN || d->K <= DMAXK) && d->M >= 4 && d->M % 4 == 0;
+    SEP_REQUIRE(direct_ok || (d->K % BK == 0 && d->k_split % BK == 0), "sep_pw_gemm: the register-staged path (gLN-backward prologue, K=%d) needs K %% 32 == 0", d->K);
     if (direct_ok) {
 #define SEP_LAUNCH_DIRECT(T, P)                                                                                              \
     do {                                                                                                                     \
