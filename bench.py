@@ -6,7 +6,7 @@ bench.py -- separated audio frames/sec (fwd + SI-SDR/PIT + bwd [+ all-reduce] + 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One JSON line on rank 0.  A "step" is one pass of the hot path over one batch resident in HBM.  `roofline` is for the
-dominant kernel (the fp32-MFMA pointwise GEMM `pw_gemm_kernel`): its launches are bracketed with HIP events on the
+dominant kernel (the fp32-MFMA pointwise GEMM `pw_gemm_direct_kernel`): its launches are bracketed with HIP events on the
 launch stream during the timed steps; achieved = algorithmic FLOPs of those launches / their summed duration.
 `cpu_baseline` is the oracle's functional port (oracle/fast_port.py, same ATen CPU kernels as the reference) timed
 on this box's host cores on a bounded sample (N=1 runs only).
@@ -185,12 +185,12 @@ def main():
             n, ms, fl = timed.summary("pw_gemm")
             nw, msw, flw = timed.summary("pw_wgrad")
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            out["roofline"] = {"bound": "mfma", "kernel": "pw_gemm_kernel", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
+            out["roofline"] = {"bound": "mfma", "kernel": "pw_gemm_direct_kernel", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
                                "launches_per_step": n / args.steps, "avg_launch_ms": ms / max(n, 1),
                                "flop_per_launch_avg": fl / max(n, 1), "share_of_step": ms / (1e3 * elapsed)}
             achw = flw / (msw * 1e-3) / 1e12 if msw > 0 else 0.0
-            out["roofline_wgrad"] = {"bound": "mfma", "kernel": "pw_wgrad_kernel", "achieved": achw, "peak": FP32_MFMA_PEAK_TFLOPS,
+            out["roofline_wgrad"] = {"bound": "mfma", "kernel": "pw_wgrad_direct_kernel", "achieved": achw, "peak": FP32_MFMA_PEAK_TFLOPS,
                                      "unit": "TFLOP/s", "frac": achw / FP32_MFMA_PEAK_TFLOPS, "launches_per_step": nw / args.steps,
                                      "avg_launch_ms": msw / max(nw, 1), "share_of_step": msw / (1e3 * elapsed)}
         if world == 1 and not args.no_cpu_baseline:

@@ -379,64 +379,57 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const sep_gemm_desc d) 
 
 
 // ======================================================================================
-// Direct-to-LDS pipelined GEMM (the fast path).
-//
-// The staged kernel above keeps ONE chunk of operands in flight (registers) per workgroup; with ~3 us of HBM latency
-// under load and 1.7 us of MFMA work per chunk it is latency-bound (measured: removing every MFMA changed its run
-// time by < 35 %).  Here both operands go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip) through a
-// ring of NST = 4 stages of 16 contraction rows: three chunks are always in flight per workgroup, waits are counted
-// (s_waitcnt vmcnt(8/4/0)) and the only barrier per chunk is a raw s_barrier, so the DMA queue is never drained
-// inside the loop.  The elementwise prologue (PReLU / gLN affine) moves from the staging registers to the B
-// fragments after the ds_read, with the per-row affine precomputed once per workgroup in LDS.
-//   A k-major ([K][M], input-gradient form): rows copied verbatim, fragments by conflict-free ds_read_b32.
-//   A row-major ([M][K], forward form): 16-byte granules copied with an XOR swizzle on the SOURCE address (the LDS
-//   image of a DMA is lane-linear), fragments by two ds_read_b128 per 32-row block; the contraction index is
-//   permuted (lane half lk owns k = 8*lk .. 8*lk+7 of the chunk) identically for A and B, which a sum allows.
+// Direct-to-LDS staging helpers shared by the fast GEMM / wgrad kernels.
+// global_load_lds_dwordx4: the 64 lanes of a wave copy 64 x 16 B from per-lane global addresses to ONE contiguous
+// 1 KiB LDS range (wave-uniform base in M0 + lane*16) without touching VGPRs.
 // ======================================================================================
-constexpr int DK = 16;
-constexpr int NST = 4;
-
-// Interleave recipe for one pipeline step of the direct kernels.  A wave issues in order: if the ~100 non-MFMA
-// instructions of a step (DMA issue, fragment ds_reads of the NEXT chunk, prologue VALU) sit in front of its 32 MFMAs
-// the matrix pipe idles while they issue (measured: one wave per SIMD reached only 58 % of the MFMA rate).  Placed
-// between the MFMAs they are free: each v_mfma_f32_32x32x2_f32 occupies the pipe for 64 cycles.
-__device__ __forceinline__ void sched_interleave_step() {
-#ifndef SEP_NO_SCHED
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read (the DMA re-arm)
-        __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);   // its SALU (M0, base bump)
-    }
-#pragma unroll
-    for (int i = 0; i < 28; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // 4 VALU (prologue on the next fragments)
-    }
-#endif
-}
-
-constexpr int DMAXK = 1024;
-
-struct __attribute__((aligned(16))) DirectSmem {
-    float As[NST][DK * 128];
-    float Bs[NST][DK * 128];
-    float sc[DMAXK];
-    float sh[DMAXK];
-    double red[8];
-#ifdef SEP_LDS_PAD
-    float pad[SEP_LDS_PAD];      // occupancy experiment only
-#endif
-};
+constexpr int DK = 16;      // contraction rows per ring stage
+constexpr int NST = 4;      // ring depth of the weight-gradient kernel
 
 __device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// ======================================================================================
+// The fast GEMM: direct-to-LDS, 2-stage ring, high occupancy.
+//
+// Why this shape (all measured on MI355X, tools/gemm_bench.py + rocprofv3):
+//  * a register-staged kernel (above, kept for odd shapes) is latency-bound: removing all its MFMAs shortened it by < 35 %;
+//  * a 4-stage DMA ring with counted vmcnt, fragment double-buffering and a hand-ordered instruction stream reached
+//    120 TF/s on long contractions but only 65 TF/s at K = 128, and 1 -> 2 workgroups per CU was worth +25...45 %:
+//    a wave issues in order, so while it runs its DMA issue / ds_reads / prologue / epilogue the matrix pipe needs
+//    OTHER waves.  Trading ring depth and register double-buffering for occupancy (2 stages = 32 KiB LDS, <= 128
+//    VGPRs => FOUR workgroups per CU) beat that kernel on every shape of the model, with far simpler code;
+//  * with one chunk of lead (a chunk's DMA is issued one MFMA burst x 4 co-resident waves before it is needed) the
+//    waits are plain vmcnt(0), so other memory traffic in flight (epilogue stores, the gLN-backward store-back) is harmless.
+//
+//   A k-major ([K][M], input-gradient form): rows DMA'd verbatim, fragments by conflict-free ds_read_b32.
+//   A row-major ([M][K], forward form): 16-byte granules DMA'd with an XOR swizzle on the SOURCE address (the LDS image
+//   of a DMA is lane-linear), fragments by two ds_read_b128 per 32-row block; the contraction index is permuted (lane
+//   half lk owns k = 8*lk .. 8*lk+7 of the chunk) identically for A and B, which a sum allows.
+//   The elementwise prologue acts on the B fragments after the ds_read; its per-row affine sits in LDS.
+//   PRO == GLN_BWD streams a third operand (the pre-activation a), forms d(pre-activation) on the fragments, and the
+//   wr == 0 waves of row tile 0 write it back for the weight-gradient GEMM and accumulate the PReLU slope gradient.
+// ======================================================================================
+constexpr int OMAXK = 768;
+
+template <bool AUX>
+struct __attribute__((aligned(16))) DirectSmem {
+    float As[2][DK * 128];
+    float Bs[2][DK * 128];
+    float Cs[AUX ? 2 : 1][AUX ? DK * 128 : 4];
+    float sc[OMAXK];
+    float sh[AUX ? 4 : OMAXK];
+    double red[8];
+};
+
 template <bool TRANS_A, int PRO, bool SPLIT>
-__global__ __launch_bounds__(256, 2) void pw_gemm_direct_kernel(const sep_gemm_desc d) {
-    __shared__ DirectSmem sm;
+__global__ __launch_bounds__(256, (PRO == SEP_PRO_GLN_BWD ? 3 : 4)) void pw_gemm_direct_kernel(const sep_gemm_desc d) {
+    constexpr bool P_PRELU = PRO == SEP_PRO_PRELU || PRO == SEP_PRO_GLN_PRELU;
+    constexpr bool P_GLN = PRO == SEP_PRO_GLN || PRO == SEP_PRO_GLN_PRELU;
+    constexpr bool P_BWD = PRO == SEP_PRO_GLN_BWD;
+    __shared__ DirectSmem<P_BWD> sm;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: the DMA's LDS base goes to M0 without a waterfall loop
     const int wr = wid >> 1, wc = wid & 1;
@@ -445,6 +438,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_direct_kernel(const sep_gemm_d
     const int NR = (d.M + BM - 1) / BM;
     const int ntile_t = d.ldt / BN;
     const int NC = d.B * ntile_t;
+    // XCD-aware decode: all row tiles of one column tile land on the same XCD (blockIdx % 8) and share X through its L2
     const int bid = blockIdx.x;
     const int xcd = bid & 7, j = bid >> 3;
     const int rt = j % NR;
@@ -454,37 +448,42 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_direct_kernel(const sep_gemm_d
     const int t0 = (ct % ntile_t) * BN;
     const int m0 = rt * BM;
     const int nk = d.K / DK;
-    constexpr bool P_PRELU = PRO == SEP_PRO_PRELU || PRO == SEP_PRO_GLN_PRELU;
-    constexpr bool P_GLN = PRO == SEP_PRO_GLN || PRO == SEP_PRO_GLN_PRELU;
 
     // per-row affine of the prologue, once per workgroup
-    float alpha_p = 0.f;
-    if (P_PRELU) alpha_p = d.pro_alpha[0];
-    if (P_GLN) {
-        float mu, rstd;
+    float alpha_p = 0.f, mu = 0.f, rstd = 1.f, mg = 0.f, mgx = 0.f;
+    if (P_PRELU || P_BWD) alpha_p = d.pro_alpha[0];
+    if (P_GLN || P_BWD) {
         gln_mu_rstd(d.pro_stats + (size_t)b * SEP_STATS_SLOTS * 2, d.count, d.eps, mu, rstd);
         for (int k = tid; k < d.K; k += 256) {
-            const float scv = d.pro_gamma[k] * rstd;
-            sm.sc[k] = scv;
-            sm.sh[k] = d.pro_beta[k] - mu * scv;
+            if (P_BWD) sm.sc[k] = d.pro_gamma[k];
+            else {
+                const float scv = d.pro_gamma[k] * rstd;
+                sm.sc[k] = scv;
+                sm.sh[k] = d.pro_beta[k] - mu * scv;
+            }
         }
     }
+    if (P_BWD) { mg = d.pro_bsum[2 * b]; mgx = d.pro_bsum[2 * b + 1]; }
+    float dalpha_pro = 0.f;
+    const bool writer = P_BWD && wr == 0 && rt == 0;           // the waves that own the store-back / slope gradient
 
-    // This wave's share of one stage: 2 DMA instructions for A, 2 for B (1 KiB each).  Every source address is a
-    // wave-uniform base (SGPR pair, advanced with scalar adds as chunks are issued strictly in order) plus a per-lane
-    // 32-bit offset fixed for the whole tile, so the per-chunk address work is SALU only.
+    // This wave's share of one stage: 2 DMA instructions per operand (1 KiB each).  Every source address is a
+    // wave-uniform base (SGPR pair, advanced with scalar adds: chunks are issued strictly in order) plus a per-lane
+    // 32-bit offset fixed for the whole tile.
     const int Ks1 = SPLIT ? d.k_split : d.K;
     const int split_chunk = SPLIT ? d.k_split / DK : -1;
     const size_t stepB = (size_t)DK * d.ldt;
     const size_t stepA = TRANS_A ? (size_t)DK * d.M : (size_t)DK;
     const float* baseB[2];
+    const float* baseC[2];
     const float* baseA[2];
-    int offB, offA[2];
-    offB = lk * d.ldt + 4 * l31;
+    int offA[2];
+    const int offB = lk * d.ldt + 4 * l31;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int r2 = 4 * wid + 2 * q;                           // first of the two k rows this instruction covers
         baseB[q] = d.X + ((size_t)b * Ks1 + r2) * d.ldt + t0;
+        baseC[q] = P_BWD ? d.pro_aux + ((size_t)b * Ks1 + r2) * d.ldt + t0 : nullptr;
         if (TRANS_A) {
             int mm = m0 + 4 * l31;
             if (mm > d.M - 4) mm = d.M - 4;                       // rows past M are never stored; keep the read in bounds
@@ -521,9 +520,11 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_direct_kernel(const sep_gemm_d
         for (int q = 0; q < 2; ++q) {
 #ifndef SEP_ABL_NO_LOADS
             glds16(baseB[q] + offB, &sm.Bs[stage][(4 * wid + 2 * q) * 128]);
+            if (P_BWD) glds16(baseC[q] + offB, &sm.Cs[stage][(4 * wid + 2 * q) * 128]);
             glds16(baseA[q] + offA[q], TRANS_A ? &sm.As[stage][(4 * wid + 2 * q) * 128] : &sm.As[stage][(2 * wid + q) * 256]);
 #endif
             baseB[q] += stepB;
+            if (P_BWD) baseC[q] += stepB;
             baseA[q] += stepA;
         }
         ++kci;
@@ -537,123 +538,99 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_direct_kernel(const sep_gemm_d
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    // wait until chunk k has landed (this wave's DMAs: counted vmcnt; everyone's: barrier).  lgkmcnt(0) retires this
-    // wave's fragment reads of the previous chunk, so after the barrier that chunk's stage may be refilled.
-#define DG_WAIT8 asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#define DG_WAIT_BARRIER(k)                                                                        \
-    {                                                                                             \
-        const int rem_ = nk - 1 - (k);                                                            \
-        if (rem_ >= 2) DG_WAIT8                                                                   \
-        else if (rem_ == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");              \
-    }
-    // LDS -> registers for one chunk (A and B fragments of all 8 k-steps), raw
-#define DG_LOAD_FRAGS(st_, FA, FB)                                                                \
-    {                                                                                             \
-        const float* Ab = sm.As[st_];                                                             \
-        const float* Bb = sm.Bs[st_];                                                             \
-        if (TRANS_A) {                                                                            \
-            _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                    \
-                FA[0][kk] = Ab[(8 * lk + kk) * 128 + wr * 64 + l31];                              \
-                FA[1][kk] = Ab[(8 * lk + kk) * 128 + wr * 64 + 32 + l31];                         \
-            }                                                                                     \
-        } else {                                                                                  \
-            _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) {                                    \
-                const int m = wr * 64 + mi * 32 + l31;                                            \
-                const int sw = (m >> 2) & 3;                                                      \
-                const float* p0 = Ab + m * 16 + 4 * ((2 * lk) ^ sw);                              \
-                const float* p1 = Ab + m * 16 + 4 * ((2 * lk + 1) ^ sw);                          \
-                _Pragma("unroll") for (int e = 0; e < 4; ++e) { FA[mi][e] = p0[e]; FA[mi][4 + e] = p1[e]; } \
-            }                                                                                     \
-        }                                                                                         \
-        _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                        \
-            FB[0][kk] = Bb[(8 * lk + kk) * 128 + wc * 64 + l31];                                  \
-            FB[1][kk] = Bb[(8 * lk + kk) * 128 + wc * 64 + 32 + l31];                             \
-        }                                                                                         \
-    }
-    // the elementwise prologue on the B fragments of chunk kc_
-#define DG_PROLOGUE(kc_, FB)                                                                      \
-    if (PRO != SEP_PRO_NONE) {                                                                    \
-        const int kbase = (kc_) * DK + 8 * lk;                                                    \
-        _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                        \
-            const float scv = P_GLN ? sm.sc[kbase + kk] : 1.f;                                    \
-            const float shv = P_GLN ? sm.sh[kbase + kk] : 0.f;                                    \
-            _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                                    \
-                float v = FB[ni][kk];                                                             \
-                if (P_PRELU) v = prelu_f(v, alpha_p);                                             \
-                FB[ni][kk] = P_GLN ? v * scv + shv : v;                                           \
-            }                                                                                     \
-        }                                                                                         \
-    }
-#ifndef SEP_ABL_NO_MFMA
-#define DG_MFMA(FA, FB)                                                                           \
-    _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                            \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0][kk], FB[0][kk], acc[0][0], 0, 0, 0); \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0][kk], FB[1][kk], acc[0][1], 0, 0, 0); \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1][kk], FB[0][kk], acc[1][0], 0, 0, 0); \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1][kk], FB[1][kk], acc[1][1], 0, 0, 0); \
-    }
-#else
-#define DG_MFMA(FA, FB) { acc[0][0][0] += FA[0][0] * FB[0][0] + FA[1][7] * FB[1][7]; }
-#endif
-    // One steady-state pipeline step: [chunk nxt has landed] -> its ds_reads go out first (pinned with a scheduling
-    // barrier), then the DMA re-arm, then the 32 MFMAs of the current chunk with the prologue VALU of the next chunk's
-    // fragments woven in behind the first few (whose 64-cycle slots also cover the LDS latency).
-#define DG_STEP(st_issue, st_next, kc_next, FAc, FBc, FAn, FBn)                                   \
-    DG_WAIT8                                                                                      \
-    DG_LOAD_FRAGS(st_next, FAn, FBn)                                                              \
-    __builtin_amdgcn_sched_barrier(0);                                                            \
-    issue(st_issue);                                                                              \
-    DG_MFMA(FAc, FBc)                                                                             \
-    DG_PROLOGUE(kc_next, FBn)                                                                     \
-    sched_interleave_step();
-
-    float fa0[2][8], fb0[2][8], fa1[2][8], fb1[2][8];
+    auto step = [&](const int kc, const int stage) {
+        // chunk kc has landed (mine: vmcnt(0); everyone's: barrier); all waves are past their reads of the other stage
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kc + 1 < nk) issue(stage ^ 1);
+        const float* Ab = sm.As[stage];
+        const float* Bb = sm.Bs[stage];
+        float fa[2][8], fb[2][8];
+        if (TRANS_A) {
 #pragma unroll
-    for (int st = 0; st < NST - 1; ++st)
-        if (st < nk) issue(st);
-    DG_WAIT_BARRIER(0)
-    if (NST - 1 < nk) issue(NST - 1);
-    DG_LOAD_FRAGS(0, fa0, fb0)
-    DG_PROLOGUE(0, fb0)
+            for (int kk = 0; kk < 8; ++kk) {
+                fa[0][kk] = Ab[(8 * lk + kk) * 128 + wr * 64 + l31];
+                fa[1][kk] = Ab[(8 * lk + kk) * 128 + wr * 64 + 32 + l31];
+            }
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int m = wr * 64 + mi * 32 + l31;
+                const int sw = (m >> 2) & 3;
+                const float* p0 = Ab + m * 16 + 4 * ((2 * lk) ^ sw);
+                const float* p1 = Ab + m * 16 + 4 * ((2 * lk + 1) ^ sw);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { fa[mi][e] = p0[e]; fa[mi][4 + e] = p1[e]; }
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            fb[0][kk] = Bb[(8 * lk + kk) * 128 + wc * 64 + l31];
+            fb[1][kk] = Bb[(8 * lk + kk) * 128 + wc * 64 + 32 + l31];
+        }
+        const int kbase = kc * DK + 8 * lk;
+        if (P_BWD) {
+            // d(pre-activation) = rstd*(gamma_k*dv - mg - xhat*mgx) * PReLU'(a)   on the fragments
+            const float* Cb = sm.Cs[stage];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int tcol = wc * 64 + ni * 32 + l31;
+                const bool live = t0 + tcol < d.T;
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const float gk = sm.sc[kbase + kk];
+                    const float a = Cb[(8 * lk + kk) * 128 + tcol];
+                    const float u = prelu_f(a, alpha_p);
+                    const float xh = (u - mu) * rstd;
+                    const float du = rstd * (gk * fb[ni][kk] - mg - xh * mgx);
+                    const float da = live ? du * prelu_grad(a, alpha_p) : 0.f;
+                    fb[ni][kk] = da;
+                    if (writer) {
+                        if (live && a <= 0.f) dalpha_pro += du * a;
+                        d.pro_store[((size_t)b * d.K + kbase + kk) * d.ldt + t0 + tcol] = da;
+                    }
+                }
+            }
+        } else if (PRO != SEP_PRO_NONE) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const float scv = P_GLN ? sm.sc[kbase + kk] : 1.f;
+                const float shv = P_GLN ? sm.sh[kbase + kk] : 0.f;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    float v = fb[ni][kk];
+                    if (P_PRELU) v = prelu_f(v, alpha_p);
+                    fb[ni][kk] = P_GLN ? v * scv + shv : v;
+                }
+            }
+        }
+#ifndef SEP_ABL_NO_MFMA
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][kk], fb[0][kk], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][kk], fb[1][kk], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][kk], fb[0][kk], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][kk], fb[1][kk], acc[1][1], 0, 0, 0);
+        }
+#endif
+    };
+
+    issue(0);
     int kc = 0;
-    // Steady state, unrolled over the 4 ring stages so every LDS address is "lane base + immediate" and every M0 a
-    // constant; each step is one basic block.  kc % 4 == 0 here.
-    for (; kc + 7 < nk; kc += 4) {
-        DG_STEP(0, 1, kc + 1, fa0, fb0, fa1, fb1)
-        DG_STEP(1, 2, kc + 2, fa1, fb1, fa0, fb0)
-        DG_STEP(2, 3, kc + 3, fa0, fb0, fa1, fb1)
-        DG_STEP(3, 0, kc + 4, fa1, fb1, fa0, fb0)
+    for (; kc + 1 < nk; kc += 2) {       // two steps per trip so the stage index is a literal
+        step(kc, 0);
+        step(kc + 1, 1);
     }
-    for (; kc < nk; kc += 2) {
-        if (kc + 1 < nk) {
-            DG_WAIT_BARRIER(kc + 1)
-            if (kc + 4 < nk) issue((kc + 4) & (NST - 1));
-            DG_LOAD_FRAGS((kc + 1) & (NST - 1), fa1, fb1)
-            DG_PROLOGUE(kc + 1, fb1)
-        }
-        DG_MFMA(fa0, fb0)
-        if (kc + 1 >= nk) break;
-        if (kc + 2 < nk) {
-            DG_WAIT_BARRIER(kc + 2)
-            if (kc + 5 < nk) issue((kc + 5) & (NST - 1));
-            DG_LOAD_FRAGS((kc + 2) & (NST - 1), fa0, fb0)
-            DG_PROLOGUE(kc + 2, fb0)
-        }
-        DG_MFMA(fa1, fb1)
-    }
-#undef DG_STEP
-#undef DG_WAIT8
-#undef DG_WAIT_BARRIER
-#undef DG_LOAD_FRAGS
-#undef DG_PROLOGUE
-#undef DG_MFMA
+    if (kc < nk) step(kc, 0);
     __syncthreads();
 #ifdef SEP_ABL_NO_EPI
     if (acc[0][0][0] + acc[0][1][3] + acc[1][0][5] + acc[1][1][7] == 123.456f) d.Y[tid] = 1.f;
 #else
     gemm_epilogue(d, acc, b, m0, t0, wr, wc, lk, l31, tid, &sm.As[0][0], sm.red);
 #endif
+    if (P_BWD && rt == 0) {
+        const double sdal = block_sum_256<double>((double)dalpha_pro, sm.red);
+        if (tid == 0) atomicAdd(d.pro_dalpha, sdal);
+    }
 }
 
 // ======================================================================================
@@ -1004,8 +981,6 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_direct_kernel(const sep_wgrad
                 WD_LOAD_FRAGS(kc + 1, fa1, fb1)
             }
             WD_MFMA(fa0, fb0)
-            sched_interleave_step();
-        sched_interleave_step();
             if (kc + 1 >= nk) break;
             if (kc + 2 < nk) {
                 WD_WAIT_BARRIER(kc + 2)
@@ -1013,8 +988,6 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_direct_kernel(const sep_wgrad
                 WD_LOAD_FRAGS(kc + 2, fa0, fb0)
             }
             WD_MFMA(fa1, fb1)
-            sched_interleave_step();
-        sched_interleave_step();
         }
     }
 #undef WD_WAIT_BARRIER
@@ -1106,12 +1079,11 @@ extern "C" int sep_pw_gemm(const sep_gemm_desc* d, sep_stream_t stream) {
     const int NR = ceil_div(d->M, BM);
     const int NC = d->B * (d->ldt / BN);
     const int grid = 8 * NR * ceil_div(NC, 8);
-    // fast path: direct-to-LDS pipelined kernel; the register-staged kernel remains for the gLN-backward prologue
-    // (it needs a second input tile and writes one back) and for shapes outside the fast path's limits
+    // fast path: direct-to-LDS high-occupancy kernel; the register-staged kernel remains for shapes outside its limits
     static const bool force_staged = getenv("SEPK_FORCE_STAGED") != nullptr;
-    const bool direct_ok = !force_staged && d->pro_mode != SEP_PRO_GLN_BWD && d->K % DK == 0 && d->k_split % DK == 0 &&
-                           (d->pro_mode < SEP_PRO_GLN || d->K <= DMAXK) && d->M >= 4 && d->M % 4 == 0;
-    SEP_REQUIRE(direct_ok || (d->K % BK == 0 && d->k_split % BK == 0), "sep_pw_gemm: the register-staged path (gLN-backward prologue, K=%d) needs K %% 32 == 0", d->K);
+    const bool direct_ok = !force_staged && d->K % DK == 0 && d->k_split % DK == 0 && d->M >= 4 && d->M % 4 == 0 &&
+                           (d->pro_mode < SEP_PRO_GLN || d->K <= OMAXK);
+    SEP_REQUIRE(direct_ok || (d->K % BK == 0 && d->k_split % BK == 0), "sep_pw_gemm: the register-staged fallback (K=%d) needs K %% 32 == 0", d->K);
     if (direct_ok) {
 #define SEP_LAUNCH_DIRECT(T, P)                                                                                              \
     do {                                                                                                                     \
@@ -1126,7 +1098,9 @@ extern "C" int sep_pw_gemm(const sep_gemm_desc* d, sep_stream_t stream) {
             case 4: SEP_LAUNCH_DIRECT(false, SEP_PRO_GLN); break;
             case 5: SEP_LAUNCH_DIRECT(true, SEP_PRO_GLN); break;
             case 6: SEP_LAUNCH_DIRECT(false, SEP_PRO_GLN_PRELU); break;
-            default: SEP_LAUNCH_DIRECT(true, SEP_PRO_GLN_PRELU); break;
+            case 7: SEP_LAUNCH_DIRECT(true, SEP_PRO_GLN_PRELU); break;
+            case 8: hipLaunchKernelGGL((pw_gemm_direct_kernel<false, SEP_PRO_GLN_BWD, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *d); break;
+            default: hipLaunchKernelGGL((pw_gemm_direct_kernel<true, SEP_PRO_GLN_BWD, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *d); break;
         }
 #undef SEP_LAUNCH_DIRECT
     } else
