@@ -386,6 +386,31 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const sep_gemm_desc d) 
 constexpr int DK = 16;      // contraction rows per ring stage
 constexpr int NST = 4;      // ring depth of the weight-gradient kernel
 
+__device__ __forceinline__ const float* byte_off(const float* base, unsigned bytes) {
+    return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)bytes);
+}
+// s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier as BUILTINS: the compiler's waitcnt pass then knows every counter is zero
+// here and emits counted lgkmcnt(N) waits afterwards (behind an opaque asm it falls back to lgkmcnt(0) everywhere)
+__device__ __forceinline__ void wait_all_and_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// LDS-DMA of 16 B per lane as an asm statement, saddr form: source = base (SGPR pair) + zext(voff), LDS image lane-linear
+// from the wave-uniform byte address lds_dst.  Why not the builtin: hipcc books a global_load_lds as a FLAT access that may
+// touch LDS, and from then on every LDS-read dependency in the loop becomes s_waitcnt lgkmcnt(0) -- no counted waits, so
+// a ds_read could never stay in flight across an MFMA burst.  Behind asm the DMA is invisible to that bookkeeping (its
+// completion is waited for by hand: vmcnt(0) before the barrier that publishes the stage).  M0 is compiler-reserved:
+// saved and restored in the same statement.
+__device__ __forceinline__ void glds16_asm(const float* base, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+    return (unsigned)reinterpret_cast<size_t>((const __attribute__((address_space(3))) float*)p);
+}
 __device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
@@ -477,8 +502,8 @@ __global__ __launch_bounds__(256, (PRO == SEP_PRO_GLN_BWD ? 3 : 4)) void pw_gemm
     const float* baseB[2];
     const float* baseC[2];
     const float* baseA[2];
-    int offA[2];
-    const int offB = lk * d.ldt + 4 * l31;
+    unsigned offA[2];                                             // BYTE offsets, unsigned: base(SGPR pair) + zext(voffset) is the
+    const unsigned offB = 4u * (unsigned)(lk * d.ldt + 4 * l31);   // saddr form of global_load_lds (one VGPR, no 64-bit VALU add)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int r2 = 4 * wid + 2 * q;                           // first of the two k rows this instruction covers
@@ -488,14 +513,14 @@ __global__ __launch_bounds__(256, (PRO == SEP_PRO_GLN_BWD ? 3 : 4)) void pw_gemm
             int mm = m0 + 4 * l31;
             if (mm > d.M - 4) mm = d.M - 4;                       // rows past M are never stored; keep the read in bounds
             baseA[q] = d.A + (size_t)r2 * d.M;
-            offA[q] = lk * d.M + mm;
+            offA[q] = 4u * (unsigned)(lk * d.M + mm);
         } else {
             // [128 m][16 k] image, 64-byte rows; instruction covers 16 rows; granule p of row r holds k-chunk p ^ ((r>>2)&3)
             const int r = lane >> 2, pch = lane & 3;
             int mm = m0 + 16 * (2 * wid + q) + r;
             if (mm > d.M - 1) mm = d.M - 1;
             baseA[q] = d.A;
-            offA[q] = mm * Ks1 + 4 * (pch ^ ((r >> 2) & 3));
+            offA[q] = 4u * (unsigned)(mm * Ks1 + 4 * (pch ^ ((r >> 2) & 3)));
         }
     }
     int kci = 0;                                                  // next chunk to issue
@@ -512,16 +537,16 @@ __global__ __launch_bounds__(256, (PRO == SEP_PRO_GLN_BWD ? 3 : 4)) void pw_gemm
                     int mm = m0 + 16 * (2 * wid + q) + r;
                     if (mm > d.M - 1) mm = d.M - 1;
                     baseA[q] = d.A2;
-                    offA[q] = mm * Ks2 + 4 * (pch ^ ((r >> 2) & 3));
+                    offA[q] = 4u * (unsigned)(mm * Ks2 + 4 * (pch ^ ((r >> 2) & 3)));
                 }
             }
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
 #ifndef SEP_ABL_NO_LOADS
-            glds16(baseB[q] + offB, &sm.Bs[stage][(4 * wid + 2 * q) * 128]);
-            if (P_BWD) glds16(baseC[q] + offB, &sm.Cs[stage][(4 * wid + 2 * q) * 128]);
-            glds16(baseA[q] + offA[q], TRANS_A ? &sm.As[stage][(4 * wid + 2 * q) * 128] : &sm.As[stage][(2 * wid + q) * 256]);
+            glds16_asm(baseB[q], offB, lds_addr(&sm.Bs[stage][(4 * wid + 2 * q) * 128]));
+            if (P_BWD) glds16_asm(baseC[q], offB, lds_addr(&sm.Cs[stage][(4 * wid + 2 * q) * 128]));
+            glds16_asm(baseA[q], offA[q], lds_addr(TRANS_A ? &sm.As[stage][(4 * wid + 2 * q) * 128] : &sm.As[stage][(2 * wid + q) * 256]));
 #endif
             baseB[q] += stepB;
             if (P_BWD) baseC[q] += stepB;
@@ -538,83 +563,113 @@ __global__ __launch_bounds__(256, (PRO == SEP_PRO_GLN_BWD ? 3 : 4)) void pw_gemm
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    auto step = [&](const int kc, const int stage) {
-        // chunk kc has landed (mine: vmcnt(0); everyone's: barrier); all waves are past their reads of the other stage
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (kc + 1 < nk) issue(stage ^ 1);
+    // Software pipeline at half-chunk granularity.  On a SIMD the co-resident waves share the matrix pipe fairly, so they
+    // run in lockstep and reach their barriers / LDS reads TOGETHER: whatever a wave does between two MFMA bursts is pipe
+    // idle time for all of them (measured: MFMA idle ~= SQ_WAIT_ANY + non-MFMA issue).  So each wave keeps its own MFMA
+    // stream dense: the fragments of half h+1 are read from LDS while the 16 MFMAs of half h run, and the per-chunk
+    // barrier sits between two bursts with the next burst's operands already in registers.  Same 32 fragment registers.
+    float fa[2][2][4], fb[2][2][4];      // [half][mi|ni][kk]
+    float fc[2][2][4];                   // GLN_BWD: the pre-activation fragments
+    float fs[2][4], fh[2][4];            // gLN prologues: the per-row scale / shift of the half's four k
+    auto read_half = [&](const int stage, const int h, const int kc) {
         const float* Ab = sm.As[stage];
         const float* Bb = sm.Bs[stage];
-        float fa[2][8], fb[2][8];
         if (TRANS_A) {
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                fa[0][kk] = Ab[(8 * lk + kk) * 128 + wr * 64 + l31];
-                fa[1][kk] = Ab[(8 * lk + kk) * 128 + wr * 64 + 32 + l31];
+            for (int kk = 0; kk < 4; ++kk) {
+                fa[h][0][kk] = Ab[(8 * lk + 4 * h + kk) * 128 + wr * 64 + l31];
+                fa[h][1][kk] = Ab[(8 * lk + 4 * h + kk) * 128 + wr * 64 + 32 + l31];
             }
         } else {
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
                 const int m = wr * 64 + mi * 32 + l31;
-                const int sw = (m >> 2) & 3;
-                const float* p0 = Ab + m * 16 + 4 * ((2 * lk) ^ sw);
-                const float* p1 = Ab + m * 16 + 4 * ((2 * lk + 1) ^ sw);
+                const float* p = Ab + m * 16 + 4 * ((2 * lk + h) ^ ((m >> 2) & 3));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { fa[mi][e] = p0[e]; fa[mi][4 + e] = p1[e]; }
+                for (int e = 0; e < 4; ++e) fa[h][mi][e] = p[e];
             }
         }
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            fb[0][kk] = Bb[(8 * lk + kk) * 128 + wc * 64 + l31];
-            fb[1][kk] = Bb[(8 * lk + kk) * 128 + wc * 64 + 32 + l31];
+        for (int kk = 0; kk < 4; ++kk) {
+            fb[h][0][kk] = Bb[(8 * lk + 4 * h + kk) * 128 + wc * 64 + l31];
+            fb[h][1][kk] = Bb[(8 * lk + 4 * h + kk) * 128 + wc * 64 + 32 + l31];
         }
-        const int kbase = kc * DK + 8 * lk;
         if (P_BWD) {
-            // d(pre-activation) = rstd*(gamma_k*dv - mg - xhat*mgx) * PReLU'(a)   on the fragments
             const float* Cb = sm.Cs[stage];
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int tcol = wc * 64 + ni * 32 + l31;
-                const bool live = t0 + tcol < d.T;
-#pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
-                    const float gk = sm.sc[kbase + kk];
-                    const float a = Cb[(8 * lk + kk) * 128 + tcol];
-                    const float u = prelu_f(a, alpha_p);
-                    const float xh = (u - mu) * rstd;
-                    const float du = rstd * (gk * fb[ni][kk] - mg - xh * mgx);
-                    const float da = live ? du * prelu_grad(a, alpha_p) : 0.f;
-                    fb[ni][kk] = da;
-                    if (writer) {
-                        if (live && a <= 0.f) dalpha_pro += du * a;
-                        d.pro_store[((size_t)b * d.K + kbase + kk) * d.ldt + t0 + tcol] = da;
-                    }
-                }
+            for (int kk = 0; kk < 4; ++kk) {
+                fc[h][0][kk] = Cb[(8 * lk + 4 * h + kk) * 128 + wc * 64 + l31];
+                fc[h][1][kk] = Cb[(8 * lk + 4 * h + kk) * 128 + wc * 64 + 32 + l31];
             }
-        } else if (PRO != SEP_PRO_NONE) {
+        }
+        if (P_GLN || P_BWD) {
+            const int kbase = kc * DK + 8 * lk + 4 * h;
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                const float scv = P_GLN ? sm.sc[kbase + kk] : 1.f;
-                const float shv = P_GLN ? sm.sh[kbase + kk] : 0.f;
+            for (int kk = 0; kk < 4; ++kk) {
+                fs[h][kk] = sm.sc[kbase + kk];
+                if (P_GLN) fh[h][kk] = sm.sh[kbase + kk];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);      // the reads stay HERE: ahead of the MFMA burst that hides their latency
+    };
+    const bool live0 = t0 + wc * 64 + l31 < d.T, live1 = t0 + wc * 64 + 32 + l31 < d.T;
+    auto mfma_half = [&](const int kc, const int h) {
+        const int kbase = kc * DK + 8 * lk + 4 * h;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (P_BWD) {
+                // d(pre-activation) = rstd*(gamma_k*dv - mg - xhat*mgx) * PReLU'(a)   on the fragments
+                const float gk = fs[h][kk];
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
-                    float v = fb[ni][kk];
+                    const bool live = ni ? live1 : live0;
+                    const float a = fc[h][ni][kk];
+                    const float u = prelu_f(a, alpha_p);
+                    const float xh = (u - mu) * rstd;
+                    const float du = rstd * (gk * fb[h][ni][kk] - mg - xh * mgx);
+                    const float da = live ? du * prelu_grad(a, alpha_p) : 0.f;
+                    fb[h][ni][kk] = da;
+                    if (writer) {
+                        if (live && a <= 0.f) dalpha_pro += du * a;
+                        d.pro_store[((size_t)b * d.K + kbase + kk) * d.ldt + t0 + wc * 64 + ni * 32 + l31] = da;
+                    }
+                }
+            } else if (PRO != SEP_PRO_NONE) {
+                const float scv = P_GLN ? fs[h][kk] : 1.f;
+                const float shv = P_GLN ? fh[h][kk] : 0.f;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    float v = fb[h][ni][kk];
                     if (P_PRELU) v = prelu_f(v, alpha_p);
-                    fb[ni][kk] = P_GLN ? v * scv + shv : v;
+                    fb[h][ni][kk] = P_GLN ? v * scv + shv : v;
                 }
             }
-        }
 #ifndef SEP_ABL_NO_MFMA
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][kk], fb[0][kk], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][kk], fb[1][kk], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][kk], fb[0][kk], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][kk], fb[1][kk], acc[1][1], 0, 0, 0);
-        }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h][0][kk], fb[h][0][kk], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h][0][kk], fb[h][1][kk], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h][1][kk], fb[h][0][kk], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h][1][kk], fb[h][1][kk], acc[1][1], 0, 0, 0);
 #endif
+        }
+    };
+    auto step = [&](const int kc, const int stage) {
+        read_half(stage, 1, kc);
+        mfma_half(kc, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kc + 1 < nk) {
+            // chunk kc+1 has landed (mine: vmcnt(0); everyone's: barrier) and every wave is past its reads of this stage
+            wait_all_and_barrier();
+            if (kc + 2 < nk) issue(stage);
+            read_half(stage ^ 1, 0, kc + 1);
+        }
+        mfma_half(kc, 1);
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     issue(0);
+    wait_all_and_barrier();
+    if (nk > 1) issue(1);
+    read_half(0, 0, 0);
     int kc = 0;
     for (; kc + 1 < nk; kc += 2) {       // two steps per trip so the stage index is a literal
         step(kc, 0);

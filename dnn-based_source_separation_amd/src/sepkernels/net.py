@@ -16,6 +16,8 @@ Everything here is plumbing: buffer allocation through torch, descriptor filling
 """
 import math
 
+import os
+
 import torch
 
 from . import (STATS_SLOTS, EPI_PRELU_BWD, EPI_RESIDUAL, EPI_ROWSUMS, EPI_ROWSUMS_PRELU, EPI_SIGMOID, EPI_STATS_PRELU, PRO_GLN,
@@ -269,6 +271,53 @@ def forward(cfg, P, mixture, want_latent=False, save=True):
     return est, latent, sv
 
 
+class _SideStream:
+    """Second HIP stream for the weight-gradient GEMMs of the backward pass.
+
+    The input-gradient chain (G3 -> depthwise^T -> G2 per layer) is serial and alternates MFMA-bound and HBM-bound
+    kernels; the weight gradients hang off it as leaves (nothing in the chain reads them).  Launched on a second stream
+    they fill the matrix pipe while the chain's streaming kernels wait on HBM, and the small reduction kernels
+    disappear under the big ones.  `fork()` orders the side stream after everything enqueued on the main stream so far;
+    `join()` orders the main stream after the side stream.  Tensors produced on the main stream and read on the side
+    stream are handed to `keep()` so that the caching allocator does not recycle them while the side stream lags.
+    Disabled (everything stays on the caller's stream) on CPU tensors -- the emulator tests -- or SEPK_SIDE_STREAM=0."""
+    _streams = {}
+
+    def __init__(self, dev):
+        self.on = dev.type == "cuda" and os.environ.get("SEPK_SIDE_STREAM", "1") != "0"
+        if self.on:
+            key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+            if key not in _SideStream._streams:
+                _SideStream._streams[key] = torch.cuda.Stream(device=dev)
+            self.side = _SideStream._streams[key]
+            self.main = torch.cuda.current_stream(dev)
+
+    def fork(self):
+        if self.on:
+            self.side.wait_stream(self.main)
+
+    def keep(self, *tensors):
+        if self.on:
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(self.side)
+
+    def __enter__(self):
+        if self.on:
+            self._ctx = torch.cuda.stream(self.side)
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self._ctx.__exit__(*exc)
+        return False
+
+    def join(self):
+        if self.on:
+            self.main.wait_stream(self.side)
+
+
 def backward(cfg, P, sv, d_est, G):
     """Writes the gradient of every parameter into G[name] (overwrites; G tensors have the parameter shapes)."""
     K = backend()
@@ -297,6 +346,8 @@ def backward(cfg, P, sv, d_est, G):
     dS, dwm = tail_backward(cfg, P, geo, w, skip, m, mixture.shape, d_est, G, dalpha[nl:nl + 1])
 
     # ---- TCN layers, reversed -----------------------------------------------------------------------
+    side = _SideStream(dev)
+    side.fork()   # dS exists
     dout = None
     for li in range(nl - 1, -1, -1):
         pre, dil, dual = layers[li]
@@ -322,25 +373,27 @@ def backward(cfg, P, sv, d_est, G):
         pgamma2 = torch.empty(B, H, **f32)
         K.gln_bwd_finalize(rp2, nt64, 2, st2, g2, cnt, teps, bsum2, pbeta2, pgamma2, None, B, H)
 
-        # head weight gradients: dWo = sum dout v2^T, dWs = sum dS v2^T   (v2 = gLN2(PReLU(z)) rebuilt on load)
+        # head weight gradients: dWo = sum dout v2^T, dWs = sum dS v2^T   (v2 = gLN2(PReLU(z)) rebuilt on load).
+        # Leaves of the graph: they run on the side stream, under this layer's input-gradient chain.
         xkw = dict(x_mode=PRO_GLN_PRELU, x_stats=st2, x_gamma=g2, x_beta=b2, x_alpha=al2, count=cnt, weps=teps)
-        segs = []
-        if dual and Bn % 128 == 0:
-            part, pb, ns = wgrad(Bn + Sc, H, dout, z, True, True, G2=dS, g_split=Bn, **xkw)
-            st = (Bn + Sc) * H
-            segs += [(part, 0, G[sp + "output_pointwise_conv1d.weight"], Bn * H, ns, st, 0, 1.0),
-                     (part, Bn * H, G[sp + "skip_pointwise_conv1d.weight"], Sc * H, ns, st, 0, 1.0),
-                     (pb, 0, G[sp + "output_pointwise_conv1d.bias"], Bn, ns, Bn + Sc, 0, 1.0),
-                     (pb, Bn, G[sp + "skip_pointwise_conv1d.bias"], Sc, ns, Bn + Sc, 0, 1.0)]
-        else:
-            if dual:
-                part, pb, ns = wgrad(Bn, H, dout, z, True, True, **xkw)
-                segs += [(part, 0, G[sp + "output_pointwise_conv1d.weight"], Bn * H, ns, Bn * H, 0, 1.0),
-                         (pb, 0, G[sp + "output_pointwise_conv1d.bias"], Bn, ns, Bn, 0, 1.0)]
-            part, pb, ns = wgrad(Sc, H, dS, z, True, True, **xkw)
-            segs += [(part, 0, G[sp + "skip_pointwise_conv1d.weight"], Sc * H, ns, Sc * H, 0, 1.0),
-                     (pb, 0, G[sp + "skip_pointwise_conv1d.bias"], Sc, ns, Sc, 0, 1.0)]
-        K.reduce_slabs(segs)
+        with side:
+            segs = []
+            if dual and Bn % 128 == 0:
+                part, pb, ns = wgrad(Bn + Sc, H, dout, z, True, True, G2=dS, g_split=Bn, **xkw)
+                st = (Bn + Sc) * H
+                segs += [(part, 0, G[sp + "output_pointwise_conv1d.weight"], Bn * H, ns, st, 0, 1.0),
+                         (part, Bn * H, G[sp + "skip_pointwise_conv1d.weight"], Sc * H, ns, st, 0, 1.0),
+                         (pb, 0, G[sp + "output_pointwise_conv1d.bias"], Bn, ns, Bn + Sc, 0, 1.0),
+                         (pb, Bn, G[sp + "skip_pointwise_conv1d.bias"], Sc, ns, Bn + Sc, 0, 1.0)]
+            else:
+                if dual:
+                    part, pb, ns = wgrad(Bn, H, dout, z, True, True, **xkw)
+                    segs += [(part, 0, G[sp + "output_pointwise_conv1d.weight"], Bn * H, ns, Bn * H, 0, 1.0),
+                             (pb, 0, G[sp + "output_pointwise_conv1d.bias"], Bn, ns, Bn, 0, 1.0)]
+                part, pb, ns = wgrad(Sc, H, dS, z, True, True, **xkw)
+                segs += [(part, 0, G[sp + "skip_pointwise_conv1d.weight"], Sc * H, ns, Sc * H, 0, 1.0),
+                         (pb, 0, G[sp + "skip_pointwise_conv1d.bias"], Sc, ns, Sc, 0, 1.0)]
+            K.reduce_slabs(segs)
 
         # depthwise^T and everything hanging off it
         dv1 = torch.empty(B, H, ldt, **f32)
@@ -371,12 +424,17 @@ def backward(cfg, P, sv, d_est, G):
                   pro_mode=PRO_GLN_BWD, pro_stats=st1, pro_gamma=g1, pro_alpha=al1, pro_aux=a, pro_bsum=bsum1,
                   pro_store=da, pro_dalpha=dalpha[li:li + 1], count=cnt, eps=teps,
                   epi_flags=(EPI_RESIDUAL if dout is not None else 0), epi_res=dout)
-        part, pb, ns = wgrad(H, Bn, da, x, True, True)
-        K.reduce_slabs([(part, 0, G[pre + "bottleneck_conv1d.weight"], H * Bn, ns, H * Bn, 0, 1.0),
-                        (pb, 0, G[pre + "bottleneck_conv1d.bias"], H, ns, H, 0, 1.0)])
+        # da and dx now exist: the side stream may go on (this layer's dW1, the next layer's head gradients)
+        side.fork()
+        side.keep(da, dx)
+        with side:
+            part, pb, ns = wgrad(H, Bn, da, x, True, True)
+            K.reduce_slabs([(part, 0, G[pre + "bottleneck_conv1d.weight"], H * Bn, ns, H * Bn, 0, 1.0),
+                            (pb, 0, G[pre + "bottleneck_conv1d.bias"], H, ns, H, 0, 1.0)])
         K.f64_to_f32(dalpha[li:li + 1], G[pre + "nonlinear1d.weight"], 1, 0)
         dout = dx
     K.f64_to_f32(dalpha[nl:nl + 1], G["separator.prelu.weight"], 1, 0)
+    side.join()
 
     # ---- head: bottleneck conv, first gLN, encoder ------------------------------------------------------
     head_backward(cfg, P, geo, stats[0], w, mixture, dout, dwm, G)

@@ -63,13 +63,13 @@ def timeit(fn):
 
 tot = 0.0
 for name, kw in cases.items():
-    if args.only and args.only not in name:
+    if args.only and not any(name.startswith(o) for o in args.only.split(",")):
         continue
     ms = timeit(lambda: K.pw_gemm(B=B, T=T, ldt=ldt, eps=1e-12, **kw))
     fl = 2.0 * kw["M"] * kw["K"] * B * T
     print("{:50s} {:8.1f} us  {:6.1f} TF/s  ({:4.1f}% of 157.3)".format(name, 1e3 * ms, fl / ms / 1e9, fl / ms / 1e9 / 1.573))
 for name, kw in wcases.items():
-    if args.only and args.only not in name:
+    if args.only and not any(name.startswith(o) for o in args.only.split(",")):
         continue
     ns_ = kw["nsplit"]
     part = torch.empty(ns_, kw["M"], kw["N"], device=dev)
