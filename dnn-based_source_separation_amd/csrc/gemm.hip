@@ -408,6 +408,12 @@ __device__ __forceinline__ void glds16_asm(const float* base, unsigned voff, uns
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
 }
+// same, with a full 64-bit per-lane source address
+__device__ __forceinline__ void glds16_asm_v(const float* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr(const float* p) {
     return (unsigned)reinterpret_cast<size_t>((const __attribute__((address_space(3))) float*)p);
 }
@@ -449,8 +455,11 @@ struct __attribute__((aligned(16))) DirectSmem {
     double red[8];
 };
 
+#ifndef SEP_GLN_OCC
+#define SEP_GLN_OCC 4       // measured: 4 blocks/CU with ~40 B of spill (outside the hot loop) = 3 blocks/CU spill-free (182 vs 186 us on the heads GEMM)
+#endif
 template <bool TRANS_A, int PRO, bool SPLIT>
-__global__ __launch_bounds__(256, (PRO == SEP_PRO_GLN_BWD ? 3 : 4)) void pw_gemm_direct_kernel(const sep_gemm_desc d) {
+__global__ __launch_bounds__(256, (PRO == SEP_PRO_GLN_BWD ? 3 : PRO >= SEP_PRO_GLN ? SEP_GLN_OCC : 4)) void pw_gemm_direct_kernel(const sep_gemm_desc d) {
     constexpr bool P_PRELU = PRO == SEP_PRO_PRELU || PRO == SEP_PRO_GLN_PRELU;
     constexpr bool P_GLN = PRO == SEP_PRO_GLN || PRO == SEP_PRO_GLN_PRELU;
     constexpr bool P_BWD = PRO == SEP_PRO_GLN_BWD;
@@ -613,6 +622,7 @@ __global__ __launch_bounds__(256, (PRO == SEP_PRO_GLN_BWD ? 3 : 4)) void pw_gemm
         __builtin_amdgcn_sched_barrier(0);      // the reads stay HERE: ahead of the MFMA burst that hides their latency
     };
     const bool live0 = t0 + wc * 64 + l31 < d.T, live1 = t0 + wc * 64 + 32 + l31 < d.T;
+    const unsigned st_lane_off = 4u * (unsigned)(8 * lk * d.ldt + l31);      // GLN_BWD store-back: this lane's byte offset in the chunk
     auto mfma_half = [&](const int kc, const int h) {
         const int kbase = kc * DK + 8 * lk + 4 * h;
 #pragma unroll
@@ -631,7 +641,9 @@ __global__ __launch_bounds__(256, (PRO == SEP_PRO_GLN_BWD ? 3 : 4)) void pw_gemm
                     fb[h][ni][kk] = da;
                     if (writer) {
                         if (live && a <= 0.f) dalpha_pro += du * a;
-                        d.pro_store[((size_t)b * d.K + kbase + kk) * d.ldt + t0 + wc * 64 + ni * 32 + l31] = da;
+                        // uniform row pointer (SGPR pair) + per-lane byte offset: the saddr form of global_store
+                        float* srow = d.pro_store + ((size_t)b * d.K + kc * DK + 4 * h + kk) * d.ldt + t0 + wc * 64 + ni * 32;
+                        *reinterpret_cast<float*>(reinterpret_cast<char*>(srow) + (size_t)st_lane_off) = da;
                     }
                 }
             } else if (PRO != SEP_PRO_NONE) {
@@ -914,6 +926,9 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_direct_kernel(const sep_wgrad
             if (n < d.N) { xg[ni] = d.x_gamma[n]; xb[ni] = d.x_beta[n]; }
         }
     }
+    // consume the loads NOW: the compiler does not count the asm LDS-DMAs below, so a wait it placed at a first use inside
+    // the loop would be vmcnt(0) and drain the whole ring
+    asm volatile("" :: "v"(xg[0]), "v"(xg[1]), "v"(xb[0]), "v"(xb[1]), "v"(alpha_x));
     // G source of this row tile (g_split is a multiple of BM -> block-uniform)
     const bool gsecond = d.g_split && m0 >= d.g_split;
     const float* Gsrc = gsecond ? d.G2 : d.G;
@@ -944,8 +959,8 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_direct_kernel(const sep_wgrad
     auto issue = [&](int stage) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            glds16(pG[q], &sm.Gs[stage][(2 * wid + q) * 256]);
-            glds16(pX[q], &sm.Xs[stage][(2 * wid + q) * 256]);
+            glds16_asm_v(pG[q], lds_addr(&sm.Gs[stage][(2 * wid + q) * 256]));
+            glds16_asm_v(pX[q], lds_addr(&sm.Xs[stage][(2 * wid + q) * 256]));
             pG[q] += DK;
             pX[q] += DK;
         }
@@ -1074,9 +1089,10 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_direct_kernel(const sep_wgrad
 }
 
 // ======================================================================================
+constexpr int RMAXSEG = 64;
 struct ReduceArgs {
-    sep_reduce_seg seg[8];
-    int blk_start[9];
+    sep_reduce_seg seg[RMAXSEG];
+    int blk_start[RMAXSEG + 1];
     int nseg;
 };
 
@@ -1191,7 +1207,7 @@ extern "C" int sep_pw_wgrad(const sep_wgrad_desc* d, sep_stream_t stream) {
 }
 
 extern "C" int sep_reduce_slabs(const sep_reduce_seg* segs, int nseg, sep_stream_t stream) {
-    SEP_REQUIRE(segs && nseg >= 1 && nseg <= 8, "sep_reduce_slabs: 1..8 segments per launch (got %d)", nseg);
+    SEP_REQUIRE(segs && nseg >= 1 && nseg <= RMAXSEG, "sep_reduce_slabs: 1..64 segments per launch (got %d)", nseg);
     ReduceArgs a;
     int blocks = 0;
     for (int i = 0; i < nseg; ++i) {

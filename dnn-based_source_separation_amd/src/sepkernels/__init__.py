@@ -164,8 +164,8 @@ class HipBackend:
     def reduce_slabs(self, segs):
         """segs: list of (src, src_offset_elems, dst, n, nslab, stride, accumulate, scale)"""
         lib = load()
-        for i in range(0, len(segs), 8):
-            chunk = segs[i:i + 8]
+        for i in range(0, len(segs), 64):
+            chunk = segs[i:i + 64]
             arr = (ReduceSeg * len(chunk))()
             for k, (src, off, dst, n, nslab, stride, acc, scale) in enumerate(chunk):
                 arr[k] = ReduceSeg(src=_ptr(src, _f32) + 4 * off, dst=_ptr(dst, _f32), n=n, nslab=nslab, stride=stride,

@@ -280,11 +280,13 @@ class _SideStream:
     disappear under the big ones.  `fork()` orders the side stream after everything enqueued on the main stream so far;
     `join()` orders the main stream after the side stream.  Tensors produced on the main stream and read on the side
     stream are handed to `keep()` so that the caching allocator does not recycle them while the side stream lags.
-    Disabled (everything stays on the caller's stream) on CPU tensors -- the emulator tests -- or SEPK_SIDE_STREAM=0."""
+    Measured on MI355X (paper-best, B=16): no gain -- 30.7 vs 30.5 ms/step.  Every kernel of this path is sized to fill the
+    chip's LDS/VGPR slots by itself, so a concurrent kernel only takes slots away from the other one; co-residency adds no
+    latency hiding.  Hence OFF by default (SEPK_SIDE_STREAM=1 turns it on); always off on CPU tensors (emulator tests)."""
     _streams = {}
 
     def __init__(self, dev):
-        self.on = dev.type == "cuda" and os.environ.get("SEPK_SIDE_STREAM", "1") != "0"
+        self.on = dev.type == "cuda" and os.environ.get("SEPK_SIDE_STREAM", "0") == "1"
         if self.on:
             key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
             if key not in _SideStream._streams:
@@ -348,6 +350,11 @@ def backward(cfg, P, sv, d_est, G):
     # ---- TCN layers, reversed -----------------------------------------------------------------------
     side = _SideStream(dev)
     side.fork()   # dS exists
+    # Every second-stage reduction of the layer loop (weight-gradient slabs, per-sample gLN/depthwise partials, PReLU
+    # slopes) is a leaf: nothing in the chain reads it.  They are queued and flushed in a handful of 64-segment launches
+    # after the loop instead of ~100 tiny launches inside it (each costs a ~5 us dispatch bubble on the critical path).
+    # Price: the slabs of all layers stay alive until the flush (~1.6 GB at B=16 paper-best; HBM is 288 GB).
+    pending = []
     dout = None
     for li in range(nl - 1, -1, -1):
         pre, dil, dual = layers[li]
@@ -393,7 +400,10 @@ def backward(cfg, P, sv, d_est, G):
                 part, pb, ns = wgrad(Sc, H, dS, z, True, True, **xkw)
                 segs += [(part, 0, G[sp + "skip_pointwise_conv1d.weight"], Sc * H, ns, Sc * H, 0, 1.0),
                          (pb, 0, G[sp + "skip_pointwise_conv1d.bias"], Sc, ns, Sc, 0, 1.0)]
-            K.reduce_slabs(segs)
+            if side.on:
+                K.reduce_slabs(segs)
+            else:
+                pending += segs
 
         # depthwise^T and everything hanging off it
         dv1 = torch.empty(B, H, ldt, **f32)
@@ -405,7 +415,7 @@ def backward(cfg, P, sv, d_est, G):
         pgamma1 = torch.empty(B, H, **f32)
         pextra = torch.empty(B * 4 * H + B + B * H, **f32)
         K.gln_bwd_finalize(rp1, nt1024, 8, st1, g1, cnt, teps, bsum1, pbeta1, pgamma1, pextra, B, H)
-        K.reduce_slabs([
+        pending += [
             (pbeta2, 0, G[sp + "norm1d.norm.bias"], H, B, H, 0, 1.0),
             (pgamma2, 0, G[sp + "norm1d.norm.weight"], H, B, H, 0, 1.0),
             (pbeta1, 0, G[pre + "norm1d.norm.bias"], H, B, H, 0, 1.0),
@@ -413,7 +423,7 @@ def backward(cfg, P, sv, d_est, G):
             (pextra, 0, G[sp + "depthwise_conv1d.bias"], H, B, 4 * H, 0, 1.0),
             (pextra, H, G[sp + "depthwise_conv1d.weight"], 3 * H, B, 4 * H, 0, 1.0),
             (pextra, B * 4 * H, G[sp + "nonlinear1d.weight"], 1, B, 1, 0, 1.0),
-        ])
+        ]
 
         # dx = W1^T da (+ dout through the residual); da = gLN1/PReLU1 backward of dv1, formed in the GEMM prologue
         dx = torch.empty(B, Bn, ldt, **f32)
@@ -429,12 +439,21 @@ def backward(cfg, P, sv, d_est, G):
         side.keep(da, dx)
         with side:
             part, pb, ns = wgrad(H, Bn, da, x, True, True)
-            K.reduce_slabs([(part, 0, G[pre + "bottleneck_conv1d.weight"], H * Bn, ns, H * Bn, 0, 1.0),
-                            (pb, 0, G[pre + "bottleneck_conv1d.bias"], H, ns, H, 0, 1.0)])
-        K.f64_to_f32(dalpha[li:li + 1], G[pre + "nonlinear1d.weight"], 1, 0)
+            segs = [(part, 0, G[pre + "bottleneck_conv1d.weight"], H * Bn, ns, H * Bn, 0, 1.0),
+                    (pb, 0, G[pre + "bottleneck_conv1d.bias"], H, ns, H, 0, 1.0)]
+            if side.on:
+                K.reduce_slabs(segs)
+            else:
+                pending += segs
         dout = dx
-    K.f64_to_f32(dalpha[nl:nl + 1], G["separator.prelu.weight"], 1, 0)
     side.join()
+    # PReLU slope gradients were accumulated in fp64 (one scalar per layer + the mask PReLU): one conversion, then
+    # scattered into the parameter gradients by the same flush
+    dal32 = torch.empty(nl + 1, **f32)
+    K.f64_to_f32(dalpha, dal32, nl + 1, 0)
+    pending += [(dal32, li, G[layers[li][0] + "nonlinear1d.weight"], 1, 1, 1, 0, 1.0) for li in range(nl)]
+    pending.append((dal32, nl, G["separator.prelu.weight"], 1, 1, 1, 0, 1.0))
+    K.reduce_slabs(pending)
 
     # ---- head: bottleneck conv, first gLN, encoder ------------------------------------------------------
     head_backward(cfg, P, geo, stats[0], w, mixture, dout, dwm, G)

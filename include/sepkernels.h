@@ -126,7 +126,7 @@ typedef struct sep_wgrad_desc {
 
 int sep_pw_wgrad(const sep_wgrad_desc* d, sep_stream_t stream);
 
-/* dst[i] (+)= scale * sum_s src[s*stride + i] for up to 8 independent segments in one launch
+/* dst[i] (+)= scale * sum_s src[s*stride + i] for up to 64 independent segments in one launch
  * (deterministic second stage of every split reduction). */
 typedef struct sep_reduce_seg {
     const float* src;

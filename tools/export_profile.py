@@ -33,4 +33,26 @@ try:
                 w.writerow([r[0], r[1], r[2], r[3], "%.1f" % r[4]])
 except sqlite3.Error:
     pass
+# idle time between kernels (launch gaps): union of the kernel intervals of the steady-state second half of the capture
+try:
+    cols = [c[1] for c in cur.execute("pragma table_info(kernels)")]
+    sc = "start" if "start" in cols else [c for c in cols if "start" in c][0]
+    ec = "end" if "end" in cols else [c for c in cols if "end" in c][0]
+    iv = sorted(cur.execute("select {}, {} from kernels".format(sc, ec)))
+    iv = iv[len(iv) // 2:]
+    busy, cur_s, cur_e = 0, iv[0][0], iv[0][1]
+    for a, b in iv[1:]:
+        if a > cur_e:
+            busy += cur_e - cur_s
+            cur_s, cur_e = a, b
+        else:
+            cur_e = max(cur_e, b)
+    busy += cur_e - cur_s
+    span = iv[-1][1] - iv[0][0]
+    with open(out + "_kernel_stats.md", "a") as f:
+        f.write("GPU busy (union of kernel intervals) over the second half of the capture: {:.1f} % of {:.1f} ms "
+                "wall -> {:.1f} % idle between kernels\n".format(100.0 * busy / span, span / 1e6, 100.0 * (1 - busy / span)))
+    print("busy fraction %.3f" % (busy / span))
+except Exception as e:  # noqa: BLE001
+    print("gap analysis skipped:", e)
 print("wrote", out + "_kernel_stats.{csv,md}", "total ms/step %.2f" % tot_ms)
