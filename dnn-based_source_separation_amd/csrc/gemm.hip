@@ -867,26 +867,36 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(const sep_wgrad_desc d
 
 
 // ======================================================================================
-// Direct-to-LDS pipelined weight gradient:  partial[s][m][n] = sum over slab s of G[b][m][t] * pro(X[b][n][t]).
+// Direct-to-LDS weight gradient:  partial[s][m][n] = sum over slab s of G[b][m][t] * pro(X[b][n][t]).
 // Both operands are row-major with the contraction index (frame t) contiguous, i.e. both take the "row-major A"
 // route of pw_gemm_direct_kernel: 16-frame chunks, 64-byte rows DMA'd with the XOR swizzle on the source address,
-// fragments by two ds_read_b128 per 32-row block, 4-stage ring, counted vmcnt.  The gLN / PReLU prologue of X is
-// applied to the B fragments (per-lane row affine x per-sample mean/rstd table in LDS); bias row sums fall out of
-// the A fragments.  Frames >= T need no mask: G is zero there by the layout contract.
+// fragments by one ds_read_b128 per 32-row block and half-chunk.
+//
+// Occupancy without more slabs: a slab's partial costs M*N*4 bytes of HBM write + re-read, so doubling the slabs to fill
+// the chip would add ~3 GB per step.  Instead a workgroup has EIGHT waves = two 4-wave groups that own alternate chunks of
+// the same slab (intra-block split of the contraction), each group a self-contained 2-stage ring + half-chunk software
+// pipeline exactly like the GEMM above; the groups share the per-chunk barrier, and group 1 hands its accumulators to
+// group 0 through LDS (the 64 KiB of the two rings) at the end.  2 workgroups per CU = 4 waves per SIMD, <= 128 VGPRs.
+// The gLN / PReLU prologue of X acts on the B fragments (per-lane row affine x per-sample mean/rstd table in LDS); bias
+// row sums fall out of the A fragments.  Frames >= T need no mask: G is zero there by the layout contract.
 // ======================================================================================
 constexpr int WMAXB = 256;      // samples whose gLN constants fit the LDS table
 
 struct __attribute__((aligned(16))) WDirectSmem {
-    float Gs[NST][128 * DK];
-    float Xs[NST][128 * DK];
+    float Gs[2][2][128 * DK];   // [group][stage]
+    float Xs[2][2][128 * DK];
     float mu[WMAXB];
     float rstd[WMAXB];
 };
 
-__global__ __launch_bounds__(256, 2) void pw_wgrad_direct_kernel(const sep_wgrad_desc d) {
+template <int XMODE>
+__global__ __launch_bounds__(512, 4) void pw_wgrad_direct_kernel(const sep_wgrad_desc d) {
+    constexpr bool X_GLN = XMODE == SEP_PRO_GLN || XMODE == SEP_PRO_GLN_PRELU;
+    constexpr bool X_PRELU = XMODE == SEP_PRO_PRELU || XMODE == SEP_PRO_GLN_PRELU;
     __shared__ WDirectSmem sm;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wid8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wid8 >> 2, wid = wid8 & 3;
     const int wr = wid >> 1, wc = wid & 1;
     const int lk = lane >> 5, l31 = lane & 31;
     const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
@@ -904,14 +914,14 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_direct_kernel(const sep_wgrad
     const long c_begin = (long)s * cper;
     long c_end = c_begin + cper;
     if (c_end > chunks_total) c_end = chunks_total;
-    const int nk = (int)(c_end > c_begin ? c_end - c_begin : 0);
+    const int nk_all = (int)(c_end > c_begin ? c_end - c_begin : 0);
+    const int nk_max = (nk_all + 1) >> 1;          // trips of the shared loop (group 0's chunk count)
+    const int nk = (nk_all + 1 - grp) >> 1;        // chunks of THIS group: c_begin + grp, +2, ...
 
-    const bool gln = d.x_mode == SEP_PRO_GLN || d.x_mode == SEP_PRO_GLN_PRELU;
-    const bool prelu = d.x_mode == SEP_PRO_PRELU || d.x_mode == SEP_PRO_GLN_PRELU;
-    const float alpha_x = prelu ? d.x_alpha[0] : 0.f;
-    if (gln) {
+    const float alpha_x = X_PRELU ? d.x_alpha[0] : 0.f;
+    if (X_GLN) {
         const int nb = d.B / d.x_div;
-        for (int bx = tid; bx < nb; bx += 256) {
+        for (int bx = tid; bx < nb; bx += 512) {
             float mu, rstd;
             gln_mu_rstd(d.x_stats + (size_t)bx * SEP_STATS_SLOTS * 2, d.count, d.eps, mu, rstd);
             sm.mu[bx] = mu; sm.rstd[bx] = rstd;
@@ -919,7 +929,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_direct_kernel(const sep_wgrad
     }
     // this lane's two X rows (B operand) and their gLN affine
     float xg[2] = {0.f, 0.f}, xb[2] = {0.f, 0.f};
-    if (gln) {
+    if (X_GLN) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             const int n = n0 + wc * 64 + ni * 32 + l31;
@@ -927,8 +937,9 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_direct_kernel(const sep_wgrad
         }
     }
     // consume the loads NOW: the compiler does not count the asm LDS-DMAs below, so a wait it placed at a first use inside
-    // the loop would be vmcnt(0) and drain the whole ring
+    // the loop would be vmcnt(0) and drain the ring
     asm volatile("" :: "v"(xg[0]), "v"(xg[1]), "v"(xb[0]), "v"(xb[1]), "v"(alpha_x));
+
     // G source of this row tile (g_split is a multiple of BM -> block-uniform)
     const bool gsecond = d.g_split && m0 >= d.g_split;
     const float* Gsrc = gsecond ? d.G2 : d.G;
@@ -936,36 +947,37 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_direct_kernel(const sep_wgrad
     const int mg0 = gsecond ? m0 - d.g_split : m0;
     const int Mg_lim = (d.M < m0 + BM ? d.M : m0 + BM) - (gsecond ? d.g_split : 0);   // rows of this tile that exist in Gsrc
 
-    // per-lane DMA sources, carried from chunk to chunk (chunks are issued strictly in order); rebuilt only when the
-    // chunk sequence crosses into the next sample
+    // DMA sources: wave-uniform base of (sample, first frame) + this lane's fixed byte offset (row, swizzled 16-byte granule)
     const int r16 = lane >> 2, cch = (lane & 3) ^ ((r16 >> 2) & 3);
-    int ib = (int)(c_begin / cps_t), itt = (int)(c_begin % cps_t) * DK;     // sample / first frame of the next chunk to issue
-    const float* pG[2];
-    const float* pX[2];
-    auto rebase = [&]() {
-        const int bx = ib / d.x_div;
+    unsigned voffG[2], voffX[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int g16 = 2 * wid + q;                              // 16-row group of the 128-row tile
+        int mm = mg0 + 16 * g16 + r16;
+        if (mm > Mg_lim - 1) mm = Mg_lim - 1;                     // rows past M: in-bounds garbage, never stored
+        voffG[q] = 4u * (unsigned)(mm * d.ldt + 4 * cch);
+        int nn = n0 + 16 * g16 + r16;
+        if (nn > d.N - 1) nn = d.N - 1;
+        voffX[q] = 4u * (unsigned)(nn * d.ldt + 4 * cch);
+    }
+    // (sample, frame) of the next chunk this group issues, and of the chunk it computes
+    const long c_first = c_begin + grp;
+    int ib = (int)(c_first / cps_t), it = (int)(c_first % cps_t);
+    int ibx = ib / d.x_div, ibm = ib % d.x_div;
+    int cb = ib, ct = it, cbx = ibx, cbm = ibm;
+    auto issue = [&](const int stage) {
+        const float* bG = Gsrc + (size_t)ib * Mg * d.ldt + it * DK;
+        const float* bX = d.X + (size_t)ibx * d.N * d.ldt + it * DK;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int g16 = 2 * wid + q;                          // 16-row group of the 128-row tile
-            int mm = mg0 + 16 * g16 + r16;
-            if (mm > Mg_lim - 1) mm = Mg_lim - 1;                 // rows past M: in-bounds garbage, never stored
-            pG[q] = Gsrc + ((size_t)ib * Mg + mm) * d.ldt + itt + 4 * cch;
-            int nn = n0 + 16 * g16 + r16;
-            if (nn > d.N - 1) nn = d.N - 1;
-            pX[q] = d.X + ((size_t)bx * d.N + nn) * d.ldt + itt + 4 * cch;
+            glds16_asm(bG, voffG[q], lds_addr(&sm.Gs[grp][stage][(2 * wid + q) * 256]));
+            glds16_asm(bX, voffX[q], lds_addr(&sm.Xs[grp][stage][(2 * wid + q) * 256]));
         }
-    };
-    rebase();
-    auto issue = [&](int stage) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            glds16_asm_v(pG[q], lds_addr(&sm.Gs[stage][(2 * wid + q) * 256]));
-            glds16_asm_v(pX[q], lds_addr(&sm.Xs[stage][(2 * wid + q) * 256]));
-            pG[q] += DK;
-            pX[q] += DK;
+        it += 2;
+        if (it >= cps_t) {
+            it -= cps_t; ++ib;
+            if (++ibm == d.x_div) { ibm = 0; ++ibx; }
         }
-        itt += DK;
-        if (itt >= d.ldt) { itt = 0; ++ib; rebase(); }
     };
 
     f32x16 acc[2][2];
@@ -978,107 +990,121 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_direct_kernel(const sep_wgrad
     float bias_acc[2] = {0.f, 0.f};
     const bool do_bias = d.partial_bias != nullptr && (tile % ntn) == 0 && wc == 0;
 
-    // sample of the chunk whose fragments are loaded next (for the per-sample gLN constants)
-    int fb_b = (int)(c_begin / cps_t), fb_t = (int)(c_begin % cps_t);
-
-#define WD_WAIT_BARRIER(k)                                                                        \
-    {                                                                                             \
-        const int rem_ = nk - 1 - (k);                                                            \
-        if (rem_ >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");    \
-        else if (rem_ == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");              \
-    }
-#define WD_LOAD_FRAGS(kc_, FA, FB)                                                                \
-    {                                                                                             \
-        const float* Gb = sm.Gs[(kc_) & (NST - 1)];                                               \
-        const float* Xb = sm.Xs[(kc_) & (NST - 1)];                                               \
-        _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) {                                        \
-            const int m = wr * 64 + mi * 32 + l31;                                                \
-            const int sw = (m >> 2) & 3;                                                          \
-            const float* p0 = Gb + m * 16 + 4 * ((2 * lk) ^ sw);                                  \
-            const float* p1 = Gb + m * 16 + 4 * ((2 * lk + 1) ^ sw);                              \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) { FA[mi][e] = p0[e]; FA[mi][4 + e] = p1[e]; } \
-        }                                                                                         \
-        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                                        \
-            const int n = wc * 64 + ni * 32 + l31;                                                \
-            const int sw = (n >> 2) & 3;                                                          \
-            const float* p0 = Xb + n * 16 + 4 * ((2 * lk) ^ sw);                                  \
-            const float* p1 = Xb + n * 16 + 4 * ((2 * lk + 1) ^ sw);                              \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) { FB[ni][e] = p0[e]; FB[ni][4 + e] = p1[e]; } \
-        }                                                                                         \
-        if (d.x_mode != SEP_PRO_NONE) {                                                           \
-            float mu = 0.f, rstd = 1.f;                                                           \
-            if (gln) { mu = sm.mu[fb_b / d.x_div]; rstd = sm.rstd[fb_b / d.x_div]; }              \
-            _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                                    \
-                const float scv = gln ? xg[ni] * rstd : 1.f;                                      \
-                const float shv = gln ? xb[ni] - mu * scv : 0.f;                                  \
-                _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                \
-                    float v = FB[ni][kk];                                                         \
-                    if (prelu) v = prelu_f(v, alpha_x);                                           \
-                    FB[ni][kk] = v * scv + shv;                                                   \
-                }                                                                                 \
-            }                                                                                     \
-        }                                                                                         \
-        if (++fb_t >= cps_t) { fb_t = 0; ++fb_b; }                                                \
-    }
-#define WD_MFMA(FA, FB)                                                                           \
-    {                                                                                             \
-        if (do_bias) {                                                                            \
-            _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                      \
-                _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) bias_acc[mi] += FA[mi][kk];      \
-        }                                                                                         \
-        _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                        \
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0][kk], FB[0][kk], acc[0][0], 0, 0, 0); \
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0][kk], FB[1][kk], acc[0][1], 0, 0, 0); \
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1][kk], FB[0][kk], acc[1][0], 0, 0, 0); \
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1][kk], FB[1][kk], acc[1][1], 0, 0, 0); \
-        }                                                                                         \
-    }
-
-    __syncthreads();                                              // mu/rstd table visible; placed BEFORE the first DMA so it drains nothing
-    float fa0[2][8], fb0[2][8], fa1[2][8], fb1[2][8];
-    if (nk > 0) {
+    float fa[2][2][4], fb[2][2][4];      // [half][mi|ni][frame]
+    auto read_half = [&](const int stage, const int h) {
+        const float* Gb = sm.Gs[grp][stage];
+        const float* Xb = sm.Xs[grp][stage];
 #pragma unroll
-        for (int st = 0; st < NST - 1; ++st)
-            if (st < nk) issue(st);
-        WD_WAIT_BARRIER(0)
-        if (NST - 1 < nk) issue(NST - 1);
-        WD_LOAD_FRAGS(0, fa0, fb0)
-        for (int kc = 0; kc < nk; kc += 2) {
-            if (kc + 1 < nk) {
-                WD_WAIT_BARRIER(kc + 1)
-                if (kc + 4 < nk) issue((kc + 4) & (NST - 1));
-                WD_LOAD_FRAGS(kc + 1, fa1, fb1)
+        for (int mi = 0; mi < 2; ++mi) {
+            const int m = wr * 64 + mi * 32 + l31;
+            const float* p = Gb + m * 16 + 4 * ((2 * lk + h) ^ ((m >> 2) & 3));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fa[h][mi][e] = p[e];
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int n = wc * 64 + ni * 32 + l31;
+            const float* p = Xb + n * 16 + 4 * ((2 * lk + h) ^ ((n >> 2) & 3));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fb[h][ni][e] = p[e];
+        }
+        __builtin_amdgcn_sched_barrier(0);      // the reads stay HERE: ahead of the MFMA burst that hides their latency
+    };
+    float scv[2] = {1.f, 1.f}, shv[2] = {0.f, 0.f};
+    auto set_sample = [&]() {
+        if (X_GLN) {
+            const float mu = sm.mu[cbx], rstd = sm.rstd[cbx];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) { scv[ni] = xg[ni] * rstd; shv[ni] = xb[ni] - mu * scv[ni]; }
+        }
+    };
+    auto mfma_half = [&](const int h) {
+        if (do_bias) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) bias_acc[mi] += fa[h][mi][kk];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (XMODE != SEP_PRO_NONE) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    float v = fb[h][ni][kk];
+                    if (X_PRELU) v = prelu_f(v, alpha_x);
+                    fb[h][ni][kk] = X_GLN ? v * scv[ni] + shv[ni] : v;
+                }
             }
-            WD_MFMA(fa0, fb0)
-            if (kc + 1 >= nk) break;
-            if (kc + 2 < nk) {
-                WD_WAIT_BARRIER(kc + 2)
-                if (kc + 5 < nk) issue((kc + 5) & (NST - 1));
-                WD_LOAD_FRAGS(kc + 2, fa0, fb0)
-            }
-            WD_MFMA(fa1, fb1)
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h][0][kk], fb[h][0][kk], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h][0][kk], fb[h][1][kk], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h][1][kk], fb[h][0][kk], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h][1][kk], fb[h][1][kk], acc[1][1], 0, 0, 0);
+        }
+    };
+
+    __syncthreads();                                              // mu/rstd table visible; BEFORE the first DMA so it drains nothing
+    set_sample();
+    if (nk > 0) issue(0);
+    wait_all_and_barrier();
+    if (nk > 1) issue(1);
+    if (nk > 0) read_half(0, 0);
+    for (int i = 0; i < nk_max; ++i) {
+        const int stage = i & 1;
+        const bool act = i < nk;                                  // group 1 may own one chunk less: it still meets the barriers
+        if (act) {
+            read_half(stage, 1);
+            mfma_half(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 1 < nk_max) {
+            // chunk i+1 has landed (mine: vmcnt(0); everyone's: barrier) and every wave is past its reads of this stage
+            wait_all_and_barrier();
+            if (i + 2 < nk) issue(stage);
+            if (i + 1 < nk) read_half(stage ^ 1, 0);
+        }
+        if (act) mfma_half(1);
+        __builtin_amdgcn_sched_barrier(0);
+        // the chunk just computed was (cb, ct); this group's next one is two chunks on
+        ct += 2;
+        if (ct >= cps_t) {
+            ct -= cps_t; ++cb;
+            if (++cbm == d.x_div) { cbm = 0; ++cbx; }
+            if (i + 1 < nk) set_sample();
         }
     }
-#undef WD_WAIT_BARRIER
-#undef WD_LOAD_FRAGS
-#undef WD_MFMA
 
+    // group 1 -> group 0 through LDS (the rings are dead now), then group 0 stores the slab
+    __syncthreads();
+    float* red = &sm.Gs[0][0][0];                                 // 16384 floats = 64 accumulators x 256 lanes
+    const int tg = tid & 255;
+    if (grp == 1) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((mi * 2 + ni) * 16 + r) * 256 + tg] = acc[mi][ni][r];
+        sm.mu[tg] = bias_acc[0];
+        sm.rstd[tg] = bias_acc[1];
+    }
+    __syncthreads();
+    if (grp == 1) return;
     float* out = d.partial + (size_t)s * d.M * d.N;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            if (row < d.M) {
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const int col = n0 + wc * 64 + ni * 32 + l31;
-                    if (col < d.N) out[(size_t)row * d.N + col] = acc[mi][ni][r];
-                }
+            for (int ni = 0; ni < 2; ++ni) {
+                const int col = n0 + wc * 64 + ni * 32 + l31;
+                const float v = acc[mi][ni][r] + red[((mi * 2 + ni) * 16 + r) * 256 + tg];
+                if (row < d.M && col < d.N) out[(size_t)row * d.N + col] = v;
             }
         }
     if (do_bias) {
+        bias_acc[0] += sm.mu[tg];
+        bias_acc[1] += sm.rstd[tg];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
             const float tot = bias_acc[mi] + __shfl_xor(bias_acc[mi], 32, 64);     // the two lane halves own different frames
@@ -1198,9 +1224,14 @@ extern "C" int sep_pw_wgrad(const sep_wgrad_desc* d, sep_stream_t stream) {
     static const bool force_staged = getenv("SEPK_FORCE_STAGED") != nullptr;
     const bool direct_ok = !force_staged && !d->g_mul && (d->x_mode < SEP_PRO_GLN || d->B / d->x_div <= WMAXB) &&
                            (long)d->nsplit <= (long)d->B * (d->ldt / DK);
-    if (direct_ok)
-        hipLaunchKernelGGL(pw_wgrad_direct_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
-    else
+    if (direct_ok) {
+        switch (d->x_mode) {
+            case SEP_PRO_NONE: hipLaunchKernelGGL((pw_wgrad_direct_kernel<SEP_PRO_NONE>), dim3(grid), dim3(512), 0, (hipStream_t)stream, *d); break;
+            case SEP_PRO_PRELU: hipLaunchKernelGGL((pw_wgrad_direct_kernel<SEP_PRO_PRELU>), dim3(grid), dim3(512), 0, (hipStream_t)stream, *d); break;
+            case SEP_PRO_GLN: hipLaunchKernelGGL((pw_wgrad_direct_kernel<SEP_PRO_GLN>), dim3(grid), dim3(512), 0, (hipStream_t)stream, *d); break;
+            default: hipLaunchKernelGGL((pw_wgrad_direct_kernel<SEP_PRO_GLN_PRELU>), dim3(grid), dim3(512), 0, (hipStream_t)stream, *d); break;
+        }
+    } else
         hipLaunchKernelGGL(pw_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
     SEP_CHECK_LAUNCH("sep_pw_wgrad");
     return 0;
