@@ -71,6 +71,16 @@ __device__ __forceinline__ void mfma_chunk32(const float* __restrict__ Ab, const
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// output tile store of the GEMM epilogue
+__device__ __forceinline__ void st4_out(float* p, float4 v) {
+#if defined(SEP_EXP_NT_STORE)
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<f4v*>(p));
+#else
+    *reinterpret_cast<float4*>(p) = v;
+#endif
+}
 
 // Shared epilogue of the GEMM kernels.  acc[mi][ni] are the wave's four 32x32 accumulators.
 //
@@ -83,11 +93,30 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 constexpr int EPI_LD = 68;                         // floats per transposed row (64 + 4: keeps float4 alignment)
 constexpr int EPI_WAVE_FLOATS = 32 * EPI_LD;       // LDS floats one wave needs
 
+#ifdef SEP_PROF
+__device__ long long g_prof[4][4][16];      // [block sample][wave][stamp]
+#define PROF_STAMP(k) do { if (prof_slot >= 0 && lane == 0) g_prof[prof_slot][wid][k] = clock64(); } while (0)
+#else
+#define PROF_STAMP(k) do { } while (0)
+#endif
+#ifdef SEP_PROF
+#define PROF_ARG , const int prof_slot
+#define PROF_PASS , prof_slot
+#else
+#define PROF_ARG
+#define PROF_PASS
+#endif
+// EF >= 0: the epilogue flag set as a compile-time constant (the host dispatch instantiates the combinations the
+// model uses); EF < 0: flags read from the descriptor.  This matters: with run-time flags every path below (sigmoid with
+// an IEEE division, row-sum shuffles, PReLU backward ...) is emitted behind ~300 branches PER TILE, and s_memtime stamps
+// showed the epilogue of a plain tile taking 14 k cycles uncontended and 47-83 k in the steady state -- as long as the
+// whole K = 128 main loop.
+template <int EF>
 __device__ __forceinline__ void gemm_epilogue(const sep_gemm_desc& d, f32x16 (&acc)[2][2], const int b, const int m0,
                                               const int t0, const int wr, const int wc, const int lk, const int l31,
-                                              const int tid, float* lds, double* red) {
+                                              const int tid, float* lds, double* red PROF_ARG) {
     const int lane = tid & 63, wid = tid >> 6;
-    const int ef = d.epi_flags;
+    const int ef = EF >= 0 ? EF : d.epi_flags;
     const float alpha_e = (ef & (SEP_EPI_STATS_PRELU | SEP_EPI_PRELU_BWD | SEP_EPI_ROWSUMS_PRELU)) ? d.epi_alpha[0] : 0.f;
     float st_s = 0.f, st_ss = 0.f, dalpha_e = 0.f;
     const int Mfirst = d.m_split ? d.m_split : d.M;
@@ -112,6 +141,10 @@ __device__ __forceinline__ void gemm_epilogue(const sep_gemm_desc& d, f32x16 (&a
             Tw[rl * EPI_LD + 32 + l31] = acc[mi][1][r];
         }
         __builtin_amdgcn_wave_barrier();       // LDS is in-order per wave; this only pins the compiler's order
+#ifdef SEP_PROF
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        PROF_STAMP(8 + 4 * mi);
+#endif
         // ---- gather every global read of this half ---------------------------------------------
         float4 ext[8], aux[8];
         float bs[8];
@@ -131,6 +164,10 @@ __device__ __forceinline__ void gemm_epilogue(const sep_gemm_desc& d, f32x16 (&a
             }
             ext[it] = e; aux[it] = a;
         }
+#ifdef SEP_PROF
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        PROF_STAMP(9 + 4 * mi);
+#endif
         // ---- compute + float4 stores -------------------------------------------------------------
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
@@ -149,7 +186,7 @@ __device__ __forceinline__ void gemm_epilogue(const sep_gemm_desc& d, f32x16 (&a
                     const float u = prelu_f(v[e], alpha_e);
                     if (valid && ok) { st_s += u; st_ss += u * u; }
                 }
-                if (ef & SEP_EPI_SIGMOID) v[e] = 1.f / (1.f + expf(-v[e]));
+                if (ef & SEP_EPI_SIGMOID) v[e] = __frcp_rn(1.f + __expf(-v[e]));     // v_exp_f32 / v_rcp_f32: ~1e-6 relative
                 if (ef & SEP_EPI_PRELU_BWD) {
                     if (valid && ok && ax[e] <= 0.f) dalpha_e += v[e] * ax[e];
                     v[e] *= prelu_grad(ax[e], alpha_e);
@@ -165,7 +202,11 @@ __device__ __forceinline__ void gemm_epilogue(const sep_gemm_desc& d, f32x16 (&a
 #else
             if (ok)
 #endif
-                st4(dst + ((size_t)b * Mdst + (row - rowoff)) * d.ldt + tc, make_float4(v[0], v[1], v[2], v[3]));
+#ifdef SEP_ABL_SMALL_DST
+                st4(dst + ((((size_t)b * Mdst + (row - rowoff)) * d.ldt + tc) & 0x3FFFCu), make_float4(v[0], v[1], v[2], v[3]));   // ablation: 1 MiB, L2-resident
+#else
+                st4_out(dst + ((size_t)b * Mdst + (row - rowoff)) * d.ldt + tc, make_float4(v[0], v[1], v[2], v[3]));
+#endif
             if (ef & SEP_EPI_ROWSUMS) {
                 // the 16 lanes with equal (lane >> 4) share this row: xor offsets < 16 stay inside the group
 #pragma unroll
@@ -180,6 +221,9 @@ __device__ __forceinline__ void gemm_epilogue(const sep_gemm_desc& d, f32x16 (&a
             }
         }
         __builtin_amdgcn_wave_barrier();
+#ifdef SEP_PROF
+        PROF_STAMP(10 + 4 * mi);
+#endif
     }
     if (ef & SEP_EPI_STATS_PRELU) {
         const double s = block_sum_256<double>((double)st_s, red);
@@ -370,7 +414,10 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const sep_gemm_desc d) 
     }
 
     __syncthreads();                                    // K-loop LDS reads are done: the staging area becomes the transpose buffer
-    gemm_epilogue(d, acc, b, m0, t0, wr, wc, lk, l31, tid, &sm.As[0][0], sm.red);
+    #ifdef SEP_PROF
+    const int prof_slot = -1;
+#endif
+    gemm_epilogue<-1>(d, acc, b, m0, t0, wr, wc, lk, l31, tid, &sm.As[0][0], sm.red PROF_PASS);
     if (pro == SEP_PRO_GLN_BWD && rt == 0) {
         const double s = block_sum_256<double>((double)dalpha_pro, sm.red);
         if (tid == 0) atomicAdd(d.pro_dalpha, s);
@@ -458,7 +505,7 @@ struct __attribute__((aligned(16))) DirectSmem {
 #ifndef SEP_GLN_OCC
 #define SEP_GLN_OCC 4       // measured: 4 blocks/CU with ~40 B of spill (outside the hot loop) = 3 blocks/CU spill-free (182 vs 186 us on the heads GEMM)
 #endif
-template <bool TRANS_A, int PRO, bool SPLIT>
+template <bool TRANS_A, int PRO, bool SPLIT, int EF>
 __global__ __launch_bounds__(256, (PRO == SEP_PRO_GLN_BWD ? 3 : PRO >= SEP_PRO_GLN ? SEP_GLN_OCC : 4)) void pw_gemm_direct_kernel(const sep_gemm_desc d) {
     constexpr bool P_PRELU = PRO == SEP_PRO_PRELU || PRO == SEP_PRO_GLN_PRELU;
     constexpr bool P_GLN = PRO == SEP_PRO_GLN || PRO == SEP_PRO_GLN_PRELU;
@@ -482,6 +529,10 @@ __global__ __launch_bounds__(256, (PRO == SEP_PRO_GLN_BWD ? 3 : PRO >= SEP_PRO_G
     const int t0 = (ct % ntile_t) * BN;
     const int m0 = rt * BM;
     const int nk = d.K / DK;
+#ifdef SEP_PROF
+    const int prof_slot = bid == 8 ? 0 : bid == 1500 ? 1 : bid == 1501 ? 2 : bid == (int)gridDim.x - 9 ? 3 : -1;
+#endif
+    PROF_STAMP(0);
 
     // per-row affine of the prologue, once per workgroup
     float alpha_p = 0.f, mu = 0.f, rstd = 1.f, mg = 0.f, mgx = 0.f;
@@ -678,8 +729,10 @@ __global__ __launch_bounds__(256, (PRO == SEP_PRO_GLN_BWD ? 3 : PRO >= SEP_PRO_G
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    PROF_STAMP(1);
     issue(0);
     wait_all_and_barrier();
+    PROF_STAMP(2);
     if (nk > 1) issue(1);
     read_half(0, 0, 0);
     int kc = 0;
@@ -688,16 +741,23 @@ __global__ __launch_bounds__(256, (PRO == SEP_PRO_GLN_BWD ? 3 : PRO >= SEP_PRO_G
         step(kc + 1, 1);
     }
     if (kc < nk) step(kc, 0);
+    PROF_STAMP(3);
     __syncthreads();
+    PROF_STAMP(4);
 #ifdef SEP_ABL_NO_EPI
     if (acc[0][0][0] + acc[0][1][3] + acc[1][0][5] + acc[1][1][7] == 123.456f) d.Y[tid] = 1.f;
 #else
-    gemm_epilogue(d, acc, b, m0, t0, wr, wc, lk, l31, tid, &sm.As[0][0], sm.red);
+    gemm_epilogue<EF>(d, acc, b, m0, t0, wr, wc, lk, l31, tid, &sm.As[0][0], sm.red PROF_PASS);
 #endif
+    PROF_STAMP(5);
     if (P_BWD && rt == 0) {
         const double sdal = block_sum_256<double>((double)dalpha_pro, sm.red);
         if (tid == 0) atomicAdd(d.pro_dalpha, sdal);
     }
+#ifdef SEP_PROF
+    __builtin_amdgcn_s_waitcnt(0x0070);
+#endif
+    PROF_STAMP(6);
 }
 
 // ======================================================================================
@@ -1150,6 +1210,12 @@ __global__ void f64_to_f32_kernel(const double* src, float* dst, int n, int accu
 
 }  // namespace
 
+#ifdef SEP_PROF
+extern "C" int sep_debug_prof(long long* out) {      // development builds only (tools/gemm_prof.py)
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(long long) * 4 * 4 * 16) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" int sep_pw_gemm(const sep_gemm_desc* d, sep_stream_t stream) {
     SEP_REQUIRE(d != nullptr, "sep_pw_gemm: null descriptor");
     SEP_REQUIRE(d->B > 0 && d->M > 0 && d->K > 0 && d->T > 0, "sep_pw_gemm: empty problem (B=%d M=%d K=%d T=%d)", d->B, d->M, d->K, d->T);
@@ -1182,24 +1248,47 @@ extern "C" int sep_pw_gemm(const sep_gemm_desc* d, sep_stream_t stream) {
                            (d->pro_mode < SEP_PRO_GLN || d->K <= OMAXK);
     SEP_REQUIRE(direct_ok || (d->K % BK == 0 && d->k_split % BK == 0), "sep_pw_gemm: the register-staged fallback (K=%d) needs K %% 32 == 0", d->K);
     if (direct_ok) {
-#define SEP_LAUNCH_DIRECT(T, P)                                                                                              \
-    do {                                                                                                                     \
-        if (d->k_split) hipLaunchKernelGGL((pw_gemm_direct_kernel<T, P, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);  \
-        else hipLaunchKernelGGL((pw_gemm_direct_kernel<T, P, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);            \
+#define SEP_LD(T, P, S, E) hipLaunchKernelGGL((pw_gemm_direct_kernel<T, P, S, E>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *d)
+        // 1. the (operand form, prologue, split, epilogue) combinations of the Conv-TasNet step, epilogue flags compile-time
+        const int ef = d->epi_flags, pm = d->pro_mode;
+        const bool tr = d->trans_a != 0, sp = d->k_split != 0;
+        bool done = true;
+        if (!tr && !sp && pm == SEP_PRO_NONE && ef == SEP_EPI_STATS_PRELU) SEP_LD(false, SEP_PRO_NONE, false, SEP_EPI_STATS_PRELU);              // TCN conv1
+        else if (!tr && !sp && pm == SEP_PRO_GLN_PRELU && ef == SEP_EPI_RESIDUAL) SEP_LD(false, SEP_PRO_GLN_PRELU, false, SEP_EPI_RESIDUAL);     // heads
+        else if (!tr && !sp && pm == SEP_PRO_GLN_PRELU && ef == 0) SEP_LD(false, SEP_PRO_GLN_PRELU, false, 0);                                   // last layer: skip head only
+        else if (!tr && !sp && pm == SEP_PRO_PRELU && ef == SEP_EPI_SIGMOID) SEP_LD(false, SEP_PRO_PRELU, false, SEP_EPI_SIGMOID);               // mask
+        else if (!tr && !sp && pm == SEP_PRO_GLN && ef == 0) SEP_LD(false, SEP_PRO_GLN, false, 0);                                               // bottleneck
+        else if (!tr && !sp && pm == SEP_PRO_NONE && ef == 0) SEP_LD(false, SEP_PRO_NONE, false, 0);                                             // plain 1x1 conv
+        else if (tr && !sp && pm == SEP_PRO_NONE && ef == 0) SEP_LD(true, SEP_PRO_NONE, false, 0);                                               // plain input gradient
+        else if (tr && !sp && pm == SEP_PRO_NONE && ef == SEP_EPI_PRELU_BWD) SEP_LD(true, SEP_PRO_NONE, false, SEP_EPI_PRELU_BWD);               // mask^T
+        else if (tr && sp && pm == SEP_PRO_NONE && ef == (SEP_EPI_ROWSUMS | SEP_EPI_ROWSUMS_PRELU)) SEP_LD(true, SEP_PRO_NONE, true, SEP_EPI_ROWSUMS | SEP_EPI_ROWSUMS_PRELU);   // heads^T
+        else if (tr && !sp && pm == SEP_PRO_NONE && ef == (SEP_EPI_ROWSUMS | SEP_EPI_ROWSUMS_PRELU)) SEP_LD(true, SEP_PRO_NONE, false, SEP_EPI_ROWSUMS | SEP_EPI_ROWSUMS_PRELU);
+        else if (tr && !sp && pm == SEP_PRO_NONE && ef == SEP_EPI_ROWSUMS) SEP_LD(true, SEP_PRO_NONE, false, SEP_EPI_ROWSUMS);                   // bottleneck^T
+        else if (tr && !sp && pm == SEP_PRO_GLN_BWD && ef == SEP_EPI_RESIDUAL) SEP_LD(true, SEP_PRO_GLN_BWD, false, SEP_EPI_RESIDUAL);           // conv1^T
+        else if (tr && !sp && pm == SEP_PRO_GLN_BWD && ef == 0) SEP_LD(true, SEP_PRO_GLN_BWD, false, 0);
+        else done = false;
+        // 2. anything else: same kernels with the flags read at run time
+        if (!done) {
+#define SEP_LAUNCH_DIRECT(T, P)                 \
+    do {                                        \
+        if (sp) SEP_LD(T, P, true, -1);         \
+        else SEP_LD(T, P, false, -1);           \
     } while (0)
-        switch (d->pro_mode * 2 + (d->trans_a ? 1 : 0)) {
-            case 0: SEP_LAUNCH_DIRECT(false, SEP_PRO_NONE); break;
-            case 1: SEP_LAUNCH_DIRECT(true, SEP_PRO_NONE); break;
-            case 2: SEP_LAUNCH_DIRECT(false, SEP_PRO_PRELU); break;
-            case 3: SEP_LAUNCH_DIRECT(true, SEP_PRO_PRELU); break;
-            case 4: SEP_LAUNCH_DIRECT(false, SEP_PRO_GLN); break;
-            case 5: SEP_LAUNCH_DIRECT(true, SEP_PRO_GLN); break;
-            case 6: SEP_LAUNCH_DIRECT(false, SEP_PRO_GLN_PRELU); break;
-            case 7: SEP_LAUNCH_DIRECT(true, SEP_PRO_GLN_PRELU); break;
-            case 8: hipLaunchKernelGGL((pw_gemm_direct_kernel<false, SEP_PRO_GLN_BWD, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *d); break;
-            default: hipLaunchKernelGGL((pw_gemm_direct_kernel<true, SEP_PRO_GLN_BWD, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *d); break;
-        }
+            switch (pm * 2 + (tr ? 1 : 0)) {
+                case 0: SEP_LAUNCH_DIRECT(false, SEP_PRO_NONE); break;
+                case 1: SEP_LAUNCH_DIRECT(true, SEP_PRO_NONE); break;
+                case 2: SEP_LAUNCH_DIRECT(false, SEP_PRO_PRELU); break;
+                case 3: SEP_LAUNCH_DIRECT(true, SEP_PRO_PRELU); break;
+                case 4: SEP_LAUNCH_DIRECT(false, SEP_PRO_GLN); break;
+                case 5: SEP_LAUNCH_DIRECT(true, SEP_PRO_GLN); break;
+                case 6: SEP_LAUNCH_DIRECT(false, SEP_PRO_GLN_PRELU); break;
+                case 7: SEP_LAUNCH_DIRECT(true, SEP_PRO_GLN_PRELU); break;
+                case 8: SEP_LD(false, SEP_PRO_GLN_BWD, false, -1); break;
+                default: SEP_LD(true, SEP_PRO_GLN_BWD, false, -1); break;
+            }
 #undef SEP_LAUNCH_DIRECT
+        }
+#undef SEP_LD
     } else
         hipLaunchKernelGGL(pw_gemm_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
     SEP_CHECK_LAUNCH("sep_pw_gemm");
