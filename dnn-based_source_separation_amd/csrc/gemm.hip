@@ -94,7 +94,8 @@ constexpr int EPI_LD = 68;                         // floats per transposed row 
 constexpr int EPI_WAVE_FLOATS = 32 * EPI_LD;       // LDS floats one wave needs
 
 #ifdef SEP_PROF
-__device__ long long g_prof[4][4][16];      // [block sample][wave][stamp]
+__device__ long long g_prof[4][4][16];
+__device__ long long g_blk_start[8192], g_blk_end[8192];      // [block sample][wave][stamp]
 #define PROF_STAMP(k) do { if (prof_slot >= 0 && lane == 0) g_prof[prof_slot][wid][k] = clock64(); } while (0)
 #else
 #define PROF_STAMP(k) do { } while (0)
@@ -533,6 +534,9 @@ __global__ __launch_bounds__(256, (PRO == SEP_PRO_GLN_BWD ? 3 : PRO >= SEP_PRO_G
     const int prof_slot = bid == 8 ? 0 : bid == 1500 ? 1 : bid == 1501 ? 2 : bid == (int)gridDim.x - 9 ? 3 : -1;
 #endif
     PROF_STAMP(0);
+#ifdef SEP_PROF
+    if (tid == 0 && bid < 8192) g_blk_start[bid] = wall_clock64();
+#endif
 
     // per-row affine of the prologue, once per workgroup
     float alpha_p = 0.f, mu = 0.f, rstd = 1.f, mg = 0.f, mgx = 0.f;
@@ -758,6 +762,9 @@ __global__ __launch_bounds__(256, (PRO == SEP_PRO_GLN_BWD ? 3 : PRO >= SEP_PRO_G
     __builtin_amdgcn_s_waitcnt(0x0070);
 #endif
     PROF_STAMP(6);
+#ifdef SEP_PROF
+    if (tid == 0 && bid < 8192) g_blk_end[bid] = wall_clock64();
+#endif
 }
 
 // ======================================================================================
@@ -1211,6 +1218,10 @@ __global__ void f64_to_f32_kernel(const double* src, float* dst, int n, int accu
 }  // namespace
 
 #ifdef SEP_PROF
+extern "C" int sep_debug_blocks(long long* start, long long* end) {
+    if (hipMemcpyFromSymbol(start, HIP_SYMBOL(g_blk_start), sizeof(long long) * 8192) != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(end, HIP_SYMBOL(g_blk_end), sizeof(long long) * 8192) == hipSuccess ? 0 : -1;
+}
 extern "C" int sep_debug_prof(long long* out) {      // development builds only (tools/gemm_prof.py)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(long long) * 4 * 4 * 16) == hipSuccess ? 0 : -1;
 }

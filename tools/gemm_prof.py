@@ -42,3 +42,20 @@ for name, kw in cases.items():
                 blk, w, *d, (s[6] - s[0]) / 2400.0))
             print("           epilogue detail: half0 transpose {:6d} | loads {:6d} | compute+stores {:6d} || half1 transpose {:6d} | loads {:6d} | compute+stores {:6d}".format(
                 s[8] - s[4], s[9] - s[8], s[10] - s[9], s[12] - s[10], s[13] - s[12], s[14] - s[13]))
+
+    # workgroup residency: how many workgroups are alive at once (start/end stamps of every workgroup, 100 MHz wall clock)
+    n = 8 * ((kw["M"] + 127) // 128) * ((B * (ldt // 128) + 7) // 8)
+    st_ = (ctypes.c_longlong * 8192)()
+    en_ = (ctypes.c_longlong * 8192)()
+    assert lib.sep_debug_blocks(st_, en_) == 0
+    n = min(n, 8192)
+    ev = sorted([(st_[i], 1) for i in range(n)] + [(en_[i], -1) for i in range(n)])
+    t0_, live, peak, area, last = ev[0][0], 0, 0, 0, ev[0][0]
+    for tt, dlt in ev:
+        area += live * (tt - last)
+        last = tt
+        live += dlt
+        peak = max(peak, live)
+    dur = [(en_[i] - st_[i]) / 100.0 for i in range(n)]
+    print("  workgroups {}: peak alive {} ({:.2f} per CU), mean alive {:.0f}, span {:.1f} us, mean workgroup life {:.1f} us".format(
+        n, peak, peak / 256.0, area / max(last - t0_, 1), (last - t0_) / 100.0, sum(dur) / n))
