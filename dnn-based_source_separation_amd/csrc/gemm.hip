@@ -71,6 +71,19 @@ __device__ __forceinline__ void mfma_chunk32(const float* __restrict__ Ab, const
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ const float* byte_off(const float* base, unsigned bytes) {
+    return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)bytes);
+}
+// Sum over the 16 lanes of a DPP row (lanes 16i .. 16i+15), result in every lane of the row.  Four VALU with DPP operands
+// (quad xor 1, quad xor 2, mirror inside 8, mirror inside 16: a sum does not care which partner it meets) instead of four
+// ds_bpermute round trips through the LDS crossbar with an lgkmcnt wait each.
+__device__ __forceinline__ float row16_sum(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));   // row_mirror
+    return x;
+}
 // output tile store of the GEMM epilogue
 __device__ __forceinline__ void st4_out(float* p, float4 v) {
 #if defined(SEP_EXP_NT_STORE)
@@ -107,16 +120,24 @@ __device__ long long g_blk_start[8192], g_blk_end[8192];      // [block sample][
 #define PROF_ARG
 #define PROF_PASS
 #endif
-// EF >= 0: the epilogue flag set as a compile-time constant (the host dispatch instantiates the combinations the
-// model uses); EF < 0: flags read from the descriptor.  This matters: with run-time flags every path below (sigmoid with
-// an IEEE division, row-sum shuffles, PReLU backward ...) is emitted behind ~300 branches PER TILE, and s_memtime stamps
-// showed the epilogue of a plain tile taking 14 k cycles uncontended and 47-83 k in the steady state -- as long as the
-// whole K = 128 main loop.
+// EF >= 0: the epilogue flag set as a compile-time constant AND a promise of the host dispatch that M (and m_split) are
+// multiples of 128, so no row predicate exists (the host instantiates this for the combinations the model uses);
+// EF < 0: flags read from the descriptor, rows predicated.  Column edge (the last column tile of a sample, frames >= T):
+// the (bias-added) tile is multiplied by a 0/1 lane mask in a small wave-uniform block BEFORE the flag-dependent math, so
+// statistics, row sums and the stored pad frames come out as zeros without a second copy of the math.
+// Why this is lean on purpose: when the other three waves of a SIMD are issuing MFMAs back to back, a VALU instruction of
+// the epilogue wave gets an issue slot roughly once per MFMA (s_memtime stamps: the same epilogue took 14 k cycles alone,
+// 47-58 k next to three busy waves, and it STRETCHED when the main loops were staggered away from it).  First version:
+// run-time flags (~300 branches per tile), 64-bit address arithmetic and a predicate per row: 800-1600 VALU per
+// tile-wave.  Now 150-800: addresses are a wave-uniform row pointer (SGPRs) plus one per-lane byte offset, the loads of a
+// group are issued before the first use, flags and predicates fold away.  Keep it free of scratch: above ~200 B/lane the
+// runtime falls back to per-dispatch scratch allocation (+25 us per launch, measured).
 template <int EF>
 __device__ __forceinline__ void gemm_epilogue(const sep_gemm_desc& d, f32x16 (&acc)[2][2], const int b, const int m0,
                                               const int t0, const int wr, const int wc, const int lk, const int l31,
                                               const int tid, float* lds, double* red PROF_ARG) {
-    const int lane = tid & 63, wid = tid >> 6;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ef = EF >= 0 ? EF : d.epi_flags;
     const float alpha_e = (ef & (SEP_EPI_STATS_PRELU | SEP_EPI_PRELU_BWD | SEP_EPI_ROWSUMS_PRELU)) ? d.epi_alpha[0] : 0.f;
     float st_s = 0.f, st_ss = 0.f, dalpha_e = 0.f;
@@ -128,9 +149,23 @@ __device__ __forceinline__ void gemm_epilogue(const sep_gemm_desc& d, f32x16 (&a
     const bool acc_this = d.accumulate && (second || !d.m_split);
     const bool use_res = (ef & SEP_EPI_RESIDUAL) && !second;
     const bool use_aux = (ef & (SEP_EPI_PRELU_BWD | SEP_EPI_ROWSUMS)) != 0;
+    const bool has_bias = d.bias != nullptr;
     float* Tw = lds + wid * EPI_WAVE_FLOATS;
     const int rsub = lane >> 4, c4 = lane & 15;              // read-back: 4 rows x 16 float4 per pass
     const int tc = t0 + wc * 64 + 4 * c4;
+    // wave-uniform pointers to (first row of this wave, first frame of this tile); a lane adds lane_off bytes
+    const int wrow = m0 + wr * 64;                           // first output row of this wave
+    const unsigned lane_off = 4u * (unsigned)(rsub * d.ldt + wc * 64 + 4 * c4);
+    float* const dst_w = dst + ((size_t)b * Mdst + (wrow - rowoff)) * d.ldt + t0;
+    const float* const res_w = use_res ? d.epi_res + ((size_t)b * Mfirst + wrow) * d.ldt + t0 : nullptr;
+    const float* const aux_w = use_aux ? d.epi_aux + ((size_t)b * d.M + wrow) * d.ldt + t0 : nullptr;
+    const float* const bias_w = has_bias ? d.bias + wrow : nullptr;
+    constexpr bool FULL = EF >= 0;          // rows never need a predicate
+    constexpr int GRP = FULL ? 4 : 1;
+    const bool full_cols = t0 + BN <= d.T;  // block-uniform
+    float cm[4];                            // 0/1 column mask of this lane's four frames
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cm[e] = (tc + e) < d.T ? 1.f : 0.f;
 
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
@@ -146,81 +181,119 @@ __device__ __forceinline__ void gemm_epilogue(const sep_gemm_desc& d, f32x16 (&a
         __builtin_amdgcn_s_waitcnt(0x0070);
         PROF_STAMP(8 + 4 * mi);
 #endif
-        // ---- gather every global read of this half ---------------------------------------------
-        float4 ext[8], aux[8];
-        float bs[8];
+        // ---- per group of GRP passes (4 rows each): every global read issued back to back, then compute + stores.
+        //      Four on full tiles (eight would spill: 3 x 8 float4 of operands next to the second half's accumulators),
+        //      two on edge tiles, whose predicates need registers too -- ANY scratch in this kernel costs occupancy.
+        //      Wave-uniform options (bias / residual / accumulate) are whole-group blocks: one scalar branch each.
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = m0 + wr * 64 + mi * 32 + it * 4 + rsub;
-            const bool ok = row < d.M;
-            bs[it] = (ok && d.bias) ? d.bias[row] : 0.f;
-            float4 e = make_float4(0.f, 0.f, 0.f, 0.f), a = e;
-            if (ok) {
-                if (use_res) e = ld4(d.epi_res + ((size_t)b * Mfirst + row) * d.ldt + tc);   // residual has the Y-part's row count
-                if (acc_this) {
-                    const float4 o = ld4(dst + ((size_t)b * Mdst + (row - rowoff)) * d.ldt + tc);
-                    e.x += o.x; e.y += o.y; e.z += o.z; e.w += o.w;
+        for (int g4 = 0; g4 < 8; g4 += GRP) {
+            float4 ext[GRP], aux[GRP], old[GRP];
+            float bs[GRP];
+            bool ok[GRP];
+#pragma unroll
+            for (int j = 0; j < GRP; ++j) {
+                ok[j] = FULL || (wrow + mi * 32 + (g4 + j) * 4 + rsub) < d.M;
+                if (!FULL) {                       // rows past M: neutral operands (on full tiles every use is guarded by the same flag as its load)
+                    bs[j] = 0.f;
+                    ext[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    aux[j] = ext[j];
+                    old[j] = ext[j];
                 }
-                if (use_aux) a = ld4(d.epi_aux + ((size_t)b * d.M + row) * d.ldt + tc);
             }
-            ext[it] = e; aux[it] = a;
-        }
+            if (has_bias) {
+#pragma unroll
+                for (int j = 0; j < GRP; ++j)
+                    if (ok[j]) bs[j] = *byte_off(bias_w + mi * 32 + (g4 + j) * 4, 4u * (unsigned)rsub);
+            }
+            if (use_res) {
+#pragma unroll
+                for (int j = 0; j < GRP; ++j)
+                    if (ok[j]) ext[j] = ld4(byte_off(res_w + (mi * 32 + (g4 + j) * 4) * (size_t)d.ldt, lane_off));
+            }
+            if (use_aux) {
+#pragma unroll
+                for (int j = 0; j < GRP; ++j)
+                    if (ok[j]) aux[j] = ld4(byte_off(aux_w + (mi * 32 + (g4 + j) * 4) * (size_t)d.ldt, lane_off));
+            }
+            if (acc_this) {
+#pragma unroll
+                for (int j = 0; j < GRP; ++j)
+                    if (ok[j]) old[j] = ld4(byte_off(dst_w + (mi * 32 + (g4 + j) * 4) * (size_t)d.ldt, lane_off));
+            }
 #ifdef SEP_PROF
-        __builtin_amdgcn_s_waitcnt(0x0070);
-        PROF_STAMP(9 + 4 * mi);
+            __builtin_amdgcn_s_waitcnt(0x0070);
+            PROF_STAMP(9 + 4 * mi);
 #endif
-        // ---- compute + float4 stores -------------------------------------------------------------
+            float4 outv[GRP];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int rl = it * 4 + rsub;
-            const int row = m0 + wr * 64 + mi * 32 + rl;
-            const bool ok = row < d.M;
-            const float4 tv = ld4(Tw + rl * EPI_LD + 4 * c4);
-            float v[4] = {tv.x + bs[it], tv.y + bs[it], tv.z + bs[it], tv.w + bs[it]};
-            const float ex[4] = {ext[it].x, ext[it].y, ext[it].z, ext[it].w};
-            const float ax[4] = {aux[it].x, aux[it].y, aux[it].z, aux[it].w};
-            float rs1 = 0.f, rs2 = 0.f;
+            for (int j = 0; j < GRP; ++j) outv[j] = ld4(Tw + ((g4 + j) * 4 + rsub) * EPI_LD + 4 * c4);
+            if (has_bias) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const bool valid = (tc + e) < d.T;
-                if (ef & SEP_EPI_STATS_PRELU) {
-                    const float u = prelu_f(v[e], alpha_e);
-                    if (valid && ok) { st_s += u; st_ss += u * u; }
+                for (int j = 0; j < GRP; ++j) { outv[j].x += bs[j]; outv[j].y += bs[j]; outv[j].z += bs[j]; outv[j].w += bs[j]; }
+            }
+            if (!full_cols) {
+#pragma unroll
+                for (int j = 0; j < GRP; ++j) { outv[j].x *= cm[0]; outv[j].y *= cm[1]; outv[j].z *= cm[2]; outv[j].w *= cm[3]; }
+            }
+#pragma unroll
+            for (int j = 0; j < GRP; ++j) {
+                float v[4] = {outv[j].x, outv[j].y, outv[j].z, outv[j].w};
+                float ax[4] = {0.f, 0.f, 0.f, 0.f};
+                if (use_aux) { ax[0] = aux[j].x; ax[1] = aux[j].y; ax[2] = aux[j].z; ax[3] = aux[j].w; }
+                float rs1 = 0.f, rs2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool live = FULL || ok[j];          // invalid frames already hold zeros
+                    if (ef & SEP_EPI_STATS_PRELU) {
+                        const float u = prelu_f(v[e], alpha_e);
+                        if (live) { st_s += u; st_ss = fmaf(u, u, st_ss); }
+                    }
+                    // 1 / (1 + 2^(-v log2 e)) on the bare v_exp_f32 / v_rcp_f32 (1 ulp each; the libm forms cost ~17 VALU)
+                    if (ef & SEP_EPI_SIGMOID) v[e] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v[e]));
+                    if (ef & SEP_EPI_PRELU_BWD) {
+                        if (live && ax[e] <= 0.f) dalpha_e = fmaf(v[e], ax[e], dalpha_e);
+                        v[e] *= prelu_grad(ax[e], alpha_e);
+                    }
+                    if (ef & SEP_EPI_ROWSUMS) {
+                        const float u = (ef & SEP_EPI_ROWSUMS_PRELU) ? prelu_f(ax[e], alpha_e) : ax[e];
+                        if (live) { rs1 += v[e]; rs2 = fmaf(v[e], u, rs2); }
+                    }
+                    if ((ef & SEP_EPI_SIGMOID) && !full_cols) v[e] *= cm[e];     // sigmoid(0) = 0.5: mask again
                 }
-                if (ef & SEP_EPI_SIGMOID) v[e] = __frcp_rn(1.f + __expf(-v[e]));     // v_exp_f32 / v_rcp_f32: ~1e-6 relative
-                if (ef & SEP_EPI_PRELU_BWD) {
-                    if (valid && ok && ax[e] <= 0.f) dalpha_e += v[e] * ax[e];
-                    v[e] *= prelu_grad(ax[e], alpha_e);
-                }
+                outv[j] = make_float4(v[0], v[1], v[2], v[3]);
                 if (ef & SEP_EPI_ROWSUMS) {
-                    const float u = (ef & SEP_EPI_ROWSUMS_PRELU) ? prelu_f(ax[e], alpha_e) : ax[e];
-                    if (valid && ok) { rs1 += v[e]; rs2 += v[e] * u; }
+                    // the 16 lanes with equal (lane >> 4) share this row: xor offsets < 16 stay inside the group
+                    rs1 = row16_sum(rs1);
+                    rs2 = row16_sum(rs2);
+                    if (c4 == 0 && ok[j]) {
+                        float* rp = d.epi_rowpart + (((size_t)b * d.M + wrow + mi * 32 + (g4 + j) * 4 + rsub) * (d.ldt / 64) + (t0 + wc * 64) / 64) * 2;
+                        rp[0] = rs1; rp[1] = rs2;
+                    }
                 }
-                v[e] = valid ? v[e] + ex[e] : 0.f;
             }
-#ifdef SEP_ABL_NO_EPI_STORE
-            if (ok && v[0] == 123.456f)
-#else
-            if (ok)
-#endif
-#ifdef SEP_ABL_SMALL_DST
-                st4(dst + ((((size_t)b * Mdst + (row - rowoff)) * d.ldt + tc) & 0x3FFFCu), make_float4(v[0], v[1], v[2], v[3]));   // ablation: 1 MiB, L2-resident
-#else
-                st4_out(dst + ((size_t)b * Mdst + (row - rowoff)) * d.ldt + tc, make_float4(v[0], v[1], v[2], v[3]));
-#endif
-            if (ef & SEP_EPI_ROWSUMS) {
-                // the 16 lanes with equal (lane >> 4) share this row: xor offsets < 16 stay inside the group
+            if (use_res) {                  // whole-group block (use_res depends on which output part this tile is in)
 #pragma unroll
-                for (int o = 8; o > 0; o >>= 1) {
-                    rs1 += __shfl_xor(rs1, o, 64);
-                    rs2 += __shfl_xor(rs2, o, 64);
-                }
-                if (c4 == 0 && ok) {
-                    float* rp = d.epi_rowpart + (((size_t)b * d.M + row) * (d.ldt / 64) + (t0 + wc * 64) / 64) * 2;
-                    rp[0] = rs1; rp[1] = rs2;
+                for (int j = 0; j < GRP; ++j) {
+                    // frames >= T of the residual / accumulated tensors are zero by contract, so the sums keep them zero
+                    outv[j].x += ext[j].x; outv[j].y += ext[j].y; outv[j].z += ext[j].z; outv[j].w += ext[j].w;
                 }
             }
-        }
+            if (acc_this) {
+#pragma unroll
+                for (int j = 0; j < GRP; ++j) {
+                    outv[j].x += old[j].x; outv[j].y += old[j].y; outv[j].z += old[j].z; outv[j].w += old[j].w;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < GRP; ++j) {
+#ifdef SEP_ABL_NO_EPI_STORE
+                if (ok[j] && outv[j].x == 123.456f)
+#else
+                if (ok[j])
+#endif
+                    st4_out(const_cast<float*>(byte_off(dst_w + (mi * 32 + (g4 + j) * 4) * (size_t)d.ldt, lane_off)), outv[j]);
+            }
+        }   // g4
         __builtin_amdgcn_wave_barrier();
 #ifdef SEP_PROF
         PROF_STAMP(10 + 4 * mi);
@@ -434,9 +507,6 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const sep_gemm_desc d) 
 constexpr int DK = 16;      // contraction rows per ring stage
 constexpr int NST = 4;      // ring depth of the weight-gradient kernel
 
-__device__ __forceinline__ const float* byte_off(const float* base, unsigned bytes) {
-    return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)bytes);
-}
 // s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier as BUILTINS: the compiler's waitcnt pass then knows every counter is zero
 // here and emits counted lgkmcnt(N) waits afterwards (behind an opaque asm it falls back to lgkmcnt(0) everywhere)
 __device__ __forceinline__ void wait_all_and_barrier() {
@@ -492,6 +562,10 @@ __device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
 //   wr == 0 waves of row tile 0 write it back for the weight-gradient GEMM and accumulate the PReLU slope gradient.
 // ======================================================================================
 constexpr int OMAXK = 768;
+#ifdef SEP_EXP_STAGGER
+__device__ int g_gemm_stagger = 0;
+__device__ unsigned g_cu_arrivals[4096];
+#endif
 
 template <bool AUX>
 struct __attribute__((aligned(16))) DirectSmem {
@@ -532,6 +606,20 @@ __global__ __launch_bounds__(256, (PRO == SEP_PRO_GLN_BWD ? 3 : PRO >= SEP_PRO_G
     const int nk = d.K / DK;
 #ifdef SEP_PROF
     const int prof_slot = bid == 8 ? 0 : bid == 1500 ? 1 : bid == 1501 ? 2 : bid == (int)gridDim.x - 9 ? 3 : -1;
+#endif
+#ifdef SEP_EXP_STAGGER
+    if (g_gemm_stagger > 0 && bid < 1024 && (int)gridDim.x > 1024) {
+        // arrival order of this workgroup on ITS compute unit -> phase 0..3 -> start delay of phase * (tile time / 4)
+        if (tid == 0) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((7 << 11) | (8 << 6) | 4);      // HW_ID[15:8]: CU_ID, SH_ID, SE_ID
+            const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);    // XCC_ID[3:0]
+            const unsigned arrival = atomicAdd(&g_cu_arrivals[((xcc & 15) << 8) | (hw & 255)], 1u);
+            const long long cycles = (long long)(arrival & 3) * nk * 2048 * g_gemm_stagger / 100;
+            const long long c0 = clock64();
+            while (clock64() - c0 < cycles) __builtin_amdgcn_s_sleep(16);
+        }
+        __syncthreads();
+    }
 #endif
     PROF_STAMP(0);
 #ifdef SEP_PROF
@@ -751,7 +839,14 @@ __global__ __launch_bounds__(256, (PRO == SEP_PRO_GLN_BWD ? 3 : PRO >= SEP_PRO_G
 #ifdef SEP_ABL_NO_EPI
     if (acc[0][0][0] + acc[0][1][3] + acc[1][0][5] + acc[1][1][7] == 123.456f) d.Y[tid] = 1.f;
 #else
-    gemm_epilogue<EF>(d, acc, b, m0, t0, wr, wc, lk, l31, tid, &sm.As[0][0], sm.red PROF_PASS);
+    // Launder the thread id: everything the epilogue derives from it (lane offsets, row pointers) would otherwise be
+    // hoisted above the main loop as loop-invariant and held in registers through it -- at 128 VGPRs that spilled INSIDE
+    // the loop (a scratch reload waits on vmcnt, i.e. on the DMA ring).
+    int etid = tid, eb = b, em0 = m0, et0 = t0;
+    asm volatile("" : "+v"(etid), "+s"(eb), "+s"(em0), "+s"(et0));
+    const int ewid = __builtin_amdgcn_readfirstlane(etid >> 6);
+    const int elane = etid & 63;
+    gemm_epilogue<EF>(d, acc, eb, em0, et0, ewid >> 1, ewid & 1, elane >> 5, elane & 31, etid, &sm.As[0][0], sm.red PROF_PASS);
 #endif
     PROF_STAMP(5);
     if (P_BWD && rt == 0) {
@@ -1259,12 +1354,22 @@ extern "C" int sep_pw_gemm(const sep_gemm_desc* d, sep_stream_t stream) {
                            (d->pro_mode < SEP_PRO_GLN || d->K <= OMAXK);
     SEP_REQUIRE(direct_ok || (d->K % BK == 0 && d->k_split % BK == 0), "sep_pw_gemm: the register-staged fallback (K=%d) needs K %% 32 == 0", d->K);
     if (direct_ok) {
+#ifdef SEP_EXP_STAGGER
+        static int stagger_set = [] {
+            const char* e = getenv("SEPK_STAGGER");
+            int v = e ? atoi(e) : 0;
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stagger), &v, sizeof(int));
+            return 1;
+        }();
+        (void)stagger_set;
+#endif
 #define SEP_LD(T, P, S, E) hipLaunchKernelGGL((pw_gemm_direct_kernel<T, P, S, E>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *d)
         // 1. the (operand form, prologue, split, epilogue) combinations of the Conv-TasNet step, epilogue flags compile-time
         const int ef = d->epi_flags, pm = d->pro_mode;
         const bool tr = d->trans_a != 0, sp = d->k_split != 0;
         bool done = true;
-        if (!tr && !sp && pm == SEP_PRO_NONE && ef == SEP_EPI_STATS_PRELU) SEP_LD(false, SEP_PRO_NONE, false, SEP_EPI_STATS_PRELU);              // TCN conv1
+        if (d->M % BM != 0) done = false;          // the specialised epilogues have no row predicate
+        else if (!tr && !sp && pm == SEP_PRO_NONE && ef == SEP_EPI_STATS_PRELU) SEP_LD(false, SEP_PRO_NONE, false, SEP_EPI_STATS_PRELU);              // TCN conv1
         else if (!tr && !sp && pm == SEP_PRO_GLN_PRELU && ef == SEP_EPI_RESIDUAL) SEP_LD(false, SEP_PRO_GLN_PRELU, false, SEP_EPI_RESIDUAL);     // heads
         else if (!tr && !sp && pm == SEP_PRO_GLN_PRELU && ef == 0) SEP_LD(false, SEP_PRO_GLN_PRELU, false, 0);                                   // last layer: skip head only
         else if (!tr && !sp && pm == SEP_PRO_PRELU && ef == SEP_EPI_SIGMOID) SEP_LD(false, SEP_PRO_PRELU, false, SEP_EPI_SIGMOID);               // mask
