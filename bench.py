@@ -155,9 +155,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # nccl = RCCL on ROCm (one rank per GPU).  SEPK_BENCH_BACKEND=gloo + SEPK_BENCH_ONE_GPU=1 exist only to exercise the
+        # multi-rank code path on a single-GPU box (all ranks on device 0, all-reduce through the host).
+        dist.init_process_group(os.environ.get("SEPK_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus {} but WORLD_SIZE {}".format(args.gpus, world), file=sys.stderr)
+    if os.environ.get("SEPK_BENCH_ONE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
