@@ -1204,10 +1204,19 @@ __global__ __launch_bounds__(512, 4) void pw_wgrad_direct_kernel(const sep_wgrad
         }
     };
 
+#ifdef SEP_PROF
+    const int prof_slot = (bid == 8 ? 0 : bid == 200 ? 1 : bid == 201 ? 2 : bid == (int)gridDim.x - 9 ? 3 : -1);
+#define WPROF(k) do { if (prof_slot >= 0 && lane == 0 && grp == 0) g_prof[prof_slot][wid][k] = clock64(); } while (0)
+#else
+#define WPROF(k) do { } while (0)
+#endif
+    WPROF(0);
     __syncthreads();                                              // mu/rstd table visible; BEFORE the first DMA so it drains nothing
     set_sample();
+    WPROF(1);
     if (nk > 0) issue(0);
     wait_all_and_barrier();
+    WPROF(2);
     if (nk > 1) issue(1);
     if (nk > 0) read_half(0, 0);
     for (int i = 0; i < nk_max; ++i) {
@@ -1235,45 +1244,53 @@ __global__ __launch_bounds__(512, 4) void pw_wgrad_direct_kernel(const sep_wgrad
         }
     }
 
-    // group 1 -> group 0 through LDS (the rings are dead now), then group 0 stores the slab
+    // The two groups hold partial sums of the same 128x128 tile.  Each keeps one 32-row half per wave (group g: mi = g),
+    // hands the other half to its partner through LDS (the rings are dead now) and stores its own: all eight waves
+    // share the exchange and the stores (first version: group 0 did everything, 34 k cycles of a 150 k-cycle workgroup).
+    WPROF(3);
     __syncthreads();
-    float* red = &sm.Gs[0][0][0];                                 // 16384 floats = 64 accumulators x 256 lanes
+    WPROF(4);
+    float* red = &sm.Gs[0][0][0];                                 // 2 x 8192 floats = 32 handed accumulators x 256 lanes per group
     const int tg = tid & 255;
-    if (grp == 1) {
+    auto hand_over = [&](f32x16 (&give)[2], const float bias_give, float* bias_slot) {
+        float* mine = red + grp * 8192;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) red[((mi * 2 + ni) * 16 + r) * 256 + tg] = acc[mi][ni][r];
-        sm.mu[tg] = bias_acc[0];
-        sm.rstd[tg] = bias_acc[1];
-    }
+            for (int r = 0; r < 16; ++r) mine[(ni * 16 + r) * 256 + tg] = give[ni][r];
+        bias_slot[tg] = bias_give;
+    };
+    if (grp == 0) hand_over(acc[1], bias_acc[1], sm.mu);           // wave-uniform branch, not 64 selects
+    else hand_over(acc[0], bias_acc[0], sm.rstd);
     __syncthreads();
-    if (grp == 1) return;
-    float* out = d.partial + (size_t)s * d.M * d.N;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    WPROF(5);
+    auto finish = [&](f32x16 (&keep)[2], const float bias_keep, const float* bias_slot, const int mi) {
+        const float* theirs = red + (1 - grp) * 8192;
+        float* out = d.partial + (size_t)s * d.M * d.N;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 const int col = n0 + wc * 64 + ni * 32 + l31;
-                const float v = acc[mi][ni][r] + red[((mi * 2 + ni) * 16 + r) * 256 + tg];
+                const float v = keep[ni][r] + theirs[(ni * 16 + r) * 256 + tg];
                 if (row < d.M && col < d.N) out[(size_t)row * d.N + col] = v;
             }
         }
-    if (do_bias) {
-        bias_acc[0] += sm.mu[tg];
-        bias_acc[1] += sm.rstd[tg];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const float tot = bias_acc[mi] + __shfl_xor(bias_acc[mi], 32, 64);     // the two lane halves own different frames
+        if (do_bias) {
+            const float mine_b = bias_keep + bias_slot[tg];
+            const float tot = mine_b + __shfl_xor(mine_b, 32, 64);     // the two lane halves own different frames
             const int row = m0 + wr * 64 + mi * 32 + l31;
             if (lk == 0 && row < d.M) d.partial_bias[(size_t)s * d.M + row] = tot;
         }
-    }
+    };
+    if (grp == 0) finish(acc[0], bias_acc[0], sm.rstd, 0);
+    else finish(acc[1], bias_acc[1], sm.mu, 1);
+#ifdef SEP_PROF
+    __builtin_amdgcn_s_waitcnt(0x0070);
+#endif
+    WPROF(6);
+#undef WPROF
 }
 
 // ======================================================================================
