@@ -60,3 +60,50 @@ class FusedTrainStep:
         K.adam_step(self.flat, self.gflat, self.m, self.v, self.sqnorm, n, self.lr, self.betas[0], self.betas[1], self.eps,
                     self.weight_decay, float(self.max_norm or 0.0), 1.0 / self.world, self.step_count)
         return loss.detach()
+
+    # ---- optimizer state in torch.optim.Adam's state_dict layout (checkpoint interchange with the reference's
+    #      driver.py:208-226 / 51-68: `optim_dict`) ---------------------------------------------------------
+    def _spans(self):
+        base = self.flat.data_ptr()
+        spans = []
+        for p in self.model.parameters():
+            off = (p.data_ptr() - base) // self.flat.element_size()
+            if off < 0 or off + p.numel() > self.flat.numel():
+                raise RuntimeError("parameter is not a view of the flat buffer")
+            spans.append((off, p.numel(), tuple(p.shape)))
+        return spans
+
+    def optim_state_dict(self):
+        state = {}
+        for i, (off, n, shape) in enumerate(self._spans()):
+            state[i] = {"step": torch.tensor(float(self.step_count)),
+                        "exp_avg": self.m[off:off + n].detach().reshape(shape).cpu().clone(),
+                        "exp_avg_sq": self.v[off:off + n].detach().reshape(shape).cpu().clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "params": list(range(len(state)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optim_state_dict(self, sd):
+        spans = self._spans()
+        groups = sd.get("param_groups", [])
+        if groups:
+            g = groups[0]
+            self.lr = g.get("lr", self.lr)
+            self.betas = tuple(g.get("betas", self.betas))
+            self.eps = g.get("eps", self.eps)
+            self.weight_decay = g.get("weight_decay", self.weight_decay)
+        state = sd.get("state", {})
+        steps = []
+        for i, (off, n, _) in enumerate(spans):
+            st = state.get(i, state.get(str(i)))
+            if st is None:
+                continue
+            self.m[off:off + n].copy_(st["exp_avg"].reshape(-1).to(self.m.device, self.m.dtype))
+            self.v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1).to(self.v.device, self.v.dtype))
+            steps.append(int(float(st["step"])))
+        if steps:
+            if len(set(steps)) != 1:
+                raise ValueError("per-parameter Adam step counts differ; the fused step keeps one")
+            self.step_count = steps[0]
+
