@@ -7,6 +7,7 @@
 // Reference arithmetic replaced (under /root/reference/src): models/filterbank.py:205-251 (Encoder/Decoder),
 // models/conv_tasnet.py:145-169 (pad, mask*w, crop), models/tdcn.py:113-132,177-186 (PReLU -> gLN -> zero pad ->
 // depthwise conv -> PReLU), modules/norm.py:11-35 (gLN = GroupNorm(1, C)).
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace {
@@ -168,6 +169,77 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
             atomicAdd(st, x0);
             atomicAdd(st + 1, x1);
         }
+    }
+}
+
+// =====================================================================================
+// Depthwise dilated conv forward, direct form (dilation 1, 2 or a multiple of 4 -- every power of two, i.e. every
+// layer of the TCN): one workgroup = one (b, c) row; a thread produces float4s of output from three float4 loads
+// (t-d, t, t+d; for d < 4 the two neighbouring float4s and a register shuffle).  The neighbours are another thread's
+// centre, so two of the three loads hit L1/L2; nothing goes through LDS and there is no barrier before the stores.
+// DM: 0 -> d % 4 == 0, 1 -> d == 1, 2 -> d == 2.
+// =====================================================================================
+template <int DM>
+__global__ __launch_bounds__(256) void dwconv_fwd_direct_kernel(const float* __restrict__ a, const double* __restrict__ stats1,
+                                                                const float* __restrict__ gamma1, const float* __restrict__ beta1,
+                                                                const float* __restrict__ alpha1, const float* __restrict__ wd,
+                                                                const float* __restrict__ bd, const float* __restrict__ alpha2,
+                                                                float* __restrict__ z, double* __restrict__ stats2, int C, int T,
+                                                                int ldt, int d, float eps) {
+    __shared__ double red[4];
+    const int row = blockIdx.x;               // b * C + c
+    const int b = row / C, c = row % C;
+    float mu, rstd;
+    gln_mu_rstd(stats1 + (size_t)b * SEP_STATS_SLOTS * 2, (double)C * T, eps, mu, rstd);
+    const float a1 = alpha1[0], a2 = alpha2[0];
+    const float sc = gamma1[c] * rstd, sh = beta1[c] - mu * sc;
+    const float w0 = wd[c * 3 + 0], w1 = wd[c * 3 + 1], w2 = wd[c * 3 + 2], bb = bd[c];
+    const float* arow = a + (size_t)row * ldt;
+    float* zrow = z + (size_t)row * ldt;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float s = 0.f, ss = 0.f;
+    auto norm = [&](float x, int t) { return (t >= 0 && t < T) ? fmaf(prelu_f(x, a1), sc, sh) : 0.f; };
+    for (int q = threadIdx.x; q < ldt / 4; q += 256) {
+        const int t = 4 * q;
+        const float4 cc = ld4(arow + t);
+        float lft[4], rgt[4];
+        if (DM == 0) {
+            const float4 l4 = t - d >= 0 ? ld4(arow + t - d) : zero4;
+            const float4 r4 = t + d < ldt ? ld4(arow + t + d) : zero4;
+            lft[0] = l4.x; lft[1] = l4.y; lft[2] = l4.z; lft[3] = l4.w;
+            rgt[0] = r4.x; rgt[1] = r4.y; rgt[2] = r4.z; rgt[3] = r4.w;
+        } else {
+            const float4 l4 = t >= 4 ? ld4(arow + t - 4) : zero4;
+            const float4 r4 = t + 4 < ldt ? ld4(arow + t + 4) : zero4;
+            if (DM == 1) {
+                lft[0] = l4.w; lft[1] = cc.x; lft[2] = cc.y; lft[3] = cc.z;
+                rgt[0] = cc.y; rgt[1] = cc.z; rgt[2] = cc.w; rgt[3] = r4.x;
+            } else {
+                lft[0] = l4.z; lft[1] = l4.w; lft[2] = cc.x; lft[3] = cc.y;
+                rgt[0] = cc.z; rgt[1] = cc.w; rgt[2] = r4.x; rgt[3] = r4.y;
+            }
+        }
+        const float ce[4] = {cc.x, cc.y, cc.z, cc.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int te = t + e;
+            float zz = 0.f;
+            if (te < T) {
+                zz = bb + w0 * norm(lft[e], te - d) + w1 * norm(ce[e], te) + w2 * norm(rgt[e], te + d);
+                const float u = prelu_f(zz, a2);
+                s += u; ss = fmaf(u, u, ss);
+            }
+            o[e] = zz;
+        }
+        st4(zrow + t, make_float4(o[0], o[1], o[2], o[3]));
+    }
+    const double ds = block_sum_256<double>((double)s, red);
+    const double dss = block_sum_256<double>((double)ss, red);
+    if (threadIdx.x == 0) {
+        double* st = stats2 + ((size_t)b * SEP_STATS_SLOTS + (blockIdx.x & (SEP_STATS_SLOTS - 1))) * 2;
+        atomicAdd(st, ds);
+        atomicAdd(st + 1, dss);
     }
 }
 
@@ -716,6 +788,15 @@ extern "C" int sep_dwconv_fwd(const float* a, const double* stats1, const float*
     SEP_REQUIRE(a && stats1 && gamma1 && beta1 && alpha1 && wd && bd && alpha2 && z && stats2, "sep_dwconv_fwd: null pointer");
     SEP_REQUIRE(B > 0 && C > 0 && T > 0 && ldt % 128 == 0 && ldt >= T, "sep_dwconv_fwd: bad sizes");
     SEP_REQUIRE(dilation >= 1 && dilation <= 4096, "sep_dwconv_fwd: dilation %d out of range [1, 4096]", dilation);
+    static const bool force_lds = getenv("SEPK_DWCONV_LDS") != nullptr;
+    if (!force_lds && (dilation == 1 || dilation == 2 || dilation % 4 == 0) && (long)B * C <= 0x7fffffffL) {
+        const dim3 grid((unsigned)((long)B * C));
+        if (dilation == 1) hipLaunchKernelGGL((dwconv_fwd_direct_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, a, stats1, gamma1, beta1, alpha1, wd, bd, alpha2, z, stats2, C, T, ldt, dilation, eps);
+        else if (dilation == 2) hipLaunchKernelGGL((dwconv_fwd_direct_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, a, stats1, gamma1, beta1, alpha1, wd, bd, alpha2, z, stats2, C, T, ldt, dilation, eps);
+        else hipLaunchKernelGGL((dwconv_fwd_direct_kernel<0>), grid, dim3(256), 0, (hipStream_t)stream, a, stats1, gamma1, beta1, alpha1, wd, bd, alpha2, z, stats2, C, T, ldt, dilation, eps);
+        SEP_CHECK_LAUNCH("sep_dwconv_fwd");
+        return 0;
+    }
     const int dpad = (dilation + 3) & ~3;
     const size_t smem = 4 * (size_t)(DW_TT + 2 * dpad) * sizeof(float);
     const long total = (long)B * C * ceil_div(ldt, DW_TT);
