@@ -342,6 +342,116 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(
 }
 
 // =====================================================================================
+// Same backward, one workgroup per (b, c) ROW: dz and u1 of the whole row live in LDS (2 x ldt floats), so there is no
+// halo to re-load or re-compute (the 1024-frame tiles of the kernel above re-do 25 % of the row at dilation 128), every
+// global access is a float4 and a thread has twelve of them in flight.  ALIGNED: d % 4 == 0 (ds_read_b128 neighbours).
+// Writes the row totals into tile 0 of rowpart and zeros into the other tiles (the finalize kernel sums over tiles).
+// =====================================================================================
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
+    const float* __restrict__ dv2, const float* __restrict__ z, const float* __restrict__ a,
+    const double* __restrict__ stats1, const float* __restrict__ gamma1, const float* __restrict__ beta1,
+    const float* __restrict__ alpha1, const double* __restrict__ stats2, const float* __restrict__ gamma2,
+    const float* __restrict__ alpha2, const float* __restrict__ bsum2, const float* __restrict__ wd,
+    float* __restrict__ dv1, float* __restrict__ rowpart, int C, int T, int ldt, int d, float eps) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float part[4][8];
+    float* dzs = lds;
+    float* us = lds + ldt;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int row = blockIdx.x;
+    const int b = row / C, c = row % C;
+    float mu1, r1, mu2, r2;
+    gln_mu_rstd(stats1 + (size_t)b * SEP_STATS_SLOTS * 2, (double)C * T, eps, mu1, r1);
+    gln_mu_rstd(stats2 + (size_t)b * SEP_STATS_SLOTS * 2, (double)C * T, eps, mu2, r2);
+    const float a1 = alpha1[0], a2 = alpha2[0];
+    const float sc1 = gamma1[c] * r1, sh1 = beta1[c] - mu1 * sc1;
+    const float g2 = gamma2[c];
+    const float mg = bsum2[2 * b], mgx = bsum2[2 * b + 1];
+    const size_t rowoff = (size_t)row * ldt;
+    float q_dal = 0.f;
+    for (int q = threadIdx.x; q < ldt / 4; q += 256) {
+        const int tp = 4 * q;
+        const float4 gv = ld4(dv2 + rowoff + tp);
+        const float4 zv = ld4(z + rowoff + tp);
+        const float4 av = ld4(a + rowoff + tp);
+        const float g4[4] = {gv.x, gv.y, gv.z, gv.w};
+        const float z4[4] = {zv.x, zv.y, zv.z, zv.w};
+        const float a4[4] = {av.x, av.y, av.z, av.w};
+        float dzv[4], uv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            dzv[e] = 0.f; uv[e] = 0.f;
+            if (tp + e < T) {
+                const float u2 = prelu_f(z4[e], a2);
+                const float xh = (u2 - mu2) * r2;
+                const float du2 = r2 * (g2 * g4[e] - mg - xh * mgx);
+                dzv[e] = du2 * prelu_grad(z4[e], a2);
+                uv[e] = prelu_f(a4[e], a1);
+                if (z4[e] <= 0.f) q_dal = fmaf(du2, z4[e], q_dal);
+            }
+        }
+        st4(dzs + tp, make_float4(dzv[0], dzv[1], dzv[2], dzv[3]));
+        st4(us + tp, make_float4(uv[0], uv[1], uv[2], uv[3]));
+    }
+    __syncthreads();
+    const float w0 = wd[c * 3 + 0], w1 = wd[c * 3 + 1], w2 = wd[c * 3 + 2];
+    float* orow = dv1 + rowoff;
+    float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f, q4 = 0.f, q5 = 0.f;
+    for (int q = threadIdx.x; q < ldt / 4; q += 256) {
+        const int t = 4 * q;
+        const float4 dzc4 = ld4(dzs + t), uc4 = ld4(us + t);
+        float dzm[4], dzp[4], um[4], up[4];
+        if (ALIGNED) {
+            const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 m1 = t - d >= 0 ? ld4(dzs + t - d) : zero4, p1 = t + d < ldt ? ld4(dzs + t + d) : zero4;
+            const float4 m2 = t - d >= 0 ? ld4(us + t - d) : zero4, p2 = t + d < ldt ? ld4(us + t + d) : zero4;
+            dzm[0] = m1.x; dzm[1] = m1.y; dzm[2] = m1.z; dzm[3] = m1.w;
+            dzp[0] = p1.x; dzp[1] = p1.y; dzp[2] = p1.z; dzp[3] = p1.w;
+            um[0] = m2.x; um[1] = m2.y; um[2] = m2.z; um[3] = m2.w;
+            up[0] = p2.x; up[1] = p2.y; up[2] = p2.z; up[3] = p2.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int tm = t + e - d, tq = t + e + d;
+                dzm[e] = tm >= 0 ? dzs[tm] : 0.f; um[e] = tm >= 0 ? us[tm] : 0.f;
+                dzp[e] = tq < ldt ? dzs[tq] : 0.f; up[e] = tq < ldt ? us[tq] : 0.f;
+            }
+        }
+        const float dzc[4] = {dzc4.x, dzc4.y, dzc4.z, dzc4.w}, uc[4] = {uc4.x, uc4.y, uc4.z, uc4.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int te = t + e;
+            float dv = 0.f;
+            if (te < T) {
+                // dv1[t] = sum_k w[k] * dz[t - (k-1) d];  dz is zero outside [0, T) by construction
+                dv = w0 * dzp[e] + w1 * dzc[e] + w2 * dzm[e];
+                // v1 = gLN1(u1) inside [0,T), literal zero outside (padding is applied after the norm)
+                const float vm = (te - d >= 0) ? fmaf(um[e], sc1, sh1) : 0.f;
+                const float v0 = fmaf(uc[e], sc1, sh1);
+                const float vp = (te + d < T) ? fmaf(up[e], sc1, sh1) : 0.f;
+                q0 += dv; q1 = fmaf(dv, uc[e], q1);
+                q2 += dzc[e]; q3 = fmaf(dzc[e], vm, q3); q4 = fmaf(dzc[e], v0, q4); q5 = fmaf(dzc[e], vp, q5);
+            }
+            o[e] = dv;
+        }
+        st4(orow + t, make_float4(o[0], o[1], o[2], o[3]));
+    }
+    q0 = wave_sum(q0); q1 = wave_sum(q1); q2 = wave_sum(q2); q3 = wave_sum(q3);
+    q4 = wave_sum(q4); q5 = wave_sum(q5); q_dal = wave_sum(q_dal);
+    if (lane == 0) {
+        part[wv][0] = q0; part[wv][1] = q1; part[wv][2] = q2; part[wv][3] = q3;
+        part[wv][4] = q4; part[wv][5] = q5; part[wv][6] = q_dal; part[wv][7] = 0.f;
+    }
+    __syncthreads();
+    const int ntile = (ldt + DW_TT - 1) / DW_TT;
+    float* rp = rowpart + (size_t)row * ntile * 8;
+    for (int i = threadIdx.x; i < ntile * 8; i += 256)
+        rp[i] = i < 8 ? (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]) : 0.f;
+}
+
+// =====================================================================================
 // gLN backward, second stage, in two small kernels.
 //  rows:   one WAVE per (b, c) row reduces that row's per-tile partials (nq in {2, 8}) and writes
 //          pbeta[b][c] = R1, pgamma[b][c] = r_b (R2 - mu_b R1), nq == 8: pextra[b] = [db[C] | dw[C][3]] and
@@ -812,6 +922,15 @@ extern "C" int sep_dwconv_bwd(const float* dv2, const float* z, const float* a, 
     SEP_REQUIRE(dv2 && z && a && stats1 && gamma1 && beta1 && alpha1 && stats2 && gamma2 && alpha2 && bsum2 && wd && dv1 && rowpart, "sep_dwconv_bwd: null pointer");
     SEP_REQUIRE(B > 0 && C > 0 && T > 0 && ldt % 128 == 0 && ldt >= T, "sep_dwconv_bwd: bad sizes");
     SEP_REQUIRE(dilation >= 1 && dilation <= 2048, "sep_dwconv_bwd: dilation %d out of range [1, 2048]", dilation);
+    static const bool force_tiles = getenv("SEPK_DWCONV_LDS") != nullptr;
+    if (!force_tiles && ldt <= 7680 && (long)B * C <= 0x7fffffffL) {        // the row (2 x ldt floats) fits 60 KiB of LDS
+        const size_t rsmem = 2 * (size_t)ldt * sizeof(float);
+        const dim3 grid((unsigned)((long)B * C));
+        if (dilation % 4 == 0) hipLaunchKernelGGL((dwconv_bwd_row_kernel<true>), grid, dim3(256), rsmem, (hipStream_t)stream, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bsum2, wd, dv1, rowpart, C, T, ldt, dilation, eps);
+        else hipLaunchKernelGGL((dwconv_bwd_row_kernel<false>), grid, dim3(256), rsmem, (hipStream_t)stream, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bsum2, wd, dv1, rowpart, C, T, ldt, dilation, eps);
+        SEP_CHECK_LAUNCH("sep_dwconv_bwd");
+        return 0;
+    }
     const int dpad = (dilation + 3) & ~3;
     const size_t smem = 4 * 2 * (size_t)(DW_TT + 2 * dpad) * sizeof(float);
     const long total = (long)B * C * ceil_div(ldt, DW_TT);
