@@ -551,11 +551,15 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const float* __restric
     extern __shared__ __attribute__((aligned(16))) float ys[];     // [256][LC+1]
     const int LC = Cout * L;
     const int R = L / S;
-    const int FB = 256 - (R - 1);
+    // LC_REG > 0: a workgroup owns 64-(R-1) frames and its four waves split the basis rows (2080 workgroups at paper-best;
+    // the 256-frame mapping gave 544 = two per CU, each thread a serial loop of 512 dependent load pairs: 1.6 TB/s)
+    const int FW = LC_REG > 0 ? 64 : 256;
+    const int FB = FW - (R - 1);
     const int bs = blockIdx.y;            // b*n_src + s
     const int b = bs / n_src;
     const int f0 = blockIdx.x * FB;
-    const int i = threadIdx.x;
+    const int i = LC_REG > 0 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+    const int wv = threadIdx.x >> 6;
     const int f = f0 - (R - 1) + i;
     const bool fvalid = f >= 0 && f < F;
     const bool owner = i >= R - 1 && f < ldt;       // this block owns latent[f]
@@ -568,7 +572,9 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const float* __restric
         float acc[LC_REG > 0 ? LC_REG : 1];
 #pragma unroll
         for (int q = 0; q < LC_REG; ++q) acc[q] = 0.f;
-        for (int n = 0; n < N; ++n) {
+        const int nper = (N + 3) / 4;
+        const int n_lo = wv * nper, n_hi = n_lo + nper < N ? n_lo + nper : N;
+        for (int n = n_lo; n < n_hi; ++n) {
             float wh = wrow[(size_t)n * ldt + fc] * mrow[(size_t)n * ldt + fc];
             if (!fvalid) wh = 0.f;
             if (lrow && owner) lrow[(size_t)n * ldt + f] = wh;
@@ -577,7 +583,7 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const float* __restric
             for (int q = 0; q < LC_REG; ++q) acc[q] = fmaf(wh, Dn[q], acc[q]);
         }
 #pragma unroll
-        for (int q = 0; q < LC_REG; ++q) ys[i * (LC + 1) + q] = acc[q];
+        for (int q = 0; q < LC_REG; ++q) ys[(wv * 64 + i) * (LC + 1) + q] = acc[q];
     } else {
         for (int q0 = 0; q0 < LC; q0 += 16) {
             float acc[16];
@@ -600,13 +606,17 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const float* __restric
     __syncthreads();
     // overlap-add: padded sample tp = S*fo + k0 gets frames fo - r at tap k0 + r*S
     const int nsamp = FB * S;
-    for (int j = i; j < nsamp * Cout; j += 256) {
+    for (int j = threadIdx.x; j < nsamp * Cout; j += 256) {
         const int c = j / nsamp, o = j % nsamp;
         const int fo = o / S, k0 = o % S;            // frame offset inside the block's owned range
         const int tau = S * (f0 + fo) + k0 - pad_left;
         if (tau < 0 || tau >= Tout) continue;
         float v = 0.f;
-        for (int r = 0; r < R; ++r) v += ys[(fo + (R - 1) - r) * (LC + 1) + c * L + k0 + r * S];
+        for (int r = 0; r < R; ++r) {
+            const int cell = (fo + (R - 1) - r) * (LC + 1) + c * L + k0 + r * S;
+            if (LC_REG > 0) v += (ys[cell] + ys[64 * (LC + 1) + cell]) + (ys[128 * (LC + 1) + cell] + ys[192 * (LC + 1) + cell]);
+            else v += ys[cell];
+        }
         est[((size_t)bs * Cout + c) * Tout + tau] = v;
     }
 }
@@ -626,6 +636,10 @@ __global__ __launch_bounds__(256) void decoder_bwd_kernel(const float* __restric
     const bool fvalid = f < F;
     const float* wrow = w + (size_t)b * N * ldt;
     float* dwrow = dwm + (size_t)b * N * ldt;
+    // basis rows are independent here: blockIdx.z splits them so that the grid fills the chip (16 x B blocks do not)
+    const int nper = (N + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int n_lo = (int)blockIdx.z * nper;
+    const int n_hi = n_lo + nper < N ? n_lo + nper : N;
 
     auto dsample = [&](int s, int q) -> float {
         const int c = q / L, k = q % L;
@@ -639,7 +653,7 @@ __global__ __launch_bounds__(256) void decoder_bwd_kernel(const float* __restric
         for (int s = 0; s < NS_REG; ++s)
 #pragma unroll
             for (int q = 0; q < LC_REG; ++q) ds[s][q] = (s < n_src) ? dsample(s, q) : 0.f;
-        for (int n = 0; n < N; ++n) {
+        for (int n = n_lo; n < n_hi; ++n) {
             const float wv = wrow[(size_t)n * ldt + f];
             const float* Dn = D + (size_t)n * LC;
             float dacc = 0.f;
@@ -658,7 +672,7 @@ __global__ __launch_bounds__(256) void decoder_bwd_kernel(const float* __restric
             dwrow[(size_t)n * ldt + f] = fvalid ? dacc : 0.f;
         }
     } else {
-        for (int n = 0; n < N; ++n) {
+        for (int n = n_lo; n < n_hi; ++n) {
             const float wv = wrow[(size_t)n * ldt + f];
             const float* Dn = D + (size_t)n * LC;
             float dacc = 0.f;
@@ -973,7 +987,8 @@ extern "C" int sep_decoder_fwd(const float* w, const float* m, const float* D, f
     const int LC = Cout * L;
     SEP_REQUIRE(LC <= 144, "sep_decoder_fwd: Cout*L=%d too large for the LDS frame buffer", LC);
     SEP_REQUIRE((long)B * n_src <= 65535, "sep_decoder_fwd: B*n_src too large");
-    const int R = L / S, FB = 256 - (R - 1);
+    const int R = L / S, FB = (LC == 16 ? 64 : 256) - (R - 1);
+    SEP_REQUIRE(FB > 0, "sep_decoder_fwd: kernel_size / stride too large");
     dim3 grid(ceil_div(ldt + R - 1, FB), B * n_src);
     const size_t smem = (size_t)256 * (LC + 1) * sizeof(float);
     if (LC == 16)
@@ -989,7 +1004,8 @@ extern "C" int sep_decoder_bwd(const float* d_est, const float* w, const float* 
                                sep_stream_t stream) {
     SEP_REQUIRE(d_est && w && m && D && dpre && dwm, "sep_decoder_bwd: null pointer");
     SEP_REQUIRE(B <= 65535, "sep_decoder_bwd: B too large");
-    dim3 grid(ceil_div(ldt, 256), B);
+    const int nz = N >= 64 ? 8 : 1;                               // 2048 workgroups at paper-best instead of 256
+    dim3 grid(ceil_div(ldt, 256), B, nz);
     const int LC = Cout * L;
     if (LC == 16 && n_src <= 2)
         hipLaunchKernelGGL((decoder_bwd_kernel<16, 2>), grid, dim3(256), 0, (hipStream_t)stream, d_est, w, m, D, dpre, dwm, n_src, N, Cout, L, S, F, ldt, Tout, pad_left);
