@@ -120,6 +120,16 @@ def test_gemm_gln_prologue_and_stats_epilogue():
                              epi_alpha=alpha, epi_stats=zstats(B)))
 
 
+@pytest.mark.parametrize("M,T", [(256, 333), (128, 128), (192, 200)])
+def test_gemm_stats_epilogue_specialised_and_generic(M, T):
+    """TCN conv1 form (no prologue, PReLU statistics): M % 128 == 0 takes the compile-time-flag instantiation without row
+    predicates, M = 192 the run-time-flag one; T off the 128 grid exercises the column pre-mask of the edge tile."""
+    B, K = 2, 64
+    ldt, X, A, bias = _gemm_common(B, M, K, T)
+    both("pw_gemm", [], dict(B=B, M=M, K=K, T=T, ldt=ldt, A=A, X=X, Y=nan(B, M, ldt), bias=bias, epi_flags=EPI_STATS_PRELU,
+                             epi_alpha=torch.tensor([0.25]), epi_stats=zstats(B), eps=1e-12))
+
+
 def test_gemm_packed_heads_residual_accumulate():
     """[Wo;Ws] as one operand: rows < m_split -> Y (+residual), rows >= m_split -> Y2 (+=)."""
     B, Bn, Sc, H, T = 2, 128, 128, 256, 500
