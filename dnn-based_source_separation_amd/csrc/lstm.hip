@@ -1,0 +1,222 @@
+// Recurrent sweeps of one LSTM direction for the dual-path RNN (reference src/models/dprnn.py:9-148: nn.LSTM inside
+// IntraChunkRNN / InterChunkRNN).  The input projection x W_ih^T + b and the three weight-gradient products are plain
+// library GEMMs on the host side; what cannot be a library call is the time recurrence, and that is what lives here:
+//
+//   forward :  a_t = xg_t + W_hh h_{t-1};  i,f,o = sigmoid, g = tanh;  c_t = f c_{t-1} + i g;  h_t = o tanh(c_t)
+//   backward:  reverse sweep carrying (dh, dc); emits the pre-activation gate gradients da_t (= d xg_t)
+//
+// One workgroup = 16 sequences x the whole hidden state, persistent over all L steps.  W_hh (4H x H fp32 = 256 KiB at
+// H = 128) does not fit LDS; it lives in REGISTERS: H/16 waves, wave w owns hidden units [16w, 16w+16) and holds the
+// 64 x H slice [i;f;g;o rows of its units] as MFMA A-fragments (4 x H/4 VGPRs).  Per step a wave runs 4 x H/4
+// v_mfma_f32_16x16x4_f32 against h_{t-1} (B operand, 8 KiB in LDS, double-buffered), and the C layout leaves all four
+// gates of (unit, sequence) in ONE lane, so the cell update is register-local; only h_t crosses waves (one barrier per
+// step).  The backward sweep is the mirror image with W_hh^T slices and the 4H x 16 gate-gradient panel in LDS.
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float tanh_f(float x) {
+    // tanh(x) = 1 - 2 / (1 + e^{2x}); exp2 overflow -> inf -> rcp 0 -> 1, underflow -> 0 -> -1
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
+__device__ __forceinline__ float4 ld4g(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4g(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+constexpr int LSTM_NS = 16;     // sequences per workgroup = N of the 16x16x4 MFMA
+
+template <int H>
+__global__ __launch_bounds__(H * 4) void lstm_fwd_kernel(const float* __restrict__ xg, const float* __restrict__ whh,
+                                                         float* __restrict__ hout, float* __restrict__ gates,
+                                                         float* __restrict__ cstate, int nseq, int L, int reverse) {
+    constexpr int KS = H / 4;                  // MFMA k-steps per gate block
+    __shared__ float hs[2][H * LSTM_NS];       // h_{t-1} / h_t as [unit][sequence]
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, q = lane >> 4;    // MFMA column (sequence) / row group
+    const int seq0 = blockIdx.x * LSTM_NS;
+    const int seq = seq0 + j;
+    const bool live = seq < nseq;
+    const int seqc = live ? seq : nseq - 1;
+    const int u0 = 16 * w + 4 * q;             // this lane owns hidden units u0 .. u0+3 of sequence `seq`
+
+    // A fragments: wf[g][ks] = W_hh[g*H + 16w + (lane & 15)][4 ks + (lane >> 4)]
+    float wf[4][KS];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wf[g][ks] = whh[(size_t)(g * H + 16 * w + j) * H + 4 * ks + q];
+    for (int i = threadIdx.x; i < H * LSTM_NS; i += H * 4) hs[0][i] = 0.f;
+    float c[4] = {0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    const size_t seq_base = (size_t)seqc * L;
+    auto load_x = [&](int t, float4 (&dst)[4]) {
+        const float* p = xg + (seq_base + t) * 4 * H + u0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dst[g] = ld4g(p + g * H);
+    };
+    float4 xc[4], xn[4];
+    load_x(reverse ? L - 1 : 0, xc);
+    for (int step = 0; step < L; ++step) {
+        const int t = reverse ? L - 1 - step : step;
+        const int cur = step & 1;
+        if (step + 1 < L) load_x(reverse ? t - 1 : t + 1, xn);          // next step's projection, in flight under the MFMAs
+        f32x4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* hp = hs[cur];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const float b = hp[(4 * ks + q) * LSTM_NS + j];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[g][ks], b, acc[g], 0, 0, 0);
+        }
+        const float xi[4] = {xc[0].x, xc[0].y, xc[0].z, xc[0].w}, xf[4] = {xc[1].x, xc[1].y, xc[1].z, xc[1].w};
+        const float xgg[4] = {xc[2].x, xc[2].y, xc[2].z, xc[2].w}, xo[4] = {xc[3].x, xc[3].y, xc[3].z, xc[3].w};
+        float gi[4], gf[4], gg[4], go[4], hn[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            gi[r] = sigmoid_f(acc[0][r] + xi[r]);
+            gf[r] = sigmoid_f(acc[1][r] + xf[r]);
+            gg[r] = tanh_f(acc[2][r] + xgg[r]);
+            go[r] = sigmoid_f(acc[3][r] + xo[r]);
+            c[r] = fmaf(gf[r], c[r], gi[r] * gg[r]);
+            hn[r] = go[r] * tanh_f(c[r]);
+            hs[cur ^ 1][(u0 + r) * LSTM_NS + j] = hn[r];
+        }
+        if (live) {
+            const size_t o = seq_base + t;
+            st4g(hout + o * H + u0, make_float4(hn[0], hn[1], hn[2], hn[3]));
+            if (gates) {
+                float* gp = gates + o * 4 * H + u0;
+                st4g(gp, make_float4(gi[0], gi[1], gi[2], gi[3]));
+                st4g(gp + H, make_float4(gf[0], gf[1], gf[2], gf[3]));
+                st4g(gp + 2 * H, make_float4(gg[0], gg[1], gg[2], gg[3]));
+                st4g(gp + 3 * H, make_float4(go[0], go[1], go[2], go[3]));
+            }
+            if (cstate) st4g(cstate + o * H + u0, make_float4(c[0], c[1], c[2], c[3]));
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xc[g] = xn[g];
+        __syncthreads();                       // h_t complete in hs[cur^1]; everyone is done reading hs[cur]
+    }
+}
+
+// Reverse sweep.  dh_out[t] is the gradient arriving at h_t from above; (dhr, dc) is what flows back from step t+1.
+template <int H>
+__global__ __launch_bounds__(H * 4) void lstm_bwd_kernel(const float* __restrict__ dhout, const float* __restrict__ gates,
+                                                         const float* __restrict__ cstate, const float* __restrict__ whh,
+                                                         float* __restrict__ dxg, int nseq, int L, int reverse) {
+    constexpr int KS = 4 * H / 4;              // k-steps over the 4H gate rows
+    __shared__ float das[4 * H * LSTM_NS];     // d(pre-activation) of the current step as [gate row][sequence]
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, q = lane >> 4;
+    const int seq = blockIdx.x * LSTM_NS + j;
+    const bool live = seq < nseq;
+    const int seqc = live ? seq : nseq - 1;
+    const int u0 = 16 * w + 4 * q;
+
+    // A fragments of W_hh^T: wt[ks] = W_hh[4 ks + (lane >> 4)][16 w + (lane & 15)]   (rows = this wave's hidden units)
+    float wt[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wt[ks] = whh[(size_t)(4 * ks + q) * H + 16 * w + j];
+    float dhr[4] = {0.f, 0.f, 0.f, 0.f}, dc[4] = {0.f, 0.f, 0.f, 0.f};
+    const size_t seq_base = (size_t)seqc * L;
+
+    for (int step = 0; step < L; ++step) {
+        const int t = reverse ? step : L - 1 - step;               // the forward sweep's LAST step first
+        const int tprev = reverse ? t + 1 : t - 1;                 // the step that fed c_{t-1}
+        const bool has_prev = tprev >= 0 && tprev < L;
+        const size_t o = seq_base + t;
+        const float4 dho = ld4g(dhout + o * H + u0);
+        const float* gp = gates + o * 4 * H + u0;
+        const float4 vi = ld4g(gp), vf = ld4g(gp + H), vg = ld4g(gp + 2 * H), vo = ld4g(gp + 3 * H);
+        const float4 vc = ld4g(cstate + o * H + u0);
+        const float4 vcp = has_prev ? ld4g(cstate + (seq_base + tprev) * H + u0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float dh4[4] = {dho.x, dho.y, dho.z, dho.w};
+        const float gi[4] = {vi.x, vi.y, vi.z, vi.w}, gf[4] = {vf.x, vf.y, vf.z, vf.w};
+        const float gg[4] = {vg.x, vg.y, vg.z, vg.w}, go[4] = {vo.x, vo.y, vo.z, vo.w};
+        const float cc[4] = {vc.x, vc.y, vc.z, vc.w}, cp[4] = {vcp.x, vcp.y, vcp.z, vcp.w};
+        float dai[4], daf[4], dag[4], dao[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float dh = dh4[r] + dhr[r];
+            const float tc = tanh_f(cc[r]);
+            const float dcc = fmaf(dh * go[r], 1.f - tc * tc, dc[r]);
+            dao[r] = dh * tc * go[r] * (1.f - go[r]);
+            dai[r] = dcc * gg[r] * gi[r] * (1.f - gi[r]);
+            daf[r] = dcc * cp[r] * gf[r] * (1.f - gf[r]);
+            dag[r] = dcc * gi[r] * (1.f - gg[r] * gg[r]);
+            dc[r] = dcc * gf[r];
+            das[(0 * H + u0 + r) * LSTM_NS + j] = dai[r];
+            das[(1 * H + u0 + r) * LSTM_NS + j] = daf[r];
+            das[(2 * H + u0 + r) * LSTM_NS + j] = dag[r];
+            das[(3 * H + u0 + r) * LSTM_NS + j] = dao[r];
+        }
+        if (live) {
+            float* dp = dxg + o * 4 * H + u0;
+            st4g(dp, make_float4(dai[0], dai[1], dai[2], dai[3]));
+            st4g(dp + H, make_float4(daf[0], daf[1], daf[2], daf[3]));
+            st4g(dp + 2 * H, make_float4(dag[0], dag[1], dag[2], dag[3]));
+            st4g(dp + 3 * H, make_float4(dao[0], dao[1], dao[2], dao[3]));
+        }
+        __syncthreads();
+        // dh_{t-1} += W_hh^T da_t   (this wave: its 16 hidden units x 16 sequences)
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[ks], das[(4 * ks + q) * LSTM_NS + j], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dhr[r] = acc[r];
+        __syncthreads();                       // das is rewritten next step
+    }
+}
+
+template <int H>
+int launch_fwd(const float* xg, const float* whh, float* hout, float* gates, float* cstate, int nseq, int L, int reverse, hipStream_t st) {
+    hipLaunchKernelGGL((lstm_fwd_kernel<H>), dim3((nseq + LSTM_NS - 1) / LSTM_NS), dim3(H * 4), 0, st, xg, whh, hout, gates, cstate, nseq, L, reverse);
+    return 0;
+}
+template <int H>
+int launch_bwd(const float* dhout, const float* gates, const float* cstate, const float* whh, float* dxg, int nseq, int L, int reverse, hipStream_t st) {
+    hipLaunchKernelGGL((lstm_bwd_kernel<H>), dim3((nseq + LSTM_NS - 1) / LSTM_NS), dim3(H * 4), 0, st, dhout, gates, cstate, whh, dxg, nseq, L, reverse);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int sep_lstm_fwd(const float* xg, const float* w_hh, float* h_out, float* gates, float* cstate, int nseq, int L,
+                            int H, int reverse, sep_stream_t stream) {
+    SEP_REQUIRE(xg && w_hh && h_out, "sep_lstm_fwd: null pointer");
+    SEP_REQUIRE(nseq > 0 && L > 0, "sep_lstm_fwd: empty problem");
+    hipStream_t st = (hipStream_t)stream;
+    switch (H) {
+        case 16: launch_fwd<16>(xg, w_hh, h_out, gates, cstate, nseq, L, reverse, st); break;
+        case 32: launch_fwd<32>(xg, w_hh, h_out, gates, cstate, nseq, L, reverse, st); break;
+        case 64: launch_fwd<64>(xg, w_hh, h_out, gates, cstate, nseq, L, reverse, st); break;
+        case 128: launch_fwd<128>(xg, w_hh, h_out, gates, cstate, nseq, L, reverse, st); break;
+        default: SEP_REQUIRE(false, "sep_lstm_fwd: hidden size %d not supported (16, 32, 64, 128)", H);
+    }
+    SEP_CHECK_LAUNCH("sep_lstm_fwd");
+    return 0;
+}
+
+extern "C" int sep_lstm_bwd(const float* dh_out, const float* gates, const float* cstate, const float* w_hh, float* dxg,
+                            int nseq, int L, int H, int reverse, sep_stream_t stream) {
+    SEP_REQUIRE(dh_out && gates && cstate && w_hh && dxg, "sep_lstm_bwd: null pointer");
+    SEP_REQUIRE(nseq > 0 && L > 0, "sep_lstm_bwd: empty problem");
+    hipStream_t st = (hipStream_t)stream;
+    switch (H) {
+        case 16: launch_bwd<16>(dh_out, gates, cstate, w_hh, dxg, nseq, L, reverse, st); break;
+        case 32: launch_bwd<32>(dh_out, gates, cstate, w_hh, dxg, nseq, L, reverse, st); break;
+        case 64: launch_bwd<64>(dh_out, gates, cstate, w_hh, dxg, nseq, L, reverse, st); break;
+        case 128: launch_bwd<128>(dh_out, gates, cstate, w_hh, dxg, nseq, L, reverse, st); break;
+        default: SEP_REQUIRE(false, "sep_lstm_bwd: hidden size %d not supported (16, 32, 64, 128)", H);
+    }
+    SEP_CHECK_LAUNCH("sep_lstm_bwd");
+    return 0;
+}

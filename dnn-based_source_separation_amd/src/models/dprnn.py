@@ -1,11 +1,15 @@
 """
 Dual-path RNN blocks: module tree / parameter names of reference src/models/dprnn.py:9-148.
 
-Interim design: the recurrences run on torch.nn.LSTM (MIOpen on ROCm); the global layer
-norm after every path is the libsepkernels gLN; layout changes are torch views/permutes.  A persistent hand-written
-LSTM (weights in LDS, chunk loop in-kernel) is the planned replacement -- it is NOT part of this round.
+The recurrences run on libsepkernels (`sep_lstm_fwd/bwd`: one persistent workgroup per 16 sequences, W_hh held in
+registers as MFMA fragments, one barrier per step); `nn.LSTM` is only the parameter container, so checkpoints keep the
+reference's keys (`rnn.weight_ih_l0`, `rnn.weight_hh_l0_reverse`, ...).  The input projection, the Linear after the RNN
+and the weight-gradient products are plain library GEMMs; the global layer norm after every path is the libsepkernels
+gLN; layout changes are torch views/permutes.
 """
 import torch.nn as nn
+
+from sepkernels.functional import lstm_bidirectional
 
 from utils.model import choose_rnn
 from utils.tasnet import choose_layer_norm
@@ -51,12 +55,13 @@ class _PathRNN(nn.Module):
     def _run(self, input, seq_axis):
         """input (B, F, S, K); seq_axis 3 -> recur over K for every (b, s); 2 -> over S for every (b, k)."""
         B, F, S, K = input.shape
-        self.rnn.flatten_parameters()
         if seq_axis == 3:
             x = input.permute(0, 2, 3, 1).reshape(B * S, K, F)
         else:
             x = input.permute(0, 3, 2, 1).reshape(B * K, S, F)
-        x, _ = self.rnn(x)
+        if self.hidden_channels not in (16, 32, 64, 128):
+            raise NotImplementedError("the LSTM sweep kernels cover hidden sizes 16, 32, 64, 128 (got {})".format(self.hidden_channels))
+        x = lstm_bidirectional(x.contiguous(), self.rnn)
         x = self.fc(x)                                           # (B*S, K, F) or (B*K, S, F)
         x = x.reshape(B, S * K, F).permute(0, 2, 1).contiguous()  # (B, F, S*K) [or (B, F, K*S)]
         if self.norm:

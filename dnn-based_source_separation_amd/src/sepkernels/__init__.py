@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("SEPKERNELS_LIB", os.path.normpath(os.path.join(_HERE,
 # ---- constants mirrored from include/sepkernels.h -------------------------------------------------
 PRO_NONE, PRO_PRELU, PRO_GLN, PRO_GLN_PRELU, PRO_GLN_BWD = 0, 1, 2, 3, 4
 EPI_STATS_PRELU, EPI_RESIDUAL, EPI_SIGMOID, EPI_PRELU_BWD, EPI_ROWSUMS, EPI_ROWSUMS_PRELU = 1, 2, 4, 8, 16, 32
-ABI_VERSION = 2
+ABI_VERSION = 3
 STATS_SLOTS = 16   # SEP_STATS_SLOTS: gLN statistics are double[B][STATS_SLOTS][2]
 
 _vp = ctypes.c_void_p
@@ -78,6 +78,8 @@ SIGNATURES = {
     "sep_sinkhorn_bwd": [_vp] * 4 + [_I, _I, _F, _I, _vp],
     "sep_sqnorm": [_vp, _vp, _L, _vp],
     "sep_adam_step": [_vp] * 5 + [_L] + [_F] * 7 + [_I, _vp],
+    "sep_lstm_fwd": [_vp] * 5 + [_I] * 4 + [_vp],
+    "sep_lstm_bwd": [_vp] * 5 + [_I] * 4 + [_vp],
 }
 
 _lib = None
@@ -273,6 +275,14 @@ class HipBackend:
 
     def sqnorm(self, g, out, n):
         _check(load().sep_sqnorm(_ptr(g, _f32), _ptr(out, _f64), n, _stream()), "sep_sqnorm")
+
+    def lstm_fwd(self, xg, w_hh, h_out, gates, cstate, nseq, L, H, reverse):
+        _check(load().sep_lstm_fwd(_ptr(xg, _f32), _ptr(w_hh, _f32), _ptr(h_out, _f32), _ptr(gates, _f32), _ptr(cstate, _f32),
+                                   nseq, L, H, int(reverse), _stream()), "sep_lstm_fwd")
+
+    def lstm_bwd(self, dh_out, gates, cstate, w_hh, dxg, nseq, L, H, reverse):
+        _check(load().sep_lstm_bwd(_ptr(dh_out, _f32), _ptr(gates, _f32), _ptr(cstate, _f32), _ptr(w_hh, _f32), _ptr(dxg, _f32),
+                                   nseq, L, H, int(reverse), _stream()), "sep_lstm_bwd")
 
     def adam_step(self, p, g, m, v, sqnorm, n, lr, beta1, beta2, eps, weight_decay, max_norm, grad_scale, step):
         _check(load().sep_adam_step(_ptr(p, _f32), _ptr(g, _f32), _ptr(m, _f32), _ptr(v, _f32), _ptr(sqnorm, _f64), n, lr, beta1,

@@ -212,3 +212,56 @@ class DepthwiseConv1dFn(torch.autograd.Function):
         K.reduce_slabs([(part, 0, dwb, C * (Kw + 1), B, C * (Kw + 1), 0, 1.0)])
         dwb = dwb.view(C, Kw + 1)
         return dx, dwb[:, :Kw].reshape(C, 1, Kw).contiguous(), (dwb[:, Kw].contiguous() if has_bias else None), None, None, None
+
+
+class LSTMDirectionFn(torch.autograd.Function):
+    """One direction of nn.LSTM(batch_first=True) with zero initial state: x (nseq, L, F) -> h (nseq, L, H).
+
+    The recurrence is libsepkernels (`sep_lstm_fwd` / `sep_lstm_bwd`: W_hh register-resident, persistent over the L
+    steps); the input projection and the three weight-gradient products are plain GEMMs and go to the BLAS library
+    through torch (addmm / mm), as a library GEMM is exactly what they are.
+    reference: src/models/dprnn.py:65-148 (nn.LSTM inside IntraChunkRNN / InterChunkRNN)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, reverse):
+        K = backend()
+        nseq, L, F = x.shape
+        H = w_hh.shape[1]
+        x2 = x.reshape(nseq * L, F)
+        xg = torch.addmm(b_ih + b_hh, x2, w_ih.t())                      # (nseq*L, 4H)
+        h = torch.empty(nseq, L, H, device=x.device, dtype=x.dtype)
+        gates = torch.empty(nseq, L, 4 * H, device=x.device, dtype=x.dtype)
+        cst = torch.empty(nseq, L, H, device=x.device, dtype=x.dtype)
+        K.lstm_fwd(xg, w_hh.contiguous(), h, gates, cst, nseq, L, H, bool(reverse))
+        ctx.save_for_backward(x2, w_ih, w_hh, h, gates, cst)
+        ctx.reverse, ctx.shape = bool(reverse), (nseq, L, F, H)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        K = backend()
+        x2, w_ih, w_hh, h, gates, cst = ctx.saved_tensors
+        nseq, L, F, H = ctx.shape
+        dxg = torch.empty(nseq, L, 4 * H, device=dh.device, dtype=dh.dtype)
+        K.lstm_bwd(dh.contiguous(), gates, cst, w_hh.contiguous(), dxg, nseq, L, H, ctx.reverse)
+        d2 = dxg.reshape(nseq * L, 4 * H)
+        hprev = torch.zeros_like(h)                                       # h_{t-1} of every step (zero initial state)
+        if ctx.reverse:
+            hprev[:, :-1] = h[:, 1:]
+        else:
+            hprev[:, 1:] = h[:, :-1]
+        dw_ih = d2.t() @ x2
+        dw_hh = d2.t() @ hprev.reshape(nseq * L, H)
+        db = d2.sum(dim=0)
+        dx = (d2 @ w_ih).reshape(nseq, L, F)
+        return dx, dw_ih, dw_hh, db, db, None
+
+
+def lstm_bidirectional(x, rnn):
+    """x (nseq, L, F) through the parameters of an nn.LSTM(num_layers=1, batch_first=True) container -> (nseq, L, D*H)."""
+    fwd = LSTMDirectionFn.apply(x, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0, False)
+    if not rnn.bidirectional:
+        return fwd
+    rev = LSTMDirectionFn.apply(x, rnn.weight_ih_l0_reverse, rnn.weight_hh_l0_reverse, rnn.bias_ih_l0_reverse, rnn.bias_hh_l0_reverse, True)
+    return torch.cat([fwd, rev], dim=2)
+

@@ -33,7 +33,7 @@ extern "C" {
 
 typedef void* sep_stream_t; /* hipStream_t */
 
-#define SEP_ABI_VERSION 2
+#define SEP_ABI_VERSION 3
 #define SEP_STATS_SLOTS 16
 
 int sep_version(void);
@@ -263,6 +263,20 @@ int sep_sqnorm(const float* g, double* sqnorm, int64_t n, sep_stream_t stream);
 int sep_adam_step(float* p, float* g, float* m, float* v, const double* sqnorm, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, float max_norm, float grad_scale, int step,
                   sep_stream_t stream);
+
+/* Time recurrence of ONE direction of nn.LSTM (reference src/models/dprnn.py:9-148 -> choose_rnn('lstm'), i.e.
+ * IntraChunkRNN / InterChunkRNN of DPRNN-TasNet).  The input projection is done by the caller (a plain GEMM):
+ *   xg[seq][t][4H] = x[seq][t][:] W_ih^T + b_ih + b_hh,   gate order i, f, g, o as in torch.
+ * forward : a_t = xg_t + W_hh h_{t-1};  c_t = sigmoid(a_f) c_{t-1} + sigmoid(a_i) tanh(a_g);  h_t = sigmoid(a_o) tanh(c_t),
+ *           h_0 = c_0 = 0, t ascending (reverse = 0) or descending (reverse = 1).  gates (post-activation i,f,g,o) and
+ *           cstate are saved for the backward sweep; both may be NULL for inference.
+ * backward: dh_out[seq][t][H] = gradient at h_t  ->  dxg[seq][t][4H] = gradient at the pre-activations a_t (= at xg_t).
+ *           The caller forms dW_ih = dxg^T x, dW_hh = dxg^T h_{t-1}, db = sum dxg, dx = dxg W_ih (plain GEMMs).
+ * H in {16, 32, 64, 128}; w_hh is [4H][H] row-major. */
+int sep_lstm_fwd(const float* xg, const float* w_hh, float* h_out, float* gates, float* cstate, int nseq, int L, int H,
+                 int reverse, sep_stream_t stream);
+int sep_lstm_bwd(const float* dh_out, const float* gates, const float* cstate, const float* w_hh, float* dxg, int nseq,
+                 int L, int H, int reverse, sep_stream_t stream);
 
 #ifdef __cplusplus
 }

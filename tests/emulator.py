@@ -451,6 +451,43 @@ class EmuBackend:
     def sqnorm(self, g, out, n):
         out += (g.reshape(-1)[:n].double() ** 2).sum()
 
+    def lstm_fwd(self, xg, w_hh, h_out, gates, cstate, nseq, L, H, reverse):
+        xg3 = xg.reshape(nseq, L, 4 * H)
+        h = torch.zeros(nseq, H, dtype=xg.dtype)
+        c = torch.zeros(nseq, H, dtype=xg.dtype)
+        ho = h_out.reshape(nseq, L, H)
+        for step in range(L):
+            t = L - 1 - step if reverse else step
+            a = xg3[:, t] + h @ w_hh.t()
+            i, f, g, o = torch.sigmoid(a[:, :H]), torch.sigmoid(a[:, H:2 * H]), torch.tanh(a[:, 2 * H:3 * H]), torch.sigmoid(a[:, 3 * H:])
+            c = f * c + i * g
+            h = o * torch.tanh(c)
+            ho[:, t] = h
+            if gates is not None:
+                gates.reshape(nseq, L, 4 * H)[:, t] = torch.cat([i, f, g, o], dim=1)
+            if cstate is not None:
+                cstate.reshape(nseq, L, H)[:, t] = c
+
+    def lstm_bwd(self, dh_out, gates, cstate, w_hh, dxg, nseq, L, H, reverse):
+        G = gates.reshape(nseq, L, 4 * H)
+        C = cstate.reshape(nseq, L, H)
+        dho = dh_out.reshape(nseq, L, H)
+        out = dxg.reshape(nseq, L, 4 * H)
+        dhr = torch.zeros(nseq, H, dtype=G.dtype)
+        dc = torch.zeros(nseq, H, dtype=G.dtype)
+        for step in range(L):
+            t = step if reverse else L - 1 - step
+            tp = t + 1 if reverse else t - 1
+            cp = C[:, tp] if 0 <= tp < L else torch.zeros(nseq, H, dtype=G.dtype)
+            i, f, g, o = G[:, t, :H], G[:, t, H:2 * H], G[:, t, 2 * H:3 * H], G[:, t, 3 * H:]
+            dh = dho[:, t] + dhr
+            tc = torch.tanh(C[:, t])
+            dcc = dh * o * (1 - tc * tc) + dc
+            da = torch.cat([dcc * g * i * (1 - i), dcc * cp * f * (1 - f), dcc * i * (1 - g * g), dh * tc * o * (1 - o)], dim=1)
+            out[:, t] = da
+            dc = dcc * f
+            dhr = da @ w_hh
+
     def adam_step(self, p, g, m, v, sqnorm, n, lr, beta1, beta2, eps, weight_decay, max_norm, grad_scale, step):
         coef = grad_scale
         if max_norm > 0:

@@ -387,3 +387,16 @@ def test_segment_overlap_add(T, chunk, hop):
     x = padded(B, C, T, ldt)
     both("segment", [x, nan(B, C, S, chunk), B * C, T, ldt, S, chunk, hop, pad_left], tol=0.0)
     both("overlap_add", [rnd(B, C, S, chunk), nan(B, C, ldt), B * C, T, ldt, S, chunk, hop, pad_left], tol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------- LSTM recurrence (DPRNN)
+@pytest.mark.parametrize("H,nseq,L,reverse", [(16, 5, 7, 0), (32, 37, 23, 1), (64, 16, 40, 0), (128, 50, 31, 1), (128, 33, 250, 0)])
+def test_lstm_sweeps(H, nseq, L, reverse):
+    """sep_lstm_fwd / sep_lstm_bwd against the step-by-step CPU restatement (ragged last workgroup: nseq % 16 != 0)."""
+    xg = rnd(nseq, L, 4 * H)
+    w_hh = rnd(4 * H, H, scale=H ** -0.5)
+    h, gates, cst = nan(nseq, L, H), nan(nseq, L, 4 * H), nan(nseq, L, H)
+    tol = 2e-4 if L < 100 else 2e-3
+    both("lstm_fwd", [xg, w_hh, h, gates, cst, nseq, L, H, reverse], tol=tol)
+    # backward on the emulator's saved gates / cell states (identical inputs for both sides)
+    both("lstm_bwd", [rnd(nseq, L, H), gates, cst, w_hh, nan(nseq, L, 4 * H), nseq, L, H, reverse], tol=tol)
