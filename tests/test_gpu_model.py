@@ -185,7 +185,7 @@ def test_global_layer_norm_module_on_gpu():
 
 
 def test_dprnn_tasnet_golden(golden_dir):
-    """BASELINE.json configs[3] family (small instance): head/tail kernels + segment/overlap-add + interim torch LSTM."""
+    """BASELINE.json configs[3] family (small instance): head/tail kernels + segment/overlap-add + the LSTM sweep kernels."""
     from oracle.make_golden import DPRNN_CFG
     from models.dprnn_tasnet import DPRNNTasNet
     g = np.load(os.path.join(golden_dir, "dprnn_tasnet_small.npz"))
@@ -216,3 +216,63 @@ def test_orpit_and_dsconv_on_gpu(golden_dir):
     assert _rel(mod.depthwise_conv1d.weight.grad, ref_dw.weight.grad) <= 1e-3
     assert _rel(mod.pointwise_conv1d.weight.grad, ref_pw.weight.grad) <= 1e-3
     assert _rel(mod.pointwise_conv1d.bias.grad, ref_pw.bias.grad) <= 1e-3
+
+
+def test_dprnn_tasnet_config4_full_size():
+    """BASELINE.json configs[3] at its real size: N=64, L=2, F=64, H=128, K=250, P=125, 6 blocks, 2 utterances of 4 s @ 8 kHz
+    (255 chunks of 250 frames).  Size-independent properties: the LSTM sweeps against nn.LSTM on the same parameters
+    (MIOpen here is the independent implementation), scale handling of SI-SDR/PIT, per-utterance independence."""
+    from models.dprnn_tasnet import DPRNNTasNet
+    torch.manual_seed(5)
+    model = DPRNNTasNet(n_basis=64, kernel_size=2, stride=1, enc_basis="trainable", dec_basis="trainable", enc_nonlinear=None,
+                        sep_hidden_channels=128, sep_bottleneck_channels=64, sep_chunk_size=250, sep_hop_size=125,
+                        sep_num_blocks=6, sep_norm=True, mask_nonlinear="sigmoid", causal=False, rnn_type="lstm", n_sources=2).cuda()
+    g = torch.Generator().manual_seed(9)
+    sources = (0.1 * torch.randn(2, 2, 32000, generator=g)).cuda()
+    mixture = sources.sum(1, keepdim=True)
+    est = model(mixture)
+    assert est.shape == (2, 2, 32000) and torch.isfinite(est).all()
+    crit = PIT1d(NegSISDR(), n_sources=2)
+    loss, pattern = crit(est, sources)
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    # utterances are independent: running the second one alone gives the same estimate
+    est1 = model(mixture[1:2])
+    assert _rel(est1.detach(), est[1:2].detach().cpu()) <= 1e-4
+    # the first intra-chunk bi-LSTM against MIOpen on the same parameters and input
+    blk = model.separator.dprnn.net[0].intra_chunk_block
+    x = torch.randn(510, 250, 64, device="cuda")
+    from sepkernels.functional import lstm_bidirectional
+    ours = lstm_bidirectional(x, blk.rnn)
+    ref, _ = blk.rnn(x)
+    assert _rel(ours.detach(), ref.detach().cpu()) <= 1e-5
+
+
+def test_paper_best_four_speakers_sinkpit_full_size():
+    """BASELINE.json configs[4]: paper-best Conv-TasNet, 4 speakers, Sinkhorn-PIT (k = 200 iterations), 4 s @ 8 kHz, per-GPU
+    batch; finite loss / gradients, permutation found = the one planted in the data, hard-PIT agreement."""
+    from criterion.pit import SinkPIT
+    from models.conv_tasnet import ConvTasNet
+    torch.manual_seed(7)
+    model = ConvTasNet(512, 16, stride=8, enc_basis="trainable", dec_basis="trainable", enc_nonlinear=None, sep_hidden_channels=512,
+                       sep_bottleneck_channels=128, sep_skip_channels=128, sep_kernel_size=3, sep_num_blocks=3, sep_num_layers=8,
+                       dilated=True, separable=True, causal=False, sep_nonlinear="prelu", sep_norm=True, mask_nonlinear="sigmoid",
+                       n_sources=4).cuda()
+    g = torch.Generator().manual_seed(11)
+    B = 4
+    sources = (0.1 * torch.randn(B, 4, 32000, generator=g)).cuda()
+    mixture = sources.sum(1, keepdim=True)
+    est = model(mixture)
+    assert est.shape == (B, 4, 32000)
+    crit = SinkPIT(NegSISDR(), n_sources=4, coldness=1.0, iteration=200)
+    loss, pattern = crit(est, sources)
+    assert torch.isfinite(loss) and pattern.shape == (B, 4)
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    # on estimates that ARE permuted targets the Sinkhorn assignment must recover the permutation, like hard PIT does
+    perm = torch.tensor([2, 0, 3, 1], device="cuda")
+    fake = sources[:, perm] + 0.01 * torch.randn(B, 4, 32000, generator=g).cuda()
+    _, pat_s = SinkPIT(NegSISDR(), n_sources=4, coldness=10.0, iteration=200)(fake, sources)
+    _, pat_h = PIT1d(NegSISDR(), n_sources=4)(fake, sources)
+    assert torch.equal(pat_s.cpu(), pat_h.cpu())
+
