@@ -77,7 +77,7 @@ def neg_sisdr_pit(est, src, eps=EPS):
         losses.append((-10 * torch.log10(v)).mean(1))
     losses = torch.stack(losses, 1)
     loss, idx = losses.min(1)
-    return loss.mean(0), pats[idx]
+    return loss.mean(0), pats[idx.cpu()]
 
 
 def train_step(p, cfg, mixture, sources, dtype=torch.float32):
