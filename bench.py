@@ -82,6 +82,30 @@ class TimedBackend:
         return len(self.records[key]), ms, fl
 
 
+# ---- workload constants; restated here so that the timed path imports nothing from oracle/ -------
+def num_frames(T, L, S):
+    """Encoder frames of a T-sample utterance with ConvTasNet's input padding (reference conv_tasnet.py:145-149)."""
+    padding = (S - (T - L) % S) % S
+    return (T + padding - L) // S + 1
+
+
+def flops_per_frame(cfg):
+    """Forward FLOP per frame: 2 x the MAC/frame formula of SURVEY.md section 8(d)."""
+    N, L = cfg["n_basis"], cfg["kernel_size"]
+    Bn, H, Sc = cfg["sep_bottleneck_channels"], cfg["sep_hidden_channels"], cfg["sep_skip_channels"]
+    P, X, R, ns = cfg["sep_kernel_size"], cfg["sep_num_layers"], cfg["sep_num_blocks"], cfg["n_sources"]
+    mac = N * L + N * Bn + (R * X - 1) * (2 * Bn * H + H * Sc + H * P) + (Bn * H + H * Sc + H * P) + Sc * ns * N + ns * N * L
+    return 2 * mac
+
+
+def bytes_per_frame(cfg):
+    """Forward algorithmic HBM bytes per frame (fp32), SURVEY.md section 8(d)."""
+    N = cfg["n_basis"]
+    Bn, H, Sc = cfg["sep_bottleneck_channels"], cfg["sep_hidden_channels"], cfg["sep_skip_channels"]
+    X, R, ns, S = cfg["sep_num_layers"], cfg["sep_num_blocks"], cfg["n_sources"], cfg["stride"]
+    return 4 * (R * X * (2 * Bn + 4 * H + 2 * Sc) + (2 * N + Bn + 2 * ns * N + ns * S))
+
+
 def pmc_traffic(variant_tally):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate FETCH_SIZE and
     WRITE_SIZE runs, gfx950 x2 correction on FETCH_SIZE; tools/pmc_passes.sh + tools/pmc_traffic.py).  PMC counters cannot
@@ -108,8 +132,7 @@ def pmc_traffic(variant_tally):
 
 def cpu_baseline(sample_steps=2):
     """Reference-equivalent CPU path (oracle/fast_port.py) on the host cores, bounded sample: B=2 utterances/step."""
-    from oracle import fast_port as FP
-    from oracle.convtasnet_oracle import num_frames
+    from oracle import fast_port as FP       # the ONLY oracle import of this file: the cpu_baseline leg
     from models.conv_tasnet import ConvTasNet
     torch.manual_seed(111)
     model = ConvTasNet(**PAPER)
@@ -170,7 +193,6 @@ def main():
     from models.conv_tasnet import ConvTasNet
     from criterion.sdr import NegSISDR
     from criterion.pit import PIT1d
-    from oracle.convtasnet_oracle import num_frames, flops_per_frame, bytes_per_frame
 
     sepkernels.load()          # fail loudly if the HIP library is missing
     timed = TimedBackend(sepkernels.backend())

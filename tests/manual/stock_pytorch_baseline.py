@@ -1,11 +1,11 @@
-"""Development tool (documentation number only, SURVEY.md section 8d "hipified baseline"): the same Conv-TasNet step written
+"""Manual measurement, kept under tests/ because it runs the oracle port (documentation number only, SURVEY.md section 8d "hipified baseline"): the same Conv-TasNet step written
 with stock torch.nn.functional ops (oracle/fast_port.py) running on the GPU through MIOpen/rocBLAS, paper-best B=16, so that
 the gain of the hand-written path is not confused with the gain of the device."""
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "dnn-based_source_separation_amd", "src"))
 import torch  # noqa: E402
