@@ -7,13 +7,18 @@
 // src/models/conv_tasnet.py:335,341 together with the elementwise ops the reference runs as separate
 // ATen kernels around them (PReLU, gLN apply, residual/skip adds, sigmoid, their backward forms).
 //
-// Design (CDNA4): 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each wave a 64x64 tile =
-// 2x2 v_mfma_f32_32x32x2_f32 accumulators = 64 VGPRs), K staged through LDS in k-major order so that both
-// MFMA operands are read with conflict-free ds_read_b32 (lane l reads element [k = l>>5][l&31]).
-// Global->register->LDS staging is software pipelined one chunk ahead; the elementwise prologue
-// (PReLU / gLN scale+shift / gLN backward) runs on the values while they sit in registers, so the
-// normalised tensors v1, v2 of the reference never exist in HBM.  Blocks that share an X column tile are
-// placed on the same XCD (blockIdx % 8) so the tile is fetched from HBM once and re-read from that L2.
+// Layout of this file:
+//   gemm_epilogue<EF>             LDS-transposed float4 epilogue shared by both GEMM kernels (bias, PReLU statistics,
+//                                 residual / skip accumulate, sigmoid, PReLU backward, gLN-backward row sums)
+//   pw_gemm_kernel                register-staged GEMM; fallback for contractions that are not a multiple of 16
+//   pw_gemm_direct_kernel<...>    THE fast path: LDS-DMA 2-stage ring, 4 workgroups per CU, half-chunk software pipeline,
+//                                 prologue (PReLU / gLN / gLN backward) on the B fragments -- design notes at the kernel
+//   pw_wgrad_kernel               register-staged weight gradient; fallback (g_mul = decoder basis gradient)
+//   pw_wgrad_direct_kernel<X>     fast weight gradient: 8-wave workgroups, two wave groups split the contraction
+//   reduce_slabs / f64_to_f32     deterministic second stages
+// Common to all: 128x128 output tile, each wave a 64x64 sub-tile = 2x2 v_mfma_f32_32x32x2_f32 accumulators (64 VGPRs);
+// the normalised tensors v1, v2 of the reference never exist in HBM; workgroups that share an X column tile are placed
+// on the same XCD (blockIdx % 8) so the tile is fetched from HBM once and re-read from that L2.
 #include "common.hpp"
 #include <stdlib.h>
 #include <stddef.h>
