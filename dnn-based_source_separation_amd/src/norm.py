@@ -1,5 +1,7 @@
-import warnings
+"""Legacy import location of the normalisation layers (`import norm`); everything lives in `modules.norm`."""
+import warnings as _warnings
 
-from modules.norm import *  # noqa: F401,F403
+import modules.norm as _new_home
 
-warnings.warn("Use modules.norm instead.", FutureWarning)
+globals().update({_n: getattr(_new_home, _n) for _n in dir(_new_home) if not _n.startswith("_")})
+_warnings.warn("`norm` is a legacy alias: import `modules.norm`", FutureWarning, stacklevel=2)

@@ -1,23 +1,35 @@
-"""choose_layer_norm with the reference's names and error behaviour (reference src/utils/tasnet.py:14-32)."""
+"""Layer-norm factory of the TasNet family: same names, arguments and error behaviour as the reference
+(src/utils/tasnet.py:14-32), resolved through a table."""
 import torch.nn as nn
 
-from modules.norm import GlobalLayerNorm, CumulativeLayerNorm1d
+from modules.norm import CumulativeLayerNorm1d, GlobalLayerNorm
 
 EPS = 1e-12
 
+_BATCH_NORMS = {1: nn.BatchNorm1d, 2: nn.BatchNorm2d}
+
+
+def _global(num_features, causal, eps, **_):
+    if causal:
+        raise ValueError("Global Layer Normalization is NOT causal.")
+    return GlobalLayerNorm(num_features, eps=eps)
+
+
+def _cumulative(num_features, causal, eps, **_):
+    return CumulativeLayerNorm1d(num_features, eps=eps)
+
+
+def _batch(num_features, causal, eps, n_dims=None, **_):
+    n_dims = n_dims or 1
+    if n_dims not in _BATCH_NORMS:
+        raise NotImplementedError("n_dims is expected 1 or 2, but give {}.".format(n_dims))
+    return _BATCH_NORMS[n_dims](num_features, eps=eps)
+
+
+_FACTORIES = {"gLN": _global, "cLN": _cumulative, "BN": _batch, "batch": _batch, "batch_norm": _batch}
+
 
 def choose_layer_norm(name, num_features, causal=False, eps=EPS, **kwargs):
-    if name == "cLN":
-        return CumulativeLayerNorm1d(num_features, eps=eps)
-    if name == "gLN":
-        if causal:
-            raise ValueError("Global Layer Normalization is NOT causal.")
-        return GlobalLayerNorm(num_features, eps=eps)
-    if name in ["BN", "batch", "batch_norm"]:
-        n_dims = kwargs.get("n_dims") or 1
-        if n_dims == 1:
-            return nn.BatchNorm1d(num_features, eps=eps)
-        if n_dims == 2:
-            return nn.BatchNorm2d(num_features, eps=eps)
-        raise NotImplementedError("n_dims is expected 1 or 2, but give {}.".format(n_dims))
-    raise NotImplementedError("Not support {} layer normalization.".format(name))
+    if name not in _FACTORIES:
+        raise NotImplementedError("Not support {} layer normalization.".format(name))
+    return _FACTORIES[name](num_features, causal, eps, **kwargs)
