@@ -31,7 +31,7 @@ class _FusedConvTasNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mixture, cfg, names, want_latent, grad_sink, *params):
         ctx.set_materialize_grads(False)
-        ctx.grad_sink = grad_sink
+        ctx.grad_sink, ctx.bucket_hook = (grad_sink if isinstance(grad_sink, tuple) else (grad_sink, None))
         if ctx.needs_input_grad[0]:
             raise NotImplementedError("gradient w.r.t. the input mixture is not implemented on the fused path")
         need_bwd = any(ctx.needs_input_grad[5:])
@@ -56,7 +56,19 @@ class _FusedConvTasNetFn(torch.autograd.Function):
         if flat is None or flat.numel() != total:
             flat = torch.empty(total, device=d_est.device, dtype=d_est.dtype)
         G = {n: flat[offs[n]:offs[n] + p.numel()].view(p.shape) for n, p in zip(names, params)}
-        _net.backward(ctx.cfg, dict(zip(names, params)), ctx.sv, d_est, G)
+        hook = ctx.bucket_hook if flat is ctx.grad_sink else None
+        on_ready = None
+        if hook is not None:
+            # gradient buckets for the data-parallel step: [block R-1 .. end of buffer], then one TCN block at a time;
+            # what is left (block 0 and the head) is the caller's last bucket after backward returns
+            R = ctx.cfg["sep_num_blocks"]
+            starts = {r: offs["separator.tdcn.net.{}.net.0.bottleneck_conv1d.weight".format(r)] for r in range(R)}
+
+            def on_ready(r):
+                hook(starts[r], total if r == R - 1 else starts[r + 1])
+        _net.backward(ctx.cfg, dict(zip(names, params)), ctx.sv, d_est, G, on_ready=on_ready)
+        if hook is not None:
+            hook(0, starts[1] if ctx.cfg["sep_num_blocks"] > 1 else total)
         ctx.sv = None
         grads = tuple(G[n] for n in names)
         G = None
@@ -229,7 +241,9 @@ class ConvTasNet(nn.Module):
         named = list(self.named_parameters())
         names = tuple(n for n, _ in named)
         params = tuple(p for _, p in named)
-        out = _FusedConvTasNetFn.apply(mixture, cfg, names, want_latent, getattr(self, "_grad_sink", None), *params)
+        sink = getattr(self, "_grad_sink", None)
+        hook = getattr(self, "_grad_bucket_hook", None)
+        out = _FusedConvTasNetFn.apply(mixture, cfg, names, want_latent, (sink, hook) if hook is not None else sink, *params)
         if want_latent:
             est, latent = out
             F = _net.Geometry(T, self.kernel_size, self.stride).F

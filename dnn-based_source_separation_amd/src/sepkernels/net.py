@@ -320,8 +320,13 @@ class _SideStream:
             self.main.wait_stream(self.side)
 
 
-def backward(cfg, P, sv, d_est, G):
-    """Writes the gradient of every parameter into G[name] (overwrites; G tensors have the parameter shapes)."""
+def backward(cfg, P, sv, d_est, G, on_ready=None):
+    """Writes the gradient of every parameter into G[name] (overwrites; G tensors have the parameter shapes).
+
+    on_ready(first_block, last_block_or_None): optional callback for gradient bucketing.  It is called when every
+    gradient of TCN blocks [first_block, ...] is final: first with the last block (plus the whole tail: mask PReLU, mask
+    conv, decoder), then once per earlier block, and the caller treats the call for block 0 as "block 0 plus the head"
+    by waiting for this function to return.  With a callback the queued reductions are flushed per block."""
     K = backend()
     mixture = sv.mixture
     dev = mixture.device
@@ -355,6 +360,7 @@ def backward(cfg, P, sv, d_est, G):
     # after the loop instead of ~100 tiny launches inside it (each costs a ~5 us dispatch bubble on the critical path).
     # Price: the slabs of all layers stay alive until the flush (~1.6 GB at B=16 paper-best; HBM is 288 GB).
     pending = []
+    flushed_from = nl + 1          # dalpha entries [flushed_from, nl] are already converted (bucketed mode)
     dout = None
     for li in range(nl - 1, -1, -1):
         pre, dil, dual = layers[li]
@@ -446,13 +452,32 @@ def backward(cfg, P, sv, d_est, G):
             else:
                 pending += segs
         dout = dx
+        X_layers = cfg["sep_num_layers"]
+        if on_ready is not None and li % X_layers == 0 and li > 0:
+            # a whole TCN block is done: flush its queued reductions (and its PReLU slopes) so that the caller can
+            # start the all-reduce of this bucket while the earlier blocks are still being differentiated
+            side.join()
+            blk = li // X_layers
+            hi = nl + 1 if blk == cfg["sep_num_blocks"] - 1 else (blk + 1) * X_layers     # the last block also owns the mask PReLU slope
+            lo = li
+            d32 = torch.empty(hi - lo, **f32)
+            K.f64_to_f32(dalpha[lo:hi], d32, hi - lo, 0)
+            pending += [(d32, q - lo, G[layers[q][0] + "nonlinear1d.weight"], 1, 1, 1, 0, 1.0) for q in range(lo, min(hi, nl))]
+            if hi == nl + 1:
+                pending.append((d32, nl - lo, G["separator.prelu.weight"], 1, 1, 1, 0, 1.0))
+            K.reduce_slabs(pending)
+            pending = []
+            flushed_from = lo
+            on_ready(blk)
     side.join()
     # PReLU slope gradients were accumulated in fp64 (one scalar per layer + the mask PReLU): one conversion, then
     # scattered into the parameter gradients by the same flush
-    dal32 = torch.empty(nl + 1, **f32)
-    K.f64_to_f32(dalpha, dal32, nl + 1, 0)
-    pending += [(dal32, li, G[layers[li][0] + "nonlinear1d.weight"], 1, 1, 1, 0, 1.0) for li in range(nl)]
-    pending.append((dal32, nl, G["separator.prelu.weight"], 1, 1, 1, 0, 1.0))
+    rest = flushed_from if on_ready is not None else nl + 1
+    dal32 = torch.empty(rest, **f32)
+    K.f64_to_f32(dalpha[:rest], dal32, rest, 0)
+    pending += [(dal32, li, G[layers[li][0] + "nonlinear1d.weight"], 1, 1, 1, 0, 1.0) for li in range(min(rest, nl))]
+    if rest == nl + 1:
+        pending.append((dal32, nl, G["separator.prelu.weight"], 1, 1, 1, 0, 1.0))
     K.reduce_slabs(pending)
 
     # ---- head: bottleneck conv, first gLN, encoder ------------------------------------------------------

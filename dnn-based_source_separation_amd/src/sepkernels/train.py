@@ -7,8 +7,11 @@ Replaces the single-process nn.DataParallel step of reference egs/wsj0-mix/commo
 (scatter / per-forward parameter broadcast / gather / loss+clip+Adam on GPU 0) -- SURVEY.md section 8(e).
 Equal per-rank batches make mean-of-rank-means the global batch mean, so the averaged gradient equals the
 reference's single-process result.  The collective is 19.9 MB per step (4,984,881 floats): latency-, not
-bandwidth-bound on 7 x 153 GB/s xGMI links, so it is issued once, un-bucketed, after backward.
+bandwidth-bound on 7 x 153 GB/s xGMI links; it is issued in three asynchronous pieces (one per TCN block, last block
+first) so that most of it hides under the rest of backward (SEPK_DDP_BUCKETS=0: one call after backward).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -34,6 +37,7 @@ class FusedTrainStep:
         self.v = torch.zeros_like(flat)
         self.sqnorm = torch.zeros(1, device=flat.device, dtype=torch.float64)
         self.step_count = 0
+        self.bucketed = os.environ.get("SEPK_DDP_BUCKETS", "1") != "0"
 
     def zero_grad(self):
         for p in self.model.parameters():
@@ -44,14 +48,27 @@ class FusedTrainStep:
         model = self.model
         self.zero_grad()
         model._grad_sink = self.gflat                 # backward writes every gradient straight into the flat buffer
+        works = []
+        if self.world > 1 and self.bucketed:
+            # one asynchronous RCCL all-reduce per TCN block, issued as soon as the block's gradients are final, so the
+            # exchange of the late layers travels under the differentiation of the early ones (3 buckets at paper-best)
+            def bucket_ready(lo, hi):
+                works.append(dist.all_reduce(self.gflat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            model._grad_bucket_hook = bucket_ready
         try:
             est = model(mixture)
             loss, _ = self.criterion(est, sources)
             loss.backward()
         finally:
             model._grad_sink = None
+            model._grad_bucket_hook = None
+        self.last_buckets = len(works)
         if self.world > 1:
-            dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM, group=self.group)
+            if works:
+                for w in works:
+                    w.wait()
+            else:
+                dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM, group=self.group)
         self.step_count += 1
         n = self.gflat.numel()
         self.sqnorm.zero_()

@@ -1,5 +1,6 @@
 """CPU, world_size 2, gloo: the data-parallel train step (sepkernels/train.py).  Utterances are sharded across ranks,
-each rank runs forward + PIT + backward locally, ONE all-reduce of the flat gradient buffer, then clip + Adam.
+each rank runs forward + PIT + backward locally, the flat gradient buffer is all-reduced in three asynchronous buckets (one
+per TCN block, issued from inside backward), then clip + Adam.
 Checked: (1) ranks end with bit-identical parameters; (2) they equal a single-process step on the concatenated
 batch (mean of equal-sized rank means == global mean), i.e. the reference's nn.DataParallel result.
 Kernels are the CPU emulator here (no GPU in this container); the collective logic is what is under test."""
@@ -14,7 +15,7 @@ import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CFG = dict(n_basis=64, kernel_size=16, stride=8, enc_basis="trainable", dec_basis="trainable", enc_nonlinear="relu",
-           sep_hidden_channels=128, sep_bottleneck_channels=64, sep_skip_channels=64, sep_kernel_size=3, sep_num_blocks=1,
+           sep_hidden_channels=128, sep_bottleneck_channels=64, sep_skip_channels=64, sep_kernel_size=3, sep_num_blocks=3,
            sep_num_layers=2, dilated=True, separable=True, causal=False, sep_nonlinear="prelu", sep_norm=True,
            mask_nonlinear="sigmoid", n_sources=2)
 
@@ -43,7 +44,7 @@ def _run_steps(mixture, sources, nsteps, distributed):
     model = ConvTasNet(**CFG)
     step = FusedTrainStep(model, PIT1d(NegSISDR(), n_sources=2), lr=1e-3, max_norm=5.0, distributed=distributed)
     losses = [step(mixture, sources).item() for _ in range(nsteps)]
-    return model.flat_parameters().clone(), losses
+    return model.flat_parameters().clone(), losses + [float(step.last_buckets)]
 
 
 def _worker(rank, world, port, out_dir):
@@ -55,6 +56,7 @@ def _worker(rank, world, port, out_dir):
     per = mixture.shape[0] // world
     sl = slice(rank * per, (rank + 1) * per)                       # utterance sharding
     flat, losses = _run_steps(mixture[sl], sources[sl], 2, True)
+    assert losses.pop() == (3.0 if os.environ.get("SEPK_DDP_BUCKETS", "1") != "0" else 0.0)   # block 2 + tail, block 1, block 0 + head
     torch.save({"flat": flat, "losses": losses}, os.path.join(out_dir, "rank{}.pt".format(rank)))
     dist.destroy_process_group()
 
@@ -73,6 +75,7 @@ def test_two_rank_step_matches_single_process(tmp_path):
     try:
         mixture, sources = _data()
         flat, losses = _run_steps(mixture, sources, 2, False)      # single process, global batch
+        assert losses.pop() == 0.0
     finally:
         sepkernels._set_backend_for_tests(old)
     assert (r0["flat"] - flat).abs().max() <= 2e-5 * flat.abs().max()
