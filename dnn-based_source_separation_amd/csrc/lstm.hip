@@ -30,8 +30,17 @@ constexpr int LSTM_NS = 16;     // sequences per workgroup = N of the 16x16x4 MF
 template <int H>
 __global__ __launch_bounds__(H * 4) void lstm_fwd_kernel(const float* __restrict__ xg, const float* __restrict__ whh,
                                                          float* __restrict__ hout, float* __restrict__ gates,
-                                                         float* __restrict__ cstate, int nseq, int L, int reverse) {
+                                                         float* __restrict__ cstate, int nseq, int L, int dirs) {
     constexpr int KS = H / 4;                  // MFMA k-steps per gate block
+    // dirs: 0 forward in time, 1 backward in time, 2 both -- blockIdx.y picks the direction and its slab of every buffer
+    const int dir = dirs == 2 ? (int)blockIdx.y : 0;
+    const int reverse = dirs == 2 ? dir : dirs;
+    {
+        const size_t rows = (size_t)nseq * L;
+        xg += dir * rows * 4 * H; whh += (size_t)dir * 4 * H * H; hout += dir * rows * H;
+        if (gates) gates += dir * rows * 4 * H;
+        if (cstate) cstate += dir * rows * H;
+    }
     __shared__ float hs[2][H * LSTM_NS];       // h_{t-1} / h_t as [unit][sequence]
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -109,8 +118,15 @@ __global__ __launch_bounds__(H * 4) void lstm_fwd_kernel(const float* __restrict
 template <int H>
 __global__ __launch_bounds__(H * 4) void lstm_bwd_kernel(const float* __restrict__ dhout, const float* __restrict__ gates,
                                                          const float* __restrict__ cstate, const float* __restrict__ whh,
-                                                         float* __restrict__ dxg, int nseq, int L, int reverse) {
+                                                         float* __restrict__ dxg, int nseq, int L, int dirs) {
     constexpr int KS = 4 * H / 4;              // k-steps over the 4H gate rows
+    const int dir = dirs == 2 ? (int)blockIdx.y : 0;
+    const int reverse = dirs == 2 ? dir : dirs;
+    {
+        const size_t rows = (size_t)nseq * L;
+        dhout += dir * rows * H; gates += dir * rows * 4 * H; cstate += dir * rows * H; whh += (size_t)dir * 4 * H * H;
+        dxg += dir * rows * 4 * H;
+    }
     __shared__ float das[4 * H * LSTM_NS];     // d(pre-activation) of the current step as [gate row][sequence]
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -178,12 +194,12 @@ __global__ __launch_bounds__(H * 4) void lstm_bwd_kernel(const float* __restrict
 
 template <int H>
 int launch_fwd(const float* xg, const float* whh, float* hout, float* gates, float* cstate, int nseq, int L, int reverse, hipStream_t st) {
-    hipLaunchKernelGGL((lstm_fwd_kernel<H>), dim3((nseq + LSTM_NS - 1) / LSTM_NS), dim3(H * 4), 0, st, xg, whh, hout, gates, cstate, nseq, L, reverse);
+    hipLaunchKernelGGL((lstm_fwd_kernel<H>), dim3((nseq + LSTM_NS - 1) / LSTM_NS, reverse == 2 ? 2 : 1), dim3(H * 4), 0, st, xg, whh, hout, gates, cstate, nseq, L, reverse);
     return 0;
 }
 template <int H>
 int launch_bwd(const float* dhout, const float* gates, const float* cstate, const float* whh, float* dxg, int nseq, int L, int reverse, hipStream_t st) {
-    hipLaunchKernelGGL((lstm_bwd_kernel<H>), dim3((nseq + LSTM_NS - 1) / LSTM_NS), dim3(H * 4), 0, st, dhout, gates, cstate, whh, dxg, nseq, L, reverse);
+    hipLaunchKernelGGL((lstm_bwd_kernel<H>), dim3((nseq + LSTM_NS - 1) / LSTM_NS, reverse == 2 ? 2 : 1), dim3(H * 4), 0, st, dhout, gates, cstate, whh, dxg, nseq, L, reverse);
     return 0;
 }
 
@@ -192,7 +208,7 @@ int launch_bwd(const float* dhout, const float* gates, const float* cstate, cons
 extern "C" int sep_lstm_fwd(const float* xg, const float* w_hh, float* h_out, float* gates, float* cstate, int nseq, int L,
                             int H, int reverse, sep_stream_t stream) {
     SEP_REQUIRE(xg && w_hh && h_out, "sep_lstm_fwd: null pointer");
-    SEP_REQUIRE(nseq > 0 && L > 0, "sep_lstm_fwd: empty problem");
+    SEP_REQUIRE(nseq > 0 && L > 0 && reverse >= 0 && reverse <= 2, "sep_lstm_fwd: bad sizes / direction");
     hipStream_t st = (hipStream_t)stream;
     switch (H) {
         case 16: launch_fwd<16>(xg, w_hh, h_out, gates, cstate, nseq, L, reverse, st); break;
@@ -208,7 +224,7 @@ extern "C" int sep_lstm_fwd(const float* xg, const float* w_hh, float* h_out, fl
 extern "C" int sep_lstm_bwd(const float* dh_out, const float* gates, const float* cstate, const float* w_hh, float* dxg,
                             int nseq, int L, int H, int reverse, sep_stream_t stream) {
     SEP_REQUIRE(dh_out && gates && cstate && w_hh && dxg, "sep_lstm_bwd: null pointer");
-    SEP_REQUIRE(nseq > 0 && L > 0, "sep_lstm_bwd: empty problem");
+    SEP_REQUIRE(nseq > 0 && L > 0 && reverse >= 0 && reverse <= 2, "sep_lstm_bwd: bad sizes / direction");
     hipStream_t st = (hipStream_t)stream;
     switch (H) {
         case 16: launch_bwd<16>(dh_out, gates, cstate, w_hh, dxg, nseq, L, reverse, st); break;

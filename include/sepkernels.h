@@ -272,7 +272,9 @@ int sep_adam_step(float* p, float* g, float* m, float* v, const double* sqnorm, 
  *           cstate are saved for the backward sweep; both may be NULL for inference.
  * backward: dh_out[seq][t][H] = gradient at h_t  ->  dxg[seq][t][4H] = gradient at the pre-activations a_t (= at xg_t).
  *           The caller forms dW_ih = dxg^T x, dW_hh = dxg^T h_{t-1}, db = sum dxg, dx = dxg W_ih (plain GEMMs).
- * H in {16, 32, 64, 128}; w_hh is [4H][H] row-major. */
+ * H in {16, 32, 64, 128}; w_hh is [4H][H] row-major.
+ * reverse = 2 runs BOTH directions in one launch (a sweep occupies only nseq/16 compute units): every buffer then holds
+ * two slabs back to back, slab 0 = forward in time, slab 1 = backward in time (xg [2][nseq][L][4H], w_hh [2][4H][H], ...). */
 int sep_lstm_fwd(const float* xg, const float* w_hh, float* h_out, float* gates, float* cstate, int nseq, int L, int H,
                  int reverse, sep_stream_t stream);
 int sep_lstm_bwd(const float* dh_out, const float* gates, const float* cstate, const float* w_hh, float* dxg, int nseq,

@@ -452,6 +452,12 @@ class EmuBackend:
         out += (g.reshape(-1)[:n].double() ** 2).sum()
 
     def lstm_fwd(self, xg, w_hh, h_out, gates, cstate, nseq, L, H, reverse):
+        if int(reverse) == 2:          # both directions: two slabs per buffer
+            for d in range(2):
+                self.lstm_fwd(xg.reshape(2, -1)[d], w_hh.reshape(2, 4 * H, H)[d], h_out.reshape(2, -1)[d],
+                              None if gates is None else gates.reshape(2, -1)[d], None if cstate is None else cstate.reshape(2, -1)[d],
+                              nseq, L, H, d)
+            return
         xg3 = xg.reshape(nseq, L, 4 * H)
         h = torch.zeros(nseq, H, dtype=xg.dtype)
         c = torch.zeros(nseq, H, dtype=xg.dtype)
@@ -469,6 +475,11 @@ class EmuBackend:
                 cstate.reshape(nseq, L, H)[:, t] = c
 
     def lstm_bwd(self, dh_out, gates, cstate, w_hh, dxg, nseq, L, H, reverse):
+        if int(reverse) == 2:
+            for d in range(2):
+                self.lstm_bwd(dh_out.reshape(2, -1)[d], gates.reshape(2, -1)[d], cstate.reshape(2, -1)[d], w_hh.reshape(2, 4 * H, H)[d],
+                              dxg.reshape(2, -1)[d], nseq, L, H, d)
+            return
         G = gates.reshape(nseq, L, 4 * H)
         C = cstate.reshape(nseq, L, H)
         dho = dh_out.reshape(nseq, L, H)

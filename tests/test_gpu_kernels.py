@@ -400,3 +400,14 @@ def test_lstm_sweeps(H, nseq, L, reverse):
     both("lstm_fwd", [xg, w_hh, h, gates, cst, nseq, L, H, reverse], tol=tol)
     # backward on the emulator's saved gates / cell states (identical inputs for both sides)
     both("lstm_bwd", [rnd(nseq, L, H), gates, cst, w_hh, nan(nseq, L, 4 * H), nseq, L, H, reverse], tol=tol)
+
+
+def test_lstm_sweeps_both_directions_one_launch():
+    """reverse = 2: two slabs per buffer, grid.y = direction."""
+    H, nseq, L = 128, 21, 40
+    xg = rnd(2, nseq, L, 4 * H)
+    w_hh = rnd(2, 4 * H, H, scale=H ** -0.5)
+    h, gates, cst = nan(2, nseq, L, H), nan(2, nseq, L, 4 * H), nan(2, nseq, L, H)
+    both("lstm_fwd", [xg, w_hh, h, gates, cst, nseq, L, H, 2])
+    both("lstm_bwd", [rnd(2, nseq, L, H), gates, cst, w_hh, nan(2, nseq, L, 4 * H), nseq, L, H, 2])
+
