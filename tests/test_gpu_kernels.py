@@ -120,6 +120,15 @@ def test_gemm_gln_prologue_and_stats_epilogue():
                              epi_alpha=alpha, epi_stats=zstats(B)))
 
 
+@pytest.mark.parametrize("B,M,T", [(2, 256, 333), (3, 512, 1000), (1, 128, 4096)])
+def test_gemm_conv1_shape_k128(B, M, T):
+    """The TCN conv1 form at its real contraction length (K = 128): also the shape of the persistent variant (SEPK_PERSIST=1)."""
+    K = 128
+    ldt, X, A, bias = _gemm_common(B, M, K, T)
+    both("pw_gemm", [], dict(B=B, M=M, K=K, T=T, ldt=ldt, A=A, X=X, Y=nan(B, M, ldt), bias=bias, epi_flags=EPI_STATS_PRELU,
+                             epi_alpha=torch.tensor([0.25]), epi_stats=zstats(B), eps=1e-12))
+
+
 @pytest.mark.parametrize("M,T", [(256, 333), (128, 128), (192, 200)])
 def test_gemm_stats_epilogue_specialised_and_generic(M, T):
     """TCN conv1 form (no prologue, PReLU statistics): M % 128 == 0 takes the compile-time-flag instantiation without row
