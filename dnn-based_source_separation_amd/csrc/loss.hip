@@ -212,6 +212,66 @@ __global__ __launch_bounds__(64) void sinkhorn_bwd_kernel(const float* __restric
     }
 }
 
+// ---- row difference sums: the O(T) part of the distance criteria and plain SDR ---------------------------
+// One workgroup per row (rows = every leading index of the reduced axis).  sums[row] = {sum |x-t|, sum (x-t)^2,
+// sum t^2}: fp32 partials per thread over <= T/256 elements, fp64 across the workgroup.
+template <bool VEC>
+__global__ __launch_bounds__(256) void rowdiff_sums_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                           double* __restrict__ sums, int T) {
+    __shared__ double red[4];
+    const int64_t base = (int64_t)blockIdx.x * T;
+    float sa = 0.f, sq = 0.f, st = 0.f;
+    if (VEC) {
+        const float4* x4 = reinterpret_cast<const float4*>(x + base);
+        const float4* t4 = reinterpret_cast<const float4*>(t + base);
+        for (int i = threadIdx.x; i < T / 4; i += 256) {
+            const float4 a = x4[i], b = t4[i];
+            const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
+            sa += (fabsf(d0) + fabsf(d1)) + (fabsf(d2) + fabsf(d3));
+            sq = fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, fmaf(d3, d3, sq))));
+            st = fmaf(b.x, b.x, fmaf(b.y, b.y, fmaf(b.z, b.z, fmaf(b.w, b.w, st))));
+        }
+    } else {
+        for (int i = threadIdx.x; i < T; i += 256) {
+            const float b = t[base + i], d = x[base + i] - b;
+            sa += fabsf(d);
+            sq = fmaf(d, d, sq);
+            st = fmaf(b, b, st);
+        }
+    }
+    const double ra = block_sum_256<double>((double)sa, red);
+    const double rq = block_sum_256<double>((double)sq, red);
+    const double rt = block_sum_256<double>((double)st, red);
+    if (threadIdx.x == 0) {
+        sums[3 * (int64_t)blockIdx.x + 0] = ra;
+        sums[3 * (int64_t)blockIdx.x + 1] = rq;
+        sums[3 * (int64_t)blockIdx.x + 2] = rt;
+    }
+}
+
+// dx[row][i] = c_abs[row] * sign(x - t) + c_sq[row] * (x - t); grid = (column chunks of 1024, rows).
+template <bool VEC>
+__global__ __launch_bounds__(256) void rowdiff_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                          const float* __restrict__ c_abs, const float* __restrict__ c_sq,
+                                                          float* __restrict__ dx, int T) {
+    const int64_t base = (int64_t)blockIdx.y * T;
+    const float ca = c_abs ? c_abs[blockIdx.y] : 0.f, cs = c_sq ? c_sq[blockIdx.y] : 0.f;
+    auto g = [&](float d) { return fmaf(cs, d, d > 0.f ? ca : (d < 0.f ? -ca : 0.f)); };
+    if (VEC) {
+        const int i = blockIdx.x * 256 + threadIdx.x;
+        if (i < T / 4) {
+            const float4 a = reinterpret_cast<const float4*>(x + base)[i], b = reinterpret_cast<const float4*>(t + base)[i];
+            reinterpret_cast<float4*>(dx + base)[i] = make_float4(g(a.x - b.x), g(a.y - b.y), g(a.z - b.z), g(a.w - b.w));
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = blockIdx.x * 1024 + k * 256 + threadIdx.x;
+            if (i < T) dx[base + i] = g(x[base + i] - t[base + i]);
+        }
+    }
+}
+
 // ---- clip + Adam on a flat fp32 buffer ----------------------------------------------------------
 __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, double* __restrict__ out, int64_t n) {
     __shared__ double red[4];
@@ -306,6 +366,26 @@ extern "C" int sep_sinkhorn_bwd(const float* C, const double* zwork, const float
     const size_t smem = (size_t)(n * n + n) * sizeof(double);
     hipLaunchKernelGGL(sinkhorn_bwd_kernel, dim3(B), dim3(64), smem, (hipStream_t)stream, C, zwork, dloss, dC, n, coldness, iters);
     SEP_CHECK_LAUNCH("sep_sinkhorn_bwd");
+    return 0;
+}
+
+extern "C" int sep_rowdiff_sums(const float* x, const float* t, double* sums, int64_t rows, int T, sep_stream_t stream) {
+    SEP_REQUIRE(x && t && sums && rows > 0 && rows < (1ll << 31) && T > 0, "sep_rowdiff_sums: bad arguments");
+    const bool vec = T % 4 == 0 && (((uintptr_t)x | (uintptr_t)t) & 15) == 0;
+    if (vec) hipLaunchKernelGGL(rowdiff_sums_kernel<true>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, t, sums, T);
+    else hipLaunchKernelGGL(rowdiff_sums_kernel<false>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, t, sums, T);
+    SEP_CHECK_LAUNCH("sep_rowdiff_sums");
+    return 0;
+}
+
+extern "C" int sep_rowdiff_bwd(const float* x, const float* t, const float* c_abs, const float* c_sq, float* dx, int64_t rows,
+                               int T, sep_stream_t stream) {
+    SEP_REQUIRE(x && t && dx && (c_abs || c_sq) && rows > 0 && rows < 65536 && T > 0, "sep_rowdiff_bwd: bad arguments");
+    const bool vec = T % 4 == 0 && (((uintptr_t)x | (uintptr_t)t | (uintptr_t)dx) & 15) == 0;
+    const dim3 grid((unsigned)((T + 1023) / 1024), (unsigned)rows);
+    if (vec) hipLaunchKernelGGL(rowdiff_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, t, c_abs, c_sq, dx, T);
+    else hipLaunchKernelGGL(rowdiff_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, t, c_abs, c_sq, dx, T);
+    SEP_CHECK_LAUNCH("sep_rowdiff_bwd");
     return 0;
 }
 

@@ -1,6 +1,6 @@
 """
-Scale-invariant SDR on MI355X.  API of reference src/criterion/sdr.py:122-231 (`sisdr`, `SISDR`, `NegSISDR`
-with `reduction`, `eps`, `forward(input, target, batch_mean=True)`, `.maximize`).
+SDR and scale-invariant SDR on MI355X.  API of reference src/criterion/sdr.py:6-231 (`sdr`, `SDR`, `NegSDR`, `sisdr`,
+`SISDR`, `NegSISDR` with `reduction`, `eps`, `forward(input, target, batch_mean=True)`, `.maximize`).
 
 The O(T) work is two kernels of libsepkernels: sep_sisdr_dots (the three dot products per pair, fp64
 accumulation) and sep_sisdr_bwd (analytic gradient applied elementwise); the value itself is formed from the
@@ -75,8 +75,22 @@ def sisdr(input, target, eps=EPS):
     return out.view(lead)
 
 
+def sdr(input, target, eps=EPS):
+    """
+    Args:
+        input, target: (batch_size, T) or (batch_size, n_sources, T) or (batch_size, n_sources, n_mics, T)
+    Returns:
+        10 log10((|target|^2 + eps) / (|target - input|^2 + eps)) over the last axis, shape input.shape[:-1]
+    """
+    from criterion.distance import row_distance
+    n_dims = input.dim()
+    assert n_dims in [2, 3, 4], "Only 2D or 3D or 4D tensor is acceptable, but given {}D tensor.".format(n_dims)
+    return row_distance(input, target, n_dims - 1, "sdr", eps=eps)
+
+
 class _SISDRBase(nn.Module):
     _sign = 1.0
+    _measure = staticmethod(lambda input, target, eps: sisdr(input, target, eps=eps))
 
     def __init__(self, reduction="mean", eps=EPS):
         super().__init__()
@@ -88,7 +102,7 @@ class _SISDRBase(nn.Module):
     def forward(self, input, target, batch_mean=True):
         n_dims = input.dim()
         assert n_dims in [2, 3, 4], "Only 2D or 3D or 4D tensor is acceptable, but given {}D tensor.".format(n_dims)
-        loss = self._sign * sisdr(input, target, eps=self.eps)
+        loss = self._sign * self._measure(input, target, self.eps)
         if self.reduction:
             dims = {3: 1, 4: (1, 2)}.get(n_dims)
             if dims is not None:
@@ -108,6 +122,24 @@ class SISDR(_SISDRBase):
 
 class NegSISDR(_SISDRBase):
     _sign = -1.0
+
+    @property
+    def maximize(self):
+        return False
+
+
+class SDR(_SISDRBase):
+    _sign = 1.0
+    _measure = staticmethod(lambda input, target, eps: sdr(input, target, eps=eps))
+
+    @property
+    def maximize(self):
+        return True
+
+
+class NegSDR(_SISDRBase):
+    _sign = -1.0
+    _measure = staticmethod(lambda input, target, eps: sdr(input, target, eps=eps))
 
     @property
     def maximize(self):

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("SEPKERNELS_LIB", os.path.normpath(os.path.join(_HERE,
 # ---- constants mirrored from include/sepkernels.h -------------------------------------------------
 PRO_NONE, PRO_PRELU, PRO_GLN, PRO_GLN_PRELU, PRO_GLN_BWD = 0, 1, 2, 3, 4
 EPI_STATS_PRELU, EPI_RESIDUAL, EPI_SIGMOID, EPI_PRELU_BWD, EPI_ROWSUMS, EPI_ROWSUMS_PRELU = 1, 2, 4, 8, 16, 32
-ABI_VERSION = 3
+ABI_VERSION = 4
 STATS_SLOTS = 16   # SEP_STATS_SLOTS: gLN statistics are double[B][STATS_SLOTS][2]
 
 _vp = ctypes.c_void_p
@@ -76,6 +76,8 @@ SIGNATURES = {
     "sep_pit_search": [_vp, _vp, _I, _I, _I, _I, _I, _vp, _vp, _vp],
     "sep_sinkhorn_fwd": [_vp] * 4 + [_I, _I, _F, _I, _vp],
     "sep_sinkhorn_bwd": [_vp] * 4 + [_I, _I, _F, _I, _vp],
+    "sep_rowdiff_sums": [_vp, _vp, _vp, _L, _I, _vp],
+    "sep_rowdiff_bwd": [_vp, _vp, _vp, _vp, _vp, _L, _I, _vp],
     "sep_sqnorm": [_vp, _vp, _L, _vp],
     "sep_adam_step": [_vp] * 5 + [_L] + [_F] * 7 + [_I, _vp],
     "sep_lstm_fwd": [_vp] * 5 + [_I] * 4 + [_vp],
@@ -272,6 +274,13 @@ class HipBackend:
     def sinkhorn_bwd(self, C, zwork, dloss, dC, B, n, coldness, iters):
         _check(load().sep_sinkhorn_bwd(_ptr(C, _f32), _ptr(zwork, _f64), _ptr(dloss, _f32), _ptr(dC, _f32), B, n, coldness, iters,
                                        _stream()), "sep_sinkhorn_bwd")
+
+    def rowdiff_sums(self, x, t, sums, rows, T):
+        _check(load().sep_rowdiff_sums(_ptr(x, _f32), _ptr(t, _f32), _ptr(sums, _f64), rows, T, _stream()), "sep_rowdiff_sums")
+
+    def rowdiff_bwd(self, x, t, c_abs, c_sq, dx, rows, T):
+        _check(load().sep_rowdiff_bwd(_ptr(x, _f32), _ptr(t, _f32), _ptr(c_abs, _f32), _ptr(c_sq, _f32), _ptr(dx, _f32), rows, T,
+                                      _stream()), "sep_rowdiff_bwd")
 
     def sqnorm(self, g, out, n):
         _check(load().sep_sqnorm(_ptr(g, _f32), _ptr(out, _f64), n, _stream()), "sep_sqnorm")

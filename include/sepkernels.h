@@ -33,7 +33,7 @@ extern "C" {
 
 typedef void* sep_stream_t; /* hipStream_t */
 
-#define SEP_ABI_VERSION 3
+#define SEP_ABI_VERSION 4
 #define SEP_STATS_SLOTS 16
 
 int sep_version(void);
@@ -255,6 +255,16 @@ int sep_sinkhorn_fwd(const float* C, double* zwork, float* loss, float* P, int B
                      sep_stream_t stream);
 int sep_sinkhorn_bwd(const float* C, const double* zwork, const float* dloss, float* dC, int B, int n, float coldness,
                      int iters, sep_stream_t stream);
+
+/* The O(T) part of the waveform-distance criteria (reference src/criterion/distance.py:7-285: L1Loss, L2Loss,
+ * SquaredError, MeanAbsoluteError, MeanSquaredError) and of plain SDR (src/criterion/sdr.py:6-22), over the last axis:
+ *   sums[row] = { sum |x-t|, sum (x-t)^2, sum t^2 }   (double [rows][3]; x, t float [rows][T])
+ *   dx[row][i] = c_abs[row] * sign(x-t) + c_sq[row] * (x-t)     (either coefficient vector may be NULL = 0)
+ * the per-row value and coefficients are a few scalars per row formed by the caller exactly as the reference formula
+ * states (mean / sqrt / log10 / eps placement).  rows < 65536 for the backward. */
+int sep_rowdiff_sums(const float* x, const float* t, double* sums, int64_t rows, int T, sep_stream_t stream);
+int sep_rowdiff_bwd(const float* x, const float* t, const float* c_abs, const float* c_sq, float* dx, int64_t rows, int T,
+                    sep_stream_t stream);
 
 /* clip_grad_norm_ + Adam of the train step (egs/wsj0-mix/common/src/driver.py:152-155), fused on a flat buffer:
  *   sqnorm[0] += sum g^2  (double, caller zeroes) ; then

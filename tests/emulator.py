@@ -447,6 +447,20 @@ class EmuBackend:
             dZ = dZ - torch.exp(zw[:, h]) * dZ.sum(dim, keepdim=True)
         dC.reshape(B, n, n).copy_((g * Pm - coldness * dZ).to(dC.dtype))
 
+    # ------------------------------------------------------------------ distance criteria
+    def rowdiff_sums(self, x, t, sums, rows, T):
+        d = (x.reshape(rows, T) - t.reshape(rows, T)).double()
+        sums.reshape(rows, 3).copy_(torch.stack([d.abs().sum(1), (d * d).sum(1), (t.reshape(rows, T).double() ** 2).sum(1)], dim=1))
+
+    def rowdiff_bwd(self, x, t, c_abs, c_sq, dx, rows, T):
+        d = x.reshape(rows, T) - t.reshape(rows, T)
+        g = torch.zeros_like(d)
+        if c_abs is not None:
+            g = g + c_abs.reshape(rows, 1) * torch.sign(d)
+        if c_sq is not None:
+            g = g + c_sq.reshape(rows, 1) * d
+        dx.reshape(rows, T).copy_(g)
+
     # ------------------------------------------------------------------ optimiser
     def sqnorm(self, g, out, n):
         out += (g.reshape(-1)[:n].double() ** 2).sum()

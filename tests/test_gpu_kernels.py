@@ -377,6 +377,24 @@ def test_sinkhorn(n, iters, beta):
     both("sinkhorn_bwd", [C, zw, rnd(B), nan(B, n, n), B, n, beta, iters], tol=1e-5)
 
 
+@pytest.mark.parametrize("rows,T", [(8, 32000), (6, 31999), (1, 5), (300, 257), (16, 88200)])
+def test_rowdiff_sums_and_bwd(rows, T):
+    x, t = rnd(rows, T), rnd(rows, T, scale=0.7)
+    x[0, :min(T, 3)] = t[0, :min(T, 3)]                        # exact ties: sign(0) = 0
+    both("rowdiff_sums", [x, t, nan(rows, 3).double(), rows, T], tol=1e-5)
+    ca, cs = rnd(rows), rnd(rows)
+    both("rowdiff_bwd", [x, t, ca, cs, nan(rows, T), rows, T], tol=1e-6)
+    both("rowdiff_bwd", [x, t, ca, None, nan(rows, T), rows, T], tol=1e-6)
+    both("rowdiff_bwd", [x, t, None, cs, nan(rows, T), rows, T], tol=1e-6)
+    # rows that start off a 16-byte boundary take the scalar path
+    xo, to = rnd(rows * T + 1)[1:].reshape(rows, T), rnd(rows * T + 1)[1:].reshape(rows, T)
+    gx, gt = torch.empty(rows * T + 1, device="cuda")[1:].reshape(rows, T).copy_(xo), torch.empty(rows * T + 1, device="cuda")[1:].reshape(rows, T).copy_(to)
+    sc, sg = torch.empty(rows, 3, dtype=torch.float64), torch.empty(rows, 3, dtype=torch.float64, device="cuda")
+    EMU.rowdiff_sums(xo, to, sc, rows, T)
+    HIP.rowdiff_sums(gx, gt, sg, rows, T)
+    assert (sg.cpu() - sc).abs().max() <= 1e-5 * sc.abs().max()
+
+
 def test_sqnorm_and_adam():
     n = 100003
     p, g, m, v = rnd(n), rnd(n, scale=3.0), rnd(n, scale=0.1), rnd(n, scale=0.1).abs()

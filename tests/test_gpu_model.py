@@ -317,3 +317,32 @@ def test_music_recipe_shapes_long_rows_and_generic_filterbank_paths():
     numeric = (vals[0] - vals[1]) / (2 * h)
     assert abs(analytic - numeric) <= 3e-2 * abs(numeric) + 1e-6, (analytic, numeric)
 
+
+
+def test_distance_and_sdr_criteria_on_gpu():
+    """criterion/distance.py + criterion/sdr.py:{SDR,NegSDR} (the music recipe's --criterion mae|mse|sdr) against the
+    reference formulas in fp64 torch: value and gradient 1e-5 relative."""
+    from criterion.distance import L1Loss, L2Loss, MeanAbsoluteError, MeanSquaredError
+    from criterion.sdr import NegSDR
+    g = torch.Generator().manual_seed(31)
+    t = 0.1 * torch.randn(2, 4, 2, 44100, generator=g)
+    x = t + 0.05 * torch.randn(2, 4, 2, 44100, generator=g)
+
+    def formulas(xd, td):
+        d = xd - td
+        sdr = 10 * torch.log10(((td ** 2).sum(-1) + 1e-12) / ((d ** 2).sum(-1) + 1e-12))
+        return {"mae": d.abs().mean(-1).mean((1, 2)).mean(0), "mse": (d ** 2).mean(-1).mean((1, 2)).mean(0),
+                "l1": d.abs().sum(2).mean((1, 2)).mean(0), "l2": torch.sqrt((d ** 2).sum((2, 3))).sum(1).mean(0),
+                "negsdr": -sdr.mean((1, 2)).mean(0)}
+
+    crits = {"mae": MeanAbsoluteError(dim=-1, reduction="mean"), "mse": MeanSquaredError(dim=-1, reduction="mean"),
+             "l1": L1Loss(dim=2), "l2": L2Loss(dim=(2, 3), reduction="sum"), "negsdr": NegSDR()}
+    for name, crit in crits.items():
+        xd = x.double().requires_grad_(True)
+        want = formulas(xd, t.double())[name]
+        want.backward()
+        xg = x.cuda().requires_grad_(True)
+        got = crit(xg, t.cuda())
+        got.backward()
+        assert abs(got.item() - want.item()) <= 1e-5 * abs(want.item()), name
+        assert _rel(xg.grad, xd.grad) <= 1e-5, name
