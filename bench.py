@@ -230,6 +230,20 @@ def main():
         sync()
         elapsed_instr = time.perf_counter() - t1
         timed.enabled = False
+    # Third pass (N = 1 only): the same K steps with sep_pw_gemm on the fp32 MFMA instruction instead of the default exact
+    # bf16 three-way split, reported beside the headline so that both arithmetics are on record from the same process.
+    arith_name = sepkernels.gemm_arith_name()
+    elapsed_f32 = None
+    if world == 1 and arith_name != "f32":
+        sepkernels.set_gemm_arith("f32")
+        step(mixture, sources)
+        sync()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            step(mixture, sources)
+        sync()
+        elapsed_f32 = time.perf_counter() - t2
+        sepkernels.set_gemm_arith(arith_name)
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -248,11 +262,18 @@ def main():
             "config": {"workload": "Conv-TasNet paper-best (N=512,L=16,B=128,H=512,Sc=128,P=3,X=8,R=3) 2-spk, 4 s @ 8 kHz "
                                    "synthetic mixtures, {} utterances/GPU, fwd + PIT(NegSI-SDR) + bwd + clip(5) + Adam".format(args.batch),
                        "global_batch": world * args.batch, "frames_per_utterance": F, "parallelism": "dp{}".format(world),
-                       "utt_per_s": value / F, "samples_per_s": value / F * T_SAMPLES, "final_loss": float(loss)},
+                       "utt_per_s": value / F, "samples_per_s": value / F * T_SAMPLES, "final_loss": float(loss),
+                       "gemm_arith": arith_name + (" (fp32 operands split exactly into 3 bf16 parts, 6 of 9 part products on the bf16 "
+                                                   "MFMA, fp32 accumulation; error vs fp64 at the fp32-MFMA path's level)"
+                                                   if arith_name == "bf16x6" else " (v_mfma_f32_32x32x2_f32)")},
             "step_roofline": {"mfma_frac": value / world * fl_frame / (FP32_MFMA_PEAK_TFLOPS * 1e12),
                               "hbm_frac": value / world * by_frame / (HBM_PEAK_TBS * 1e12),
                               "algorithmic_flop_per_frame": fl_frame, "algorithmic_bytes_per_frame": by_frame},
         }
+        if elapsed_f32 is not None:
+            out["fp32_mfma_pass"] = {"value": frames_per_step * args.steps / elapsed_f32, "unit": "frames/s",
+                                     "ms_per_step": 1e3 * elapsed_f32 / args.steps,
+                                     "what": "same process, same K steps, SEP_ARITH_F32 for every sep_pw_gemm"}
         if not args.no_kernel_timing:
             n, ms, fl = timed.summary("pw_gemm")
             nw, msw, flw = timed.summary("pw_wgrad")
@@ -262,7 +283,9 @@ def main():
                                "launches_per_step": n / args.steps, "avg_launch_ms": ms / max(n, 1),
                                "flop_per_launch_avg": fl / max(n, 1), "share_of_step": ms / (1e3 * elapsed_instr),
                                "measured": "HIP events around every launch, second pass of the same {} steps "
-                                           "({:.2f} ms/step with the events in)".format(args.steps, 1e3 * elapsed_instr / args.steps)}
+                                           "({:.2f} ms/step with the events in)".format(args.steps, 1e3 * elapsed_instr / args.steps),
+                               "arith": arith_name,
+                               "peak_is": "dense fp32 MFMA (v_mfma_f32_32x32x2_f32); achieved = algorithmic fp32 flop / time"}
             out["roofline"].update(pmc_traffic(timed.variants))
             achw = flw / (msw * 1e-3) / 1e12 if msw > 0 else 0.0
             out["roofline_wgrad"] = {"bound": "mfma", "kernel": "pw_wgrad_direct_kernel", "achieved": achw, "peak": FP32_MFMA_PEAK_TFLOPS,

@@ -21,6 +21,7 @@
 // on the same XCD (blockIdx % 8) so the tile is fetched from HBM once and re-read from that L2.
 #include "common.hpp"
 #include <stdlib.h>
+#include <string.h>
 #include <stddef.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -514,6 +515,24 @@ constexpr int NST = 4;      // ring depth of the weight-gradient kernel
 
 // s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier as BUILTINS: the compiler's waitcnt pass then knows every counter is zero
 // here and emits counted lgkmcnt(N) waits afterwards (behind an opaque asm it falls back to lgkmcnt(0) everywhere)
+// all but the newest `keep4` DMA instructions of this wave have landed (keep4 in {0, 4}), then the barrier
+__device__ __forceinline__ void wait_keep4_and_barrier(const bool keep4) {
+    asm volatile("" ::: "memory");
+    if (keep4) __builtin_amdgcn_s_waitcnt(0x0074);
+    else __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// all but the DMAs of the newest `chunks` chunks (4 instructions each) of this wave have landed, then the barrier
+__device__ __forceinline__ void wait_chunks_and_barrier(const int chunks) {
+    asm volatile("" ::: "memory");
+    if (chunks >= 3) __builtin_amdgcn_s_waitcnt(0x007c);
+    else if (chunks == 2) __builtin_amdgcn_s_waitcnt(0x0078);
+    else if (chunks == 1) __builtin_amdgcn_s_waitcnt(0x0074);
+    else __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 __device__ __forceinline__ void wait_all_and_barrier() {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0x0070);
@@ -566,16 +585,16 @@ __device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
 //   PRO == GLN_BWD streams a third operand (the pre-activation a), forms d(pre-activation) on the fragments, and the
 //   wr == 0 waves of row tile 0 write it back for the weight-gradient GEMM and accumulate the PReLU slope gradient.
 // ======================================================================================
-constexpr int OMAXK = 768;
+constexpr int OMAXK = 512;      // rows of the per-row affine table in LDS (3 stages x 3 workgroups per CU must fit 160 KiB)
 #ifdef SEP_EXP_STAGGER
 __device__ int g_gemm_stagger = 0;
 __device__ unsigned g_cu_arrivals[4096];
 #endif
 
-template <bool AUX>
+template <bool AUX, int NS = 2>
 struct __attribute__((aligned(16))) DirectSmem {
-    float As[2][DK * 128];
-    float Bs[2][DK * 128];
+    float As[NS][DK * 128];
+    float Bs[NS][DK * 128];
     float Cs[AUX ? 2 : 1][AUX ? DK * 128 : 4];
     float sc[OMAXK];
     float sh[AUX ? 4 : OMAXK];
@@ -585,12 +604,58 @@ struct __attribute__((aligned(16))) DirectSmem {
 #ifndef SEP_GLN_OCC
 #define SEP_GLN_OCC 4       // measured: 4 blocks/CU with ~40 B of spill (outside the hot loop) = 3 blocks/CU spill-free (182 vs 186 us on the heads GEMM)
 #endif
-template <bool TRANS_A, int PRO, bool SPLIT, int EF>
-__global__ __launch_bounds__(256, (PRO == SEP_PRO_GLN_BWD ? 3 : PRO >= SEP_PRO_GLN ? SEP_GLN_OCC : 4)) void pw_gemm_direct_kernel(const sep_gemm_desc d) {
+// AR selects the arithmetic of the contraction:
+//   0  v_mfma_f32_32x32x2_f32 on the fp32 fragments (157 TF/s peak).
+//   1  fp32 by exact three-way bf16 splitting: every fragment value x = hi + mid + lo with each part a truncated bf16
+//      (8 + 8 + 8 significand bits: the sum is EXACT), and x*y = hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi
+//      (+ three terms <= 2^-24 |xy| that are dropped) on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 6 MFMAs of
+//      32 cycles per 16-deep chunk and tile pair instead of 8 of 64.  Error per product <= 2^-23 relative, i.e. the
+//      rounding of an fp32 multiply; measured against fp64 it is no worse than the fp32 MFMA path (tests).  The
+//      lane half lk already owns k = 8*lk .. 8*lk+7 of a chunk, which is the operand layout of the bf16 instruction.
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_t;
+
+// two fp32 values -> their (hi, mid, lo) bf16 parts packed {x0 low half, x1 high half}: 11 VALU instructions
+__device__ __forceinline__ void split3_pair(const float x0, const float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    hi = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    mid = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float q0 = r0 - __uint_as_float(v0 & 0xffff0000u), q1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    lo = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+}
+// the 8 chunk values of one 32-row (32-column) block -> three packed operands
+__device__ __forceinline__ void split3_frag(const float (&lo4)[4], const float (&hi4)[4], u32x4_t (&out)[3]) {
+    unsigned p[3][4];
+    split3_pair(lo4[0], lo4[1], p[0][0], p[1][0], p[2][0]);
+    split3_pair(lo4[2], lo4[3], p[0][1], p[1][1], p[2][1]);
+    split3_pair(hi4[0], hi4[1], p[0][2], p[1][2], p[2][2]);
+    split3_pair(hi4[2], hi4[3], p[0][3], p[1][3], p[2][3]);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) out[q] = u32x4_t{p[q][0], p[q][1], p[q][2], p[q][3]};
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4_t a, const u32x4_t b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+// acc += A * B on the split operands (6 of the 9 part products)
+__device__ __forceinline__ void mfma_split6(const u32x4_t (&a)[3], const u32x4_t (&b)[3], f32x16& acc) {
+    acc = mfma_bf16(a[0], b[2], acc);
+    acc = mfma_bf16(a[2], b[0], acc);
+    acc = mfma_bf16(a[1], b[1], acc);
+    acc = mfma_bf16(a[0], b[1], acc);
+    acc = mfma_bf16(a[1], b[0], acc);
+    acc = mfma_bf16(a[0], b[0], acc);
+}
+
+template <bool TRANS_A, int PRO, bool SPLIT, int EF, int AR = 0>
+__global__ __launch_bounds__(256, (AR == 1 ? 3 : PRO == SEP_PRO_GLN_BWD ? 3 : PRO >= SEP_PRO_GLN ? SEP_GLN_OCC : 4)) void pw_gemm_direct_kernel(const sep_gemm_desc d) {
     constexpr bool P_PRELU = PRO == SEP_PRO_PRELU || PRO == SEP_PRO_GLN_PRELU;
     constexpr bool P_GLN = PRO == SEP_PRO_GLN || PRO == SEP_PRO_GLN_PRELU;
     constexpr bool P_BWD = PRO == SEP_PRO_GLN_BWD;
-    __shared__ DirectSmem<P_BWD> sm;
+    static_assert(AR == 0 || PRO != SEP_PRO_GLN_BWD, "the split arithmetic has no GLN_BWD form");
+    constexpr int NS = AR == 1 ? 3 : 2;          // ring depth: the bf16 path consumes a chunk ~3x faster, so it prefetches two ahead
+    __shared__ DirectSmem<P_BWD, NS> sm;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: the DMA's LDS base goes to M0 without a waterfall loop
     const int wr = wid >> 1, wc = wid & 1;
@@ -701,9 +766,17 @@ __global__ __launch_bounds__(256, (PRO == SEP_PRO_GLN_BWD ? 3 : PRO >= SEP_PRO_G
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
 #ifndef SEP_ABL_NO_LOADS
+#ifdef SEP_ABL_B_FIXED
+            glds16_asm(d.X, 0u, lds_addr(&sm.Bs[stage][(4 * wid + 2 * q) * 128]));
+#else
             glds16_asm(baseB[q], offB, lds_addr(&sm.Bs[stage][(4 * wid + 2 * q) * 128]));
+#endif
             if (P_BWD) glds16_asm(baseC[q], offB, lds_addr(&sm.Cs[stage][(4 * wid + 2 * q) * 128]));
+#ifdef SEP_ABL_A_FIXED
+            glds16_asm(d.A, 0u, lds_addr(TRANS_A ? &sm.As[stage][(4 * wid + 2 * q) * 128] : &sm.As[stage][(2 * wid + q) * 256]));
+#else
             glds16_asm(baseA[q], offA[q], lds_addr(TRANS_A ? &sm.As[stage][(4 * wid + 2 * q) * 128] : &sm.As[stage][(2 * wid + q) * 256]));
+#endif
 #endif
             baseB[q] += stepB;
             if (P_BWD) baseC[q] += stepB;
@@ -771,39 +844,41 @@ __global__ __launch_bounds__(256, (PRO == SEP_PRO_GLN_BWD ? 3 : PRO >= SEP_PRO_G
     };
     const bool live0 = t0 + wc * 64 + l31 < d.T, live1 = t0 + wc * 64 + 32 + l31 < d.T;
     const unsigned st_lane_off = 4u * (unsigned)(8 * lk * d.ldt + l31);      // GLN_BWD store-back: this lane's byte offset in the chunk
-    auto mfma_half = [&](const int kc, const int h) {
-        const int kbase = kc * DK + 8 * lk + 4 * h;
+    auto apply_pro = [&](const int kc, const int h, const int kk) {
+        if (P_BWD) {
+            // d(pre-activation) = rstd*(gamma_k*dv - mg - xhat*mgx) * PReLU'(a)   on the fragments
+            const float gk = fs[h][kk];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            if (P_BWD) {
-                // d(pre-activation) = rstd*(gamma_k*dv - mg - xhat*mgx) * PReLU'(a)   on the fragments
-                const float gk = fs[h][kk];
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const bool live = ni ? live1 : live0;
-                    const float a = fc[h][ni][kk];
-                    const float u = prelu_f(a, alpha_p);
-                    const float xh = (u - mu) * rstd;
-                    const float du = rstd * (gk * fb[h][ni][kk] - mg - xh * mgx);
-                    const float da = live ? du * prelu_grad(a, alpha_p) : 0.f;
-                    fb[h][ni][kk] = da;
-                    if (writer) {
-                        if (live && a <= 0.f) dalpha_pro += du * a;
-                        // uniform row pointer (SGPR pair) + per-lane byte offset: the saddr form of global_store
-                        float* srow = d.pro_store + ((size_t)b * d.K + kc * DK + 4 * h + kk) * d.ldt + t0 + wc * 64 + ni * 32;
-                        *reinterpret_cast<float*>(reinterpret_cast<char*>(srow) + (size_t)st_lane_off) = da;
-                    }
-                }
-            } else if (PRO != SEP_PRO_NONE) {
-                const float scv = P_GLN ? fs[h][kk] : 1.f;
-                const float shv = P_GLN ? fh[h][kk] : 0.f;
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    float v = fb[h][ni][kk];
-                    if (P_PRELU) v = prelu_f(v, alpha_p);
-                    fb[h][ni][kk] = P_GLN ? v * scv + shv : v;
+            for (int ni = 0; ni < 2; ++ni) {
+                const bool live = ni ? live1 : live0;
+                const float a = fc[h][ni][kk];
+                const float u = prelu_f(a, alpha_p);
+                const float xh = (u - mu) * rstd;
+                const float du = rstd * (gk * fb[h][ni][kk] - mg - xh * mgx);
+                const float da = live ? du * prelu_grad(a, alpha_p) : 0.f;
+                fb[h][ni][kk] = da;
+                if (writer) {
+                    if (live && a <= 0.f) dalpha_pro += du * a;
+                    // uniform row pointer (SGPR pair) + per-lane byte offset: the saddr form of global_store
+                    float* srow = d.pro_store + ((size_t)b * d.K + kc * DK + 4 * h + kk) * d.ldt + t0 + wc * 64 + ni * 32;
+                    *reinterpret_cast<float*>(reinterpret_cast<char*>(srow) + (size_t)st_lane_off) = da;
                 }
             }
+        } else if (PRO != SEP_PRO_NONE) {
+            const float scv = P_GLN ? fs[h][kk] : 1.f;
+            const float shv = P_GLN ? fh[h][kk] : 0.f;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                float v = fb[h][ni][kk];
+                if (P_PRELU) v = prelu_f(v, alpha_p);
+                fb[h][ni][kk] = P_GLN ? v * scv + shv : v;
+            }
+        }
+    };
+    auto mfma_half = [&](const int kc, const int h) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            apply_pro(kc, h, kk);
 #ifndef SEP_ABL_NO_MFMA
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h][0][kk], fb[h][0][kk], acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h][0][kk], fb[h][1][kk], acc[0][1], 0, 0, 0);
@@ -811,6 +886,81 @@ __global__ __launch_bounds__(256, (PRO == SEP_PRO_GLN_BWD ? 3 : PRO >= SEP_PRO_G
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h][1][kk], fb[h][1][kk], acc[1][1], 0, 0, 0);
 #endif
         }
+    };
+    // AR == 1: whole-chunk steps.  prologue + split of chunk kc (VALU), then -- behind the barrier that says chunk kc+1 has
+    // landed -- the LDS reads of chunk kc+1 in three portions between the four groups of six bf16 MFMAs of chunk kc, so
+    // that no more than one portion of raw fragments is live beside the 48 packed operand registers.
+    auto read_a6 = [&](const int stage) {
+        const float* Ab = sm.As[stage];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (TRANS_A) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    fa[h][0][kk] = Ab[(8 * lk + 4 * h + kk) * 128 + wr * 64 + l31];
+                    fa[h][1][kk] = Ab[(8 * lk + 4 * h + kk) * 128 + wr * 64 + 32 + l31];
+                }
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    const int m = wr * 64 + mi * 32 + l31;
+                    const float* p = Ab + m * 16 + 4 * ((2 * lk + h) ^ ((m >> 2) & 3));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) fa[h][mi][e] = p[e];
+                }
+            }
+        }
+    };
+    auto read_b6 = [&](const int stage, const int ni) {
+        const float* Bb = sm.Bs[stage];
+        const float* Cb = sm.Cs[P_BWD ? stage : 0];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                fb[h][ni][kk] = Bb[(8 * lk + 4 * h + kk) * 128 + wc * 64 + ni * 32 + l31];
+                if (P_BWD) fc[h][ni][kk] = Cb[(8 * lk + 4 * h + kk) * 128 + wc * 64 + ni * 32 + l31];
+            }
+    };
+    auto step6 = [&](const int kc, const int stage, const int nstage) {
+        u32x4_t pa[2][3], pb[2][3];
+        if (P_GLN || P_BWD) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    fs[h][kk] = sm.sc[kc * DK + 8 * lk + 4 * h + kk];
+                    if (P_GLN) fh[h][kk] = sm.sh[kc * DK + 8 * lk + 4 * h + kk];
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) split3_frag(fa[0][i], fa[1][i], pa[i]);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) apply_pro(kc, h, kk);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) split3_frag(fb[0][i], fb[1][i], pb[i]);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool more = kc + 1 < nk;
+        if (more) {
+            // chunk kc+1 has landed (mine: all but the DMAs of chunk kc+2; everyone's: barrier), and every wave is past
+            // its reads of chunk kc's stage, which chunk kc+NS now overwrites
+            wait_keep4_and_barrier(NS == 3 && kc + 2 < nk);
+            if (kc + NS < nk) issue(stage);
+            read_a6(nstage);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_split6(pa[0], pb[0], acc[0][0]);
+        mfma_split6(pa[1], pb[0], acc[1][0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) read_b6(nstage, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_split6(pa[0], pb[1], acc[0][1]);
+        mfma_split6(pa[1], pb[1], acc[1][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) read_b6(nstage, 1);
+        __builtin_amdgcn_sched_barrier(0);
     };
     auto step = [&](const int kc, const int stage) {
         read_half(stage, 1, kc);
@@ -828,16 +978,43 @@ __global__ __launch_bounds__(256, (PRO == SEP_PRO_GLN_BWD ? 3 : PRO >= SEP_PRO_G
 
     PROF_STAMP(1);
     issue(0);
-    wait_all_and_barrier();
-    PROF_STAMP(2);
-    if (nk > 1) issue(1);
-    read_half(0, 0, 0);
-    int kc = 0;
-    for (; kc + 1 < nk; kc += 2) {       // two steps per trip so the stage index is a literal
-        step(kc, 0);
-        step(kc + 1, 1);
+    if (NS == 3 && nk > 1) {
+        issue(1);
+        wait_keep4_and_barrier(true);
+        if (nk > 2) issue(2);
+    } else {
+        wait_all_and_barrier();
+        if (nk > 1) issue(1);
     }
-    if (kc < nk) step(kc, 0);
+    PROF_STAMP(2);
+    if (AR == 0) read_half(0, 0, 0);
+    int kc = 0;
+    if (AR == 1) {
+        read_a6(0);
+        read_b6(0, 0);
+        read_b6(0, 1);
+        if (NS == 3) {
+            for (; kc + 2 < nk; kc += 3) {
+                step6(kc, 0, 1);
+                step6(kc + 1, 1, 2);
+                step6(kc + 2, 2, 0);
+            }
+            if (kc < nk) step6(kc, 0, 1);
+            if (kc + 1 < nk) step6(kc + 1, 1, 2);
+        } else {
+            for (; kc + 1 < nk; kc += 2) {
+                step6(kc, 0, 1);
+                step6(kc + 1, 1, 0);
+            }
+            if (kc < nk) step6(kc, 0, 1);
+        }
+    } else {
+        for (; kc + 1 < nk; kc += 2) {       // two steps per trip so the stage index is a literal
+            step(kc, 0);
+            step(kc + 1, 1);
+        }
+        if (kc < nk) step(kc, 0);
+    }
     PROF_STAMP(3);
     __syncthreads();
     PROF_STAMP(4);
@@ -1356,6 +1533,7 @@ extern "C" int sep_pw_gemm(const sep_gemm_desc* d, sep_stream_t stream) {
     SEP_REQUIRE(!d->k_split || (d->A2 && d->X2), "sep_pw_gemm: k_split without A2/X2");
     SEP_REQUIRE(!d->m_split || d->Y2, "sep_pw_gemm: m_split without Y2");
     SEP_REQUIRE(d->pro_mode >= 0 && d->pro_mode <= SEP_PRO_GLN_BWD, "sep_pw_gemm: bad pro_mode %d", d->pro_mode);
+    SEP_REQUIRE(d->arith == SEP_ARITH_F32 || d->arith == SEP_ARITH_BF16X6, "sep_pw_gemm: bad arith %d", d->arith);
     if (d->pro_mode == SEP_PRO_PRELU || d->pro_mode == SEP_PRO_GLN_PRELU || d->pro_mode == SEP_PRO_GLN_BWD)
         SEP_REQUIRE(d->pro_alpha, "sep_pw_gemm: prologue needs pro_alpha");
     if (d->pro_mode >= SEP_PRO_GLN)
@@ -1385,7 +1563,14 @@ extern "C" int sep_pw_gemm(const sep_gemm_desc* d, sep_stream_t stream) {
         }();
         (void)stagger_set;
 #endif
-#define SEP_LD(T, P, S, E) hipLaunchKernelGGL((pw_gemm_direct_kernel<T, P, S, E>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *d)
+        // curated combinations exist in both arithmetics (GLN_BWD: fp32 MFMA only -- its time is the prologue, measured equal)
+        const bool split6 = d->arith == SEP_ARITH_BF16X6;
+#define SEP_LD(T, P, S, E)                                                                                                                           \
+    do {                                                                                                                                             \
+        if (split6 && P != SEP_PRO_GLN_BWD)                                                                                                          \
+            hipLaunchKernelGGL((pw_gemm_direct_kernel<T, P, S, E, (P != SEP_PRO_GLN_BWD ? 1 : 0)>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *d); \
+        else hipLaunchKernelGGL((pw_gemm_direct_kernel<T, P, S, E, 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);                          \
+    } while (0)
         // 1. the (operand form, prologue, split, epilogue) combinations of the Conv-TasNet step, epilogue flags compile-time
         const int ef = d->epi_flags, pm = d->pro_mode;
         const bool tr = d->trans_a != 0, sp = d->k_split != 0;
@@ -1407,10 +1592,11 @@ extern "C" int sep_pw_gemm(const sep_gemm_desc* d, sep_stream_t stream) {
         else done = false;
         // 2. anything else: same kernels with the flags read at run time
         if (!done) {
-#define SEP_LAUNCH_DIRECT(T, P)                 \
-    do {                                        \
-        if (sp) SEP_LD(T, P, true, -1);         \
-        else SEP_LD(T, P, false, -1);           \
+#define SEP_LG(T, P, S) hipLaunchKernelGGL((pw_gemm_direct_kernel<T, P, S, -1, 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *d)
+#define SEP_LAUNCH_DIRECT(T, P)               \
+    do {                                      \
+        if (sp) SEP_LG(T, P, true);           \
+        else SEP_LG(T, P, false);             \
     } while (0)
             switch (pm * 2 + (tr ? 1 : 0)) {
                 case 0: SEP_LAUNCH_DIRECT(false, SEP_PRO_NONE); break;
@@ -1421,10 +1607,11 @@ extern "C" int sep_pw_gemm(const sep_gemm_desc* d, sep_stream_t stream) {
                 case 5: SEP_LAUNCH_DIRECT(true, SEP_PRO_GLN); break;
                 case 6: SEP_LAUNCH_DIRECT(false, SEP_PRO_GLN_PRELU); break;
                 case 7: SEP_LAUNCH_DIRECT(true, SEP_PRO_GLN_PRELU); break;
-                case 8: SEP_LD(false, SEP_PRO_GLN_BWD, false, -1); break;
-                default: SEP_LD(true, SEP_PRO_GLN_BWD, false, -1); break;
+                case 8: SEP_LG(false, SEP_PRO_GLN_BWD, false); break;
+                default: SEP_LG(true, SEP_PRO_GLN_BWD, false); break;
             }
 #undef SEP_LAUNCH_DIRECT
+#undef SEP_LG
         }
 #undef SEP_LD
     } else

@@ -17,8 +17,38 @@ LIB_PATH = os.environ.get("SEPKERNELS_LIB", os.path.normpath(os.path.join(_HERE,
 # ---- constants mirrored from include/sepkernels.h -------------------------------------------------
 PRO_NONE, PRO_PRELU, PRO_GLN, PRO_GLN_PRELU, PRO_GLN_BWD = 0, 1, 2, 3, 4
 EPI_STATS_PRELU, EPI_RESIDUAL, EPI_SIGMOID, EPI_PRELU_BWD, EPI_ROWSUMS, EPI_ROWSUMS_PRELU = 1, 2, 4, 8, 16, 32
-ABI_VERSION = 4
+ABI_VERSION = 5
 STATS_SLOTS = 16   # SEP_STATS_SLOTS: gLN statistics are double[B][STATS_SLOTS][2]
+ARITH_F32, ARITH_BF16X6 = 0, 1     # SEP_ARITH_*: how sep_pw_gemm forms its fp32 products (include/sepkernels.h)
+_ARITH_NAMES = {"f32": ARITH_F32, "bf16x6": ARITH_BF16X6}
+_gemm_arith = None
+
+
+def gemm_arith():
+    """Arithmetic requested of sep_pw_gemm when a call does not name one: SEPK_GEMM_ARITH = bf16x6 (default) | f32."""
+    global _gemm_arith
+    if _gemm_arith is None:
+        name = os.environ.get("SEPK_GEMM_ARITH", "bf16x6")
+        if name not in _ARITH_NAMES:
+            raise SepKernelsError("SEPK_GEMM_ARITH must be one of {} (got '{}')".format(sorted(_ARITH_NAMES), name))
+        _gemm_arith = _ARITH_NAMES[name]
+    return _gemm_arith
+
+
+def gemm_arith_name():
+    return {v: k for k, v in _ARITH_NAMES.items()}[gemm_arith()]
+
+
+def arith_code(name):
+    return _ARITH_NAMES[name]
+
+
+def set_gemm_arith(name):
+    """'f32' | 'bf16x6'; returns the previous setting's name."""
+    global _gemm_arith
+    prev = gemm_arith_name()
+    _gemm_arith = _ARITH_NAMES[name]
+    return prev
 
 _vp = ctypes.c_void_p
 _i32 = ctypes.c_int32
@@ -26,7 +56,7 @@ _i32 = ctypes.c_int32
 
 class GemmDesc(ctypes.Structure):
     _fields_ = [(n, _i32) for n in ("B", "M", "K", "T", "ldt", "trans_a", "k_split", "m_split", "pro_mode", "epi_flags",
-                                    "accumulate")] + [("eps", ctypes.c_float), ("count", ctypes.c_double)] + \
+                                    "accumulate", "arith")] + [("eps", ctypes.c_float), ("count", ctypes.c_double)] + \
                [(n, _vp) for n in ("A", "A2", "X", "X2", "Y", "Y2", "bias", "pro_alpha", "pro_stats", "pro_gamma", "pro_beta",
                                    "pro_aux", "pro_bsum", "pro_store", "pro_dalpha", "epi_alpha", "epi_stats", "epi_res",
                                    "epi_aux", "epi_dalpha", "epi_rowpart")]
@@ -145,9 +175,10 @@ class HipBackend:
                 pro_mode=PRO_NONE, epi_flags=0, accumulate=0, eps=1e-12, count=0.0, bias=None, pro_alpha=None,
                 pro_stats=None, pro_gamma=None, pro_beta=None, pro_aux=None, pro_bsum=None, pro_store=None,
                 pro_dalpha=None, epi_alpha=None, epi_stats=None, epi_res=None, epi_aux=None, epi_dalpha=None,
-                epi_rowpart=None):
+                epi_rowpart=None, arith=None):
         d = GemmDesc(B=B, M=M, K=K, T=T, ldt=ldt, trans_a=trans_a, k_split=k_split, m_split=m_split, pro_mode=pro_mode,
-                     epi_flags=epi_flags, accumulate=accumulate, eps=eps, count=float(count),
+                     epi_flags=epi_flags, accumulate=accumulate, arith=gemm_arith() if arith is None else arith, eps=eps,
+                     count=float(count),
                      A=_ptr(A, _f32), A2=_ptr(A2, _f32), X=_ptr(X, _f32), X2=_ptr(X2, _f32), Y=_ptr(Y, _f32), Y2=_ptr(Y2, _f32),
                      bias=_ptr(bias, _f32), pro_alpha=_ptr(pro_alpha, _f32), pro_stats=_ptr(pro_stats, _f64),
                      pro_gamma=_ptr(pro_gamma, _f32), pro_beta=_ptr(pro_beta, _f32), pro_aux=_ptr(pro_aux, _f32),

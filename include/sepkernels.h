@@ -33,7 +33,7 @@ extern "C" {
 
 typedef void* sep_stream_t; /* hipStream_t */
 
-#define SEP_ABI_VERSION 4
+#define SEP_ABI_VERSION 5
 #define SEP_STATS_SLOTS 16
 
 int sep_version(void);
@@ -56,6 +56,15 @@ const char* sep_last_error(void);
 #define SEP_EPI_ROWSUMS 16    /* epi_rowpart[b][m][t/64][0..1] = sum_t y, sum_t y*u, u = epi_aux (or PReLU(epi_aux)) */
 #define SEP_EPI_ROWSUMS_PRELU 32
 
+/* ---- arithmetic of the contraction (fp32 operands and fp32 accumulation in both) ------------------------------
+ * F32:    v_mfma_f32_32x32x2_f32 on the operands as they are.
+ * BF16X6: every operand value is split EXACTLY into three truncated-bf16 parts (8+8+8 significand bits) and
+ *         x*y = hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (the three dropped part
+ *         products are <= 2^-24 |xy| each); results agree with fp64 as closely as the F32 path's do (tests), at
+ *         6 x 32 instead of 8 x 64 matrix-pipe cycles per 16-deep chunk.  Inputs are assumed finite. */
+#define SEP_ARITH_F32 0
+#define SEP_ARITH_BF16X6 1
+
 /* Pointwise (1x1) convolution as a GEMM on MFMA (fp32 in / fp32 accumulate):
  *     Y[b][m][t] = epilogue( sum_k A[m][k] * prologue(X[b][k][t]) + bias[m] )
  * Replaces nn.Conv1d(kernel_size=1) at tdcn.py:86,173,175 and conv_tasnet.py:335,341 in the
@@ -69,6 +78,7 @@ typedef struct sep_gemm_desc {
     int32_t pro_mode;   /* SEP_PRO_* */
     int32_t epi_flags;  /* SEP_EPI_* bitmask; RESIDUAL applies to Y rows only */
     int32_t accumulate; /* 1: Y2 (or Y when m_split==0) += result instead of = */
+    int32_t arith;      /* SEP_ARITH_* */
     float eps;
     double count; /* number of valid elements per sample (C*T) of the gLN used by the prologue */
     const float* A;

@@ -21,6 +21,14 @@ HIP = sepkernels.HipBackend()
 G = torch.Generator().manual_seed(1234)
 
 
+@pytest.fixture(params=["bf16x6", "f32"])
+def arith(request):
+    """Both arithmetics of sep_pw_gemm (SEP_ARITH_*): exact three-way bf16 split on the bf16 MFMA, and the fp32 MFMA."""
+    prev = sepkernels.set_gemm_arith(request.param)
+    yield request.param
+    sepkernels.set_gemm_arith(prev)
+
+
 def rnd(*shape, scale=1.0):
     return (torch.randn(*shape, generator=G) * scale).float()
 
@@ -103,12 +111,12 @@ def _gemm_common(B, M, K, T):
 
 
 @pytest.mark.parametrize("B,M,K,T", [(2, 64, 128, 300), (1, 512, 128, 3999), (3, 128, 64, 129)])
-def test_gemm_plain_bias(B, M, K, T):
+def test_gemm_plain_bias(B, M, K, T, arith):
     ldt, X, A, bias = _gemm_common(B, M, K, T)
     both("pw_gemm", [], dict(B=B, M=M, K=K, T=T, ldt=ldt, A=A, X=X, Y=nan(B, M, ldt), bias=bias))
 
 
-def test_gemm_gln_prologue_and_stats_epilogue():
+def test_gemm_gln_prologue_and_stats_epilogue(arith):
     B, M, K, T = 2, 128, 256, 777
     ldt, X, A, bias = _gemm_common(B, M, K, T)
     X = X * 2 + 0.3
@@ -121,7 +129,7 @@ def test_gemm_gln_prologue_and_stats_epilogue():
 
 
 @pytest.mark.parametrize("B,M,T", [(2, 256, 333), (3, 512, 1000), (1, 128, 4096)])
-def test_gemm_conv1_shape_k128(B, M, T):
+def test_gemm_conv1_shape_k128(B, M, T, arith):
     """The TCN conv1 form at its real contraction length (K = 128): also the shape of the persistent variant (SEPK_PERSIST=1)."""
     K = 128
     ldt, X, A, bias = _gemm_common(B, M, K, T)
@@ -130,7 +138,7 @@ def test_gemm_conv1_shape_k128(B, M, T):
 
 
 @pytest.mark.parametrize("M,T", [(256, 333), (128, 128), (192, 200)])
-def test_gemm_stats_epilogue_specialised_and_generic(M, T):
+def test_gemm_stats_epilogue_specialised_and_generic(M, T, arith):
     """TCN conv1 form (no prologue, PReLU statistics): M % 128 == 0 takes the compile-time-flag instantiation without row
     predicates, M = 192 the run-time-flag one; T off the 128 grid exercises the column pre-mask of the edge tile."""
     B, K = 2, 64
@@ -139,7 +147,7 @@ def test_gemm_stats_epilogue_specialised_and_generic(M, T):
                              epi_alpha=torch.tensor([0.25]), epi_stats=zstats(B), eps=1e-12))
 
 
-def test_gemm_packed_heads_residual_accumulate():
+def test_gemm_packed_heads_residual_accumulate(arith):
     """[Wo;Ws] as one operand: rows < m_split -> Y (+residual), rows >= m_split -> Y2 (+=)."""
     B, Bn, Sc, H, T = 2, 128, 128, 256, 500
     ldt = 512
@@ -155,14 +163,14 @@ def test_gemm_packed_heads_residual_accumulate():
     both("pw_gemm", [], kw)
 
 
-def test_gemm_prelu_prologue_sigmoid():
+def test_gemm_prelu_prologue_sigmoid(arith):
     B, M, K, T = 2, 384, 64, 260
     ldt, X, A, bias = _gemm_common(B, M, K, T)
     both("pw_gemm", [], dict(B=B, M=M, K=K, T=T, ldt=ldt, A=A, X=X, Y=nan(B, M, ldt), bias=bias, pro_mode=PRO_PRELU,
                              pro_alpha=torch.tensor([0.25]), epi_flags=EPI_SIGMOID))
 
 
-def test_gemm_dgrad_two_sources_rowsums():
+def test_gemm_dgrad_two_sources_rowsums(arith):
     """dv2 = Wo^T dout + Ws^T dS with the gLN-backward row sums in the epilogue."""
     B, Bn, Sc, H, T = 2, 128, 64, 256, 700
     ldt = 768
@@ -174,7 +182,7 @@ def test_gemm_dgrad_two_sources_rowsums():
     both("pw_gemm", [], kw)
 
 
-def test_gemm_dgrad_prelu_bwd():
+def test_gemm_dgrad_prelu_bwd(arith):
     B, M, K, T = 2, 64, 384, 333
     ldt = 384
     Wm = rnd(K, M, scale=0.1)
@@ -184,7 +192,7 @@ def test_gemm_dgrad_prelu_bwd():
 
 
 @pytest.mark.parametrize("residual", [0, 1])
-def test_gemm_gln_bwd_prologue(residual):
+def test_gemm_gln_bwd_prologue(residual, arith):
     B, M, K, T = 2, 128, 256, 450
     ldt = 512
     W1 = rnd(K, M, scale=0.1)
@@ -222,6 +230,28 @@ def _wgrad_both(kw, tol=3e-4):
     if kw.get("partial_bias") is not None:
         assert torch.isfinite(gk["partial_bias"]).all()
         _reduce_check(ck["partial_bias"], gk["partial_bias"], tol)
+
+
+@pytest.mark.parametrize("K,scale", [(128, 1.0), (512, 1.0), (1024, 1e-3), (512, 1e4)])
+def test_gemm_split_arithmetic_is_as_accurate_as_fp32_mfma(K, scale):
+    """Against fp64: the error of the bf16x6 path is at the level of the fp32-MFMA path's (both are fp32 products with
+    fp32 accumulation), over wide dynamic range of the operands (the split is exact for any finite fp32 value)."""
+    B, M, T = 2, 256, 1000
+    ldt = 1024
+    X = padded(B, K, T, ldt) * torch.exp(3 * rnd(B, K, 1))          # rows of very different magnitude
+    X[..., T:] = 0
+    A = rnd(M, K) * scale
+    ref = torch.einsum("mk,bkt->bmt", A.double(), X.double())
+    err = {}
+    for name in ("f32", "bf16x6"):
+        Y = torch.full((B, M, ldt), float("nan"), device="cuda")
+        HIP.pw_gemm(B=B, M=M, K=K, T=T, ldt=ldt, A=A.cuda(), X=X.cuda(), Y=Y, arith=sepkernels.arith_code(name))
+        torch.cuda.synchronize()
+        d = (Y.cpu().double() - ref)[..., :T]
+        err[name] = (d.abs().max().item() / ref.abs().max().item(), (d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item())
+    assert err["bf16x6"][0] <= max(2 * err["f32"][0], 2e-7), err
+    assert err["bf16x6"][1] <= max(2 * err["f32"][1], 1e-7), err
+    assert err["f32"][0] <= 5e-6, err
 
 
 @pytest.mark.parametrize("B,M,N,T,ns", [(2, 256, 128, 999, 7), (1, 128, 16, 300, 3), (3, 64, 64, 130, 1), (2, 512, 128, 3999, 64)])

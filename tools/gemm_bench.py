@@ -15,10 +15,11 @@ from sepkernels import (EPI_PRELU_BWD, EPI_RESIDUAL, EPI_ROWSUMS, EPI_ROWSUMS_PR
 ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--only", default="")
+ap.add_argument("--ldt", type=int, default=4096)
 args = ap.parse_args()
 K = sepkernels.HipBackend()
 dev = "cuda"
-B, T, ldt = 16, 3999, 4096
+B, T, ldt = 16, 3999, args.ldt
 N, Bn, H, Sc, ns = 512, 128, 512, 128, 2
 f = lambda *s: torch.randn(*s, device=dev)
 z = lambda *s: torch.zeros(*s, device=dev)
