@@ -273,7 +273,7 @@ def main():
         if elapsed_f32 is not None:
             out["fp32_mfma_pass"] = {"value": frames_per_step * args.steps / elapsed_f32, "unit": "frames/s",
                                      "ms_per_step": 1e3 * elapsed_f32 / args.steps,
-                                     "what": "same process, same K steps, SEP_ARITH_F32 for every sep_pw_gemm"}
+                                     "what": "same process, same K steps, SEP_ARITH_F32 for every sep_pw_gemm / sep_pw_wgrad"}
         if not args.no_kernel_timing:
             n, ms, fl = timed.summary("pw_gemm")
             nw, msw, flw = timed.summary("pw_wgrad")
@@ -288,7 +288,7 @@ def main():
                                "peak_is": "dense fp32 MFMA (v_mfma_f32_32x32x2_f32); achieved = algorithmic fp32 flop / time"}
             out["roofline"].update(pmc_traffic(timed.variants))
             achw = flw / (msw * 1e-3) / 1e12 if msw > 0 else 0.0
-            out["roofline_wgrad"] = {"bound": "mfma", "kernel": "pw_wgrad_direct_kernel", "achieved": achw, "peak": FP32_MFMA_PEAK_TFLOPS,
+            out["roofline_wgrad"] = {"bound": "mfma", "kernel": "pw_wgrad_split_kernel" if arith_name == "bf16x6" else "pw_wgrad_direct_kernel", "achieved": achw, "peak": FP32_MFMA_PEAK_TFLOPS,
                                      "unit": "TFLOP/s", "frac": achw / FP32_MFMA_PEAK_TFLOPS, "launches_per_step": nw / args.steps,
                                      "avg_launch_ms": msw / max(nw, 1), "share_of_step": msw / (1e3 * elapsed_instr)}
         if world == 1 and not args.no_cpu_baseline:

@@ -33,7 +33,7 @@ extern "C" {
 
 typedef void* sep_stream_t; /* hipStream_t */
 
-#define SEP_ABI_VERSION 5
+#define SEP_ABI_VERSION 6
 #define SEP_STATS_SLOTS 16
 
 int sep_version(void);
@@ -120,6 +120,7 @@ typedef struct sep_wgrad_desc {
     int32_t x_mode; /* SEP_PRO_NONE / PRELU / GLN / GLN_PRELU */
     int32_t x_div;  /* X (and its gLN stats) are indexed with b / x_div */
     int32_t nsplit; /* number of partial slabs, <= B*ldt/32 */
+    int32_t arith;  /* SEP_ARITH_* */
     float eps;
     double count;
     const float* G;

@@ -125,7 +125,7 @@ class EmuBackend:
 
     def pw_wgrad(self, *, B, M, N, T, ldt, G, X, partial, nsplit, G2=None, g_split=0, Gaux=None, g_mul=0, g_div=1,
                  x_mode=PRO_NONE, x_div=1, eps=1e-12, count=0.0, x_alpha=None, x_stats=None, x_gamma=None, x_beta=None,
-                 partial_bias=None):
+                 partial_bias=None, arith=None):
         dt = G.dtype
         m1 = g_split if g_split else M
         Gf = G.reshape(B, m1, ldt)

@@ -255,13 +255,13 @@ def test_gemm_split_arithmetic_is_as_accurate_as_fp32_mfma(K, scale):
 
 
 @pytest.mark.parametrize("B,M,N,T,ns", [(2, 256, 128, 999, 7), (1, 128, 16, 300, 3), (3, 64, 64, 130, 1), (2, 512, 128, 3999, 64)])
-def test_wgrad_plain(B, M, N, T, ns):
+def test_wgrad_plain(B, M, N, T, ns, arith):
     ldt = (T + 127) // 128 * 128
     part, pb = _wg_out(ns, M, N)
     _wgrad_both(dict(B=B, M=M, N=N, T=T, ldt=ldt, G=padded(B, M, T, ldt), X=padded(B, N, T, ldt), partial=part, partial_bias=pb, nsplit=ns))
 
 
-def test_wgrad_two_sources_gln_prelu():
+def test_wgrad_two_sources_gln_prelu(arith):
     B, Bn, Sc, H, T, ns = 2, 128, 64, 256, 640, 5
     ldt = 640
     z = padded(B, H, T, ldt)
@@ -272,7 +272,7 @@ def test_wgrad_two_sources_gln_prelu():
                      count=H * T, eps=1e-12, partial=part, partial_bias=pb, nsplit=ns))
 
 
-def test_wgrad_latent_product_and_prelu():
+def test_wgrad_latent_product_and_prelu(arith):
     B, n_src, N, LC, T, ns = 2, 3, 64, 16, 500, 4
     ldt = 512
     m, w = padded(B * n_src, N, T, ldt), padded(B, N, T, ldt)

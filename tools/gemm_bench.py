@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--only", default="")
 ap.add_argument("--ldt", type=int, default=4096)
+ap.add_argument("--nsplit-scale", type=float, default=1.0)
 args = ap.parse_args()
 K = sepkernels.HipBackend()
 dev = "cuda"
@@ -72,6 +73,7 @@ for name, kw in cases.items():
 for name, kw in wcases.items():
     if args.only and not any(name.startswith(o) for o in args.only.split(",")):
         continue
+    kw = dict(kw, nsplit=int(round(kw["nsplit"] * args.nsplit_scale)))
     ns_ = kw["nsplit"]
     part = torch.empty(ns_, kw["M"], kw["N"], device=dev)
     pb = torch.empty(ns_, kw["M"], device=dev)
