@@ -170,6 +170,7 @@ def main():
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="utterances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-f32-pass", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -234,7 +235,7 @@ def main():
     # bf16 three-way split, reported beside the headline so that both arithmetics are on record from the same process.
     arith_name = sepkernels.gemm_arith_name()
     elapsed_f32 = None
-    if world == 1 and arith_name != "f32":
+    if world == 1 and arith_name != "f32" and not args.no_f32_pass:
         sepkernels.set_gemm_arith("f32")
         step(mixture, sources)
         sync()

@@ -11,12 +11,16 @@
 //   gemm_epilogue<EF>             LDS-transposed float4 epilogue shared by both GEMM kernels (bias, PReLU statistics,
 //                                 residual / skip accumulate, sigmoid, PReLU backward, gLN-backward row sums)
 //   pw_gemm_kernel                register-staged GEMM; fallback for contractions that are not a multiple of 16
-//   pw_gemm_direct_kernel<...>    THE fast path: LDS-DMA 2-stage ring, 4 workgroups per CU, half-chunk software pipeline,
-//                                 prologue (PReLU / gLN / gLN backward) on the B fragments -- design notes at the kernel
+//   pw_gemm_direct_kernel<...,AR> THE fast path, LDS-DMA ring, prologue (PReLU / gLN / gLN backward) on the B fragments.
+//                                 AR = 1 (SEP_ARITH_BF16X6, default): fp32 products by exact three-way bf16 split on
+//                                 v_mfma_f32_32x32x16_bf16, 3-stage ring, 3 workgroups per CU, whole-chunk steps;
+//                                 AR = 0 (SEP_ARITH_F32): v_mfma_f32_32x32x2_f32, 2-stage ring, 4 workgroups per CU,
+//                                 half-chunk software pipeline -- design notes at the kernel
 //   pw_wgrad_kernel               register-staged weight gradient; fallback (g_mul = decoder basis gradient)
-//   pw_wgrad_direct_kernel<X>     fast weight gradient: 8-wave workgroups, two wave groups split the contraction
+//   pw_wgrad_split_kernel<X>      weight gradient in the split arithmetic: 4-wave workgroups, 3 per CU, 3-stage ring
+//   pw_wgrad_direct_kernel<X>     weight gradient on the fp32 MFMA: 8-wave workgroups, two wave groups split the contraction
 //   reduce_slabs / f64_to_f32     deterministic second stages
-// Common to all: 128x128 output tile, each wave a 64x64 sub-tile = 2x2 v_mfma_f32_32x32x2_f32 accumulators (64 VGPRs);
+// Common to all: 128x128 output tile, each wave a 64x64 sub-tile = 2x2 32x32 MFMA accumulators (64 VGPRs);
 // the normalised tensors v1, v2 of the reference never exist in HBM; workgroups that share an X column tile are placed
 // on the same XCD (blockIdx % 8) so the tile is fetched from HBM once and re-read from that L2.
 #include "common.hpp"
@@ -1231,248 +1235,8 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(const sep_wgrad_desc d
 // The gLN / PReLU prologue of X acts on the B fragments (per-lane row affine x per-sample mean/rstd table in LDS); bias
 // row sums fall out of the A fragments.  Frames >= T need no mask: G is zero there by the layout contract.
 // ======================================================================================
-// Weight gradient in the split arithmetic (SEP_ARITH_BF16X6, see pw_gemm_direct_kernel): the same tiles, DMA layout and
-// fragment reads as pw_wgrad_direct_kernel, but 4-wave workgroups that own a whole slab (no in-block split of the
-// contraction: the packed operands need 168 registers, so three independent workgroups per CU give the overlap that two
-// 8-wave ones gave), a 3-stage ring, whole-chunk steps: prologue + split of chunk i (VALU), barrier, then the LDS reads
-// of chunk i+1 in three portions between the four groups of six bf16 MFMAs.  The caller uses ~1.5x the slabs.
-// ======================================================================================
+
 constexpr int WMAXB = 256;      // samples whose gLN constants fit the LDS table
-struct __attribute__((aligned(16))) WSplitSmem {
-    float Gs[3][128 * DK];
-    float Xs[3][128 * DK];
-    float mu[WMAXB];
-    float rstd[WMAXB];
-};
-
-template <int XMODE>
-__global__ __launch_bounds__(256, 3) void pw_wgrad_split_kernel(const sep_wgrad_desc d) {
-    constexpr bool X_GLN = XMODE == SEP_PRO_GLN || XMODE == SEP_PRO_GLN_PRELU;
-    constexpr bool X_PRELU = XMODE == SEP_PRO_PRELU || XMODE == SEP_PRO_GLN_PRELU;
-    constexpr int NS = 3;
-    __shared__ WSplitSmem sm;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wid >> 1, wc = wid & 1;
-    const int lk = lane >> 5, l31 = lane & 31;
-    const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
-    const int ntiles = ntm * ntn;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, j = bid >> 3;
-    const int tile = j % ntiles;
-    const int s = (j / ntiles) * 8 + xcd;
-    if (s >= d.nsplit) return;
-    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
-
-    const int cps_t = d.ldt / DK;                  // chunks per sample
-    const long chunks_total = (long)d.B * cps_t;
-    const long cper = (chunks_total + d.nsplit - 1) / d.nsplit;
-    const long c_begin = (long)s * cper;
-    long c_end = c_begin + cper;
-    if (c_end > chunks_total) c_end = chunks_total;
-    const int nk = (int)(c_end > c_begin ? c_end - c_begin : 0);
-
-    const float alpha_x = X_PRELU ? d.x_alpha[0] : 0.f;
-    if (X_GLN) {
-        const int nb = d.B / d.x_div;
-        for (int bx = tid; bx < nb; bx += 256) {
-            float mu, rstd;
-            gln_mu_rstd(d.x_stats + (size_t)bx * SEP_STATS_SLOTS * 2, d.count, d.eps, mu, rstd);
-            sm.mu[bx] = mu; sm.rstd[bx] = rstd;
-        }
-    }
-    float xg[2] = {0.f, 0.f}, xb[2] = {0.f, 0.f};
-    if (X_GLN) {
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int n = n0 + wc * 64 + ni * 32 + l31;
-            if (n < d.N) { xg[ni] = d.x_gamma[n]; xb[ni] = d.x_beta[n]; }
-        }
-    }
-    asm volatile("" :: "v"(xg[0]), "v"(xg[1]), "v"(xb[0]), "v"(xb[1]), "v"(alpha_x));      // consumed before the first asm DMA
-
-    const bool gsecond = d.g_split && m0 >= d.g_split;
-    const float* Gsrc = gsecond ? d.G2 : d.G;
-    const int Mg = gsecond ? d.M - d.g_split : (d.g_split ? d.g_split : d.M);
-    const int mg0 = gsecond ? m0 - d.g_split : m0;
-    const int Mg_lim = (d.M < m0 + BM ? d.M : m0 + BM) - (gsecond ? d.g_split : 0);
-
-    const int r16 = lane >> 2, cch = (lane & 3) ^ ((r16 >> 2) & 3);
-    unsigned voffG[2], voffX[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int g16 = 2 * wid + q;
-        int mm = mg0 + 16 * g16 + r16;
-        if (mm > Mg_lim - 1) mm = Mg_lim - 1;
-        voffG[q] = 4u * (unsigned)(mm * d.ldt + 4 * cch);
-        int nn = n0 + 16 * g16 + r16;
-        if (nn > d.N - 1) nn = d.N - 1;
-        voffX[q] = 4u * (unsigned)(nn * d.ldt + 4 * cch);
-    }
-    int ib = (int)(c_begin / cps_t), it = (int)(c_begin % cps_t);
-    int ibx = ib / d.x_div, ibm = ib % d.x_div;
-    int ct = it, cbx = ibx, cbm = ibm;
-    auto issue = [&](const int stage) {
-        const float* bG = Gsrc + (size_t)ib * Mg * d.ldt + it * DK;
-        const float* bX = d.X + (size_t)ibx * d.N * d.ldt + it * DK;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            glds16_asm(bG, voffG[q], lds_addr(&sm.Gs[stage][(2 * wid + q) * 256]));
-            glds16_asm(bX, voffX[q], lds_addr(&sm.Xs[stage][(2 * wid + q) * 256]));
-        }
-        if (++it >= cps_t) {
-            it = 0; ++ib;
-            if (++ibm == d.x_div) { ibm = 0; ++ibx; }
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-    float bias_acc[2] = {0.f, 0.f};
-    const bool do_bias = d.partial_bias != nullptr && (tile % ntn) == 0 && wc == 0;
-
-    float fa[2][2][4], fb[2][2][4];      // [half][mi|ni][frame]
-    auto read_g = [&](const int stage) {
-        const float* Gb = sm.Gs[stage];
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                const int m = wr * 64 + mi * 32 + l31;
-                const float* p = Gb + m * 16 + 4 * ((2 * lk + h) ^ ((m >> 2) & 3));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) fa[h][mi][e] = p[e];
-            }
-    };
-    auto read_x = [&](const int stage, const int ni) {
-        const float* Xb = sm.Xs[stage];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int n = wc * 64 + ni * 32 + l31;
-            const float* p = Xb + n * 16 + 4 * ((2 * lk + h) ^ ((n >> 2) & 3));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) fb[h][ni][e] = p[e];
-        }
-    };
-    float s_mu = 0.f, s_rstd = 1.f;      // the current sample's statistics, wave-uniform (SGPRs)
-    auto set_sample = [&]() {
-        if (X_GLN) {
-            s_mu = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sm.mu[cbx])));
-            s_rstd = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sm.rstd[cbx])));
-        }
-    };
-    auto step = [&](const int i, const int stage, const int nstage) {
-        u32x4_t pa[2][3], pb[2][3];
-        if (do_bias) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) bias_acc[mi] += fa[h][mi][kk];
-        }
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) split3_frag(fa[0][mi], fa[1][mi], pa[mi]);
-        if (XMODE != SEP_PRO_NONE) {
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const float scv = xg[ni] * s_rstd, shv = xb[ni] - s_mu * scv;      // re-formed per chunk: four registers fewer across the MFMAs
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        float v = fb[h][ni][kk];
-                        if (X_PRELU) v = prelu_f(v, alpha_x);
-                        fb[h][ni][kk] = X_GLN ? v * scv + shv : v;
-                    }
-            }
-        }
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) split3_frag(fb[0][ni], fb[1][ni], pb[ni]);
-        __builtin_amdgcn_sched_barrier(0);
-        const bool more = i + 1 < nk;
-        if (more) {
-            // chunk i+1 has landed (mine: all but the DMAs of chunk i+2; everyone's: barrier); every wave holds chunk i in
-            // registers, so chunk i+3 may overwrite its stage
-            wait_keep4_and_barrier(i + 2 < nk);
-            if (i + NS < nk) issue(stage);
-            read_g(nstage);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_split6(pa[0], pb[0], acc[0][0]);
-        mfma_split6(pa[1], pb[0], acc[1][0]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) read_x(nstage, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_split6(pa[0], pb[1], acc[0][1]);
-        mfma_split6(pa[1], pb[1], acc[1][1]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) read_x(nstage, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        // the chunk just computed was frame chunk ct of sample cbx
-        if (++ct >= cps_t) {
-            ct = 0;
-            if (++cbm == d.x_div) { cbm = 0; ++cbx; }
-            if (more) set_sample();
-        }
-    };
-
-    __syncthreads();                                              // mu/rstd table visible; before the first DMA so it drains nothing
-    set_sample();
-    if (nk > 0) {
-        issue(0);
-        if (nk > 1) {
-            issue(1);
-            wait_keep4_and_barrier(true);
-            if (nk > 2) issue(2);
-        } else
-            wait_all_and_barrier();
-        read_g(0);
-        read_x(0, 0);
-        read_x(0, 1);
-        int i = 0;
-        for (; i + 2 < nk; i += 3) {
-            step(i, 0, 1);
-            step(i + 1, 1, 2);
-            step(i + 2, 2, 0);
-        }
-        if (i < nk) step(i, 0, 1);
-        if (i + 1 < nk) step(i + 1, 1, 2);
-    }
-
-    // launder what the stores derive their addresses from: hoisted above the loop it would be held (and spilled) through it
-    int etid = tid, es = s, em0 = m0, en0 = n0;
-    asm volatile("" : "+v"(etid), "+s"(es), "+s"(em0), "+s"(en0));
-    const int ewid = __builtin_amdgcn_readfirstlane(etid >> 6);
-    const int ewr = ewid >> 1, ewc = ewid & 1, elk = (etid >> 5) & 1, el31 = etid & 31;
-    float* out = d.partial + (size_t)es * d.M * d.N;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = em0 + ewr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * elk;
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int col = en0 + ewc * 64 + ni * 32 + el31;
-                if (row < d.M && col < d.N) out[(size_t)row * d.N + col] = acc[mi][ni][r];
-            }
-        }
-    if (do_bias) {
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const float tot = bias_acc[mi] + __shfl_xor(bias_acc[mi], 32, 64);     // the two lane halves own different frames
-            const int row = em0 + ewr * 64 + mi * 32 + el31;
-            if (elk == 0 && row < d.M) d.partial_bias[(size_t)es * d.M + row] = tot;
-        }
-    }
-}
-
-// ======================================================================================
 
 struct __attribute__((aligned(16))) WDirectSmem {
     float Gs[2][2][128 * DK];   // [group][stage]
@@ -1721,6 +1485,247 @@ __global__ __launch_bounds__(512, 4) void pw_wgrad_direct_kernel(const sep_wgrad
 #endif
     WPROF(6);
 #undef WPROF
+}
+
+// ======================================================================================
+// Weight gradient in the split arithmetic (SEP_ARITH_BF16X6, see pw_gemm_direct_kernel): the same tiles, DMA layout and
+// fragment reads as pw_wgrad_direct_kernel, but 4-wave workgroups that own a whole slab (no in-block split of the
+// contraction: the packed operands need 168 registers, so three independent workgroups per CU give the overlap that two
+// 8-wave ones gave), a 3-stage ring, whole-chunk steps: prologue + split of chunk i (VALU), barrier, then the LDS reads
+// of chunk i+1 in three portions between the four groups of six bf16 MFMAs.  Same slab count as the 8-wave kernel.
+// ======================================================================================
+struct __attribute__((aligned(16))) WSplitSmem {
+    float Gs[3][128 * DK];
+    float Xs[3][128 * DK];
+    float mu[WMAXB];
+    float rstd[WMAXB];
+};
+
+template <int XMODE>
+__global__ __launch_bounds__(256, 3) void pw_wgrad_split_kernel(const sep_wgrad_desc d) {
+    constexpr bool X_GLN = XMODE == SEP_PRO_GLN || XMODE == SEP_PRO_GLN_PRELU;
+    constexpr bool X_PRELU = XMODE == SEP_PRO_PRELU || XMODE == SEP_PRO_GLN_PRELU;
+    constexpr int NS = 3;
+    __shared__ WSplitSmem sm;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+    const int lk = lane >> 5, l31 = lane & 31;
+    const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
+    const int ntiles = ntm * ntn;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, j = bid >> 3;
+    const int tile = j % ntiles;
+    const int s = (j / ntiles) * 8 + xcd;
+    if (s >= d.nsplit) return;
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+
+    const int cps_t = d.ldt / DK;                  // chunks per sample
+    const long chunks_total = (long)d.B * cps_t;
+    const long cper = (chunks_total + d.nsplit - 1) / d.nsplit;
+    const long c_begin = (long)s * cper;
+    long c_end = c_begin + cper;
+    if (c_end > chunks_total) c_end = chunks_total;
+    const int nk = (int)(c_end > c_begin ? c_end - c_begin : 0);
+
+    const float alpha_x = X_PRELU ? d.x_alpha[0] : 0.f;
+    if (X_GLN) {
+        const int nb = d.B / d.x_div;
+        for (int bx = tid; bx < nb; bx += 256) {
+            float mu, rstd;
+            gln_mu_rstd(d.x_stats + (size_t)bx * SEP_STATS_SLOTS * 2, d.count, d.eps, mu, rstd);
+            sm.mu[bx] = mu; sm.rstd[bx] = rstd;
+        }
+    }
+    float xg[2] = {0.f, 0.f}, xb[2] = {0.f, 0.f};
+    if (X_GLN) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int n = n0 + wc * 64 + ni * 32 + l31;
+            if (n < d.N) { xg[ni] = d.x_gamma[n]; xb[ni] = d.x_beta[n]; }
+        }
+    }
+    asm volatile("" :: "v"(xg[0]), "v"(xg[1]), "v"(xb[0]), "v"(xb[1]), "v"(alpha_x));      // consumed before the first asm DMA
+
+    const bool gsecond = d.g_split && m0 >= d.g_split;
+    const float* Gsrc = gsecond ? d.G2 : d.G;
+    const int Mg = gsecond ? d.M - d.g_split : (d.g_split ? d.g_split : d.M);
+    const int mg0 = gsecond ? m0 - d.g_split : m0;
+    const int Mg_lim = (d.M < m0 + BM ? d.M : m0 + BM) - (gsecond ? d.g_split : 0);
+
+    const int r16 = lane >> 2, cch = (lane & 3) ^ ((r16 >> 2) & 3);
+    unsigned voffG[2], voffX[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int g16 = 2 * wid + q;
+        int mm = mg0 + 16 * g16 + r16;
+        if (mm > Mg_lim - 1) mm = Mg_lim - 1;
+        voffG[q] = 4u * (unsigned)(mm * d.ldt + 4 * cch);
+        int nn = n0 + 16 * g16 + r16;
+        if (nn > d.N - 1) nn = d.N - 1;
+        voffX[q] = 4u * (unsigned)(nn * d.ldt + 4 * cch);
+    }
+    int ib = (int)(c_begin / cps_t), it = (int)(c_begin % cps_t);
+    int ibx = ib / d.x_div, ibm = ib % d.x_div;
+    int ct = it, cbx = ibx, cbm = ibm;
+    auto issue = [&](const int stage) {
+        const float* bG = Gsrc + (size_t)ib * Mg * d.ldt + it * DK;
+        const float* bX = d.X + (size_t)ibx * d.N * d.ldt + it * DK;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            glds16_asm(bG, voffG[q], lds_addr(&sm.Gs[stage][(2 * wid + q) * 256]));
+            glds16_asm(bX, voffX[q], lds_addr(&sm.Xs[stage][(2 * wid + q) * 256]));
+        }
+        if (++it >= cps_t) {
+            it = 0; ++ib;
+            if (++ibm == d.x_div) { ibm = 0; ++ibx; }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    float bias_acc[2] = {0.f, 0.f};
+    const bool do_bias = d.partial_bias != nullptr && (tile % ntn) == 0 && wc == 0;
+
+    float fa[2][2][4], fb[2][2][4];      // [half][mi|ni][frame]
+    auto read_g = [&](const int stage) {
+        const float* Gb = sm.Gs[stage];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int m = wr * 64 + mi * 32 + l31;
+                const float* p = Gb + m * 16 + 4 * ((2 * lk + h) ^ ((m >> 2) & 3));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) fa[h][mi][e] = p[e];
+            }
+    };
+    auto read_x = [&](const int stage, const int ni) {
+        const float* Xb = sm.Xs[stage];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int n = wc * 64 + ni * 32 + l31;
+            const float* p = Xb + n * 16 + 4 * ((2 * lk + h) ^ ((n >> 2) & 3));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fb[h][ni][e] = p[e];
+        }
+    };
+    float s_mu = 0.f, s_rstd = 1.f;      // the current sample's statistics, wave-uniform (SGPRs)
+    auto set_sample = [&]() {
+        if (X_GLN) {
+            s_mu = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sm.mu[cbx])));
+            s_rstd = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sm.rstd[cbx])));
+        }
+    };
+    auto step = [&](const int i, const int stage, const int nstage) {
+        u32x4_t pa[2][3], pb[2][3];
+        if (do_bias) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) bias_acc[mi] += fa[h][mi][kk];
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) split3_frag(fa[0][mi], fa[1][mi], pa[mi]);
+        if (XMODE != SEP_PRO_NONE) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const float scv = xg[ni] * s_rstd, shv = xb[ni] - s_mu * scv;      // re-formed per chunk: four registers fewer across the MFMAs
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        float v = fb[h][ni][kk];
+                        if (X_PRELU) v = prelu_f(v, alpha_x);
+                        fb[h][ni][kk] = X_GLN ? v * scv + shv : v;
+                    }
+            }
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) split3_frag(fb[0][ni], fb[1][ni], pb[ni]);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool more = i + 1 < nk;
+        if (more) {
+            // chunk i+1 has landed (mine: all but the DMAs of chunk i+2; everyone's: barrier); every wave holds chunk i in
+            // registers, so chunk i+3 may overwrite its stage
+            wait_keep4_and_barrier(i + 2 < nk);
+            if (i + NS < nk) issue(stage);
+            read_g(nstage);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_split6(pa[0], pb[0], acc[0][0]);
+        mfma_split6(pa[1], pb[0], acc[1][0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) read_x(nstage, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_split6(pa[0], pb[1], acc[0][1]);
+        mfma_split6(pa[1], pb[1], acc[1][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) read_x(nstage, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // the chunk just computed was frame chunk ct of sample cbx
+        if (++ct >= cps_t) {
+            ct = 0;
+            if (++cbm == d.x_div) { cbm = 0; ++cbx; }
+            if (more) set_sample();
+        }
+    };
+
+    __syncthreads();                                              // mu/rstd table visible; before the first DMA so it drains nothing
+    set_sample();
+    if (nk > 0) {
+        issue(0);
+        if (nk > 1) {
+            issue(1);
+            wait_keep4_and_barrier(true);
+            if (nk > 2) issue(2);
+        } else
+            wait_all_and_barrier();
+        read_g(0);
+        read_x(0, 0);
+        read_x(0, 1);
+        int i = 0;
+        for (; i + 2 < nk; i += 3) {
+            step(i, 0, 1);
+            step(i + 1, 1, 2);
+            step(i + 2, 2, 0);
+        }
+        if (i < nk) step(i, 0, 1);
+        if (i + 1 < nk) step(i + 1, 1, 2);
+    }
+
+    // launder what the stores derive their addresses from: hoisted above the loop it would be held (and spilled) through it
+    int etid = tid, es = s, em0 = m0, en0 = n0;
+    asm volatile("" : "+v"(etid), "+s"(es), "+s"(em0), "+s"(en0));
+    const int ewid = __builtin_amdgcn_readfirstlane(etid >> 6);
+    const int ewr = ewid >> 1, ewc = ewid & 1, elk = (etid >> 5) & 1, el31 = etid & 31;
+    float* out = d.partial + (size_t)es * d.M * d.N;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = em0 + ewr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * elk;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int col = en0 + ewc * 64 + ni * 32 + el31;
+                if (row < d.M && col < d.N) out[(size_t)row * d.N + col] = acc[mi][ni][r];
+            }
+        }
+    if (do_bias) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const float tot = bias_acc[mi] + __shfl_xor(bias_acc[mi], 32, 64);     // the two lane halves own different frames
+            const int row = em0 + ewr * 64 + mi * 32 + el31;
+            if (elk == 0 && row < d.M) d.partial_bias[(size_t)es * d.M + row] = tot;
+        }
+    }
 }
 
 // ======================================================================================

@@ -32,7 +32,7 @@ for k in sorted(F):
     fetch = 2.0 * F[k].get("FETCH_SIZE", 0.0) * 1024.0
     write = W.get(k, {}).get("WRITE_SIZE", 0.0) * 1024.0
     rows.append((name, grid, n, fetch, write))
-    m = re.match(r"pw_gemm_direct_kernel<(true|false), (\d), (true|false)(?:, -?\d+)?>", name)
+    m = re.match(r"pw_gemm_direct_kernel<(true|false), (\d), (true|false)(?:, -?\d+){0,2}>", name)
     if m:
         key = "T{}P{}S{}".format(int(m.group(1) == "true"), m.group(2), int(m.group(3) == "true"))
         v = variants.setdefault(key, {"launches": 0, "bytes": 0.0})
