@@ -621,14 +621,14 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const float* __restric
     }
 }
 
-// Decoder + mask backward (sigmoid mask).  Thread = frame, every source handled by the same thread so that
-// dwm = sum_s dlatent*m needs no atomics.
+// Decoder + mask backward.  Thread = frame, every source handled by the same thread so that dwm = sum_s dlatent*m needs
+// no atomics.  raw_mask = 0: dpre = d(sigmoid pre-activation); 1: dpre = d(mask) (softmax masks: sep_softmax_ch_bwd follows).
 template <int LC_REG, int NS_REG>
 __global__ __launch_bounds__(256) void decoder_bwd_kernel(const float* __restrict__ d_est, const float* __restrict__ w,
                                                           const float* __restrict__ m, const float* __restrict__ D,
                                                           float* __restrict__ dpre, float* __restrict__ dwm, int n_src,
                                                           int N, int Cout, int L, int S, int F, int ldt, int Tout,
-                                                          int pad_left) {
+                                                          int pad_left, int raw_mask) {
     const int LC = Cout * L;
     const int b = blockIdx.y;
     const int f = blockIdx.x * 256 + threadIdx.x;
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(256) void decoder_bwd_kernel(const float* __restric
                     float dl = 0.f;
 #pragma unroll
                     for (int q = 0; q < LC_REG; ++q) dl = fmaf(ds[s][q], Dn[q], dl);
-                    dpre[off] = fvalid ? dl * wv * mv * (1.f - mv) : 0.f;
+                    dpre[off] = fvalid ? (raw_mask ? dl * wv : dl * wv * mv * (1.f - mv)) : 0.f;
                     dacc += dl * mv;
                 }
             }
@@ -681,10 +681,56 @@ __global__ __launch_bounds__(256) void decoder_bwd_kernel(const float* __restric
                 const float mv = m[off];
                 float dl = 0.f;
                 for (int q = 0; q < LC; ++q) dl = fmaf(dsample(s, q), Dn[q], dl);
-                dpre[off] = fvalid ? dl * wv * mv * (1.f - mv) : 0.f;
+                dpre[off] = fvalid ? (raw_mask ? dl * wv : dl * wv * mv * (1.f - mv)) : 0.f;
                 dacc += dl * mv;
             }
             dwrow[(size_t)n * ldt + f] = fvalid ? dacc : 0.f;
+        }
+    }
+}
+
+// =====================================================================================
+// Softmax over the channel axis, in place (reference conv_tasnet.py:353-357, 375: nn.Softmax(dim=1) on the (B, n_src*N, T')
+// output of the mask convolution -- over ALL n_src*N channels of a frame, not over the sources).
+// Workgroup = 64 frames x 4 channel groups (one wave each); a wave reads 256 contiguous bytes per channel row.
+//   forward : y <- exp(y - max_c y) / sum_c exp(y - max_c y)      (frames >= T: 0, the layout contract)
+//   backward: g <- y * (g - sum_c g*y)                            (frames >= T: 0)
+// =====================================================================================
+template <bool BWD>
+__global__ __launch_bounds__(256) void softmax_ch_kernel(float* __restrict__ y, float* __restrict__ g, int C, int T, int ldt) {
+    __shared__ float sa[4][64], sb[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + lane;
+    const size_t base = (size_t)blockIdx.y * C * ldt + t;
+    const bool valid = t < T;
+    if (!BWD) {
+        float mx = -INFINITY, sum = 0.f;
+        for (int c = w; c < C; c += 4) {
+            const float v = y[base + (size_t)c * ldt];
+            const float nm = fmaxf(mx, v);
+            sum = sum * expf(mx - nm) + expf(v - nm);
+            mx = nm;
+        }
+        sa[w][lane] = mx; sb[w][lane] = sum;
+        __syncthreads();
+        float M = fmaxf(fmaxf(sa[0][lane], sa[1][lane]), fmaxf(sa[2][lane], sa[3][lane]));
+        float S = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) S += sb[q][lane] * expf(sa[q][lane] - M);
+        const float inv = 1.f / S;
+        for (int c = w; c < C; c += 4) {
+            const size_t off = base + (size_t)c * ldt;
+            y[off] = valid ? expf(y[off] - M) * inv : 0.f;
+        }
+    } else {
+        float dot = 0.f;
+        for (int c = w; c < C; c += 4) dot = fmaf(g[base + (size_t)c * ldt], y[base + (size_t)c * ldt], dot);
+        sa[w][lane] = dot;
+        __syncthreads();
+        const float tot = (sa[0][lane] + sa[1][lane]) + (sa[2][lane] + sa[3][lane]);
+        for (int c = w; c < C; c += 4) {
+            const size_t off = base + (size_t)c * ldt;
+            g[off] = valid ? y[off] * (g[off] - tot) : 0.f;
         }
     }
 }
@@ -1001,19 +1047,33 @@ extern "C" int sep_decoder_fwd(const float* w, const float* m, const float* D, f
 
 extern "C" int sep_decoder_bwd(const float* d_est, const float* w, const float* m, const float* D, float* dpre, float* dwm,
                                int B, int n_src, int N, int Cout, int L, int S, int F, int ldt, int Tout, int pad_left,
-                               sep_stream_t stream) {
+                               int raw_mask, sep_stream_t stream) {
     SEP_REQUIRE(d_est && w && m && D && dpre && dwm, "sep_decoder_bwd: null pointer");
     SEP_REQUIRE(B <= 65535, "sep_decoder_bwd: B too large");
     const int nz = N >= 64 ? 8 : 1;                               // 2048 workgroups at paper-best instead of 256
     dim3 grid(ceil_div(ldt, 256), B, nz);
     const int LC = Cout * L;
     if (LC == 16 && n_src <= 2)
-        hipLaunchKernelGGL((decoder_bwd_kernel<16, 2>), grid, dim3(256), 0, (hipStream_t)stream, d_est, w, m, D, dpre, dwm, n_src, N, Cout, L, S, F, ldt, Tout, pad_left);
+        hipLaunchKernelGGL((decoder_bwd_kernel<16, 2>), grid, dim3(256), 0, (hipStream_t)stream, d_est, w, m, D, dpre, dwm, n_src, N, Cout, L, S, F, ldt, Tout, pad_left, raw_mask);
     else if (LC == 16 && n_src <= 4)
-        hipLaunchKernelGGL((decoder_bwd_kernel<16, 4>), grid, dim3(256), 0, (hipStream_t)stream, d_est, w, m, D, dpre, dwm, n_src, N, Cout, L, S, F, ldt, Tout, pad_left);
+        hipLaunchKernelGGL((decoder_bwd_kernel<16, 4>), grid, dim3(256), 0, (hipStream_t)stream, d_est, w, m, D, dpre, dwm, n_src, N, Cout, L, S, F, ldt, Tout, pad_left, raw_mask);
     else
-        hipLaunchKernelGGL((decoder_bwd_kernel<0, 0>), grid, dim3(256), 0, (hipStream_t)stream, d_est, w, m, D, dpre, dwm, n_src, N, Cout, L, S, F, ldt, Tout, pad_left);
+        hipLaunchKernelGGL((decoder_bwd_kernel<0, 0>), grid, dim3(256), 0, (hipStream_t)stream, d_est, w, m, D, dpre, dwm, n_src, N, Cout, L, S, F, ldt, Tout, pad_left, raw_mask);
     SEP_CHECK_LAUNCH("sep_decoder_bwd");
+    return 0;
+}
+
+extern "C" int sep_softmax_ch_fwd(float* y, int B, int C, int T, int ldt, sep_stream_t stream) {
+    SEP_REQUIRE(y && B > 0 && B <= 65535 && C > 0 && T > 0 && ldt % 64 == 0 && ldt >= T, "sep_softmax_ch_fwd: bad arguments");
+    hipLaunchKernelGGL((softmax_ch_kernel<false>), dim3(ldt / 64, B), dim3(256), 0, (hipStream_t)stream, y, (float*)nullptr, C, T, ldt);
+    SEP_CHECK_LAUNCH("sep_softmax_ch_fwd");
+    return 0;
+}
+
+extern "C" int sep_softmax_ch_bwd(const float* y, float* g, int B, int C, int T, int ldt, sep_stream_t stream) {
+    SEP_REQUIRE(y && g && B > 0 && B <= 65535 && C > 0 && T > 0 && ldt % 64 == 0 && ldt >= T, "sep_softmax_ch_bwd: bad arguments");
+    hipLaunchKernelGGL((softmax_ch_kernel<true>), dim3(ldt / 64, B), dim3(256), 0, (hipStream_t)stream, const_cast<float*>(y), g, C, T, ldt);
+    SEP_CHECK_LAUNCH("sep_softmax_ch_bwd");
     return 0;
 }
 

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("SEPKERNELS_LIB", os.path.normpath(os.path.join(_HERE,
 # ---- constants mirrored from include/sepkernels.h -------------------------------------------------
 PRO_NONE, PRO_PRELU, PRO_GLN, PRO_GLN_PRELU, PRO_GLN_BWD = 0, 1, 2, 3, 4
 EPI_STATS_PRELU, EPI_RESIDUAL, EPI_SIGMOID, EPI_PRELU_BWD, EPI_ROWSUMS, EPI_ROWSUMS_PRELU = 1, 2, 4, 8, 16, 32
-ABI_VERSION = 6
+ABI_VERSION = 7
 STATS_SLOTS = 16   # SEP_STATS_SLOTS: gLN statistics are double[B][STATS_SLOTS][2]
 ARITH_F32, ARITH_BF16X6 = 0, 1     # SEP_ARITH_*: how sep_pw_gemm forms its fp32 products (include/sepkernels.h)
 _ARITH_NAMES = {"f32": ARITH_F32, "bf16x6": ARITH_BF16X6}
@@ -89,7 +89,9 @@ SIGNATURES = {
     "sep_gln_bwd_finalize": [_vp, _I, _I, _vp, _vp, _D, _F, _vp, _vp, _vp, _vp, _I, _I, _vp],
     "sep_head_bwd": [_vp] * 6 + [_I] * 4 + [_D, _F, _I, _vp],
     "sep_decoder_fwd": [_vp] * 5 + [_I] * 10 + [_vp],
-    "sep_decoder_bwd": [_vp] * 6 + [_I] * 10 + [_vp],
+    "sep_decoder_bwd": [_vp] * 6 + [_I] * 11 + [_vp],
+    "sep_softmax_ch_fwd": [_vp] + [_I] * 4 + [_vp],
+    "sep_softmax_ch_bwd": [_vp, _vp] + [_I] * 4 + [_vp],
     "sep_gln_stats": [_vp, _vp, _I, _I, _I, _I, _vp],
     "sep_gln_apply": [_vp] * 5 + [_I] * 4 + [_D, _F, _vp],
     "sep_gln_bwd_rowsums": [_vp, _vp, _vp, _I, _I, _I, _I, _vp],
@@ -242,9 +244,16 @@ class HipBackend:
         _check(load().sep_decoder_fwd(_ptr(w, _f32), _ptr(m, _f32), _ptr(D, _f32), _ptr(est, _f32), _ptr(latent, _f32), B, n_src,
                                       N, Cout, L, S, F, ldt, Tout, pad_left, _stream()), "sep_decoder_fwd")
 
-    def decoder_bwd(self, d_est, w, m, D, dpre, dwm, B, n_src, N, Cout, L, S, F, ldt, Tout, pad_left):
+    def decoder_bwd(self, d_est, w, m, D, dpre, dwm, B, n_src, N, Cout, L, S, F, ldt, Tout, pad_left, raw_mask=0):
         _check(load().sep_decoder_bwd(_ptr(d_est, _f32), _ptr(w, _f32), _ptr(m, _f32), _ptr(D, _f32), _ptr(dpre, _f32),
-                                      _ptr(dwm, _f32), B, n_src, N, Cout, L, S, F, ldt, Tout, pad_left, _stream()), "sep_decoder_bwd")
+                                      _ptr(dwm, _f32), B, n_src, N, Cout, L, S, F, ldt, Tout, pad_left, int(raw_mask), _stream()),
+               "sep_decoder_bwd")
+
+    def softmax_ch_fwd(self, y, B, C, T, ldt):
+        _check(load().sep_softmax_ch_fwd(_ptr(y, _f32), B, C, T, ldt, _stream()), "sep_softmax_ch_fwd")
+
+    def softmax_ch_bwd(self, y, g, B, C, T, ldt):
+        _check(load().sep_softmax_ch_bwd(_ptr(y, _f32), _ptr(g, _f32), B, C, T, ldt, _stream()), "sep_softmax_ch_bwd")
 
     def gln_stats(self, x, stats, B, C, T, ldt):
         _check(load().sep_gln_stats(_ptr(x, _f32), _ptr(stats, _f64), B, C, T, ldt, _stream()), "sep_gln_stats")

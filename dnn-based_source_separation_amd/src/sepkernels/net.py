@@ -63,8 +63,8 @@ def check_supported(cfg):
         problems.append("separable=True and dilated=True are required")
     if cfg.get("sep_nonlinear") != "prelu" or not cfg.get("sep_norm", True):
         problems.append("sep_nonlinear='prelu' and sep_norm=True are required")
-    if cfg.get("mask_nonlinear") != "sigmoid":
-        problems.append("mask_nonlinear must be 'sigmoid'")
+    if cfg.get("mask_nonlinear") not in ("sigmoid", "softmax"):
+        problems.append("mask_nonlinear must be 'sigmoid' or 'softmax'")
     if cfg.get("sep_kernel_size") != 3:
         problems.append("sep_kernel_size must be 3")
     for k in ("n_basis", "sep_hidden_channels", "sep_bottleneck_channels", "sep_skip_channels"):
@@ -114,7 +114,7 @@ def head_forward(cfg, P, mixture, stats0):
 
 
 def tail_forward(cfg, P, geo, w, core, mixture_shape, want_latent):
-    """PReLU -> 1x1 mask conv -> sigmoid -> mask*w -> decoder (overlap-add) -> crop.  core (B, C, ldt)."""
+    """PReLU -> 1x1 mask conv -> sigmoid | channel softmax -> mask*w -> decoder (overlap-add) -> crop.  core (B, C, ldt)."""
     K = backend()
     B, Cin, T_in = mixture_shape
     N, L, S, n_src = cfg["n_basis"], cfg["kernel_size"], cfg["stride"], cfg["n_sources"]
@@ -123,9 +123,12 @@ def tail_forward(cfg, P, geo, w, core, mixture_shape, want_latent):
     C = core.shape[1]
     f32 = dict(device=w.device, dtype=w.dtype)
     m = torch.empty(B, n_src * N, ldt, **f32)
+    softmax = cfg.get("mask_nonlinear") == "softmax"
     K.pw_gemm(B=B, M=n_src * N, K=C, T=F, ldt=ldt, A=P["separator.mask_conv1d.weight"], X=core, Y=m,
               bias=P["separator.mask_conv1d.bias"], pro_mode=PRO_PRELU, pro_alpha=P["separator.prelu.weight"],
-              epi_flags=EPI_SIGMOID, eps=eps)
+              epi_flags=0 if softmax else EPI_SIGMOID, eps=eps)
+    if softmax:      # nn.Softmax(dim=1) over all n_src*N channels of a frame (reference conv_tasnet.py:357)
+        K.softmax_ch_fwd(m, B, n_src * N, F, ldt)
     est = torch.empty(B, n_src, Cin, T_in, **f32)
     latent = torch.empty(B, n_src, N, ldt, **f32) if want_latent else None
     K.decoder_fwd(w, m, P["decoder.conv_transpose1d.weight"], est, latent, B, n_src, N, Cin, L, S, F, ldt, T_in, geo.pad_left)
@@ -161,7 +164,10 @@ def tail_backward(cfg, P, geo, w, core, m, mixture_shape, d_est, G, dalpha_slot)
     K.reduce_slabs([(part, 0, G["decoder.conv_transpose1d.weight"], N * Cin * L, ns, N * Cin * L, 0, 1.0)])
     dpre = torch.empty(B, n_src * N, ldt, **f32)
     dwm = torch.empty(B, N, ldt, **f32)
-    K.decoder_bwd(d_est, w, m, D, dpre, dwm, B, n_src, N, Cin, L, S, F, ldt, T_in, geo.pad_left)
+    softmax = cfg.get("mask_nonlinear") == "softmax"
+    K.decoder_bwd(d_est, w, m, D, dpre, dwm, B, n_src, N, Cin, L, S, F, ldt, T_in, geo.pad_left, raw_mask=int(softmax))
+    if softmax:
+        K.softmax_ch_bwd(m, dpre, B, n_src * N, F, ldt)
     Wm = P["separator.mask_conv1d.weight"]
     alpha_m = P["separator.prelu.weight"]
     dcore = torch.empty(B, C, ldt, **f32)

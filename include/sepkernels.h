@@ -33,7 +33,7 @@ extern "C" {
 
 typedef void* sep_stream_t; /* hipStream_t */
 
-#define SEP_ABI_VERSION 6
+#define SEP_ABI_VERSION 7
 #define SEP_STATS_SLOTS 16
 
 int sep_version(void);
@@ -203,11 +203,16 @@ int sep_head_bwd(float* dvw, const float* w, const float* dwm, const double* sta
 int sep_decoder_fwd(const float* w, const float* m, const float* D, float* est, float* latent, int B, int n_src, int N,
                     int Cout, int L, int S, int F, int ldt, int Tout, int pad_left, sep_stream_t stream);
 
-/* Backward of the same: given d_est, writes dpre = d(mask pre-activation) (sigmoid) as (B, n_src*N, ldt)
- * and dwm[b][n][f] = sum_s dlatent*m. */
+/* Backward of the same: given d_est, writes dpre as (B, n_src*N, ldt) and dwm[b][n][f] = sum_s dlatent*m.
+ * raw_mask = 0: dpre = d(mask pre-activation) of a sigmoid mask; 1: dpre = d(mask) (softmax mask: sep_softmax_ch_bwd next). */
 int sep_decoder_bwd(const float* d_est, const float* w, const float* m, const float* D, float* dpre, float* dwm, int B,
-                    int n_src, int N, int Cout, int L, int S, int F, int ldt, int Tout, int pad_left,
+                    int n_src, int N, int Cout, int L, int S, int F, int ldt, int Tout, int pad_left, int raw_mask,
                     sep_stream_t stream);
+
+/* mask_nonlinear = 'softmax' (conv_tasnet.py:353-357, 375): nn.Softmax(dim=1) over the n_src*N channels of a frame, in place
+ * on y (B, C, ldt); backward in place on g given the forward output y: g <- y * (g - sum_c g*y).  Frames >= T are zeroed. */
+int sep_softmax_ch_fwd(float* y, int B, int C, int T, int ldt, sep_stream_t stream);
+int sep_softmax_ch_bwd(const float* y, float* g, int B, int C, int T, int ldt, sep_stream_t stream);
 
 /* Stand-alone gLN (modules/norm.py:11-35) for callers outside the fused network. */
 int sep_gln_stats(const float* x, double* stats, int B, int C, int T, int ldt, sep_stream_t stream);

@@ -58,7 +58,9 @@ def conv_tasnet(x, p, cfg):
             h, skip = _layer(h, p, "separator.tdcn.net.{}.net.{}.".format(r, l), 2 ** l, not last, EPS)
             skip_sum = skip_sum + skip
     h = F.prelu(skip_sum, p["separator.prelu.weight"])
-    mask = torch.sigmoid(F.conv1d(h, p["separator.mask_conv1d.weight"], p["separator.mask_conv1d.bias"]))
+    mask = F.conv1d(h, p["separator.mask_conv1d.weight"], p["separator.mask_conv1d.bias"])
+    # reference conv_tasnet.py:353-357: Sigmoid, or Softmax(dim=1) over all n_src*N channels of a frame
+    mask = torch.softmax(mask, dim=1) if cfg.get("mask_nonlinear", "sigmoid") == "softmax" else torch.sigmoid(mask)
     latent = w.unsqueeze(1) * mask.view(B, n_src, N, -1)
     xh = F.conv_transpose1d(latent.view(B * n_src, N, -1), p["decoder.conv_transpose1d.weight"], stride=S)
     xh = F.pad(xh.view(B, n_src, Cin, -1), (-pl, -pr))        # crop per channel, then the reference's views

@@ -44,8 +44,13 @@ CONFIGS = {
                 sep_hidden_channels=256, sep_bottleneck_channels=128, sep_skip_channels=64, sep_kernel_size=3,
                 sep_num_blocks=2, sep_num_layers=3, dilated=True, separable=True, causal=False, sep_nonlinear="prelu",
                 sep_norm=True, mask_nonlinear="sigmoid", n_sources=3),
+    # mask_nonlinear='softmax' (nn.Softmax(dim=1) over the n_src*N channels of a frame, reference conv_tasnet.py:357)
+    "softmax": dict(n_basis=64, kernel_size=16, stride=8, enc_basis="trainable", dec_basis="trainable", enc_nonlinear="relu",
+                    sep_hidden_channels=128, sep_bottleneck_channels=64, sep_skip_channels=64, sep_kernel_size=3,
+                    sep_num_blocks=1, sep_num_layers=2, dilated=True, separable=True, causal=False, sep_nonlinear="prelu",
+                    sep_norm=True, mask_nonlinear="softmax", n_sources=2),
 }
-SHAPES = {"tiny": (1, 4000), "mid": (2, 3203)}   # (batch, samples); 3203 exercises the input padding branch
+SHAPES = {"tiny": (1, 4000), "mid": (2, 3203), "softmax": (2, 2500)}   # (batch, samples); 3203 / 2500 exercise the input padding branch
 
 
 def perturb(model, seed):
@@ -216,9 +221,12 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ConvTasNet, NegSISDR, SISDR, PIT1d, SinkPIT = import_reference()
+    only = sys.argv[1:]                  # e.g. `python -m oracle.make_golden softmax` regenerates one model fixture
     for name in CONFIGS:
-        model_golden(name, ConvTasNet, NegSISDR, PIT1d)
-    pit_kat(NegSISDR, SISDR, PIT1d, SinkPIT)
-    op_golden(NegSISDR)
-    dprnn_golden(NegSISDR, PIT1d)
+        if not only or name in only:
+            model_golden(name, ConvTasNet, NegSISDR, PIT1d)
+    if not only:
+        pit_kat(NegSISDR, SISDR, PIT1d, SinkPIT)
+        op_golden(NegSISDR)
+        dprnn_golden(NegSISDR, PIT1d)
     print("golden vectors written to", OUT)

@@ -203,13 +203,25 @@ class EmuBackend:
         out.index_add_(3, idx, fr.reshape(B, n_src, Cout, L * F))
         est.reshape(B, n_src, Cout, Tout).copy_(out[..., pad_left:pad_left + Tout])
 
-    def decoder_bwd(self, d_est, w, m, D, dpre, dwm, B, n_src, N, Cout, L, S, F, ldt, Tout, pad_left):
+    def softmax_ch_fwd(self, y, B, C, T, ldt):
+        v = y.reshape(B, C, ldt)
+        out = torch.zeros_like(v)
+        out[..., :T] = torch.softmax(v[..., :T], dim=1)
+        v.copy_(out)
+
+    def softmax_ch_bwd(self, y, g, B, C, T, ldt):
+        yv, gv = y.reshape(B, C, ldt), g.reshape(B, C, ldt)
+        out = yv * (gv - (gv * yv).sum(1, keepdim=True))
+        out[..., T:] = 0
+        gv.copy_(out)
+
+    def decoder_bwd(self, d_est, w, m, D, dpre, dwm, B, n_src, N, Cout, L, S, F, ldt, Tout, pad_left, raw_mask=0):
         fr = torch.zeros(B * n_src, Cout * L, ldt, dtype=w.dtype)
         self.unfold(d_est.reshape(B * n_src, Cout, Tout), fr, B * n_src, Cout, Tout, L, S, F, ldt, pad_left)
         dl = torch.einsum("nq,bqf->bnf", D.reshape(N, Cout * L), fr).reshape(B, n_src, N, ldt)
         mv = m.reshape(B, n_src, N, ldt)
         wv = w.reshape(B, 1, N, ldt)
-        dp = dl * wv * mv * (1 - mv)
+        dp = dl * wv if raw_mask else dl * wv * mv * (1 - mv)
         dp[..., F:] = 0
         dpre.reshape(B, n_src, N, ldt).copy_(dp)
         dw = (dl * mv).sum(1)

@@ -357,6 +357,20 @@ def test_decoder_fwd_bwd(n_src, Cout, L, S, pad_left, latent):
     D = rnd(N, Cout, L)
     both("decoder_fwd", [w, m, D, nan(B, n_src, Cout, Tout), nan(B, n_src, N, ldt) if latent else None, B, n_src, N, Cout, L, S, F, ldt, Tout, pad_left])
     both("decoder_bwd", [rnd(B, n_src, Cout, Tout), w, m, D, nan(B, n_src * N, ldt), nan(B, N, ldt), B, n_src, N, Cout, L, S, F, ldt, Tout, pad_left])
+    both("decoder_bwd", [rnd(B, n_src, Cout, Tout), w, m, D, nan(B, n_src * N, ldt), nan(B, N, ldt), B, n_src, N, Cout, L, S, F, ldt, Tout, pad_left],
+         dict(raw_mask=1))
+
+
+@pytest.mark.parametrize("B,C,T", [(2, 128, 300), (1, 1024, 3999), (3, 50, 64), (2, 7, 1)])
+def test_softmax_over_channels(B, C, T):
+    """mask_nonlinear='softmax': nn.Softmax(dim=1) over the channel rows of every frame, in place; padding frames zeroed
+    (they arrive as arbitrary finite values from a GEMM without the pad mask)."""
+    ldt = (T + 127) // 128 * 128
+    y = rnd(B, C, ldt, scale=3.0)
+    both("softmax_ch_fwd", [y, B, C, T, ldt], tol=1e-5)
+    probs = torch.zeros(B, C, ldt)
+    probs[..., :T] = torch.softmax(rnd(B, C, T, scale=2.0), dim=1)
+    both("softmax_ch_bwd", [probs, rnd(B, C, ldt), B, C, T, ldt], tol=1e-5)
 
 
 # ------------------------------------------------------------------------------------------- stand-alone gLN / repack

@@ -42,7 +42,7 @@ def _grad_report(model, ref_grads):
     return num / den, worst
 
 
-@pytest.mark.parametrize("name", ["tiny", "mid"])
+@pytest.mark.parametrize("name", ["tiny", "mid", "softmax"])
 def test_golden_forward_loss_grads(golden_dir, name):
     g = np.load(os.path.join(golden_dir, "convtasnet_{}.npz".format(name)))
     model = ConvTasNet(**CONFIGS[name])

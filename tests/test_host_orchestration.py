@@ -38,7 +38,7 @@ def _run(golden_dir, name, dtype):
     return g, est, latent, loss, pattern, G, sv
 
 
-@pytest.mark.parametrize("name", ["tiny", "mid"])
+@pytest.mark.parametrize("name", ["tiny", "mid", "softmax"])
 def test_forward_backward_fp64(golden_dir, emu, name):
     g, est, latent, loss, pattern, G, sv = _run(golden_dir, name, torch.float64)
     ref = torch.from_numpy(g["output_f64"])

@@ -27,7 +27,7 @@ def _golden(golden_dir, name):
     return np.load(os.path.join(golden_dir, "convtasnet_{}.npz".format(name)))
 
 
-@pytest.mark.parametrize("name", ["tiny", "mid"])
+@pytest.mark.parametrize("name", ["tiny", "mid", "softmax"])
 def test_state_dict_contract_and_default_init(golden_dir, name):
     g = _golden(golden_dir, name)
     torch.manual_seed(111)
@@ -82,7 +82,7 @@ def test_error_behaviour():
         NegSISDR(reduction="max")
 
 
-@pytest.mark.parametrize("name", ["tiny", "mid"])
+@pytest.mark.parametrize("name", ["tiny", "mid", "softmax"])
 def test_module_forward_backward_via_emulator(golden_dir, emu, name):
     g = _golden(golden_dir, name)
     model = ConvTasNet(**CONFIGS[name])

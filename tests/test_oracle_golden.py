@@ -35,7 +35,7 @@ def test_ops_against_reference_modules(golden_dir):
     assert torch.allclose(y, t("sdr_negsisdr"), rtol=1e-10, atol=1e-10)
 
 
-@pytest.mark.parametrize("name", ["tiny", "mid"])
+@pytest.mark.parametrize("name", ["tiny", "mid", "softmax"])
 def test_model_forward_loss_grads(golden_dir, name):
     g = _load(golden_dir, "convtasnet_{}.npz".format(name))
     cfg = CONFIGS[name]
@@ -97,7 +97,7 @@ def test_roofline_constants():
     assert O.num_frames(32000, 16, 8) == 3999
 
 
-@pytest.mark.parametrize("name", ["tiny", "mid"])
+@pytest.mark.parametrize("name", ["tiny", "mid", "softmax"])
 def test_fast_port_matches_reference_and_algebra_oracle(golden_dir, name):
     """oracle/fast_port.py (what bench.py times as cpu_baseline) against the reference golden vectors."""
     from oracle import fast_port as FP
