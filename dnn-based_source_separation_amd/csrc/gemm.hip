@@ -590,10 +590,6 @@ __device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
 //   wr == 0 waves of row tile 0 write it back for the weight-gradient GEMM and accumulate the PReLU slope gradient.
 // ======================================================================================
 constexpr int OMAXK = 512;      // rows of the per-row affine table in LDS (3 stages x 3 workgroups per CU must fit 160 KiB)
-#ifdef SEP_EXP_STAGGER
-__device__ int g_gemm_stagger = 0;
-__device__ unsigned g_cu_arrivals[4096];
-#endif
 
 template <bool AUX, int NS = 2>
 struct __attribute__((aligned(16))) DirectSmem {
@@ -680,20 +676,6 @@ __global__ __launch_bounds__(256, (AR == 1 ? 3 : PRO == SEP_PRO_GLN_BWD ? 3 : PR
     const int nk = d.K / DK;
 #ifdef SEP_PROF
     const int prof_slot = bid == 8 ? 0 : bid == 1500 ? 1 : bid == 1501 ? 2 : bid == (int)gridDim.x - 9 ? 3 : -1;
-#endif
-#ifdef SEP_EXP_STAGGER
-    if (g_gemm_stagger > 0 && bid < 1024 && (int)gridDim.x > 1024) {
-        // arrival order of this workgroup on ITS compute unit -> phase 0..3 -> start delay of phase * (tile time / 4)
-        if (tid == 0) {
-            const unsigned hw = __builtin_amdgcn_s_getreg((7 << 11) | (8 << 6) | 4);      // HW_ID[15:8]: CU_ID, SH_ID, SE_ID
-            const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);    // XCC_ID[3:0]
-            const unsigned arrival = atomicAdd(&g_cu_arrivals[((xcc & 15) << 8) | (hw & 255)], 1u);
-            const long long cycles = (long long)(arrival & 3) * nk * 2048 * g_gemm_stagger / 100;
-            const long long c0 = clock64();
-            while (clock64() - c0 < cycles) __builtin_amdgcn_s_sleep(16);
-        }
-        __syncthreads();
-    }
 #endif
     PROF_STAMP(0);
 #ifdef SEP_PROF
@@ -1807,15 +1789,6 @@ extern "C" int sep_pw_gemm(const sep_gemm_desc* d, sep_stream_t stream) {
                            (d->pro_mode < SEP_PRO_GLN || d->K <= OMAXK);
     SEP_REQUIRE(direct_ok || (d->K % BK == 0 && d->k_split % BK == 0), "sep_pw_gemm: the register-staged fallback (K=%d) needs K %% 32 == 0", d->K);
     if (direct_ok) {
-#ifdef SEP_EXP_STAGGER
-        static int stagger_set = [] {
-            const char* e = getenv("SEPK_STAGGER");
-            int v = e ? atoi(e) : 0;
-            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stagger), &v, sizeof(int));
-            return 1;
-        }();
-        (void)stagger_set;
-#endif
         // curated combinations exist in both arithmetics (GLN_BWD: fp32 MFMA only -- its time is the prologue, measured equal)
         const bool split6 = d->arith == SEP_ARITH_BF16X6;
 #define SEP_LD(T, P, S, E)                                                                                                                           \
