@@ -21,6 +21,22 @@ def _is_sisdr(criterion, input):
     return isinstance(criterion, (SISDR, NegSISDR)) and input.dim() == 3 and criterion.reduction in ("mean", "sum")
 
 
+_DEVICE_PATTERNS = {}
+
+
+def _on_device(patterns, device):
+    """(int64, int32) device copies of a permutation table, cached: a pageable host-to-device copy per step is a
+    host-side synchronisation in the middle of the step (the host would wait for the whole forward pass)."""
+    if patterns.device == device:
+        return patterns, patterns.to(torch.int32).contiguous()
+    key = (str(device), tuple(patterns.shape))
+    hit = _DEVICE_PATTERNS.get(key)
+    if hit is None or not torch.equal(hit[0], patterns):
+        hit = (patterns.clone(), patterns.to(device), patterns.to(device=device, dtype=torch.int32).contiguous())
+        _DEVICE_PATTERNS[key] = hit
+    return hit[1], hit[2]
+
+
 def _fused_pit(criterion, input, target, patterns, batch_mean):
     K = sepkernels.backend()
     B, n, _ = input.shape
@@ -29,11 +45,11 @@ def _fused_pit(criterion, input, target, patterns, batch_mean):
     if not maximize:
         val = -val                                                 # NegSISDR values
     P = patterns.size(0)
-    perms32 = patterns.to(device=input.device, dtype=torch.int32).contiguous()
+    perms64, perms32 = _on_device(patterns, input.device)
     best_val = torch.empty(B, device=input.device, dtype=val.dtype)
     best_idx = torch.empty(B, device=input.device, dtype=torch.int64)
     K.pit_search(val.detach().contiguous(), perms32, P, n, B, maximize, criterion.reduction == "mean", best_val, best_idx)
-    chosen = patterns.to(input.device)[best_idx]                   # (B, n)
+    chosen = perms64[best_idx]                                     # (B, n)
     picked = torch.gather(val, 2, chosen.unsqueeze(2)).squeeze(2)  # val[b, s, chosen[b, s]]
     loss = picked.mean(dim=1) if criterion.reduction == "mean" else picked.sum(dim=1)
     if batch_mean:
