@@ -14,14 +14,13 @@ split-K weight-gradient GEMMs).  Only the pre-activations a, z and the layer inp
 
 Everything here is plumbing: buffer allocation through torch, descriptor filling, launch order.
 """
-import math
 
 import os
 
 import torch
 
 from . import (STATS_SLOTS, EPI_PRELU_BWD, EPI_RESIDUAL, EPI_ROWSUMS, EPI_ROWSUMS_PRELU, EPI_SIGMOID, EPI_STATS_PRELU, PRO_GLN,
-               PRO_GLN_BWD, PRO_GLN_PRELU, PRO_NONE, PRO_PRELU, backend)
+               PRO_GLN_BWD, PRO_GLN_PRELU, PRO_PRELU, backend)
 
 
 def round_up(a, b):

@@ -2,16 +2,14 @@
 emulation (tests/emulator.py) on identical seeded buffers.  The emulator itself is pinned to the oracle / the
 reference golden vectors by the CPU tests, so agreement here chains each HIP kernel to the reference.
 Pure outputs are pre-filled with NaN so that an element the kernel forgets to write is caught."""
-import copy
 import itertools
-import math
 
 import pytest
 import torch
 
 import sepkernels
 from sepkernels import (EPI_PRELU_BWD, EPI_RESIDUAL, EPI_ROWSUMS, EPI_ROWSUMS_PRELU, EPI_SIGMOID, EPI_STATS_PRELU, PRO_GLN,
-                        PRO_GLN_BWD, PRO_GLN_PRELU, PRO_NONE, PRO_PRELU)
+                        PRO_GLN_BWD, PRO_GLN_PRELU, PRO_PRELU)
 from emulator import EmuBackend
 
 pytestmark = pytest.mark.gpu
