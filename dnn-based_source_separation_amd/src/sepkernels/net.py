@@ -19,6 +19,8 @@ import os
 
 import torch
 
+import sepkernels
+
 from . import (STATS_SLOTS, EPI_PRELU_BWD, EPI_RESIDUAL, EPI_ROWSUMS, EPI_ROWSUMS_PRELU, EPI_SIGMOID, EPI_STATS_PRELU, PRO_GLN,
                PRO_GLN_BWD, PRO_GLN_PRELU, PRO_PRELU, backend)
 
@@ -285,13 +287,16 @@ class _SideStream:
     disappear under the big ones.  `fork()` orders the side stream after everything enqueued on the main stream so far;
     `join()` orders the main stream after the side stream.  Tensors produced on the main stream and read on the side
     stream are handed to `keep()` so that the caching allocator does not recycle them while the side stream lags.
-    Measured on MI355X (paper-best, B=16): no gain -- 30.7 vs 30.5 ms/step.  Every kernel of this path is sized to fill the
-    chip's LDS/VGPR slots by itself, so a concurrent kernel only takes slots away from the other one; co-residency adds no
-    latency hiding.  Hence OFF by default (SEPK_SIDE_STREAM=1 turns it on); always off on CPU tensors (emulator tests)."""
+    Measured on MI355X (paper-best, B=16).  fp32-MFMA arithmetic: no gain -- 30.7 vs 30.5 ms/step: every kernel of that
+    path fills the chip's LDS/VGPR slots by itself, so a concurrent kernel only takes slots away from the other one.
+    Split arithmetic: 20.8 vs 21.2 ms/step (same box, twice, bit-identical loss) -- its weight-gradient kernel launches
+    512 workgroups onto 768 slots, and the chain's kernels take the rest.  Hence ON by default with SEP_ARITH_BF16X6 and
+    OFF with SEP_ARITH_F32 (SEPK_SIDE_STREAM=1 / 0 force it); always off on CPU tensors (emulator tests)."""
     _streams = {}
 
     def __init__(self, dev):
-        self.on = dev.type == "cuda" and os.environ.get("SEPK_SIDE_STREAM", "0") == "1"
+        want = os.environ.get("SEPK_SIDE_STREAM", "auto")
+        self.on = dev.type == "cuda" and (want == "1" or (want not in ("0", "1") and sepkernels.gemm_arith() == sepkernels.ARITH_BF16X6))
         if self.on:
             key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
             if key not in _SideStream._streams:
