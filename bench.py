@@ -274,9 +274,13 @@ def main():
                                    "synthetic mixtures, {} utterances/GPU, fwd + PIT(NegSI-SDR) + bwd + clip(5) + Adam".format(args.batch),
                        "global_batch": world * args.batch, "frames_per_utterance": F, "parallelism": "dp{}".format(world),
                        "utt_per_s": value / F, "samples_per_s": value / F * T_SAMPLES, "final_loss": float(loss),
-                       "gemm_arith": arith_name + (" (fp32 operands split exactly into 3 bf16 parts, 6 of 9 part products on the bf16 "
-                                                   "MFMA, fp32 accumulation; error vs fp64 at the fp32-MFMA path's level)"
-                                                   if arith_name == "bf16x6" else " (v_mfma_f32_32x32x2_f32)")},
+                       "gemm_arith": arith_name + {
+                           "bf16x6": " (fp32 operands split exactly into 3 bf16 parts, 6 of 9 part products on the bf16 MFMA, fp32 "
+                                     "accumulation; error vs fp64 at the fp32-MFMA path's level)",
+                           "f16x3": " (1x1-conv GEMMs: fp32 operands scaled by exact powers of two -- one for the weights, one per "
+                                    "frame column -- and split into 2 fp16 parts, 3 of 4 part products on the fp16 MFMA, fp32 "
+                                    "accumulation; weight gradients: exact 3-part bf16 split; error vs fp64 at the fp32-MFMA path's level)",
+                           "f32": " (v_mfma_f32_32x32x2_f32)"}[arith_name]},
             "step_roofline": {"mfma_frac": value / world * fl_frame / (FP32_MFMA_PEAK_TFLOPS * 1e12),
                               "hbm_frac": value / world * by_frame / (HBM_PEAK_TBS * 1e12),
                               "algorithmic_flop_per_frame": fl_frame, "algorithmic_bytes_per_frame": by_frame},
@@ -300,7 +304,7 @@ def main():
                                "peak_is": "dense fp32 MFMA (v_mfma_f32_32x32x2_f32); achieved = algorithmic fp32 flop / time"}
             out["roofline"].update(pmc_traffic(timed.variants))
             achw = flw / (msw * 1e-3) / 1e12 if msw > 0 else 0.0
-            out["roofline_wgrad"] = {"bound": "mfma", "kernel": "pw_wgrad_split_kernel" if arith_name == "bf16x6" else "pw_wgrad_direct_kernel", "achieved": achw, "peak": FP32_MFMA_PEAK_TFLOPS,
+            out["roofline_wgrad"] = {"bound": "mfma", "kernel": "pw_wgrad_split_kernel" if arith_name != "f32" else "pw_wgrad_direct_kernel", "achieved": achw, "peak": FP32_MFMA_PEAK_TFLOPS,
                                      "unit": "TFLOP/s", "frac": achw / FP32_MFMA_PEAK_TFLOPS, "launches_per_step": nw / args.steps,
                                      "avg_launch_ms": msw / max(nw, 1), "share_of_step": msw / (1e3 * elapsed_instr)}
         if world == 1 and not args.no_cpu_baseline:

@@ -648,13 +648,46 @@ __device__ __forceinline__ void mfma_split6(const u32x4_t (&a)[3], const u32x4_t
     acc = mfma_bf16(a[0], b[0], acc);
 }
 
+// AR == 2 (SEP_ARITH_F16X3): fp32 products from a TWO-part fp16 split, x*2^s = hi + lo with hi = fp16(x*2^s) (toward zero),
+// lo = fp16(x*2^s - hi) (11 + 11 significand bits), three part products hi*hi + hi*lo + lo*hi on
+// v_mfma_f32_32x32x16_f16: 3 x 32 matrix-pipe cycles and 6 VALU per pair of values where the bf16 split needs 6 x 32 and 11.
+// fp16 has 5 exponent bits, so the operands are brought into range with exact power-of-two scales: ONE for A, from a
+// caller-supplied upper bound of |A| (largest scaled value < 2^13), and for B one PER COLUMN, kept per lane (a column of
+// the B tile is a lane of the MFMA operand and owns its accumulator column) and lowered on the fly: when a chunk's column
+// maximum would pass 2^14 the lane's accumulators are rescaled (rare after the first chunks); both are undone on the
+// accumulators before the epilogue.  Values more than ~2^-25 below their column's maximum lose low bits (fp16 underflow):
+// the error is relative to |A||X| per output like fp32 accumulation's, not elementwise -- tools/split_accuracy.py,
+// tools/gemm_accuracy.py and the kernel tests put it at the fp32-MFMA path's level on operands spread over e^+-6.
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2_pair(const float x0, const float x1, unsigned& hi, unsigned& lo) {
+    const fp16x2_t h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+    const fp16x2_t l = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h.x, x1 - (float)h.y);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ void split2_frag(const float (&lo4)[4], const float (&hi4)[4], u32x4_t (&out)[2]) {
+    unsigned p[2][4];
+    split2_pair(lo4[0], lo4[1], p[0][0], p[1][0]);
+    split2_pair(lo4[2], lo4[3], p[0][1], p[1][1]);
+    split2_pair(hi4[0], hi4[1], p[0][2], p[1][2]);
+    split2_pair(hi4[2], hi4[3], p[0][3], p[1][3]);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) out[q] = u32x4_t{p[q][0], p[q][1], p[q][2], p[q][3]};
+}
+__device__ __forceinline__ void mfma_split3(const u32x4_t (&a)[2], const u32x4_t (&b)[2], f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a[0]), __builtin_bit_cast(f16x8_t, b[1]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a[1]), __builtin_bit_cast(f16x8_t, b[0]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a[0]), __builtin_bit_cast(f16x8_t, b[0]), acc, 0, 0, 0);
+}
+
 template <bool TRANS_A, int PRO, bool SPLIT, int EF, int AR = 0>
-__global__ __launch_bounds__(256, (AR == 1 ? 3 : PRO == SEP_PRO_GLN_BWD ? 3 : PRO >= SEP_PRO_GLN ? SEP_GLN_OCC : 4)) void pw_gemm_direct_kernel(const sep_gemm_desc d) {
+__global__ __launch_bounds__(256, (AR >= 1 ? 3 : PRO == SEP_PRO_GLN_BWD ? 3 : PRO >= SEP_PRO_GLN ? SEP_GLN_OCC : 4)) void pw_gemm_direct_kernel(const sep_gemm_desc d) {
     constexpr bool P_PRELU = PRO == SEP_PRO_PRELU || PRO == SEP_PRO_GLN_PRELU;
     constexpr bool P_GLN = PRO == SEP_PRO_GLN || PRO == SEP_PRO_GLN_PRELU;
     constexpr bool P_BWD = PRO == SEP_PRO_GLN_BWD;
     static_assert(AR == 0 || PRO != SEP_PRO_GLN_BWD, "the split arithmetic has no GLN_BWD form");
-    constexpr int NS = AR == 1 ? 3 : 2;          // ring depth: the bf16 path consumes a chunk ~3x faster, so it prefetches two ahead
+    constexpr int NS = AR >= 1 ? 3 : 2;          // ring depth: the split paths consume a chunk ~3x faster, so they prefetch two ahead          // ring depth: the bf16 path consumes a chunk ~3x faster, so it prefetches two ahead
     __shared__ DirectSmem<P_BWD, NS> sm;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: the DMA's LDS base goes to M0 without a waterfall loop
@@ -955,6 +988,76 @@ __global__ __launch_bounds__(256, (AR == 1 ? 3 : PRO == SEP_PRO_GLN_BWD ? 3 : PR
         if (more) read_b6(nstage, 1);
         __builtin_amdgcn_sched_barrier(0);
     };
+    int bexp[2] = {100, 100};            // per-lane scale exponent of this lane's column in column block ni (100 = not set yet)
+    int aexp = 0;                        // A * 2^aexp < 2^13
+    if (AR == 2) aexp = 13 - __builtin_amdgcn_frexp_expf(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, d.a_amax[0]))));
+    auto step3h = [&](const int kc, const int stage, const int nstage) {
+        u32x4_t pa[2][2], pb[2][2];
+        if (P_GLN) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    fs[h][kk] = sm.sc[kc * DK + 8 * lk + 4 * h + kk];
+                    fh[h][kk] = sm.sh[kc * DK + 8 * lk + 4 * h + kk];
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) fa[h][i][kk] = __builtin_ldexpf(fa[h][i][kk], aexp);
+            split2_frag(fa[0][i], fa[1][i], pa[i]);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) apply_pro(kc, h, kk);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            float m = 0.f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) m = fmaxf(m, fabsf(fb[h][ni][kk]));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));                          // the other lane half holds the column's other 8 k
+            const int e = __builtin_amdgcn_frexp_expf(m);                  // m = f * 2^e, f in [0.5, 1)
+            const bool grow = e + bexp[ni] > 14;
+            const int nexp = grow ? 9 - e : bexp[ni];
+            if (__builtin_amdgcn_ballot_w64(grow) != 0) {                  // rare after the first chunks
+                const int delta = nexp - bexp[ni];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = __builtin_ldexpf(acc[mi][ni][r], delta);
+            }
+            bexp[ni] = nexp;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) fb[h][ni][kk] = __builtin_ldexpf(fb[h][ni][kk], nexp);
+            split2_frag(fb[0][ni], fb[1][ni], pb[ni]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const bool more = kc + 1 < nk;
+        if (more) {
+            wait_keep4_and_barrier(NS == 3 && kc + 2 < nk);
+            if (kc + NS < nk) issue(stage);
+            read_a6(nstage);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_split3(pa[0], pb[0], acc[0][0]);
+        mfma_split3(pa[1], pb[0], acc[1][0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) read_b6(nstage, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_split3(pa[0], pb[1], acc[0][1]);
+        mfma_split3(pa[1], pb[1], acc[1][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) read_b6(nstage, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    };
     auto step = [&](const int kc, const int stage) {
         read_half(stage, 1, kc);
         mfma_half(kc, 0);
@@ -982,7 +1085,25 @@ __global__ __launch_bounds__(256, (AR == 1 ? 3 : PRO == SEP_PRO_GLN_BWD ? 3 : PR
     PROF_STAMP(2);
     if (AR == 0) read_half(0, 0, 0);
     int kc = 0;
-    if (AR == 1) {
+    if (AR == 2) {
+        read_a6(0);
+        read_b6(0, 0);
+        read_b6(0, 1);
+        for (; kc + 2 < nk; kc += 3) {
+            step3h(kc, 0, 1);
+            step3h(kc + 1, 1, 2);
+            step3h(kc + 2, 2, 0);
+        }
+        if (kc < nk) step3h(kc, 0, 1);
+        if (kc + 1 < nk) step3h(kc + 1, 1, 2);
+        // undo the scales: 2^aexp of A, 2^bexp of this lane's column
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = __builtin_ldexpf(acc[mi][ni][r], -aexp - bexp[ni]);
+    } else if (AR == 1) {
         read_a6(0);
         read_b6(0, 0);
         read_b6(0, 1);
@@ -1768,7 +1889,7 @@ extern "C" int sep_pw_gemm(const sep_gemm_desc* d, sep_stream_t stream) {
     SEP_REQUIRE(!d->k_split || (d->A2 && d->X2), "sep_pw_gemm: k_split without A2/X2");
     SEP_REQUIRE(!d->m_split || d->Y2, "sep_pw_gemm: m_split without Y2");
     SEP_REQUIRE(d->pro_mode >= 0 && d->pro_mode <= SEP_PRO_GLN_BWD, "sep_pw_gemm: bad pro_mode %d", d->pro_mode);
-    SEP_REQUIRE(d->arith == SEP_ARITH_F32 || d->arith == SEP_ARITH_BF16X6, "sep_pw_gemm: bad arith %d", d->arith);
+    SEP_REQUIRE(d->arith >= SEP_ARITH_F32 && d->arith <= SEP_ARITH_F16X3, "sep_pw_gemm: bad arith %d", d->arith);
     if (d->pro_mode == SEP_PRO_PRELU || d->pro_mode == SEP_PRO_GLN_PRELU || d->pro_mode == SEP_PRO_GLN_BWD)
         SEP_REQUIRE(d->pro_alpha, "sep_pw_gemm: prologue needs pro_alpha");
     if (d->pro_mode >= SEP_PRO_GLN)
@@ -1790,10 +1911,13 @@ extern "C" int sep_pw_gemm(const sep_gemm_desc* d, sep_stream_t stream) {
     SEP_REQUIRE(direct_ok || (d->K % BK == 0 && d->k_split % BK == 0), "sep_pw_gemm: the register-staged fallback (K=%d) needs K %% 32 == 0", d->K);
     if (direct_ok) {
         // curated combinations exist in both arithmetics (GLN_BWD: fp32 MFMA only -- its time is the prologue, measured equal)
-        const bool split6 = d->arith == SEP_ARITH_BF16X6;
+        const bool split3 = d->arith == SEP_ARITH_F16X3 && d->a_amax != nullptr;
+        const bool split6 = d->arith == SEP_ARITH_BF16X6 || d->arith == SEP_ARITH_F16X3;
 #define SEP_LD(T, P, S, E)                                                                                                                           \
     do {                                                                                                                                             \
-        if (split6 && P != SEP_PRO_GLN_BWD)                                                                                                          \
+        if (split3 && P != SEP_PRO_GLN_BWD)                                                                                                          \
+            hipLaunchKernelGGL((pw_gemm_direct_kernel<T, P, S, E, (P != SEP_PRO_GLN_BWD ? 2 : 0)>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *d); \
+        else if (split6 && P != SEP_PRO_GLN_BWD)                                                                                                     \
             hipLaunchKernelGGL((pw_gemm_direct_kernel<T, P, S, E, (P != SEP_PRO_GLN_BWD ? 1 : 0)>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *d); \
         else hipLaunchKernelGGL((pw_gemm_direct_kernel<T, P, S, E, 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);                          \
     } while (0)
@@ -1864,8 +1988,8 @@ extern "C" int sep_pw_wgrad(const sep_wgrad_desc* d, sep_stream_t stream) {
     static const bool force_staged = getenv("SEPK_FORCE_STAGED") != nullptr;
     const bool direct_ok = !force_staged && !d->g_mul && (d->x_mode < SEP_PRO_GLN || d->B / d->x_div <= WMAXB) &&
                            (long)d->nsplit <= (long)d->B * (d->ldt / DK);
-    SEP_REQUIRE(d->arith == SEP_ARITH_F32 || d->arith == SEP_ARITH_BF16X6, "sep_pw_wgrad: bad arith %d", d->arith);
-    if (direct_ok && d->arith == SEP_ARITH_BF16X6) {
+    SEP_REQUIRE(d->arith >= SEP_ARITH_F32 && d->arith <= SEP_ARITH_F16X3, "sep_pw_wgrad: bad arith %d", d->arith);
+    if (direct_ok && d->arith != SEP_ARITH_F32) {      // F16X3: the weight gradient stays on the bf16 split (both operands are activations)
         switch (d->x_mode) {
             case SEP_PRO_NONE: hipLaunchKernelGGL((pw_wgrad_split_kernel<SEP_PRO_NONE>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *d); break;
             case SEP_PRO_PRELU: hipLaunchKernelGGL((pw_wgrad_split_kernel<SEP_PRO_PRELU>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *d); break;

@@ -17,22 +17,34 @@ LIB_PATH = os.environ.get("SEPKERNELS_LIB", os.path.normpath(os.path.join(_HERE,
 # ---- constants mirrored from include/sepkernels.h -------------------------------------------------
 PRO_NONE, PRO_PRELU, PRO_GLN, PRO_GLN_PRELU, PRO_GLN_BWD = 0, 1, 2, 3, 4
 EPI_STATS_PRELU, EPI_RESIDUAL, EPI_SIGMOID, EPI_PRELU_BWD, EPI_ROWSUMS, EPI_ROWSUMS_PRELU = 1, 2, 4, 8, 16, 32
-ABI_VERSION = 7
+ABI_VERSION = 8
 STATS_SLOTS = 16   # SEP_STATS_SLOTS: gLN statistics are double[B][STATS_SLOTS][2]
-ARITH_F32, ARITH_BF16X6 = 0, 1     # SEP_ARITH_*: how sep_pw_gemm forms its fp32 products (include/sepkernels.h)
-_ARITH_NAMES = {"f32": ARITH_F32, "bf16x6": ARITH_BF16X6}
+ARITH_F32, ARITH_BF16X6, ARITH_F16X3 = 0, 1, 2     # SEP_ARITH_*: how sep_pw_gemm forms its fp32 products (include/sepkernels.h)
+_ARITH_NAMES = {"f32": ARITH_F32, "bf16x6": ARITH_BF16X6, "f16x3": ARITH_F16X3}
 _gemm_arith = None
 
 
 def gemm_arith():
-    """Arithmetic requested of sep_pw_gemm when a call does not name one: SEPK_GEMM_ARITH = bf16x6 (default) | f32."""
+    """Arithmetic requested of sep_pw_gemm / sep_pw_wgrad when a call does not name one:
+    SEPK_GEMM_ARITH = f16x3 (default) | bf16x6 | f32."""
     global _gemm_arith
     if _gemm_arith is None:
-        name = os.environ.get("SEPK_GEMM_ARITH", "bf16x6")
+        name = os.environ.get("SEPK_GEMM_ARITH", "f16x3")
         if name not in _ARITH_NAMES:
             raise SepKernelsError("SEPK_GEMM_ARITH must be one of {} (got '{}')".format(sorted(_ARITH_NAMES), name))
         _gemm_arith = _ARITH_NAMES[name]
     return _gemm_arith
+
+
+_weights_amax = None
+
+
+def set_weights_amax(t):
+    """Device scalar >= max|A| over every weight the following sep_pw_gemm calls will use (SEP_ARITH_F16X3), or None.
+    Returns the previous one.  net.forward / net.backward set it once per pass from the co-located parameter buffer."""
+    global _weights_amax
+    prev, _weights_amax = _weights_amax, t
+    return prev
 
 
 def gemm_arith_name():
@@ -44,7 +56,7 @@ def arith_code(name):
 
 
 def set_gemm_arith(name):
-    """'f32' | 'bf16x6'; returns the previous setting's name."""
+    """'f32' | 'bf16x6' | 'f16x3'; returns the previous setting's name."""
     global _gemm_arith
     prev = gemm_arith_name()
     _gemm_arith = _ARITH_NAMES[name]
@@ -59,7 +71,7 @@ class GemmDesc(ctypes.Structure):
                                     "accumulate", "arith")] + [("eps", ctypes.c_float), ("count", ctypes.c_double)] + \
                [(n, _vp) for n in ("A", "A2", "X", "X2", "Y", "Y2", "bias", "pro_alpha", "pro_stats", "pro_gamma", "pro_beta",
                                    "pro_aux", "pro_bsum", "pro_store", "pro_dalpha", "epi_alpha", "epi_stats", "epi_res",
-                                   "epi_aux", "epi_dalpha", "epi_rowpart")]
+                                   "epi_aux", "epi_dalpha", "epi_rowpart", "a_amax")]
 
 
 class WgradDesc(ctypes.Structure):
@@ -177,16 +189,22 @@ class HipBackend:
                 pro_mode=PRO_NONE, epi_flags=0, accumulate=0, eps=1e-12, count=0.0, bias=None, pro_alpha=None,
                 pro_stats=None, pro_gamma=None, pro_beta=None, pro_aux=None, pro_bsum=None, pro_store=None,
                 pro_dalpha=None, epi_alpha=None, epi_stats=None, epi_res=None, epi_aux=None, epi_dalpha=None,
-                epi_rowpart=None, arith=None):
+                epi_rowpart=None, arith=None, a_amax=None):
+        arith = gemm_arith() if arith is None else arith
+        if arith == ARITH_F16X3 and a_amax is None:
+            a_amax = _weights_amax
+            if a_amax is None:      # stand-alone caller: the bound is formed here (two small kernels per call)
+                a_amax = A.detach().abs().amax().reshape(1) if A2 is None else torch.maximum(A.detach().abs().amax(), A2.detach().abs().amax()).reshape(1)
         d = GemmDesc(B=B, M=M, K=K, T=T, ldt=ldt, trans_a=trans_a, k_split=k_split, m_split=m_split, pro_mode=pro_mode,
-                     epi_flags=epi_flags, accumulate=accumulate, arith=gemm_arith() if arith is None else arith, eps=eps,
+                     epi_flags=epi_flags, accumulate=accumulate, arith=arith, eps=eps,
                      count=float(count),
                      A=_ptr(A, _f32), A2=_ptr(A2, _f32), X=_ptr(X, _f32), X2=_ptr(X2, _f32), Y=_ptr(Y, _f32), Y2=_ptr(Y2, _f32),
                      bias=_ptr(bias, _f32), pro_alpha=_ptr(pro_alpha, _f32), pro_stats=_ptr(pro_stats, _f64),
                      pro_gamma=_ptr(pro_gamma, _f32), pro_beta=_ptr(pro_beta, _f32), pro_aux=_ptr(pro_aux, _f32),
                      pro_bsum=_ptr(pro_bsum, _f32), pro_store=_ptr(pro_store, _f32), pro_dalpha=_ptr(pro_dalpha, _f64),
                      epi_alpha=_ptr(epi_alpha, _f32), epi_stats=_ptr(epi_stats, _f64), epi_res=_ptr(epi_res, _f32),
-                     epi_aux=_ptr(epi_aux, _f32), epi_dalpha=_ptr(epi_dalpha, _f64), epi_rowpart=_ptr(epi_rowpart, _f32))
+                     epi_aux=_ptr(epi_aux, _f32), epi_dalpha=_ptr(epi_dalpha, _f64), epi_rowpart=_ptr(epi_rowpart, _f32),
+                     a_amax=_ptr(a_amax, _f32))
         _check(load().sep_pw_gemm(ctypes.byref(d), _stream()), "sep_pw_gemm")
 
     def pw_wgrad(self, *, B, M, N, T, ldt, G, X, partial, nsplit, G2=None, g_split=0, Gaux=None, g_mul=0, g_div=1,

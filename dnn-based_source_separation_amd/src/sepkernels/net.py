@@ -93,6 +93,22 @@ class Saved:
     pass
 
 
+def _weights_amax(P):
+    """(1,) device tensor >= max|w| over all parameters in P: the A-operand bound of SEP_ARITH_F16X3.  One reduction over
+    the co-located parameter buffer when the parameters are views of one (ConvTasNet._flatten_parameters); otherwise
+    one per tensor."""
+    if sepkernels.gemm_arith() != sepkernels.ARITH_F16X3 or getattr(backend(), "name", "") != "hip":
+        return None
+    ts = [t for t in P.values() if torch.is_tensor(t)]
+    lo = min(ts, key=lambda t: t.data_ptr())
+    hi = max(ts, key=lambda t: t.data_ptr())
+    n = (hi.data_ptr() - lo.data_ptr()) // 4 + hi.numel()
+    same = all(t.untyped_storage().data_ptr() == lo.untyped_storage().data_ptr() for t in ts)
+    if same and lo.dtype == torch.float32 and n <= 4 * sum(t.numel() for t in ts):
+        return lo.detach().as_strided((n,), (1,)).abs().amax().reshape(1)
+    return torch.stack([t.detach().abs().amax() for t in ts]).amax().reshape(1).float()
+
+
 def head_forward(cfg, P, mixture, stats0):
     """Encoder (+input padding) and the separator's first gLN + 1x1 bottleneck.
     Returns (geo, w (B,N,ldt), x0 (B,Bn,ldt)); stats0 (B,SLOTS,2) zeroed by the caller receives the statistics of w."""
@@ -215,6 +231,14 @@ def head_backward(cfg, P, geo, stats0, w, mixture, dx0, dwm, G):
 
 
 def forward(cfg, P, mixture, want_latent=False, save=True):
+    prev = sepkernels.set_weights_amax(_weights_amax(P))
+    try:
+        return _forward(cfg, P, mixture, want_latent, save)
+    finally:
+        sepkernels.set_weights_amax(prev)
+
+
+def _forward(cfg, P, mixture, want_latent, save):
     """cfg: model config dict; P: dict name -> parameter tensor; mixture (B, Cin, T) fp32 contiguous.
     Returns (est (B, n_src, Cin, T), latent or None, Saved or None)."""
     K = backend()
@@ -290,13 +314,13 @@ class _SideStream:
     Measured on MI355X (paper-best, B=16).  fp32-MFMA arithmetic: no gain -- 30.7 vs 30.5 ms/step: every kernel of that
     path fills the chip's LDS/VGPR slots by itself, so a concurrent kernel only takes slots away from the other one.
     Split arithmetic: 20.8 vs 21.2 ms/step (same box, twice, bit-identical loss) -- its weight-gradient kernel launches
-    512 workgroups onto 768 slots, and the chain's kernels take the rest.  Hence ON by default with SEP_ARITH_BF16X6 and
+    512 workgroups onto 768 slots, and the chain's kernels take the rest.  Hence ON by default with the split arithmetics and
     OFF with SEP_ARITH_F32 (SEPK_SIDE_STREAM=1 / 0 force it); always off on CPU tensors (emulator tests)."""
     _streams = {}
 
     def __init__(self, dev):
         want = os.environ.get("SEPK_SIDE_STREAM", "auto")
-        self.on = dev.type == "cuda" and (want == "1" or (want not in ("0", "1") and sepkernels.gemm_arith() == sepkernels.ARITH_BF16X6))
+        self.on = dev.type == "cuda" and (want == "1" or (want not in ("0", "1") and sepkernels.gemm_arith() != sepkernels.ARITH_F32))
         if self.on:
             key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
             if key not in _SideStream._streams:
@@ -331,6 +355,14 @@ class _SideStream:
 
 
 def backward(cfg, P, sv, d_est, G, on_ready=None):
+    prev = sepkernels.set_weights_amax(_weights_amax(P))
+    try:
+        return _backward(cfg, P, sv, d_est, G, on_ready)
+    finally:
+        sepkernels.set_weights_amax(prev)
+
+
+def _backward(cfg, P, sv, d_est, G, on_ready):
     """Writes the gradient of every parameter into G[name] (overwrites; G tensors have the parameter shapes).
 
     on_ready(first_block, last_block_or_None): optional callback for gradient bucketing.  It is called when every

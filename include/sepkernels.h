@@ -33,7 +33,7 @@ extern "C" {
 
 typedef void* sep_stream_t; /* hipStream_t */
 
-#define SEP_ABI_VERSION 7
+#define SEP_ABI_VERSION 8
 #define SEP_STATS_SLOTS 16
 
 int sep_version(void);
@@ -61,9 +61,16 @@ const char* sep_last_error(void);
  * BF16X6: every operand value is split EXACTLY into three truncated-bf16 parts (8+8+8 significand bits) and
  *         x*y = hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (the three dropped part
  *         products are <= 2^-24 |xy| each); results agree with fp64 as closely as the F32 path's do (tests), at
- *         6 x 32 instead of 8 x 64 matrix-pipe cycles per 16-deep chunk.  Inputs are assumed finite. */
+ *         6 x 32 instead of 8 x 64 matrix-pipe cycles per 16-deep chunk.  Inputs are assumed finite.
+ * F16X3:  sep_pw_gemm only (sep_pw_wgrad treats it as BF16X6).  Two-part fp16 split x*2^s = hi + lo (11 + 11 bits),
+ *         x*y = hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 (3 x 32 cycles), operands brought into fp16's exponent
+ *         range by exact power-of-two scales: one for A from the caller's bound a_amax >= max|A| (device scalar), one per
+ *         column of X chosen and adjusted inside the kernel.  The error is relative to |A||X| per output (like fp32
+ *         accumulation's), not elementwise: values ~2^-25 below their column's maximum lose low bits.  Without a_amax
+ *         the call runs as BF16X6. */
 #define SEP_ARITH_F32 0
 #define SEP_ARITH_BF16X6 1
+#define SEP_ARITH_F16X3 2
 
 /* Pointwise (1x1) convolution as a GEMM on MFMA (fp32 in / fp32 accumulate):
  *     Y[b][m][t] = epilogue( sum_k A[m][k] * prologue(X[b][k][t]) + bias[m] )
@@ -102,6 +109,7 @@ typedef struct sep_gemm_desc {
     const float* epi_aux;
     double* epi_dalpha;
     float* epi_rowpart;
+    const float* a_amax; /* SEP_ARITH_F16X3: device scalar >= max|A| (and |A2|); any upper bound, e.g. over all parameters */
 } sep_gemm_desc;
 
 int sep_pw_gemm(const sep_gemm_desc* d, sep_stream_t stream);

@@ -54,7 +54,7 @@ class EmuBackend:
                 pro_mode=PRO_NONE, epi_flags=0, accumulate=0, eps=1e-12, count=0.0, bias=None, pro_alpha=None,
                 pro_stats=None, pro_gamma=None, pro_beta=None, pro_aux=None, pro_bsum=None, pro_store=None,
                 pro_dalpha=None, epi_alpha=None, epi_stats=None, epi_res=None, epi_aux=None, epi_dalpha=None,
-                epi_rowpart=None, arith=None):
+                epi_rowpart=None, arith=None, a_amax=None):
         dt = X.dtype
         k1 = k_split if k_split else K
         if trans_a:

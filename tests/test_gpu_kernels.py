@@ -19,9 +19,10 @@ HIP = sepkernels.HipBackend()
 G = torch.Generator().manual_seed(1234)
 
 
-@pytest.fixture(params=["bf16x6", "f32"])
+@pytest.fixture(params=["bf16x6", "f32", "f16x3"])
 def arith(request):
-    """Both arithmetics of sep_pw_gemm (SEP_ARITH_*): exact three-way bf16 split on the bf16 MFMA, and the fp32 MFMA."""
+    """The arithmetics of sep_pw_gemm / sep_pw_wgrad (SEP_ARITH_*): exact three-way bf16 split on the bf16 MFMA, the fp32
+    MFMA, and the scaled two-part fp16 split (stand-alone calls form the |A| bound themselves)."""
     prev = sepkernels.set_gemm_arith(request.param)
     yield request.param
     sepkernels.set_gemm_arith(prev)
@@ -232,8 +233,9 @@ def _wgrad_both(kw, tol=3e-4):
 
 @pytest.mark.parametrize("K,scale", [(128, 1.0), (512, 1.0), (1024, 1e-3), (512, 1e4)])
 def test_gemm_split_arithmetic_is_as_accurate_as_fp32_mfma(K, scale):
-    """Against fp64: the error of the bf16x6 path is at the level of the fp32-MFMA path's (both are fp32 products with
-    fp32 accumulation), over wide dynamic range of the operands (the split is exact for any finite fp32 value)."""
+    """Against fp64: the errors of the bf16x6 and f16x3 paths are at the level of the fp32-MFMA path's (all are fp32
+    products with fp32 accumulation), over wide dynamic range of the operands (the bf16 split is exact for any finite fp32
+    value; the fp16 split is scaled per column of X)."""
     B, M, T = 2, 256, 1000
     ldt = 1024
     X = padded(B, K, T, ldt) * torch.exp(3 * rnd(B, K, 1))          # rows of very different magnitude
@@ -241,7 +243,7 @@ def test_gemm_split_arithmetic_is_as_accurate_as_fp32_mfma(K, scale):
     A = rnd(M, K) * scale
     ref = torch.einsum("mk,bkt->bmt", A.double(), X.double())
     err = {}
-    for name in ("f32", "bf16x6"):
+    for name in ("f32", "bf16x6", "f16x3"):
         Y = torch.full((B, M, ldt), float("nan"), device="cuda")
         HIP.pw_gemm(B=B, M=M, K=K, T=T, ldt=ldt, A=A.cuda(), X=X.cuda(), Y=Y, arith=sepkernels.arith_code(name))
         torch.cuda.synchronize()
@@ -249,6 +251,8 @@ def test_gemm_split_arithmetic_is_as_accurate_as_fp32_mfma(K, scale):
         err[name] = (d.abs().max().item() / ref.abs().max().item(), (d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item())
     assert err["bf16x6"][0] <= max(2 * err["f32"][0], 2e-7), err
     assert err["bf16x6"][1] <= max(2 * err["f32"][1], 1e-7), err
+    assert err["f16x3"][0] <= max(3 * err["f32"][0], 3e-7), err          # error relative to |A||X| per output, like fp32's
+    assert err["f16x3"][1] <= max(3 * err["f32"][1], 2e-7), err
     assert err["f32"][0] <= 5e-6, err
 
 
