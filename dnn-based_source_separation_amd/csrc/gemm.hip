@@ -12,8 +12,10 @@
 //                                 residual / skip accumulate, sigmoid, PReLU backward, gLN-backward row sums)
 //   pw_gemm_kernel                register-staged GEMM; fallback for contractions that are not a multiple of 16
 //   pw_gemm_direct_kernel<...,AR> THE fast path, LDS-DMA ring, prologue (PReLU / gLN / gLN backward) on the B fragments.
-//                                 AR = 1 (SEP_ARITH_BF16X6, default): fp32 products by exact three-way bf16 split on
-//                                 v_mfma_f32_32x32x16_bf16, 3-stage ring, 3 workgroups per CU, whole-chunk steps;
+//                                 AR = 2 (SEP_ARITH_F16X3, default): fp32 products by a scaled two-part fp16 split on
+//                                 v_mfma_f32_32x32x16_f16 (one scale for A, one per column of X kept per lane);
+//                                 AR = 1 (SEP_ARITH_BF16X6): fp32 products by exact three-way bf16 split on
+//                                 v_mfma_f32_32x32x16_bf16; both: 3-stage ring, 3 workgroups per CU, whole-chunk steps;
 //                                 AR = 0 (SEP_ARITH_F32): v_mfma_f32_32x32x2_f32, 2-stage ring, 4 workgroups per CU,
 //                                 half-chunk software pipeline -- design notes at the kernel
 //   pw_wgrad_kernel               register-staged weight gradient; fallback (g_mul = decoder basis gradient)
