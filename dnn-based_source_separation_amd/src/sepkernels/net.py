@@ -93,20 +93,24 @@ class Saved:
     pass
 
 
-def _weights_amax(P):
-    """(1,) device tensor >= max|w| over all parameters in P: the A-operand bound of SEP_ARITH_F16X3.  One reduction over
-    the co-located parameter buffer when the parameters are views of one (ConvTasNet._flatten_parameters); otherwise
-    one per tensor."""
-    if sepkernels.gemm_arith() != sepkernels.ARITH_F16X3 or getattr(backend(), "name", "") != "hip":
-        return None
-    ts = [t for t in P.values() if torch.is_tensor(t)]
+def amax_over(ts):
+    """(1,) tensor >= max|t| over the tensors ts: ONE reduction when they are views of one buffer (spans it, alignment gaps
+    included -- they are zero), else one per tensor."""
     lo = min(ts, key=lambda t: t.data_ptr())
     hi = max(ts, key=lambda t: t.data_ptr())
-    n = (hi.data_ptr() - lo.data_ptr()) // 4 + hi.numel()
-    same = all(t.untyped_storage().data_ptr() == lo.untyped_storage().data_ptr() for t in ts)
-    if same and lo.dtype == torch.float32 and n <= 4 * sum(t.numel() for t in ts):
+    n = (hi.data_ptr() - lo.data_ptr()) // lo.element_size() + hi.numel()
+    same = all(t.untyped_storage().data_ptr() == lo.untyped_storage().data_ptr() and t.dtype == lo.dtype for t in ts)
+    if same and lo.is_contiguous() and n <= 4 * sum(t.numel() for t in ts):
         return lo.detach().as_strided((n,), (1,)).abs().amax().reshape(1)
-    return torch.stack([t.detach().abs().amax() for t in ts]).amax().reshape(1).float()
+    return torch.stack([t.detach().abs().amax().float() for t in ts]).amax().reshape(1)
+
+
+def _weights_amax(P):
+    """(1,) device tensor >= max|w| over all parameters in P: the A-operand bound of SEP_ARITH_F16X3 (None when another
+    arithmetic or the CPU emulator is in use)."""
+    if sepkernels.gemm_arith() != sepkernels.ARITH_F16X3 or getattr(backend(), "name", "") != "hip":
+        return None
+    return amax_over([t for t in P.values() if torch.is_tensor(t)])
 
 
 def head_forward(cfg, P, mixture, stats0):
@@ -231,6 +235,7 @@ def head_backward(cfg, P, geo, stats0, w, mixture, dx0, dwm, G):
 
 
 def forward(cfg, P, mixture, want_latent=False, save=True):
+    """See _forward; sets the per-pass weight bound of SEP_ARITH_F16X3 around it."""
     prev = sepkernels.set_weights_amax(_weights_amax(P))
     try:
         return _forward(cfg, P, mixture, want_latent, save)
@@ -355,6 +360,7 @@ class _SideStream:
 
 
 def backward(cfg, P, sv, d_est, G, on_ready=None):
+    """See _backward; sets the per-pass weight bound of SEP_ARITH_F16X3 around it."""
     prev = sepkernels.set_weights_amax(_weights_amax(P))
     try:
         return _backward(cfg, P, sv, d_est, G, on_ready)

@@ -70,3 +70,24 @@ def test_pad_frames_are_zero(golden_dir, emu):
     assert sv.geo.ldt % 128 == 0 and sv.geo.ldt >= F
     for t in [sv.w, sv.m, sv.skip] + [u for act in sv.acts for u in act]:
         assert t[..., F:].abs().max() == 0
+
+
+def test_weight_bound_over_a_flat_buffer_and_over_scattered_tensors():
+    """net.amax_over: the |A| bound of SEP_ARITH_F16X3 -- one reduction over the span when the tensors are views of one
+    buffer (gaps included), per tensor otherwise; always >= every element's magnitude."""
+    flat = torch.zeros(300)
+    a, b, c = flat[16:116].view(10, 10), flat[128:160], flat[200:300].view(4, 25)
+    torch.manual_seed(0)
+    for t in (a, b, c):
+        t.copy_(torch.randn(t.shape))
+    b[3] = -7.5
+    flat[180] = 99.0                                       # inside the span, in no tensor: may raise the bound, never lower it
+    got = net.amax_over([c, a, b])
+    assert got.shape == (1,) and got.item() == 99.0
+    flat[180] = 0.0
+    assert net.amax_over([c, a, b]).item() == 7.5
+    scattered = [torch.randn(5, 5), torch.full((3,), -11.0), torch.randn(2, 2, 2)]
+    assert net.amax_over(scattered).item() == 11.0
+    far = torch.zeros(1_000_000)
+    far[500_000] = 5.0
+    assert net.amax_over([far[:4], far[-4:]]).item() == 0.0          # same buffer, but a span 125000x the data: per tensor
