@@ -35,18 +35,24 @@ def fp16x3(A, B, scale_b="column"):
     return (ah @ bl + al @ bh + ah @ bh) / (sa * sb)
 
 
-def report(name, A, B):
+def cases(K=512, M=256, N=512):
+    A = torch.randn(M, K) * K ** -0.5
+    return A, [("unit-variance activations", torch.randn(K, N)),
+               ("channels spread over e^+-4", torch.randn(K, N) * torch.exp(4 * torch.randn(K, 1))),
+               ("gradient-like, 1e-6 overall", 1e-6 * torch.randn(K, N) * torch.exp(2 * torch.randn(K, 1))),
+               ("columns spread over e^+-6", torch.randn(K, N) * torch.exp(6 * torch.randn(1, N))),
+               ("sparse spikes (1e4) in noise", torch.randn(K, N) + 1e4 * (torch.rand(K, N) < 1e-3))]
+
+
+def errors(A, B):
     ref = A.double() @ B.double()
-    den = (A.double().abs() @ B.double().abs())                              # the natural scale of a dot product's rounding error
+    den = A.double().abs() @ B.double().abs()                                # the natural scale of a dot product's rounding error
     out = {"fp32": A @ B, "bf16x6": bf16x6(A, B), "fp16x3 col-scale": fp16x3(A, B), "fp16x3 one scale": fp16x3(A, B, "tensor")}
-    print("{:34s}".format(name) + "  ".join("{} {:.1e}".format(k, ((v.double() - ref).abs() / den).max().item()) for k, v in out.items()))
+    return {k: ((v.double() - ref).abs() / den).max().item() for k, v in out.items()}
 
 
-K, M, N = 512, 256, 512
-A = torch.randn(M, K) * K ** -0.5
-print("max |err| / (|A| |B|)  (fp32 rounding of a length-{} dot product is ~1e-7)".format(K))
-report("unit-variance activations", A, torch.randn(K, N))
-report("channels spread over e^+-4", A, torch.randn(K, N) * torch.exp(4 * torch.randn(K, 1)))
-report("gradient-like, 1e-6 overall", A, 1e-6 * torch.randn(K, N) * torch.exp(2 * torch.randn(K, 1)))
-report("columns spread over e^+-6", A, torch.randn(K, N) * torch.exp(6 * torch.randn(1, N)))
-report("sparse spikes (1e4) in noise", A, torch.randn(K, N) + 1e4 * (torch.rand(K, N) < 1e-3))
+if __name__ == "__main__":
+    A, cs = cases()
+    print("max |err| / (|A| |B|)  (fp32 rounding of a length-512 dot product is ~1e-7)")
+    for name, B in cs:
+        print("{:34s}".format(name) + "  ".join("{} {:.1e}".format(k, v) for k, v in errors(A, B).items()))
