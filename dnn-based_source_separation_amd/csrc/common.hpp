@@ -76,3 +76,6 @@ __device__ __forceinline__ void gln_mu_rstd(const double* st, double count, floa
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// gemm_coop.hip: the packed-weight form of sep_pw_gemm (1 = launched, 0 = not one of its shapes)
+int sep_pw_gemm_packed(const sep_gemm_desc* d, hipStream_t stream);

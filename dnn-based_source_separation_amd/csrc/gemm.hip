@@ -25,12 +25,10 @@
 // Common to all: 128x128 output tile, each wave a 64x64 sub-tile = 2x2 32x32 MFMA accumulators (64 VGPRs);
 // the normalised tensors v1, v2 of the reference never exist in HBM; workgroups that share an X column tile are placed
 // on the same XCD (blockIdx % 8) so the tile is fetched from HBM once and re-read from that L2.
-#include "common.hpp"
+#include "gemm_common.hpp"
 #include <stdlib.h>
 #include <string.h>
 #include <stddef.h>
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
@@ -81,246 +79,7 @@ __device__ __forceinline__ void mfma_chunk32(const float* __restrict__ Ab, const
 #undef SEP_MFMA_GROUP
 }
 
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
-__device__ __forceinline__ const float* byte_off(const float* base, unsigned bytes) {
-    return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)bytes);
-}
-// Sum over the 16 lanes of a DPP row (lanes 16i .. 16i+15), result in every lane of the row.  Four VALU with DPP operands
-// (quad xor 1, quad xor 2, mirror inside 8, mirror inside 16: a sum does not care which partner it meets) instead of four
-// ds_bpermute round trips through the LDS crossbar with an lgkmcnt wait each.
-__device__ __forceinline__ float row16_sum(float x) {
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));   // row_half_mirror
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));   // row_mirror
-    return x;
-}
-// output tile store of the GEMM epilogue
-__device__ __forceinline__ void st4_out(float* p, float4 v) {
-#if defined(SEP_EXP_NT_STORE)
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    f4v t = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(t, reinterpret_cast<f4v*>(p));
-#else
-    *reinterpret_cast<float4*>(p) = v;
-#endif
-}
 
-// Shared epilogue of the GEMM kernels.  acc[mi][ni] are the wave's four 32x32 accumulators.
-//
-// The MFMA C layout gives a lane ONE column of 16 different rows, i.e. 4-byte stores.  Measured on the first
-// version: 64 dword stores per lane made the epilogue 40 % of the short-K GEMMs (store-issue bound, ~2 TB/s).
-// So each wave transposes its tile through LDS (32 rows at a time, wave-private region, conflict-free
-// ds_write_b32 / ds_read_b128) and every global access of the epilogue -- result stores, residual / accumulate /
-// aux reads -- is a float4 covering 256 contiguous bytes per 16 lanes.  All reads of a half tile are issued before
-// its first store (a load placed after a store cannot be hoisted: possible alias).
-constexpr int EPI_LD = 68;                         // floats per transposed row (64 + 4: keeps float4 alignment)
-constexpr int EPI_WAVE_FLOATS = 32 * EPI_LD;       // LDS floats one wave needs
-
-#ifdef SEP_PROF
-__device__ long long g_prof[4][4][16];
-__device__ long long g_blk_start[8192], g_blk_end[8192];      // [block sample][wave][stamp]
-#define PROF_STAMP(k) do { if (prof_slot >= 0 && lane == 0) g_prof[prof_slot][wid][k] = clock64(); } while (0)
-#else
-#define PROF_STAMP(k) do { } while (0)
-#endif
-#ifdef SEP_PROF
-#define PROF_ARG , const int prof_slot
-#define PROF_PASS , prof_slot
-#else
-#define PROF_ARG
-#define PROF_PASS
-#endif
-// EF >= 0: the epilogue flag set as a compile-time constant AND a promise of the host dispatch that M (and m_split) are
-// multiples of 128, so no row predicate exists (the host instantiates this for the combinations the model uses);
-// EF < 0: flags read from the descriptor, rows predicated.  Column edge (the last column tile of a sample, frames >= T):
-// the (bias-added) tile is multiplied by a 0/1 lane mask in a small wave-uniform block BEFORE the flag-dependent math, so
-// statistics, row sums and the stored pad frames come out as zeros without a second copy of the math.
-// Why this is lean on purpose: when the other three waves of a SIMD are issuing MFMAs back to back, a VALU instruction of
-// the epilogue wave gets an issue slot roughly once per MFMA (s_memtime stamps: the same epilogue took 14 k cycles alone,
-// 47-58 k next to three busy waves, and it STRETCHED when the main loops were staggered away from it).  First version:
-// run-time flags (~300 branches per tile), 64-bit address arithmetic and a predicate per row: 800-1600 VALU per
-// tile-wave.  Now 150-800: addresses are a wave-uniform row pointer (SGPRs) plus one per-lane byte offset, the loads of a
-// group are issued before the first use, flags and predicates fold away.  Keep it free of scratch: above ~200 B/lane the
-// runtime falls back to per-dispatch scratch allocation (+25 us per launch, measured).
-template <int EF>
-__device__ __forceinline__ void gemm_epilogue(const sep_gemm_desc& d, f32x16 (&acc)[2][2], const int b, const int m0,
-                                              const int t0, const int wr, const int wc, const int lk, const int l31,
-                                              const int tid, float* lds, double* red PROF_ARG) {
-    const int lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ef = EF >= 0 ? EF : d.epi_flags;
-    const float alpha_e = (ef & (SEP_EPI_STATS_PRELU | SEP_EPI_PRELU_BWD | SEP_EPI_ROWSUMS_PRELU)) ? d.epi_alpha[0] : 0.f;
-    float st_s = 0.f, st_ss = 0.f, dalpha_e = 0.f;
-    const int Mfirst = d.m_split ? d.m_split : d.M;
-    const bool second = d.m_split && m0 >= d.m_split;        // block-uniform: m_split is a multiple of BM
-    const int Mdst = second ? d.M - d.m_split : Mfirst;
-    const int rowoff = second ? d.m_split : 0;
-    float* __restrict__ dst = second ? d.Y2 : d.Y;
-    const bool acc_this = d.accumulate && (second || !d.m_split);
-    const bool use_res = (ef & SEP_EPI_RESIDUAL) && !second;
-    const bool use_aux = (ef & (SEP_EPI_PRELU_BWD | SEP_EPI_ROWSUMS)) != 0;
-    const bool has_bias = d.bias != nullptr;
-    float* Tw = lds + wid * EPI_WAVE_FLOATS;
-    const int rsub = lane >> 4, c4 = lane & 15;              // read-back: 4 rows x 16 float4 per pass
-    const int tc = t0 + wc * 64 + 4 * c4;
-    // wave-uniform pointers to (first row of this wave, first frame of this tile); a lane adds lane_off bytes
-    const int wrow = m0 + wr * 64;                           // first output row of this wave
-    const unsigned lane_off = 4u * (unsigned)(rsub * d.ldt + wc * 64 + 4 * c4);
-    float* const dst_w = dst + ((size_t)b * Mdst + (wrow - rowoff)) * d.ldt + t0;
-    const float* const res_w = use_res ? d.epi_res + ((size_t)b * Mfirst + wrow) * d.ldt + t0 : nullptr;
-    const float* const aux_w = use_aux ? d.epi_aux + ((size_t)b * d.M + wrow) * d.ldt + t0 : nullptr;
-    const float* const bias_w = has_bias ? d.bias + wrow : nullptr;
-    constexpr bool FULL = EF >= 0;          // rows never need a predicate
-    constexpr int GRP = FULL ? 4 : 1;
-    const bool full_cols = t0 + BN <= d.T;  // block-uniform
-    float cm[4];                            // 0/1 column mask of this lane's four frames
-#pragma unroll
-    for (int e = 0; e < 4; ++e) cm[e] = (tc + e) < d.T ? 1.f : 0.f;
-
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        // ---- transpose: registers -> LDS (C layout) --------------------------------------------
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rl = (r & 3) + 8 * (r >> 2) + 4 * lk;
-            Tw[rl * EPI_LD + l31] = acc[mi][0][r];
-            Tw[rl * EPI_LD + 32 + l31] = acc[mi][1][r];
-        }
-        __builtin_amdgcn_wave_barrier();       // LDS is in-order per wave; this only pins the compiler's order
-#ifdef SEP_PROF
-        __builtin_amdgcn_s_waitcnt(0x0070);
-        PROF_STAMP(8 + 4 * mi);
-#endif
-        // ---- per group of GRP passes (4 rows each): every global read issued back to back, then compute + stores.
-        //      Four on full tiles (eight would spill: 3 x 8 float4 of operands next to the second half's accumulators),
-        //      two on edge tiles, whose predicates need registers too -- ANY scratch in this kernel costs occupancy.
-        //      Wave-uniform options (bias / residual / accumulate) are whole-group blocks: one scalar branch each.
-#pragma unroll
-        for (int g4 = 0; g4 < 8; g4 += GRP) {
-            float4 ext[GRP], aux[GRP], old[GRP];
-            float bs[GRP];
-            bool ok[GRP];
-#pragma unroll
-            for (int j = 0; j < GRP; ++j) {
-                ok[j] = FULL || (wrow + mi * 32 + (g4 + j) * 4 + rsub) < d.M;
-                if (!FULL) {                       // rows past M: neutral operands (on full tiles every use is guarded by the same flag as its load)
-                    bs[j] = 0.f;
-                    ext[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    aux[j] = ext[j];
-                    old[j] = ext[j];
-                }
-            }
-            if (has_bias) {
-#pragma unroll
-                for (int j = 0; j < GRP; ++j)
-                    if (ok[j]) bs[j] = *byte_off(bias_w + mi * 32 + (g4 + j) * 4, 4u * (unsigned)rsub);
-            }
-            if (use_res) {
-#pragma unroll
-                for (int j = 0; j < GRP; ++j)
-                    if (ok[j]) ext[j] = ld4(byte_off(res_w + (mi * 32 + (g4 + j) * 4) * (size_t)d.ldt, lane_off));
-            }
-            if (use_aux) {
-#pragma unroll
-                for (int j = 0; j < GRP; ++j)
-                    if (ok[j]) aux[j] = ld4(byte_off(aux_w + (mi * 32 + (g4 + j) * 4) * (size_t)d.ldt, lane_off));
-            }
-            if (acc_this) {
-#pragma unroll
-                for (int j = 0; j < GRP; ++j)
-                    if (ok[j]) old[j] = ld4(byte_off(dst_w + (mi * 32 + (g4 + j) * 4) * (size_t)d.ldt, lane_off));
-            }
-#ifdef SEP_PROF
-            __builtin_amdgcn_s_waitcnt(0x0070);
-            PROF_STAMP(9 + 4 * mi);
-#endif
-            float4 outv[GRP];
-#pragma unroll
-            for (int j = 0; j < GRP; ++j) outv[j] = ld4(Tw + ((g4 + j) * 4 + rsub) * EPI_LD + 4 * c4);
-            if (has_bias) {
-#pragma unroll
-                for (int j = 0; j < GRP; ++j) { outv[j].x += bs[j]; outv[j].y += bs[j]; outv[j].z += bs[j]; outv[j].w += bs[j]; }
-            }
-            if (!full_cols) {
-#pragma unroll
-                for (int j = 0; j < GRP; ++j) { outv[j].x *= cm[0]; outv[j].y *= cm[1]; outv[j].z *= cm[2]; outv[j].w *= cm[3]; }
-            }
-#pragma unroll
-            for (int j = 0; j < GRP; ++j) {
-                float v[4] = {outv[j].x, outv[j].y, outv[j].z, outv[j].w};
-                float ax[4] = {0.f, 0.f, 0.f, 0.f};
-                if (use_aux) { ax[0] = aux[j].x; ax[1] = aux[j].y; ax[2] = aux[j].z; ax[3] = aux[j].w; }
-                float rs1 = 0.f, rs2 = 0.f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool live = FULL || ok[j];          // invalid frames already hold zeros
-                    if (ef & SEP_EPI_STATS_PRELU) {
-                        const float u = prelu_f(v[e], alpha_e);
-                        if (live) { st_s += u; st_ss = fmaf(u, u, st_ss); }
-                    }
-                    // 1 / (1 + 2^(-v log2 e)) on the bare v_exp_f32 / v_rcp_f32 (1 ulp each; the libm forms cost ~17 VALU)
-                    if (ef & SEP_EPI_SIGMOID) v[e] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v[e]));
-                    if (ef & SEP_EPI_PRELU_BWD) {
-                        if (live && ax[e] <= 0.f) dalpha_e = fmaf(v[e], ax[e], dalpha_e);
-                        v[e] *= prelu_grad(ax[e], alpha_e);
-                    }
-                    if (ef & SEP_EPI_ROWSUMS) {
-                        const float u = (ef & SEP_EPI_ROWSUMS_PRELU) ? prelu_f(ax[e], alpha_e) : ax[e];
-                        if (live) { rs1 += v[e]; rs2 = fmaf(v[e], u, rs2); }
-                    }
-                    if ((ef & SEP_EPI_SIGMOID) && !full_cols) v[e] *= cm[e];     // sigmoid(0) = 0.5: mask again
-                }
-                outv[j] = make_float4(v[0], v[1], v[2], v[3]);
-                if (ef & SEP_EPI_ROWSUMS) {
-                    // the 16 lanes with equal (lane >> 4) share this row: xor offsets < 16 stay inside the group
-                    rs1 = row16_sum(rs1);
-                    rs2 = row16_sum(rs2);
-                    if (c4 == 0 && ok[j]) {
-                        float* rp = d.epi_rowpart + (((size_t)b * d.M + wrow + mi * 32 + (g4 + j) * 4 + rsub) * (d.ldt / 64) + (t0 + wc * 64) / 64) * 2;
-                        rp[0] = rs1; rp[1] = rs2;
-                    }
-                }
-            }
-            if (use_res) {                  // whole-group block (use_res depends on which output part this tile is in)
-#pragma unroll
-                for (int j = 0; j < GRP; ++j) {
-                    // frames >= T of the residual / accumulated tensors are zero by contract, so the sums keep them zero
-                    outv[j].x += ext[j].x; outv[j].y += ext[j].y; outv[j].z += ext[j].z; outv[j].w += ext[j].w;
-                }
-            }
-            if (acc_this) {
-#pragma unroll
-                for (int j = 0; j < GRP; ++j) {
-                    outv[j].x += old[j].x; outv[j].y += old[j].y; outv[j].z += old[j].z; outv[j].w += old[j].w;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < GRP; ++j) {
-#ifdef SEP_ABL_NO_EPI_STORE
-                if (ok[j] && outv[j].x == 123.456f)
-#else
-                if (ok[j])
-#endif
-                    st4_out(const_cast<float*>(byte_off(dst_w + (mi * 32 + (g4 + j) * 4) * (size_t)d.ldt, lane_off)), outv[j]);
-            }
-        }   // g4
-        __builtin_amdgcn_wave_barrier();
-#ifdef SEP_PROF
-        PROF_STAMP(10 + 4 * mi);
-#endif
-    }
-    if (ef & SEP_EPI_STATS_PRELU) {
-        const double s = block_sum_256<double>((double)st_s, red);
-        const double ss = block_sum_256<double>((double)st_ss, red);
-        if (tid == 0) { double* st = d.epi_stats + ((size_t)b * SEP_STATS_SLOTS + (blockIdx.x & (SEP_STATS_SLOTS - 1))) * 2; atomicAdd(st, s); atomicAdd(st + 1, ss); }
-    }
-    if (ef & SEP_EPI_PRELU_BWD) {
-        const double s = block_sum_256<double>((double)dalpha_e, red);
-        if (tid == 0) atomicAdd(d.epi_dalpha, s);
-    }
-}
 
 __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const sep_gemm_desc d) {
     __shared__ GemmSmem sm;
@@ -492,9 +251,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const sep_gemm_desc d) 
     for (int kc = 0; kc < nk; ++kc) {
         const int cur = kc & 1;
         if (kc + 1 < nk) load_global(kc + 1);
-#ifndef SEP_ABL_NO_MFMA
         mfma_chunk32(sm.As[cur], lda_s, sm.Bs[cur], LDB_S, wr * 64 + l31, wc * 64 + l31, lk, acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
-#endif
         if (kc + 1 < nk) store_lds(kc + 1, cur ^ 1);
         __syncthreads();
     }
@@ -503,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const sep_gemm_desc d) 
     #ifdef SEP_PROF
     const int prof_slot = -1;
 #endif
-    gemm_epilogue<-1>(d, acc, b, m0, t0, wr, wc, lk, l31, tid, &sm.As[0][0], sm.red PROF_PASS);
+    gemm_epilogue<-1>(d, acc, b, m0, t0, wr, wc, lk, l31, tid, &sm.As[0][0], sm.red, BN PROF_PASS);
     if (pro == SEP_PRO_GLN_BWD && rt == 0) {
         const double s = block_sum_256<double>((double)dalpha_pro, sm.red);
         if (tid == 0) atomicAdd(d.pro_dalpha, s);
@@ -511,64 +268,6 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const sep_gemm_desc d) 
 }
 
 
-// ======================================================================================
-// Direct-to-LDS staging helpers shared by the fast GEMM / wgrad kernels.
-// global_load_lds_dwordx4: the 64 lanes of a wave copy 64 x 16 B from per-lane global addresses to ONE contiguous
-// 1 KiB LDS range (wave-uniform base in M0 + lane*16) without touching VGPRs.
-// ======================================================================================
-constexpr int DK = 16;      // contraction rows per ring stage
-constexpr int NST = 4;      // ring depth of the weight-gradient kernel
-
-// s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier as BUILTINS: the compiler's waitcnt pass then knows every counter is zero
-// here and emits counted lgkmcnt(N) waits afterwards (behind an opaque asm it falls back to lgkmcnt(0) everywhere)
-// all but the newest `keep4` DMA instructions of this wave have landed (keep4 in {0, 4}), then the barrier
-__device__ __forceinline__ void wait_keep4_and_barrier(const bool keep4) {
-    asm volatile("" ::: "memory");
-    if (keep4) __builtin_amdgcn_s_waitcnt(0x0074);
-    else __builtin_amdgcn_s_waitcnt(0x0070);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-// all but the DMAs of the newest `chunks` chunks (4 instructions each) of this wave have landed, then the barrier
-__device__ __forceinline__ void wait_chunks_and_barrier(const int chunks) {
-    asm volatile("" ::: "memory");
-    if (chunks >= 3) __builtin_amdgcn_s_waitcnt(0x007c);
-    else if (chunks == 2) __builtin_amdgcn_s_waitcnt(0x0078);
-    else if (chunks == 1) __builtin_amdgcn_s_waitcnt(0x0074);
-    else __builtin_amdgcn_s_waitcnt(0x0070);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-__device__ __forceinline__ void wait_all_and_barrier() {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0x0070);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-// LDS-DMA of 16 B per lane as an asm statement, saddr form: source = base (SGPR pair) + zext(voff), LDS image lane-linear
-// from the wave-uniform byte address lds_dst.  Why not the builtin: hipcc books a global_load_lds as a FLAT access that may
-// touch LDS, and from then on every LDS-read dependency in the loop becomes s_waitcnt lgkmcnt(0) -- no counted waits, so
-// a ds_read could never stay in flight across an MFMA burst.  Behind asm the DMA is invisible to that bookkeeping (its
-// completion is waited for by hand: vmcnt(0) before the barrier that publishes the stage).  M0 is compiler-reserved:
-// saved and restored in the same statement.
-__device__ __forceinline__ void glds16_asm(const float* base, unsigned voff, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
-}
-// same, with a full 64-bit per-lane source address
-__device__ __forceinline__ void glds16_asm_v(const float* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ unsigned lds_addr(const float* p) {
-    return (unsigned)reinterpret_cast<size_t>((const __attribute__((address_space(3))) float*)p);
-}
-__device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
 
 // ======================================================================================
 // The fast GEMM: direct-to-LDS, 2-stage ring, high occupancy.
@@ -614,8 +313,6 @@ struct __attribute__((aligned(16))) DirectSmem {
 //      32 cycles per 16-deep chunk and tile pair instead of 8 of 64.  Error per product <= 2^-23 relative, i.e. the
 //      rounding of an fp32 multiply; measured against fp64 it is no worse than the fp32 MFMA path (tests).  The
 //      lane half lk already owns k = 8*lk .. 8*lk+7 of a chunk, which is the operand layout of the bf16 instruction.
-typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
-typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_t;
 
 // two fp32 values -> their (hi, mid, lo) bf16 parts packed {x0 low half, x1 high half}: 11 VALU instructions
 __device__ __forceinline__ void split3_pair(const float x0, const float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
@@ -650,38 +347,6 @@ __device__ __forceinline__ void mfma_split6(const u32x4_t (&a)[3], const u32x4_t
     acc = mfma_bf16(a[0], b[0], acc);
 }
 
-// AR == 2 (SEP_ARITH_F16X3): fp32 products from a TWO-part fp16 split, x*2^s = hi + lo with hi = fp16(x*2^s) (toward zero),
-// lo = fp16(x*2^s - hi) (11 + 11 significand bits), three part products hi*hi + hi*lo + lo*hi on
-// v_mfma_f32_32x32x16_f16: 3 x 32 matrix-pipe cycles and 6 VALU per pair of values where the bf16 split needs 6 x 32 and 11.
-// fp16 has 5 exponent bits, so the operands are brought into range with exact power-of-two scales: ONE for A, from a
-// caller-supplied upper bound of |A| (largest scaled value < 2^13), and for B one PER COLUMN, kept per lane (a column of
-// the B tile is a lane of the MFMA operand and owns its accumulator column) and lowered on the fly: when a chunk's column
-// maximum would pass 2^14 the lane's accumulators are rescaled (rare after the first chunks); both are undone on the
-// accumulators before the epilogue.  Values more than ~2^-25 below their column's maximum lose low bits (fp16 underflow):
-// the error is relative to |A||X| per output like fp32 accumulation's, not elementwise -- tools/split_accuracy.py,
-// tools/gemm_accuracy.py and the kernel tests put it at the fp32-MFMA path's level on operands spread over e^+-6.
-typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
-typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split2_pair(const float x0, const float x1, unsigned& hi, unsigned& lo) {
-    const fp16x2_t h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
-    const fp16x2_t l = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h.x, x1 - (float)h.y);
-    hi = __builtin_bit_cast(unsigned, h);
-    lo = __builtin_bit_cast(unsigned, l);
-}
-__device__ __forceinline__ void split2_frag(const float (&lo4)[4], const float (&hi4)[4], u32x4_t (&out)[2]) {
-    unsigned p[2][4];
-    split2_pair(lo4[0], lo4[1], p[0][0], p[1][0]);
-    split2_pair(lo4[2], lo4[3], p[0][1], p[1][1]);
-    split2_pair(hi4[0], hi4[1], p[0][2], p[1][2]);
-    split2_pair(hi4[2], hi4[3], p[0][3], p[1][3]);
-#pragma unroll
-    for (int q = 0; q < 2; ++q) out[q] = u32x4_t{p[q][0], p[q][1], p[q][2], p[q][3]};
-}
-__device__ __forceinline__ void mfma_split3(const u32x4_t (&a)[2], const u32x4_t (&b)[2], f32x16& acc) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a[0]), __builtin_bit_cast(f16x8_t, b[1]), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a[1]), __builtin_bit_cast(f16x8_t, b[0]), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a[0]), __builtin_bit_cast(f16x8_t, b[0]), acc, 0, 0, 0);
-}
 
 template <bool TRANS_A, int PRO, bool SPLIT, int EF, int AR = 0>
 __global__ __launch_bounds__(256, (AR >= 1 ? 3 : PRO == SEP_PRO_GLN_BWD ? 3 : PRO >= SEP_PRO_GLN ? SEP_GLN_OCC : 4)) void pw_gemm_direct_kernel(const sep_gemm_desc d) {
@@ -786,19 +451,9 @@ __global__ __launch_bounds__(256, (AR >= 1 ? 3 : PRO == SEP_PRO_GLN_BWD ? 3 : PR
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-#ifndef SEP_ABL_NO_LOADS
-#ifdef SEP_ABL_B_FIXED
-            glds16_asm(d.X, 0u, lds_addr(&sm.Bs[stage][(4 * wid + 2 * q) * 128]));
-#else
             glds16_asm(baseB[q], offB, lds_addr(&sm.Bs[stage][(4 * wid + 2 * q) * 128]));
-#endif
             if (P_BWD) glds16_asm(baseC[q], offB, lds_addr(&sm.Cs[stage][(4 * wid + 2 * q) * 128]));
-#ifdef SEP_ABL_A_FIXED
-            glds16_asm(d.A, 0u, lds_addr(TRANS_A ? &sm.As[stage][(4 * wid + 2 * q) * 128] : &sm.As[stage][(2 * wid + q) * 256]));
-#else
             glds16_asm(baseA[q], offA[q], lds_addr(TRANS_A ? &sm.As[stage][(4 * wid + 2 * q) * 128] : &sm.As[stage][(2 * wid + q) * 256]));
-#endif
-#endif
             baseB[q] += stepB;
             if (P_BWD) baseC[q] += stepB;
             baseA[q] += stepA;
@@ -900,12 +555,10 @@ __global__ __launch_bounds__(256, (AR >= 1 ? 3 : PRO == SEP_PRO_GLN_BWD ? 3 : PR
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             apply_pro(kc, h, kk);
-#ifndef SEP_ABL_NO_MFMA
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h][0][kk], fb[h][0][kk], acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h][0][kk], fb[h][1][kk], acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h][1][kk], fb[h][0][kk], acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h][1][kk], fb[h][1][kk], acc[1][1], 0, 0, 0);
-#endif
         }
     };
     // AR == 1: whole-chunk steps.  prologue + split of chunk kc (VALU), then -- behind the barrier that says chunk kc+1 has
@@ -956,12 +609,7 @@ __global__ __launch_bounds__(256, (AR >= 1 ? 3 : PRO == SEP_PRO_GLN_BWD ? 3 : PR
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-#ifdef SEP_ABL_NO_A_SPLIT
-#pragma unroll
-            for (int q = 0; q < 3; ++q) pa[i][q] = u32x4_t{__float_as_uint(fa[0][i][0]) + q, __float_as_uint(fa[0][i][2]), __float_as_uint(fa[1][i][1]), __float_as_uint(fa[1][i][3])};
-#else
             split3_frag(fa[0][i], fa[1][i], pa[i]);
-#endif
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -1134,9 +782,6 @@ __global__ __launch_bounds__(256, (AR >= 1 ? 3 : PRO == SEP_PRO_GLN_BWD ? 3 : PR
     PROF_STAMP(3);
     __syncthreads();
     PROF_STAMP(4);
-#ifdef SEP_ABL_NO_EPI
-    if (acc[0][0][0] + acc[0][1][3] + acc[1][0][5] + acc[1][1][7] == 123.456f) d.Y[tid] = 1.f;
-#else
     // Launder the thread id: everything the epilogue derives from it (lane offsets, row pointers) would otherwise be
     // hoisted above the main loop as loop-invariant and held in registers through it -- at 128 VGPRs that spilled INSIDE
     // the loop (a scratch reload waits on vmcnt, i.e. on the DMA ring).
@@ -1144,8 +789,7 @@ __global__ __launch_bounds__(256, (AR >= 1 ? 3 : PRO == SEP_PRO_GLN_BWD ? 3 : PR
     asm volatile("" : "+v"(etid), "+s"(eb), "+s"(em0), "+s"(et0));
     const int ewid = __builtin_amdgcn_readfirstlane(etid >> 6);
     const int elane = etid & 63;
-    gemm_epilogue<EF>(d, acc, eb, em0, et0, ewid >> 1, ewid & 1, elane >> 5, elane & 31, etid, &sm.As[0][0], sm.red PROF_PASS);
-#endif
+    gemm_epilogue<EF>(d, acc, eb, em0, et0, ewid >> 1, ewid & 1, elane >> 5, elane & 31, etid, &sm.As[0][0], sm.red, BN PROF_PASS);
     PROF_STAMP(5);
     if (P_BWD && rt == 0) {
         const double sdal = block_sum_256<double>((double)dalpha_pro, sm.red);
@@ -1903,6 +1547,13 @@ extern "C" int sep_pw_gemm(const sep_gemm_desc* d, sep_stream_t stream) {
     if (d->epi_flags & SEP_EPI_PRELU_BWD) SEP_REQUIRE(d->epi_aux && d->epi_alpha && d->epi_dalpha, "sep_pw_gemm: PRELU_BWD needs aux/alpha/dalpha");
     if (d->epi_flags & SEP_EPI_ROWSUMS) SEP_REQUIRE(d->epi_aux && d->epi_rowpart && !d->m_split, "sep_pw_gemm: ROWSUMS needs aux/rowpart");
     if (d->epi_flags & SEP_EPI_ROWSUMS_PRELU) SEP_REQUIRE(d->epi_alpha, "sep_pw_gemm: ROWSUMS_PRELU needs epi_alpha");
+    if (d->arith == SEP_ARITH_F16X3 && d->A_pk != nullptr) {
+        SEP_REQUIRE(d->a_rscale != nullptr, "sep_pw_gemm: A_pk without a_rscale");
+        if (sep_pw_gemm_packed(d, (hipStream_t)stream)) {      // packed weights, cooperative split (gemm_coop.hip)
+            SEP_CHECK_LAUNCH("sep_pw_gemm (packed)");
+            return 0;
+        }
+    }
     const int NR = ceil_div(d->M, BM);
     const int NC = d->B * (d->ldt / BN);
     const int grid = 8 * NR * ceil_div(NC, 8);

@@ -1,0 +1,493 @@
+// The 1x1-convolution GEMM of the Conv-TasNet step in its packed-weight / cooperative-split form (SEP_ARITH_F16X3 with
+// sep_gemm_desc.A_pk), and the weight packer that feeds it.
+//
+//   Y[b][m][t] = epi( a_rscale[m] * sum_k Apk[m][k] * 2^-e_t * split(2^e_t * pro(X[b][k][t])) + bias[m] )
+//
+// Replaces nn.Conv1d(kernel_size=1) of reference src/models/tdcn.py:86,173,175 and src/models/conv_tasnet.py:335,341
+// (forward and input-gradient products) exactly like pw_gemm_direct_kernel<..., AR = 2> in gemm.hip, whose arithmetic
+// (fp32 products from two fp16 parts per operand, three part products on v_mfma_f32_32x32x16_f16, fp32 accumulation,
+// exact power-of-two scales) it keeps.  What changes is WHERE the operand splits are computed -- rocprofv3 on the round-1
+// kernel showed the matrix pipe ~16 % busy and the VALU saturated by the splits (profiles/r01k_sq_counters.txt):
+//
+//  * A (the weights) is split ONCE per pass by sep_pack_weights into {hi[8], lo[8]} fp16 groups, 4 bytes per weight like
+//    the fp32 matrix, with one scale per ROW of A (undone in the epilogue together with the bias add).  The LDS image a
+//    DMA leaves is already the MFMA A operand: two ds_read_b128 per 32-row block and chunk, zero VALU.  The packer also
+//    writes the transposed / concatenated forms, so the kernel has one operand path for forward and input gradients.
+//  * X is put through the prologue (PReLU / gLN / gLN-backward) and split ONCE PER WORKGROUP: the four waves of a
+//    workgroup are stacked along the rows (wave tile 32*MI x 64) over ONE 64-column tile, each thread prepares 4 of the
+//    1024 values of a 16-deep chunk and writes them operand-ready to LDS, from where all four waves read them with
+//    ds_read_b128.  Per MFMA the kernel now issues ~1/6 of the VALU of the per-wave split.
+//  * The per-column scale (a column of X is an accumulator column, owned by a lane) is chosen by the quad of threads that
+//    prepares the column (two DPP max) and handed over with the operands; a consumer lane rescales its accumulators when
+//    its column's exponent changes (rare after the first chunks).
+//
+// Pipeline per 16-deep chunk kc, ONE barrier: [ds_read operands of kc | ds_read raw X of kc+1] -> MFMAs of kc interleaved
+// with prologue + split of kc+1 -> ds_write operands of kc+1 -> wait (DMA group kc+1 landed) + barrier -> DMA group kc+NS.
+// DMA group g = {A chunk g, raw X chunk g+1}: the raw X ring runs one chunk ahead of the A ring.
+#include "gemm_common.hpp"
+#include <stdlib.h>
+#ifndef COOP_ABL
+#define COOP_ABL 0
+#endif
+
+#ifdef COOP_PROF
+__device__ long long g_coop_prof[4][64][8];      // [sampled block][step][stamp]
+#define CSTAMP(s) do { if (pslot >= 0 && tid == 0 && kc < 64) g_coop_prof[pslot][kc][s] = clock64(); } while (0)
+extern "C" int sep_debug_coop_prof(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coop_prof), sizeof(long long) * 4 * 64 * 8) == hipSuccess ? 0 : -1; }
+#else
+#define CSTAMP(s) do { } while (0)
+#endif
+
+namespace {
+
+constexpr int CBN = 64;          // columns (frames) per workgroup
+constexpr int RBI = 264;         // floats per raw-X image of 4 contraction rows: 1 KiB + 32 B, so the four images of a chunk
+                                 // start 8 banks apart and the quad-per-column reads below are conflict-free
+constexpr int COMAXK = 512;      // rows of the per-row affine table of the gLN prologues
+
+template <int MI, int NS, bool AUX>
+struct __attribute__((aligned(16))) CoopSmem {
+    double red[8];
+    float As[NS][128 * MI * DK];             // A operand image [row][4 x 16 B], granule p of row r holds part p ^ ((r >> 2) & 3)
+    float Bs[NS][4 * RBI];                   // raw X chunk as DMA'd
+    float Cs[AUX ? NS : 1][AUX ? 4 * RBI : 4];   // GLN_BWD: the pre-activation chunk
+    float Bp[2][CBN * 16];                   // split X chunk [col][4 x 16 B], same granule swizzle
+    int be[2][CBN];                          // its per-column scale exponents
+    float sc[COMAXK];
+    float sh[AUX ? 4 : COMAXK];
+};
+
+template <int MI, int NS, bool BWD>
+constexpr int coop_occupancy() {
+    return (int)((160 * 1024) / ((sizeof(CoopSmem<MI, NS, BWD>) + 511) / 512 * 512)) > 4 ? 4
+         : (int)((160 * 1024) / ((sizeof(CoopSmem<MI, NS, BWD>) + 511) / 512 * 512));
+}
+
+__device__ __forceinline__ f32x16 mfma_f16(const u32x4_t a, const u32x4_t b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+// max over the four lanes of a quad, in every lane: two VALU with DPP operands
+__device__ __forceinline__ float quad_max(float x) {
+    x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true)));   // quad_perm [1,0,3,2]
+    x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true)));   // quad_perm [2,3,0,1]
+    return x;
+}
+template <int N>
+__device__ __forceinline__ void wait_vm_lgkm0_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0070 | (N & 15) | ((N >> 4) << 14));      // vmcnt(N) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int MI, int PRO, bool SPLIT, int EF, int NS>
+__global__ __launch_bounds__(256, (coop_occupancy<MI, NS, PRO == SEP_PRO_GLN_BWD>()))
+void pw_gemm_coop_kernel(const sep_gemm_desc d) {
+    constexpr bool P_PRELU = PRO == SEP_PRO_PRELU || PRO == SEP_PRO_GLN_PRELU;
+    constexpr bool P_GLN = PRO == SEP_PRO_GLN || PRO == SEP_PRO_GLN_PRELU;
+    constexpr bool P_BWD = PRO == SEP_PRO_GLN_BWD;
+    constexpr int RW = 32 * MI;                          // rows per wave
+    constexpr int BMc = 4 * RW;                          // rows per workgroup
+    constexpr int G = 2 * MI + 1 + (P_BWD ? 1 : 0);      // DMA instructions per wave and group
+    // stores of the GLN_BWD store-back share vmcnt with the DMAs and may retire out of order with them: plain vmcnt(0) there
+    constexpr int KEEP = P_BWD ? 0 : (NS - 2) * G;
+    static_assert(KEEP < 64, "vmcnt field");
+    __shared__ CoopSmem<MI, NS, P_BWD> sm;
+    static_assert(sizeof(sm) - 64 >= 4 * EPI_WAVE_FLOATS * sizeof(float), "epilogue transpose buffer");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lk = lane >> 5, l31 = lane & 31;
+
+    const int NR = d.M / BMc;
+    const int ntile_t = d.ldt / CBN;
+    const int NC = d.B * ntile_t;
+    // XCD-aware decode: all row tiles of one column tile land on the same XCD (blockIdx % 8) and share X through its L2
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, jj = bid >> 3;
+    const int rt = jj % NR;
+    const int ct = (jj / NR) * 8 + xcd;
+    if (ct >= NC) return;
+    const int b = ct / ntile_t;
+    const int t0 = (ct % ntile_t) * CBN;
+    const int m0 = rt * BMc;
+    const int nk = d.K / DK;
+    const bool dead_tile = !P_BWD && t0 >= d.T;          // whole tile in the pad frames: outputs are zeros (block-uniform)
+
+    // per-row affine of the prologue, once per workgroup
+    float alpha_p = 0.f, mu = 0.f, rstd = 1.f, mg = 0.f, mgx = 0.f;
+    if (P_PRELU || P_BWD) alpha_p = d.pro_alpha[0];
+    if (P_GLN || P_BWD) {
+        gln_mu_rstd(d.pro_stats + (size_t)b * SEP_STATS_SLOTS * 2, d.count, d.eps, mu, rstd);
+        for (int k = tid; k < d.K; k += 256) {
+            if (P_BWD) sm.sc[k] = d.pro_gamma[k];
+            else {
+                const float scv = d.pro_gamma[k] * rstd;
+                sm.sc[k] = scv;
+                sm.sh[k] = d.pro_beta[k] - mu * scv;
+            }
+        }
+    }
+    if (P_BWD) { mg = d.pro_bsum[2 * b]; mgx = d.pro_bsum[2 * b + 1]; }
+    float dalpha_pro = 0.f;
+    // consume the loads NOW: the compiler does not count the asm LDS-DMAs below, so a wait it placed at a first use inside
+    // the loop would be vmcnt(0) and drain the ring
+    asm volatile("" :: "v"(alpha_p), "v"(mu), "v"(rstd), "v"(mg), "v"(mgx));
+
+    // ---- DMA sources: wave-uniform base (SGPR pair, advanced with scalar adds) + a per-lane 32-bit byte offset -------
+    const int Ks1 = SPLIT ? d.k_split : d.K;
+    const int split_chunk = SPLIT ? d.k_split / DK : -1;
+    const size_t stepX = (size_t)DK * d.ldt;
+    const unsigned offX = 4u * (unsigned)((lane >> 4) * d.ldt + 4 * (lane & 15));
+    const float* baseX = d.X + ((size_t)b * Ks1 + 4 * wid) * d.ldt + t0;
+    const float* baseC = P_BWD ? d.pro_aux + ((size_t)b * Ks1 + 4 * wid) * d.ldt + t0 : nullptr;
+    const float* baseA = reinterpret_cast<const float*>(d.A_pk);
+    unsigned offA[2 * MI];
+    {
+        const int r = lane >> 2, p = lane & 3;
+#pragma unroll
+        for (int q = 0; q < 2 * MI; ++q)
+            offA[q] = 4u * (unsigned)((m0 + wid * RW + 16 * q + r) * d.K + 4 * (p ^ ((r >> 2) & 3)));
+    }
+    int xi = 0, xst = 0, ai = 0, ast = 0;      // next chunk to issue and its ring stage, per operand
+    auto issue_x = [&]() {
+        if (SPLIT && xi == split_chunk) baseX = d.X2 + ((size_t)b * (d.K - d.k_split) + 4 * wid) * d.ldt + t0;
+        glds16_asm(baseX, offX, lds_addr(&sm.Bs[xst][wid * RBI]));
+        if (P_BWD) glds16_asm(baseC, offX, lds_addr(&sm.Cs[P_BWD ? xst : 0][wid * RBI]));
+#if COOP_ABL != 1
+        baseX += stepX;
+#endif
+        if (P_BWD) baseC += stepX;
+        ++xi;
+        xst = xst + 1 == NS ? 0 : xst + 1;
+    };
+    auto issue_a = [&]() {
+#pragma unroll
+        for (int q = 0; q < 2 * MI; ++q) glds16_asm(baseA, offA[q], lds_addr(&sm.As[ast][(wid * RW + 16 * q) * DK]));
+#if COOP_ABL != 5
+        baseA += DK;
+#endif
+        ++ai;
+        ast = ast + 1 == NS ? 0 : ast + 1;
+    };
+    auto issue_group = [&]() {
+        if (ai < nk) issue_a();
+        if (xi < nk) issue_x();
+    };
+
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    // ---- consumer side: this lane's operand granules (row / column l31 of a 32-block, contraction half lk) ------------
+    const int fsw = (l31 >> 2) & 3;                                  // granule swizzle of row l31 (+ any multiple of 16)
+    const int c_hi = l31 * 16 + 4 * ((2 * lk) ^ fsw);                // float offset inside a 32-row (32-column) block image
+    const int c_lo = l31 * 16 + 4 * ((2 * lk + 1) ^ fsw);
+    int bcur[2] = {0, 0};                                            // scale exponent the accumulators of column block ni are in
+
+    // ---- splitter side: quad (lane & 3 = kq) of column col_s = 16*wid + (lane >> 2); this thread owns k = 4*kq .. 4*kq+3 --
+    const int kq = lane & 3;
+    const int col_s = 16 * wid + (lane >> 2);
+    const int s_raw = kq * RBI + col_s;                              // + j*64
+    const int s_fsw = (col_s >> 2) & 3;
+    const int s_hi = col_s * 16 + 4 * ((2 * (kq >> 1)) ^ s_fsw) + 2 * (kq & 1);
+    const int s_lo = col_s * 16 + 4 * ((2 * (kq >> 1) + 1) ^ s_fsw) + 2 * (kq & 1);
+    const bool s_live = t0 + col_s < d.T;
+    const unsigned st_lane_off = 4u * (unsigned)(4 * kq * d.ldt + col_s);   // GLN_BWD store-back: this thread's byte offset in a chunk
+    int bexp = 100;                                                  // scale exponent of this thread's column (100 = not set yet)
+
+    float raw[4], aux[4];
+    float4 sc4 = make_float4(0.f, 0.f, 0.f, 0.f), sh4 = sc4;
+    auto read_raw = [&](const int stage, const int kn) {
+        const float* Bb = sm.Bs[stage];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) raw[j] = Bb[s_raw + j * 64];
+        if (P_BWD) {
+            const float* Cb = sm.Cs[P_BWD ? stage : 0];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) aux[j] = Cb[s_raw + j * 64];
+        }
+        if (P_GLN || P_BWD) sc4 = ld4(&sm.sc[kn * DK + 4 * kq]);
+        if (P_GLN) sh4 = ld4(&sm.sh[kn * DK + 4 * kq]);
+    };
+    // prologue + column scale + split of this thread's four values of chunk kn, operand-ready into Bp[pb]
+    auto split_chunk_vals = [&](const int kn, const int pb) {
+        const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
+        const float shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float x = raw[j];
+            if (P_BWD) {
+                // d(pre-activation) = rstd*(gamma_k*dv - mg - xhat*mgx) * PReLU'(a)
+                const float a = aux[j];
+                const float u = prelu_f(a, alpha_p);
+                const float xh = (u - mu) * rstd;
+                const float du = rstd * (scv[j] * x - mg - xh * mgx);
+                const float da = s_live ? du * prelu_grad(a, alpha_p) : 0.f;
+                if (rt == 0) {
+                    if (s_live && a <= 0.f) dalpha_pro += du * a;
+                    float* srow = d.pro_store + ((size_t)b * d.K + kn * DK + j) * d.ldt + t0;     // uniform row pointer + lane offset
+                    *reinterpret_cast<float*>(reinterpret_cast<char*>(srow) + (size_t)st_lane_off) = da;
+                }
+                x = da;
+            } else {
+                if (P_PRELU) x = prelu_f(x, alpha_p);
+                if (P_GLN) x = x * scv[j] + shv[j];
+            }
+            v[j] = x;
+        }
+        float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        m = quad_max(m);                                                 // the column's maximum over the 16 k of the chunk
+        const int e = __builtin_amdgcn_frexp_expf(m);                    // m = f * 2^e, f in [0.5, 1)
+        if (e + bexp > 14) bexp = 9 - e;                                 // first chunk, or the column outgrew its scale
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = __builtin_ldexpf(v[j], bexp);
+        unsigned h01, l01, h23, l23;
+        split2_pair(v[0], v[1], h01, l01);
+        split2_pair(v[2], v[3], h23, l23);
+        float* Bp = sm.Bp[pb];
+        *reinterpret_cast<uint2*>(Bp + s_hi) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(Bp + s_lo) = make_uint2(l01, l23);
+        if (kq == 0) sm.be[pb][col_s] = bexp;
+    };
+
+    u32x4_t pa[MI][2], pbv[2][2];
+    int en[2];
+    auto read_operands = [&](const int astage, const int pb) {
+        const float* Ab = sm.As[astage] + wid * RW * DK;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            pa[mi][0] = *reinterpret_cast<const u32x4_t*>(Ab + mi * 32 * DK + c_hi);
+            pa[mi][1] = *reinterpret_cast<const u32x4_t*>(Ab + mi * 32 * DK + c_lo);
+        }
+        const float* Bp = sm.Bp[pb];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            pbv[ni][0] = *reinterpret_cast<const u32x4_t*>(Bp + ni * 32 * 16 + c_hi);
+            pbv[ni][1] = *reinterpret_cast<const u32x4_t*>(Bp + ni * 32 * 16 + c_lo);
+            en[ni] = sm.be[pb][ni * 32 + l31];
+        }
+    };
+    auto mfma_part = [&](const int asel, const int bsel) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+#if COOP_ABL != 2
+                acc[mi][ni] = mfma_f16(pa[mi][asel], pbv[ni][bsel], acc[mi][ni]);
+#else
+                acc[mi][ni][0] += __builtin_bit_cast(float, pa[mi][asel][0] ^ pbv[ni][bsel][1]);
+#endif
+            }
+    };
+
+    if (!dead_tile) {
+        // ---- fill the rings: X0, then groups 0 .. NS-2 ------------------------------------------------------------------
+        __syncthreads();                               // prologue tables visible (no DMA in flight yet: drains nothing)
+        issue_x();
+#pragma unroll
+        for (int g = 0; g < NS - 1; ++g) issue_group();
+        wait_vm_lgkm0_barrier<0>();                    // X0 (and with it groups 0 .. NS-2) landed
+        read_raw(0, 0);
+        split_chunk_vals(0, 0);
+        wait_vm_lgkm0_barrier<0>();                    // operands of chunk 0 visible; raw stage 0 free
+        issue_group();                                 // group NS-1: A(NS-1), X(NS) -> raw stage 0
+
+        int astage = 0, xstage = 1 % NS;               // ring stages of A(kc) and raw X(kc+1)
+#ifdef COOP_PROF
+        const int pslot = bid == 8 ? 0 : bid == 801 ? 1 : bid == 1602 ? 2 : bid == (int)gridDim.x - 9 ? 3 : -1;
+#endif
+        for (int kc = 0; kc < nk; ++kc) {
+            const int pb = kc & 1;
+            const bool more = kc + 1 < nk;
+            CSTAMP(0);
+            read_operands(astage, pb);
+            if (more) read_raw(xstage, kc + 1);
+#ifdef COOP_PROF
+            __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): operands have arrived
+            CSTAMP(1);
+#endif
+            // the accumulators follow their column's scale
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int delta = en[ni] - bcur[ni];
+                if (__builtin_amdgcn_ballot_w64(delta != 0) != 0) {        // rare after the first chunks
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = __builtin_ldexpf(acc[mi][ni][r], delta);
+                }
+                bcur[ni] = en[ni];
+            }
+            mfma_part(0, 1);
+            mfma_part(1, 0);
+#if COOP_ABL != 3
+            if (more) split_chunk_vals(kc + 1, pb ^ 1);
+#else
+            if (more && kc == 0) { split_chunk_vals(1, 0); split_chunk_vals(1, 1); }
+#endif
+            mfma_part(0, 0);
+            CSTAMP(2);
+            if (more) {
+                // DMA group kc+1 (A(kc+1), raw X(kc+2)) has landed -- mine: all but the newer groups; everyone's: barrier --
+                // the operands of chunk kc+1 are written, and every wave is past its reads of this step's stages
+#ifdef COOP_PROF
+                if (KEEP > 0 && kc + NS < nk) __builtin_amdgcn_s_waitcnt(0x0070 | (KEEP & 15) | ((KEEP >> 4) << 14));
+                else __builtin_amdgcn_s_waitcnt(0x0070);
+                CSTAMP(3);
+#endif
+                if (KEEP > 0 && kc + NS < nk) wait_vm_lgkm0_barrier<KEEP>();
+                else wait_vm_lgkm0_barrier<0>();
+                CSTAMP(4);
+                issue_group();                                           // group kc+NS into the stages this step freed
+                CSTAMP(5);
+                astage = astage + 1 == NS ? 0 : astage + 1;
+                xstage = xstage + 1 == NS ? 0 : xstage + 1;
+            }
+        }
+        // undo the column scales (the row scales of A leave in the epilogue)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = __builtin_ldexpf(acc[mi][ni][r], -bcur[ni]);
+    }
+    __syncthreads();                                    // ring reads done: the staging area becomes the transpose buffer
+    // Launder what the epilogue derives its addresses from: hoisted above the main loop it would be held through it.
+    int etid = tid, eb = b, em0 = m0, et0 = t0;
+    asm volatile("" : "+v"(etid), "+s"(eb), "+s"(em0), "+s"(et0));
+    const int ewid = __builtin_amdgcn_readfirstlane(etid >> 6);
+    const int elane = etid & 63;
+#if COOP_ABL != 4
+    gemm_epilogue<EF, MI, true>(d, acc, eb, em0, et0, ewid, 0, elane >> 5, elane & 31, etid, &sm.As[0][0], sm.red, CBN);
+#else
+    if (acc[0][0][0] + acc[0][1][3] == 123.456f) d.Y[tid] = 1.f;
+#endif
+    if (P_BWD && rt == 0) {
+        const double sdal = block_sum_256<double>((double)dalpha_pro, sm.red);
+        if (tid == 0) atomicAdd(d.pro_dalpha, sdal);
+    }
+}
+
+// ======================================================================================
+// Weight packer: one wave per row of A.
+// ======================================================================================
+constexpr int PMAXSEG = 64;
+struct PackArgs {
+    sep_pack_seg seg[PMAXSEG];
+    int blk_start[PMAXSEG + 1];
+    int nseg;
+};
+
+__global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
+    int sgi = 0;
+    while (sgi + 1 < a.nseg && (int)blockIdx.x >= a.blk_start[sgi + 1]) ++sgi;
+    const sep_pack_seg sg = a.seg[sgi];
+    const int lane = threadIdx.x & 63;
+    const int m = ((int)blockIdx.x - a.blk_start[sgi]) * 4 + (threadIdx.x >> 6);
+    if (m >= sg.M) return;
+    const int ng = sg.K / 8;                         // groups of 8 contraction indices; a lane owns groups lane, lane+64, ...
+    float amax = 0.f;
+    for (int g = lane; g < ng; g += 64) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 8 * g + e;
+            const float x = sg.trans ? sg.W[(size_t)k * sg.ldw + m] : sg.W[(size_t)m * sg.ldw + k];
+            amax = fmaxf(amax, fabsf(x));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    const int aexp = 13 - __builtin_amdgcn_frexp_expf(amax);      // A * 2^aexp < 2^13
+    if (lane == 0) sg.rscale[m] = __builtin_ldexpf(1.f, -aexp);
+    uint4* dst = reinterpret_cast<uint4*>(sg.dst) + (size_t)m * ng * 2;
+    for (int g = lane; g < ng; g += 64) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 8 * g + e;
+            x[e] = __builtin_ldexpf(sg.trans ? sg.W[(size_t)k * sg.ldw + m] : sg.W[(size_t)m * sg.ldw + k], aexp);
+        }
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) split2_pair(x[2 * q], x[2 * q + 1], hi[q], lo[q]);
+        dst[2 * g] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        dst[2 * g + 1] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+}
+
+template <int MI, int PRO, bool SPLIT, int EF>
+void launch_coop(const sep_gemm_desc& d, const int ns, hipStream_t stream) {
+    const int NR = d.M / (128 * MI);
+    const int NC = d.B * (d.ldt / CBN);
+    const int grid = 8 * NR * ceil_div(NC, 8);
+    if (ns == 3) hipLaunchKernelGGL((pw_gemm_coop_kernel<MI, PRO, SPLIT, EF, 3>), dim3(grid), dim3(256), 0, stream, d);
+    else hipLaunchKernelGGL((pw_gemm_coop_kernel<MI, PRO, SPLIT, EF, 2>), dim3(grid), dim3(256), 0, stream, d);
+}
+
+}  // namespace
+
+// Called by sep_pw_gemm (gemm.hip) for SEP_ARITH_F16X3 descriptors that carry packed weights.  Returns 1 when the call was
+// launched here, 0 when the shape / flag combination is not one of the packed kernel's (the caller then uses A / A2).
+int sep_pw_gemm_packed(const sep_gemm_desc* d, hipStream_t stream) {
+    static const bool off = getenv("SEPK_COOP") != nullptr && atoi(getenv("SEPK_COOP")) == 0;
+    static const int force_mi = getenv("SEPK_COOP_MI") ? atoi(getenv("SEPK_COOP_MI")) : 0;
+    static const int env_ns = getenv("SEPK_COOP_NS") ? atoi(getenv("SEPK_COOP_NS")) : 0;
+    if (off || !d->A_pk || !d->a_rscale || d->arith != SEP_ARITH_F16X3) return 0;
+    if (d->M % 128 != 0 || d->K % DK != 0 || d->k_split % DK != 0 || (d->m_split % 128) != 0) return 0;
+    if (d->pro_mode >= SEP_PRO_GLN && d->K > COMAXK) return 0;
+    if ((size_t)d->M * d->K * 4 >= (1ull << 32) || (size_t)4 * d->ldt * 4 >= (1ull << 31)) return 0;     // 32-bit DMA offsets
+    const int ef = d->epi_flags, pm = d->pro_mode;
+    const bool sp = d->k_split != 0;
+    const int mi = (force_mi == 1 || d->M % 256 != 0) ? 1 : 2;
+    const int ns = env_ns == 2 || env_ns == 3 ? env_ns : 2;
+#define SEP_LC(P, S, E)                                              \
+    do {                                                             \
+        if (mi == 2) launch_coop<2, P, S, E>(*d, ns, stream);        \
+        else launch_coop<1, P, S, E>(*d, ns, stream);                \
+        return 1;                                                    \
+    } while (0)
+    // the (prologue, two-source contraction, epilogue) combinations of the Conv-TasNet step, epilogue flags compile-time
+    if (!sp && pm == SEP_PRO_NONE && ef == SEP_EPI_STATS_PRELU) SEP_LC(SEP_PRO_NONE, false, SEP_EPI_STATS_PRELU);                      // TCN conv1
+    if (!sp && pm == SEP_PRO_GLN_PRELU && ef == SEP_EPI_RESIDUAL) SEP_LC(SEP_PRO_GLN_PRELU, false, SEP_EPI_RESIDUAL);                 // heads
+    if (!sp && pm == SEP_PRO_GLN_PRELU && ef == 0) SEP_LC(SEP_PRO_GLN_PRELU, false, 0);                                               // last layer: skip head only
+    if (!sp && pm == SEP_PRO_PRELU && ef == SEP_EPI_SIGMOID) SEP_LC(SEP_PRO_PRELU, false, SEP_EPI_SIGMOID);                           // mask (sigmoid)
+    if (!sp && pm == SEP_PRO_PRELU && ef == 0) SEP_LC(SEP_PRO_PRELU, false, 0);                                                       // mask (softmax follows)
+    if (!sp && pm == SEP_PRO_GLN && ef == 0) SEP_LC(SEP_PRO_GLN, false, 0);                                                           // bottleneck
+    if (!sp && pm == SEP_PRO_NONE && ef == 0) SEP_LC(SEP_PRO_NONE, false, 0);                                                         // plain 1x1 conv / input gradient
+    if (!sp && pm == SEP_PRO_NONE && ef == SEP_EPI_PRELU_BWD) SEP_LC(SEP_PRO_NONE, false, SEP_EPI_PRELU_BWD);                         // mask^T
+    if (sp && pm == SEP_PRO_NONE && ef == (SEP_EPI_ROWSUMS | SEP_EPI_ROWSUMS_PRELU)) SEP_LC(SEP_PRO_NONE, true, SEP_EPI_ROWSUMS | SEP_EPI_ROWSUMS_PRELU);    // heads^T
+    if (!sp && pm == SEP_PRO_NONE && ef == (SEP_EPI_ROWSUMS | SEP_EPI_ROWSUMS_PRELU)) SEP_LC(SEP_PRO_NONE, false, SEP_EPI_ROWSUMS | SEP_EPI_ROWSUMS_PRELU);  // last layer's skip^T
+    if (!sp && pm == SEP_PRO_NONE && ef == SEP_EPI_ROWSUMS) SEP_LC(SEP_PRO_NONE, false, SEP_EPI_ROWSUMS);                             // bottleneck^T
+    if (!sp && pm == SEP_PRO_GLN_BWD && ef == SEP_EPI_RESIDUAL) SEP_LC(SEP_PRO_GLN_BWD, false, SEP_EPI_RESIDUAL);                     // conv1^T
+    if (!sp && pm == SEP_PRO_GLN_BWD && ef == 0) SEP_LC(SEP_PRO_GLN_BWD, false, 0);
+#undef SEP_LC
+    return 0;
+}
+
+extern "C" int sep_pack_weights(const sep_pack_seg* segs, int nseg, sep_stream_t stream) {
+    SEP_REQUIRE(segs && nseg >= 1, "sep_pack_weights: no segments");
+    for (int s0 = 0; s0 < nseg; s0 += PMAXSEG) {
+        PackArgs a;
+        const int n = nseg - s0 < PMAXSEG ? nseg - s0 : PMAXSEG;
+        int blocks = 0;
+        for (int i = 0; i < n; ++i) {
+            const sep_pack_seg& s = segs[s0 + i];
+            SEP_REQUIRE(s.W && s.dst && s.rscale && s.M > 0 && s.K > 0 && s.K % 8 == 0 && s.ldw > 0, "sep_pack_weights: bad segment %d (M=%d K=%d)", s0 + i, s.M, s.K);
+            SEP_REQUIRE((reinterpret_cast<size_t>(s.dst) & 31) == 0, "sep_pack_weights: dst of segment %d is not 32-byte aligned", s0 + i);
+            a.seg[i] = s;
+            a.blk_start[i] = blocks;
+            blocks += ceil_div(s.M, 4);
+        }
+        a.blk_start[n] = blocks;
+        a.nseg = n;
+        hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+        SEP_CHECK_LAUNCH("sep_pack_weights");
+    }
+    return 0;
+}

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("SEPKERNELS_LIB", os.path.normpath(os.path.join(_HERE,
 # ---- constants mirrored from include/sepkernels.h -------------------------------------------------
 PRO_NONE, PRO_PRELU, PRO_GLN, PRO_GLN_PRELU, PRO_GLN_BWD = 0, 1, 2, 3, 4
 EPI_STATS_PRELU, EPI_RESIDUAL, EPI_SIGMOID, EPI_PRELU_BWD, EPI_ROWSUMS, EPI_ROWSUMS_PRELU = 1, 2, 4, 8, 16, 32
-ABI_VERSION = 8
+ABI_VERSION = 9
 STATS_SLOTS = 16   # SEP_STATS_SLOTS: gLN statistics are double[B][STATS_SLOTS][2]
 ARITH_F32, ARITH_BF16X6, ARITH_F16X3 = 0, 1, 2     # SEP_ARITH_*: how sep_pw_gemm forms its fp32 products (include/sepkernels.h)
 _ARITH_NAMES = {"f32": ARITH_F32, "bf16x6": ARITH_BF16X6, "f16x3": ARITH_F16X3}
@@ -71,13 +71,27 @@ class GemmDesc(ctypes.Structure):
                                     "accumulate", "arith")] + [("eps", ctypes.c_float), ("count", ctypes.c_double)] + \
                [(n, _vp) for n in ("A", "A2", "X", "X2", "Y", "Y2", "bias", "pro_alpha", "pro_stats", "pro_gamma", "pro_beta",
                                    "pro_aux", "pro_bsum", "pro_store", "pro_dalpha", "epi_alpha", "epi_stats", "epi_res",
-                                   "epi_aux", "epi_dalpha", "epi_rowpart", "a_amax")]
+                                   "epi_aux", "epi_dalpha", "epi_rowpart", "a_amax", "A_pk", "a_rscale")]
 
 
 class WgradDesc(ctypes.Structure):
     _fields_ = [(n, _i32) for n in ("B", "M", "N", "T", "ldt", "g_split", "g_mul", "g_div", "x_mode", "x_div", "nsplit", "arith")] + \
                [("eps", ctypes.c_float), ("count", ctypes.c_double)] + \
                [(n, _vp) for n in ("G", "G2", "Gaux", "X", "x_alpha", "x_stats", "x_gamma", "x_beta", "partial", "partial_bias")]
+
+
+class PackSeg(ctypes.Structure):
+    _fields_ = [("W", _vp), ("dst", _vp), ("rscale", _vp), ("M", _i32), ("K", _i32), ("trans", _i32), ("ldw", _i32)]
+
+
+class PackedA:
+    """One weight matrix as written by sep_pack_weights: A ([M][K], in the orientation of the product) as {hi, lo} fp16
+    groups (`data`, M*K fp32-sized words) plus the inverse row scales (`rscale`, [M]).  `src` remembers what it was packed
+    from (the CPU emulator of the tests multiplies with that)."""
+    __slots__ = ("data", "rscale", "M", "K", "src")
+
+    def __init__(self, data, rscale, M, K, src=None):
+        self.data, self.rscale, self.M, self.K, self.src = data, rscale, M, K, src
 
 
 class ReduceSeg(ctypes.Structure):
@@ -91,6 +105,7 @@ SIGNATURES = {
     "sep_version": [],
     "sep_last_error": [],
     "sep_pw_gemm": [ctypes.POINTER(GemmDesc), _vp],
+    "sep_pack_weights": [ctypes.POINTER(PackSeg), _I, _vp],
     "sep_pw_wgrad": [ctypes.POINTER(WgradDesc), _vp],
     "sep_reduce_slabs": [ctypes.POINTER(ReduceSeg), _I, _vp],
     "sep_f64_to_f32": [_vp, _vp, _I, _I, _vp],
@@ -189,8 +204,10 @@ class HipBackend:
                 pro_mode=PRO_NONE, epi_flags=0, accumulate=0, eps=1e-12, count=0.0, bias=None, pro_alpha=None,
                 pro_stats=None, pro_gamma=None, pro_beta=None, pro_aux=None, pro_bsum=None, pro_store=None,
                 pro_dalpha=None, epi_alpha=None, epi_stats=None, epi_res=None, epi_aux=None, epi_dalpha=None,
-                epi_rowpart=None, arith=None, a_amax=None):
+                epi_rowpart=None, arith=None, a_amax=None, A_pk=None):
         arith = gemm_arith() if arith is None else arith
+        if A_pk is not None and (A_pk.M != M or A_pk.K != K):
+            raise SepKernelsError("packed weights are {}x{}, the product needs {}x{}".format(A_pk.M, A_pk.K, M, K))
         if arith == ARITH_F16X3 and a_amax is None:
             a_amax = _weights_amax
             if a_amax is None:      # stand-alone caller: the bound is formed here (two small kernels per call)
@@ -204,8 +221,36 @@ class HipBackend:
                      pro_bsum=_ptr(pro_bsum, _f32), pro_store=_ptr(pro_store, _f32), pro_dalpha=_ptr(pro_dalpha, _f64),
                      epi_alpha=_ptr(epi_alpha, _f32), epi_stats=_ptr(epi_stats, _f64), epi_res=_ptr(epi_res, _f32),
                      epi_aux=_ptr(epi_aux, _f32), epi_dalpha=_ptr(epi_dalpha, _f64), epi_rowpart=_ptr(epi_rowpart, _f32),
-                     a_amax=_ptr(a_amax, _f32))
+                     a_amax=_ptr(a_amax, _f32), A_pk=_ptr(A_pk.data, _f32) if A_pk is not None else None,
+                     a_rscale=_ptr(A_pk.rscale, _f32) if A_pk is not None else None)
         _check(load().sep_pw_gemm(ctypes.byref(d), _stream()), "sep_pw_gemm")
+
+    def pack_weights(self, specs):
+        """specs: list of (W, rows, cols, trans) with W a contiguous fp32 view holding a row-major rows x cols matrix.
+        Returns one PackedA per spec: A = W (trans = 0, M x K = rows x cols) or W^T (trans = 1, M x K = cols x rows), split
+        once into {hi, lo} fp16 groups with a power-of-two scale per row of A (sep_pack_weights; one launch per 64 specs)."""
+        if not specs:
+            return []
+        dev = specs[0][0].device
+        total = sum(r * c for _, r, c, _ in specs)
+        rows_total = sum((c if t else r) for _, r, c, t in specs)
+        data = torch.empty(total + 8, device=dev, dtype=_f32)
+        off0 = (-data.data_ptr() // 4) % 8                       # 32-byte alignment of the first segment; sizes are multiples of 8
+        rsc = torch.empty(rows_total, device=dev, dtype=_f32)
+        arr = (PackSeg * len(specs))()
+        out = []
+        off, roff = off0, 0
+        for i, (W, r, c, t) in enumerate(specs):
+            M, K = (c, r) if t else (r, c)
+            if K % 8:
+                raise SepKernelsError("pack_weights: contraction length {} is not a multiple of 8".format(K))
+            pk = PackedA(data[off:off + M * K], rsc[roff:roff + M], M, K, src=(W, r, c, t))
+            arr[i] = PackSeg(W=_ptr(W, _f32), dst=pk.data.data_ptr(), rscale=pk.rscale.data_ptr(), M=M, K=K, trans=int(bool(t)), ldw=c)
+            out.append(pk)
+            off += M * K
+            roff += M
+        _check(load().sep_pack_weights(arr, len(specs), _stream()), "sep_pack_weights")
+        return out
 
     def pw_wgrad(self, *, B, M, N, T, ldt, G, X, partial, nsplit, G2=None, g_split=0, Gaux=None, g_mul=0, g_div=1,
                  x_mode=PRO_NONE, x_div=1, eps=1e-12, count=0.0, x_alpha=None, x_stats=None, x_gamma=None, x_beta=None,

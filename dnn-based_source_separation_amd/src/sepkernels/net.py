@@ -113,7 +113,48 @@ def _weights_amax(P):
     return amax_over([t for t in P.values() if torch.is_tensor(t)])
 
 
-def head_forward(cfg, P, mixture, stats0):
+def pack_weights(cfg, P, need_bwd):
+    """Every 1x1-convolution weight of the step, split once for SEP_ARITH_F16X3 (sep_pack_weights: {hi, lo} fp16 groups,
+    one power-of-two scale per row) in the orientation of each product: forward products use W, input-gradient products
+    W^T, and the two heads of a layer -- adjacent in the flat parameter buffer -- are one matrix [Wo;Ws] either way.
+    Returns {} when another arithmetic is selected (the kernels then split the fp32 weights themselves).  Done at the start of
+    every forward pass: the weights change between steps through raw pointers (fused Adam), so there is nothing to cache
+    on, and the whole pack is ~40 MB of writes (~15 us)."""
+    K = backend()
+    if sepkernels.gemm_arith() != sepkernels.ARITH_F16X3 or not hasattr(K, "pack_weights"):
+        return {}
+    N, n_src = cfg["n_basis"], cfg["n_sources"]
+    Bn, H, Sc = cfg["sep_bottleneck_channels"], cfg["sep_hidden_channels"], cfg["sep_skip_channels"]
+    names, specs = [], []
+
+    def add(name, W, r, c):
+        names.append(name)
+        specs.append((W, r, c, 0))
+        if need_bwd:
+            names.append(name + "^T")
+            specs.append((W, r, c, 1))
+
+    add("bottleneck", P["separator.bottleneck_conv1d.weight"], Bn, N)
+    for li, (pre, _, dual) in enumerate(layer_names(cfg)):
+        sp = pre + "separable_conv1d."
+        add("conv1.{}".format(li), P[pre + "bottleneck_conv1d.weight"], H, Bn)
+        Ws = P[sp + "skip_pointwise_conv1d.weight"]
+        if dual:
+            Wo = P[sp + "output_pointwise_conv1d.weight"]
+            if Bn % 128 == 0 and _adjacent(Wo, Ws):
+                add("heads.{}".format(li), Wo.as_strided((Bn + Sc, H), (H, 1)), Bn + Sc, H)
+            else:
+                add("out.{}".format(li), Wo, Bn, H)
+                add("skip.{}".format(li), Ws, Sc, H)
+        else:
+            add("skip.{}".format(li), Ws, Sc, H)
+    add("mask", P["separator.mask_conv1d.weight"], n_src * N, Sc)
+    keep = [i for i, (_, r, c, t) in enumerate(specs) if (r if t else c) % 16 == 0]     # contraction length the kernel takes
+    packs = K.pack_weights([specs[i] for i in keep])
+    return {names[i]: pk for i, pk in zip(keep, packs)}
+
+
+def head_forward(cfg, P, mixture, stats0, PK=None):
     """Encoder (+input padding) and the separator's first gLN + 1x1 bottleneck.
     Returns (geo, w (B,N,ldt), x0 (B,Bn,ldt)); stats0 (B,SLOTS,2) zeroed by the caller receives the statistics of w."""
     K = backend()
@@ -128,13 +169,13 @@ def head_forward(cfg, P, mixture, stats0):
     w = torch.empty(B, N, ldt, **f32)
     K.encoder_fwd(mixture, P["encoder.conv1d.weight"], w, stats0, B, Cin, T_in, N, L, S, F, ldt, geo.pad_left, relu)
     x = torch.empty(B, Bn, ldt, **f32)
-    K.pw_gemm(B=B, M=Bn, K=N, T=F, ldt=ldt, A=P["separator.bottleneck_conv1d.weight"], X=w, Y=x,
+    K.pw_gemm(B=B, M=Bn, K=N, T=F, ldt=ldt, A=P["separator.bottleneck_conv1d.weight"], A_pk=(PK or {}).get("bottleneck"), X=w, Y=x,
               bias=P["separator.bottleneck_conv1d.bias"], pro_mode=PRO_GLN, pro_stats=stats0,
               pro_gamma=P["separator.norm1d.norm.weight"], pro_beta=P["separator.norm1d.norm.bias"], count=N * F, eps=eps)
     return geo, w, x
 
 
-def tail_forward(cfg, P, geo, w, core, mixture_shape, want_latent):
+def tail_forward(cfg, P, geo, w, core, mixture_shape, want_latent, PK=None):
     """PReLU -> 1x1 mask conv -> sigmoid | channel softmax -> mask*w -> decoder (overlap-add) -> crop.  core (B, C, ldt)."""
     K = backend()
     B, Cin, T_in = mixture_shape
@@ -145,7 +186,7 @@ def tail_forward(cfg, P, geo, w, core, mixture_shape, want_latent):
     f32 = dict(device=w.device, dtype=w.dtype)
     m = torch.empty(B, n_src * N, ldt, **f32)
     softmax = cfg.get("mask_nonlinear") == "softmax"
-    K.pw_gemm(B=B, M=n_src * N, K=C, T=F, ldt=ldt, A=P["separator.mask_conv1d.weight"], X=core, Y=m,
+    K.pw_gemm(B=B, M=n_src * N, K=C, T=F, ldt=ldt, A=P["separator.mask_conv1d.weight"], A_pk=(PK or {}).get("mask"), X=core, Y=m,
               bias=P["separator.mask_conv1d.bias"], pro_mode=PRO_PRELU, pro_alpha=P["separator.prelu.weight"],
               epi_flags=0 if softmax else EPI_SIGMOID, eps=eps)
     if softmax:      # nn.Softmax(dim=1) over all n_src*N channels of a frame (reference conv_tasnet.py:357)
@@ -167,7 +208,7 @@ def _wgrad(K, B, F, ldt, eps, f32, M, Nn, Gt, Xt, want_bias, Bq=None, weps=None,
     return part, pb, ns
 
 
-def tail_backward(cfg, P, geo, w, core, m, mixture_shape, d_est, G, dalpha_slot):
+def tail_backward(cfg, P, geo, w, core, m, mixture_shape, d_est, G, dalpha_slot, PK=None):
     """Backward of tail_forward.  Writes the gradients of decoder / mask conv; accumulates the PReLU slope gradient
     into dalpha_slot (double, 1 element, zeroed by the caller).  Returns (dcore (B,C,ldt), dwm (B,N,ldt))."""
     K = backend()
@@ -192,7 +233,7 @@ def tail_backward(cfg, P, geo, w, core, m, mixture_shape, d_est, G, dalpha_slot)
     Wm = P["separator.mask_conv1d.weight"]
     alpha_m = P["separator.prelu.weight"]
     dcore = torch.empty(B, C, ldt, **f32)
-    K.pw_gemm(B=B, M=C, K=n_src * N, T=F, ldt=ldt, trans_a=1, A=Wm, X=dpre, Y=dcore, epi_flags=EPI_PRELU_BWD, epi_aux=core,
+    K.pw_gemm(B=B, M=C, K=n_src * N, T=F, ldt=ldt, trans_a=1, A=Wm, A_pk=(PK or {}).get("mask^T"), X=dpre, Y=dcore, epi_flags=EPI_PRELU_BWD, epi_aux=core,
               epi_alpha=alpha_m, epi_dalpha=dalpha_slot, eps=eps)
     part, pb, ns = _wgrad(K, B, F, ldt, eps, f32, n_src * N, C, dpre, core, True, x_mode=PRO_PRELU, x_alpha=alpha_m)
     K.reduce_slabs([(part, 0, G["separator.mask_conv1d.weight"], n_src * N * C, ns, n_src * N * C, 0, 1.0),
@@ -200,7 +241,7 @@ def tail_backward(cfg, P, geo, w, core, m, mixture_shape, d_est, G, dalpha_slot)
     return dcore, dwm
 
 
-def head_backward(cfg, P, geo, stats0, w, mixture, dx0, dwm, G):
+def head_backward(cfg, P, geo, stats0, w, mixture, dx0, dwm, G, PK=None):
     """Backward of head_forward given dx0 = d(bottleneck output) and dwm = d(w) arriving through mask*w."""
     K = backend()
     B, Cin, T_in = mixture.shape
@@ -217,7 +258,7 @@ def head_backward(cfg, P, geo, stats0, w, mixture, dx0, dwm, G):
     part, pb, ns = _wgrad(K, B, F, ldt, eps, f32, Bn, N, dx0, w, True, x_mode=PRO_GLN, x_stats=stats0, x_gamma=g0, x_beta=b0, count=cnt0)
     dvw = torch.empty(B, N, ldt, **f32)
     rp0 = torch.empty(B, N, nt64, 2, **f32)
-    K.pw_gemm(B=B, M=N, K=Bn, T=F, ldt=ldt, trans_a=1, A=Wb, X=dx0, Y=dvw, epi_flags=EPI_ROWSUMS, epi_aux=w,
+    K.pw_gemm(B=B, M=N, K=Bn, T=F, ldt=ldt, trans_a=1, A=Wb, A_pk=(PK or {}).get("bottleneck^T"), X=dx0, Y=dvw, epi_flags=EPI_ROWSUMS, epi_aux=w,
               epi_rowpart=rp0, eps=eps)
     bsum0 = torch.empty(B, 2, **f32)
     pbeta0 = torch.empty(B, N, **f32)
@@ -262,7 +303,8 @@ def _forward(cfg, P, mixture, want_latent, save):
     f32 = dict(device=dev, dtype=mixture.dtype)   # always fp32 in the product; the CPU emulator tests also run fp64
 
     stats = torch.zeros(2 * nl + 1, B, STATS_SLOTS, 2, device=dev, dtype=torch.float64)
-    geo, w, x = head_forward(cfg, P, mixture, stats[0])
+    PK = pack_weights(cfg, P, need_bwd=save)
+    geo, w, x = head_forward(cfg, P, mixture, stats[0], PK)
 
     skip = torch.empty(B, Sc, ldt, **f32)
     acts = []
@@ -270,7 +312,7 @@ def _forward(cfg, P, mixture, want_latent, save):
         sp = pre + "separable_conv1d."
         st1, st2 = stats[1 + 2 * li], stats[2 + 2 * li]
         a = torch.empty(B, H, ldt, **f32)
-        K.pw_gemm(B=B, M=H, K=Bn, T=F, ldt=ldt, A=P[pre + "bottleneck_conv1d.weight"], X=x, Y=a,
+        K.pw_gemm(B=B, M=H, K=Bn, T=F, ldt=ldt, A=P[pre + "bottleneck_conv1d.weight"], A_pk=PK.get("conv1.{}".format(li)), X=x, Y=a,
                   bias=P[pre + "bottleneck_conv1d.bias"], epi_flags=EPI_STATS_PRELU, epi_alpha=P[pre + "nonlinear1d.weight"],
                   epi_stats=st1, eps=teps)
         z = torch.empty(B, H, ldt, **f32)
@@ -287,23 +329,27 @@ def _forward(cfg, P, mixture, want_latent, save):
                 # [Wo;Ws] contiguous (flat parameter layout): one GEMM reads the H-tensor z once for both heads
                 Wcat = Wo.as_strided((Bn + Sc, H), (H, 1))      # views over the flat parameter buffer
                 bcat = bo.as_strided((Bn + Sc,), (1,))
-                K.pw_gemm(B=B, M=Bn + Sc, K=H, T=F, ldt=ldt, A=Wcat, X=z, Y=xo, Y2=skip, m_split=Bn, bias=bcat,
-                          accumulate=int(li > 0), epi_flags=EPI_RESIDUAL, epi_res=x, **pro)
+                K.pw_gemm(B=B, M=Bn + Sc, K=H, T=F, ldt=ldt, A=Wcat, A_pk=PK.get("heads.{}".format(li)), X=z, Y=xo, Y2=skip, m_split=Bn,
+                          bias=bcat, accumulate=int(li > 0), epi_flags=EPI_RESIDUAL, epi_res=x, **pro)
             else:
-                K.pw_gemm(B=B, M=Bn, K=H, T=F, ldt=ldt, A=Wo, X=z, Y=xo, bias=bo, epi_flags=EPI_RESIDUAL, epi_res=x, **pro)
-                K.pw_gemm(B=B, M=Sc, K=H, T=F, ldt=ldt, A=Ws, X=z, Y=skip, bias=bs, accumulate=int(li > 0), **pro)
+                K.pw_gemm(B=B, M=Bn, K=H, T=F, ldt=ldt, A=Wo, A_pk=PK.get("out.{}".format(li)), X=z, Y=xo, bias=bo, epi_flags=EPI_RESIDUAL,
+                          epi_res=x, **pro)
+                K.pw_gemm(B=B, M=Sc, K=H, T=F, ldt=ldt, A=Ws, A_pk=PK.get("skip.{}".format(li)), X=z, Y=skip, bias=bs,
+                          accumulate=int(li > 0), **pro)
         else:
             xo = None
-            K.pw_gemm(B=B, M=Sc, K=H, T=F, ldt=ldt, A=Ws, X=z, Y=skip, bias=bs, accumulate=int(li > 0), **pro)
+            K.pw_gemm(B=B, M=Sc, K=H, T=F, ldt=ldt, A=Ws, A_pk=PK.get("skip.{}".format(li)), X=z, Y=skip, bias=bs,
+                      accumulate=int(li > 0), **pro)
         acts.append((x, a, z))
         x = xo
 
-    est, latent, m = tail_forward(cfg, P, geo, w, skip, mixture.shape, want_latent)
+    est, latent, m = tail_forward(cfg, P, geo, w, skip, mixture.shape, want_latent, PK)
 
     sv = None
     if save:
         sv = Saved()
         sv.geo, sv.stats, sv.w, sv.acts, sv.skip, sv.m, sv.mixture = geo, stats, w, acts, skip, m, mixture
+        sv.packs = PK          # the transposed packs made above are the backward pass's A operands
     return est, latent, sv
 
 
@@ -398,7 +444,8 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
         return _wgrad(K, B, F, ldt, eps, f32, M, Nn, Gt, Xt, dbias is not None, Bq=Bq, weps=weps, **kw)
 
     # ---- tail: decoder / mask ---------------------------------------------------------------------
-    dS, dwm = tail_backward(cfg, P, geo, w, skip, m, mixture.shape, d_est, G, dalpha[nl:nl + 1])
+    PK = getattr(sv, "packs", None) or {}
+    dS, dwm = tail_backward(cfg, P, geo, w, skip, m, mixture.shape, d_est, G, dalpha[nl:nl + 1], PK)
 
     # ---- TCN layers, reversed -----------------------------------------------------------------------
     side = _SideStream(dev)
@@ -426,9 +473,13 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
         epi = dict(epi_flags=EPI_ROWSUMS | EPI_ROWSUMS_PRELU, epi_aux=z, epi_alpha=al2, epi_rowpart=rp2, eps=teps)
         if dual:
             Wo = P[sp + "output_pointwise_conv1d.weight"]
-            K.pw_gemm(B=B, M=H, K=Bn + Sc, T=F, ldt=ldt, trans_a=1, A=Wo, A2=Ws, X=dout, X2=dS, k_split=Bn, Y=dv2, **epi)
+            if "heads.{}^T".format(li) in PK:
+                K.pw_gemm(B=B, M=H, K=Bn + Sc, T=F, ldt=ldt, trans_a=1, A=Wo, A2=Ws, A_pk=PK["heads.{}^T".format(li)], X=dout, X2=dS,
+                          k_split=Bn, Y=dv2, **epi)
+            else:
+                K.pw_gemm(B=B, M=H, K=Bn + Sc, T=F, ldt=ldt, trans_a=1, A=Wo, A2=Ws, X=dout, X2=dS, k_split=Bn, Y=dv2, **epi)
         else:
-            K.pw_gemm(B=B, M=H, K=Sc, T=F, ldt=ldt, trans_a=1, A=Ws, X=dS, Y=dv2, **epi)
+            K.pw_gemm(B=B, M=H, K=Sc, T=F, ldt=ldt, trans_a=1, A=Ws, A_pk=PK.get("skip.{}^T".format(li)), X=dS, Y=dv2, **epi)
         bsum2 = torch.empty(B, 2, **f32)
         pbeta2 = torch.empty(B, H, **f32)
         pgamma2 = torch.empty(B, H, **f32)
@@ -484,8 +535,8 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
         # da overwrites dv1 in place when a single row tile covers all outputs (each X element is then read once);
         # with several row tiles the other tiles still need the untouched dv1, so da goes to its own buffer
         da = dv1 if Bn <= 128 else torch.empty_like(dv1)
-        K.pw_gemm(B=B, M=Bn, K=H, T=F, ldt=ldt, trans_a=1, A=P[pre + "bottleneck_conv1d.weight"], X=dv1, Y=dx,
-                  pro_mode=PRO_GLN_BWD, pro_stats=st1, pro_gamma=g1, pro_alpha=al1, pro_aux=a, pro_bsum=bsum1,
+        K.pw_gemm(B=B, M=Bn, K=H, T=F, ldt=ldt, trans_a=1, A=P[pre + "bottleneck_conv1d.weight"], A_pk=PK.get("conv1.{}^T".format(li)),
+                  X=dv1, Y=dx, pro_mode=PRO_GLN_BWD, pro_stats=st1, pro_gamma=g1, pro_alpha=al1, pro_aux=a, pro_bsum=bsum1,
                   pro_store=da, pro_dalpha=dalpha[li:li + 1], count=cnt, eps=teps,
                   epi_flags=(EPI_RESIDUAL if dout is not None else 0), epi_res=dout)
         # da and dx now exist: the side stream may go on (this layer's dW1, the next layer's head gradients)
@@ -529,4 +580,4 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
     K.reduce_slabs(pending)
 
     # ---- head: bottleneck conv, first gLN, encoder ------------------------------------------------------
-    head_backward(cfg, P, geo, stats[0], w, mixture, dout, dwm, G)
+    head_backward(cfg, P, geo, stats[0], w, mixture, dout, dwm, G, PK)

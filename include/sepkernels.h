@@ -33,7 +33,7 @@ extern "C" {
 
 typedef void* sep_stream_t; /* hipStream_t */
 
-#define SEP_ABI_VERSION 8
+#define SEP_ABI_VERSION 9
 #define SEP_STATS_SLOTS 16
 
 int sep_version(void);
@@ -67,7 +67,11 @@ const char* sep_last_error(void);
  *         range by exact power-of-two scales: one for A from the caller's bound a_amax >= max|A| (device scalar), one per
  *         column of X chosen and adjusted inside the kernel.  The error is relative to |A||X| per output (like fp32
  *         accumulation's), not elementwise: values ~2^-25 below their column's maximum lose low bits.  Without a_amax
- *         the call runs as BF16X6. */
+ *         the call runs as BF16X6.
+ *         PACKED WEIGHTS (A_pk != NULL, the form the Conv-TasNet step uses): A has been split ONCE per pass by
+ *         sep_pack_weights into {hi, lo} fp16 pairs with one power-of-two scale PER ROW of A (a_rscale[m] undoes it in the
+ *         epilogue); the kernel then DMAs MFMA-ready A operands, and the X tile is put through the prologue and split once
+ *         per workgroup (cooperatively, shared through LDS) instead of once per wave.  Needs M % 128 == 0. */
 #define SEP_ARITH_F32 0
 #define SEP_ARITH_BF16X6 1
 #define SEP_ARITH_F16X3 2
@@ -110,9 +114,28 @@ typedef struct sep_gemm_desc {
     double* epi_dalpha;
     float* epi_rowpart;
     const float* a_amax; /* SEP_ARITH_F16X3: device scalar >= max|A| (and |A2|); any upper bound, e.g. over all parameters */
+    const void* A_pk;       /* SEP_ARITH_F16X3: A ([M][K], already in the orientation of the product: the transpose and the
+                               [A|A2] concatenation of a k_split call are done by the packer) as written by sep_pack_weights,
+                               or NULL.  A / A2 / trans_a must still describe the fp32 weights: shapes the packed kernel does
+                               not cover run on them. */
+    const float* a_rscale;  /* [M] = 2^-e_m, the inverse row scales belonging to A_pk */
 } sep_gemm_desc;
 
 int sep_pw_gemm(const sep_gemm_desc* d, sep_stream_t stream);
+
+/* Weight packer of the SEP_ARITH_F16X3 path: for every segment, A[m][k] = trans ? W[k*ldw + m] : W[m*ldw + k] (M x K,
+ * K % 8 == 0), e_m = 13 - exponent(max_k |A[m][k]|), and each group of 8 consecutive k becomes 32 bytes
+ *     dst[(m*K/8 + g)*32 ..] = { fp16 hi[8] , fp16 lo[8] },  A*2^e_m = hi + lo (hi toward zero, 11 + 11 significand bits)
+ * i.e. 4 bytes per weight like the fp32 matrix; rscale[m] = 2^-e_m.  One launch for up to 256 segments (all 1x1-conv
+ * weights of a Conv-TasNet in both orientations).  Replaces nothing in the reference: it is the once-per-pass half of the
+ * operand split of the nn.Conv1d(kernel_size=1) products (tdcn.py:86,173,175; conv_tasnet.py:335,341). */
+typedef struct sep_pack_seg {
+    const float* W;
+    void* dst;      /* M*K*4 bytes, 32-byte aligned */
+    float* rscale;  /* [M] */
+    int32_t M, K, trans, ldw;
+} sep_pack_seg;
+int sep_pack_weights(const sep_pack_seg* segs_host, int nseg, sep_stream_t stream);
 
 /* Weight gradient of a pointwise convolution (reduction over batch and frames) on MFMA:
  *     partial[s][m][n] = sum over the (b,t) columns of slab s of  Gp[b][m][t] * Xp[b][n][t]

@@ -13,6 +13,8 @@ import math
 
 import torch
 
+import sepkernels
+
 PRO_NONE, PRO_PRELU, PRO_GLN, PRO_GLN_PRELU, PRO_GLN_BWD = 0, 1, 2, 3, 4
 EPI_STATS_PRELU, EPI_RESIDUAL, EPI_SIGMOID, EPI_PRELU_BWD, EPI_ROWSUMS, EPI_ROWSUMS_PRELU = 1, 2, 4, 8, 16, 32
 
@@ -50,11 +52,16 @@ class EmuBackend:
     name = "emulator"
 
     # ------------------------------------------------------------------ GEMMs
+    def pack_weights(self, specs):
+        """No arithmetic here: the emulator multiplies with the fp32 weights; the PackedA only remembers its source so that
+        pw_gemm can check that the host code pairs every product with the right pack."""
+        return [sepkernels.PackedA(None, None, (c if t else r), (r if t else c), src=(W, r, c, t)) for W, r, c, t in specs]
+
     def pw_gemm(self, *, B, M, K, T, ldt, A, X, Y, trans_a=0, A2=None, X2=None, k_split=0, Y2=None, m_split=0,
                 pro_mode=PRO_NONE, epi_flags=0, accumulate=0, eps=1e-12, count=0.0, bias=None, pro_alpha=None,
                 pro_stats=None, pro_gamma=None, pro_beta=None, pro_aux=None, pro_bsum=None, pro_store=None,
                 pro_dalpha=None, epi_alpha=None, epi_stats=None, epi_res=None, epi_aux=None, epi_dalpha=None,
-                epi_rowpart=None, arith=None, a_amax=None):
+                epi_rowpart=None, arith=None, a_amax=None, A_pk=None):
         dt = X.dtype
         k1 = k_split if k_split else K
         if trans_a:
@@ -66,6 +73,12 @@ class EmuBackend:
             Am = A.reshape(M, k1)
             if k_split:
                 Am = torch.cat([Am, A2.reshape(M, K - k1)], 1)
+        if A_pk is not None:
+            # plumbing check of the packed-weight path: the pack handed over must BE the matrix of this product
+            W, r, c, t = A_pk.src
+            Apk = W.reshape(-1)[:r * c].reshape(r, c)
+            Apk = Apk.t() if t else Apk
+            assert (A_pk.M, A_pk.K) == (M, K) and tuple(Apk.shape) == (M, K) and torch.equal(Apk, Am), "wrong packed weights for this product"
         Xf = X.reshape(B, k1, ldt)
         if k_split:
             Xf = torch.cat([Xf, X2.reshape(B, K - k1, ldt)], 1)

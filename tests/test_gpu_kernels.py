@@ -19,13 +19,30 @@ HIP = sepkernels.HipBackend()
 G = torch.Generator().manual_seed(1234)
 
 
-@pytest.fixture(params=["bf16x6", "f32", "f16x3"])
+PACKED = [False]
+
+
+@pytest.fixture(params=["bf16x6", "f32", "f16x3", "f16x3-packed"])
 def arith(request):
     """The arithmetics of sep_pw_gemm / sep_pw_wgrad (SEP_ARITH_*): exact three-way bf16 split on the bf16 MFMA, the fp32
-    MFMA, and the scaled two-part fp16 split (stand-alone calls form the |A| bound themselves)."""
-    prev = sepkernels.set_gemm_arith(request.param)
+    MFMA, the scaled two-part fp16 split (stand-alone calls form the |A| bound themselves), and the same with the weights
+    split beforehand by sep_pack_weights (sep_gemm_desc.A_pk: the form the Conv-TasNet step uses; shapes the packed kernel
+    does not take fall through to the fp32 weights inside sep_pw_gemm)."""
+    prev = sepkernels.set_gemm_arith(request.param.split("-")[0])
+    PACKED[0] = request.param.endswith("packed")
     yield request.param
+    PACKED[0] = False
     sepkernels.set_gemm_arith(prev)
+
+
+def packed_operand(gkw):
+    """A_pk of a pw_gemm call from its device-side A / A2 / trans_a, as net.pack_weights builds it."""
+    A, A2, M, K = gkw["A"], gkw.get("A2"), gkw["M"], gkw["K"]
+    if gkw.get("trans_a"):
+        W = A.reshape(-1, M) if A2 is None else torch.cat([A.reshape(-1, M), A2.reshape(-1, M)], 0).contiguous()
+        return HIP.pack_weights([(W, K, M, 1)])[0]
+    assert A2 is None
+    return HIP.pack_weights([(A.reshape(M, K), M, K, 0)])[0]
 
 
 def rnd(*shape, scale=1.0):
@@ -72,9 +89,11 @@ def both(op, args, kwargs=None, tol=2e-4, names=None):
     gargs = [to_gpu(a) for a in args]
     gkw = {k: to_gpu(v) for k, v in kwargs.items()}
     getattr(EMU, op)(*args, **kwargs)
+    if op == "pw_gemm" and PACKED[0] and gkw["K"] % 16 == 0:
+        gkw["A_pk"] = packed_operand(gkw)
     getattr(HIP, op)(*gargs, **gkw)
     torch.cuda.synchronize()
-    items = list(enumerate(zip(args, gargs))) + [(k, (kwargs[k], gkw[k])) for k in kwargs]
+    items = list(enumerate(zip(args, gargs))) + [(k, (kwargs[k], gkw[k])) for k in kwargs]      # (A_pk exists on one side only)
     for key, (c, g) in items:
         if not torch.is_tensor(c):
             continue
@@ -205,6 +224,52 @@ def test_gemm_gln_bwd_prologue(residual, arith):
     if residual:
         kw.update(epi_flags=EPI_RESIDUAL, epi_res=padded(B, M, T, ldt))
     both("pw_gemm", [], kw)
+
+
+@pytest.mark.parametrize("M,K,T", [(128, 512, 3999), (256, 512, 1000), (512, 128, 3999), (1024, 128, 700), (128, 1024, 450), (512, 256, 2100)])
+def test_gemm_packed_weights_model_shapes(M, K, T):
+    """The packed-weight kernel at the (M, K) pairs of the paper-best model -- one and two 32-row blocks per wave, short and
+    long contractions, edge / dead column tiles -- against fp64, beside the fp32-MFMA kernel on the same operands; weights
+    with rows of very different magnitude (the packer scales per row) and X rows spread over e^+-3 (per-column scales)."""
+    B = 2
+    ldt = (T + 127) // 128 * 128
+    X = padded(B, K, T, ldt) * torch.exp(3 * rnd(B, K, 1))
+    X[..., T:] = 0
+    A = rnd(M, K, scale=K ** -0.5) * torch.exp(4 * rnd(M, 1))
+    bias = rnd(M)
+    ref = torch.einsum("mk,bkt->bmt", A.double(), X.double()) + bias.double().view(1, M, 1)
+    scale = torch.einsum("mk,bkt->bmt", A.double().abs(), X.double().abs())[..., :T] + bias.double().abs().view(1, M, 1) + 1e-30
+    err = {}
+    for name in ("f32", "packed"):
+        Y = torch.full((B, M, ldt), float("nan"), device="cuda")
+        Ag = A.cuda()
+        kw = dict(B=B, M=M, K=K, T=T, ldt=ldt, A=Ag, X=X.cuda(), Y=Y, bias=bias.cuda())
+        if name == "packed":
+            kw.update(arith=sepkernels.ARITH_F16X3, A_pk=HIP.pack_weights([(Ag, M, K, 0)])[0])
+        else:
+            kw.update(arith=sepkernels.ARITH_F32)
+        HIP.pw_gemm(**kw)
+        torch.cuda.synchronize()
+        assert torch.isfinite(Y).all()
+        assert (Y[..., T:] == 0).all()
+        err[name] = (((Y.cpu().double() - ref)[..., :T]).abs() / scale).max().item()
+    assert err["f32"] <= 2e-6, err
+    assert err["packed"] <= max(3 * err["f32"], 6e-7), err
+
+
+def test_pack_weights_reproduces_the_weights():
+    """hi + lo of every packed group, times the row's inverse scale, is the weight to 2^-22 relative to the row maximum."""
+    W = rnd(96, 64) * torch.exp(5 * rnd(96, 1))
+    W[5] = 0
+    for trans in (0, 1):
+        pk = HIP.pack_weights([(W.cuda(), 96, 64, trans)])[0]
+        torch.cuda.synchronize()
+        M, K = pk.M, pk.K
+        h = pk.data.view(torch.float16).view(M, K // 8, 2, 8).float().cpu()
+        back = (h[:, :, 0] + h[:, :, 1]).reshape(M, K).double() * pk.rscale.cpu().double().view(M, 1)
+        A = (W.t() if trans else W).double()
+        assert (back - A).abs().max() <= 2.0 ** -21 * A.abs().amax(1, keepdim=True).clamp_min(1e-30).max()
+        assert ((back - A).abs() <= 2.0 ** -21 * A.abs().amax(1, keepdim=True)).all()
 
 
 # ------------------------------------------------------------------------------------------- weight gradient

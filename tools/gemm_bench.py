@@ -17,6 +17,7 @@ ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--only", default="")
 ap.add_argument("--ldt", type=int, default=4096)
 ap.add_argument("--nsplit-scale", type=float, default=1.0)
+ap.add_argument("--packed", action="store_true", help="hand sep_pw_gemm the weights pre-split by sep_pack_weights (A_pk)")
 args = ap.parse_args()
 K = sepkernels.HipBackend()
 dev = "cuda"
@@ -67,9 +68,19 @@ tot = 0.0
 for name, kw in cases.items():
     if args.only and not any(name.startswith(o) for o in args.only.split(",")):
         continue
+    if args.packed:
+        M_, K_ = kw["M"], kw["K"]
+        if kw.get("trans_a"):
+            W = kw["A"].reshape(-1, M_) if kw.get("A2") is None else torch.cat([kw["A"].reshape(-1, M_), kw["A2"].reshape(-1, M_)], 0).contiguous()
+            kw = dict(kw, A_pk=K.pack_weights([(W, K_, M_, 1)])[0])
+        else:
+            kw = dict(kw, A_pk=K.pack_weights([(kw["A"], M_, K_, 0)])[0])
     ms = timeit(lambda: K.pw_gemm(B=B, T=T, ldt=ldt, eps=1e-12, **kw))
     fl = 2.0 * kw["M"] * kw["K"] * B * T
-    print("{:50s} {:8.1f} us  {:6.1f} TF/s  ({:4.1f}% of 157.3)".format(name, 1e3 * ms, fl / ms / 1e9, fl / ms / 1e9 / 1.573))
+    rows = kw["K"] + kw["M"] + (kw["M"] - kw.get("m_split", 0) if kw.get("accumulate") else 0) + ((kw.get("m_split", 0) or kw["M"]) if kw.get("epi_res") is not None else 0) \
+        + (kw["M"] if kw.get("epi_aux") is not None else 0) + (2 * kw["K"] if kw.get("pro_store") is not None else 0)
+    by = 4.0 * rows * B * ldt
+    print("{:50s} {:8.1f} us  {:6.1f} TF/s-eq  {:5.2f} TB/s algorithmic ({:4.1f}% of 6.3)".format(name, 1e3 * ms, fl / ms / 1e9, by / ms / 1e9, by / ms / 1e9 / 0.063))
 for name, kw in wcases.items():
     if args.only and not any(name.startswith(o) for o in args.only.split(",")):
         continue
