@@ -54,6 +54,20 @@ __device__ __forceinline__ T block_sum_256(T v, T* sm) {
     return r;
 }
 
+// Same for a workgroup of NW waves (NW <= 8).
+template <typename T, int NW>
+__device__ __forceinline__ T block_sum_n(T v, T* sm) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sm[w] = v;
+    __syncthreads();
+    T r = sm[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) r += sm[i];
+    __syncthreads();
+    return r;
+}
+
 __device__ __forceinline__ float prelu_f(float x, float a) { return x > 0.f ? x : a * x; }
 __device__ __forceinline__ float prelu_grad(float x, float a) { return x > 0.f ? 1.f : a; }
 
@@ -79,3 +93,5 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // gemm_coop.hip: the packed-weight form of sep_pw_gemm (1 = launched, 0 = not one of its shapes)
 int sep_pw_gemm_packed(const sep_gemm_desc* d, hipStream_t stream);
+// gemm_pc.hip: its producer / consumer kernel (same contract)
+int sep_pw_gemm_pc(const sep_gemm_desc* d, hipStream_t stream);

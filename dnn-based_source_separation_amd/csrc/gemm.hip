@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const sep_gemm_desc d) 
     #ifdef SEP_PROF
     const int prof_slot = -1;
 #endif
-    gemm_epilogue<-1>(d, acc, b, m0, t0, wr, wc, lk, l31, tid, &sm.As[0][0], sm.red, BN PROF_PASS);
+    gemm_epilogue<-1>(d, acc, b, m0, t0, wr, wc, lk, l31, tid, &sm.As[0][0], sm.red, BN, true PROF_PASS);
     if (pro == SEP_PRO_GLN_BWD && rt == 0) {
         const double s = block_sum_256<double>((double)dalpha_pro, sm.red);
         if (tid == 0) atomicAdd(d.pro_dalpha, s);
@@ -789,7 +789,7 @@ __global__ __launch_bounds__(256, (AR >= 1 ? 3 : PRO == SEP_PRO_GLN_BWD ? 3 : PR
     asm volatile("" : "+v"(etid), "+s"(eb), "+s"(em0), "+s"(et0));
     const int ewid = __builtin_amdgcn_readfirstlane(etid >> 6);
     const int elane = etid & 63;
-    gemm_epilogue<EF>(d, acc, eb, em0, et0, ewid >> 1, ewid & 1, elane >> 5, elane & 31, etid, &sm.As[0][0], sm.red, BN PROF_PASS);
+    gemm_epilogue<EF>(d, acc, eb, em0, et0, ewid >> 1, ewid & 1, elane >> 5, elane & 31, etid, &sm.As[0][0], sm.red, BN, true PROF_PASS);
     PROF_STAMP(5);
     if (P_BWD && rt == 0) {
         const double sdal = block_sum_256<double>((double)dalpha_pro, sm.red);

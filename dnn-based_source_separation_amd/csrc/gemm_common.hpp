@@ -67,10 +67,13 @@ __device__ long long g_blk_start[8192], g_blk_end[8192];      // [block sample][
 // MI: 32-row blocks per wave (the wave's tile is 32*MI rows x 64 columns); RS: the accumulators are in the scaled units of
 // the packed-weight path and each output row is multiplied by d.a_rscale[row] (fused with the bias add); bn_tile: columns
 // of the workgroup's tile (128, or 64 for the cooperative kernel whose waves are stacked along the rows: wc = 0).
-template <int EF, int MI = 2, bool RS = false>
+// NW: waves of the workgroup (the block reductions at the end are executed by ALL of them); active = false: this wave owns
+// no output tile (the producer waves of pw_gemm_pc_kernel) and only takes part in those reductions.
+template <int EF, int MI = 2, bool RS = false, int NW = 4>
 __device__ __forceinline__ void gemm_epilogue(const sep_gemm_desc& d, f32x16 (&acc)[MI][2], const int b, const int m0,
                                               const int t0, const int wr, const int wc, const int lk, const int l31,
-                                              const int tid, float* lds, double* red, const int bn_tile PROF_ARG) {
+                                              const int tid, float* lds, double* red, const int bn_tile,
+                                              const bool active = true PROF_ARG) {
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ef = EF >= 0 ? EF : d.epi_flags;
@@ -103,6 +106,7 @@ __device__ __forceinline__ void gemm_epilogue(const sep_gemm_desc& d, f32x16 (&a
 #pragma unroll
     for (int e = 0; e < 4; ++e) cm[e] = (tc + e) < d.T ? 1.f : 0.f;
 
+    if (active) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         // ---- transpose: registers -> LDS (C layout) --------------------------------------------
@@ -246,13 +250,14 @@ __device__ __forceinline__ void gemm_epilogue(const sep_gemm_desc& d, f32x16 (&a
         PROF_STAMP(10 + 4 * mi);
 #endif
     }
+    }   // active
     if (ef & SEP_EPI_STATS_PRELU) {
-        const double s = block_sum_256<double>((double)st_s, red);
-        const double ss = block_sum_256<double>((double)st_ss, red);
+        const double s = block_sum_n<double, NW>((double)st_s, red);
+        const double ss = block_sum_n<double, NW>((double)st_ss, red);
         if (tid == 0) { double* st = d.epi_stats + ((size_t)b * SEP_STATS_SLOTS + (blockIdx.x & (SEP_STATS_SLOTS - 1))) * 2; atomicAdd(st, s); atomicAdd(st + 1, ss); }
     }
     if (ef & SEP_EPI_PRELU_BWD) {
-        const double s = block_sum_256<double>((double)dalpha_e, red);
+        const double s = block_sum_n<double, NW>((double)dalpha_e, red);
         if (tid == 0) atomicAdd(d.epi_dalpha, s);
     }
 }

@@ -26,9 +26,6 @@
 // DMA group g = {A chunk g, raw X chunk g+1}: the raw X ring runs one chunk ahead of the A ring.
 #include "gemm_common.hpp"
 #include <stdlib.h>
-#ifndef COOP_ABL
-#define COOP_ABL 0
-#endif
 
 #ifdef COOP_PROF
 __device__ long long g_coop_prof[4][64][8];      // [sampled block][step][stamp]
@@ -48,7 +45,7 @@ constexpr int COMAXK = 512;      // rows of the per-row affine table of the gLN 
 template <int MI, int NS, bool AUX>
 struct __attribute__((aligned(16))) CoopSmem {
     double red[8];
-    float As[NS][128 * MI * DK];             // A operand image [row][4 x 16 B], granule p of row r holds part p ^ ((r >> 2) & 3)
+    float As[NS][128 * MI * DK];             // A operand image: per 32-row block [hi | lo][lane][16 B], a straight copy of the packed layout
     float Bs[NS][4 * RBI];                   // raw X chunk as DMA'd
     float Cs[AUX ? NS : 1][AUX ? 4 * RBI : 4];   // GLN_BWD: the pre-activation chunk
     float Bp[2][CBN * 16];                   // split X chunk [col][4 x 16 B], same granule swizzle
@@ -141,21 +138,17 @@ void pw_gemm_coop_kernel(const sep_gemm_desc d) {
     const float* baseX = d.X + ((size_t)b * Ks1 + 4 * wid) * d.ldt + t0;
     const float* baseC = P_BWD ? d.pro_aux + ((size_t)b * Ks1 + 4 * wid) * d.ldt + t0 : nullptr;
     const float* baseA = reinterpret_cast<const float*>(d.A_pk);
+    // piece q = 2 * mi + part of this wave: 1 KiB at ((block * nk + chunk) * 2 + part) KiB of the packed matrix
     unsigned offA[2 * MI];
-    {
-        const int r = lane >> 2, p = lane & 3;
 #pragma unroll
-        for (int q = 0; q < 2 * MI; ++q)
-            offA[q] = 4u * (unsigned)((m0 + wid * RW + 16 * q + r) * d.K + 4 * (p ^ ((r >> 2) & 3)));
-    }
+    for (int q = 0; q < 2 * MI; ++q)
+        offA[q] = 16u * (unsigned)lane + 1024u * (unsigned)((((m0 + wid * RW) >> 5) + (q >> 1)) * nk * 2 + (q & 1));
     int xi = 0, xst = 0, ai = 0, ast = 0;      // next chunk to issue and its ring stage, per operand
     auto issue_x = [&]() {
         if (SPLIT && xi == split_chunk) baseX = d.X2 + ((size_t)b * (d.K - d.k_split) + 4 * wid) * d.ldt + t0;
         glds16_asm(baseX, offX, lds_addr(&sm.Bs[xst][wid * RBI]));
         if (P_BWD) glds16_asm(baseC, offX, lds_addr(&sm.Cs[P_BWD ? xst : 0][wid * RBI]));
-#if COOP_ABL != 1
         baseX += stepX;
-#endif
         if (P_BWD) baseC += stepX;
         ++xi;
         xst = xst + 1 == NS ? 0 : xst + 1;
@@ -163,9 +156,7 @@ void pw_gemm_coop_kernel(const sep_gemm_desc d) {
     auto issue_a = [&]() {
 #pragma unroll
         for (int q = 0; q < 2 * MI; ++q) glds16_asm(baseA, offA[q], lds_addr(&sm.As[ast][(wid * RW + 16 * q) * DK]));
-#if COOP_ABL != 5
-        baseA += DK;
-#endif
+        baseA += 512;                                                  // 2 KiB: the next chunk of every block
         ++ai;
         ast = ast + 1 == NS ? 0 : ast + 1;
     };
@@ -261,8 +252,8 @@ void pw_gemm_coop_kernel(const sep_gemm_desc d) {
         const float* Ab = sm.As[astage] + wid * RW * DK;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-            pa[mi][0] = *reinterpret_cast<const u32x4_t*>(Ab + mi * 32 * DK + c_hi);
-            pa[mi][1] = *reinterpret_cast<const u32x4_t*>(Ab + mi * 32 * DK + c_lo);
+            pa[mi][0] = *reinterpret_cast<const u32x4_t*>(Ab + mi * 32 * DK + 4 * lane);
+            pa[mi][1] = *reinterpret_cast<const u32x4_t*>(Ab + mi * 32 * DK + 256 + 4 * lane);
         }
         const float* Bp = sm.Bp[pb];
 #pragma unroll
@@ -276,13 +267,7 @@ void pw_gemm_coop_kernel(const sep_gemm_desc d) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-#if COOP_ABL != 2
-                acc[mi][ni] = mfma_f16(pa[mi][asel], pbv[ni][bsel], acc[mi][ni]);
-#else
-                acc[mi][ni][0] += __builtin_bit_cast(float, pa[mi][asel][0] ^ pbv[ni][bsel][1]);
-#endif
-            }
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma_f16(pa[mi][asel], pbv[ni][bsel], acc[mi][ni]);
     };
 
     if (!dead_tile) {
@@ -325,11 +310,7 @@ void pw_gemm_coop_kernel(const sep_gemm_desc d) {
             }
             mfma_part(0, 1);
             mfma_part(1, 0);
-#if COOP_ABL != 3
             if (more) split_chunk_vals(kc + 1, pb ^ 1);
-#else
-            if (more && kc == 0) { split_chunk_vals(1, 0); split_chunk_vals(1, 1); }
-#endif
             mfma_part(0, 0);
             CSTAMP(2);
             if (more) {
@@ -363,11 +344,7 @@ void pw_gemm_coop_kernel(const sep_gemm_desc d) {
     asm volatile("" : "+v"(etid), "+s"(eb), "+s"(em0), "+s"(et0));
     const int ewid = __builtin_amdgcn_readfirstlane(etid >> 6);
     const int elane = etid & 63;
-#if COOP_ABL != 4
     gemm_epilogue<EF, MI, true>(d, acc, eb, em0, et0, ewid, 0, elane >> 5, elane & 31, etid, &sm.As[0][0], sm.red, CBN);
-#else
-    if (acc[0][0][0] + acc[0][1][3] == 123.456f) d.Y[tid] = 1.f;
-#endif
     if (P_BWD && rt == 0) {
         const double sdal = block_sum_256<double>((double)dalpha_pro, sm.red);
         if (tid == 0) atomicAdd(d.pro_dalpha, sdal);
@@ -405,7 +382,9 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
     const int aexp = 13 - __builtin_amdgcn_frexp_expf(amax);      // A * 2^aexp < 2^13
     if (lane == 0) sg.rscale[m] = __builtin_ldexpf(1.f, -aexp);
-    uint4* dst = reinterpret_cast<uint4*>(sg.dst) + (size_t)m * ng * 2;
+    // operand-block layout: [m / 32][k / 16][hi | lo][lane = 32 * ((k >> 3) & 1) + (m & 31)][8 fp16] -- the 1 KiB a wave reads for
+    // one 32-row block, 16-deep chunk and part is contiguous, lane-linear, and IS the MFMA A operand
+    uint4* dst = reinterpret_cast<uint4*>(sg.dst) + (size_t)(m >> 5) * (ng >> 1) * 128 + (m & 31);
     for (int g = lane; g < ng; g += 64) {
         float x[8];
 #pragma unroll
@@ -416,8 +395,9 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
         unsigned hi[4], lo[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) split2_pair(x[2 * q], x[2 * q + 1], hi[q], lo[q]);
-        dst[2 * g] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-        dst[2 * g + 1] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        uint4* q = dst + (size_t)(g >> 1) * 128 + 32 * (g & 1);
+        q[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        q[64] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
     }
 }
 
@@ -436,9 +416,17 @@ void launch_coop(const sep_gemm_desc& d, const int ns, hipStream_t stream) {
 // launched here, 0 when the shape / flag combination is not one of the packed kernel's (the caller then uses A / A2).
 int sep_pw_gemm_packed(const sep_gemm_desc* d, hipStream_t stream) {
     static const bool off = getenv("SEPK_COOP") != nullptr && atoi(getenv("SEPK_COOP")) == 0;
+    // SEPK_GEMM_KERNEL = auto (default): the producer / consumer kernel where it wins (long contractions), the per-wave-split
+    // kernel of gemm.hip elsewhere; "pc" / "coop": that packed kernel for every shape it takes (tests, A/B runs)
+    static const char* kern = getenv("SEPK_GEMM_KERNEL");
+    static const bool only_coop = kern != nullptr && kern[0] == 'c';
+    static const bool all_pc = kern != nullptr && kern[0] == 'p';
+    static const int pc_min_k = getenv("SEPK_PC_MINK") ? atoi(getenv("SEPK_PC_MINK")) : 512;
     static const int force_mi = getenv("SEPK_COOP_MI") ? atoi(getenv("SEPK_COOP_MI")) : 0;
     static const int env_ns = getenv("SEPK_COOP_NS") ? atoi(getenv("SEPK_COOP_NS")) : 0;
     if (off || !d->A_pk || !d->a_rscale || d->arith != SEP_ARITH_F16X3) return 0;
+    if (!only_coop && (all_pc || d->K >= pc_min_k) && sep_pw_gemm_pc(d, stream)) return 1;      // producer / consumer form (gemm_pc.hip)
+    if (!only_coop && !all_pc) return 0;
     if (d->M % 128 != 0 || d->K % DK != 0 || d->k_split % DK != 0 || (d->m_split % 128) != 0) return 0;
     if (d->pro_mode >= SEP_PRO_GLN && d->K > COMAXK) return 0;
     if ((size_t)d->M * d->K * 4 >= (1ull << 32) || (size_t)4 * d->ldt * 4 >= (1ull << 31)) return 0;     // 32-bit DMA offsets
@@ -478,7 +466,7 @@ extern "C" int sep_pack_weights(const sep_pack_seg* segs, int nseg, sep_stream_t
         int blocks = 0;
         for (int i = 0; i < n; ++i) {
             const sep_pack_seg& s = segs[s0 + i];
-            SEP_REQUIRE(s.W && s.dst && s.rscale && s.M > 0 && s.K > 0 && s.K % 8 == 0 && s.ldw > 0, "sep_pack_weights: bad segment %d (M=%d K=%d)", s0 + i, s.M, s.K);
+            SEP_REQUIRE(s.W && s.dst && s.rscale && s.M > 0 && s.K > 0 && s.K % 16 == 0 && s.M % 32 == 0 && s.ldw > 0, "sep_pack_weights: bad segment %d (M=%d K=%d)", s0 + i, s.M, s.K);
             SEP_REQUIRE((reinterpret_cast<size_t>(s.dst) & 31) == 0, "sep_pack_weights: dst of segment %d is not 32-byte aligned", s0 + i);
             a.seg[i] = s;
             a.blk_start[i] = blocks;
