@@ -67,9 +67,12 @@ __device__ long long g_blk_start[8192], g_blk_end[8192];      // [block sample][
 // MI: 32-row blocks per wave (the wave's tile is 32*MI rows x 64 columns); RS: the accumulators are in the scaled units of
 // the packed-weight path and each output row is multiplied by d.a_rscale[row] (fused with the bias add); bn_tile: columns
 // of the workgroup's tile (128, or 64 for the cooperative kernel whose waves are stacked along the rows: wc = 0).
+// PIPE: the global reads of group g+1 (bias, row scale, residual / aux / accumulate operands) are issued before group g is
+// processed (two operand buffers): one exposed memory round trip per call instead of one per group -- for kernels that run
+// ONE workgroup per CU (pw_gemm_pc_kernel), where no other workgroup hides those round trips.
 // NW: waves of the workgroup (the block reductions at the end are executed by ALL of them); active = false: this wave owns
 // no output tile (the producer waves of pw_gemm_pc_kernel) and only takes part in those reductions.
-template <int EF, int MI = 2, bool RS = false, int NW = 4>
+template <int EF, int MI = 2, bool RS = false, int NW = 4, bool PIPE = false>
 __device__ __forceinline__ void gemm_epilogue(const sep_gemm_desc& d, f32x16 (&acc)[MI][2], const int b, const int m0,
                                               const int t0, const int wr, const int wc, const int lk, const int l31,
                                               const int tid, float* lds, double* red, const int bn_tile,
@@ -107,67 +110,50 @@ __device__ __forceinline__ void gemm_epilogue(const sep_gemm_desc& d, f32x16 (&a
     for (int e = 0; e < 4; ++e) cm[e] = (tc + e) < d.T ? 1.f : 0.f;
 
     if (active) {
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        // ---- transpose: registers -> LDS (C layout) --------------------------------------------
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rl = (r & 3) + 8 * (r >> 2) + 4 * lk;
-            Tw[rl * EPI_LD + l31] = acc[mi][0][r];
-            Tw[rl * EPI_LD + 32 + l31] = acc[mi][1][r];
-        }
-        __builtin_amdgcn_wave_barrier();       // LDS is in-order per wave; this only pins the compiler's order
-#ifdef SEP_PROF
-        __builtin_amdgcn_s_waitcnt(0x0070);
-        PROF_STAMP(8 + 4 * mi);
-#endif
-        // ---- per group of GRP passes (4 rows each): every global read issued back to back, then compute + stores.
-        //      Four on full tiles (eight would spill: 3 x 8 float4 of operands next to the second half's accumulators),
-        //      two on edge tiles, whose predicates need registers too -- ANY scratch in this kernel costs occupancy.
-        //      Wave-uniform options (bias / residual / accumulate) are whole-group blocks: one scalar branch each.
-#pragma unroll
-        for (int g4 = 0; g4 < 8; g4 += GRP) {
-            float4 ext[GRP], aux[GRP], old[GRP];
-            float bs[GRP], rs[GRP];
+struct GrpOps { float4 ext[GRP], aux[GRP], old[GRP]; float bs[GRP], rs[GRP]; };
+        // every global read of a group of GRP passes, issued back to back
+        auto issue_loads = [&](const int mi, const int g4, GrpOps& o) {
             bool ok[GRP];
 #pragma unroll
             for (int j = 0; j < GRP; ++j) {
                 ok[j] = FULL || (wrow + mi * 32 + (g4 + j) * 4 + rsub) < d.M;
                 if (!FULL) {                       // rows past M: neutral operands (on full tiles every use is guarded by the same flag as its load)
-                    bs[j] = 0.f;
-                    ext[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    aux[j] = ext[j];
-                    old[j] = ext[j];
+                    o.bs[j] = 0.f;
+                    o.ext[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    o.aux[j] = o.ext[j];
+                    o.old[j] = o.ext[j];
                 }
             }
             if (has_bias) {
 #pragma unroll
                 for (int j = 0; j < GRP; ++j)
-                    if (ok[j]) bs[j] = *byte_off(bias_w + mi * 32 + (g4 + j) * 4, 4u * (unsigned)rsub);
+                    if (ok[j]) o.bs[j] = *byte_off(bias_w + mi * 32 + (g4 + j) * 4, 4u * (unsigned)rsub);
             }
             if (RS) {
 #pragma unroll
-                for (int j = 0; j < GRP; ++j) rs[j] = ok[j] ? *byte_off(rs_w + mi * 32 + (g4 + j) * 4, 4u * (unsigned)rsub) : 0.f;
+                for (int j = 0; j < GRP; ++j) o.rs[j] = ok[j] ? *byte_off(rs_w + mi * 32 + (g4 + j) * 4, 4u * (unsigned)rsub) : 0.f;
             }
             if (use_res) {
 #pragma unroll
                 for (int j = 0; j < GRP; ++j)
-                    if (ok[j]) ext[j] = ld4(byte_off(res_w + (mi * 32 + (g4 + j) * 4) * (size_t)d.ldt, lane_off));
+                    if (ok[j]) o.ext[j] = ld4(byte_off(res_w + (mi * 32 + (g4 + j) * 4) * (size_t)d.ldt, lane_off));
             }
             if (use_aux) {
 #pragma unroll
                 for (int j = 0; j < GRP; ++j)
-                    if (ok[j]) aux[j] = ld4(byte_off(aux_w + (mi * 32 + (g4 + j) * 4) * (size_t)d.ldt, lane_off));
+                    if (ok[j]) o.aux[j] = ld4(byte_off(aux_w + (mi * 32 + (g4 + j) * 4) * (size_t)d.ldt, lane_off));
             }
             if (acc_this) {
 #pragma unroll
                 for (int j = 0; j < GRP; ++j)
-                    if (ok[j]) old[j] = ld4(byte_off(dst_w + (mi * 32 + (g4 + j) * 4) * (size_t)d.ldt, lane_off));
+                    if (ok[j]) o.old[j] = ld4(byte_off(dst_w + (mi * 32 + (g4 + j) * 4) * (size_t)d.ldt, lane_off));
             }
-#ifdef SEP_PROF
-            __builtin_amdgcn_s_waitcnt(0x0070);
-            PROF_STAMP(9 + 4 * mi);
-#endif
+        };
+        // transposed tile rows of the group -> bias / scale / flag-dependent math -> stores
+        auto process = [&](const int mi, const int g4, GrpOps& o) {
+            bool ok[GRP];
+#pragma unroll
+            for (int j = 0; j < GRP; ++j) ok[j] = FULL || (wrow + mi * 32 + (g4 + j) * 4 + rsub) < d.M;
             float4 outv[GRP];
 #pragma unroll
             for (int j = 0; j < GRP; ++j) outv[j] = ld4(Tw + ((g4 + j) * 4 + rsub) * EPI_LD + 4 * c4);
@@ -175,16 +161,16 @@ __device__ __forceinline__ void gemm_epilogue(const sep_gemm_desc& d, f32x16 (&a
                 if (has_bias) {
 #pragma unroll
                     for (int j = 0; j < GRP; ++j) {
-                        outv[j].x = fmaf(outv[j].x, rs[j], bs[j]); outv[j].y = fmaf(outv[j].y, rs[j], bs[j]);
-                        outv[j].z = fmaf(outv[j].z, rs[j], bs[j]); outv[j].w = fmaf(outv[j].w, rs[j], bs[j]);
+                        outv[j].x = fmaf(outv[j].x, o.rs[j], o.bs[j]); outv[j].y = fmaf(outv[j].y, o.rs[j], o.bs[j]);
+                        outv[j].z = fmaf(outv[j].z, o.rs[j], o.bs[j]); outv[j].w = fmaf(outv[j].w, o.rs[j], o.bs[j]);
                     }
                 } else {
 #pragma unroll
-                    for (int j = 0; j < GRP; ++j) { outv[j].x *= rs[j]; outv[j].y *= rs[j]; outv[j].z *= rs[j]; outv[j].w *= rs[j]; }
+                    for (int j = 0; j < GRP; ++j) { outv[j].x *= o.rs[j]; outv[j].y *= o.rs[j]; outv[j].z *= o.rs[j]; outv[j].w *= o.rs[j]; }
                 }
             } else if (has_bias) {
 #pragma unroll
-                for (int j = 0; j < GRP; ++j) { outv[j].x += bs[j]; outv[j].y += bs[j]; outv[j].z += bs[j]; outv[j].w += bs[j]; }
+                for (int j = 0; j < GRP; ++j) { outv[j].x += o.bs[j]; outv[j].y += o.bs[j]; outv[j].z += o.bs[j]; outv[j].w += o.bs[j]; }
             }
             if (!full_cols) {
 #pragma unroll
@@ -194,7 +180,7 @@ __device__ __forceinline__ void gemm_epilogue(const sep_gemm_desc& d, f32x16 (&a
             for (int j = 0; j < GRP; ++j) {
                 float v[4] = {outv[j].x, outv[j].y, outv[j].z, outv[j].w};
                 float ax[4] = {0.f, 0.f, 0.f, 0.f};
-                if (use_aux) { ax[0] = aux[j].x; ax[1] = aux[j].y; ax[2] = aux[j].z; ax[3] = aux[j].w; }
+                if (use_aux) { ax[0] = o.aux[j].x; ax[1] = o.aux[j].y; ax[2] = o.aux[j].z; ax[3] = o.aux[j].w; }
                 float rs1 = 0.f, rs2 = 0.f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -230,13 +216,13 @@ __device__ __forceinline__ void gemm_epilogue(const sep_gemm_desc& d, f32x16 (&a
 #pragma unroll
                 for (int j = 0; j < GRP; ++j) {
                     // frames >= T of the residual / accumulated tensors are zero by contract, so the sums keep them zero
-                    outv[j].x += ext[j].x; outv[j].y += ext[j].y; outv[j].z += ext[j].z; outv[j].w += ext[j].w;
+                    outv[j].x += o.ext[j].x; outv[j].y += o.ext[j].y; outv[j].z += o.ext[j].z; outv[j].w += o.ext[j].w;
                 }
             }
             if (acc_this) {
 #pragma unroll
                 for (int j = 0; j < GRP; ++j) {
-                    outv[j].x += old[j].x; outv[j].y += old[j].y; outv[j].z += old[j].z; outv[j].w += old[j].w;
+                    outv[j].x += o.old[j].x; outv[j].y += o.old[j].y; outv[j].z += o.old[j].z; outv[j].w += o.old[j].w;
                 }
             }
 #pragma unroll
@@ -244,7 +230,40 @@ __device__ __forceinline__ void gemm_epilogue(const sep_gemm_desc& d, f32x16 (&a
                 if (ok[j])
                     st4_out(const_cast<float*>(byte_off(dst_w + (mi * 32 + (g4 + j) * 4) * (size_t)d.ldt, lane_off)), outv[j]);
             }
-        }   // g4
+        };
+        constexpr int NGB = 8 / GRP;                  // groups per 32-row block
+        GrpOps ops[PIPE ? 2 : 1];
+        if (PIPE) issue_loads(0, 0, ops[0]);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        // ---- transpose: registers -> LDS (C layout) --------------------------------------------
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * lk;
+            Tw[rl * EPI_LD + l31] = acc[mi][0][r];
+            Tw[rl * EPI_LD + 32 + l31] = acc[mi][1][r];
+        }
+        __builtin_amdgcn_wave_barrier();       // LDS is in-order per wave; this only pins the compiler's order
+#ifdef SEP_PROF
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        PROF_STAMP(8 + 4 * mi);
+#endif
+        // ---- per group of GRP passes (4 rows each): every global read issued back to back, then compute + stores.
+        //      Four on full tiles (eight would spill: 3 x 8 float4 of operands next to the second half's accumulators),
+        //      two on edge tiles, whose predicates need registers too -- ANY scratch in this kernel costs occupancy.
+        //      Wave-uniform options (bias / residual / accumulate) are whole-group blocks: one scalar branch each.
+#pragma unroll
+        for (int gi = 0; gi < NGB; ++gi) {
+            const int s = mi * NGB + gi;
+            if (PIPE) {
+                // the next group's operands travel while this group is computed and stored (next group may be in the next block)
+                if (s + 1 < MI * NGB) issue_loads((s + 1) / NGB, ((s + 1) % NGB) * GRP, ops[(s + 1) & 1]);
+                process(mi, gi * GRP, ops[s & 1]);
+            } else {
+                issue_loads(mi, gi * GRP, ops[0]);
+                process(mi, gi * GRP, ops[0]);
+            }
+        }
         __builtin_amdgcn_wave_barrier();
 #ifdef SEP_PROF
         PROF_STAMP(10 + 4 * mi);

@@ -416,8 +416,8 @@ void launch_coop(const sep_gemm_desc& d, const int ns, hipStream_t stream) {
 // launched here, 0 when the shape / flag combination is not one of the packed kernel's (the caller then uses A / A2).
 int sep_pw_gemm_packed(const sep_gemm_desc* d, hipStream_t stream) {
     static const bool off = getenv("SEPK_COOP") != nullptr && atoi(getenv("SEPK_COOP")) == 0;
-    // SEPK_GEMM_KERNEL = auto (default): the producer / consumer kernel where it wins (long contractions), the per-wave-split
-    // kernel of gemm.hip elsewhere; "pc" / "coop": that packed kernel for every shape it takes (tests, A/B runs)
+    // SEPK_GEMM_KERNEL = auto (default): the producer / consumer kernel where it wins (long contractions), the cooperative
+    // kernel elsewhere; "pc" / "coop": that kernel for every shape it takes (tests, A/B runs)
     static const char* kern = getenv("SEPK_GEMM_KERNEL");
     static const bool only_coop = kern != nullptr && kern[0] == 'c';
     static const bool all_pc = kern != nullptr && kern[0] == 'p';
@@ -425,8 +425,12 @@ int sep_pw_gemm_packed(const sep_gemm_desc* d, hipStream_t stream) {
     static const int force_mi = getenv("SEPK_COOP_MI") ? atoi(getenv("SEPK_COOP_MI")) : 0;
     static const int env_ns = getenv("SEPK_COOP_NS") ? atoi(getenv("SEPK_COOP_NS")) : 0;
     if (off || !d->A_pk || !d->a_rscale || d->arith != SEP_ARITH_F16X3) return 0;
-    if (!only_coop && (all_pc || d->K >= pc_min_k) && sep_pw_gemm_pc(d, stream)) return 1;      // producer / consumer form (gemm_pc.hip)
-    if (!only_coop && !all_pc) return 0;
+    // measured per shape (tools/gemm_bench.py --packed, SEPK_GEMM_KERNEL=pc vs the default): the one-workgroup-per-CU kernel wins
+    // where the main loop is long (K >= 512) or the row tiles are many (M >= 1024); at K = 128 / 256 its un-overlapped ring
+    // fill and epilogue per tile cost more than its denser MFMA stream gains
+    if (!only_coop && (all_pc || d->K >= pc_min_k || d->M >= 1024) && sep_pw_gemm_pc(d, stream)) return 1;      // producer / consumer form (gemm_pc.hip)
+    // everything else the packed path takes runs on this file's cooperative kernel: ~5 % behind the per-wave-split kernel of
+    // gemm.hip on the K = 128 shapes, but with the packer's per-row weight scales instead of one bound for all weights
     if (d->M % 128 != 0 || d->K % DK != 0 || d->k_split % DK != 0 || (d->m_split % 128) != 0) return 0;
     if (d->pro_mode >= SEP_PRO_GLN && d->K > COMAXK) return 0;
     if ((size_t)d->M * d->K * 4 >= (1ull << 32) || (size_t)4 * d->ldt * 4 >= (1ull << 31)) return 0;     // 32-bit DMA offsets

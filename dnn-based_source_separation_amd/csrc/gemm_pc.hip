@@ -35,6 +35,10 @@ extern "C" int sep_debug_pc_prof(long long* out) { return hipMemcpyFromSymbol(ou
 #define SSTAMP(role, s) do { } while (0)
 #endif
 
+#ifndef PC_SETPRIO
+#define PC_SETPRIO 1
+#endif
+
 namespace {
 
 constexpr int PCMAXK = 512;      // rows of the per-row affine table of the gLN prologues
@@ -88,6 +92,7 @@ __global__ __launch_bounds__(512, 2) void pw_gemm_pc_kernel(const sep_gemm_desc 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool producer = wid >= 4;
+    const bool prio_consumers = d.accumulate >= 0 && PC_SETPRIO;
     const int lk = lane >> 5, l31 = lane & 31;
 
     const int NR = d.M / TM;
@@ -262,7 +267,9 @@ __global__ __launch_bounds__(512, 2) void pw_gemm_pc_kernel(const sep_gemm_desc 
         const int b_base = 128 * wcc * 16;
         // A fragments come straight from the packed matrix (operand-block layout: 1 KiB per 32-row block, chunk and part,
         // lane-linear), one chunk ahead of their use: L2-resident weights, perfectly coalesced, no LDS and no barrier involved
-        const u32x4_t* Apk = reinterpret_cast<const u32x4_t*>(d.A_pk) + (size_t)((m0 + 64 * wr) >> 5) * nk * 128 + lane;
+        const char* Apk = reinterpret_cast<const char*>(d.A_pk) + (size_t)((m0 + 64 * wr) >> 5) * nk * 2048;     // wave-uniform
+        const unsigned a_lane = 16u * (unsigned)lane;
+        if (prio_consumers) __builtin_amdgcn_s_setprio(2);        // the MFMA stream wins the issue arbitration against its SIMD's producer wave
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -282,8 +289,9 @@ __global__ __launch_bounds__(512, 2) void pw_gemm_pc_kernel(const sep_gemm_desc 
             constexpr int par = decltype(parc)::value;
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
-                sa[par][mi][0] = Apk[((size_t)mi * nk + chunk) * 128];
-                sa[par][mi][1] = Apk[((size_t)mi * nk + chunk) * 128 + 64];
+                const char* q = Apk + ((size_t)mi * nk + chunk) * 2048;                   // scalar arithmetic: the load takes the saddr form
+                sa[par][mi][0] = *reinterpret_cast<const u32x4_t*>(q + a_lane);
+                sa[par][mi][1] = *reinterpret_cast<const u32x4_t*>(q + 1024 + a_lane);
             }
         };
         auto read_b = [&](auto halfc, const int pb) {
@@ -363,6 +371,7 @@ __global__ __launch_bounds__(512, 2) void pw_gemm_pc_kernel(const sep_gemm_desc 
             __builtin_amdgcn_s_waitcnt(0xc07f);
             compute(I1, I1);
         }
+        if (prio_consumers) __builtin_amdgcn_s_setprio(0);
         // undo the column scales (the row scales of A leave in the epilogue)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
@@ -383,7 +392,7 @@ __global__ __launch_bounds__(512, 2) void pw_gemm_pc_kernel(const sep_gemm_desc 
     const int cw = cons ? ewid : 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
-        gemm_epilogue<EF, 2, true, 8>(d, acc[h], eb, em0, et0, cw / WC, 2 * (cw % WC) + h, elane >> 5, elane & 31, etid, &sm.Xr[0][0], sm.red, TN, cons);
+        gemm_epilogue<EF, 2, true, 8, true>(d, acc[h], eb, em0, et0, cw / WC, 2 * (cw % WC) + h, elane >> 5, elane & 31, etid, &sm.Xr[0][0], sm.red, TN, cons);
 #ifdef PC_PROF
     __builtin_amdgcn_s_waitcnt(0x0070);
     if (ewid == 0 && elane == 0 && blockIdx.x < 4096) g_pc_prof[blockIdx.x][3] = wall_clock64();
@@ -416,7 +425,7 @@ int sep_pw_gemm_pc(const sep_gemm_desc* d, hipStream_t stream) {
     const int ef = d->epi_flags, pm = d->pro_mode;
     const bool sp = d->k_split != 0;
     const bool tall = d->M % 256 == 0 && !force_22;      // 256 x 128 tile (consumers 4 x 1), else 128 x 256 (2 x 2)
-    const int ns = env_ns == 3 || env_ns == 5 ? env_ns : 3;
+    const int ns = env_ns == 3 || env_ns == 5 ? env_ns : (pm == SEP_PRO_GLN_BWD ? 5 : 3);      // measured: the deeper ring pays on the two-operand stream of the gLN-backward prologue only
 #define SEP_LP(P, S, E)                                              \
     do {                                                             \
         if (tall) launch_pc<4, 1, P, S, E>(*d, ns, stream);          \
