@@ -6,10 +6,12 @@ bench.py -- separated audio frames/sec (fwd + SI-SDR/PIT + bwd [+ all-reduce] + 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One JSON line on rank 0.  A "step" is one pass of the hot path over one batch resident in HBM.  `roofline` is for the
-dominant kernel (the fp32-MFMA pointwise GEMM `pw_gemm_direct_kernel`): its launches are bracketed with HIP events on the
-launch stream during the timed steps; achieved = algorithmic FLOPs of those launches / their summed duration.
-`cpu_baseline` is the oracle's functional port (oracle/fast_port.py, same ATen CPU kernels as the reference) timed
-on this box's host cores on a bounded sample (N=1 runs only).
+dominant kernel group, the 1x1-convolution GEMM `sep_pw_gemm` (pw_gemm_pc_kernel / pw_gemm_coop_kernel: fp32 products from a
+two-part fp16 split on v_mfma_f32_32x32x16_f16): its launches are bracketed with HIP events on the launch stream in a second
+pass of the same K steps; the roof is min(matrix pipe / MFMAs per product, HBM x FLOP per byte) -- HBM for these shapes --
+and achieved = algorithmic bytes of those launches / their summed duration.  `cpu_baseline` is the oracle's functional port
+(oracle/fast_port.py, same ATen CPU kernels as the reference; pinned to the live reference by tests/test_oracle_vs_reference_cpu.py)
+timed on this box's host cores on a bounded sample (N=1 runs only).
 """
 import argparse
 import json
@@ -32,7 +34,10 @@ PAPER = dict(n_basis=512, kernel_size=16, stride=8, enc_basis="trainable", dec_b
 T_SAMPLES = 32000            # 4 s @ 8 kHz
 PER_GPU_BATCH = 16
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+F16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA (32x32x16)
 HBM_PEAK_TBS = 8.0
+# matrix-pipe instructions per fp32 product and the pipe they run on, per arithmetic of the contraction
+MFMA_PER_PRODUCT = {"f16x3": (3, F16_MFMA_PEAK_TFLOPS), "bf16x6": (6, F16_MFMA_PEAK_TFLOPS), "f32": (1, FP32_MFMA_PEAK_TFLOPS)}
 
 
 class TimedBackend:
@@ -43,43 +48,42 @@ class TimedBackend:
         self._inner = inner
         self.enabled = False
         self.records = {"pw_gemm": [], "pw_wgrad": []}
-        self.variants = {}
         self.name = inner.name
 
     def __getattr__(self, item):
         return getattr(self._inner, item)
 
-    def _timed(self, key, flops, fn, kw):
+    def _timed(self, key, flops, nbytes, fn, kw):
         if not self.enabled:
             return fn(**kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         fn(**kw)
         e1.record()
-        self.records[key].append((e0, e1, flops))
+        self.records[key].append((e0, e1, flops, nbytes))
 
     def pw_gemm(self, **kw):
-        if self.enabled:
-            # algorithmic HBM bytes of this launch: every operand row once (fp32), weights ignored
-            M, K = kw["M"], kw["K"]
-            msp = kw.get("m_split", 0)
-            rows = K + M                                                     # X in, Y out
-            rows += (M - msp if kw.get("accumulate") else 0)                 # accumulated part read back
-            rows += ((msp or M) if kw.get("epi_res") is not None else 0)     # residual
-            rows += (M if kw.get("epi_aux") is not None else 0)              # PReLU-bwd / row-sum operand
-            rows += (2 * K if kw.get("pro_store") is not None else 0)        # gLN-bwd: pre-activation in, d(pre-activation) out
-            key = "T{}P{}S{}".format(int(bool(kw.get("trans_a"))), int(kw.get("pro_mode", 0)), int(bool(kw.get("k_split"))))
-            c, a = self.variants.get(key, (0, 0.0))
-            self.variants[key] = (c + 1, a + 4.0 * rows * kw["B"] * kw["T"])
-        self._timed("pw_gemm", 2.0 * kw["M"] * kw["K"] * kw["B"] * kw["T"], self._inner.pw_gemm, kw)
+        # algorithmic HBM bytes of this launch (SURVEY.md 8d convention): every activation row once, fp32, valid frames only;
+        # the weights (<= 1 MB, L2-resident) are not counted
+        M, K = kw["M"], kw["K"]
+        msp = kw.get("m_split", 0)
+        rows = K + M                                                     # X in, Y out
+        rows += (M - msp if kw.get("accumulate") else 0)                 # accumulated part read back
+        rows += ((msp or M) if kw.get("epi_res") is not None else 0)     # residual
+        rows += (M if kw.get("epi_aux") is not None else 0)              # PReLU-bwd / row-sum operand
+        rows += (2 * K if kw.get("pro_store") is not None else 0)        # gLN-bwd: pre-activation in, d(pre-activation) out
+        self._timed("pw_gemm", 2.0 * M * K * kw["B"] * kw["T"], 4.0 * rows * kw["B"] * kw["T"], self._inner.pw_gemm, kw)
 
     def pw_wgrad(self, **kw):
-        self._timed("pw_wgrad", 2.0 * kw["M"] * kw["N"] * kw["B"] * kw["T"], self._inner.pw_wgrad, kw)
+        rows = kw["M"] + kw["N"]                                         # both operands once; the slabs are written + re-read: not algorithmic
+        self._timed("pw_wgrad", 2.0 * kw["M"] * kw["N"] * kw["B"] * kw["T"], 4.0 * rows * kw["B"] * kw["T"], self._inner.pw_wgrad, kw)
+
+    def reset(self):
+        self.records = {"pw_gemm": [], "pw_wgrad": []}
 
     def summary(self, key):
-        ms = sum(a.elapsed_time(b) for a, b, _ in self.records[key])
-        fl = sum(f for _, _, f in self.records[key])
-        return len(self.records[key]), ms, fl
+        ms = sum(r[0].elapsed_time(r[1]) for r in self.records[key])
+        return len(self.records[key]), ms, sum(r[2] for r in self.records[key]), sum(r[3] for r in self.records[key])
 
 
 # ---- workload constants; restated here so that the timed path imports nothing from oracle/ -------
@@ -106,60 +110,97 @@ def bytes_per_frame(cfg):
     return 4 * (R * X * (2 * Bn + 4 * H + 2 * Sc) + (2 * N + Bn + 2 * ns * N + ns * S))
 
 
-def pmc_traffic(variant_tally):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate FETCH_SIZE and
-    WRITE_SIZE runs, gfx950 x2 correction on FETCH_SIZE; tools/pmc_passes.sh + tools/pmc_traffic.py).  PMC counters cannot
-    be read from inside the timed process, so this is the value measured on the profiled run of this same command."""
+def pmc_traffic(group):
+    """HBM bytes per launch of a kernel group ("gemm" / "wgrad") from the committed rocprofv3 PMC passes of THIS build's step
+    (profiles/hbm_traffic.json, written by tools/pmc_passes.sh + tools/pmc_traffic.py: separate --pmc FETCH_SIZE and --pmc
+    WRITE_SIZE runs, FETCH_SIZE x2 on gfx950 as MI355X_MICROARCH.md prescribes), launch-weighted over all launches of the group
+    in a step.  PMC counters cannot be read from inside the timed process: the value is the one measured on the profiled run of
+    this same command and is labelled so."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
-        pmc = {k: v["bytes_per_launch"] for k, v in t["gemm_variants"].items() if v["bytes_per_launch"] > 1e6}   # rocprofv3 reports ~0 for one instantiation: left out on both sides
-        n = tr = al = 0.0
-        for key, (cnt, abytes) in variant_tally.items():      # launch-weighted over the template variants both sides saw
-            if key in pmc:
-                n += cnt
-                tr += cnt * pmc[key]
-                al += abytes
-        if n == 0:
-            return {"traffic": None}
-        return {"traffic": tr / n, "traffic_unit": "bytes/launch", "algorithmic_bytes_per_launch": al / n,
-                "traffic_over_algorithmic": tr / al, "traffic_source": t["source"],
-                "traffic_variants_covered": "{:.0f} of {:.0f} launches".format(n, sum(c for c, _ in variant_tally.values()))}
+        g = t["groups"][group]
+        return {"traffic": g["bytes_per_launch"], "traffic_unit": "bytes/launch", "traffic_launches_per_step": g["launches_per_step"],
+                "traffic_launches_per_step_without_counters": g.get("launches_per_step_without_counters", 0.0),
+                "traffic_live": False, "traffic_source": t["source"]}
     except (OSError, KeyError, ValueError):
         return {"traffic": None}
 
 
-def cpu_baseline(sample_steps=2):
-    """Reference-equivalent CPU path (oracle/fast_port.py) on the host cores, bounded sample: B=2 utterances/step."""
+def roof_of(arith, flop, nbytes):
+    """Physical roof of a launch mix with `flop` algorithmic fp32 FLOP over `nbytes` algorithmic HBM bytes in arithmetic `arith`:
+    min(matrix-pipe peak / MFMAs per product, HBM peak x FLOP per byte), as (bound, roof in TFLOP/s-equivalent, both terms)."""
+    per, pipe = MFMA_PER_PRODUCT[arith]
+    mfma_roof = pipe / per
+    hbm_roof = HBM_PEAK_TBS * flop / nbytes
+    return ("hbm" if hbm_roof <= mfma_roof else "mfma"), min(mfma_roof, hbm_roof), mfma_roof, hbm_roof
+
+
+def kernel_roofline(timed, key, arith, steps, elapsed_instr, names):
+    n, ms, fl, by = timed.summary(key)
+    if n == 0 or ms <= 0:
+        return None
+    bound, roof_tf, mfma_roof, hbm_roof = roof_of(arith, fl, by)
+    tf = fl / (ms * 1e-3) / 1e12
+    gbs = by / (ms * 1e-3) / 1e9
+    out = {"kernel": names, "arith": arith, "bound": bound,
+           "achieved": gbs if bound == "hbm" else tf, "peak": HBM_PEAK_TBS * 1e3 if bound == "hbm" else mfma_roof,
+           "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": tf / roof_tf,
+           "roofs_tflops_equiv": {"matrix_pipe": mfma_roof, "hbm": hbm_roof, "what": "matrix pipe = dense MFMA peak of the instruction "
+                                  "the arithmetic issues / MFMAs per fp32 product; hbm = 8 TB/s x algorithmic FLOP per algorithmic byte"},
+           "achieved_tflops_equiv": tf, "achieved_GBps_algorithmic": gbs,
+           "launches_per_step": n / steps, "avg_launch_ms": ms / n, "flop_per_launch_avg": fl / n,
+           "algorithmic_bytes_per_launch": by / n, "share_of_step": ms / (1e3 * elapsed_instr),
+           "measured": "HIP events around every launch, separate pass of the same {} steps with the weight gradients on the main "
+                       "stream, i.e. no kernel overlap ({:.2f} ms/step with the events in)".format(steps, 1e3 * elapsed_instr / steps)}
+    return out
+
+
+def cpu_baseline(timed_steps=5):
+    """Reference-equivalent CPU path (oracle/fast_port.py) on the host cores, bounded sample: `timed_steps` fwd+PIT+bwd steps
+    of B=2 paper-best utterances (median), plus one step at the benchmark's own B=16 when the host has the memory."""
     from oracle import fast_port as FP       # the ONLY oracle import of this file: the cpu_baseline leg
     from models.conv_tasnet import ConvTasNet
     torch.manual_seed(111)
     model = ConvTasNet(**PAPER)
     p = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    B = 2
     g = torch.Generator().manual_seed(111)
-    sources = 0.1 * torch.randn(B, 2, T_SAMPLES, generator=g)
-    mixture = sources.sum(1, keepdim=True)
+    F = num_frames(T_SAMPLES, 16, 8)
+
+    def run(B, cores, n):
+        sources = 0.1 * torch.randn(B, 2, T_SAMPLES, generator=g)
+        mixture = sources.sum(1, keepdim=True)
+        torch.set_num_threads(cores)
+        FP.train_step(p, PAPER, mixture, sources, dtype=torch.float32)      # oneDNN primitive caches / allocator warm-up
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            FP.train_step(p, PAPER, mixture, sources, dtype=torch.float32)
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2]
+
     all_cores = torch.get_num_threads()
     best = None
     for cores in sorted({all_cores, min(all_cores, 32)}, reverse=True):   # oneDNN often peaks below the full core count
-        torch.set_num_threads(cores)
-        for _ in range(2):                  # oneDNN primitive caches / allocator warm-up
-            FP.train_step(p, PAPER, mixture, sources, dtype=torch.float32)
-        t0 = time.perf_counter()
-        for _ in range(sample_steps):
-            FP.train_step(p, PAPER, mixture, sources, dtype=torch.float32)
-        dt_c = (time.perf_counter() - t0) / sample_steps
+        dt_c = run(2, cores, 2)
         if best is None or dt_c < best[0]:
             best = (dt_c, cores)
+    cores = best[1]
+    dt = run(2, cores, timed_steps)
+    out = {"value": 2 * F / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": "median of {} timed fwd+PIT+bwd steps (after warm-up) of B=2 paper-best utterances, fp32, torch CPU (oracle/fast_port.py: "
+                     "same ATen conv/GroupNorm kernels as the reference modules; equality with the live reference is tested in "
+                     "tests/test_oracle_vs_reference_cpu.py), {:.2f} s/step".format(timed_steps, dt)}
+    try:
+        free_gb = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 2 ** 30
+    except (ValueError, OSError):
+        free_gb = 0.0
+    if free_gb > 48:                      # one B=16 step keeps ~14 GB of activations for autograd
+        dt16 = run(16, cores, 1)
+        out["batch16"] = {"value": 16 * F / dt16, "unit": "frames/s", "s_per_step": dt16, "sample": "one timed step (after one warm-up) at the benchmark's B=16"}
     torch.set_num_threads(all_cores)
-    dt, cores = best
-    frames = B * num_frames(T_SAMPLES, 16, 8)
-    return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "{} timed fwd+PIT+bwd steps (after 2 warm-up) of B={} paper-best utterances, fp32, torch CPU "
-                      "(oracle/fast_port.py: same ATen conv/GroupNorm kernels as the reference modules), {:.2f} s/step".format(
-                          sample_steps, B, dt)}
+    return out
 
 
 def main():
@@ -176,12 +217,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend_name = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # nccl = RCCL on ROCm (one rank per GPU).  SEPK_BENCH_BACKEND=gloo + SEPK_BENCH_ONE_GPU=1 exist only to exercise the
         # multi-rank code path on a single-GPU box (all ranks on device 0, all-reduce through the host).
-        dist.init_process_group(os.environ.get("SEPK_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+        backend_name = os.environ.get("SEPK_BENCH_BACKEND", "nccl")
+        dist.init_process_group(backend_name, rank=rank, world_size=world)
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus {} but WORLD_SIZE {}".format(args.gpus, world), file=sys.stderr)
     if os.environ.get("SEPK_BENCH_ONE_GPU") == "1":
@@ -212,53 +255,69 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        loss = step(mixture, sources)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step(mixture, sources)
-    sync()
-    elapsed = time.perf_counter() - t0
-    # Second pass of the SAME K steps with every MFMA-kernel launch bracketed by HIP events (roofline.achieved).  Kept out
-    # of the headline region: the ~300 event pairs per step cost 1.05 ms/step (3.5 %) of dispatch bubbles (measured A/B).
-    elapsed_instr = None
-    if not args.no_kernel_timing:
-        # kernel-alone durations: the weight gradients go back onto the main stream for this pass (on their side stream
-        # they overlap the input-gradient chain, and an event pair around a launch would time the overlap, not the kernel)
+    def timed_steps(n):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = step(mixture, sources)
+        sync()
+        return time.perf_counter() - t0, out
+
+    def instrumented_pass(n):
+        """The same n steps with every MFMA-kernel launch bracketed by HIP events.  Kept out of the headline region: the ~300
+        event pairs per step cost ~1 ms/step of dispatch bubbles (measured A/B).  The weight gradients go back onto the main
+        stream for this pass: on their side stream they overlap the input-gradient chain, and an event pair around a launch
+        would time the overlap, not the kernel."""
         side_prev = os.environ.get("SEPK_SIDE_STREAM")
         os.environ["SEPK_SIDE_STREAM"] = "0"
         step(mixture, sources)
-        sync()
+        timed.reset()
         timed.enabled = True
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step(mixture, sources)
-        sync()
-        elapsed_instr = time.perf_counter() - t1
+        el, _ = timed_steps(n)
         timed.enabled = False
         if side_prev is None:
             del os.environ["SEPK_SIDE_STREAM"]
         else:
             os.environ["SEPK_SIDE_STREAM"] = side_prev
-    # Third pass (N = 1 only): the same K steps with sep_pw_gemm on the fp32 MFMA instruction instead of the default exact
-    # bf16 three-way split, reported beside the headline so that both arithmetics are on record from the same process.
+        return el
+
+    for _ in range(args.warmup):
+        loss = step(mixture, sources)
+    elapsed, loss = timed_steps(args.steps)              # THE timed region: K steps, nothing else in it
+    my_elapsed = elapsed
+
     arith_name = sepkernels.gemm_arith_name()
-    elapsed_f32 = None
+    roof = roof_w = None
+    if not args.no_kernel_timing:
+        el_i = instrumented_pass(args.steps)
+        roof = kernel_roofline(timed, "pw_gemm", arith_name, args.steps, el_i,
+                               "sep_pw_gemm: pw_gemm_pc_kernel (K >= 512 or M >= 1024) / pw_gemm_coop_kernel")
+        # the weight gradient keeps the exact three-way bf16 split in every non-f32 arithmetic
+        roof_w = kernel_roofline(timed, "pw_wgrad", "f32" if arith_name == "f32" else "bf16x6", args.steps, el_i,
+                                 "sep_pw_wgrad: pw_wgrad_split_kernel" if arith_name != "f32" else "sep_pw_wgrad: pw_wgrad_direct_kernel")
+    # N = 1 only: the same K steps with sep_pw_gemm / sep_pw_wgrad on the fp32 MFMA instruction (v_mfma_f32_32x32x2_f32), i.e. the
+    # reference's own arithmetic, reported beside the headline with its own roofline (peak 157.3 TFLOP/s)
+    f32_pass = None
     if world == 1 and arith_name != "f32" and not args.no_f32_pass:
         sepkernels.set_gemm_arith("f32")
         step(mixture, sources)
-        sync()
-        t2 = time.perf_counter()
-        for _ in range(args.steps):
-            step(mixture, sources)
-        sync()
-        elapsed_f32 = time.perf_counter() - t2
+        el_f32, _ = timed_steps(args.steps)
+        f32_pass = {"value": world * args.batch * num_frames(T_SAMPLES, PAPER["kernel_size"], PAPER["stride"]) * args.steps / el_f32,
+                    "unit": "frames/s", "ms_per_step": 1e3 * el_f32 / args.steps, "dtype": "f32",
+                    "what": "same process, same K steps, SEP_ARITH_F32 (v_mfma_f32_32x32x2_f32) for every sep_pw_gemm / sep_pw_wgrad"}
+        if not args.no_kernel_timing:
+            el_fi = instrumented_pass(args.steps)
+            f32_pass["roofline"] = kernel_roofline(timed, "pw_gemm", "f32", args.steps, el_fi, "sep_pw_gemm: pw_gemm_direct_kernel<..., AR = 0>")
         sepkernels.set_gemm_arith(arith_name)
+
+    rank_ms = [1e3 * my_elapsed / args.steps]
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
+        allt = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(allt, torch.tensor([my_elapsed], device=dev, dtype=torch.float64))
+        rank_ms = [1e3 * t.item() / args.steps for t in allt]
 
     F = num_frames(T_SAMPLES, PAPER["kernel_size"], PAPER["stride"])
     frames_per_step = world * args.batch * F
@@ -266,10 +325,14 @@ def main():
     fl_frame, by_frame = 3 * flops_per_frame(PAPER), 3 * bytes_per_frame(PAPER)
 
     if rank == 0:
+        per, pipe = MFMA_PER_PRODUCT[arith_name]
         out = {
             "metric": "separated audio frames/sec (fwd+bwd), Conv-TasNet 2-spk 4s@8kHz", "value": value, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"f16x3": "f32 (f16x3 split emulation: fp32 operands and accumulators, products from two fp16 parts per operand on the fp16 MFMA)",
+                      "bf16x6": "f32 (bf16x6 split emulation: exact three-way bf16 split on the bf16 MFMA)", "f32": "f32"}[arith_name],
+            "data": "synthetic",
             "config": {"workload": "Conv-TasNet paper-best (N=512,L=16,B=128,H=512,Sc=128,P=3,X=8,R=3) 2-spk, 4 s @ 8 kHz "
                                    "synthetic mixtures, {} utterances/GPU, fwd + PIT(NegSI-SDR) + bwd + clip(5) + Adam".format(args.batch),
                        "global_batch": world * args.batch, "frames_per_utterance": F, "parallelism": "dp{}".format(world),
@@ -277,36 +340,29 @@ def main():
                        "gemm_arith": arith_name + {
                            "bf16x6": " (fp32 operands split exactly into 3 bf16 parts, 6 of 9 part products on the bf16 MFMA, fp32 "
                                      "accumulation; error vs fp64 at the fp32-MFMA path's level)",
-                           "f16x3": " (1x1-conv GEMMs: fp32 operands scaled by exact powers of two -- one for the weights, one per "
+                           "f16x3": " (1x1-conv GEMMs: fp32 operands scaled by exact powers of two -- one per weight row, one per "
                                     "frame column -- and split into 2 fp16 parts, 3 of 4 part products on the fp16 MFMA, fp32 "
                                     "accumulation; weight gradients: exact 3-part bf16 split; error vs fp64 at the fp32-MFMA path's level)",
                            "f32": " (v_mfma_f32_32x32x2_f32)"}[arith_name]},
-            "step_roofline": {"mfma_frac": value / world * fl_frame / (FP32_MFMA_PEAK_TFLOPS * 1e12),
-                              "hbm_frac": value / world * by_frame / (HBM_PEAK_TBS * 1e12),
-                              "algorithmic_flop_per_frame": fl_frame, "algorithmic_bytes_per_frame": by_frame},
+            "step_roofline": {"hbm_frac": value / world * by_frame / (HBM_PEAK_TBS * 1e12),
+                              "matrix_pipe_frac": value / world * fl_frame / (pipe / per * 1e12),
+                              "matrix_pipe_peak_tflops_equiv": pipe / per,
+                              "algorithmic_flop_per_frame": fl_frame, "algorithmic_bytes_per_frame": by_frame,
+                              "what": "whole step against both roofs: algorithmic bytes (SURVEY.md 8d) x frames/s / 8 TB/s, and algorithmic fp32 "
+                                      "FLOP x frames/s / (dense MFMA peak of the issued instruction / MFMAs per fp32 product); the binding one is HBM"},
+            "ranks": {"backend": backend_name, "rccl_ranks": world if backend_name == "nccl" else 0, "ms_per_step_per_rank": rank_ms,
+                      "ddp_buckets": getattr(step, "last_buckets", None)},
         }
-        if elapsed_f32 is not None:
-            out["fp32_mfma_pass"] = {"value": frames_per_step * args.steps / elapsed_f32, "unit": "frames/s",
-                                     "ms_per_step": 1e3 * elapsed_f32 / args.steps,
-                                     "what": "same process, same K steps, SEP_ARITH_F32 for every sep_pw_gemm / sep_pw_wgrad"}
-        if not args.no_kernel_timing:
-            n, ms, fl = timed.summary("pw_gemm")
-            nw, msw, flw = timed.summary("pw_wgrad")
-            ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            out["roofline"] = {"bound": "mfma", "kernel": "pw_gemm_direct_kernel", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                               "launches_per_step": n / args.steps, "avg_launch_ms": ms / max(n, 1),
-                               "flop_per_launch_avg": fl / max(n, 1), "share_of_step": ms / (1e3 * elapsed_instr),
-                               "measured": "HIP events around every launch, second pass of the same {} steps with the weight "
-                                           "gradients on the main stream, i.e. no kernel overlap ({:.2f} ms/step with the events "
-                                           "in)".format(args.steps, 1e3 * elapsed_instr / args.steps),
-                               "arith": arith_name,
-                               "peak_is": "dense fp32 MFMA (v_mfma_f32_32x32x2_f32); achieved = algorithmic fp32 flop / time"}
-            out["roofline"].update(pmc_traffic(timed.variants))
-            achw = flw / (msw * 1e-3) / 1e12 if msw > 0 else 0.0
-            out["roofline_wgrad"] = {"bound": "mfma", "kernel": "pw_wgrad_split_kernel" if arith_name != "f32" else "pw_wgrad_direct_kernel", "achieved": achw, "peak": FP32_MFMA_PEAK_TFLOPS,
-                                     "unit": "TFLOP/s", "frac": achw / FP32_MFMA_PEAK_TFLOPS, "launches_per_step": nw / args.steps,
-                                     "avg_launch_ms": msw / max(nw, 1), "share_of_step": msw / (1e3 * elapsed_instr)}
+        if f32_pass is not None:
+            out["fp32_mfma_pass"] = f32_pass
+        if roof is not None:
+            roof.update(pmc_traffic("gemm"))
+            if roof.get("traffic"):
+                roof["traffic_over_algorithmic"] = roof["traffic"] / roof["algorithmic_bytes_per_launch"]
+            out["roofline"] = roof
+        if roof_w is not None:
+            roof_w.update(pmc_traffic("wgrad"))
+            out["roofline_wgrad"] = roof_w
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

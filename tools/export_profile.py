@@ -21,6 +21,12 @@ with open(out + "_kernel_stats.md", "w") as f:
         short = name.replace("(anonymous namespace)::", "").split("(")[0][:70]
         f.write("| `{}` | {:.1f} | {:.1f} | {:.3f} | {:.1f} |\n".format(short, calls / steps, avg, tot / 1e3 / steps, pct))
     f.write("\nGPU kernel time per step: {:.2f} ms ({} steps in the capture)\n".format(tot_ms, int(steps)))
+    for label, pref in (("sep_pw_gemm group (pw_gemm_pc_kernel + pw_gemm_coop_kernel + pw_gemm_direct_kernel + pw_gemm_kernel)", "pw_gemm"), ("sep_pw_wgrad group (pw_wgrad_*)", "pw_wgrad")):
+        sel = [r for r in rows if pref in r[0].replace("(anonymous namespace)::", "")]
+        calls = sum(r[1] for r in sel)
+        if calls:
+            f.write("{}: {:.1f} launches/step, average duration {:.1f} us, {:.3f} ms/step  (what bench.py's roofline.avg_launch_ms must agree with)\n".format(
+                label, calls / steps, sum(r[2] for r in sel) / calls, sum(r[2] for r in sel) / 1e3 / steps))
 try:
     q = ("select kernel_name, grid_size_x, counter_name, count(*), avg(value) from counters_collection "
          "group by kernel_name, grid_size_x, counter_name order by kernel_name, grid_size_x, counter_name")

@@ -27,11 +27,19 @@ def parse(fn):
 F = parse(os.path.join(src, "pmc_FETCH_SIZE.txt"))
 W = parse(os.path.join(src, "pmc_WRITE_SIZE.txt"))
 rows, variants = [], {}
+groups = {"gemm": {"launches": 0, "bytes": 0.0, "uncounted": 0}, "wgrad": {"launches": 0, "bytes": 0.0, "uncounted": 0}}
+steps = float(sys.argv[3]) if len(sys.argv) > 3 else 3.0      # steps in the capture (tools/pmc_passes.sh: 2 + 1 warm-up)
 for k in sorted(F):
     name, grid, n = k
     fetch = 2.0 * F[k].get("FETCH_SIZE", 0.0) * 1024.0
     write = W.get(k, {}).get("WRITE_SIZE", 0.0) * 1024.0
     rows.append((name, grid, n, fetch, write))
+    grp = "gemm" if re.match(r"pw_gemm_(pc|coop|direct)_kernel|pw_gemm_kernel", name) else "wgrad" if re.match(r"pw_wgrad", name) else None
+    if grp and fetch + write <= 0.0:
+        groups[grp]["uncounted"] += n        # rocprofv3 returns zeros for every counter of one kernel per capture (it runs normally in the trace): left out
+    elif grp:
+        groups[grp]["launches"] += n
+        groups[grp]["bytes"] += n * (fetch + write)
     m = re.match(r"pw_gemm_direct_kernel<(true|false), (\d), (true|false)(?:, -?\d+){0,2}>", name)
     if m:
         key = "T{}P{}S{}".format(int(m.group(1) == "true"), m.group(2), int(m.group(3) == "true"))
@@ -45,7 +53,10 @@ with open(prefix + "_hbm_traffic.md", "w") as f:
     tot = sum(n * (fe + wr) for _, _, n, fe, wr in rows)
     f.write("\nAll kernels of the capture: {:.2f} GB.\n".format(tot / 1e9))
 out = {"source": os.path.basename(prefix) + "_hbm_traffic.md (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, FETCH_SIZE x2 on gfx950)",
+       "groups": {g: {"launches_per_step": v["launches"] / steps, "bytes_per_launch": v["bytes"] / max(v["launches"], 1),
+                      "launches_per_step_without_counters": v["uncounted"] / steps} for g, v in groups.items()},
+       "step_total_bytes": sum(n * (fe + wr) for _, _, n, fe, wr in rows) / steps,
        "gemm_variants": {k: {"launches": v["launches"], "bytes_per_launch": v["bytes"] / max(v["launches"], 1)} for k, v in variants.items()}}
 with open(os.path.join(os.path.dirname(prefix), "hbm_traffic.json"), "w") as f:
     json.dump(out, f, indent=1, sort_keys=True)
-print(json.dumps(out["gemm_variants"], indent=1))
+print(json.dumps(out["groups"], indent=1), "step total GB:", out["step_total_bytes"] / 1e9)
