@@ -13,6 +13,7 @@ import os
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from utils.filterbank import choose_filterbank
 from utils.tasnet import choose_layer_norm
@@ -162,6 +163,14 @@ class ConvTasNet(nn.Module):
         self._flat = None
         self._names = None
         self._grad_sink = None      # optional flat buffer the backward pass writes into (sepkernels.train.FusedTrainStep)
+        # Which way forward() runs is decided HERE, not at the first call: the fused HIP kernel sequence for the configuration
+        # family it implements, else the module-by-module composition (unsupported option combinations
+        # fall back to the PyTorch composition) -- `fused_reason` says why.
+        try:
+            _net.check_supported(self.get_config())
+            self.fused, self.fused_reason = True, None
+        except NotImplementedError as e:
+            self.fused, self.fused_reason = False, str(e)
         self._flatten_parameters()
 
     # ------------------------------------------------------------------ parameter storage
@@ -229,16 +238,20 @@ class ConvTasNet(nn.Module):
         else:
             raise ValueError("Not support {} dimension input".format(n_dims))
         cfg = self.get_config()
-        _net.check_supported(cfg)
         if mixture.size(1) != self.in_channels:
             raise ValueError("input has {} channels, the model was built with in_channels={}".format(mixture.size(1), self.in_channels))
+        if not self.fused:
+            est, latent = self._run_composed(mixture.contiguous(), want_latent)
+            if n_dims == 3:
+                est = est.view(batch_size, self.n_sources, T)
+            return est, latent
         if not mixture.is_cuda and _net.backend().name == "hip":
             raise RuntimeError("ConvTasNet (MI355X build) runs on the GPU only: move the model and the input to 'cuda'. "
                                "There is no CPU fallback.")
         mixture = mixture.contiguous()
         if mixture.dtype != torch.float32 and _net.backend().name == "hip":
             mixture = mixture.float()
-        named = list(self.named_parameters())
+        named = self._named_tensors()
         names = tuple(n for n, _ in named)
         params = tuple(p for _, p in named)
         sink = getattr(self, "_grad_sink", None)
@@ -253,6 +266,42 @@ class ConvTasNet(nn.Module):
         if n_dims == 3:
             est = est.view(batch_size, self.n_sources, T)
         return est, latent
+
+    def _named_tensors(self):
+        """(name, tensor) of every parameter, also inside an nn.DataParallel replica: torch's replicate() empties `_parameters`
+        of the replica modules and hands them the broadcast copies as plain attributes / `_former_parameters` (they carry the
+        autograd edge back to the master parameters), so the walk goes through those.  The copies are separate tensors, not
+        views of one flat buffer: net.py then runs the two heads of a layer as two products."""
+        named = list(self.named_parameters())
+        if named:
+            return named
+        out = []
+        for mname, mod in self.named_modules():
+            for k, v in getattr(mod, "_former_parameters", {}).items():
+                if v is not None:
+                    out.append(((mname + "." if mname else "") + k, v))
+        if not out:
+            raise RuntimeError("ConvTasNet has no parameters to run with (a module replica without `_former_parameters`?); for "
+                               "multi-GPU training use one process per GPU with sepkernels.train.FusedTrainStep")
+        return out
+
+    def _run_composed(self, mixture, want_latent):
+        """The reference's own sequence (conv_tasnet.py:121-171) on this repository's modules, for configurations outside
+        the fused family: pad -> encoder -> separator -> mask * w -> decoder (transposed convolution = overlap-add) -> crop.
+        Torch convolutions on the device of the input; gLN through sep_gln_*, cLN as its prefix-sum composition."""
+        B, _, T = mixture.shape
+        L, S, n_src, N = self.kernel_size, self.stride, self.n_sources, self.n_basis
+        padding = (S - (T - L) % S) % S
+        left = padding // 2
+        x = F.pad(mixture, (left, padding - left))
+        w = F.conv1d(x, self.encoder.conv1d.weight, stride=S)
+        if self.encoder.nonlinear:
+            w = torch.relu(w)
+        mask = self.separator(w)                                   # (B, n_src, N, F)
+        latent = w.unsqueeze(1) * mask
+        y = F.conv_transpose1d(latent.reshape(B * n_src, N, -1), self.decoder.conv_transpose1d.weight, stride=S)
+        y = y.view(B, n_src, self.in_channels, -1)[..., left:left + T]
+        return y, (latent if want_latent else None)
 
     # ------------------------------------------------------------------ config / checkpoints
     def get_config(self):
@@ -345,8 +394,8 @@ class ConvTasNet(nn.Module):
 
 
 class Separator(nn.Module):
-    """gLN -> 1x1 bottleneck -> TCN -> PReLU -> 1x1 mask conv -> sigmoid (reference conv_tasnet.py:322-378):
-    parameter container; executed by the fused sequence of ConvTasNet."""
+    """norm -> 1x1 bottleneck -> TCN -> PReLU -> 1x1 mask conv -> sigmoid | softmax (reference conv_tasnet.py:322-378).
+    Inside a fused ConvTasNet this is a parameter container; `forward` is the stand-alone / fallback composition."""
 
     def __init__(self, num_features, bottleneck_channels=128, hidden_channels=256, skip_channels=128, kernel_size=3,
                  num_blocks=3, num_layers=8, dilated=True, separable=True, causal=True, nonlinear="prelu", norm=True,
@@ -366,4 +415,7 @@ class Separator(nn.Module):
         self.mask_nonlinear = nn.Sigmoid() if mask_nonlinear == "sigmoid" else nn.Softmax(dim=1)
 
     def forward(self, input):
-        raise NotImplementedError("Separator is executed as part of the fused ConvTasNet kernel sequence (sepkernels/net.py)")
+        """input (batch_size, num_features, T') -> mask (batch_size, n_sources, num_features, T')"""
+        x = self.tdcn(self.bottleneck_conv1d(self.norm1d(input)))
+        x = self.mask_nonlinear(self.mask_conv1d(self.prelu(x)))
+        return x.view(x.size(0), self.n_sources, self.num_features, x.size(-1))

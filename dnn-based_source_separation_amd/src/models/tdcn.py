@@ -2,18 +2,20 @@
 Time-dilated convolutional network (TCN) of Conv-TasNet: module tree, parameter names, shapes and default
 initialisation of reference src/models/tdcn.py:13-196, so that reference checkpoints load unchanged.
 
-The modules are parameter containers: on MI355X the whole stack runs as the fused kernel sequence of
-sepkernels/net.py (three kernels per layer forward, with gLN / PReLU / residual / skip folded into the MFMA
-GEMMs and the LDS-staged depthwise kernel), driven by models.conv_tasnet.ConvTasNet.  Calling a TCN sub-module
-on its own is not part of the separation path and raises.
+On MI355X the whole stack of the north-star configuration family (non-causal, separable, dilated, gLN, PReLU, P = 3) runs
+as the fused kernel sequence of sepkernels/net.py (three kernels per layer forward, with gLN / PReLU / residual / skip
+folded into the MFMA GEMMs and the LDS-staged depthwise kernel), driven by models.conv_tasnet.ConvTasNet, and these modules
+are then only its parameter containers.  Their own `forward` methods are the layer-by-layer composition (torch convolutions
+on the device of the input, this repository's norm modules): what a stand-alone call runs, and what ConvTasNet falls back to
+for the configurations the fused sequence does not cover (causal / cLN, non-separable, non-dilated, no norm, P != 3) --
+SURVEY.md section 8b.
 """
 import torch.nn as nn
+import torch.nn.functional as F
 
 from utils.tasnet import choose_layer_norm
 
 EPS = 1e-12
-
-_MSG = "{} is executed as part of the fused ConvTasNet kernel sequence (sepkernels/net.py); stand-alone forward is not implemented"
 
 
 def _activation(owner, nonlinear):
@@ -29,14 +31,16 @@ def _normalisation(owner, channels, causal, eps):
     owner.norm1d = choose_layer_norm("cLN" if causal else "gLN", channels, causal=causal, eps=eps)
 
 
-class _Container(nn.Module):
-    """Parameter container: the arithmetic lives in sepkernels/net.py."""
+def _act_norm(owner, x):
+    """nonlinear1d then norm1d, each only if the layer has it (reference tdcn.py:113-116, 182-186)."""
+    if owner.nonlinear:
+        x = owner.nonlinear1d(x)
+    if owner.norm:
+        x = owner.norm1d(x)
+    return x
 
-    def forward(self, input):
-        raise NotImplementedError(_MSG.format(type(self).__name__))
 
-
-class TimeDilatedConvNet(_Container):
+class TimeDilatedConvNet(nn.Module):
     def __init__(self, num_features, hidden_channels=256, skip_channels=256, kernel_size=3, num_blocks=3, num_layers=10,
                  dilated=True, separable=False, causal=True, nonlinear=None, norm=True, eps=EPS):
         super().__init__()
@@ -46,8 +50,16 @@ class TimeDilatedConvNet(_Container):
         # every block but the last feeds the next one, so only the last block's last layer lacks the output head
         self.net = nn.Sequential(*[TimeDilatedConvBlock1d(num_features, dual_head=(b + 1 < num_blocks), **shared) for b in range(num_blocks)])
 
+    def forward(self, input):
+        """input (batch_size, num_features, T) -> sum of every layer's skip output (batch_size, skip_channels, T)  (tdcn.py:29-41)"""
+        x, total = input, 0
+        for block in self.net:
+            x, skip = block(x)
+            total = total + skip
+        return total
 
-class TimeDilatedConvBlock1d(_Container):
+
+class TimeDilatedConvBlock1d(nn.Module):
     def __init__(self, num_features, hidden_channels=256, skip_channels=256, kernel_size=3, num_layers=10, dilated=True,
                  separable=False, causal=True, nonlinear=None, norm=True, dual_head=True, eps=EPS):
         super().__init__()
@@ -60,8 +72,16 @@ class TimeDilatedConvBlock1d(_Container):
             layers.append(ResidualBlock1d(num_features, dual_head=(dual_head or x + 1 < num_layers), **geometry, **shared))
         self.net = nn.Sequential(*layers)
 
+    def forward(self, input):
+        """-> (output of the last layer, or None if it has no output head ; sum of the layers' skip outputs)  (tdcn.py:65-75)"""
+        x, total = input, 0
+        for layer in self.net:
+            x, skip = layer(x)
+            total = total + skip
+        return x, total
 
-class ResidualBlock1d(_Container):
+
+class ResidualBlock1d(nn.Module):
     def __init__(self, num_features, hidden_channels=256, skip_channels=256, kernel_size=3, stride=2, dilation=1,
                  separable=False, causal=True, nonlinear=None, norm=True, dual_head=True, eps=EPS):
         super().__init__()
@@ -82,8 +102,23 @@ class ResidualBlock1d(_Container):
             self.output_conv1d = nn.Conv1d(hidden_channels, num_features, **taps)
         self.skip_conv1d = nn.Conv1d(hidden_channels, skip_channels, **taps)
 
+    def forward(self, input):
+        """input (batch_size, num_features, T) -> (input + output head, or None ; skip head), both with T frames  (tdcn.py:107-147).
+        The zero padding goes in AFTER the norm: all of it on the left when causal, split (left gets the smaller half) otherwise."""
+        T = input.size(-1)
+        x = _act_norm(self, self.bottleneck_conv1d(input))
+        pad = (T - 1) * self.stride - T + (self.kernel_size - 1) * self.dilation + 1
+        left = pad if self.causal else pad // 2
+        x = F.pad(x, (left, pad - left))
+        if self.separable:
+            out, skip = self.separable_conv1d(x)
+        else:
+            out = self.output_conv1d(x) if self.dual_head else None
+            skip = self.skip_conv1d(x)
+        return (None if out is None else out + input), skip
 
-class DepthwiseSeparableConv1d(_Container):
+
+class DepthwiseSeparableConv1d(nn.Module):
     def __init__(self, in_channels, out_channels=256, skip_channels=256, kernel_size=3, stride=2, dilation=1, causal=True,
                  nonlinear=None, norm=True, dual_head=True, eps=EPS):
         super().__init__()
@@ -96,3 +131,8 @@ class DepthwiseSeparableConv1d(_Container):
         if dual_head:
             self.output_pointwise_conv1d = nn.Conv1d(in_channels, out_channels, kernel_size=1, stride=1)
         self.skip_pointwise_conv1d = nn.Conv1d(in_channels, skip_channels, kernel_size=1, stride=1)
+
+    def forward(self, input):
+        """already padded input (batch_size, C, T_padded) -> (output head or None, skip head)  (tdcn.py:177-196)"""
+        x = _act_norm(self, self.depthwise_conv1d(input))
+        return (self.output_pointwise_conv1d(x) if self.dual_head else None), self.skip_pointwise_conv1d(x)

@@ -4,8 +4,9 @@ Global layer normalisation on MI355X.  API of reference src/modules/norm.py:11-3
 
 Inside ConvTasNet the norm never runs as its own kernel (it is folded into the neighbouring GEMM / depthwise
 kernels, see sepkernels/net.py); this module is the stand-alone form for other callers.
-`CumulativeLayerNorm1d` (causal cLN, reference :42-101) is outside the hot path (causal=0 in every BASELINE
-config) and is declared only so that factories and checkpoints referring to it import cleanly.
+`CumulativeLayerNorm1d` (causal cLN, reference :42-101) is outside the hot path (causal=0 in every BASELINE config): it
+is a composition of torch operations (column sums, two prefix sums, one elementwise pass) that runs on whatever device its
+input lives on -- the SURVEY.md section 8b fallback for configurations the fused kernel sequence does not cover.
 """
 import torch
 import torch.nn as nn
@@ -95,8 +96,18 @@ class CumulativeLayerNorm1d(nn.Module):
         self.beta = nn.Parameter(torch.zeros(1, num_features, 1))
 
     def forward(self, input):
-        raise NotImplementedError("CumulativeLayerNorm1d (causal Conv-TasNet) is outside the MI355X hot path "
-                                  "(SURVEY.md section 8: causal=0 in every benchmark configuration)")
+        """input (batch_size, C, T) or (batch_size, C, S, chunk_size) -> same shape.  Frame t is normalised with the mean and
+        the (biased) variance of everything up to and including frame t: C * (t + 1) values."""
+        if input.dim() not in (3, 4):
+            raise ValueError("Only support 3D or 4D input, but given {}D".format(input.dim()))
+        shape = input.shape
+        x = input.reshape(shape[0], shape[1], -1)
+        C, T = x.shape[1], x.shape[2]
+        count = torch.arange(1, T + 1, device=x.device, dtype=x.dtype) * C                 # values seen after frame t
+        mean = x.sum(dim=1).cumsum(dim=1) / count                                           # (batch_size, T)
+        var = (x * x).sum(dim=1).cumsum(dim=1) / count - mean * mean
+        y = (x - mean.unsqueeze(1)) / (var.sqrt().unsqueeze(1) + self.eps) * self.gamma + self.beta
+        return y.reshape(shape)
 
     def __repr__(self):
         return "{}({}, eps={})".format(self.__class__.__name__, self.num_features, self.eps)

@@ -49,8 +49,26 @@ CONFIGS = {
                     sep_hidden_channels=128, sep_bottleneck_channels=64, sep_skip_channels=64, sep_kernel_size=3,
                     sep_num_blocks=1, sep_num_layers=2, dilated=True, separable=True, causal=False, sep_nonlinear="prelu",
                     sep_norm=True, mask_nonlinear="softmax", n_sources=2),
+    # --- configurations OUTSIDE the fused kernel family: the product runs them as the module-by-module composition
+    # the reference constructor's default: causal = True -> cLN everywhere, all padding on the left
+    "causal": dict(n_basis=64, kernel_size=16, stride=8, enc_basis="trainable", dec_basis="trainable", enc_nonlinear="relu",
+                   sep_hidden_channels=96, sep_bottleneck_channels=48, sep_skip_channels=40, sep_kernel_size=3,
+                   sep_num_blocks=2, sep_num_layers=3, dilated=True, separable=True, causal=True, sep_nonlinear="prelu",
+                   sep_norm=True, mask_nonlinear="sigmoid", n_sources=2),
+    # full (non-separable) 5-tap convolutions, channel counts off the multiples of 16
+    "plainconv": dict(n_basis=60, kernel_size=20, stride=10, enc_basis="trainable", dec_basis="trainable", enc_nonlinear=None,
+                      sep_hidden_channels=72, sep_bottleneck_channels=36, sep_skip_channels=28, sep_kernel_size=5,
+                      sep_num_blocks=2, sep_num_layers=2, dilated=True, separable=False, causal=False, sep_nonlinear="prelu",
+                      sep_norm=True, mask_nonlinear="sigmoid", n_sources=3),
+    # not dilated (stride-2 geometry of the padding formula), no norm, no activation inside the TCN, softmax mask
+    "nodil": dict(n_basis=64, kernel_size=16, stride=8, enc_basis="trainable", dec_basis="trainable", enc_nonlinear="relu",
+                  sep_hidden_channels=64, sep_bottleneck_channels=32, sep_skip_channels=32, sep_kernel_size=3,
+                  sep_num_blocks=1, sep_num_layers=3, dilated=False, separable=True, causal=False, sep_nonlinear=None,
+                  sep_norm=False, mask_nonlinear="softmax", n_sources=2),
 }
-SHAPES = {"tiny": (1, 4000), "mid": (2, 3203), "softmax": (2, 2500)}   # (batch, samples); 3203 / 2500 exercise the input padding branch
+SHAPES = {"tiny": (1, 4000), "mid": (2, 3203), "softmax": (2, 2500),   # (batch, samples); 3203 / 2500 exercise the input padding branch
+          "causal": (2, 2403), "plainconv": (2, 2000), "nodil": (1, 1607)}
+COMPOSED = ("causal", "plainconv", "nodil")
 
 
 def perturb(model, seed):

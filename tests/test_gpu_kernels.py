@@ -257,6 +257,47 @@ def test_gemm_packed_weights_model_shapes(M, K, T):
     assert err["packed"] <= max(3 * err["f32"], 6e-7), err
 
 
+@pytest.mark.parametrize("case", ["row_scales_1e12", "subnormal_activations", "late_jump_k1024", "zero_rows_and_columns"])
+def test_gemm_packed_adversarial_operands(case):
+    """SEP_ARITH_F16X3 (packed weights) where a shared scale would fail: weight rows 24 decades apart; activations in fp32's
+    subnormal range; a column whose magnitude jumps by 1e6 in the LAST chunk of a K = 1024 contraction (accumulator rescale path);
+    all-zero rows of A and columns of X.  Error relative to |A||X| per output, beside the fp32-MFMA kernel on the same operands."""
+    B, M, K, T = 1, 256, 1024 if case == "late_jump_k1024" else 512, 700
+    ldt = 768
+    X = padded(B, K, T, ldt)
+    A = rnd(M, K, scale=K ** -0.5)
+    if case == "row_scales_1e12":
+        A[::2] *= 1e12
+        A[1::2] *= 1e-12
+    elif case == "subnormal_activations":
+        X = X * 1e-39                                    # |x| ~ 1e-39 < 1.18e-38 = the smallest normal fp32
+    elif case == "late_jump_k1024":
+        X[:, K - 16:, ::3] *= 1e6
+    else:
+        A[5] = 0
+        A[77] = 0
+        X[:, :, 10:200:7] = 0
+    X[..., T:] = 0
+    ref = torch.einsum("mk,bkt->bmt", A.double(), X.double())
+    scale = torch.einsum("mk,bkt->bmt", A.double().abs(), X.double().abs())[..., :T]
+    floor = 1.4e-45 * A.double().abs().sum(1).view(1, M, 1)          # one fp32 ulp at the bottom of the subnormal range per term
+    err = {}
+    for name in ("f32", "packed"):
+        Y = torch.full((B, M, ldt), float("nan"), device="cuda")
+        Ag = A.cuda()
+        kw = dict(B=B, M=M, K=K, T=T, ldt=ldt, A=Ag, X=X.cuda(), Y=Y)
+        kw.update(arith=sepkernels.ARITH_F16X3, A_pk=HIP.pack_weights([(Ag, M, K, 0)])[0]) if name == "packed" else kw.update(arith=sepkernels.ARITH_F32)
+        HIP.pw_gemm(**kw)
+        torch.cuda.synchronize()
+        assert torch.isfinite(Y).all()
+        e = ((Y.cpu().double() - ref)[..., :T]).abs()
+        err[name] = (e / (scale + floor + 1e-300)).max().item()
+        if case == "zero_rows_and_columns":
+            assert (Y[:, 5, :T] == 0).all() and (Y[:, :, 10:200:7] == 0).all()
+    assert err["f32"] <= 1e-5, err
+    assert err["packed"] <= max(3 * err["f32"], 2e-6), err
+
+
 def test_pack_weights_reproduces_the_weights():
     """hi + lo of every packed group, times the row's inverse scale, is the weight to 2^-22 relative to the row maximum."""
     W = rnd(96, 64) * torch.exp(5 * rnd(96, 1))

@@ -1,0 +1,90 @@
+"""CPU: the drop-in boundary, exercised by the REFERENCE'S OWN training driver.  The unmodified
+/root/reference/egs/wsj0-mix/common/src/driver.py (TrainerBase: run_one_epoch_train with nn.utils.clip_grad_norm_ and a stock
+torch.optim.Adam, run_one_epoch_eval, save_model) is imported with this repository's src/ FIRST on the path and the
+reference's src/ BEHIND it (INTEGRATION.md route A: Python merges the flat namespace packages, so `utils.utils`,
+`transforms.stft`, ... come from the reference and models/ criterion/ modules/ from here), and drives this repository's
+ConvTasNet / PIT1d / NegSISDR classes; then ConvTasNet.build_model reloads the checkpoint it wrote.  Kernels: the CPU emulator of
+the C ABI (tests/emulator.py) -- this is a test of the Python boundary, not of the HIP kernels.  Skipped where the reference
+tree is absent (the GPU box).  mir_eval (an evaluation-only dependency of utils/bss.py) is stubbed, torchaudio is the wav shim."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "egs", "wsj0-mix", "common", "src")), reason="reference tree not present")
+
+SCRIPT = textwrap.dedent('''
+    import os, sys, types, argparse
+    sys.path[:0] = [{src!r}, {tests!r}, {root!r}]                 # this repository first ...
+    sys.path += [{ref_src!r}, {ref_common!r}]                     # ... the reference behind it (INTEGRATION.md route A)
+    import torch
+    torch.manual_seed(0)
+    from recipes.audio_io import install_torchaudio_shim
+    install_torchaudio_shim()
+    me = types.ModuleType("mir_eval"); sep = types.ModuleType("mir_eval.separation")
+    sep.bss_eval_sources = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("evaluation-only"))
+    me.separation = sep; sys.modules["mir_eval"] = me; sys.modules["mir_eval.separation"] = sep
+    import matplotlib; matplotlib.use("Agg")
+    import sepkernels
+    from emulator import EmuBackend
+    sepkernels._set_backend_for_tests(EmuBackend())
+
+    import driver                                                  # the reference's file, unmodified
+    assert driver.__file__.startswith({ref_common!r}), driver.__file__
+    import utils.utils, models.conv_tasnet, criterion.pit
+    assert utils.utils.__file__.startswith({ref_src!r}) and models.conv_tasnet.__file__.startswith({src!r}) and criterion.pit.__file__.startswith({src!r})
+    from models.conv_tasnet import ConvTasNet
+    from criterion.sdr import NegSISDR
+    from criterion.pit import PIT1d
+
+    model = ConvTasNet(64, kernel_size=16, stride=8, enc_basis="trainable", dec_basis="trainable", enc_nonlinear="relu", sep_hidden_channels=128,
+                       sep_bottleneck_channels=64, sep_skip_channels=64, sep_kernel_size=3, sep_num_blocks=1, sep_num_layers=2, dilated=True,
+                       separable=True, causal=False, sep_nonlinear="prelu", sep_norm=True, mask_nonlinear="sigmoid", n_sources=2)
+    src = [0.1 * torch.randn(2, 2, 1600) for _ in range(3)]
+    train = [(s.sum(1, keepdim=True), s) for s in src]
+
+    class Valid(list):
+        dataset = [0, 1]
+    v = [0.1 * torch.randn(1, 2, 2000) for _ in range(2)]
+    valid = Valid((s.sum(1, keepdim=True), s, ["utt{{}}".format(i)]) for i, s in enumerate(v))
+    out = {out!r}
+    args = argparse.Namespace(sample_rate=8000, n_sources=2, max_norm=5.0, model_dir=out + "/model", loss_dir=out + "/loss", sample_dir=out + "/sample",
+                              epochs=2, use_cuda=False, continue_from=None, overwrite=False)
+    trainer = driver.TrainerBase(model, {{"train": train, "valid": valid}}, PIT1d(NegSISDR(), n_sources=2), torch.optim.Adam(model.parameters(), lr=1e-3), args)
+    trainer.run()
+    print("LOSSES", float(trainer.train_loss[0]), float(trainer.train_loss[1]), float(trainer.valid_loss[1]))
+    for f in ("best.pth", "last.pth"):
+        assert os.path.exists(os.path.join(out, "model", f))
+    assert os.path.exists(os.path.join(out, "sample", "utt0", "epoch2-1.wav")) and os.path.exists(os.path.join(out, "loss", "loss.png"))
+    m2 = ConvTasNet.build_model(os.path.join(out, "model", "last.pth"), load_state_dict=True)
+    x = train[0][0]
+    model.eval(); m2.eval()
+    with torch.no_grad():
+        d = (model(x) - m2(x)).abs().max().item()
+    print("RELOAD", d)
+    # resume through the reference's --continue_from branch (stock Adam state_dict round trip)
+    args2 = argparse.Namespace(**dict(vars(args), epochs=3, continue_from=os.path.join(out, "model", "last.pth")))
+    m3 = ConvTasNet.build_model(args2.continue_from)
+    tr2 = driver.TrainerBase(m3, {{"train": train, "valid": valid}}, PIT1d(NegSISDR(), n_sources=2), torch.optim.Adam(m3.parameters(), lr=1e-3), args2)
+    assert tr2.start_epoch == 2
+    tr2.run()
+    print("RESUMED", float(tr2.train_loss[2]))
+''')
+
+
+def test_reference_trainer_drives_this_repositorys_classes(tmp_path):
+    code = SCRIPT.format(src=os.path.join(ROOT, "dnn-based_source_separation_amd", "src"), tests=os.path.join(ROOT, "tests"), root=ROOT,
+                         ref_src=os.path.join(REF, "src"), ref_common=os.path.join(REF, "egs", "wsj0-mix", "common", "src"), out=str(tmp_path))
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = {l.split()[0]: l.split()[1:] for l in r.stdout.splitlines() if l.split() and l.split()[0] in ("LOSSES", "RELOAD", "RESUMED")}
+    l0, l1, v1 = map(float, lines["LOSSES"])
+    assert l1 < l0, "training loss did not decrease under the reference's driver: {} -> {}".format(l0, l1)
+    assert float(lines["RELOAD"][0]) < 1e-6
+    assert float(lines["RESUMED"][0]) < l0
