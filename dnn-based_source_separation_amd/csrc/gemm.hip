@@ -638,7 +638,8 @@ __global__ __launch_bounds__(256, (AR >= 1 ? 3 : PRO == SEP_PRO_GLN_BWD ? 3 : PR
         if (more) read_b6(nstage, 1);
         __builtin_amdgcn_sched_barrier(0);
     };
-    int bexp[2] = {100, 100};            // per-lane scale exponent of this lane's column in column block ni (100 = not set yet)
+    int bexp[2] = {0, 0};                // per-lane scale exponent of this lane's column in column block ni
+    bool bset[2] = {false, false};       // ... chosen yet?  (a column stays unset while it has only seen zeros)
     int aexp = 0;                        // A * 2^aexp < 2^13
     if (AR == 2) aexp = 13 - __builtin_amdgcn_frexp_expf(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, d.a_amax[0]))));
     auto step3h = [&](const int kc, const int stage, const int nstage) {
@@ -673,7 +674,8 @@ __global__ __launch_bounds__(256, (AR >= 1 ? 3 : PRO == SEP_PRO_GLN_BWD ? 3 : PR
                 for (int kk = 0; kk < 4; ++kk) m = fmaxf(m, fabsf(fb[h][ni][kk]));
             m = fmaxf(m, __shfl_xor(m, 32, 64));                          // the other lane half holds the column's other 8 k
             const int e = __builtin_amdgcn_frexp_expf(m);                  // m = f * 2^e, f in [0.5, 1)
-            const bool grow = e + bexp[ni] > 14;
+            const bool grow = m > 0.f && (!bset[ni] || e + bexp[ni] > 14);      // first non-zero chunk, or the column outgrew its scale
+            bset[ni] = bset[ni] || m > 0.f;
             const int nexp = grow ? 9 - e : bexp[ni];
             if (__builtin_amdgcn_ballot_w64(grow) != 0) {                  // rare after the first chunks
                 const int delta = nexp - bexp[ni];

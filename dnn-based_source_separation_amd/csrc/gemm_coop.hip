@@ -188,7 +188,8 @@ void pw_gemm_coop_kernel(const sep_gemm_desc d) {
     const int s_lo = col_s * 16 + 4 * ((2 * (kq >> 1) + 1) ^ s_fsw) + 2 * (kq & 1);
     const bool s_live = t0 + col_s < d.T;
     const unsigned st_lane_off = 4u * (unsigned)(4 * kq * d.ldt + col_s);   // GLN_BWD store-back: this thread's byte offset in a chunk
-    int bexp = 100;                                                  // scale exponent of this thread's column (100 = not set yet)
+    int bexp = 0;                                                    // scale exponent of this thread's column ...
+    bool bset = false;                                               // ... chosen yet?  (stays unset while the column has only seen zeros)
 
     float raw[4], aux[4];
     float4 sc4 = make_float4(0.f, 0.f, 0.f, 0.f), sh4 = sc4;
@@ -234,7 +235,8 @@ void pw_gemm_coop_kernel(const sep_gemm_desc d) {
         float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
         m = quad_max(m);                                                 // the column's maximum over the 16 k of the chunk
         const int e = __builtin_amdgcn_frexp_expf(m);                    // m = f * 2^e, f in [0.5, 1)
-        if (e + bexp > 14) bexp = 9 - e;                                 // first chunk, or the column outgrew its scale
+        if (m > 0.f && (!bset || e + bexp > 14)) bexp = 9 - e;          // first non-zero chunk, or the column outgrew its scale
+        bset = bset || m > 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = __builtin_ldexpf(v[j], bexp);
         unsigned h01, l01, h23, l23;

@@ -168,9 +168,10 @@ __global__ __launch_bounds__(512, 2) void pw_gemm_pc_kernel(const sep_gemm_desc 
         const int s_fsw = (colb >> 2) & 3;                                       // 128 is a multiple of 16: same swizzle for both columns
         const int w_hi = colb * 16 + 4 * ((2 * kh) ^ s_fsw);
         const int w_lo = colb * 16 + 4 * ((2 * kh + 1) ^ s_fsw);
-        int bexp[WC];
+        int bexp[WC];                                                            // scale exponent of the column ...
+        bool bset[WC];                                                           // ... chosen yet?  (stays unset while the column has only seen zeros)
 #pragma unroll
-        for (int cc = 0; cc < WC; ++cc) bexp[cc] = 100;                          // scale exponent of the column (100 = not set yet)
+        for (int cc = 0; cc < WC; ++cc) { bexp[cc] = 0; bset[cc] = false; }
         const unsigned st_lane_off = 4u * (unsigned)(8 * kh * d.ldt + colb);     // GLN_BWD store-back: byte offset inside a chunk
 
         issue_x();
@@ -234,7 +235,8 @@ __global__ __launch_bounds__(512, 2) void pw_gemm_pc_kernel(const sep_gemm_desc 
                 // the column's other 8 contraction rows sit in the neighbouring lane (quad_perm [1,0,3,2])
                 m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xF, 0xF, true)));
                 const int ex = __builtin_amdgcn_frexp_expf(m);                   // m = f * 2^ex, f in [0.5, 1)
-                if (ex + bexp[cc] > 14) bexp[cc] = 9 - ex;                       // first chunk, or the column outgrew its scale
+                if (m > 0.f && (!bset[cc] || ex + bexp[cc] > 14)) bexp[cc] = 9 - ex;      // first non-zero chunk, or the column outgrew its scale
+                bset[cc] = bset[cc] || m > 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = __builtin_ldexpf(v[e], bexp[cc]);
                 unsigned hi[4], lo[4];
