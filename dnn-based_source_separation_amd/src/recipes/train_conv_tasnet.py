@@ -91,9 +91,12 @@ def main(argv=None):
     if rank == 0:
         print("Training dataset includes {} samples.".format(len(train_set)))
         print("Valid dataset includes {} samples.".format(len(valid_set)))
-    shard = shard_for_rank(train_set, rank, world, seed=args.seed) if world > 1 else train_set
-    loader = {"train": TrainDataLoader(shard, batch_size=args.batch_size, shuffle=True, drop_last=True, num_workers=args.num_workers),
-              "valid": EvalDataLoader(valid_set, batch_size=1, shuffle=False)}
+    def train_loader(epoch):
+        shard = shard_for_rank(train_set, rank, world, seed=args.seed, epoch=epoch) if world > 1 else train_set
+        return TrainDataLoader(shard, batch_size=args.batch_size, shuffle=True, drop_last=True, num_workers=args.num_workers)
+
+    loader = {"train": train_loader(0), "valid": EvalDataLoader(valid_set, batch_size=1, shuffle=False)}
+    args.reshard = train_loader if world > 1 else None      # every rank trains on a different subset each epoch
 
     stride = args.kernel_size // 2 if args.stride is None else args.stride
     model = ConvTasNet(args.n_basis, args.kernel_size, stride=stride, enc_basis=args.enc_basis, dec_basis=args.dec_basis,

@@ -51,8 +51,19 @@ class Trainer:
         if self.is_main:
             for d in (self.model_dir, self.loss_dir, self.sample_dir):
                 os.makedirs(d, exist_ok=True)
+        # the overwrite guard of the reference (driver.py:70-76) is decided on rank 0 and SHARED before any collective of the
+        # step is issued: a rank-0-only exception would leave the other ranks hanging in their first all-reduce
+        best = os.path.join(self.model_dir, "best.pth")
+        refuse = bool(self.is_main and not getattr(args, "continue_from", None) and os.path.exists(best) and not getattr(args, "overwrite", False))
+        if _is_dist() and dist.get_world_size() > 1:
+            flag = torch.tensor([int(refuse)], device=self.device if dist.get_backend() == "nccl" else "cpu")
+            dist.broadcast(flag, src=0)
+            refuse = bool(flag.item())
+        if refuse:
+            raise ValueError("{} already exists. If you continue to run, set --overwrite to be True.".format(best))
         self.step = FusedTrainStep(model, pit_criterion, lr=args.lr, weight_decay=getattr(args, "weight_decay", 0.0),
                                    max_norm=args.max_norm or 0.0)
+        self.reshard = getattr(args, "reshard", None)       # callable(epoch) -> this rank's train loader for that epoch, or None
         self.train_loss = torch.empty(self.epochs)
         self.valid_loss = torch.empty(self.epochs)
         if getattr(args, "continue_from", None):
@@ -66,9 +77,6 @@ class Trainer:
             model.load_state_dict(ck["state_dict"])
             self.step.load_optim_state_dict(ck["optim_dict"])
         else:
-            best = os.path.join(self.model_dir, "best.pth")
-            if self.is_main and os.path.exists(best) and not getattr(args, "overwrite", False):
-                raise ValueError("{} already exists. If you continue to run, set --overwrite to be True.".format(best))
             self.start_epoch = 0
             self.best_loss = float("infinity")
             self.prev_loss = float("infinity")
@@ -112,6 +120,8 @@ class Trainer:
 
     def run_one_epoch_train(self, epoch):
         self.model.train()
+        if self.reshard is not None:                        # a fresh shard of the training set per epoch (same permutation on every rank)
+            self.train_loader = self.reshard(epoch)
         total = torch.zeros((), device=self.device, dtype=torch.float64)   # no .item() per step: the step stays asynchronous
         n = 0
         for idx, (mixture, sources) in enumerate(DevicePrefetcher(self.train_loader, self.device)):

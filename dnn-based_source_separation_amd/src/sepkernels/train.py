@@ -43,9 +43,22 @@ class FusedTrainStep:
         for p in self.model.parameters():
             p.grad = None
 
+    def _rebind(self):
+        """model.to() / .float() / load through _apply re-home the parameters into a NEW flat buffer: follow it (moments are kept
+        when only the storage moved, and refused when the size changed) instead of running Adam on a buffer nobody reads."""
+        flat = self.model.flat_parameters()
+        if flat is self.flat:
+            return
+        if flat is None or flat.numel() != self.flat.numel():
+            raise RuntimeError("the model's parameters are no longer co-located in a flat buffer of the size this step was built for")
+        self.flat = flat
+        self.gflat, self.m, self.v = (t.to(flat.device) for t in (self.gflat, self.m, self.v))
+        self.sqnorm = self.sqnorm.to(flat.device)
+
     def __call__(self, mixture, sources):
         K = sepkernels.backend()
         model = self.model
+        self._rebind()
         self.zero_grad()
         model._grad_sink = self.gflat                 # backward writes every gradient straight into the flat buffer
         works = []
