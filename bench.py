@@ -212,6 +212,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-f32-pass", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured step (N = 1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -270,18 +271,29 @@ def main():
         would time the overlap, not the kernel."""
         side_prev = os.environ.get("SEPK_SIDE_STREAM")
         os.environ["SEPK_SIDE_STREAM"] = "0"
+        graph, step._graph = step._graph, None            # the event brackets live in the Python launch wrappers: eager for this pass
         step(mixture, sources)
         timed.reset()
         timed.enabled = True
         el, _ = timed_steps(n)
         timed.enabled = False
+        step._graph = graph
         if side_prev is None:
             del os.environ["SEPK_SIDE_STREAM"]
         else:
             os.environ["SEPK_SIDE_STREAM"] = side_prev
         return el
 
-    for _ in range(args.warmup):
+    # SEPK_GRAPH=1 (N = 1): the step (forward, PIT, backward on both streams, clip, Adam: ~400 launches) is captured once into a
+    # hipGraph and replayed; capture() itself runs 3 eager steps + the captured one, which count as warm-up.
+    # Measured (profiles/r02d_graph_vs_eager.md): replay 19.5 ms vs 19.6 eager on ONE stream, but 20.1 vs 18.6 with the weight
+    # gradients on their side stream (the two-branch graph loses the overlap the eager streams have) -- so the capture is opt-in.
+    use_graph = world == 1 and not args.no_graph and os.environ.get("SEPK_GRAPH", "0") == "1"
+    done = 0
+    if use_graph:
+        loss = step.capture(mixture, sources)
+        done = 4
+    for _ in range(max(0, args.warmup - done)):
         loss = step(mixture, sources)
     elapsed, loss = timed_steps(args.steps)              # THE timed region: K steps, nothing else in it
     my_elapsed = elapsed
@@ -300,7 +312,11 @@ def main():
     f32_pass = None
     if world == 1 and arith_name != "f32" and not args.no_f32_pass:
         sepkernels.set_gemm_arith("f32")
-        step(mixture, sources)
+        step._graph = None
+        if use_graph:
+            step.capture(mixture, sources)                 # the captured launches carry the arithmetic: record the step again
+        else:
+            step(mixture, sources)
         el_f32, _ = timed_steps(args.steps)
         f32_pass = {"value": world * args.batch * num_frames(T_SAMPLES, PAPER["kernel_size"], PAPER["stride"]) * args.steps / el_f32,
                     "unit": "frames/s", "ms_per_step": 1e3 * el_f32 / args.steps, "dtype": "f32",
@@ -309,6 +325,7 @@ def main():
             el_fi = instrumented_pass(args.steps)
             f32_pass["roofline"] = kernel_roofline(timed, "pw_gemm", "f32", args.steps, el_fi, "sep_pw_gemm: pw_gemm_direct_kernel<..., AR = 0>")
         sepkernels.set_gemm_arith(arith_name)
+        step._graph = None
 
     rank_ms = [1e3 * my_elapsed / args.steps]
     if world > 1:
@@ -337,6 +354,7 @@ def main():
                                    "synthetic mixtures, {} utterances/GPU, fwd + PIT(NegSI-SDR) + bwd + clip(5) + Adam".format(args.batch),
                        "global_batch": world * args.batch, "frames_per_utterance": F, "parallelism": "dp{}".format(world),
                        "utt_per_s": value / F, "samples_per_s": value / F * T_SAMPLES, "final_loss": float(loss),
+                       "launch": "hipGraph replay of the captured step" if use_graph else "eager (one launch per kernel)",
                        "gemm_arith": arith_name + {
                            "bf16x6": " (fp32 operands split exactly into 3 bf16 parts, 6 of 9 part products on the bf16 MFMA, fp32 "
                                      "accumulation; error vs fp64 at the fp32-MFMA path's level)",

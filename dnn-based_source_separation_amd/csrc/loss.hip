@@ -312,7 +312,50 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     p[i] = pi - (lr / bc1) * (mi / denom);
 }
 
+// Graph-replayable form: the step count and the learning rate live in device memory (a captured launch freezes its kernel
+// arguments), the count is advanced by a one-thread kernel in front of this one.
+__global__ void adam_tick_kernel(int* step) { step[0] += 1; }
+
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, const double* __restrict__ sqnorm, int64_t n,
+                                                       const float* __restrict__ lr_dev, const int* __restrict__ step_dev, float b1, float b2,
+                                                       float eps, float wd, float max_norm, float grad_scale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float lr = lr_dev[0];
+    const float st = (float)step_dev[0];
+    const float bc1 = 1.f - powf(b1, st);
+    const float bc2s = sqrtf(1.f - powf(b2, st));
+    float coef = grad_scale;
+    if (max_norm > 0.f) {
+        const float total = grad_scale * (float)sqrt(sqnorm[0]);
+        const float c = max_norm / (total + 1e-6f);
+        coef *= (c < 1.f ? c : 1.f);
+    }
+    float gi = g[i] * coef;
+    g[i] = gi;
+    const float pi = p[i];
+    if (wd != 0.f) gi = fmaf(wd, pi, gi);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2s + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+}
+
 }  // namespace
+
+extern "C" int sep_adam_step_dev(float* p, float* g, float* m, float* v, const double* sqnorm, int64_t n, const float* lr_dev,
+                                 int32_t* step_dev, float beta1, float beta2, float eps, float weight_decay, float max_norm,
+                                 float grad_scale, sep_stream_t stream) {
+    SEP_REQUIRE(p && g && m && v && n > 0 && lr_dev && step_dev, "sep_adam_step_dev: bad arguments");
+    SEP_REQUIRE(max_norm <= 0.f || sqnorm, "sep_adam_step_dev: clipping needs sqnorm");
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
+    hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, sqnorm, n, lr_dev, step_dev,
+                       beta1, beta2, eps, weight_decay, max_norm, grad_scale);
+    SEP_CHECK_LAUNCH("sep_adam_step_dev");
+    return 0;
+}
 
 extern "C" int sep_sisdr_dots(const float* est, const float* tgt, double* dots, double* tt, double* xx, int B, int n, int T,
                               int all_pairs, sep_stream_t stream) {

@@ -139,6 +139,7 @@ SIGNATURES = {
     "sep_rowdiff_bwd": [_vp, _vp, _vp, _vp, _vp, _L, _I, _vp],
     "sep_sqnorm": [_vp, _vp, _L, _vp],
     "sep_adam_step": [_vp] * 5 + [_L] + [_F] * 7 + [_I, _vp],
+    "sep_adam_step_dev": [_vp] * 5 + [_L, _vp, _vp] + [_F] * 6 + [_vp],
     "sep_lstm_fwd": [_vp] * 5 + [_I] * 4 + [_vp],
     "sep_lstm_bwd": [_vp] * 5 + [_I] * 4 + [_vp],
 }
@@ -399,6 +400,11 @@ class HipBackend:
     def adam_step(self, p, g, m, v, sqnorm, n, lr, beta1, beta2, eps, weight_decay, max_norm, grad_scale, step):
         _check(load().sep_adam_step(_ptr(p, _f32), _ptr(g, _f32), _ptr(m, _f32), _ptr(v, _f32), _ptr(sqnorm, _f64), n, lr, beta1,
                                     beta2, eps, weight_decay, max_norm, grad_scale, step, _stream()), "sep_adam_step")
+
+
+    def adam_step_dev(self, p, g, m, v, sqnorm, n, lr_dev, step_dev, beta1, beta2, eps, weight_decay, max_norm, grad_scale):
+        _check(load().sep_adam_step_dev(_ptr(p, _f32), _ptr(g, _f32), _ptr(m, _f32), _ptr(v, _f32), _ptr(sqnorm, _f64), n, _ptr(lr_dev, _f32),
+                                        _ptr(step_dev, torch.int32), beta1, beta2, eps, weight_decay, max_norm, grad_scale, _stream()), "sep_adam_step_dev")
 
 
 _backend = HipBackend()

@@ -9,6 +9,12 @@ Equal per-rank batches make mean-of-rank-means the global batch mean, so the ave
 reference's single-process result.  The collective is 19.9 MB per step (4,984,881 floats): latency-, not
 bandwidth-bound on 7 x 153 GB/s xGMI links; it is issued in three asynchronous pieces (one per TCN block, last block
 first) so that most of it hides under the rest of backward (SEPK_DDP_BUCKETS=0: one call after backward).
+
+hipGraph: a step is ~400 kernel launches with fixed shapes, and the gaps between them were 10-17 % of the profiled wall time
+(profiles/r02c_kernel_stats.md).  `capture(mixture, sources)` records ONE step -- forward, criterion, backward on both streams,
+clip, Adam -- into a graph over static input buffers and the caching allocator's private pool; later calls with the same shapes
+copy their batch in and replay it.  The two scalars that change from step to step (Adam's step count, the learning rate) live in
+device memory for that (sep_adam_step_dev).  Single-process only: the RCCL all-reduce stays eager.
 """
 import os
 
@@ -38,6 +44,11 @@ class FusedTrainStep:
         self.sqnorm = torch.zeros(1, device=flat.device, dtype=torch.float64)
         self.step_count = 0
         self.bucketed = os.environ.get("SEPK_DDP_BUCKETS", "1") != "0"
+        # graph state (see capture())
+        self._graph = None
+        self._static = None
+        self._step_dev = None
+        self._lr_dev = None
 
     def zero_grad(self):
         for p in self.model.parameters():
@@ -55,10 +66,51 @@ class FusedTrainStep:
         self.gflat, self.m, self.v = (t.to(flat.device) for t in (self.gflat, self.m, self.v))
         self.sqnorm = self.sqnorm.to(flat.device)
 
+    # ---- hipGraph of the whole step -----------------------------------------------------------------------------------
+    def capture(self, mixture, sources, warmup=3):
+        """Record one step on inputs of this shape.  `warmup` eager steps run first on a side stream (allocator and lazy
+        initialisation settle there, as torch.cuda.graphs asks for); they ARE training steps.  Returns the loss of the captured step
+        (which is executed too)."""
+        if self.world > 1:
+            raise RuntimeError("graph capture of the train step is single-process only (the gradient all-reduce stays eager)")
+        dev = self.flat.device
+        self._static = (torch.empty_like(mixture), torch.empty_like(sources))
+        self._static[0].copy_(mixture)
+        self._static[1].copy_(sources)
+        self._lr_dev = torch.tensor([self.lr], device=dev, dtype=torch.float32)
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self._eager(*self._static)
+        torch.cuda.current_stream(dev).wait_stream(s)
+        self._step_dev = torch.tensor([self.step_count], device=dev, dtype=torch.int32)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._static_loss = self._eager(*self._static, graph=True)
+        self._graph = g
+        self._graph_shapes = (tuple(mixture.shape), tuple(sources.shape))
+        # capture only records: run the step it recorded once, so that the caller sees warmup + 1 steps done
+        return self._replay()
+
+    def _replay(self):
+        self._lr_dev.fill_(self.lr)
+        self._graph.replay()
+        self.step_count += 1
+        return self._static_loss
+
     def __call__(self, mixture, sources):
+        if self._graph is not None and (tuple(mixture.shape), tuple(sources.shape)) == self._graph_shapes:
+            self._static[0].copy_(mixture)
+            self._static[1].copy_(sources)
+            return self._replay()
+        return self._eager(mixture, sources)
+
+    def _eager(self, mixture, sources, graph=False):
         K = sepkernels.backend()
         model = self.model
-        self._rebind()
+        if not graph:
+            self._rebind()
         self.zero_grad()
         model._grad_sink = self.gflat                 # backward writes every gradient straight into the flat buffer
         works = []
@@ -82,13 +134,19 @@ class FusedTrainStep:
                     w.wait()
             else:
                 dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM, group=self.group)
-        self.step_count += 1
         n = self.gflat.numel()
         self.sqnorm.zero_()
         if self.max_norm and self.max_norm > 0:
             K.sqnorm(self.gflat, self.sqnorm, n)
-        K.adam_step(self.flat, self.gflat, self.m, self.v, self.sqnorm, n, self.lr, self.betas[0], self.betas[1], self.eps,
-                    self.weight_decay, float(self.max_norm or 0.0), 1.0 / self.world, self.step_count)
+        if graph:
+            K.adam_step_dev(self.flat, self.gflat, self.m, self.v, self.sqnorm, n, self._lr_dev, self._step_dev, self.betas[0], self.betas[1],
+                            self.eps, self.weight_decay, float(self.max_norm or 0.0), 1.0 / self.world)
+        else:
+            self.step_count += 1
+            if self._step_dev is not None:
+                self._step_dev.fill_(self.step_count)          # an eager step between replays (other shapes) keeps the device count in step
+            K.adam_step(self.flat, self.gflat, self.m, self.v, self.sqnorm, n, self.lr, self.betas[0], self.betas[1], self.eps,
+                        self.weight_decay, float(self.max_norm or 0.0), 1.0 / self.world, self.step_count)
         return loss.detach()
 
     # ---- optimizer state in torch.optim.Adam's state_dict layout (checkpoint interchange with the reference's

@@ -321,6 +321,13 @@ int sep_adam_step(float* p, float* g, float* m, float* v, const double* sqnorm, 
                   float beta2, float eps, float weight_decay, float max_norm, float grad_scale, int step,
                   sep_stream_t stream);
 
+/* The same step with its two per-step scalars in DEVICE memory, so that a captured launch (hipGraph of the whole train step)
+ * replays correctly: step_dev[0] is incremented first (a one-thread kernel), then used for the bias corrections; lr_dev[0] is
+ * read at run time (learning-rate halving of driver.py:101-111 is a host write into that word between replays). */
+int sep_adam_step_dev(float* p, float* g, float* m, float* v, const double* sqnorm, int64_t n, const float* lr_dev,
+                      int32_t* step_dev, float beta1, float beta2, float eps, float weight_decay, float max_norm,
+                      float grad_scale, sep_stream_t stream);
+
 /* Time recurrence of ONE direction of nn.LSTM (reference src/models/dprnn.py:9-148 -> choose_rnn('lstm'), i.e.
  * IntraChunkRNN / InterChunkRNN of DPRNN-TasNet).  The input projection is done by the caller (a plain GEMM):
  *   xg[seq][t][4H] = x[seq][t][:] W_ih^T + b_ih + b_hh,   gate order i, f, g, o as in torch.

@@ -538,6 +538,10 @@ class EmuBackend:
             dc = dcc * f
             dhr = da @ w_hh
 
+    def adam_step_dev(self, p, g, m, v, sqnorm, n, lr_dev, step_dev, beta1, beta2, eps, weight_decay, max_norm, grad_scale):
+        step_dev += 1
+        self.adam_step(p, g, m, v, sqnorm, n, float(lr_dev[0]), beta1, beta2, eps, weight_decay, max_norm, grad_scale, int(step_dev[0]))
+
     def adam_step(self, p, g, m, v, sqnorm, n, lr, beta1, beta2, eps, weight_decay, max_norm, grad_scale, step):
         coef = grad_scale
         if max_norm > 0:
