@@ -37,6 +37,9 @@ extern "C" int sep_debug_coop_prof(long long* out) { return hipMemcpyFromSymbol(
 
 namespace {
 
+#ifndef COOP_PIPE
+#define COOP_PIPE true
+#endif
 constexpr int CBN = 64;          // columns (frames) per workgroup
 constexpr int RBI = 264;         // floats per raw-X image of 4 contraction rows: 1 KiB + 32 B, so the four images of a chunk
                                  // start 8 banks apart and the quad-per-column reads below are conflict-free
@@ -346,7 +349,7 @@ void pw_gemm_coop_kernel(const sep_gemm_desc d) {
     asm volatile("" : "+v"(etid), "+s"(eb), "+s"(em0), "+s"(et0));
     const int ewid = __builtin_amdgcn_readfirstlane(etid >> 6);
     const int elane = etid & 63;
-    gemm_epilogue<EF, MI, true>(d, acc, eb, em0, et0, ewid, 0, elane >> 5, elane & 31, etid, &sm.As[0][0], sm.red, CBN);
+    gemm_epilogue<EF, MI, true, 4, COOP_PIPE>(d, acc, eb, em0, et0, ewid, 0, elane >> 5, elane & 31, etid, &sm.As[0][0], sm.red, CBN);
     if (P_BWD && rt == 0) {
         const double sdal = block_sum_256<double>((double)dalpha_pro, sm.red);
         if (tid == 0) atomicAdd(d.pro_dalpha, sdal);
