@@ -203,6 +203,56 @@ def cpu_baseline(timed_steps=5):
     return out
 
 
+def bench_dprnn(args):
+    """BASELINE.json configs[3]: DPRNN-TasNet (N=64, L=2, F=64, H=128, K=250, P=125, 6 blocks, egs/wsj0-mix/dprnn-tasnet/train.sh:28-37),
+    2 speakers, 4 s @ 8 kHz, recipe batch size 2, one GPU: forward + PIT(NegSI-SDR) + backward + clip(5) + Adam (torch.optim.Adam:
+    this model's parameters are ordinary tensors).  A frame is one encoder frame (31,999 per utterance).  Segment / overlap-add, gLN,
+    encoder / mask / decoder and the LSTM time recurrence are this library's kernels; the LSTM input projections, the Linear
+    layers and their weight gradients are library GEMMs (torch -> rocBLAS), as DESIGN.md states."""
+    import sepkernels
+    from models.dprnn_tasnet import DPRNNTasNet
+    from criterion.sdr import NegSISDR
+    from criterion.pit import PIT1d
+    sepkernels.load()
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(111)
+    model = DPRNNTasNet(n_basis=64, kernel_size=2, stride=1, enc_basis="trainable", dec_basis="trainable", enc_nonlinear=None,
+                        sep_hidden_channels=128, sep_bottleneck_channels=64, sep_chunk_size=250, sep_hop_size=125, sep_num_blocks=6,
+                        sep_norm=True, mask_nonlinear="sigmoid", causal=False, rnn_type="lstm", n_sources=2).to(dev)
+    crit = PIT1d(NegSISDR(), n_sources=2)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    B = 2 if args.batch == PER_GPU_BATCH else args.batch
+    src = (0.1 * torch.randn(B, 2, T_SAMPLES, generator=torch.Generator().manual_seed(111))).to(dev)
+    mix = src.sum(1, keepdim=True).contiguous()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss, _ = crit(model(mix), src)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+        opt.step()
+        return loss.detach()
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    F = T_SAMPLES - 2 + 1
+    print(json.dumps({
+        "metric": "separated audio frames/sec (fwd+bwd), DPRNN-TasNet 2-spk 4s@8kHz (BASELINE configs[3])", "value": B * F * args.steps / el, "unit": "frames/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "DPRNN-TasNet N=64 L=2 F=64 H=128 K=250 P=125 B=6, 2 spk, 4 s @ 8 kHz synthetic mixtures, batch {} (recipe default), "
+                               "fwd + PIT(NegSI-SDR) + bwd + clip(5) + Adam".format(B),
+                   "global_batch": B, "frames_per_utterance": F, "parallelism": "dp1", "utt_per_s": B * args.steps / el, "final_loss": float(loss),
+                   "algorithmic_gflop_per_utterance_fwd_bwd": 980.07},
+        "roofline": None, "roofline_note": "980 GFLOP per utterance (SURVEY.md 8d): {:.1f} TFLOP/s achieved; 57 % of it in this library's LSTM "
+                                           "recurrence kernel (fp32 MFMA), the rest in rocBLAS GEMMs".format(980.07e9 * B * args.steps / el / 1e12)}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,7 +263,12 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-f32-pass", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured step (N = 1)")
+    ap.add_argument("--config", default="convtasnet2", choices=["convtasnet2", "sinkpit4", "dprnn"],
+                    help="convtasnet2 (default) = BASELINE.json configs[1]/[2], the headline; sinkpit4 = configs[4] (paper-best Conv-TasNet, "
+                         "4 speakers, SinkPIT(NegSI-SDR, coldness 1, 200 iterations)); dprnn = configs[3] (DPRNN-TasNet N64 L2 F64 H128 K250 P125 B6, batch 2)")
     args = ap.parse_args()
+    if args.config == "dprnn":
+        return bench_dprnn(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -244,11 +299,19 @@ def main():
     sepkernels._backend = timed
 
     torch.manual_seed(111)
-    model = ConvTasNet(**PAPER).to(dev)
-    crit = PIT1d(NegSISDR(), n_sources=2)
+    cfg_model = dict(PAPER)
+    n_src = 2
+    if args.config == "sinkpit4":                      # egs/tutorials/sinkpit_conv-tasnet/train.sh:7,38,42-43
+        from criterion.pit import SinkPIT
+        n_src = 4
+        cfg_model.update(n_sources=4, mask_nonlinear="softmax")
+        crit = SinkPIT(NegSISDR(), n_sources=4, coldness=1.0, iteration=200)
+    else:
+        crit = PIT1d(NegSISDR(), n_sources=2)
+    model = ConvTasNet(**cfg_model).to(dev)
     step = FusedTrainStep(model, crit, lr=1e-3, max_norm=5.0)   # recipe defaults: adam 1e-3, clip 5 (train.sh:50-57)
     g = torch.Generator().manual_seed(111 + rank)
-    sources = (0.1 * torch.randn(args.batch, 2, T_SAMPLES, generator=g)).to(dev)
+    sources = (0.1 * torch.randn(args.batch, n_src, T_SAMPLES, generator=g)).to(dev)
     mixture = sources.sum(1, keepdim=True).contiguous()
 
     def sync():
@@ -339,19 +402,23 @@ def main():
     F = num_frames(T_SAMPLES, PAPER["kernel_size"], PAPER["stride"])
     frames_per_step = world * args.batch * F
     value = frames_per_step * args.steps / elapsed
-    fl_frame, by_frame = 3 * flops_per_frame(PAPER), 3 * bytes_per_frame(PAPER)
+    fl_frame, by_frame = 3 * flops_per_frame(cfg_model), 3 * bytes_per_frame(cfg_model)
 
     if rank == 0:
         per, pipe = MFMA_PER_PRODUCT[arith_name]
         out = {
-            "metric": "separated audio frames/sec (fwd+bwd), Conv-TasNet 2-spk 4s@8kHz", "value": value, "unit": "frames/s",
+            "metric": "separated audio frames/sec (fwd+bwd), Conv-TasNet 2-spk 4s@8kHz" if args.config == "convtasnet2" else
+                      "separated audio frames/sec (fwd+bwd), Conv-TasNet 4-spk 4s@8kHz with Sinkhorn-PIT (BASELINE configs[4])",
+            "value": value, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f16x3": "f32 (f16x3 split emulation: fp32 operands and accumulators, products from two fp16 parts per operand on the fp16 MFMA)",
                       "bf16x6": "f32 (bf16x6 split emulation: exact three-way bf16 split on the bf16 MFMA)", "f32": "f32"}[arith_name],
             "data": "synthetic",
-            "config": {"workload": "Conv-TasNet paper-best (N=512,L=16,B=128,H=512,Sc=128,P=3,X=8,R=3) 2-spk, 4 s @ 8 kHz "
-                                   "synthetic mixtures, {} utterances/GPU, fwd + PIT(NegSI-SDR) + bwd + clip(5) + Adam".format(args.batch),
+            "config": {"workload": ("Conv-TasNet paper-best (N=512,L=16,B=128,H=512,Sc=128,P=3,X=8,R=3) 2-spk, 4 s @ 8 kHz "
+                                    "synthetic mixtures, {} utterances/GPU, fwd + PIT(NegSI-SDR) + bwd + clip(5) + Adam" if args.config == "convtasnet2" else
+                                    "Conv-TasNet paper-best, 4 speakers, softmax mask, 4 s @ 8 kHz synthetic mixtures, {} utterances/GPU, fwd + "
+                                    "SinkPIT(NegSI-SDR, coldness 1, 200 iterations) + bwd + clip(5) + Adam").format(args.batch),
                        "global_batch": world * args.batch, "frames_per_utterance": F, "parallelism": "dp{}".format(world),
                        "utt_per_s": value / F, "samples_per_s": value / F * T_SAMPLES, "final_loss": float(loss),
                        "launch": "hipGraph replay of the captured step" if use_graph else "eager (one launch per kernel)",
