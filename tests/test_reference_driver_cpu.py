@@ -88,3 +88,71 @@ def test_reference_trainer_drives_this_repositorys_classes(tmp_path):
     assert l1 < l0, "training loss did not decrease under the reference's driver: {} -> {}".format(l0, l1)
     assert float(lines["RELOAD"][0]) < 1e-6
     assert float(lines["RESUMED"][0]) < l0
+
+
+TRAIN_SCRIPT = textwrap.dedent('''
+    import os, sys, types, runpy
+    sys.path[:0] = [{src!r}, {tests!r}, {root!r}]
+    sys.path += [{ref_src!r}, {ref_common!r}, {ref_recipe_src!r}]
+    import torch
+    from recipes.audio_io import install_torchaudio_shim
+    install_torchaudio_shim()
+    me = types.ModuleType("mir_eval"); sep = types.ModuleType("mir_eval.separation")
+    sep.bss_eval_sources = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("evaluation-only"))
+    me.separation = sep; sys.modules["mir_eval"] = me; sys.modules["mir_eval.separation"] = sep
+    import matplotlib; matplotlib.use("Agg")
+    import sepkernels
+    from emulator import EmuBackend
+    sepkernels._set_backend_for_tests(EmuBackend())
+    sys.argv = {argv!r}
+    runpy.run_path({train_py!r}, run_name="__main__")
+''')
+
+
+def _wav_tree(root, n_utt, seed):
+    """wsj0-mix layout: <root>/(mix|s1|s2)/<ID>.wav + a list file of IDs."""
+    import torch
+    from recipes.audio_io import write_wav
+    g = torch.Generator().manual_seed(seed)
+    ids = []
+    for k in range(n_utt):
+        ID = "utt%02d" % k
+        T = 2400 + 160 * k
+        s = 0.1 * torch.randn(2, T, generator=g)
+        for name, x in (("s1", s[0:1]), ("s2", s[1:2]), ("mix", s.sum(0, keepdim=True))):
+            os.makedirs(os.path.join(root, name), exist_ok=True)
+            write_wav(os.path.join(root, name, ID + ".wav"), x, 8000, 16)
+        ids.append(ID)
+    lst = os.path.join(root, "list")
+    open(lst, "w").write("\n".join(ids) + "\n")
+    return lst
+
+
+def test_reference_recipe_train_py_runs_end_to_end(tmp_path):
+    """The reference's own egs/wsj0-mix/conv-tasnet/local/train.py (argparse -> WaveTrainDataset / WaveEvalDataset over a wav tree ->
+    ConvTasNet(...) -> torch.optim.Adam -> PIT1d(NegSISDR()) -> AdhocTrainer.run()), unmodified, on a synthetic wsj0-mix-style tree,
+    with this repository's src/ in front of the reference's: two epochs, checkpoints in the reference's format, reloadable."""
+    sys.path.insert(0, os.path.join(ROOT, "dnn-based_source_separation_amd", "src"))
+    tr, cv = str(tmp_path / "tr"), str(tmp_path / "cv")
+    tr_list, cv_list = _wav_tree(tr, 5, 1), _wav_tree(cv, 2, 2)
+    out = str(tmp_path / "exp")
+    argv = ["train.py", "--train_wav_root", tr, "--valid_wav_root", cv, "--train_list_path", tr_list, "--valid_list_path", cv_list,
+            "--sample_rate", "8000", "--duration", "0.2", "--valid_duration", "0.5", "--enc_basis", "trainable", "--dec_basis", "trainable",
+            "--enc_nonlinear", "relu", "-N", "64", "-L", "16", "-B", "64", "-H", "128", "-Sc", "64", "-P", "3", "-X", "2", "-R", "1",
+            "--dilated", "1", "--separable", "1", "--causal", "0", "--sep_nonlinear", "prelu", "--sep_norm", "1", "--mask_nonlinear", "sigmoid",
+            "--n_sources", "2", "--criterion", "sisdr", "--optimizer", "adam", "--lr", "1e-3", "--max_norm", "5", "--batch_size", "2",
+            "--epochs", "2", "--model_dir", out + "/model", "--loss_dir", out + "/loss", "--sample_dir", out + "/sample", "--use_cuda", "0",
+            "--overwrite", "0", "--seed", "111"]
+    recipe = os.path.join(REF, "egs", "wsj0-mix", "conv-tasnet")
+    code = TRAIN_SCRIPT.format(src=os.path.join(ROOT, "dnn-based_source_separation_amd", "src"), tests=os.path.join(ROOT, "tests"), root=ROOT,
+                               ref_src=os.path.join(REF, "src"), ref_common=os.path.join(REF, "egs", "wsj0-mix", "common", "src"),
+                               ref_recipe_src=os.path.join(recipe, "src"), argv=argv, train_py=os.path.join(recipe, "local", "train.py"))
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "# Parameters: 58117" in r.stdout and "[Epoch 2/2]" in r.stdout, r.stdout[-1500:]
+    for f in ("best.pth", "last.pth"):
+        assert os.path.exists(os.path.join(out, "model", f))
+    import torch
+    ck = torch.load(os.path.join(out, "model", "last.pth"), map_location="cpu", weights_only=False)
+    assert ck["epoch"] == 2 and ck["n_basis"] == 64 and "optim_dict" in ck and len(ck["state_dict"]) > 20
