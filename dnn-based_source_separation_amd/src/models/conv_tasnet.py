@@ -294,12 +294,13 @@ class ConvTasNet(nn.Module):
         padding = (S - (T - L) % S) % S
         left = padding // 2
         x = F.pad(mixture, (left, padding - left))
-        w = F.conv1d(x, self.encoder.conv1d.weight, stride=S)
-        if self.encoder.nonlinear:
-            w = torch.relu(w)
-        mask = self.separator(w)                                   # (B, n_src, N, F)
-        latent = w.unsqueeze(1) * mask
-        y = F.conv_transpose1d(latent.reshape(B * n_src, N, -1), self.decoder.conv_transpose1d.weight, stride=S)
+        w = self.encoder(x)
+        if torch.is_complex(w):                                    # Fourier basis with complex output: mask the magnitude, keep the phase
+            mag, phase = torch.abs(w), torch.angle(w)
+            latent = mag.unsqueeze(1) * self.separator(mag) * torch.exp(1j * phase.unsqueeze(1))
+        else:
+            latent = w.unsqueeze(1) * self.separator(w)            # (B, n_src, N, F)
+        y = self.decoder(latent.reshape(B * n_src, N, -1))
         y = y.view(B, n_src, self.in_channels, -1)[..., left:left + T]
         return y, (latent if want_latent else None)
 

@@ -51,8 +51,9 @@ def layer_names(cfg):
 
 
 def check_supported(cfg):
-    """The fused HIP path covers the north-star configuration family; anything else fails loudly
-    (there is deliberately no silent PyTorch fallback)."""
+    """Raises NotImplementedError (with the reasons) for configurations outside the family the fused HIP kernel sequence
+    implements.  ConvTasNet calls it once, in its constructor, and runs such configurations as the module-by-module
+    composition instead; the message is kept on the model as `fused_reason`."""
     problems = []
     if cfg.get("enc_basis") != "trainable" or cfg.get("dec_basis") != "trainable":
         problems.append("enc_basis/dec_basis must be 'trainable'")

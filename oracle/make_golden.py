@@ -65,10 +65,28 @@ CONFIGS = {
                   sep_hidden_channels=64, sep_bottleneck_channels=32, sep_skip_channels=32, sep_kernel_size=3,
                   sep_num_blocks=1, sep_num_layers=3, dilated=False, separable=True, causal=False, sep_nonlinear=None,
                   sep_norm=False, mask_nonlinear="softmax", n_sources=2),
+    # --- other filterbanks (reference models/filterbank.py:12-203, 253-323): fixed Fourier basis with complex latent (the magnitude is
+    # masked, the phase kept), trainable frequencies + phases with a real-valued one-sided latent, pseudo-inverse decoders
+    "fourier": dict(n_basis=17, kernel_size=32, stride=8, enc_basis="Fourier", dec_basis="Fourier", enc_nonlinear=None, window_fn="hann",
+                    enc_onesided=1, enc_return_complex=1, sep_hidden_channels=48, sep_bottleneck_channels=32, sep_skip_channels=32,
+                    sep_kernel_size=3, sep_num_blocks=1, sep_num_layers=2, dilated=True, separable=True, causal=False, sep_nonlinear="prelu",
+                    sep_norm=True, mask_nonlinear="sigmoid", n_sources=2),
+    "fourier_phase": dict(n_basis=34, kernel_size=32, stride=16, enc_basis="trainableFourierTrainablePhase", dec_basis="trainableFourierTrainablePhase",
+                          enc_nonlinear=None, window_fn="hamming", enc_onesided=1, enc_return_complex=0, sep_hidden_channels=48,
+                          sep_bottleneck_channels=32, sep_skip_channels=32, sep_kernel_size=3, sep_num_blocks=1, sep_num_layers=2, dilated=True,
+                          separable=True, causal=False, sep_nonlinear="prelu", sep_norm=True, mask_nonlinear="sigmoid", n_sources=2),
+    "fourier_pinv": dict(n_basis=32, kernel_size=16, stride=8, enc_basis="trainableFourier", dec_basis="pinv", enc_nonlinear=None, window_fn="hann",
+                         enc_onesided=0, enc_return_complex=0, sep_hidden_channels=48, sep_bottleneck_channels=32, sep_skip_channels=32,
+                         sep_kernel_size=3, sep_num_blocks=1, sep_num_layers=2, dilated=True, separable=True, causal=False, sep_nonlinear="prelu",
+                         sep_norm=True, mask_nonlinear="sigmoid", n_sources=2),
+    "pinv": dict(n_basis=64, kernel_size=16, stride=8, enc_basis="trainable", dec_basis="pinv", enc_nonlinear=None, sep_hidden_channels=48,
+                 sep_bottleneck_channels=32, sep_skip_channels=32, sep_kernel_size=3, sep_num_blocks=1, sep_num_layers=2, dilated=True,
+                 separable=True, causal=False, sep_nonlinear="prelu", sep_norm=True, mask_nonlinear="sigmoid", n_sources=2),
 }
 SHAPES = {"tiny": (1, 4000), "mid": (2, 3203), "softmax": (2, 2500),   # (batch, samples); 3203 / 2500 exercise the input padding branch
-          "causal": (2, 2403), "plainconv": (2, 2000), "nodil": (1, 1607)}
-COMPOSED = ("causal", "plainconv", "nodil")
+          "causal": (2, 2403), "plainconv": (2, 2000), "nodil": (1, 1607),
+          "fourier": (2, 1603), "fourier_phase": (2, 1603), "fourier_pinv": (1, 1603), "pinv": (2, 1603)}
+COMPOSED = ("causal", "plainconv", "nodil", "fourier", "fourier_phase", "fourier_pinv", "pinv")
 
 
 def perturb(model, seed):
@@ -109,14 +127,15 @@ def model_golden(name, ConvTasNet, NegSISDR, PIT1d):
 
     blob = {"mixture": mixture.numpy(), "sources": sources.numpy(),
             "output_f32": out32.detach().numpy(), "output_f64": out64.detach().numpy(),
-            "latent_f64_sum": np.array(latent64.detach().sum().item()),
+            "latent_f64_sum": np.array(latent64.detach().sum().real.item() if torch.is_complex(latent64) else latent64.detach().sum().item()),
             "latent_f64_abs_sum": np.array(latent64.detach().abs().sum().item()),
             "loss_f32": np.array(loss32.item()), "loss_f64": np.array(loss64.item()),
             "pattern": pattern.numpy()}
     for k, v in model.state_dict().items():
         blob["param/" + k] = v.numpy()
     for k, p in m64.named_parameters():
-        blob["grad/" + k] = p.grad.numpy().astype(np.float32)  # fp64 truth, stored as f32 to keep the fixture small
+        if p.grad is not None:             # (Fourier bases carry non-trainable parameters: time_seq, and frequency when not trainable)
+            blob["grad/" + k] = p.grad.numpy().astype(np.float32)  # fp64 truth, stored as f32 to keep the fixture small
     blob["num_parameters"] = np.array(model.num_parameters)
     np.savez_compressed(os.path.join(OUT, "convtasnet_{}.npz".format(name)), **blob)
     print(name, "params", model.num_parameters, "loss", loss64.item(), "pattern", pattern.tolist())
@@ -225,7 +244,7 @@ def dprnn_golden(NegSISDR, PIT1d):
     loss64, pattern = PIT1d(NegSISDR(), n_sources=2)(out64, sources.double())
     loss64.backward()
     blob = {"mixture": mixture.numpy(), "sources": sources.numpy(), "output_f64": out64.detach().numpy(),
-            "latent_f64_sum": np.array(latent64.detach().sum().item()), "loss_f64": np.array(loss64.item()),
+            "latent_f64_sum": np.array(latent64.detach().sum().real.item() if torch.is_complex(latent64) else latent64.detach().sum().item()), "loss_f64": np.array(loss64.item()),
             "pattern": pattern.numpy(), "num_parameters": np.array(model.num_parameters)}
     for k, v in model.state_dict().items():
         blob["param/" + k] = v.numpy()

@@ -46,14 +46,21 @@ def test_composed_path_matches_the_reference(golden_dir, name, emu):
     est, latent = model.extract_latent(mixture)
     ref = torch.from_numpy(g["output_f64"])
     assert (est - ref).abs().max() <= 1e-9 * ref.abs().max()
-    assert abs(latent.sum().item() - float(g["latent_f64_sum"])) <= 1e-8 * float(g["latent_f64_abs_sum"])
+    lsum = latent.sum().real.item() if torch.is_complex(latent) else latent.sum().item()      # (complex latent of the Fourier basis: real part of the sum)
+    assert abs(lsum - float(g["latent_f64_sum"])) <= 1e-8 * float(g["latent_f64_abs_sum"])
     loss, pattern = PIT1d(NegSISDR(), n_sources=CONFIGS[name]["n_sources"])(est, sources)
     assert abs(loss.item() - float(g["loss_f64"])) <= 1e-9 * abs(float(g["loss_f64"]))
     assert np.array_equal(pattern.numpy(), g["pattern"])
     loss.backward()
+    seen = 0
     for k, p in model.named_parameters():
+        if "grad/" + k not in g.files:             # non-trainable parameters of the Fourier bases (time_seq; frequency when fixed)
+            assert p.grad is None, k
+            continue
         gr = torch.from_numpy(g["grad/" + k]).double()
         assert (p.grad - gr).abs().max() <= 2e-6 * max(gr.abs().max().item(), 1e-6), k          # the fixture stores fp64 gradients as fp32
+        seen += 1
+    assert seen == sum(1 for f in g.files if f.startswith("grad/"))
 
 
 def test_cumulative_layer_norm_formula():
