@@ -73,9 +73,14 @@ def test_error_behaviour():
         model(torch.zeros(1, 2, 4000))                            # C_in must be 1
     with pytest.raises(RuntimeError):
         model(torch.zeros(1, 1, 4000))                            # CPU tensor on the HIP build: loud failure, no fallback
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(AssertionError):                              # one-sided complex Fourier basis needs an odd feature count (reference utils/filterbank.py:50-66)
         ConvTasNet(64, 16, enc_basis="Fourier", dec_basis="Fourier", enc_nonlinear=None, window_fn="hann",
                    enc_onesided=True, enc_return_complex=True)
+    with pytest.raises(NotImplementedError):
+        ConvTasNet(64, 16, enc_basis="wavelet", dec_basis="trainable", enc_nonlinear=None)
+    with pytest.raises(ValueError):                                  # pseudo-inverse of an encoder with a non-linearity does not exist
+        from models.filterbank import Encoder, PinvDecoder
+        PinvDecoder(Encoder(1, 64, 16, 8, nonlinear="relu"))
     with pytest.raises(ValueError):
         ConvTasNet(**dict(CONFIGS["tiny"], mask_nonlinear="tanh"))
     with pytest.raises(ValueError):
