@@ -95,6 +95,5 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 int sep_pw_gemm_packed(const sep_gemm_desc* d, hipStream_t stream);
 // gemm_pc.hip: its producer / consumer kernel (same contract)
 int sep_pw_gemm_pc(const sep_gemm_desc* d, hipStream_t stream);
-int sep_pw_gemm_pcd(const sep_gemm_desc* d, hipStream_t stream);
 // wgrad_pc.hip: producer / consumer form of sep_pw_wgrad in the bf16 split arithmetic (same contract)
 int sep_pw_wgrad_pc(const sep_wgrad_desc* d, hipStream_t stream);

@@ -427,14 +427,13 @@ int sep_pw_gemm_packed(const sep_gemm_desc* d, hipStream_t stream) {
     static const bool only_coop = kern != nullptr && kern[0] == 'c';
     static const bool all_pc = kern != nullptr && kern[0] == 'p';
     static const int pc_min_k = getenv("SEPK_PC_MINK") ? atoi(getenv("SEPK_PC_MINK")) : 512;
-    static const bool pc_barrier = getenv("SEPK_PC_SYNC") != nullptr && getenv("SEPK_PC_SYNC")[0] == 'b';      // A/B: the barrier form (gemm_pc.hip)
     static const int force_mi = getenv("SEPK_COOP_MI") ? atoi(getenv("SEPK_COOP_MI")) : 0;
     static const int env_ns = getenv("SEPK_COOP_NS") ? atoi(getenv("SEPK_COOP_NS")) : 0;
     if (off || !d->A_pk || !d->a_rscale || d->arith != SEP_ARITH_F16X3) return 0;
     // measured per shape (tools/gemm_bench.py --packed, SEPK_GEMM_KERNEL=pc vs the default): the one-workgroup-per-CU kernel wins
     // where the main loop is long (K >= 512) or the row tiles are many (M >= 1024); at K = 128 / 256 its un-overlapped ring
     // fill and epilogue per tile cost more than its denser MFMA stream gains
-    if (!only_coop && (all_pc || d->K >= pc_min_k || d->M >= 1024) && (pc_barrier ? sep_pw_gemm_pc(d, stream) : sep_pw_gemm_pcd(d, stream))) return 1;      // producer / consumer form (gemm_pcd.hip)
+    if (!only_coop && (all_pc || d->K >= pc_min_k || d->M >= 1024) && sep_pw_gemm_pc(d, stream)) return 1;      // producer / consumer form (gemm_pc.hip)
     // everything else the packed path takes runs on this file's cooperative kernel: ~5 % behind the per-wave-split kernel of
     // gemm.hip on the K = 128 shapes, but with the packer's per-row weight scales instead of one bound for all weights
     if (d->M % 128 != 0 || d->K % DK != 0 || d->k_split % DK != 0 || (d->m_split % 128) != 0) return 0;
