@@ -4,9 +4,9 @@ Global layer normalisation on MI355X.  API of reference src/modules/norm.py:11-3
 
 Inside ConvTasNet the norm never runs as its own kernel (it is folded into the neighbouring GEMM / depthwise
 kernels, see sepkernels/net.py); this module is the stand-alone form for other callers.
-`CumulativeLayerNorm1d` (causal cLN, reference :42-101) is outside the hot path (causal=0 in every BASELINE config): it
-is a composition of torch operations (column sums, two prefix sums, one elementwise pass) that runs on whatever device its
-input lives on -- the SURVEY.md section 8b fallback for configurations the fused kernel sequence does not cover.
+`CumulativeLayerNorm1d` (causal cLN, reference :42-101; causal=0 in every BASELINE config) runs on sep_cln_fwd / sep_cln_bwd
+(csrc/cln.hip: column sums, fp64 prefix sums, one apply pass each way) for fp32 tensors the backend takes, and as the same
+arithmetic composed from torch operations otherwise (float64 checks, CPU tensors in the fallback path's CPU tests).
 """
 import torch
 import torch.nn as nn
@@ -87,6 +87,62 @@ class GlobalLayerNorm(nn.Module):
         return "{}({}, eps={})".format(self.__class__.__name__, self.num_features, self.eps)
 
 
+class _CumulativeLayerNormFn(torch.autograd.Function):
+    """cLN on libsepkernels (sep_cln_fwd / sep_cln_bwd, csrc/cln.hip): column sums, fp64 prefix sums, one apply pass."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        K = sepkernels.backend()
+        B, C = x.shape[0], x.shape[1]
+        T = x.numel() // (B * C)
+        ldt = (T + 3) // 4 * 4
+        x3 = x.contiguous().view(B, C, T)
+        f32 = dict(device=x.device, dtype=torch.float32)
+        if ldt != T:
+            xp = torch.empty(B, C, ldt, **f32)
+            K.repack(x3, T, xp, ldt, B * C, T)
+        else:
+            xp = x3
+        yp = torch.empty_like(xp)
+        mean, rstd = torch.empty(B, T, **f32), torch.empty(B, T, **f32)
+        ws = torch.empty(B, 2, T, device=x.device, dtype=torch.float64)
+        g1, b1 = gamma.reshape(C).contiguous(), beta.reshape(C).contiguous()
+        K.cln_fwd(xp, g1, b1, yp, mean, rstd, ws, B, C, T, ldt, eps)
+        if ldt != T:
+            y = torch.empty(B, C, T, **f32)
+            K.repack(yp, ldt, y, T, B * C, T)
+        else:
+            y = yp
+        ctx.save_for_backward(xp, g1, mean, rstd)
+        ctx.geom = (B, C, T, ldt, eps, x.shape, gamma.shape)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        K = sepkernels.backend()
+        xp, g1, mean, rstd = ctx.saved_tensors
+        B, C, T, ldt, eps, shape, pshape = ctx.geom
+        f32 = dict(device=xp.device, dtype=torch.float32)
+        dy3 = dy.contiguous().view(B, C, T)
+        if ldt != T:
+            dyp = torch.empty_like(xp)
+            K.repack(dy3, T, dyp, ldt, B * C, T)
+        else:
+            dyp = dy3
+        dxp = torch.empty_like(xp)
+        pg, pb = torch.empty(B, C, **f32), torch.empty(B, C, **f32)
+        ws = torch.empty(B, 2, T, device=xp.device, dtype=torch.float64)
+        K.cln_bwd(dyp, xp, g1, mean, rstd, dxp, pg, pb, ws, B, C, T, ldt, eps)
+        dgamma, dbeta = torch.empty(C, **f32), torch.empty(C, **f32)
+        K.reduce_slabs([(pg, 0, dgamma, C, B, C, 0, 1.0), (pb, 0, dbeta, C, B, C, 0, 1.0)])
+        if ldt != T:
+            dx = torch.empty(B, C, T, **f32)
+            K.repack(dxp, ldt, dx, T, B * C, T)
+        else:
+            dx = dxp
+        return dx.view(shape), dgamma.view(pshape), dbeta.view(pshape), None
+
+
 class CumulativeLayerNorm1d(nn.Module):
     def __init__(self, num_features, eps=EPS):
         super().__init__()
@@ -100,6 +156,13 @@ class CumulativeLayerNorm1d(nn.Module):
         the (biased) variance of everything up to and including frame t: C * (t + 1) values."""
         if input.dim() not in (3, 4):
             raise ValueError("Only support 3D or 4D input, but given {}D".format(input.dim()))
+        if input.dtype == torch.float32 and (input.is_cuda or sepkernels.backend().name != "hip"):
+            return _CumulativeLayerNormFn.apply(input, self.gamma, self.beta, self.eps)
+        return self._compose(input)
+
+    def _compose(self, input):
+        """the same arithmetic as a torch composition: float64 inputs (the CPU reference checks) and tensors the backend
+        does not take (CPU tensors on the HIP build, used by the fallback path's tests)"""
         shape = input.shape
         x = input.reshape(shape[0], shape[1], -1)
         C, T = x.shape[1], x.shape[2]

@@ -33,7 +33,7 @@ extern "C" {
 
 typedef void* sep_stream_t; /* hipStream_t */
 
-#define SEP_ABI_VERSION 9
+#define SEP_ABI_VERSION 10
 #define SEP_STATS_SLOTS 16
 
 int sep_version(void);
@@ -244,6 +244,16 @@ int sep_decoder_bwd(const float* d_est, const float* w, const float* m, const fl
  * on y (B, C, ldt); backward in place on g given the forward output y: g <- y * (g - sum_c g*y).  Frames >= T are zeroed. */
 int sep_softmax_ch_fwd(float* y, int B, int C, int T, int ldt, sep_stream_t stream);
 int sep_softmax_ch_bwd(const float* y, float* g, int B, int C, int T, int ldt, sep_stream_t stream);
+
+/* Cumulative layer norm (causal cLN), CumulativeLayerNorm1d of reference src/modules/norm.py:42-101 and its autograd backward:
+ *   y = (x - m_t) / (sqrt(v_t) + eps) * gamma_c + beta_c with the mean / biased variance of all channels and frames <= t.
+ * x, y, dy, dx: (B, C, ldt) fp32, frames contiguous, ldt % 4 == 0, frames >= T written as zeros; mean, rstd: (B, T) fp32, written
+ * by the forward and read by the backward; ws: (B, 2, T) fp64 scratch (column sums, then their prefix / suffix sums);
+ * dgamma_part, dbeta_part: (B, C) per-sample sums, to be added over the samples (sep_reduce_slabs). */
+int sep_cln_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, double* ws, int B, int C,
+                int T, int ldt, float eps, sep_stream_t stream);
+int sep_cln_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
+                float* dgamma_part, float* dbeta_part, double* ws, int B, int C, int T, int ldt, float eps, sep_stream_t stream);
 
 /* Stand-alone gLN (modules/norm.py:11-35) for callers outside the fused network. */
 int sep_gln_stats(const float* x, double* stats, int B, int C, int T, int ldt, sep_stream_t stream);

@@ -328,6 +328,38 @@ class EmuBackend:
         v[:, :, T:] = 0
         g.copy_(v)
 
+    # ------------------------------------------------------------------ cumulative layer norm
+    def cln_fwd(self, x, gamma, beta, y, mean, rstd, ws, B, C, T, ldt, eps):
+        v = x.reshape(B, C, ldt)[:, :, :T].double()
+        n = torch.arange(1, T + 1, dtype=torch.float64) * C
+        m = v.sum(1).cumsum(1) / n
+        var = ((v * v).sum(1).cumsum(1) / n - m * m).clamp_min(0)
+        r = 1.0 / (var.sqrt() + eps)
+        mean.reshape(B, T).copy_(m.float())
+        rstd.reshape(B, T).copy_(r.float())
+        out = torch.zeros(B, C, ldt, dtype=x.dtype)
+        mf, rf = mean.reshape(B, 1, T), rstd.reshape(B, 1, T)
+        out[:, :, :T] = (x.reshape(B, C, ldt)[:, :, :T] - mf) * rf * gamma.view(1, C, 1) + beta.view(1, C, 1)
+        y.reshape(B, C, ldt).copy_(out)
+
+    def cln_bwd(self, dy, x, gamma, mean, rstd, dx, dgamma_part, dbeta_part, ws, B, C, T, ldt, eps):
+        g = dy.reshape(B, C, ldt)[:, :, :T].double()
+        v = x.reshape(B, C, ldt)[:, :, :T].double()
+        m, r = mean.reshape(B, 1, T).double(), rstd.reshape(B, 1, T).double()
+        gh = g * gamma.view(1, C, 1).double()
+        A, Bq = gh.sum(1), (gh * (v - m)).sum(1)
+        n = torch.arange(1, T + 1, dtype=torch.float64) * C
+        sigma = 1.0 / r[:, 0] - eps
+        Dq = torch.where(sigma > 0, -Bq * r[:, 0] ** 2 / (2 * sigma.clamp_min(1e-300)), torch.zeros_like(Bq))
+        Dm = -r[:, 0] * A - 2 * m[:, 0] * Dq
+        P = (Dm / n).flip(1).cumsum(1).flip(1).unsqueeze(1)
+        Q = (Dq / n).flip(1).cumsum(1).flip(1).unsqueeze(1)
+        out = torch.zeros(B, C, ldt, dtype=x.dtype)
+        out[:, :, :T] = (gh * r + P + 2 * v * Q).float()
+        dx.reshape(B, C, ldt).copy_(out)
+        dgamma_part.reshape(B, C).copy_((g * (v - m) * r).sum(2).float())
+        dbeta_part.reshape(B, C).copy_(g.sum(2).float())
+
     # ------------------------------------------------------------------ stand-alone gLN
     def gln_stats(self, x, stats, B, C, T, ldt):
         v = x.reshape(B, C, ldt)[:, :, :T]

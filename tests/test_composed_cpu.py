@@ -147,3 +147,34 @@ def test_data_parallel_replica_finds_its_parameters(golden_dir, emu):
     for k, p in model.named_parameters():
         gr = torch.from_numpy(g["grad/" + k]).double()
         assert p.grad is not None and (p.grad - gr).abs().max() <= 2e-6 * max(gr.abs().max().item(), 1e-6), k
+
+
+def test_cln_kernel_contract_via_emulator():
+    """CumulativeLayerNorm1d through the C-ABI contract (sep_cln_fwd / sep_cln_bwd as restated by the CPU emulator): forward and
+    all three gradients against autograd of the float64 composition (reference src/modules/norm.py:58-101)."""
+    import sepkernels
+    from emulator import EmuBackend
+    from modules.norm import CumulativeLayerNorm1d
+    old = sepkernels._set_backend_for_tests(EmuBackend())
+    try:
+        torch.manual_seed(5)
+        B, C, T = 3, 24, 203
+        m32 = CumulativeLayerNorm1d(C)
+        with torch.no_grad():
+            m32.gamma.copy_(torch.randn(1, C, 1))
+            m32.beta.copy_(torch.randn(1, C, 1))
+        m64 = CumulativeLayerNorm1d(C).double()
+        m64.load_state_dict({k: v.double() for k, v in m32.state_dict().items()})
+        x = (torch.randn(B, C, T) * torch.linspace(0.2, 3.0, T) + 0.7).requires_grad_(True)
+        x64 = x.detach().double().requires_grad_(True)
+        w = torch.randn(B, C, T)
+        (m32(x) * w).sum().backward()
+        (m64(x64) * w.double()).sum().backward()
+        assert (m32(x).detach().double() - m64(x64).detach()).abs().max() < 2e-5
+        for a, b in ((x.grad, x64.grad), (m32.gamma.grad, m64.gamma.grad), (m32.beta.grad, m64.beta.grad)):
+            assert (a.double() - b).abs().max() <= 3e-5 * b.abs().max()
+        # 4-D input (batch, C, S, chunk): same arithmetic on the flattened frames
+        x4 = torch.randn(2, C, 7, 12)
+        assert (m32(x4).double() - m64(x4.double())).abs().max() < 2e-5
+    finally:
+        sepkernels._set_backend_for_tests(old)

@@ -502,6 +502,49 @@ def test_gln_standalone_and_repack():
     both("repack", [rnd(B * C, T), T, nan(B * C, ldt), ldt, B * C, T])
 
 
+# ------------------------------------------------------------------------------------------- cumulative layer norm
+@pytest.mark.parametrize("B,C,T", [(2, 24, 203), (3, 128, 3999), (1, 512, 5003)])
+def test_cln_fwd_bwd(B, C, T):
+    """sep_cln_fwd / sep_cln_bwd against the float64 composition of reference src/modules/norm.py:58-101 and its autograd
+    backward (T > 1024 and > 4096: the prefix / suffix scans carry across tiles; ldt > T: pad frames come out as zeros)."""
+    ldt = (T + 3) // 4 * 4
+    torch.manual_seed(B * 1000 + C)
+    x = torch.zeros(B, C, ldt)
+    x[..., :T] = torch.randn(B, C, T) * torch.linspace(0.3, 2.5, T) + 0.4          # non-stationary, non-zero mean
+    gamma, beta, dy = torch.randn(C) + 1, torch.randn(C), torch.zeros(B, C, ldt)
+    dy[..., :T] = torch.randn(B, C, T)
+    eps = 1e-12
+    x64 = x[..., :T].double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    n = torch.arange(1, T + 1, dtype=torch.float64) * C
+    m = x64.sum(1).cumsum(1) / n
+    v = (x64 * x64).sum(1).cumsum(1) / n - m * m
+    y64 = (x64 - m.unsqueeze(1)) / (v.sqrt().unsqueeze(1) + eps) * g64.view(1, C, 1) + b64.view(1, C, 1)
+    (y64 * dy[..., :T].double()).sum().backward()
+    f32 = dict(device="cuda", dtype=torch.float32)
+    y, mean, rstd = torch.full((B, C, ldt), float("nan"), **f32), torch.empty(B, T, **f32), torch.empty(B, T, **f32)
+    ws = torch.empty(B, 2, T, device="cuda", dtype=torch.float64)
+    HIP.cln_fwd(x.cuda(), gamma.cuda(), beta.cuda(), y, mean, rstd, ws, B, C, T, ldt, eps)
+    dx, pg, pb = torch.full((B, C, ldt), float("nan"), **f32), torch.empty(B, C, **f32), torch.empty(B, C, **f32)
+    HIP.cln_bwd(dy.cuda(), x.cuda(), gamma.cuda(), mean, rstd, dx, pg, pb, ws, B, C, T, ldt, eps)
+    torch.cuda.synchronize()
+    y, dx = y.cpu(), dx.cpu()
+    assert torch.isfinite(y).all() and torch.isfinite(dx).all()
+    assert (y[..., T:] == 0).all() and (dx[..., T:] == 0).all()
+    assert (mean.cpu().double() - m.detach()).abs().max() <= 2e-6 * (1 + m.detach().abs().max())
+    assert (y[..., :T].double() - y64.detach()).abs().max() <= 2e-5 * y64.detach().abs().max()
+    assert (dx[..., :T].double() - x64.grad).abs().max() <= 5e-5 * x64.grad.abs().max()
+    assert (pg.cpu().double().sum(0) - g64.grad).abs().max() <= 5e-5 * g64.grad.abs().max()
+    assert (pb.cpu().double().sum(0) - b64.grad).abs().max() <= 5e-5 * b64.grad.abs().max()
+    # and the emulator's restatement of the same contract
+    ye, me, re_ = torch.empty(B, C, ldt), torch.empty(B, T), torch.empty(B, T)
+    EMU.cln_fwd(x, gamma, beta, ye, me, re_, None, B, C, T, ldt, eps)
+    assert (ye - y).abs().max() <= 2e-5 * ye.abs().max()
+    dxe, pge, pbe = torch.empty(B, C, ldt), torch.empty(B, C), torch.empty(B, C)
+    EMU.cln_bwd(dy, x, gamma, me, re_, dxe, pge, pbe, None, B, C, T, ldt, eps)
+    assert (dxe - dx).abs().max() <= 5e-5 * dxe.abs().max() and (pge - pg.cpu()).abs().max() <= 5e-5 * pge.abs().max()
+
+
 # ------------------------------------------------------------------------------------------- losses / optimiser
 @pytest.mark.parametrize("n,all_pairs", [(1, 0), (2, 1), (4, 1), (3, 0)])
 def test_sisdr_kernels(n, all_pairs):
