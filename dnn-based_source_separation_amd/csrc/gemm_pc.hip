@@ -105,7 +105,7 @@ __device__ __forceinline__ void pcd_unroll(F&& f) {      // f(integral_constant<
 }
 
 template <int WR, int WC, int PRO, bool SPLIT, int EF, int NS, int NB>
-__global__ __launch_bounds__(512, 2) void pw_gemm_pcd_kernel(const sep_gemm_desc d) {
+__global__ __launch_bounds__(512, 2) void pw_gemm_pc_kernel(const sep_gemm_desc d) {
     constexpr bool P_PRELU = PRO == SEP_PRO_PRELU || PRO == SEP_PRO_GLN_PRELU;
     constexpr bool P_GLN = PRO == SEP_PRO_GLN || PRO == SEP_PRO_GLN_PRELU;
     constexpr bool P_BWD = PRO == SEP_PRO_GLN_BWD;
@@ -567,7 +567,7 @@ void launch_pcd(const sep_gemm_desc& d, hipStream_t stream) {
     const int NR = d.M / (64 * WR);
     const int NC = d.B * (d.ldt / (128 * WC));
     const int grid = 8 * NR * ceil_div(NC, 8);
-    hipLaunchKernelGGL((pw_gemm_pcd_kernel<WR, WC, PRO, SPLIT, EF, NS, NB>), dim3(grid), dim3(512), 0, stream, d);
+    hipLaunchKernelGGL((pw_gemm_pc_kernel<WR, WC, PRO, SPLIT, EF, NS, NB>), dim3(grid), dim3(512), 0, stream, d);
 }
 
 }  // namespace
