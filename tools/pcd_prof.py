@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(ROOT, "dnn-based_source_separation_amd", "src"))
 import numpy as np
 import torch
 import sepkernels
-from sepkernels import EPI_RESIDUAL, EPI_PRELU_BWD, PRO_GLN, PRO_GLN_PRELU, STATS_SLOTS
+from sepkernels import EPI_RESIDUAL, EPI_PRELU_BWD, EPI_ROWSUMS, EPI_ROWSUMS_PRELU, EPI_STATS_PRELU, PRO_GLN, PRO_GLN_PRELU, STATS_SLOTS
 K = sepkernels.HipBackend()
 lib = ctypes.CDLL(sepkernels.LIB_PATH)
 B, T, ldt, H, Bn, Sc, N = 16, 3999, 4096, 512, 128, 128, 512
@@ -18,10 +18,17 @@ cases = {
     "F3": dict(M=Bn + Sc, K=H, A=f(Bn + Sc, H), X=f(B, H, ldt), Y=f(B, Bn, ldt), Y2=f(B, Sc, ldt), m_split=Bn, bias=f(Bn + Sc), accumulate=1, epi_flags=EPI_RESIDUAL, epi_res=f(B, Bn, ldt),
                pro_mode=PRO_GLN_PRELU, pro_stats=st(), pro_gamma=f(H), pro_beta=f(H), pro_alpha=al, count=H * T),
     "P0": dict(M=H, K=H, A=f(H, H), X=f(B, H, ldt), Y=f(B, H, ldt)),
+    "F2": dict(M=H, K=Bn, A=f(H, Bn), X=f(B, Bn, ldt), Y=f(B, H, ldt), bias=f(H), epi_flags=EPI_STATS_PRELU, epi_alpha=al, epi_stats=st()),
+    "G3": dict(M=H, K=Bn + Sc, trans_a=1, A=f(Bn, H), A2=f(Sc, H), X=f(B, Bn, ldt), X2=f(B, Sc, ldt), k_split=Bn, Y=f(B, H, ldt),
+               epi_flags=EPI_ROWSUMS | EPI_ROWSUMS_PRELU, epi_aux=f(B, H, ldt), epi_alpha=al, epi_rowpart=torch.zeros(B, H, ldt // 64, 2, device="cuda")),
 }
 for which in sys.argv[1:] or ["F1", "F3", "P0"]:
     kw = dict(cases[which])
-    kw["A_pk"] = K.pack_weights([(kw["A"], kw["M"], kw["K"], 0)])[0]
+    if kw.get("trans_a"):
+        W = torch.cat([kw["A"].reshape(-1, kw["M"]), kw["A2"].reshape(-1, kw["M"])], 0).contiguous()
+        kw["A_pk"] = K.pack_weights([(W, kw["K"], kw["M"], 1)])[0]
+    else:
+        kw["A_pk"] = K.pack_weights([(kw["A"], kw["M"], kw["K"], 0)])[0]
     for _ in range(3):
         K.pw_gemm(B=B, T=T, ldt=ldt, eps=1e-12, **kw)
     torch.cuda.synchronize()
