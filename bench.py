@@ -369,7 +369,7 @@ def main():
                                "sep_pw_gemm: pw_gemm_pc_kernel (K >= 512 or M >= 1024) / pw_gemm_coop_kernel")
         # the weight gradient keeps the exact three-way bf16 split in every non-f32 arithmetic
         roof_w = kernel_roofline(timed, "pw_wgrad", "f32" if arith_name == "f32" else "bf16x6", args.steps, el_i,
-                                 "sep_pw_wgrad: pw_wgrad_split_kernel" if arith_name != "f32" else "sep_pw_wgrad: pw_wgrad_direct_kernel")
+                                 "sep_pw_wgrad: pw_wgrad_pc_kernel" if arith_name != "f32" else "sep_pw_wgrad: pw_wgrad_direct_kernel")
     # N = 1 only: the same K steps with sep_pw_gemm / sep_pw_wgrad on the fp32 MFMA instruction (v_mfma_f32_32x32x2_f32), i.e. the
     # reference's own arithmetic, reported beside the headline with its own roofline (peak 157.3 TFLOP/s)
     f32_pass = None
