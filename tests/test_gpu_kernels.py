@@ -226,6 +226,34 @@ def test_gemm_gln_bwd_prologue(residual, arith):
     both("pw_gemm", [], kw)
 
 
+@pytest.mark.parametrize("alpha", [-0.3, 0.0, 1.0, 1.7])
+def test_gemm_prelu_prologues_any_slope(alpha):
+    """The producer / consumer kernel has a two-instruction PReLU (max(x, alpha x)) for 0 <= alpha <= 1 and the general form
+    otherwise: both, at the boundaries, for the three prologues that contain a PReLU (packed weights, K multiple of 64)."""
+    PACKED[0] = True
+    try:
+        al = torch.tensor([alpha])
+        B, Bn, Sc, H, T, ldt = 2, 128, 128, 512, 500, 512           # K = 512, M = 1024, K = 512: the shapes the dispatch gives to gemm_pc.hip
+        z = padded(B, H, T, ldt) * 1.5 + 0.2
+        z[..., T:] = 0
+        st = stats_of(torch.where(z > 0, z, alpha * z), T)
+        both("pw_gemm", [], dict(B=B, M=Bn + Sc, K=H, T=T, ldt=ldt, A=rnd(Bn + Sc, H, scale=H ** -0.5), X=z, Y=nan(B, Bn, ldt), Y2=padded(B, Sc, T, ldt),
+                                 m_split=Bn, bias=rnd(Bn + Sc), accumulate=1, epi_flags=EPI_RESIDUAL, epi_res=padded(B, Bn, T, ldt), pro_mode=PRO_GLN_PRELU,
+                                 pro_stats=st, pro_gamma=rnd(H) + 1, pro_beta=rnd(H), pro_alpha=al, count=H * T, eps=1e-12))
+        M, K = 1024, 128
+        both("pw_gemm", [], dict(B=B, M=M, K=K, T=T, ldt=ldt, A=rnd(M, K, scale=K ** -0.5), X=padded(B, K, T, ldt), Y=nan(B, M, ldt), bias=rnd(M),
+                                 pro_mode=PRO_PRELU, pro_alpha=al, epi_flags=EPI_SIGMOID))
+        M, K = 128, 512
+        a = padded(B, K, T, ldt)
+        dv = padded(B, K, T, ldt)
+        both("pw_gemm", [], dict(B=B, M=M, K=K, T=T, ldt=ldt, trans_a=1, A=rnd(K, M, scale=0.1), X=dv, Y=nan(B, M, ldt), pro_mode=PRO_GLN_BWD,
+                                 pro_stats=stats_of(torch.where(a > 0, a, alpha * a), T), pro_gamma=rnd(K) + 1, pro_alpha=al, pro_aux=a,
+                                 pro_bsum=rnd(B, 2, scale=0.01), pro_store=dv, pro_dalpha=torch.zeros(1, dtype=torch.float64), count=K * T, eps=1e-12,
+                                 epi_flags=EPI_RESIDUAL, epi_res=padded(B, M, T, ldt)))
+    finally:
+        PACKED[0] = False
+
+
 @pytest.mark.parametrize("M,K,T", [(128, 512, 3999), (256, 512, 1000), (512, 128, 3999), (1024, 128, 700), (128, 1024, 450), (512, 256, 2100)])
 def test_gemm_packed_weights_model_shapes(M, K, T):
     """The packed-weight kernel at the (M, K) pairs of the paper-best model -- one and two 32-row blocks per wave, short and
