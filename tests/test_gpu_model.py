@@ -426,6 +426,34 @@ def test_paper_best_four_speakers_sinkpit_full_size():
     assert torch.equal(pat_s.cpu(), pat_h.cpu())
 
 
+def test_paper_best_four_speakers_sinkpit_against_oracle():
+    """BASELINE.json configs[4] at one utterance: forward, Sinkhorn-PIT (k = 200) loss and every parameter gradient against the
+    fp64 CPU port (oracle/fast_port.py forward + oracle/convtasnet_oracle.py sinkpit)."""
+    from criterion.pit import SinkPIT
+    from oracle import convtasnet_oracle as O
+    cfg = dict(PAPER, n_sources=4)
+    torch.manual_seed(23)
+    model = ConvTasNet(**cfg)
+    p = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(19)
+    sources = 0.1 * torch.randn(1, 4, 32000, generator=g)
+    mixture = sources.sum(1, keepdim=True)
+    pp = {k: v.double().requires_grad_(True) for k, v in p.items()}
+    ref_out, _ = FP.conv_tasnet(mixture.double(), pp, cfg)
+    ref_loss, ref_P = O.sinkpit(lambda a, b, batch_mean=False: O.neg_sisdr(a, b, batch_mean=batch_mean), ref_out, sources.double(), coldness=1.0, iteration=200)
+    ref_loss.backward()
+    ref_grads = {k: v.grad for k, v in pp.items()}
+    model.cuda()
+    est = model(mixture.cuda())
+    assert _rel(est, ref_out.detach()) <= TOL
+    loss, pattern = SinkPIT(NegSISDR(), n_sources=4, coldness=1.0, iteration=200)(est, sources.cuda())
+    assert abs(loss.item() - ref_loss.item()) <= TOL * abs(ref_loss.item())
+    assert torch.equal(pattern.cpu().view(-1), ref_P.detach().argmax(dim=2).view(-1))
+    loss.backward()
+    flat_rel, worst = _grad_report(model, ref_grads)
+    assert flat_rel <= TOL, "flat gradient rel-inf {:.3e}, worst tensor {}".format(flat_rel, worst)
+
+
 def test_music_recipe_shapes_long_rows_and_generic_filterbank_paths():
     """SURVEY.md section 8f rank 3 (musdb18 / WHAM callers): stereo input, kernel 20 / stride 10 (Cout*L = 40: the generic
     encoder / decoder kernels), 2 s @ 44.1 kHz -> 8,819 frames per row (> 7,680: the tiled depthwise backward), 4 sources.
