@@ -177,6 +177,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
 // layer of the TCN): one workgroup = one (b, c) row; a thread produces float4s of output from three float4 loads
 // (t-d, t, t+d; for d < 4 the two neighbouring float4s and a register shuffle).  The neighbours are another thread's
 // centre, so two of the three loads hit L1/L2; nothing goes through LDS and there is no barrier before the stores.
+// (Issuing all of a thread's loads before the first use, as dwconv_bwd_row_kernel does, was measured 6 % SLOWER here.)
 // DM: 0 -> d % 4 == 0, 1 -> d == 1, 2 -> d == 2.
 // =====================================================================================
 template <int DM>
@@ -342,12 +343,16 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(
 }
 
 // =====================================================================================
-// Same backward, one workgroup per (b, c) ROW: dz and u1 of the whole row live in LDS (2 x ldt floats), so there is no
-// halo to re-load or re-compute (the 1024-frame tiles of the kernel above re-do 25 % of the row at dilation 128), every
-// global access is a float4 and a thread has twelve of them in flight.  ALIGNED: d % 4 == 0 (ds_read_b128 neighbours).
-// Writes the row totals into tile 0 of rowpart and zeros into the other tiles (the finalize kernel sums over tiles).
+// Same backward, one workgroup per (b, c) ROW: dz of the whole row lives in LDS (ldt floats), so there is no halo to re-load
+// or re-compute (the 1024-frame tiles of the kernel above re-do 25 % of the row at dilation 128) and every global access is
+// a float4.  u1 never goes to LDS: the three correlation sums are re-indexed onto the thread's own frame,
+//   sum_t dz[t] v1[t-d] = sum_s v1[s] dz[s+d],   sum_t dz[t] v1[t+d] = sum_s v1[s] dz[s-d]      (dz = 0 outside [0, T)),
+// so a thread keeps the PReLU1 outputs of its NIT float4 in registers across the barrier: 16 KiB of LDS per workgroup at
+// ldt = 4096 instead of 32 (8 workgroups per CU instead of 4) and half the LDS traffic.  ALIGNED: d % 4 == 0 (ds_read_b128
+// neighbours); NIT >= ldt / 1024.  Writes the row totals into tile 0 of rowpart and zeros into the other tiles (the
+// finalize kernel sums over tiles).
 // =====================================================================================
-template <bool ALIGNED>
+template <bool ALIGNED, int NIT>
 __global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
     const float* __restrict__ dv2, const float* __restrict__ z, const float* __restrict__ a,
     const double* __restrict__ stats1, const float* __restrict__ gamma1, const float* __restrict__ beta1,
@@ -357,7 +362,6 @@ __global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float part[4][8];
     float* dzs = lds;
-    float* us = lds + ldt;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int row = blockIdx.x;
     const int b = row / C, c = row % C;
@@ -369,74 +373,86 @@ __global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
     const float g2 = gamma2[c];
     const float mg = bsum2[2 * b], mgx = bsum2[2 * b + 1];
     const size_t rowoff = (size_t)row * ldt;
+    const int nq4 = ldt / 4;
     float q_dal = 0.f;
-    for (int q = threadIdx.x; q < ldt / 4; q += 256) {
-        const int tp = 4 * q;
-        const float4 gv = ld4(dv2 + rowoff + tp);
-        const float4 zv = ld4(z + rowoff + tp);
-        const float4 av = ld4(a + rowoff + tp);
-        const float g4[4] = {gv.x, gv.y, gv.z, gv.w};
-        const float z4[4] = {zv.x, zv.y, zv.z, zv.w};
-        const float a4[4] = {av.x, av.y, av.z, av.w};
-        float dzv[4], uv[4];
+    float4 gv[NIT], zv[NIT], av[NIT];
+    float uv[NIT][4];
+    // all global reads of the row first: 3 * NIT float4 in flight per thread
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            dzv[e] = 0.f; uv[e] = 0.f;
-            if (tp + e < T) {
-                const float u2 = prelu_f(z4[e], a2);
-                const float xh = (u2 - mu2) * r2;
-                const float du2 = r2 * (g2 * g4[e] - mg - xh * mgx);
-                dzv[e] = du2 * prelu_grad(z4[e], a2);
-                uv[e] = prelu_f(a4[e], a1);
-                if (z4[e] <= 0.f) q_dal = fmaf(du2, z4[e], q_dal);
-            }
+    for (int k = 0; k < NIT; ++k) {
+        const int q = threadIdx.x + 256 * k;
+        if (q < nq4) {
+            gv[k] = ld4(dv2 + rowoff + 4 * q);
+            zv[k] = ld4(z + rowoff + 4 * q);
+            av[k] = ld4(a + rowoff + 4 * q);
         }
-        st4(dzs + tp, make_float4(dzv[0], dzv[1], dzv[2], dzv[3]));
-        st4(us + tp, make_float4(uv[0], uv[1], uv[2], uv[3]));
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int q = threadIdx.x + 256 * k;
+        if (q < nq4) {
+            const int tp = 4 * q;
+            const float g4[4] = {gv[k].x, gv[k].y, gv[k].z, gv[k].w};
+            const float z4[4] = {zv[k].x, zv[k].y, zv[k].z, zv[k].w};
+            const float a4[4] = {av[k].x, av[k].y, av[k].z, av[k].w};
+            float dzv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dzv[e] = 0.f; uv[k][e] = 0.f;
+                if (tp + e < T) {
+                    const float u2 = prelu_f(z4[e], a2);
+                    const float xh = (u2 - mu2) * r2;
+                    const float du2 = r2 * (g2 * g4[e] - mg - xh * mgx);
+                    dzv[e] = du2 * prelu_grad(z4[e], a2);
+                    uv[k][e] = prelu_f(a4[e], a1);
+                    if (z4[e] <= 0.f) q_dal = fmaf(du2, z4[e], q_dal);
+                }
+            }
+            st4(dzs + tp, make_float4(dzv[0], dzv[1], dzv[2], dzv[3]));
+        }
     }
     __syncthreads();
     const float w0 = wd[c * 3 + 0], w1 = wd[c * 3 + 1], w2 = wd[c * 3 + 2];
     float* orow = dv1 + rowoff;
     float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f, q4 = 0.f, q5 = 0.f;
-    for (int q = threadIdx.x; q < ldt / 4; q += 256) {
-        const int t = 4 * q;
-        const float4 dzc4 = ld4(dzs + t), uc4 = ld4(us + t);
-        float dzm[4], dzp[4], um[4], up[4];
-        if (ALIGNED) {
-            const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 m1 = t - d >= 0 ? ld4(dzs + t - d) : zero4, p1 = t + d < ldt ? ld4(dzs + t + d) : zero4;
-            const float4 m2 = t - d >= 0 ? ld4(us + t - d) : zero4, p2 = t + d < ldt ? ld4(us + t + d) : zero4;
-            dzm[0] = m1.x; dzm[1] = m1.y; dzm[2] = m1.z; dzm[3] = m1.w;
-            dzp[0] = p1.x; dzp[1] = p1.y; dzp[2] = p1.z; dzp[3] = p1.w;
-            um[0] = m2.x; um[1] = m2.y; um[2] = m2.z; um[3] = m2.w;
-            up[0] = p2.x; up[1] = p2.y; up[2] = p2.z; up[3] = p2.w;
-        } else {
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int q = threadIdx.x + 256 * k;
+        if (q < nq4) {
+            const int t = 4 * q;
+            const float4 dzc4 = ld4(dzs + t);
+            float dzm[4], dzp[4];
+            if (ALIGNED) {
+                const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 m1 = t - d >= 0 ? ld4(dzs + t - d) : zero4, p1 = t + d < ldt ? ld4(dzs + t + d) : zero4;
+                dzm[0] = m1.x; dzm[1] = m1.y; dzm[2] = m1.z; dzm[3] = m1.w;
+                dzp[0] = p1.x; dzp[1] = p1.y; dzp[2] = p1.z; dzp[3] = p1.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int tm = t + e - d, tq = t + e + d;
+                    dzm[e] = tm >= 0 ? dzs[tm] : 0.f;
+                    dzp[e] = tq < ldt ? dzs[tq] : 0.f;
+                }
+            }
+            const float dzc[4] = {dzc4.x, dzc4.y, dzc4.z, dzc4.w};
+            float o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int tm = t + e - d, tq = t + e + d;
-                dzm[e] = tm >= 0 ? dzs[tm] : 0.f; um[e] = tm >= 0 ? us[tm] : 0.f;
-                dzp[e] = tq < ldt ? dzs[tq] : 0.f; up[e] = tq < ldt ? us[tq] : 0.f;
+                const int te = t + e;
+                float dv = 0.f;
+                if (te < T) {
+                    // dv1[t] = sum_k w[k] * dz[t - (k-1) d];  dz is zero outside [0, T) by construction
+                    dv = w0 * dzp[e] + w1 * dzc[e] + w2 * dzm[e];
+                    // v1 = gLN1(u1) inside [0,T) (the zero padding is applied after the norm and is covered by dz = 0 there)
+                    const float v0 = fmaf(uv[k][e], sc1, sh1);
+                    q0 += dv; q1 = fmaf(dv, uv[k][e], q1);
+                    q2 += dzc[e]; q3 = fmaf(dzp[e], v0, q3); q4 = fmaf(dzc[e], v0, q4); q5 = fmaf(dzm[e], v0, q5);
+                }
+                o[e] = dv;
             }
+            st4(orow + t, make_float4(o[0], o[1], o[2], o[3]));
         }
-        const float dzc[4] = {dzc4.x, dzc4.y, dzc4.z, dzc4.w}, uc[4] = {uc4.x, uc4.y, uc4.z, uc4.w};
-        float o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int te = t + e;
-            float dv = 0.f;
-            if (te < T) {
-                // dv1[t] = sum_k w[k] * dz[t - (k-1) d];  dz is zero outside [0, T) by construction
-                dv = w0 * dzp[e] + w1 * dzc[e] + w2 * dzm[e];
-                // v1 = gLN1(u1) inside [0,T), literal zero outside (padding is applied after the norm)
-                const float vm = (te - d >= 0) ? fmaf(um[e], sc1, sh1) : 0.f;
-                const float v0 = fmaf(uc[e], sc1, sh1);
-                const float vp = (te + d < T) ? fmaf(up[e], sc1, sh1) : 0.f;
-                q0 += dv; q1 = fmaf(dv, uc[e], q1);
-                q2 += dzc[e]; q3 = fmaf(dzc[e], vm, q3); q4 = fmaf(dzc[e], v0, q4); q5 = fmaf(dzc[e], vp, q5);
-            }
-            o[e] = dv;
-        }
-        st4(orow + t, make_float4(o[0], o[1], o[2], o[3]));
     }
     q0 = wave_sum(q0); q1 = wave_sum(q1); q2 = wave_sum(q2); q3 = wave_sum(q3);
     q4 = wave_sum(q4); q5 = wave_sum(q5); q_dal = wave_sum(q_dal);
@@ -983,11 +999,13 @@ extern "C" int sep_dwconv_bwd(const float* dv2, const float* z, const float* a, 
     SEP_REQUIRE(B > 0 && C > 0 && T > 0 && ldt % 128 == 0 && ldt >= T, "sep_dwconv_bwd: bad sizes");
     SEP_REQUIRE(dilation >= 1 && dilation <= 2048, "sep_dwconv_bwd: dilation %d out of range [1, 2048]", dilation);
     static const bool force_tiles = getenv("SEPK_DWCONV_LDS") != nullptr;
-    if (!force_tiles && ldt <= 7680 && (long)B * C <= 0x7fffffffL) {        // the row (2 x ldt floats) fits 60 KiB of LDS
-        const size_t rsmem = 2 * (size_t)ldt * sizeof(float);
+    if (!force_tiles && ldt <= 8192 && (long)B * C <= 0x7fffffffL) {        // the row (ldt floats of LDS, ldt / 1024 float4 triples in registers)
+        const size_t rsmem = (size_t)ldt * sizeof(float);
         const dim3 grid((unsigned)((long)B * C));
-        if (dilation % 4 == 0) hipLaunchKernelGGL((dwconv_bwd_row_kernel<true>), grid, dim3(256), rsmem, (hipStream_t)stream, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bsum2, wd, dv1, rowpart, C, T, ldt, dilation, eps);
-        else hipLaunchKernelGGL((dwconv_bwd_row_kernel<false>), grid, dim3(256), rsmem, (hipStream_t)stream, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bsum2, wd, dv1, rowpart, C, T, ldt, dilation, eps);
+#define SEP_DWB(AL, NIT) hipLaunchKernelGGL((dwconv_bwd_row_kernel<AL, NIT>), grid, dim3(256), rsmem, (hipStream_t)stream, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bsum2, wd, dv1, rowpart, C, T, ldt, dilation, eps)
+        if (dilation % 4 == 0) { if (ldt <= 4096) SEP_DWB(true, 4); else SEP_DWB(true, 8); }
+        else { if (ldt <= 4096) SEP_DWB(false, 4); else SEP_DWB(false, 8); }
+#undef SEP_DWB
         SEP_CHECK_LAUNCH("sep_dwconv_bwd");
         return 0;
     }
