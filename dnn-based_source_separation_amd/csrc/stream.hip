@@ -1044,6 +1044,80 @@ extern "C" int sep_head_bwd(float* dvw, const float* w, const float* dwm, const 
     return 0;
 }
 
+namespace {
+
+// =====================================================================================
+// Decoder forward for the mono 16-tap / stride-8 basis (Cout*L = 16, R = 2): one workgroup = 64 frames, a 256-byte ALIGNED
+// run of every row, of one sample for ALL its sources, so w is read once and every mask once, two full cache lines per
+// wave load (the 63-frame tiles of the general kernel start on odd frames: three lines per 256 bytes, and every source
+// re-read w: 797 MB fetched for 402).  No halo frame: the eight samples a tile shares with its neighbour are added with
+// atomicAdd onto a zeroed `est` by both of them (two addends: the sum does not depend on the order), the rest are stores.
+// Four waves split the basis rows; lane = frame; the decoder row D[n][:] is wave-uniform (scalar loads).
+// =====================================================================================
+template <int NSRC>
+__global__ __launch_bounds__(256) void decoder_fwd16_kernel(const float* __restrict__ w, const float* __restrict__ m, const float* __restrict__ D,
+                                                            float* __restrict__ est, float* __restrict__ latent, int n_src, int N, int F,
+                                                            int ldt, int Tout, int pad_left) {
+    constexpr int RU = 4;                             // rows per trip: RU * (1 + n_src) independent loads in flight per lane (8 rows: 197 us instead of 134)
+    __shared__ float ys[4][NSRC][64][17];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.y, f0 = blockIdx.x * 64, f = f0 + lane;
+    const bool fvalid = f < F;
+    const float* wrow = w + (size_t)b * N * ldt + f;
+    const float* mrow = m + (size_t)b * n_src * N * ldt + f;
+    float* lrow = latent ? latent + (size_t)b * n_src * N * ldt + f : nullptr;
+    float acc[NSRC][16];
+#pragma unroll
+    for (int s = 0; s < NSRC; ++s)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[s][q] = 0.f;
+    const int nper = (N + 3) / 4;
+    const int n_lo = wv * nper, n_hi = n_lo + nper < N ? n_lo + nper : N;
+    for (int n = n_lo; n < n_hi; n += RU) {
+        float wv4[RU], mv4[NSRC][RU];
+#pragma unroll
+        for (int r = 0; r < RU; ++r) {
+            const bool ok = n + r < n_hi;
+            wv4[r] = ok ? wrow[(size_t)(n + r) * ldt] : 0.f;
+#pragma unroll
+            for (int s = 0; s < NSRC; ++s) mv4[s][r] = ok && s < n_src ? mrow[((size_t)s * N + n + r) * ldt] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < RU; ++r) {
+            if (n + r >= n_hi) break;
+            const float* Dn = D + (size_t)(n + r) * 16;
+#pragma unroll
+            for (int s = 0; s < NSRC; ++s) {
+                if (s >= n_src) break;
+                const float wh = fvalid ? wv4[r] * mv4[s][r] : 0.f;
+                if (lrow) lrow[((size_t)s * N + n + r) * ldt] = wh;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[s][q] = fmaf(wh, Dn[q], acc[s][q]);
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NSRC; ++s)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) ys[wv][s][lane][q] = acc[s][q];
+    __syncthreads();
+    // overlap-add: padded sample 8*f + k of this tile, o = 8*(f - f0) + k in [0, 520): frame o/8 at tap k (o < 512) and frame o/8 - 1 at tap k + 8 (o >= 8)
+    for (int j = threadIdx.x; j < 520 * n_src; j += 256) {
+        const int s = j / 520, o = j % 520;
+        const int tau = 8 * f0 + o - pad_left;
+        if (tau < 0 || tau >= Tout) continue;
+        const int fo = o >> 3, k = o & 7;
+        float v = 0.f;
+        if (fo < 64) v += (ys[0][s][fo][k] + ys[1][s][fo][k]) + (ys[2][s][fo][k] + ys[3][s][fo][k]);
+        if (fo >= 1) v += (ys[0][s][fo - 1][k + 8] + ys[1][s][fo - 1][k + 8]) + (ys[2][s][fo - 1][k + 8] + ys[3][s][fo - 1][k + 8]);
+        float* dst = est + ((size_t)b * n_src + s) * Tout + tau;
+        if (o < 8 || o >= 512) atomicAdd(dst, v);          // shared with the neighbouring tile
+        else *dst = v;
+    }
+}
+
+}  // namespace
+
 extern "C" int sep_decoder_fwd(const float* w, const float* m, const float* D, float* est, float* latent, int B, int n_src,
                                int N, int Cout, int L, int S, int F, int ldt, int Tout, int pad_left, sep_stream_t stream) {
     SEP_REQUIRE(w && m && D && est, "sep_decoder_fwd: null pointer");
@@ -1051,6 +1125,15 @@ extern "C" int sep_decoder_fwd(const float* w, const float* m, const float* D, f
     const int LC = Cout * L;
     SEP_REQUIRE(LC <= 144, "sep_decoder_fwd: Cout*L=%d too large for the LDS frame buffer", LC);
     SEP_REQUIRE((long)B * n_src <= 65535, "sep_decoder_fwd: B*n_src too large");
+    if (LC == 16 && L == 16 && S == 8 && n_src <= 4 && ldt % 64 == 0 && B <= 65535) {
+        // est is completed by stores and by two-addend atomic adds at the tile seams: it starts from zero
+        SEP_REQUIRE(hipMemsetAsync(est, 0, (size_t)B * n_src * Tout * sizeof(float), (hipStream_t)stream) == hipSuccess, "sep_decoder_fwd: memset failed");
+        const dim3 g16(ldt / 64, B);
+        if (n_src <= 2) hipLaunchKernelGGL(decoder_fwd16_kernel<2>, g16, dim3(256), 0, (hipStream_t)stream, w, m, D, est, latent, n_src, N, F, ldt, Tout, pad_left);
+        else hipLaunchKernelGGL(decoder_fwd16_kernel<4>, g16, dim3(256), 0, (hipStream_t)stream, w, m, D, est, latent, n_src, N, F, ldt, Tout, pad_left);
+        SEP_CHECK_LAUNCH("sep_decoder_fwd");
+        return 0;
+    }
     const int R = L / S, FB = (LC == 16 ? 64 : 256) - (R - 1);
     SEP_REQUIRE(FB > 0, "sep_decoder_fwd: kernel_size / stride too large");
     dim3 grid(ceil_div(ldt + R - 1, FB), B * n_src);

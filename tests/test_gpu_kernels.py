@@ -481,7 +481,7 @@ def test_head_bwd(relu):
 
 
 # ------------------------------------------------------------------------------------------- decoder
-@pytest.mark.parametrize("n_src,Cout,L,S,pad_left,latent", [(2, 1, 16, 8, 0, True), (3, 1, 16, 8, 3, False), (5, 1, 16, 8, 0, False),
+@pytest.mark.parametrize("n_src,Cout,L,S,pad_left,latent", [(2, 1, 16, 8, 0, True), (3, 1, 16, 8, 3, False), (5, 1, 16, 8, 0, False), (4, 1, 16, 8, 5, True),
                                                             (2, 2, 20, 10, 4, True), (2, 1, 2, 1, 0, False), (1, 1, 64, 16, 0, False)])
 def test_decoder_fwd_bwd(n_src, Cout, L, S, pad_left, latent):
     B, N, F = 2, 64, 300
