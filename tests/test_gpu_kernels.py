@@ -370,7 +370,10 @@ def _wgrad_both(kw, tol=3e-4):
 def test_gemm_split_arithmetic_is_as_accurate_as_fp32_mfma(K, scale):
     """Against fp64: the errors of the bf16x6 and f16x3 paths are at the level of the fp32-MFMA path's (all are fp32
     products with fp32 accumulation), over wide dynamic range of the operands (the bf16 split is exact for any finite fp32
-    value; the fp16 split is scaled per column of X)."""
+    value; the fp16 split is scaled per column of X).  The two-part fp16 split carries 22 significand bits against fp32's 24, i.e.
+    up to 4x the rounding error of a single product; at short contractions that is what shows (K = 128: ratio 2.0 median, 3.6
+    worst over 12 operand draws, tools/_acc.py on the GPU box), at K >= 512 the fp32 accumulation both share dominates (1.1-1.5)."""
+    G.manual_seed(1000 + K)                                          # own operand draw: independent of which tests ran before
     B, M, T = 2, 256, 1000
     ldt = 1024
     X = padded(B, K, T, ldt) * torch.exp(3 * rnd(B, K, 1))          # rows of very different magnitude
@@ -386,8 +389,8 @@ def test_gemm_split_arithmetic_is_as_accurate_as_fp32_mfma(K, scale):
         err[name] = (d.abs().max().item() / ref.abs().max().item(), (d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item())
     assert err["bf16x6"][0] <= max(2 * err["f32"][0], 2e-7), err
     assert err["bf16x6"][1] <= max(2 * err["f32"][1], 1e-7), err
-    assert err["f16x3"][0] <= max(3 * err["f32"][0], 3e-7), err          # error relative to |A||X| per output, like fp32's
-    assert err["f16x3"][1] <= max(3 * err["f32"][1], 2e-7), err
+    assert err["f16x3"][0] <= max(4 * err["f32"][0], 3e-7), err          # error relative to |A||X| per output, like fp32's
+    assert err["f16x3"][1] <= max(4 * err["f32"][1], 2e-7), err
     assert err["f32"][0] <= 5e-6, err
 
 
