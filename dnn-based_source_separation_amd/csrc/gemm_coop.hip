@@ -25,7 +25,9 @@
 // with prologue + split of kc+1 -> ds_write operands of kc+1 -> wait (DMA group kc+1 landed) + barrier -> DMA group kc+NS.
 // DMA group g = {A chunk g, raw X chunk g+1}: the raw X ring runs one chunk ahead of the A ring.
 #include "gemm_common.hpp"
+#include <stddef.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #ifdef COOP_PROF
 __device__ long long g_coop_prof[4][64][8];      // [sampled block][step][stamp]
@@ -48,21 +50,51 @@ constexpr int COMAXK = 512;      // rows of the per-row affine table of the gLN 
 template <int MI, int NS, bool AUX>
 struct __attribute__((aligned(16))) CoopSmem {
     double red[8];
-    float As[NS][128 * MI * DK];             // A operand image: per 32-row block [hi | lo][lane][16 B], a straight copy of the packed layout
     float Bs[NS][4 * RBI];                   // raw X chunk as DMA'd
     float Cs[AUX ? NS : 1][AUX ? 4 * RBI : 4];   // GLN_BWD: the pre-activation chunk
     float Bp[2][CBN * 16];                   // split X chunk [col][4 x 16 B], same granule swizzle
     int be[2][CBN];                          // its per-column scale exponents
     float sc[COMAXK];
     float sh[AUX ? 4 : COMAXK];
+    float epi_pad[(4 * EPI_WAVE_FLOATS > NS * 4 * RBI + (AUX ? NS * 4 * RBI : 4) + 2 * CBN * 16 + 2 * CBN + COMAXK + (AUX ? 4 : COMAXK))
+                      ? 4 * EPI_WAVE_FLOATS - (NS * 4 * RBI + (AUX ? NS * 4 * RBI : 4) + 2 * CBN * 16 + 2 * CBN + COMAXK + (AUX ? 4 : COMAXK)) : 4];
+                                             // the epilogue transposes through this block from Bs on: keep it large enough
 };
 
 template <int MI, int NS, bool BWD>
 constexpr int coop_occupancy() {
-    return (int)((160 * 1024) / ((sizeof(CoopSmem<MI, NS, BWD>) + 511) / 512 * 512)) > 4 ? 4
-         : (int)((160 * 1024) / ((sizeof(CoopSmem<MI, NS, BWD>) + 511) / 512 * 512));
+    // registers, not LDS, bound the residency now: 64 accumulators + two operand sets (64) + the splitter's values need ~160 VGPRs
+    // with two 32-row blocks per wave (3 waves per SIMD), ~120 with one (4)
+    constexpr int by_lds = (int)((160 * 1024) / ((sizeof(CoopSmem<MI, NS, BWD>) + 511) / 512 * 512));
+    constexpr int by_regs = MI == 2 ? 3 : 4;
+    return by_lds < by_regs ? by_lds : by_regs;
 }
 
+// single-instruction forms hipcc does not emit by itself (see gemm_pc.hip): v_max_f32 without the canonicalising v_max(x, x), the quad
+// maximum as two dpp instructions, lo = x - float(hi half) as one mixed-precision FMA
+__device__ __forceinline__ float co_vmax(const float a, const float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float co_quad_max(const float m) {               // max over the four lanes of a quad, in every lane
+    float r, t;
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=&v"(t) : "v"(m));
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=&v"(r) : "v"(t));
+    return r;
+}
+__device__ __forceinline__ void co_split2_pair(const float x0, const float x1, unsigned& hi, unsigned& lo) {
+    const fp16x2_t h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+    hi = __builtin_bit_cast(unsigned, h);
+    float l0, l1;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(x0), "v"(hi));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(x1), "v"(hi));
+    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l0, l1));
+}
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void pco_unroll(F&& f) {      // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); pco_unroll<N, I + 1>(f); }
+}
 __device__ __forceinline__ f32x16 mfma_f16(const u32x4_t a, const u32x4_t b, const f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
 }
@@ -88,12 +120,9 @@ void pw_gemm_coop_kernel(const sep_gemm_desc d) {
     constexpr bool P_BWD = PRO == SEP_PRO_GLN_BWD;
     constexpr int RW = 32 * MI;                          // rows per wave
     constexpr int BMc = 4 * RW;                          // rows per workgroup
-    constexpr int G = 2 * MI + 1 + (P_BWD ? 1 : 0);      // DMA instructions per wave and group
-    // stores of the GLN_BWD store-back share vmcnt with the DMAs and may retire out of order with them: plain vmcnt(0) there
-    constexpr int KEEP = P_BWD ? 0 : (NS - 2) * G;
-    static_assert(KEEP < 64, "vmcnt field");
     __shared__ CoopSmem<MI, NS, P_BWD> sm;
-    static_assert(sizeof(sm) - 64 >= 4 * EPI_WAVE_FLOATS * sizeof(float), "epilogue transpose buffer");
+    using CoSmem = CoopSmem<MI, NS, P_BWD>;
+    static_assert(sizeof(CoSmem) - offsetof(CoSmem, Bs) >= 4 * EPI_WAVE_FLOATS * sizeof(float), "epilogue transpose buffer");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lk = lane >> 5, l31 = lane & 31;
@@ -133,20 +162,16 @@ void pw_gemm_coop_kernel(const sep_gemm_desc d) {
     // the loop would be vmcnt(0) and drain the ring
     asm volatile("" :: "v"(alpha_p), "v"(mu), "v"(rstd), "v"(mg), "v"(mgx));
 
-    // ---- DMA sources: wave-uniform base (SGPR pair, advanced with scalar adds) + a per-lane 32-bit byte offset -------
+    // ---- X: LDS-DMA ring of raw chunks (wave-uniform base in an SGPR pair + a per-lane 32-bit byte offset).  A: straight from the
+    // packed matrix into registers, one chunk ahead (operand-block layout: 1 KiB per 32-row block, chunk and part, lane-linear;
+    // L2-resident, perfectly coalesced): no LDS copy of A, one DMA instruction per wave and chunk instead of five. ----------------
     const int Ks1 = SPLIT ? d.k_split : d.K;
     const int split_chunk = SPLIT ? d.k_split / DK : -1;
     const size_t stepX = (size_t)DK * d.ldt;
     const unsigned offX = 4u * (unsigned)((lane >> 4) * d.ldt + 4 * (lane & 15));
     const float* baseX = d.X + ((size_t)b * Ks1 + 4 * wid) * d.ldt + t0;
     const float* baseC = P_BWD ? d.pro_aux + ((size_t)b * Ks1 + 4 * wid) * d.ldt + t0 : nullptr;
-    const float* baseA = reinterpret_cast<const float*>(d.A_pk);
-    // piece q = 2 * mi + part of this wave: 1 KiB at ((block * nk + chunk) * 2 + part) KiB of the packed matrix
-    unsigned offA[2 * MI];
-#pragma unroll
-    for (int q = 0; q < 2 * MI; ++q)
-        offA[q] = 16u * (unsigned)lane + 1024u * (unsigned)((((m0 + wid * RW) >> 5) + (q >> 1)) * nk * 2 + (q & 1));
-    int xi = 0, xst = 0, ai = 0, ast = 0;      // next chunk to issue and its ring stage, per operand
+    int xi = 0, xst = 0;                       // next chunk to issue and its ring stage
     auto issue_x = [&]() {
         if (SPLIT && xi == split_chunk) baseX = d.X2 + ((size_t)b * (d.K - d.k_split) + 4 * wid) * d.ldt + t0;
         glds16_asm(baseX, offX, lds_addr(&sm.Bs[xst][wid * RBI]));
@@ -156,17 +181,8 @@ void pw_gemm_coop_kernel(const sep_gemm_desc d) {
         ++xi;
         xst = xst + 1 == NS ? 0 : xst + 1;
     };
-    auto issue_a = [&]() {
-#pragma unroll
-        for (int q = 0; q < 2 * MI; ++q) glds16_asm(baseA, offA[q], lds_addr(&sm.As[ast][(wid * RW + 16 * q) * DK]));
-        baseA += 512;                                                  // 2 KiB: the next chunk of every block
-        ++ai;
-        ast = ast + 1 == NS ? 0 : ast + 1;
-    };
-    auto issue_group = [&]() {
-        if (ai < nk) issue_a();
-        if (xi < nk) issue_x();
-    };
+    const char* Apk = reinterpret_cast<const char*>(d.A_pk) + (size_t)((m0 + wid * RW) >> 5) * nk * 2048;     // wave-uniform
+    const unsigned a_lane = 16u * (unsigned)lane;
 
     f32x16 acc[MI][2];
 #pragma unroll
@@ -191,10 +207,11 @@ void pw_gemm_coop_kernel(const sep_gemm_desc d) {
     const int s_lo = col_s * 16 + 4 * ((2 * (kq >> 1) + 1) ^ s_fsw) + 2 * (kq & 1);
     const bool s_live = t0 + col_s < d.T;
     const unsigned st_lane_off = 4u * (unsigned)(4 * kq * d.ldt + col_s);   // GLN_BWD store-back: this thread's byte offset in a chunk
-    int bexp = 0;                                                    // scale exponent of this thread's column ...
-    bool bset = false;                                               // ... chosen yet?  (stays unset while the column has only seen zeros)
+    constexpr int UNSET = 10000;                                     // scale exponent of a column that has only seen zeros: any first maximum
+    int bexp = UNSET;                                                // "outgrows" it, and ldexp(0, UNSET) stays 0
+    const bool fast_prelu = alpha_p >= 0.f && alpha_p <= 1.f;        // PReLU(x) = max(x, alpha x) there
 
-    float raw[4], aux[4];
+    float raw[4], aux[4], v[4];
     float4 sc4 = make_float4(0.f, 0.f, 0.f, 0.f), sh4 = sc4;
     auto read_raw = [&](const int stage, const int kn) {
         const float* Bb = sm.Bs[stage];
@@ -208,11 +225,10 @@ void pw_gemm_coop_kernel(const sep_gemm_desc d) {
         if (P_GLN || P_BWD) sc4 = ld4(&sm.sc[kn * DK + 4 * kq]);
         if (P_GLN) sh4 = ld4(&sm.sh[kn * DK + 4 * kq]);
     };
-    // prologue + column scale + split of this thread's four values of chunk kn, operand-ready into Bp[pb]
-    auto split_chunk_vals = [&](const int kn, const int pb) {
+    // prologue of this thread's four values of chunk kn -> v[]
+    auto pro_vals = [&](const int kn) {
         const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
         const float shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
-        float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float x = raw[j];
@@ -230,36 +246,48 @@ void pw_gemm_coop_kernel(const sep_gemm_desc d) {
                 }
                 x = da;
             } else {
-                if (P_PRELU) x = prelu_f(x, alpha_p);
-                if (P_GLN) x = x * scv[j] + shv[j];
+                if (P_PRELU) x = fast_prelu ? co_vmax(x, alpha_p * x) : prelu_f(x, alpha_p);
+                if (P_GLN) x = fmaf(x, scv[j], shv[j]);
             }
             v[j] = x;
         }
+    };
+    // column scale of the chunk (the column's 16 values sit in the four lanes of a quad): branch-free, see gemm_pc.hip
+    auto scale_vals = [&]() {
         float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-        m = quad_max(m);                                                 // the column's maximum over the 16 k of the chunk
+        m = co_quad_max(m);
         const int e = __builtin_amdgcn_frexp_expf(m);                    // m = f * 2^e, f in [0.5, 1)
-        if (m > 0.f && (!bset || e + bexp > 14)) bexp = 9 - e;          // first non-zero chunk, or the column outgrew its scale
-        bset = bset || m > 0.f;
+        const int e2 = __builtin_bit_cast(int, m) == 0 ? -3 * UNSET : e; // a chunk of zeros never moves the scale
+        bexp = e2 + bexp > 14 ? 9 - e : bexp;                            // first non-zero chunk, or the column outgrew its scale
+    };
+    unsigned h01, l01, h23, l23;
+    auto split_vals = [&]() {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = __builtin_ldexpf(v[j], bexp);
-        unsigned h01, l01, h23, l23;
-        split2_pair(v[0], v[1], h01, l01);
-        split2_pair(v[2], v[3], h23, l23);
+        co_split2_pair(v[0], v[1], h01, l01);
+        co_split2_pair(v[2], v[3], h23, l23);
+    };
+    auto write_vals = [&](const int pb) {
         float* Bp = sm.Bp[pb];
         *reinterpret_cast<uint2*>(Bp + s_hi) = make_uint2(h01, h23);
         *reinterpret_cast<uint2*>(Bp + s_lo) = make_uint2(l01, l23);
-        if (kq == 0) sm.be[pb][col_s] = bexp;
+        sm.be[pb][col_s] = bexp;                                         // the four lanes of the quad store the same word
     };
 
-    u32x4_t pa[MI][2], pbv[2][2];
+    // operand registers: A of two consecutive chunks (pa[s & 1]: loaded at the start of step s-1, a whole step ahead), B of the chunk
+    // being multiplied (read at the start of its step; the other two or three waves of the SIMD cover that LDS round trip)
+    u32x4_t pa[2][MI][2], pbv[2][2];
     int en[2];
-    auto read_operands = [&](const int astage, const int pb) {
-        const float* Ab = sm.As[astage] + wid * RW * DK;
+    auto load_a = [&](auto setc, const int chunk) {
+        constexpr int q = decltype(setc)::value;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-            pa[mi][0] = *reinterpret_cast<const u32x4_t*>(Ab + mi * 32 * DK + 4 * lane);
-            pa[mi][1] = *reinterpret_cast<const u32x4_t*>(Ab + mi * 32 * DK + 256 + 4 * lane);
+            const char* src = Apk + ((size_t)mi * nk + chunk) * 2048;
+            pa[q][mi][0] = *reinterpret_cast<const u32x4_t*>(src + a_lane);
+            pa[q][mi][1] = *reinterpret_cast<const u32x4_t*>(src + 1024 + a_lane);
         }
+    };
+    auto read_b = [&](const int pb) {
         const float* Bp = sm.Bp[pb];
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
@@ -268,73 +296,93 @@ void pw_gemm_coop_kernel(const sep_gemm_desc d) {
             en[ni] = sm.be[pb][ni * 32 + l31];
         }
     };
-    auto mfma_part = [&](const int asel, const int bsel) {
+    auto rescale = [&]() {                                               // the accumulators follow their column's scale
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+        for (int ni = 0; ni < 2; ++ni) {
+            const int delta = en[ni] - bcur[ni];
+            if (__builtin_amdgcn_ballot_w64(delta != 0) != 0) {          // rare after the first chunks
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma_f16(pa[mi][asel], pbv[ni][bsel], acc[mi][ni]);
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = __builtin_ldexpf(acc[mi][ni][r], delta);
+            }
+            bcur[ni] = en[ni];
+        }
+    };
+    constexpr int NM = 6 * MI;                                           // MFMAs per chunk: parts hi*lo, lo*hi, hi*hi over MI x 2 blocks
+    auto M = [&](auto setc, auto ic) {
+        constexpr int q = decltype(setc)::value, i = decltype(ic)::value;
+        constexpr int part = i / (2 * MI), mi = (i % (2 * MI)) / 2, ni = i % 2;
+        constexpr int asel = part == 1 ? 1 : 0, bsel = part == 0 ? 1 : 0;
+        acc[mi][ni] = mfma_f16(pa[q][mi][asel], pbv[ni][bsel], acc[mi][ni]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#define CO_I(k) std::integral_constant<int, (k)>{}
+#define CO_SB() __builtin_amdgcn_sched_barrier(0)
+    constexpr int GX = P_BWD ? 2 : 1;                                    // DMA instructions per wave and chunk
+    // at the barrier of step s raw X(s+2) must have landed; younger in the queue and allowed to fly on: the A loads of chunk s+1 (issued
+    // at the start of step s) and, with a ring of three, one more X group.  The GLN_BWD store-back shares vmcnt and may retire out of
+    // order with the loads: plain vmcnt(0) there.
+    constexpr int KEEP = P_BWD ? 0 : (NS - 2) * GX + 2 * MI;
+    static_assert(KEEP < 64, "vmcnt field");
+    // One pipeline step = one chunk: its MFMAs with everything else of the step woven between them and pinned -- an in-order wave that
+    // issues [reads | split | 12 MFMAs | DMA] one after the other leaves the matrix pipe idle through three of the four phases
+    // (tools/coop_prof.py: 1950 cycles per chunk for 384 cycles of MFMAs).
+    auto step = [&](auto pc, const int s) {
+        constexpr int P = decltype(pc)::value;
+        const bool more = s + 1 < nk;
+        read_b(s & 1);                                                   // operands of chunk s (written before the last barrier)
+        if (more) {
+            read_raw((s + 1) % NS, s + 1);
+            load_a(CO_I(P ^ 1), s + 1);                                  // set P ^ 1 was multiplied in the previous step
+        }
+        CO_SB();
+        rescale();
+        CO_SB();
+        pco_unroll<NM / 3>([&](auto ic) { M(CO_I(P), ic); });
+        if (more) pro_vals(s + 1);
+        CO_SB();
+        pco_unroll<NM / 6>([&](auto ic) { M(CO_I(P), CO_I(decltype(ic)::value + NM / 3)); });
+        if (more) scale_vals();
+        CO_SB();
+        pco_unroll<NM / 6>([&](auto ic) { M(CO_I(P), CO_I(decltype(ic)::value + NM / 2)); });
+        if (more) split_vals();
+        CO_SB();
+        pco_unroll<NM / 6>([&](auto ic) { M(CO_I(P), CO_I(decltype(ic)::value + 2 * NM / 3)); });
+        if (more) write_vals((s + 1) & 1);
+        CO_SB();
+        pco_unroll<NM / 6>([&](auto ic) { M(CO_I(P), CO_I(decltype(ic)::value + 5 * NM / 6)); });
+        if (more) {
+            // raw X(s+2) has landed -- mine: all but the younger loads; everyone's: the barrier --, the operands of chunk s+1 are
+            // written, and every wave is past its reads of this step's stages
+            if (KEEP > 0 && s + NS < nk) wait_vm_lgkm0_barrier<KEEP>();
+            else wait_vm_lgkm0_barrier<0>();
+            if (xi < nk) issue_x();                                      // X(s+NS+1) into the raw stage this step has read
+        }
     };
 
     if (!dead_tile) {
-        // ---- fill the rings: X0, then groups 0 .. NS-2 ------------------------------------------------------------------
+        // ---- fill the raw ring: X0 .. X(NS-1); A(0) ----------------------------------------------------------------------
         __syncthreads();                               // prologue tables visible (no DMA in flight yet: drains nothing)
         issue_x();
 #pragma unroll
-        for (int g = 0; g < NS - 1; ++g) issue_group();
-        wait_vm_lgkm0_barrier<0>();                    // X0 (and with it groups 0 .. NS-2) landed
+        for (int g = 0; g < NS - 1; ++g)
+            if (xi < nk) issue_x();
+        load_a(CO_I(0), 0);
+        wait_vm_lgkm0_barrier<0>();                    // X0 (and everything else) landed
         read_raw(0, 0);
-        split_chunk_vals(0, 0);
+        pro_vals(0);
+        scale_vals();
+        split_vals();
+        write_vals(0);
         wait_vm_lgkm0_barrier<0>();                    // operands of chunk 0 visible; raw stage 0 free
-        issue_group();                                 // group NS-1: A(NS-1), X(NS) -> raw stage 0
-
-        int astage = 0, xstage = 1 % NS;               // ring stages of A(kc) and raw X(kc+1)
-#ifdef COOP_PROF
-        const int pslot = bid == 8 ? 0 : bid == 801 ? 1 : bid == 1602 ? 2 : bid == (int)gridDim.x - 9 ? 3 : -1;
-#endif
-        for (int kc = 0; kc < nk; ++kc) {
-            const int pb = kc & 1;
-            const bool more = kc + 1 < nk;
-            CSTAMP(0);
-            read_operands(astage, pb);
-            if (more) read_raw(xstage, kc + 1);
-#ifdef COOP_PROF
-            __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): operands have arrived
-            CSTAMP(1);
-#endif
-            // the accumulators follow their column's scale
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int delta = en[ni] - bcur[ni];
-                if (__builtin_amdgcn_ballot_w64(delta != 0) != 0) {        // rare after the first chunks
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = __builtin_ldexpf(acc[mi][ni][r], delta);
-                }
-                bcur[ni] = en[ni];
-            }
-            mfma_part(0, 1);
-            mfma_part(1, 0);
-            if (more) split_chunk_vals(kc + 1, pb ^ 1);
-            mfma_part(0, 0);
-            CSTAMP(2);
-            if (more) {
-                // DMA group kc+1 (A(kc+1), raw X(kc+2)) has landed -- mine: all but the newer groups; everyone's: barrier --
-                // the operands of chunk kc+1 are written, and every wave is past its reads of this step's stages
-#ifdef COOP_PROF
-                if (KEEP > 0 && kc + NS < nk) __builtin_amdgcn_s_waitcnt(0x0070 | (KEEP & 15) | ((KEEP >> 4) << 14));
-                else __builtin_amdgcn_s_waitcnt(0x0070);
-                CSTAMP(3);
-#endif
-                if (KEEP > 0 && kc + NS < nk) wait_vm_lgkm0_barrier<KEEP>();
-                else wait_vm_lgkm0_barrier<0>();
-                CSTAMP(4);
-                issue_group();                                           // group kc+NS into the stages this step freed
-                CSTAMP(5);
-                astage = astage + 1 == NS ? 0 : astage + 1;
-                xstage = xstage + 1 == NS ? 0 : xstage + 1;
-            }
+        if (xi < nk) issue_x();                        // X(NS) -> raw stage 0
+        int s = 0;
+        for (; s + 1 < nk; s += 2) {
+            step(CO_I(0), s);
+            step(CO_I(1), s + 1);
         }
+        if (s < nk) step(CO_I(0), s);
         // undo the column scales (the row scales of A leave in the epilogue)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -349,7 +397,7 @@ void pw_gemm_coop_kernel(const sep_gemm_desc d) {
     asm volatile("" : "+v"(etid), "+s"(eb), "+s"(em0), "+s"(et0));
     const int ewid = __builtin_amdgcn_readfirstlane(etid >> 6);
     const int elane = etid & 63;
-    gemm_epilogue<EF, MI, true, 4, COOP_PIPE>(d, acc, eb, em0, et0, ewid, 0, elane >> 5, elane & 31, etid, &sm.As[0][0], sm.red, CBN);
+    gemm_epilogue<EF, MI, true, 4, COOP_PIPE>(d, acc, eb, em0, et0, ewid, 0, elane >> 5, elane & 31, etid, &sm.Bs[0][0], sm.red, CBN);
     if (P_BWD && rt == 0) {
         const double sdal = block_sum_256<double>((double)dalpha_pro, sm.red);
         if (tid == 0) atomicAdd(d.pro_dalpha, sdal);
