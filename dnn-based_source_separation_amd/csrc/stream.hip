@@ -73,6 +73,44 @@ __global__ __launch_bounds__(256) void encoder_fwd_kernel(const float* __restric
     if (tid == 0) { double* st = stats + ((size_t)b * SEP_STATS_SLOTS + (blockIdx.x & (SEP_STATS_SLOTS - 1))) * 2; atomicAdd(st, ds); atomicAdd(st + 1, dss); }
 }
 
+// Mono 16-tap / stride-8 encoder (the paper-best front end): a lane owns FOUR consecutive frames (40 input samples in registers),
+// so every store of w is a float4 -- 1 KiB per wave instruction instead of 256 B (the dword-per-lane form is store-issue bound:
+// 81 us for 131 MB).  One workgroup = 256 frames of one sample; its four waves take the basis rows n = wave (mod 4).
+__global__ __launch_bounds__(256) void encoder_fwd_l16s8_kernel(const float* __restrict__ x, const float* __restrict__ E, float* __restrict__ w,
+                                                                double* __restrict__ stats, int Tin, int N, int F, int ldt, int pad_left, int relu) {
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int f = blockIdx.x * 256 + 4 * lane;            // first of this lane's four frames
+    float xr[40];
+#pragma unroll
+    for (int i = 0; i < 40; ++i) {
+        const int tau = 8 * f + i - pad_left;
+        xr[i] = (tau >= 0 && tau < Tin) ? x[(size_t)b * Tin + tau] : 0.f;
+    }
+    float s = 0.f, ss = 0.f;
+    if (f < ldt) {
+        for (int n = wv; n < N; n += 4) {
+            const float* En = E + (size_t)n * 16;         // wave-uniform: scalar loads
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc = fmaf(En[k], xr[8 * j + k], acc);
+                if (relu) acc = fmaxf(acc, 0.f);
+                if (f + j >= F) acc = 0.f;
+                s += acc; ss = fmaf(acc, acc, ss);
+                o[j] = acc;
+            }
+            st4(w + ((size_t)b * N + n) * ldt + f, make_float4(o[0], o[1], o[2], o[3]));
+        }
+    }
+    const double ds = block_sum_256<double>((double)s, red);
+    const double dss = block_sum_256<double>((double)ss, red);
+    if (threadIdx.x == 0) { double* st = stats + ((size_t)b * SEP_STATS_SLOTS + (blockIdx.x & (SEP_STATS_SLOTS - 1))) * 2; atomicAdd(st, ds); atomicAdd(st + 1, dss); }
+}
+
 // frames[bp][c*L+k][f] = xpad[bp][c][S f + k] (f < F), 0 for F <= f < ldt
 __global__ __launch_bounds__(256) void unfold_kernel(const float* __restrict__ x, float* __restrict__ frames, int C,
                                                      int Tin, int L, int S, int F, int ldt, int pad_left) {
@@ -953,6 +991,11 @@ extern "C" int sep_encoder_fwd(const float* x, const float* E, float* w, double*
     const int span = ENC_FT * S + L - S;
     const size_t smem = (size_t)Cin * span * sizeof(float);
     SEP_REQUIRE(smem <= 150 * 1024, "sep_encoder_fwd: Cin*(128*S+L-S) floats exceed LDS (Cin=%d L=%d S=%d)", Cin, L, S);
+    if (Cin == 1 && L == 16 && S == 8 && B <= 65535) {
+        hipLaunchKernelGGL(encoder_fwd_l16s8_kernel, dim3(ceil_div(ldt, 256), B), dim3(256), 0, (hipStream_t)stream, x, E, w, stats, Tin, N, F, ldt, pad_left, relu);
+        SEP_CHECK_LAUNCH("sep_encoder_fwd");
+        return 0;
+    }
     dim3 grid(ldt / ENC_FT, B);
     if (Cin * L == 16)
         hipLaunchKernelGGL(encoder_fwd_kernel<16>, grid, dim3(256), smem, (hipStream_t)stream, x, E, w, stats, B, Cin, Tin, N, L, S, F, ldt, pad_left, relu);
