@@ -372,7 +372,7 @@ def test_gemm_split_arithmetic_is_as_accurate_as_fp32_mfma(K, scale):
     products with fp32 accumulation), over wide dynamic range of the operands (the bf16 split is exact for any finite fp32
     value; the fp16 split is scaled per column of X).  The two-part fp16 split carries 22 significand bits against fp32's 24, i.e.
     up to 4x the rounding error of a single product; at short contractions that is what shows (K = 128: ratio 2.0 median, 3.6
-    worst over 12 operand draws, tools/_acc.py on the GPU box), at K >= 512 the fp32 accumulation both share dominates (1.1-1.5)."""
+    worst over 12 operand draws, tools/split_ratio.py on the GPU box), at K >= 512 the fp32 accumulation both share dominates (1.1-1.5)."""
     G.manual_seed(1000 + K)                                          # own operand draw: independent of which tests ran before
     B, M, T = 2, 256, 1000
     ldt = 1024

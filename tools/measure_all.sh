@@ -1,3 +1,5 @@
+# The measurement recipe behind profiles/r02*: full GPU test suite, bench JSON, rocprofv3 kernel trace, the PMC passes and the traffic
+# table, all written to gpurun_out/<tag>_*.  Run on the GPU box:  gpurun -- 'bash tools/measure_all.sh r02x'
 cd $GRAFT_REPO_ROOT
 tag=${1:-r02g}
 export PYTHONPATH=dnn-based_source_separation_amd/src

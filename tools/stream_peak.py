@@ -1,3 +1,5 @@
+"""Development tool: what plain streaming kernels reach on this part (torch copy / add / sum / fill at 131 MB - 2 GB): the practical
+HBM ceiling the depthwise / head / tail kernels are compared with in DESIGN.md (add: 6.0 TB/s, copy 4.8-6.9, fill 6.4-6.9)."""
 import torch
 def t(fn, n=30):
     for _ in range(5): fn()
