@@ -10,20 +10,22 @@
 // kernel showed the matrix pipe ~16 % busy and the VALU saturated by the splits (profiles/r01k_sq_counters.txt):
 //
 //  * A (the weights) is split ONCE per pass by sep_pack_weights into {hi[8], lo[8]} fp16 groups, 4 bytes per weight like
-//    the fp32 matrix, with one scale per ROW of A (undone in the epilogue together with the bias add).  The LDS image a
-//    DMA leaves is already the MFMA A operand: two ds_read_b128 per 32-row block and chunk, zero VALU.  The packer also
-//    writes the transposed / concatenated forms, so the kernel has one operand path for forward and input gradients.
+//    the fp32 matrix, with one scale per ROW of A (undone in the epilogue together with the bias add), in an operand-block
+//    layout: the 1 KiB a wave needs for one 32-row block, chunk and part is contiguous and lane-linear, i.e. one
+//    global_load_dwordx4 per lane IS the MFMA A operand -- no LDS copy, zero VALU.  The packer also writes the transposed /
+//    concatenated forms, so the kernel has one operand path for forward and input gradients.
 //  * X is put through the prologue (PReLU / gLN / gLN-backward) and split ONCE PER WORKGROUP: the four waves of a
 //    workgroup are stacked along the rows (wave tile 32*MI x 64) over ONE 64-column tile, each thread prepares 4 of the
 //    1024 values of a 16-deep chunk and writes them operand-ready to LDS, from where all four waves read them with
-//    ds_read_b128.  Per MFMA the kernel now issues ~1/6 of the VALU of the per-wave split.
+//    ds_read_b128.  Per MFMA the kernel issues ~1/6 of the VALU of the per-wave split.
 //  * The per-column scale (a column of X is an accumulator column, owned by a lane) is chosen by the quad of threads that
 //    prepares the column (two DPP max) and handed over with the operands; a consumer lane rescales its accumulators when
 //    its column's exponent changes (rare after the first chunks).
 //
-// Pipeline per 16-deep chunk kc, ONE barrier: [ds_read operands of kc | ds_read raw X of kc+1] -> MFMAs of kc interleaved
-// with prologue + split of kc+1 -> ds_write operands of kc+1 -> wait (DMA group kc+1 landed) + barrier -> DMA group kc+NS.
-// DMA group g = {A chunk g, raw X chunk g+1}: the raw X ring runs one chunk ahead of the A ring.
+// Pipeline, ONE barrier per 16-deep chunk s: [ds_read operands of s | ds_read raw X of s+1 | global_load A of s+1] -> the MFMAs
+// of s with prologue, column scale, split and operand writes of s+1 woven between them (pinned with sched_barrier: an in-order
+// wave that issues these phases one after the other leaves the matrix pipe idle through most of them) -> wait (raw X(s+2)
+// landed) + barrier -> LDS-DMA of raw X(s+NS+1).  The raw X ring is the only LDS-DMA traffic: one instruction per wave and chunk.
 #include "gemm_common.hpp"
 #include <stddef.h>
 #include <stdlib.h>
