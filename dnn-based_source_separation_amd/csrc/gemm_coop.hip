@@ -31,13 +31,6 @@
 #include <stdlib.h>
 #include <type_traits>
 
-#ifdef COOP_PROF
-__device__ long long g_coop_prof[4][64][8];      // [sampled block][step][stamp]
-#define CSTAMP(s) do { if (pslot >= 0 && tid == 0 && kc < 64) g_coop_prof[pslot][kc][s] = clock64(); } while (0)
-extern "C" int sep_debug_coop_prof(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coop_prof), sizeof(long long) * 4 * 64 * 8) == hipSuccess ? 0 : -1; }
-#else
-#define CSTAMP(s) do { } while (0)
-#endif
 
 namespace {
 
@@ -329,7 +322,7 @@ void pw_gemm_coop_kernel(const sep_gemm_desc d) {
     static_assert(KEEP < 64, "vmcnt field");
     // One pipeline step = one chunk: its MFMAs with everything else of the step woven between them and pinned -- an in-order wave that
     // issues [reads | split | 12 MFMAs | DMA] one after the other leaves the matrix pipe idle through three of the four phases
-    // (tools/coop_prof.py: 1950 cycles per chunk for 384 cycles of MFMAs).
+    // (s_memtime stamps of the first form: 1950 cycles per chunk for 384 cycles of MFMAs).
     auto step = [&](auto pc, const int s) {
         constexpr int P = decltype(pc)::value;
         const bool more = s + 1 < nk;
