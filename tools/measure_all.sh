@@ -10,4 +10,3 @@ print('ms/step', d['ms_per_step'], 'roofline', r['bound'], r['achieved'], r['pea
 bash tools/profile_step.sh $tag 8 2>&1 | tail -3
 bash tools/pmc_passes.sh 2>&1 | tail -6
 python tools/pmc_traffic.py gpurun_out gpurun_out/$tag 3
-cp profiles/hbm_traffic.json gpurun_out/hbm_traffic.json
