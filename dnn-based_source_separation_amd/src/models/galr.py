@@ -1,0 +1,113 @@
+"""
+GALR blocks (globally attentive, locally recurrent): module tree / parameter names of reference src/models/galr.py:9-226.
+Locally: the intra-chunk bi-LSTM path of DPRNN (models/dprnn.py, LSTM sweep kernels + gLN kernels).  Globally: self-attention
+across chunks for every position of a chunk -- optionally of a chunk squeezed from K to Q positions by a Linear map --
+between a layer norm along the channels and a gLN / cLN, with sinusoidal position codes added in front.
+"""
+import torch
+import torch.nn as nn
+
+from utils.tasnet import choose_layer_norm
+from models.dprnn import IntraChunkRNN as LocallyRecurrentBlock
+
+EPS = 1e-12
+
+
+class GALR(nn.Module):
+    def __init__(self, num_features, hidden_channels, num_blocks=6, num_heads=8, norm=True, dropout=1e-1, low_dimension=True,
+                 causal=False, eps=EPS, **kwargs):
+        super().__init__()
+        self.net = nn.Sequential(*[GALRBlock(num_features, hidden_channels, num_heads=num_heads, norm=norm, dropout=dropout,
+                                             low_dimension=low_dimension, causal=causal, eps=eps, **kwargs) for _ in range(num_blocks)])
+
+    def forward(self, input):
+        """(batch_size, num_features, S, chunk_size) -> same shape"""
+        return self.net(input)
+
+
+class GALRBlock(nn.Module):
+    def __init__(self, num_features, hidden_channels, num_heads=8, causal=False, norm=True, dropout=1e-1, low_dimension=True, eps=EPS, **kwargs):
+        super().__init__()
+        self.intra_chunk_block = LocallyRecurrentBlock(num_features, hidden_channels=hidden_channels, norm=norm, eps=eps)
+        if low_dimension:
+            self.inter_chunk_block = LowDimensionGloballyAttentiveBlock(num_features, chunk_size=kwargs["chunk_size"],
+                                                                        down_chunk_size=kwargs["down_chunk_size"], num_heads=num_heads,
+                                                                        causal=causal, norm=norm, dropout=dropout, eps=eps)
+        else:
+            self.inter_chunk_block = GloballyAttentiveBlock(num_features, num_heads=num_heads, causal=causal, norm=norm, dropout=dropout, eps=eps)
+
+    def forward(self, input):
+        return self.inter_chunk_block(self.intra_chunk_block(input))
+
+
+class GloballyAttentiveBlockBase(nn.Module):
+    def positional_encoding(self, length, dimension, base=10000):
+        """(length, dimension): [sin(p / base^(i/dimension)) for i < dimension/2 | the cosines]  (halves, not interleaved)"""
+        assert dimension % 2 == 0, "dimension is expected even number but given odd number."
+        position = torch.arange(length).unsqueeze(dim=1)
+        index = (torch.arange(dimension // 2) / dimension).unsqueeze(dim=0)
+        angle = position / base ** index
+        return torch.cat([torch.sin(angle), torch.cos(angle)], dim=1)
+
+    def _attend(self, x):
+        """x (batch_size, num_features, S, Q): [channel norm ->] + position code -> attention over S -> [dropout] + its input
+        -> [gLN / cLN].  The position code runs over the FLATTENED (S, Q) index, as the reference's does."""
+        B, C, S, Q = x.size()
+        if self.norm:
+            x = self.norm2d_in(x)
+        code = self.positional_encoding(length=S * Q, dimension=C).t().reshape(C, S, Q).to(device=x.device, dtype=x.dtype)
+        seq = (x + code).permute(2, 0, 3, 1).reshape(S, B * Q, C)
+        y = self.multihead_attn(seq, seq, seq, need_weights=False)[0]
+        if self.dropout:
+            y = self.dropout1d(y)
+        y = (y + seq).view(S, B, Q, C).permute(1, 3, 0, 2).contiguous()
+        return self.norm2d_out(y) if self.norm else y
+
+    def _make_core(self, num_features, num_heads, causal, norm, dropout, eps):
+        self.norm = norm
+        if norm:
+            self.norm2d_in = LayerNormAlongChannel(num_features, eps=eps)
+        self.multihead_attn = nn.MultiheadAttention(num_features, num_heads)
+        self.dropout = dropout is not None
+        if self.dropout:
+            self.dropout1d = nn.Dropout(p=dropout)
+        if norm:
+            self.norm2d_out = choose_layer_norm("cLN" if causal else "gLN", num_features, causal=causal, eps=eps)
+
+
+class GloballyAttentiveBlock(GloballyAttentiveBlockBase):
+    def __init__(self, num_features, num_heads=8, causal=False, norm=True, dropout=1e-1, eps=EPS):
+        super().__init__()
+        self._make_core(num_features, num_heads, causal, norm, dropout, eps)
+
+    def forward(self, input):
+        """(batch_size, num_features, S, K) -> same shape"""
+        return self._attend(input) + input
+
+
+class LowDimensionGloballyAttentiveBlock(GloballyAttentiveBlockBase):
+    def __init__(self, num_features, chunk_size=100, down_chunk_size=32, num_heads=8, causal=False, norm=True, dropout=1e-1, eps=EPS):
+        super().__init__()
+        self.down_chunk_size = down_chunk_size
+        self.fc_map = nn.Linear(chunk_size, down_chunk_size)          # registration order of the reference: fc_map, core, fc_inv
+        self._make_core(num_features, num_heads, causal, norm, dropout, eps)
+        self.fc_inv = nn.Linear(down_chunk_size, chunk_size)
+
+    def forward(self, input):
+        """(batch_size, num_features, S, K) -> same shape; attention runs on K squeezed to Q = down_chunk_size positions"""
+        return self.fc_inv(self._attend(self.fc_map(input))) + input
+
+
+class LayerNormAlongChannel(nn.Module):
+    """nn.LayerNorm over the channel axis of (batch_size, num_features, *)"""
+
+    def __init__(self, num_features, eps=EPS):
+        super().__init__()
+        self.num_features, self.eps = num_features, eps
+        self.norm = nn.LayerNorm(num_features, eps=eps)
+
+    def forward(self, input):
+        return self.norm(input.movedim(1, -1)).movedim(-1, 1).contiguous()
+
+    def __repr__(self):
+        return "{}({}, eps={})".format(self.__class__.__name__, self.num_features, self.eps)

@@ -1,0 +1,198 @@
+"""
+SepFormer on MI355X: constructor, module tree, state_dict keys and config of reference src/models/sepformer.py:16-560.
+Front: encoder -> gLN -> 1x1 bottleneck, i.e. the fused head of the TasNet kernels (HeadFn) when not causal.  Shell and
+gated mask end (with the extra 1x1 output convolution): models/masking.py.  Core: stacks of `nn.TransformerEncoder` layers
+along and across chunks (library attention / GEMMs), each stack closed by a gLN / cLN (kernels) and wrapped in a residual.
+"""
+import torch.nn as nn
+import torch.nn.functional as F
+
+from sepkernels.functional import HeadFn, HEAD_KEYS, OverlapAddFn, PaddedPointwiseFn, SegmentFn
+from utils.tasnet import choose_layer_norm
+from models.gtu import GTU1d
+from models.masking import EPS, GatedMaskSeparator, MaskingTasNet, make_mask_nonlinear
+from models.transform import OverlapAdd1d, Segment1d
+from models.transformer import PositionalEncoding
+
+
+class SepFormer(MaskingTasNet):
+    pretrained_model_ids = {"wsj0-mix": {8000: {2: "1-9pOv2B612IykvpA6kaGZSg4AUQPnoCg", 3: "1-Rz31CGWVVzYVHXgIdp7Tuc0__K2SCPs"}}}
+    SEP_KEYS = ("sep_bottleneck_channels", "sep_chunk_size", "sep_hop_size", "sep_num_blocks", "sep_num_layers_intra",
+                "sep_num_layers_inter", "sep_num_heads_intra", "sep_num_heads_inter", "sep_d_ff_intra", "sep_d_ff_inter", "sep_norm",
+                "sep_nonlinear", "sep_dropout")
+    CONFIG_HAS_IN_CHANNELS = True
+    MULTICHANNEL_INPUT = True
+
+    def __init__(self, n_basis, kernel_size, stride=None, enc_basis=None, dec_basis=None, sep_bottleneck_channels=None,
+                 sep_chunk_size=250, sep_hop_size=125, sep_num_blocks=2, sep_num_layers_intra=8, sep_num_layers_inter=8,
+                 sep_num_heads_intra=8, sep_num_heads_inter=8, sep_d_ff_intra=1024, sep_d_ff_inter=1024, sep_norm=True,
+                 sep_nonlinear="relu", sep_dropout=1e-1, mask_nonlinear="relu", causal=True, n_sources=2, eps=EPS, **kwargs):
+        super().__init__()
+        if sep_bottleneck_channels is None:
+            sep_bottleneck_channels = n_basis
+        self.sep_bottleneck_channels = sep_bottleneck_channels
+        self.sep_chunk_size, self.sep_hop_size = sep_chunk_size, sep_hop_size
+        self.sep_num_blocks = sep_num_blocks
+        self.sep_num_layers_intra, self.sep_num_layers_inter = sep_num_layers_intra, sep_num_layers_inter
+        self.sep_num_heads_intra, self.sep_num_heads_inter = sep_num_heads_intra, sep_num_heads_inter
+        self.sep_d_ff_intra, self.sep_d_ff_inter = sep_d_ff_intra, sep_d_ff_inter
+        self.sep_norm, self.sep_nonlinear, self.sep_dropout = sep_norm, sep_nonlinear, sep_dropout
+        self.causal, self.mask_nonlinear = causal, mask_nonlinear
+        self.n_sources, self.eps = n_sources, eps
+        self._init_filterbank(n_basis, kernel_size, stride, enc_basis, dec_basis, kwargs)
+        encoder, decoder = self.encoder, self.decoder           # registration order of the reference: encoder, separator, decoder
+        del self.encoder, self.decoder
+        self.encoder = encoder
+        self.separator = Separator(n_basis, sep_bottleneck_channels, chunk_size=sep_chunk_size, hop_size=sep_hop_size,
+                                   num_blocks=sep_num_blocks, num_layers_intra=sep_num_layers_intra, num_layers_inter=sep_num_layers_inter,
+                                   num_heads_intra=sep_num_heads_intra, num_heads_inter=sep_num_heads_inter, d_ff_intra=sep_d_ff_intra,
+                                   d_ff_inter=sep_d_ff_inter, norm=sep_norm, nonlinear=sep_nonlinear, dropout=sep_dropout,
+                                   mask_nonlinear=mask_nonlinear, causal=causal, n_sources=n_sources, eps=eps)
+        self.decoder = decoder
+
+    def _enter(self, mixture):
+        """not causal: analysis basis, gLN and the 1x1 bottleneck as the fused head of the TasNet kernels -> (w, bottleneck output)"""
+        if self.causal:
+            return super()._enter(mixture)
+        cfg = {"n_basis": self.n_basis, "kernel_size": self.kernel_size, "stride": self.stride, "n_sources": self.n_sources,
+               "sep_bottleneck_channels": self.sep_bottleneck_channels, "enc_nonlinear": "relu" if self.encoder.nonlinear else None,
+               "eps": self.eps}
+        sep = self.separator
+        params = {"encoder.conv1d.weight": self.encoder.conv1d.weight, "separator.norm1d.norm.weight": sep.norm1d.norm.weight,
+                  "separator.norm1d.norm.bias": sep.norm1d.norm.bias, "separator.bottleneck_conv1d.weight": sep.bottleneck_conv1d_in.weight,
+                  "separator.bottleneck_conv1d.bias": sep.bottleneck_conv1d_in.bias}
+        w, x0 = HeadFn.apply(mixture, cfg, *[params[k] for k in HEAD_KEYS])
+        return w, (w, x0)
+
+
+class Separator(GatedMaskSeparator):
+    """norm -> 1x1 bottleneck -> chunks -> SepFormer blocks -> overlap-add -> gated mask end with a 1x1 output convolution
+    (reference sepformer.py:281-361)"""
+
+    def __init__(self, num_features, bottleneck_channels, chunk_size=250, hop_size=125, num_blocks=2, num_layers_intra=8,
+                 num_layers_inter=8, num_heads_intra=8, num_heads_inter=8, d_ff_intra=1024, d_ff_inter=1024, norm=True, nonlinear="relu",
+                 dropout=1e-1, mask_nonlinear="relu", causal=False, n_sources=2, eps=EPS):
+        super().__init__()
+        self.num_features, self.n_sources = num_features, n_sources
+        self.bottleneck_channels = bottleneck_channels
+        self.chunk_size, self.hop_size = chunk_size, hop_size
+        self.norm = norm
+        self.norm1d = choose_layer_norm("cLN" if causal else "gLN", num_features, causal=causal, eps=eps)
+        self.bottleneck_conv1d_in = nn.Conv1d(num_features, bottleneck_channels, kernel_size=1, stride=1)
+        self.segment1d = Segment1d(chunk_size, hop_size)
+        self.dptransformer = SepFormerBackbone(num_blocks=num_blocks, num_layers_intra=num_layers_intra, num_layers_inter=num_layers_inter,
+                                               num_heads_intra=num_heads_intra, num_heads_inter=num_heads_inter, d_intra=bottleneck_channels,
+                                               d_inter=bottleneck_channels, d_ff_intra=d_ff_intra, d_ff_inter=d_ff_inter, norm=norm,
+                                               dropout=dropout, nonlinear=nonlinear, causal=causal, eps=eps)
+        self.overlap_add1d = OverlapAdd1d(chunk_size, hop_size)
+        self.prelu = nn.PReLU()
+        self.map = nn.Conv1d(bottleneck_channels, n_sources * num_features, kernel_size=1, stride=1)
+        self.gtu = GTU1d(num_features, num_features, kernel_size=1, stride=1)
+        self.bottleneck_conv1d_out = nn.Conv1d(num_features, num_features, kernel_size=1, stride=1)
+        self.mask_nonlinear = make_mask_nonlinear(mask_nonlinear)
+
+    def forward(self, input):
+        """input (batch_size, num_features, n_frames) -> (batch_size, n_sources, num_features, n_frames)"""
+        batch_size, _, n_frames = input.size()
+        pad_left, pad_right = self._chunk_padding(n_frames)
+        x = F.pad(self.bottleneck_conv1d_in(self.norm1d(input)), (pad_left, pad_right))
+        x = self.dptransformer(self.segment1d(x))
+        x = F.pad(self.overlap_add1d(x), (-pad_left, -pad_right))
+        return self._mask(x, batch_size, n_frames)
+
+    def mask_padded(self, entry, n_frames):
+        if isinstance(entry, tuple):                   # (w, bottleneck output) of the fused head
+            ldt, x = entry[0].shape[2], entry[1]
+        else:                                          # causal: cLN is a kernel of its own, on the valid frames
+            ldt = entry.shape[2]
+            x = F.pad(self.norm1d(entry[..., :n_frames]), (0, ldt - n_frames))
+            x = PaddedPointwiseFn.apply(x, n_frames, self.bottleneck_conv1d_in.weight, self.bottleneck_conv1d_in.bias, None)
+        x = self.dptransformer(SegmentFn.apply(x, n_frames, self.chunk_size, self.hop_size))
+        return self._mask_padded(OverlapAddFn.apply(x, n_frames, ldt, self.hop_size), n_frames)
+
+
+class SepFormerBackbone(nn.Module):
+    def __init__(self, num_blocks=2, num_layers_intra=8, num_layers_inter=8, num_heads_intra=8, num_heads_inter=8, d_intra=256,
+                 d_inter=256, d_ff_intra=1024, d_ff_inter=1024, norm=True, dropout=1e-1, nonlinear="relu", causal=False, eps=EPS):
+        super().__init__()
+        self.net = nn.Sequential(*[SepFormerBlock(num_layers_intra=num_layers_intra, num_layers_inter=num_layers_inter,
+                                                  num_heads_intra=num_heads_intra, num_heads_inter=num_heads_inter, d_intra=d_intra,
+                                                  d_inter=d_inter, d_ff_intra=d_ff_intra, d_ff_inter=d_ff_inter, norm=norm, dropout=dropout,
+                                                  nonlinear=nonlinear, causal=causal, eps=eps) for _ in range(num_blocks)])
+
+    def forward(self, input):
+        """(batch_size, num_features, S, chunk_size) -> same shape"""
+        return self.net(input)
+
+
+class SepFormerBlock(nn.Module):
+    def __init__(self, num_layers_intra=8, num_layers_inter=8, num_heads_intra=8, num_heads_inter=8, d_intra=256, d_inter=256,
+                 d_ff_intra=1024, d_ff_inter=1024, norm=True, dropout=1e-1, nonlinear="relu", causal=False, eps=EPS):
+        super().__init__()
+        self.intra_transformer = IntraTransformer(d_intra, num_layers=num_layers_intra, num_heads=num_heads_intra, d_ff=d_ff_intra,
+                                                  norm=norm, dropout=dropout, nonlinear=nonlinear, eps=eps)
+        self.inter_transformer = InterTransformer(d_inter, num_layers=num_layers_inter, num_heads=num_heads_inter, d_ff=d_ff_inter,
+                                                  norm=norm, dropout=dropout, nonlinear=nonlinear, causal=causal, eps=eps)
+
+    def forward(self, input):
+        return self.inter_transformer(self.intra_transformer(input))
+
+
+class _ChunkPathEncoder(nn.Module):
+    """A transformer-encoder stack along one of the two chunk axes with a residual connection around it.
+    Its input is x + (x + code): the reference adds the OUTPUT of its positional-encoding module -- which already contains
+    x -- back onto x (sepformer.py:470-472, 512-514), and a drop-in keeps that."""
+    SEQ_AXIS = None         # 3: along the chunk (intra), 2: across chunks (inter)
+
+    def __init__(self, num_features, num_layers, num_heads, d_ff, norm, nonlinear, dropout, norm_first, default_norm, eps):
+        super().__init__()
+        self.num_features = num_features
+        if isinstance(norm, int):                      # True / False (bool is an int) -> gLN, or cLN for a causal inter path
+            final = LayerNormWrapper(default_norm, num_features, causal=False, batch_first=False, eps=eps) if norm else None
+        else:                                          # a norm name
+            final = LayerNormWrapper(norm, num_features, causal=False, batch_first=False, eps=eps)
+        self.positional_encoding = PositionalEncoding(num_features, batch_first=False)
+        layer = nn.TransformerEncoderLayer(num_features, num_heads, d_ff, dropout=dropout, activation=nonlinear, layer_norm_eps=eps,
+                                           batch_first=False, norm_first=norm_first)
+        self.transformer = nn.TransformerEncoder(layer, num_layers=num_layers, norm=final, enable_nested_tensor=False)
+
+    def forward(self, input):
+        """(batch_size, num_features, S, chunk_size) -> same shape"""
+        B, C, S, K = input.size()
+        if self.SEQ_AXIS == 3:
+            x = input.permute(3, 0, 2, 1).reshape(K, B * S, C)
+            y = self.transformer(x + self.positional_encoding(x)).view(K, B, S, C).permute(1, 3, 2, 0)
+        else:
+            x = input.permute(2, 0, 3, 1).reshape(S, B * K, C)
+            y = self.transformer(x + self.positional_encoding(x)).view(S, B, K, C).permute(1, 3, 0, 2)
+        return y + input
+
+
+class IntraTransformer(_ChunkPathEncoder):
+    SEQ_AXIS = 3
+
+    def __init__(self, num_features, num_layers=8, num_heads=8, d_ff=1024, norm=True, nonlinear="relu", dropout=1e-1, norm_first=False, eps=EPS):
+        super().__init__(num_features, num_layers, num_heads, d_ff, norm, nonlinear, dropout, norm_first, "gLN", eps)
+
+
+class InterTransformer(_ChunkPathEncoder):
+    SEQ_AXIS = 2
+
+    def __init__(self, num_features, num_layers=8, num_heads=8, d_ff=1024, norm=True, nonlinear="relu", dropout=1e-1, causal=False,
+                 norm_first=False, eps=EPS):
+        super().__init__(num_features, num_layers, num_heads, d_ff, norm, nonlinear, dropout, norm_first, "cLN" if causal else "gLN", eps)
+
+
+class LayerNormWrapper(nn.Module):
+    """a (batch_size, C, T) layer norm of the TasNet family on (T, batch_size, C) -- or (batch_size, T, C) if batch_first"""
+
+    def __init__(self, norm_name, num_features, causal=False, batch_first=False, eps=EPS):
+        super().__init__()
+        self.batch_first = batch_first
+        extra = {"n_dims": 1} if norm_name in ("BN", "batch", "batch_norm") else {}
+        self.norm1d = choose_layer_norm(norm_name, num_features, causal=causal, eps=eps, **extra)
+
+    def forward(self, input):
+        if self.batch_first:
+            return self.norm1d(input.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
+        return self.norm1d(input.permute(1, 2, 0).contiguous()).permute(2, 0, 1).contiguous()

@@ -14,6 +14,7 @@ import torch.nn as nn
 import sepkernels
 
 EPS = 1e-12
+GRID_ROWS = 65535      # rows one launch of the gLN / cLN kernels takes (grid.y)
 
 
 class _GlobalLayerNormFn(torch.autograd.Function):
@@ -81,7 +82,11 @@ class GlobalLayerNorm(nn.Module):
 
     def forward(self, input):
         """input (batch_size, C, *) -> same shape; statistics over (C, *) per sample."""
-        return _GlobalLayerNormFn.apply(input, self.norm.weight, self.norm.bias, self.eps)
+        per_launch = max(1, GRID_ROWS // self.num_features)       # one grid row per (sample, channel): the dual-path models of
+        if input.shape[0] <= per_launch:                          # models/{dptnet,galr,sepformer}.py normalise thousands of short samples
+            return _GlobalLayerNormFn.apply(input, self.norm.weight, self.norm.bias, self.eps)
+        return torch.cat([_GlobalLayerNormFn.apply(part, self.norm.weight, self.norm.bias, self.eps)
+                          for part in input.split(per_launch, dim=0)], dim=0)
 
     def __repr__(self):
         return "{}({}, eps={})".format(self.__class__.__name__, self.num_features, self.eps)
@@ -157,7 +162,9 @@ class CumulativeLayerNorm1d(nn.Module):
         if input.dim() not in (3, 4):
             raise ValueError("Only support 3D or 4D input, but given {}D".format(input.dim()))
         if input.dtype == torch.float32 and (input.is_cuda or sepkernels.backend().name != "hip"):
-            return _CumulativeLayerNormFn.apply(input, self.gamma, self.beta, self.eps)
+            if input.shape[0] <= GRID_ROWS:
+                return _CumulativeLayerNormFn.apply(input, self.gamma, self.beta, self.eps)
+            return torch.cat([_CumulativeLayerNormFn.apply(part, self.gamma, self.beta, self.eps) for part in input.split(GRID_ROWS, dim=0)], dim=0)
         return self._compose(input)
 
     def _compose(self, input):

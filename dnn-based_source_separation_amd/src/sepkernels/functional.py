@@ -3,6 +3,9 @@ Autograd-capable building blocks on top of the C ABI, for models that are not on
 Used by DPRNN-TasNet (models/dprnn_tasnet.py): the encoder+gLN+bottleneck "head" and the
 PReLU+mask+decoder "tail" are the same kernels as in Conv-TasNet (sepkernels/net.py), exposed as two
 torch.autograd.Functions working on padded (B, C, ldt) tensors; Segment1d / OverlapAdd1d are index-map kernels.
+DPTNet / GALRNet / SepFormer (models/dptnet.py, galrnet.py, sepformer.py) start and end differently (no gLN in front of the
+bottleneck or no bottleneck at all; a gated tanh unit between the mask convolution and the decoder), so the same kernels are
+also exposed one operation at a time: EncodeFn, PaddedPointwiseFn, MaskDecodeFn.
 """
 import torch
 
@@ -71,6 +74,132 @@ class TailFn(torch.autograd.Function):
         dcore, dwm = _net.tail_backward(ctx.cfg, P, ctx.geo, w, core, m, ctx.mixture_shape, d_est, G, dalpha)
         K.f64_to_f32(dalpha, G["separator.prelu.weight"], 1, 0)
         return (dwm, dcore, None, None, None, None) + tuple(G[k] for k in TAIL_KEYS)
+
+
+class EncodeFn(torch.autograd.Function):
+    """Learned analysis basis alone (reference models/filterbank.py:205-235 incl. the input padding of the TasNet
+    forwards): mixture (B, Cin, T), basis (N, Cin, L) -> w (B, N, ldt) = [ReLU] conv1d(pad(mixture)), frames >= T' zero.
+    For the separators whose first operation is not the gLN + bottleneck pair HeadFn fuses (DPTNet, GALRNet)."""
+
+    @staticmethod
+    def forward(ctx, mixture, weight, stride, relu):
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("gradient w.r.t. the input mixture is not implemented")
+        K = backend()
+        mixture = mixture.contiguous()
+        B, Cin, T_in = mixture.shape
+        N, L = weight.shape[0], weight.shape[2]
+        geo = _net.Geometry(T_in, L, stride)
+        w = torch.empty(B, N, geo.ldt, device=mixture.device, dtype=mixture.dtype)
+        stats = torch.zeros(B, STATS_SLOTS, 2, device=mixture.device, dtype=torch.float64)     # the kernel's by-product, unused here
+        K.encoder_fwd(mixture, weight, w, stats, B, Cin, T_in, N, L, stride, geo.F, geo.ldt, geo.pad_left, bool(relu))
+        ctx.save_for_backward(mixture, w if relu else None)
+        ctx.meta = (B, Cin, T_in, N, L, stride, geo, bool(relu))
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        K = backend()
+        mixture, w = ctx.saved_tensors
+        B, Cin, T_in, N, L, S, geo, relu = ctx.meta
+        f32 = dict(device=dw.device, dtype=dw.dtype)
+        dpre = torch.where(w > 0, dw, torch.zeros_like(dw)) if relu else dw
+        Fx = torch.empty(B, Cin * L, geo.ldt, **f32)
+        K.unfold(mixture, Fx, B, Cin, T_in, L, S, geo.F, geo.ldt, geo.pad_left)
+        part, _, ns = _net._wgrad(K, B, geo.F, geo.ldt, 0.0, f32, N, Cin * L, dpre.contiguous(), Fx, False)
+        dE = torch.empty(N, Cin, L, **f32)
+        K.reduce_slabs([(part, 0, dE, N * Cin * L, ns, N * Cin * L, 0, 1.0)])
+        return None, dE, None, None
+
+
+class PaddedPointwiseFn(torch.autograd.Function):
+    """[PReLU ->] nn.Conv1d(kernel_size=1) on rows that already carry the workspace stride: x (B, Cin, ldt) with n_frames
+    valid frames -> (B, Cout, ldt), frames beyond zero.  `alpha` (the single PReLU slope) or None.  Same kernels as
+    PointwiseConv1dFn minus the repacking; with the slope it is the mask convolution of the TasNet tails without its
+    sigmoid (sepkernels/net.py tail_forward / tail_backward)."""
+
+    @staticmethod
+    def forward(ctx, x, n_frames, weight, bias, alpha):
+        K = backend()
+        x = x.contiguous()
+        B, Cin, ldt = x.shape
+        Cout = weight.shape[0]
+        if Cin % 16 or Cout % 16:
+            raise NotImplementedError("PaddedPointwiseFn: channel counts must be multiples of 16 (got {} -> {})".format(Cin, Cout))
+        y = torch.empty(B, Cout, ldt, device=x.device, dtype=x.dtype)
+        pro = dict(pro_mode=_net.PRO_PRELU, pro_alpha=alpha) if alpha is not None else {}
+        K.pw_gemm(B=B, M=Cout, K=Cin, T=n_frames, ldt=ldt, A=weight, X=x, Y=y, bias=bias, **pro)
+        ctx.save_for_backward(x, weight, alpha)
+        ctx.meta = (B, Cin, Cout, n_frames, ldt, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        K = backend()
+        x, weight, alpha = ctx.saved_tensors
+        B, Cin, Cout, F, ldt, has_bias = ctx.meta
+        f32 = dict(device=x.device, dtype=x.dtype)
+        dy = dy.contiguous()
+        dx = torch.empty(B, Cin, ldt, **f32)
+        dalpha = None
+        if alpha is None:
+            K.pw_gemm(B=B, M=Cin, K=Cout, T=F, ldt=ldt, trans_a=1, A=weight, X=dy, Y=dx)
+            part, pb, ns = _net._wgrad(K, B, F, ldt, 0.0, f32, Cout, Cin, dy, x, True)
+        else:
+            slot = torch.zeros(1, device=x.device, dtype=torch.float64)
+            K.pw_gemm(B=B, M=Cin, K=Cout, T=F, ldt=ldt, trans_a=1, A=weight, X=dy, Y=dx, epi_flags=_net.EPI_PRELU_BWD, epi_aux=x,
+                      epi_alpha=alpha, epi_dalpha=slot)
+            part, pb, ns = _net._wgrad(K, B, F, ldt, 0.0, f32, Cout, Cin, dy, x, True, x_mode=_net.PRO_PRELU, x_alpha=alpha)
+            dalpha = torch.empty_like(alpha)
+            K.f64_to_f32(slot, dalpha, 1, 0)
+        dW, db = torch.empty_like(weight), torch.empty(Cout, **f32)
+        K.reduce_slabs([(part, 0, dW, Cout * Cin, ns, Cout * Cin, 0, 1.0), (pb, 0, db, Cout, ns, Cout, 0, 1.0)])
+        return dx, None, dW, (db if has_bias else None), dalpha
+
+
+class MaskDecodeFn(torch.autograd.Function):
+    """est[b, s] = crop(overlap-add(D^T (w[b] * mask[b, s]))): the last two lines of every masking TasNet (reference
+    dptnet.py:139-147 and the same lines of galrnet.py / sepformer.py) for an ALREADY ACTIVATED mask.
+    w (B, N, ldt), mask (B, n_src*N, ldt), D (N, Cin, L) -> est (B, n_src, Cin, T) [, latent (B, n_src, N, ldt)]."""
+
+    @staticmethod
+    def forward(ctx, w, mask, weight, stride, T_in, want_latent):
+        K = backend()
+        w, mask = w.contiguous(), mask.contiguous()
+        B, N, ldt = w.shape
+        n_src = mask.shape[1] // N
+        Cin, L = weight.shape[1], weight.shape[2]
+        geo = _net.Geometry(T_in, L, stride)
+        assert geo.ldt == ldt, "w does not carry the workspace stride of this input length"
+        f32 = dict(device=w.device, dtype=w.dtype)
+        est = torch.empty(B, n_src, Cin, T_in, **f32)
+        latent = torch.empty(B, n_src, N, ldt, **f32) if want_latent else None
+        K.decoder_fwd(w, mask, weight, est, latent, B, n_src, N, Cin, L, stride, geo.F, ldt, T_in, geo.pad_left)
+        ctx.save_for_backward(w, mask, weight)
+        ctx.meta = (B, n_src, N, Cin, L, stride, geo, T_in)
+        ctx.set_materialize_grads(False)
+        if want_latent:
+            ctx.mark_non_differentiable(latent)
+            return est, latent
+        return est
+
+    @staticmethod
+    def backward(ctx, d_est, *unused):
+        K = backend()
+        w, mask, D = ctx.saved_tensors
+        B, n_src, N, Cin, L, S, geo, T_in = ctx.meta
+        F, ldt = geo.F, geo.ldt
+        f32 = dict(device=w.device, dtype=w.dtype)
+        d_est = d_est.contiguous()
+        Fd = torch.empty(B * n_src, Cin * L, ldt, **f32)
+        K.unfold(d_est, Fd, B * n_src, Cin, T_in, L, S, F, ldt, geo.pad_left)
+        part, _, ns = _net._wgrad(K, B, F, ldt, 0.0, f32, N, Cin * L, mask, Fd, False, Bq=B * n_src, Gaux=w, g_mul=1, g_div=n_src)
+        dD = torch.empty_like(D)
+        K.reduce_slabs([(part, 0, dD, N * Cin * L, ns, N * Cin * L, 0, 1.0)])
+        dmask = torch.empty(B, n_src * N, ldt, **f32)
+        dw = torch.empty(B, N, ldt, **f32)
+        K.decoder_bwd(d_est, w, mask, D, dmask, dw, B, n_src, N, Cin, L, S, F, ldt, T_in, geo.pad_left, raw_mask=1)
+        return dw, dmask, dD, None, None, None
 
 
 def segment_geometry(T, chunk_size, hop_size):
@@ -305,3 +434,23 @@ def lstm_bidirectional(x, rnn):
     return LSTMBidirectionalFn.apply(x, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0,
                                      rnn.weight_ih_l0_reverse, rnn.weight_hh_l0_reverse, rnn.bias_ih_l0_reverse, rnn.bias_hh_l0_reverse)
 
+
+
+LSTM_KERNEL_HIDDEN = (16, 32, 64, 128)
+
+
+def takes(x):
+    """can this tensor go to libsepkernels as it is?  (fp32 on the GPU; the CPU stand-in of the tests takes any real dtype)"""
+    if backend().name != "hip":
+        return not torch.is_complex(x)
+    return x.is_cuda and x.dtype == torch.float32
+
+
+def lstm_apply(x, rnn):
+    """x (nseq, L, F) through a single-layer nn.LSTM parameter container -> (nseq, L, D*H): the sweep kernels when they
+    cover the shape (hidden size, fp32 on the device the backend drives), torch's own LSTM otherwise."""
+    if isinstance(rnn, torch.nn.LSTM) and rnn.num_layers == 1 and rnn.hidden_size in LSTM_KERNEL_HIDDEN and takes(x):
+        return lstm_bidirectional(x.contiguous(), rnn)
+    if rnn.batch_first:
+        return rnn(x)[0]
+    return rnn(x.transpose(0, 1))[0].transpose(0, 1)

@@ -254,6 +254,81 @@ def dprnn_golden(NegSISDR, PIT1d):
     print("dprnn params", model.num_parameters, "loss", loss64.item(), "pattern", pattern.tolist())
 
 
+# DPTNet / GALRNet / SepFormer: small configurations, channel counts in multiples of 16 so that the
+# product runs them on its kernel path, plus one with odd widths (composition path).  403 samples -> 201 frames: both the
+# waveform padding and the chunk padding (1 frame left, 2 right) are exercised.
+_ENC = dict(kernel_size=4, stride=2, enc_basis="trainable", dec_basis="trainable")
+SIBLINGS = {
+    "dptnet": ("DPTNet", dict(n_basis=32, enc_nonlinear="relu", sep_bottleneck_channels=32, sep_hidden_channels=16, sep_chunk_size=12,
+                              sep_num_blocks=2, sep_num_heads=4, sep_dropout=0, mask_nonlinear="relu", causal=False, n_sources=2, **_ENC)),
+    "dptnet_causal": ("DPTNet", dict(n_basis=32, enc_nonlinear=None, sep_bottleneck_channels=16, sep_hidden_channels=32, sep_chunk_size=10,
+                                     sep_hop_size=5, sep_num_blocks=1, sep_num_heads=2, sep_dropout=0, mask_nonlinear="sigmoid", causal=True,
+                                     n_sources=3, **_ENC)),
+    "dptnet_odd": ("DPTNet", dict(n_basis=24, enc_nonlinear="relu", sep_bottleneck_channels=20, sep_hidden_channels=12, sep_chunk_size=12,
+                                  sep_num_blocks=1, sep_num_heads=4, sep_dropout=0, mask_nonlinear="softmax", causal=False, n_sources=2, **_ENC)),
+    "galrnet": ("GALRNet", dict(n_basis=32, enc_nonlinear="relu", sep_hidden_channels=16, sep_chunk_size=12, sep_hop_size=6,
+                                sep_down_chunk_size=4, sep_num_blocks=2, sep_num_heads=4, sep_dropout=0.0, mask_nonlinear="relu",
+                                causal=False, n_sources=2, low_dimension=True, **_ENC)),
+    "galrnet_causal": ("GALRNet", dict(n_basis=32, enc_nonlinear=None, sep_hidden_channels=16, sep_chunk_size=10, sep_hop_size=5,
+                                       sep_num_blocks=1, sep_num_heads=2, sep_dropout=0.0, mask_nonlinear="sigmoid", causal=True,
+                                       n_sources=2, low_dimension=False, **_ENC)),
+    "sepformer": ("SepFormer", dict(n_basis=32, enc_nonlinear="relu", sep_bottleneck_channels=32, sep_chunk_size=12, sep_hop_size=6,
+                                    sep_num_blocks=1, sep_num_layers_intra=2, sep_num_layers_inter=2, sep_num_heads_intra=4,
+                                    sep_num_heads_inter=4, sep_d_ff_intra=48, sep_d_ff_inter=48, sep_dropout=0.0, mask_nonlinear="relu",
+                                    causal=False, n_sources=2, **_ENC)),
+    "sepformer_causal": ("SepFormer", dict(n_basis=32, enc_nonlinear=None, sep_bottleneck_channels=16, sep_chunk_size=10, sep_hop_size=5,
+                                           sep_num_blocks=1, sep_num_layers_intra=1, sep_num_layers_inter=1, sep_num_heads_intra=2,
+                                           sep_num_heads_inter=2, sep_d_ff_intra=24, sep_d_ff_inter=24, sep_dropout=0.0,
+                                           mask_nonlinear="sigmoid", causal=True, n_sources=2, **_ENC)),
+}
+
+
+def perturb_all(model, seed):
+    """every normalisation gain / shift, every bias (attention and transformer biases start at zero) and the PReLU slope moved
+    off their initial values, so that none of them can be dropped or mis-indexed unnoticed"""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            leaf = name.split(".")[-1]
+            if "norm" in name or leaf in ("gamma", "beta"):
+                p.add_((0.2 if leaf in ("weight", "gamma") else 0.1) * torch.randn(p.shape, generator=g))
+            elif leaf.startswith("bias") or leaf.endswith("bias"):
+                p.add_(0.05 * torch.randn(p.shape, generator=g))
+            elif name.endswith("prelu.weight"):
+                p.add_(0.1 * torch.rand(p.shape, generator=g))
+
+
+def sibling_golden(name, NegSISDR, PIT1d):
+    """reference src/models/{dptnet,galrnet,sepformer}.py, fp64 module run as ground truth"""
+    import copy
+    import importlib
+    kind, cfg = SIBLINGS[name]
+    cls = getattr(importlib.import_module("models." + kind.lower()), kind)
+    torch.manual_seed(111)
+    model = cls(**cfg)
+    perturb_all(model, 17)
+    n_src = cfg["n_sources"]
+    g = torch.Generator().manual_seed(444)
+    sources = 0.1 * torch.randn(2, n_src, 403, generator=g)
+    mixture = sources.sum(dim=1, keepdim=True)
+    m64 = copy.deepcopy(model).double()
+    out64, latent64 = m64.extract_latent(mixture.double())
+    loss64, pattern = PIT1d(NegSISDR(), n_sources=n_src)(out64, sources.double())
+    loss64.backward()
+    blob = {"mixture": mixture.numpy(), "sources": sources.numpy(), "output_f64": out64.detach().numpy(),
+            "latent_f64_sum": np.array(latent64.detach().sum().item()), "latent_f64_abs_sum": np.array(latent64.detach().abs().sum().item()),
+            "loss_f64": np.array(loss64.item()), "pattern": pattern.numpy(), "num_parameters": np.array(model.num_parameters),
+            "config_keys": np.array(list(model.get_config().keys()))}
+    blob["state_keys"] = np.array(list(model.state_dict().keys()))
+    for k, v in model.state_dict().items():
+        if not k.endswith("positional_encoding.positional_encoding"):      # 5000 x C table of a closed formula per transformer stack: not stored
+            blob["param/" + k] = v.numpy()
+    for k, p in m64.named_parameters():
+        blob["grad/" + k] = p.grad.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "{}.npz".format(name)), **blob)
+    print(name, "params", model.num_parameters, "loss", loss64.item(), "pattern", pattern.tolist())
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -262,6 +337,9 @@ if __name__ == "__main__":
     for name in CONFIGS:
         if not only or name in only:
             model_golden(name, ConvTasNet, NegSISDR, PIT1d)
+    for name in SIBLINGS:
+        if not only or name in only:
+            sibling_golden(name, NegSISDR, PIT1d)
     if not only:
         pit_kat(NegSISDR, SISDR, PIT1d, SinkPIT)
         op_golden(NegSISDR)

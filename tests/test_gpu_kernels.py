@@ -134,6 +134,24 @@ def test_gemm_plain_bias(B, M, K, T, arith):
     both("pw_gemm", [], dict(B=B, M=M, K=K, T=T, ldt=ldt, A=A, X=X, Y=nan(B, M, ldt), bias=bias))
 
 
+@pytest.mark.parametrize("M,K,T", [(16, 32, 201), (64, 32, 201), (32, 16, 130), (48, 48, 77)])
+def test_gemm_small_widths_of_the_dual_path_separators(M, K, T, arith):
+    """the 1x1 convolutions of the small DPTNet / GALRNet / SepFormer fixtures (tests/golden/{dptnet,galrnet,sepformer}*.npz):
+    fewer rows than one tile, contraction lengths of one to three ring stages -- plain, with the PReLU prologue, and both
+    input-gradient forms (plain, PReLU-derivative epilogue)"""
+    if PACKED[0]:
+        pytest.skip("stand-alone callers (the only users of these widths) hand over fp32 weights; sep_pack_weights needs M % 32 == 0")
+    B = 2
+    ldt, X, A, bias = _gemm_common(B, M, K, T)
+    alpha = torch.tensor([0.3])
+    both("pw_gemm", [], dict(B=B, M=M, K=K, T=T, ldt=ldt, A=A, X=X, Y=nan(B, M, ldt), bias=bias))
+    both("pw_gemm", [], dict(B=B, M=M, K=K, T=T, ldt=ldt, A=A, X=X, Y=nan(B, M, ldt), bias=bias, pro_mode=PRO_PRELU, pro_alpha=alpha))
+    dY = padded(B, M, T, ldt)
+    both("pw_gemm", [], dict(B=B, M=K, K=M, T=T, ldt=ldt, trans_a=1, A=A, X=dY, Y=nan(B, K, ldt)))
+    both("pw_gemm", [], dict(B=B, M=K, K=M, T=T, ldt=ldt, trans_a=1, A=A, X=dY, Y=nan(B, K, ldt), epi_flags=EPI_PRELU_BWD, epi_aux=X,
+                             epi_alpha=alpha, epi_dalpha=torch.zeros(1, dtype=torch.float64)))
+
+
 def test_gemm_gln_prologue_and_stats_epilogue(arith):
     B, M, K, T = 2, 128, 256, 777
     ldt, X, A, bias = _gemm_common(B, M, K, T)
@@ -394,7 +412,8 @@ def test_gemm_split_arithmetic_is_as_accurate_as_fp32_mfma(K, scale):
     assert err["f32"][0] <= 5e-6, err
 
 
-@pytest.mark.parametrize("B,M,N,T,ns", [(2, 256, 128, 999, 7), (1, 128, 16, 300, 3), (3, 64, 64, 130, 1), (2, 512, 128, 3999, 64)])
+@pytest.mark.parametrize("B,M,N,T,ns", [(2, 256, 128, 999, 7), (1, 128, 16, 300, 3), (3, 64, 64, 130, 1), (2, 512, 128, 3999, 64),
+                                        (2, 32, 4, 201, 2), (2, 16, 32, 201, 3), (4, 64, 32, 201, 1)])
 def test_wgrad_plain(B, M, N, T, ns, arith):
     ldt = (T + 127) // 128 * 128
     part, pb = _wg_out(ns, M, N)

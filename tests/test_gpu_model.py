@@ -353,6 +353,58 @@ def test_dprnn_tasnet_golden(golden_dir):
     assert flat_rel <= 2e-3, "flat gradient rel-inf {:.3e}, worst tensor {}".format(flat_rel, worst)
 
 
+@pytest.mark.parametrize("name", ["dptnet", "dptnet_causal", "dptnet_odd", "galrnet", "galrnet_causal", "sepformer", "sepformer_causal"])
+def test_sibling_separators_golden(golden_dir, name):
+    """DPTNet / GALRNet / SepFormer on the device against the reference's fp64 run -- encoder, 1x1
+    convolutions (bottleneck, PReLU + map, the stacked GTU pair, SepFormer's fused head and output convolution), chunking,
+    gLN / cLN, LSTM sweeps and mask * w + decoder on libsepkernels; `_odd` (widths off the multiples of 16, softmax mask) is the
+    composition path on the device."""
+    from oracle.make_golden import SIBLINGS
+    from models.dptnet import DPTNet
+    from models.galrnet import GALRNet
+    from models.sepformer import SepFormer
+    kind, cfg = SIBLINGS[name]
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    model = {"DPTNet": DPTNet, "GALRNet": GALRNet, "SepFormer": SepFormer}[kind](**cfg)
+    assert list(model.state_dict().keys()) == list(g["state_keys"])
+    model.load_state_dict({k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param/")}, strict=False)
+    model.cuda()
+    assert (not model.kernel_path_problems()) == (not name.endswith("_odd"))
+    mixture, sources = torch.from_numpy(g["mixture"]).cuda(), torch.from_numpy(g["sources"]).cuda()
+    est, latent = model.extract_latent(mixture)
+    assert _rel(est, torch.from_numpy(g["output_f64"])) <= TOL
+    assert abs(latent.sum().item() - float(g["latent_f64_sum"])) <= TOL * float(g["latent_f64_abs_sum"])
+    loss, pattern = PIT1d(NegSISDR(), n_sources=cfg["n_sources"])(est, sources)
+    assert abs(loss.item() - float(g["loss_f64"])) <= TOL * abs(float(g["loss_f64"]))
+    assert np.array_equal(pattern.cpu().numpy(), g["pattern"])
+    loss.backward()
+    flat_rel, worst = _grad_report(model, {k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("grad/")})
+    assert flat_rel <= 2e-3, "flat gradient rel-inf {:.3e}, worst tensor {}".format(flat_rel, worst)
+
+
+def test_dptnet_full_width_step():
+    """DPTNet at the widths of its paper (N = 64, L = 2, 64 bottleneck channels, chunks of 100 frames) on 4 x 2 s @ 8 kHz:
+    320 chunks per utterance, i.e. 1280 x 64 rows in every intra-chunk gLN -- more than one launch takes (the module splits the
+    batch); LSTM sweeps at H = 128.  Size-independent properties: finite loss / gradients, utterances independent of each other."""
+    from models.dptnet import DPTNet
+    torch.manual_seed(3)
+    model = DPTNet(64, 2, stride=1, enc_basis="trainable", dec_basis="trainable", enc_nonlinear="relu", sep_bottleneck_channels=64,
+                   sep_hidden_channels=128, sep_chunk_size=100, sep_num_blocks=2, sep_num_heads=4, sep_dropout=0, mask_nonlinear="relu",
+                   causal=False, n_sources=2).cuda()
+    assert not model.kernel_path_problems()
+    g = torch.Generator().manual_seed(12)
+    sources = (0.1 * torch.randn(4, 2, 16000, generator=g)).cuda()
+    mixture = sources.sum(1, keepdim=True)
+    est = model(mixture)
+    assert est.shape == (4, 2, 16000) and torch.isfinite(est).all()
+    loss, _ = PIT1d(NegSISDR(), n_sources=2)(est, sources)
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    with torch.no_grad():
+        alone = model(mixture[2:3])
+    assert _rel(alone, est[2:3].detach().cpu()) <= 1e-4
+
+
 def test_orpit_and_dsconv_on_gpu(golden_dir):
     from test_modules_cpu import _orpit_case, _dsconv_case
     g, x, loss, idx = _orpit_case(golden_dir, "cuda")
