@@ -203,25 +203,56 @@ def cpu_baseline(timed_steps=5):
     return out
 
 
-def bench_dprnn(args):
-    """BASELINE.json configs[3]: DPRNN-TasNet (N=64, L=2, F=64, H=128, K=250, P=125, 6 blocks, egs/wsj0-mix/dprnn-tasnet/train.sh:28-37),
-    2 speakers, 4 s @ 8 kHz, recipe batch size 2, one GPU: forward + PIT(NegSI-SDR) + backward + clip(5) + Adam (torch.optim.Adam:
-    this model's parameters are ordinary tensors).  A frame is one encoder frame (31,999 per utterance).  Segment / overlap-add, gLN,
-    encoder / mask / decoder and the LSTM time recurrence are this library's kernels; the LSTM input projections, the Linear
-    layers and their weight gradients are library GEMMs (torch -> rocBLAS), as DESIGN.md states."""
-    import sepkernels
+def _dual_path_workloads():
+    """--config name -> (class, constructor arguments, recipe batch size, Adam arguments, GFLOP/utterance or None, what runs where)"""
     from models.dprnn_tasnet import DPRNNTasNet
+    from models.dptnet import DPTNet
+    from models.galrnet import GALRNet
+    from models.sepformer import SepFormer
+    tr = dict(enc_basis="trainable", dec_basis="trainable")
+    return {
+        # BASELINE.json configs[3]: egs/wsj0-mix/dprnn-tasnet/train.sh:28-37
+        "dprnn": (DPRNNTasNet, dict(n_basis=64, kernel_size=2, stride=1, enc_nonlinear=None, sep_hidden_channels=128, sep_bottleneck_channels=64,
+                                    sep_chunk_size=250, sep_hop_size=125, sep_num_blocks=6, sep_norm=True, mask_nonlinear="sigmoid", causal=False,
+                                    rnn_type="lstm", n_sources=2, **tr), 2, dict(lr=1e-3), 980.07,
+                  "DPRNN-TasNet N=64 L=2 F=64 H=128 K=250 P=125 B=6 (BASELINE configs[3])"),
+        # SURVEY.md section 8 row f4, the reference recipes' own sizes: egs/wsj0-mix/{dptnet,galrnet,sepformer}/train.sh
+        "dptnet": (DPTNet, dict(n_basis=64, kernel_size=2, stride=1, enc_nonlinear=None, sep_bottleneck_channels=64, sep_hidden_channels=128,
+                                sep_chunk_size=250, sep_hop_size=125, sep_num_blocks=6, sep_num_heads=4, sep_norm=True, sep_nonlinear="relu",
+                                sep_dropout=0, mask_nonlinear="relu", causal=False, n_sources=2, **tr), 1, dict(lr=1e-3), None,
+                   "DPTNet N=64 L=2 F=64 d_ff=128 K=250 P=125 B=6 h=4 (egs/wsj0-mix/dptnet/train.sh:28-44)"),
+        "galrnet": (GALRNet, dict(n_basis=64, kernel_size=16, stride=8, enc_nonlinear=None, sep_hidden_channels=128, sep_chunk_size=100,
+                                  sep_hop_size=50, sep_down_chunk_size=32, sep_num_blocks=6, sep_num_heads=8, sep_norm=True, sep_dropout=1e-1,
+                                  mask_nonlinear="relu", causal=False, n_sources=2, low_dimension=True, **tr), 4, dict(lr=1e-3, weight_decay=1e-6), None,
+                    "GALRNet D=64 M=16 H=128 K=100 P=50 Q=32 N=6 J=8 (egs/wsj0-mix/galrnet/train.sh:28-42)"),
+        "sepformer": (SepFormer, dict(n_basis=256, kernel_size=16, stride=8, enc_nonlinear="relu", sep_bottleneck_channels=256, sep_chunk_size=250,
+                                      sep_hop_size=125, sep_num_blocks=2, sep_num_layers_intra=8, sep_num_layers_inter=8, sep_num_heads_intra=8,
+                                      sep_num_heads_inter=8, sep_d_ff_intra=1024, sep_d_ff_inter=1024, sep_norm=True, sep_nonlinear="relu",
+                                      sep_dropout=1e-1, mask_nonlinear="relu", causal=False, n_sources=2, **tr), 4, dict(lr=15e-5), None,
+                      "SepFormer F=256 L=16 B=256 C=250 P=125 N=2 K=8+8 h=8 d_ff=1024 (egs/wsj0-mix/sepformer/train.sh:27-47)"),
+    }
+
+
+def bench_dual_path(args):
+    """The dual-path separators at the sizes of the reference's own recipes, 2 speakers, 4 s @ 8 kHz, the recipe's batch size, one
+    GPU: forward + PIT(NegSI-SDR) + backward + clip(5) + Adam (torch.optim.Adam: these models' parameters are ordinary tensors).
+    A frame is one encoder frame.  Analysis / synthesis bases, every 1x1 convolution of the separator's two ends, chunking /
+    overlap-add, gLN and the LSTM time recurrences are this library's kernels; attention, the transformer feed-forward layers, the
+    LSTM input projections, the Linear layers and their weight gradients are library GEMMs (torch -> rocBLAS / SDPA), as DESIGN.md
+    states."""
+    import sepkernels
     from criterion.sdr import NegSISDR
     from criterion.pit import PIT1d
     sepkernels.load()
     dev = torch.device("cuda", 0)
+    cls, cfg, recipe_batch, adam, gflop, label = _dual_path_workloads()[args.config]
     torch.manual_seed(111)
-    model = DPRNNTasNet(n_basis=64, kernel_size=2, stride=1, enc_basis="trainable", dec_basis="trainable", enc_nonlinear=None,
-                        sep_hidden_channels=128, sep_bottleneck_channels=64, sep_chunk_size=250, sep_hop_size=125, sep_num_blocks=6,
-                        sep_norm=True, mask_nonlinear="sigmoid", causal=False, rnn_type="lstm", n_sources=2).to(dev)
+    model = cls(**cfg).to(dev)
+    problems = model.kernel_path_problems() if hasattr(model, "kernel_path_problems") else []
+    assert not problems, problems
     crit = PIT1d(NegSISDR(), n_sources=2)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-    B = 2 if args.batch == PER_GPU_BATCH else args.batch
+    opt = torch.optim.Adam(model.parameters(), **adam)
+    B = recipe_batch if args.batch == PER_GPU_BATCH else args.batch
     src = (0.1 * torch.randn(B, 2, T_SAMPLES, generator=torch.Generator().manual_seed(111))).to(dev)
     mix = src.sum(1, keepdim=True).contiguous()
 
@@ -240,17 +271,21 @@ def bench_dprnn(args):
         loss = step()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    F = T_SAMPLES - 2 + 1
+    L, S = cfg["kernel_size"], cfg["stride"]
+    F = (T_SAMPLES + (S - (T_SAMPLES - L) % S) % S - L) // S + 1
+    config = {"workload": "{}, 2 spk, 4 s @ 8 kHz synthetic mixtures, batch {} (recipe default), fwd + PIT(NegSI-SDR) + bwd + clip(5) + Adam".format(label, B),
+              "global_batch": B, "frames_per_utterance": F, "parallelism": "dp1", "utt_per_s": B * args.steps / el, "final_loss": float(loss),
+              "parameters": model.num_parameters}
+    note = "no roofline: the step is a sequence of library GEMM / attention calls between this library's kernels, none of which dominates"
+    if gflop is not None:
+        config["algorithmic_gflop_per_utterance_fwd_bwd"] = gflop
+        note = "{:.0f} GFLOP per utterance (SURVEY.md 8d): {:.1f} TFLOP/s achieved; 57 % of it in this library's LSTM recurrence kernel " \
+               "(fp32 MFMA), the rest in rocBLAS GEMMs".format(gflop, gflop * 1e9 * B * args.steps / el / 1e12)
     print(json.dumps({
-        "metric": "separated audio frames/sec (fwd+bwd), DPRNN-TasNet 2-spk 4s@8kHz (BASELINE configs[3])", "value": B * F * args.steps / el, "unit": "frames/s",
+        "metric": "separated audio frames/sec (fwd+bwd), {} 2-spk 4s@8kHz".format("DPRNN-TasNet" if args.config == "dprnn" else cls.__name__) +
+                  (" (BASELINE configs[3])" if args.config == "dprnn" else ""), "value": B * F * args.steps / el, "unit": "frames/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "DPRNN-TasNet N=64 L=2 F=64 H=128 K=250 P=125 B=6, 2 spk, 4 s @ 8 kHz synthetic mixtures, batch {} (recipe default), "
-                               "fwd + PIT(NegSI-SDR) + bwd + clip(5) + Adam".format(B),
-                   "global_batch": B, "frames_per_utterance": F, "parallelism": "dp1", "utt_per_s": B * args.steps / el, "final_loss": float(loss),
-                   "algorithmic_gflop_per_utterance_fwd_bwd": 980.07},
-        "roofline": None, "roofline_note": "980 GFLOP per utterance (SURVEY.md 8d): {:.1f} TFLOP/s achieved; 57 % of it in this library's LSTM "
-                                           "recurrence kernel (fp32 MFMA), the rest in rocBLAS GEMMs".format(980.07e9 * B * args.steps / el / 1e12)}))
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": config, "roofline": None, "roofline_note": note}))
 
 
 def main():
@@ -263,12 +298,13 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-f32-pass", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured step (N = 1)")
-    ap.add_argument("--config", default="convtasnet2", choices=["convtasnet2", "sinkpit4", "dprnn"],
+    ap.add_argument("--config", default="convtasnet2", choices=["convtasnet2", "sinkpit4", "dprnn", "dptnet", "galrnet", "sepformer"],
                     help="convtasnet2 (default) = BASELINE.json configs[1]/[2], the headline; sinkpit4 = configs[4] (paper-best Conv-TasNet, "
-                         "4 speakers, SinkPIT(NegSI-SDR, coldness 1, 200 iterations)); dprnn = configs[3] (DPRNN-TasNet N64 L2 F64 H128 K250 P125 B6, batch 2)")
+                         "4 speakers, SinkPIT(NegSI-SDR, coldness 1, 200 iterations)); dprnn = configs[3] (DPRNN-TasNet N64 L2 F64 H128 K250 P125 B6, batch 2); dptnet / galrnet / sepformer = the reference recipes' "
+                         "own sizes of those separators (SURVEY.md section 8 row f4)")
     args = ap.parse_args()
-    if args.config == "dprnn":
-        return bench_dprnn(args)
+    if args.config in ("dprnn", "dptnet", "galrnet", "sepformer"):
+        return bench_dual_path(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

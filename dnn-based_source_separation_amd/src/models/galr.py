@@ -49,13 +49,23 @@ class GloballyAttentiveBlockBase(nn.Module):
         angle = position / base ** index
         return torch.cat([torch.sin(angle), torch.cos(angle)], dim=1)
 
+    def _position_code(self, S, Q, C, like):
+        """(C, S, Q) code on the device / in the dtype of `like`, built once per shape: forming it on the host and copying it
+        over in every forward would stall the launch queue once per block"""
+        cache = self.__dict__.setdefault("_codes", {})
+        key = (S, Q, C, like.device, like.dtype)
+        if key not in cache:
+            cache.clear()                                    # one shape at a time (training: fixed length; evaluation: one utterance)
+            cache[key] = self.positional_encoding(length=S * Q, dimension=C).t().reshape(C, S, Q).to(device=like.device, dtype=like.dtype)
+        return cache[key]
+
     def _attend(self, x):
         """x (batch_size, num_features, S, Q): [channel norm ->] + position code -> attention over S -> [dropout] + its input
         -> [gLN / cLN].  The position code runs over the FLATTENED (S, Q) index, as the reference's does."""
         B, C, S, Q = x.size()
         if self.norm:
             x = self.norm2d_in(x)
-        code = self.positional_encoding(length=S * Q, dimension=C).t().reshape(C, S, Q).to(device=x.device, dtype=x.dtype)
+        code = self._position_code(S, Q, C, x)
         seq = (x + code).permute(2, 0, 3, 1).reshape(S, B * Q, C)
         y = self.multihead_attn(seq, seq, seq, need_weights=False)[0]
         if self.dropout:
