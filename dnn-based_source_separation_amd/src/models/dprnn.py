@@ -3,13 +3,14 @@ Dual-path RNN blocks: module tree / parameter names of reference src/models/dprn
 
 The recurrences run on libsepkernels (`sep_lstm_fwd/bwd`: one persistent workgroup per 16 sequences, W_hh held in
 registers as MFMA fragments, one barrier per step); `nn.LSTM` is only the parameter container, so checkpoints keep the
-reference's keys (`rnn.weight_ih_l0`, `rnn.weight_hh_l0_reverse`, ...).  The input projection, the Linear after the RNN
+reference's keys (`rnn.weight_ih_l0`, `rnn.weight_hh_l0_reverse`, ...).  Hidden sizes the sweep kernels do not cover run on
+torch's own LSTM.  The input projection, the Linear after the RNN
 and the weight-gradient products are plain library GEMMs; the global layer norm after every path is the libsepkernels
 gLN; layout changes are torch views/permutes.
 """
 import torch.nn as nn
 
-from sepkernels.functional import lstm_bidirectional
+from sepkernels.functional import lstm_apply
 
 from utils.model import choose_rnn
 from utils.tasnet import choose_layer_norm
@@ -44,7 +45,7 @@ class _PathRNN(nn.Module):
     def __init__(self, num_features, hidden_channels, bidirectional, norm_name, norm, rnn_type, causal, eps):
         super().__init__()
         if rnn_type != "lstm":
-            raise NotImplementedError("Not support {}.".format(rnn_type))
+            raise NotImplementedError("Not support {}.".format(rnn_type))            # as the reference (dprnn.py:59-62, 110-113)
         self.num_features, self.hidden_channels = num_features, hidden_channels
         self.norm = norm
         self.rnn = choose_rnn(rnn_type, input_size=num_features, hidden_size=hidden_channels, batch_first=True, bidirectional=bidirectional)
@@ -59,9 +60,7 @@ class _PathRNN(nn.Module):
             x = input.permute(0, 2, 3, 1).reshape(B * S, K, F)
         else:
             x = input.permute(0, 3, 2, 1).reshape(B * K, S, F)
-        if self.hidden_channels not in (16, 32, 64, 128):
-            raise NotImplementedError("the LSTM sweep kernels cover hidden sizes 16, 32, 64, 128 (got {})".format(self.hidden_channels))
-        x = lstm_bidirectional(x.contiguous(), self.rnn)
+        x = lstm_apply(x, self.rnn)              # the sweep kernels for 16 / 32 / 64 / 128 units, torch's LSTM otherwise
         x = self.fc(x)                                           # (B*S, K, F) or (B*K, S, F)
         x = x.reshape(B, S * K, F).permute(0, 2, 1).contiguous()  # (B, F, S*K) [or (B, F, K*S)]
         if self.norm:

@@ -1,36 +1,37 @@
 """
 DPRNN-TasNet on MI355X (BASELINE.json configs[3]).  API, module tree and state_dict keys of reference
-src/models/dprnn_tasnet.py:15-351.  Encoder + first gLN + bottleneck ("head") and PReLU + mask conv + sigmoid +
+src/models/dprnn_tasnet.py:15-351.  Encoder + first gLN + bottleneck ("head") and PReLU + mask conv + sigmoid | softmax +
 mask*w + decoder/overlap-add ("tail") are the Conv-TasNet kernels of libsepkernels; chunking is sep_segment /
-sep_overlap_add; the dual-path recurrences are the interim torch.nn.LSTM composition of models/dprnn.py.
+sep_overlap_add; the dual-path recurrences are models/dprnn.py (LSTM sweep kernels).  Configurations outside that family
+(causal: cLN in front of the bottleneck; Fourier / pinv bases; widths off the multiples of 16; float64) run as the
+module-by-module composition of the shared shell (models/masking.py), with cLN, gLN, chunking and the recurrences still on
+their kernels.
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
-from utils.filterbank import choose_filterbank
 from utils.tasnet import choose_layer_norm
 from models.dprnn import DPRNN
+from models.masking import MaskingTasNet
 from models.transform import Segment1d, OverlapAdd1d
 from sepkernels import net as _net
-from sepkernels.functional import HeadFn, TailFn, SegmentFn, OverlapAddFn, HEAD_KEYS, TAIL_KEYS
+from sepkernels.functional import HeadFn, TailFn, SegmentFn, OverlapAddFn, HEAD_KEYS, TAIL_KEYS, segment_geometry
 
 EPS = 1e-12
 
 
-class DPRNNTasNet(nn.Module):
+class DPRNNTasNet(MaskingTasNet):
+    pretrained_model_ids = {"wsj0-mix": {8000: {2: "1-2DOUDi2NImL7akQzTXLpDqJsJL4HyiY", 3: "1-5EhjEBiArjFat4gXyNkKyUjAkTvkgU0"}, 16000: {2: "", 3: ""}},
+                            "librispeech": {16000: {2: "1hTmxhI8JQlNnWVjwWUBGYlC7O_-ykK4H"}}}
+    SEP_KEYS = ("sep_hidden_channels", "sep_bottleneck_channels", "sep_chunk_size", "sep_hop_size", "sep_num_blocks", "sep_norm", "rnn_type")
+    CONFIG_HAS_IN_CHANNELS = True
+    MULTICHANNEL_INPUT = True
+
     def __init__(self, n_basis, kernel_size, stride=None, enc_basis=None, dec_basis=None, sep_hidden_channels=128,
                  sep_bottleneck_channels=64, sep_chunk_size=100, sep_hop_size=50, sep_num_blocks=6, sep_norm=True,
                  mask_nonlinear="sigmoid", causal=True, rnn_type="lstm", n_sources=2, eps=EPS, **kwargs):
         super().__init__()
-        if stride is None:
-            stride = kernel_size // 2
-        assert kernel_size % stride == 0, "kernel_size is expected divisible by stride"
-        self.in_channels = kwargs.get("in_channels", 1)
-        self.n_basis = n_basis
-        self.kernel_size, self.stride = kernel_size, stride
-        self.enc_basis, self.dec_basis = enc_basis, dec_basis
-        self.enc_nonlinear = kwargs["enc_nonlinear"] if (enc_basis == "trainable" and not dec_basis == "pinv") else None
-        self.window_fn, self.enc_onesided, self.enc_return_complex = None, None, None
         self.sep_hidden_channels, self.sep_bottleneck_channels = sep_hidden_channels, sep_bottleneck_channels
         self.sep_chunk_size, self.sep_hop_size = sep_chunk_size, sep_hop_size
         self.sep_num_blocks = sep_num_blocks
@@ -40,75 +41,38 @@ class DPRNNTasNet(nn.Module):
         self.rnn_type = rnn_type
         self.n_sources = n_sources
         self.eps = eps
-        encoder, decoder = choose_filterbank(n_basis, kernel_size=kernel_size, stride=stride, enc_basis=enc_basis, dec_basis=dec_basis, **kwargs)
+        stride = self._init_filterbank(n_basis, kernel_size, stride, enc_basis, dec_basis, kwargs)
+        encoder, decoder = self.encoder, self.decoder           # registration order of the reference: encoder, separator, decoder
+        del self.encoder, self.decoder
         self.encoder = encoder
         self.separator = Separator(n_basis, bottleneck_channels=sep_bottleneck_channels, hidden_channels=sep_hidden_channels,
                                    chunk_size=sep_chunk_size, hop_size=sep_hop_size, num_blocks=sep_num_blocks, norm=sep_norm,
                                    mask_nonlinear=mask_nonlinear, causal=causal, rnn_type=rnn_type, n_sources=n_sources, eps=eps)
         self.decoder = decoder
 
-    def forward(self, input):
-        output, _ = self._run(input, False)
-        return output
-
-    def extract_latent(self, input):
-        """input (B, 1, T) -> output (B, n_sources, T), latent (B, n_sources, n_basis, T')"""
-        return self._run(input, True)
-
-    def _kernel_cfg(self):
+    def kernel_path_problems(self):
+        problems = super().kernel_path_problems()
         if self.causal:
-            raise NotImplementedError("causal DPRNN-TasNet (cLN) is not implemented on the MI355X path")
-        if self.mask_nonlinear != "sigmoid":
-            raise NotImplementedError("mask_nonlinear must be 'sigmoid'")
-        if self.enc_nonlinear not in (None, "", "relu"):
-            raise NotImplementedError("enc_nonlinear must be None or 'relu'")
-        if self.n_basis % 16 or self.sep_bottleneck_channels % 16 or (self.n_sources * self.n_basis) % 16:
-            raise NotImplementedError("n_basis and sep_bottleneck_channels must be multiples of 16")
-        return {"n_basis": self.n_basis, "kernel_size": self.kernel_size, "stride": self.stride,
-                "sep_bottleneck_channels": self.sep_bottleneck_channels, "n_sources": self.n_sources,
-                "enc_nonlinear": self.enc_nonlinear, "eps": self.eps}
+            problems.append("causal=True puts a cLN in front of the bottleneck (the fused head normalises globally)")
+        return problems
 
-    def _run(self, input, want_latent):
-        n_dim = input.dim()
-        if n_dim == 3:
-            batch_size, C_in, T = input.size()
-            assert C_in == 1, "input.size() is expected (?, 1, ?), but given {}".format(input.size())
-            mixture = input
-        elif n_dim == 4:
-            batch_size, C_in, n_mics, T = input.size()
-            assert C_in == 1, "input.size() is expected (?, 1, ?, ?), but given {}".format(input.size())
-            mixture = input.view(batch_size, n_mics, T)
-        else:
-            raise ValueError("Not support {} dimension input".format(n_dim))
-        cfg = self._kernel_cfg()
-        if not mixture.is_cuda and _net.backend().name == "hip":
-            raise RuntimeError("DPRNNTasNet (MI355X build) runs on the GPU only; there is no CPU fallback.")
-        mixture = mixture.contiguous()
-        if mixture.dtype != torch.float32 and _net.backend().name == "hip":
-            mixture = mixture.float()
+    def _run_kernels(self, mixture):
+        T = mixture.shape[-1]
+        cfg = {"n_basis": self.n_basis, "kernel_size": self.kernel_size, "stride": self.stride,
+               "sep_bottleneck_channels": self.sep_bottleneck_channels, "n_sources": self.n_sources,
+               "enc_nonlinear": "relu" if self.encoder.nonlinear else None, "mask_nonlinear": self.mask_nonlinear, "eps": self.eps}
         P = dict(self.named_parameters())
         w, x0 = HeadFn.apply(mixture, cfg, *[P[k] for k in HEAD_KEYS])
         geo = _net.Geometry(T, self.kernel_size, self.stride)
         core = self.separator.dual_path(x0, geo.F, geo.ldt)
-        out = TailFn.apply(w, core, cfg, geo, tuple(mixture.shape), want_latent, *[P[k] for k in TAIL_KEYS])
-        est, latent = (out if want_latent else (out, None))
-        if latent is not None:
-            latent = latent[..., :geo.F]
-        if n_dim == 3:
-            est = est.view(batch_size, self.n_sources, T)
-        return est, latent
+        est, latent = TailFn.apply(w, core, cfg, geo, tuple(mixture.shape), True, *[P[k] for k in TAIL_KEYS])
+        return est, latent[..., :geo.F]
 
     def get_config(self):
-        return {"in_channels": self.in_channels, "n_basis": self.n_basis, "kernel_size": self.kernel_size, "stride": self.stride,
-                "enc_basis": self.enc_basis, "dec_basis": self.dec_basis, "enc_nonlinear": self.enc_nonlinear,
-                "window_fn": self.window_fn, "enc_onesided": self.enc_onesided, "enc_return_complex": self.enc_return_complex,
-                "sep_hidden_channels": self.sep_hidden_channels, "sep_bottleneck_channels": self.sep_bottleneck_channels,
-                "sep_chunk_size": self.sep_chunk_size, "sep_hop_size": self.sep_hop_size, "sep_num_blocks": self.sep_num_blocks,
-                "causal": self.causal, "sep_norm": self.sep_norm, "mask_nonlinear": self.mask_nonlinear,
-                "rnn_type": self.rnn_type, "n_sources": self.n_sources, "eps": self.eps}
-
-    def get_package(self):
-        return self.get_config()
+        config = super().get_config()
+        return {k: config[k] for k in ("in_channels", "n_basis", "kernel_size", "stride", "enc_basis", "dec_basis", "enc_nonlinear", "window_fn",
+                                       "enc_onesided", "enc_return_complex", "sep_hidden_channels", "sep_bottleneck_channels", "sep_chunk_size",
+                                       "sep_hop_size", "sep_num_blocks", "causal", "sep_norm", "mask_nonlinear", "rnn_type", "n_sources", "eps")}
 
     @classmethod
     def build_model(cls, model_path, load_state_dict=False):
@@ -125,10 +89,6 @@ class DPRNNTasNet(nn.Module):
         if load_state_dict:
             model.load_state_dict(config["state_dict"])
         return model
-
-    @property
-    def num_parameters(self):
-        return sum(p.numel() for p in self.parameters() if p.requires_grad)
 
 
 class Separator(nn.Module):
@@ -158,4 +118,17 @@ class Separator(nn.Module):
         return OverlapAddFn.apply(y, n_frames, ldt, self.hop_size)
 
     def forward(self, input):
-        raise NotImplementedError("the DPRNN-TasNet separator runs inside DPRNNTasNet (head / dual_path / tail)")
+        """the separator module by module (reference dprnn_tasnet.py:323-349): input (batch_size, num_features, n_frames) ->
+        mask (batch_size, n_sources, num_features, n_frames)"""
+        batch_size, _, n_frames = input.size()
+        pad_left, pad_right, _ = segment_geometry(n_frames, self.chunk_size, self.hop_size)
+        x = F.pad(self.bottleneck_conv1d(self.norm1d(input)), (pad_left, pad_right))
+        x = F.pad(self.overlap_add1d(self.dprnn(self.segment1d(x))), (-pad_left, -pad_right))
+        x = self.mask_nonlinear(self.mask_conv1d(self.prelu(x)))
+        return x.view(batch_size, self.n_sources, self.num_features, n_frames)
+
+    def padded_problems(self):
+        """why the head / dual_path / tail kernel sequence cannot run (empty: it can)"""
+        widths = {"num_features": self.num_features, "bottleneck_channels": self.bottleneck_conv1d.out_channels,
+                  "n_sources*num_features": self.n_sources * self.num_features}
+        return ["{} must be a multiple of 16".format(k) for k, v in widths.items() if v % 16]

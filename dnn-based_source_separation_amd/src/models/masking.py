@@ -208,9 +208,10 @@ class MaskingTasNet(nn.Module):
         task = kwargs.get("task")
         if task not in cls.pretrained_model_ids:
             raise KeyError("Invalid task ({}) is specified.".format(task))
-        if task not in ("wsj0-mix", "wsj0"):
+        defaults = {"wsj0-mix": 8000, "wsj0": 8000, "librispeech": 16000}
+        if task not in defaults:
             raise NotImplementedError("Not support task={}.".format(task))
-        sample_rate, n_sources = kwargs.get("sample_rate") or 8000, kwargs.get("n_sources") or 2
+        sample_rate, n_sources = kwargs.get("sample_rate") or defaults[task], kwargs.get("n_sources") or 2
         model_choice = kwargs.get("model_choice") or "best"
         model_id = cls.pretrained_model_ids[task][sample_rate][n_sources]
         download_dir = os.path.join(root, cls.__name__, task, "sr{}/{}speakers".format(sample_rate, n_sources))

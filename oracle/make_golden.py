@@ -280,7 +280,18 @@ SIBLINGS = {
                                            sep_num_blocks=1, sep_num_layers_intra=1, sep_num_layers_inter=1, sep_num_heads_intra=2,
                                            sep_num_heads_inter=2, sep_d_ff_intra=24, sep_d_ff_inter=24, sep_dropout=0.0,
                                            mask_nonlinear="sigmoid", causal=True, n_sources=2, **_ENC)),
+    # DPRNN-TasNet outside its head / tail kernel family (the small in-family instance is dprnn_tasnet_small above)
+    "dprnn_tasnet_causal": ("DPRNNTasNet", dict(n_basis=32, enc_nonlinear=None, sep_hidden_channels=16, sep_bottleneck_channels=32,
+                                                sep_chunk_size=10, sep_hop_size=5, sep_num_blocks=1, sep_norm=True, mask_nonlinear="sigmoid",
+                                                causal=True, rnn_type="lstm", n_sources=2, **_ENC)),
+    "dprnn_tasnet_odd": ("DPRNNTasNet", dict(n_basis=24, enc_nonlinear="relu", sep_hidden_channels=12, sep_bottleneck_channels=20,
+                                             sep_chunk_size=12, sep_hop_size=6, sep_num_blocks=1, sep_norm=True, mask_nonlinear="softmax",
+                                             causal=False, rnn_type="lstm", n_sources=2, **_ENC)),
+    "dprnn_tasnet_softmax": ("DPRNNTasNet", dict(n_basis=32, enc_nonlinear="relu", sep_hidden_channels=16, sep_bottleneck_channels=32,
+                                                 sep_chunk_size=12, sep_hop_size=6, sep_num_blocks=1, sep_norm=True, mask_nonlinear="softmax",
+                                                 causal=False, rnn_type="lstm", n_sources=3, **_ENC)),
 }
+SIBLING_MODULES = {"DPTNet": "models.dptnet", "GALRNet": "models.galrnet", "SepFormer": "models.sepformer", "DPRNNTasNet": "models.dprnn_tasnet"}
 
 
 def perturb_all(model, seed):
@@ -303,7 +314,7 @@ def sibling_golden(name, NegSISDR, PIT1d):
     import copy
     import importlib
     kind, cfg = SIBLINGS[name]
-    cls = getattr(importlib.import_module("models." + kind.lower()), kind)
+    cls = getattr(importlib.import_module(SIBLING_MODULES[kind]), kind)
     torch.manual_seed(111)
     model = cls(**cfg)
     perturb_all(model, 17)

@@ -353,23 +353,26 @@ def test_dprnn_tasnet_golden(golden_dir):
     assert flat_rel <= 2e-3, "flat gradient rel-inf {:.3e}, worst tensor {}".format(flat_rel, worst)
 
 
-@pytest.mark.parametrize("name", ["dptnet", "dptnet_causal", "dptnet_odd", "galrnet", "galrnet_causal", "sepformer", "sepformer_causal"])
+@pytest.mark.parametrize("name", ["dptnet", "dptnet_causal", "dptnet_odd", "galrnet", "galrnet_causal", "sepformer", "sepformer_causal",
+                                  "dprnn_tasnet_causal", "dprnn_tasnet_odd", "dprnn_tasnet_softmax"])
 def test_sibling_separators_golden(golden_dir, name):
     """DPTNet / GALRNet / SepFormer on the device against the reference's fp64 run -- encoder, 1x1
     convolutions (bottleneck, PReLU + map, the stacked GTU pair, SepFormer's fused head and output convolution), chunking,
     gLN / cLN, LSTM sweeps and mask * w + decoder on libsepkernels; `_odd` (widths off the multiples of 16, softmax mask) is the
-    composition path on the device."""
+    composition path on the device, and so are DPRNN-TasNet's causal / odd-width instances (`dprnn_tasnet_softmax`: the head / tail
+    kernels with the channel softmax)."""
     from oracle.make_golden import SIBLINGS
     from models.dptnet import DPTNet
     from models.galrnet import GALRNet
     from models.sepformer import SepFormer
+    from models.dprnn_tasnet import DPRNNTasNet
     kind, cfg = SIBLINGS[name]
     g = np.load(os.path.join(golden_dir, name + ".npz"))
-    model = {"DPTNet": DPTNet, "GALRNet": GALRNet, "SepFormer": SepFormer}[kind](**cfg)
+    model = {"DPTNet": DPTNet, "GALRNet": GALRNet, "SepFormer": SepFormer, "DPRNNTasNet": DPRNNTasNet}[kind](**cfg)
     assert list(model.state_dict().keys()) == list(g["state_keys"])
     model.load_state_dict({k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param/")}, strict=False)
     model.cuda()
-    assert (not model.kernel_path_problems()) == (not name.endswith("_odd"))
+    assert (not model.kernel_path_problems()) == (name not in ("dptnet_odd", "dprnn_tasnet_odd", "dprnn_tasnet_causal"))
     mixture, sources = torch.from_numpy(g["mixture"]).cuda(), torch.from_numpy(g["sources"]).cuda()
     est, latent = model.extract_latent(mixture)
     assert _rel(est, torch.from_numpy(g["output_f64"])) <= TOL

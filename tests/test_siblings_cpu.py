@@ -1,4 +1,5 @@
-"""CPU: DPTNet, GALRNet and SepFormer through the public module API with the CPU emulator of the C ABI,
+"""CPU: DPTNet, GALRNet and SepFormer -- and DPRNN-TasNet outside its head / tail kernel family (causal,
+odd widths; softmax mask inside it) -- through the public module API with the CPU emulator of the C ABI,
 against golden vectors generated from the unmodified reference (oracle/make_golden.py::sibling_golden, fp64 run): state_dict key
 list and order, parameter count, config keys, forward, latent, PIT loss, permutation and EVERY parameter gradient -- on the
 kernel path (channel counts in multiples of 16) and on the composition path (odd widths, softmax mask), both checked to be the
@@ -15,12 +16,14 @@ from oracle.make_golden import SIBLINGS
 from models.dptnet import DPTNet
 from models.galrnet import GALRNet
 from models.sepformer import SepFormer
+from models.dprnn_tasnet import DPRNNTasNet
 from models.gtu import GTU1d
 from models.transformer import PositionalEncoding
 from criterion.sdr import NegSISDR
 from criterion.pit import PIT1d
 
-CLASSES = {"DPTNet": DPTNet, "GALRNet": GALRNet, "SepFormer": SepFormer}
+CLASSES = {"DPTNet": DPTNet, "GALRNet": GALRNet, "SepFormer": SepFormer, "DPRNNTasNet": DPRNNTasNet}
+COMPOSED = ("dptnet_odd", "dprnn_tasnet_odd", "dprnn_tasnet_causal")          # fixtures that must take the composition path
 
 
 class CountingEmu(EmuBackend):
@@ -62,7 +65,7 @@ def _build(golden_dir, name):
 @pytest.mark.parametrize("name", sorted(SIBLINGS))
 def test_sibling_separator_matches_the_reference(golden_dir, name, emu):
     g, cfg, model = _build(golden_dir, name)
-    on_kernels = not name.endswith("_odd")
+    on_kernels = name not in COMPOSED
     assert (not model.kernel_path_problems()) == on_kernels
     mixture, sources = torch.from_numpy(g["mixture"]).double(), torch.from_numpy(g["sources"]).double()
     est, latent = model.extract_latent(mixture)
@@ -81,7 +84,7 @@ def test_sibling_separator_matches_the_reference(golden_dir, name, emu):
         assert (p.grad - r).abs().max() <= 2e-6 * max(r.abs().max().item(), 1e-6), k          # the fixture stores fp64 gradients as fp32
 
 
-@pytest.mark.parametrize("name", ["dptnet", "galrnet_causal", "sepformer", "sepformer_causal"])
+@pytest.mark.parametrize("name", ["dptnet", "galrnet_causal", "sepformer", "sepformer_causal", "dprnn_tasnet_softmax"])
 def test_kernel_path_equals_composition(golden_dir, name, emu):
     """same model, same input: the libsepkernels sequence and the module-by-module composition, outputs and gradients"""
     g, cfg, model = _build(golden_dir, name)
