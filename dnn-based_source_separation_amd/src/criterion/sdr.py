@@ -99,10 +99,14 @@ class _SISDRBase(nn.Module):
         self.reduction = reduction
         self.eps = eps
 
+    def _clip(self, per_source):
+        """hook of the clipped variants: applied to the value of every (estimate, target) pair before any reduction"""
+        return per_source
+
     def forward(self, input, target, batch_mean=True):
         n_dims = input.dim()
         assert n_dims in [2, 3, 4], "Only 2D or 3D or 4D tensor is acceptable, but given {}D tensor.".format(n_dims)
-        loss = self._sign * self._measure(input, target, self.eps)
+        loss = self._clip(self._sign * self._measure(input, target, self.eps))
         if self.reduction:
             dims = {3: 1, 4: (1, 2)}.get(n_dims)
             if dims is not None:
@@ -144,3 +148,31 @@ class NegSDR(_SISDRBase):
     @property
     def maximize(self):
         return False
+
+
+class ClippedSISDR(SISDR):
+    """SI-SDR with every per-source value capped at `max` dB before the reductions (reference sdr.py:233-279)"""
+
+    def __init__(self, max=None, reduction="mean", eps=EPS):
+        super().__init__(reduction=reduction, eps=eps)
+        self.max = max
+
+    def _clip(self, per_source):
+        return torch.clamp(per_source, max=self.max)
+
+
+class ClippedNegSISDR(NegSISDR):
+    """-SI-SDR with every per-source value floored at `min` (the SepFormer recipe's criterion: min = -30 dB;
+    reference sdr.py:281-327, egs/wsj0-mix/sepformer/local/train.py:125-126)"""
+
+    def __init__(self, min=None, reduction="mean", eps=EPS):
+        super().__init__(reduction=reduction, eps=eps)
+        self.min = min
+
+    def _clip(self, per_source):
+        return torch.clamp(per_source, min=self.min)
+
+
+from sepkernels.shadowed import fall_through as _fall_through      # names of the reference's same-named module this tree does not define
+
+__getattr__ = _fall_through(__name__, __file__)

