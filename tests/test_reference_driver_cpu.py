@@ -109,8 +109,9 @@ TRAIN_SCRIPT = textwrap.dedent('''
 ''')
 
 
-def _wav_tree(root, n_utt, seed):
-    """wsj0-mix layout: <root>/(mix|s1|s2)/<ID>.wav + a list file of IDs."""
+def _wav_tree(root, n_utt, seed, mixed_numbers=False):
+    """wsj0-mix layout: <root>/(mix|s1|s2[|s3])/<ID>.wav + a list file of IDs (mixed_numbers: every other utterance has three sources,
+    the tree of the one-and-rest recipe)."""
     import torch
     from recipes.audio_io import write_wav
     g = torch.Generator().manual_seed(seed)
@@ -118,8 +119,9 @@ def _wav_tree(root, n_utt, seed):
     for k in range(n_utt):
         ID = "utt%02d" % k
         T = 2400 + 160 * k
-        s = 0.1 * torch.randn(2, T, generator=g)
-        for name, x in (("s1", s[0:1]), ("s2", s[1:2]), ("mix", s.sum(0, keepdim=True))):
+        n = 3 if (mixed_numbers and k % 2) else 2
+        s = 0.1 * torch.randn(n, T, generator=g)
+        for name, x in [("s%d" % (i + 1), s[i:i + 1]) for i in range(n)] + [("mix", s.sum(0, keepdim=True))]:
             os.makedirs(os.path.join(root, name), exist_ok=True)
             write_wav(os.path.join(root, name, ID + ".wav"), x, 8000, 16)
         ids.append(ID)
@@ -135,6 +137,9 @@ RECIPES = {
     "conv-tasnet": (["--enc_nonlinear", "relu", "-N", "64", "-L", "16", "-B", "64", "-H", "128", "-Sc", "64", "-P", "3", "-X", "2", "-R", "1",
                      "--dilated", "1", "--separable", "1", "--causal", "0", "--sep_nonlinear", "prelu", "--sep_norm", "1",
                      "--mask_nonlinear", "sigmoid", "--criterion", "sisdr", "--lr", "1e-3"], 58117, "models.conv_tasnet:ConvTasNet"),
+    "orpit_conv-tasnet": (["--enc_nonlinear", "relu", "-N", "64", "-L", "16", "-B", "64", "-H", "128", "-Sc", "64", "-P", "3", "-X", "2", "-R", "1",
+                           "--dilated", "1", "--separable", "1", "--causal", "0", "--sep_nonlinear", "prelu", "--sep_norm", "1",
+                           "--mask_nonlinear", "sigmoid", "--criterion", "sisdr", "--lr", "1e-3"], 58117, "models.conv_tasnet:ConvTasNet"),
     "dprnn-tasnet": (["-N", "32", "-L", "4", "-F", "32", "-H", "16", "-K", "20", "-P", "10", "-B", "1", "--causal", "0", "--sep_norm", "1",
                       "--mask_nonlinear", "sigmoid", "--criterion", "sisdr", "--lr", "1e-3"], None, "models.dprnn_tasnet:DPRNNTasNet"),
     "dptnet": (["-N", "32", "-L", "4", "-F", "32", "-d_ff", "16", "-K", "20", "-P", "10", "-B", "1", "--sep_num_heads", "4", "--causal", "0",
@@ -154,15 +159,17 @@ def test_reference_recipe_train_py_runs_end_to_end(tmp_path, recipe_name):
     """The reference's own egs/wsj0-mix/<recipe>/local/train.py (argparse -> WaveTrainDataset / WaveEvalDataset over a wav tree ->
     the model class -> torch.optim.Adam -> PIT1d(NegSISDR() | ClippedNegSISDR()) -> the recipe's trainer, DPTNet's warm-up schedule
     included), unmodified, on a synthetic wsj0-mix-style tree, with this repository's src/ in front of the reference's: two epochs,
-    checkpoints in the reference's format, reloadable through this repository's build_model.  Conv-TasNet, DPRNN-TasNet, DPTNet,
-    GALRNet, SepFormer."""
+    checkpoints in the reference's format, reloadable through this repository's build_model.  Conv-TasNet (PIT and the one-and-rest
+    recipe with its mixed-number-of-sources loaders and ORPIT), DPRNN-TasNet, DPTNet, GALRNet, SepFormer."""
     model_args, n_params, loader = RECIPES[recipe_name]
     sys.path.insert(0, os.path.join(ROOT, "dnn-based_source_separation_amd", "src"))
     tr, cv = str(tmp_path / "tr"), str(tmp_path / "cv")
-    tr_list, cv_list = _wav_tree(tr, 5, 1), _wav_tree(cv, 2, 2)
+    orpit = recipe_name.startswith("orpit")                        # one-and-rest PIT on mixtures of 2 and 3 speakers, a 2-output model
+    tr_list, cv_list = _wav_tree(tr, 5, 1, mixed_numbers=orpit), _wav_tree(cv, 2, 2, mixed_numbers=orpit)
     out = str(tmp_path / "exp")
+    tail = [a if a != "2" or _COMMON_TAIL[i - 1] != "--n_sources" else "2+3" for i, a in enumerate(_COMMON_TAIL)] if orpit else _COMMON_TAIL
     argv = ["train.py", "--train_wav_root", tr, "--valid_wav_root", cv, "--train_list_path", tr_list, "--valid_list_path", cv_list,
-            "--sample_rate", "8000", "--duration", "0.2", "--valid_duration", "0.5"] + model_args + _COMMON_TAIL + \
+            "--sample_rate", "8000", "--duration", "0.2", "--valid_duration", "0.5"] + model_args + tail + \
            ["--model_dir", out + "/model", "--loss_dir", out + "/loss", "--sample_dir", out + "/sample"]
     recipe = os.path.join(REF, "egs", "wsj0-mix", recipe_name)
     code = TRAIN_SCRIPT.format(src=os.path.join(ROOT, "dnn-based_source_separation_amd", "src"), tests=os.path.join(ROOT, "tests"), root=ROOT,
@@ -174,7 +181,7 @@ def test_reference_recipe_train_py_runs_end_to_end(tmp_path, recipe_name):
     assert "[Epoch 2/2]" in r.stdout and "# Parameters: " in r.stdout, r.stdout[-1500:]
     if n_params is not None:
         assert "# Parameters: {}".format(n_params) in r.stdout
-    for f in ("best.pth", "last.pth"):
+    for f in (("last.pth",) if orpit else ("best.pth", "last.pth")):      # the one-and-rest recipe's trainer has no validation pass, hence no best.pth
         assert os.path.exists(os.path.join(out, "model", f))
     import importlib
     import torch
