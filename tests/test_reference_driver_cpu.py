@@ -222,3 +222,50 @@ def test_names_hidden_by_shadowing_modules_fall_through_to_the_reference(tmp_pat
     env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
     assert r.returncode == 0 and "MERGED-OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_sinkpit_tutorial_recipe_runs_end_to_end(tmp_path):
+    """BASELINE.json configs[4]'s caller: the reference's egs/tutorials/sinkpit_conv-tasnet/local/train.py (json-described
+    LibriSpeech-style mixtures of FOUR speakers -> ConvTasNet(n_sources=4) -> SinkPIT(NegSISDR(), coldness, iteration) -> the
+    tutorials' Trainer), unmodified, on a synthetic tree, with this repository's src/ in front of the reference's."""
+    import json
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "dnn-based_source_separation_amd", "src"))
+    from recipes.audio_io import write_wav
+    wav_root = str(tmp_path / "wav")
+    os.makedirs(wav_root)
+    g = torch.Generator().manual_seed(3)
+    for k in range(8):
+        write_wav(os.path.join(wav_root, "spk%d.wav" % k), 0.1 * torch.randn(1, 4000, generator=g), 8000, 16)
+
+    def items(n, seed):
+        rng = torch.Generator().manual_seed(seed)
+        out = []
+        for i in range(n):
+            who = torch.randperm(8, generator=rng)[:4].tolist()
+            start = 100 * i
+            out.append({"sources": {"source-%d" % j: {"path": "spk%d.wav" % w, "start": start, "end": start + 1600, "utterance-ID": "spk%d" % w}
+                                    for j, w in enumerate(who)}})
+        return out
+    tr_json, cv_json = str(tmp_path / "train.json"), str(tmp_path / "valid.json")
+    json.dump(items(5, 1), open(tr_json, "w"))
+    json.dump(items(2, 2), open(cv_json, "w"))
+    out = str(tmp_path / "exp")
+    argv = ["train.py", "--wav_root", wav_root, "--train_json_path", tr_json, "--valid_json_path", cv_json, "--sample_rate", "8000",
+            "--enc_basis", "trainable", "--dec_basis", "trainable", "--enc_nonlinear", "relu", "-N", "64", "-L", "16", "-B", "64", "-H", "128",
+            "-Sc", "64", "-P", "3", "-X", "2", "-R", "1", "--dilated", "1", "--separable", "1", "--causal", "0", "--sep_nonlinear", "prelu",
+            "--sep_norm", "1", "--mask_nonlinear", "sigmoid", "--n_sources", "4", "--criterion", "sisdr", "--coldness", "1", "-k", "20",
+            "--optimizer", "adam", "--lr", "1e-3", "--max_norm", "5", "--batch_size", "2", "--epochs", "2", "--use_cuda", "0", "--overwrite", "0",
+            "--seed", "111", "--model_dir", out + "/model", "--loss_dir", out + "/loss", "--sample_dir", out + "/sample"]
+    recipe = os.path.join(REF, "egs", "tutorials", "sinkpit_conv-tasnet")
+    code = TRAIN_SCRIPT.format(src=os.path.join(ROOT, "dnn-based_source_separation_amd", "src"), tests=os.path.join(ROOT, "tests"), root=ROOT,
+                               ref_src=os.path.join(REF, "src"), ref_common=os.path.join(REF, "egs", "tutorials", "common", "src"),
+                               ref_recipe_src=os.path.join(recipe, "src"), argv=argv, train_py=os.path.join(recipe, "local", "train.py"))
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "[Epoch 2/2]" in r.stdout and "# Parameters: " in r.stdout, r.stdout[-1500:]
+    ck = torch.load(os.path.join(out, "model", "last.pth"), map_location="cpu", weights_only=False)
+    assert ck["epoch"] == 2 and ck["n_sources"] == 4
+    from models.conv_tasnet import ConvTasNet
+    assert ConvTasNet.build_model(os.path.join(out, "model", "last.pth"), load_state_dict=True).n_sources == 4
