@@ -83,3 +83,71 @@ def test_two_rank_step_matches_single_process(tmp_path):
     for k in range(2):
         assert abs(0.5 * (r0["losses"][k] + r1["losses"][k]) - losses[k]) <= 1e-4 * abs(losses[k])
     assert losses[1] < losses[0]                                   # and the optimiser actually descends
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The dual-path separators shard the same way (one process per GPU, utterances split across ranks); their parameters are ordinary
+# tensors, so the gradient exchange is torch's DistributedDataParallel (RCCL on the GPUs, gloo here) around the module whose
+# 1x1 convolutions / chunking / norms / recurrences are custom autograd Functions on the C ABI.
+DPT_CFG = dict(n_basis=32, kernel_size=4, stride=2, enc_basis="trainable", dec_basis="trainable", enc_nonlinear="relu",
+               sep_bottleneck_channels=32, sep_hidden_channels=16, sep_chunk_size=12, sep_num_blocks=1, sep_num_heads=4, sep_dropout=0,
+               mask_nonlinear="relu", causal=False, n_sources=2)
+
+
+def _dual_path_steps(mixture, sources, nsteps, ddp):
+    import sepkernels
+    from emulator import EmuBackend
+    from models.dptnet import DPTNet
+    from criterion.sdr import NegSISDR
+    from criterion.pit import PIT1d
+    sepkernels._set_backend_for_tests(EmuBackend())
+    torch.manual_seed(111)
+    model = DPTNet(**DPT_CFG).double()          # fp64: Adam turns rounding noise on near-zero gradients into O(lr) steps in fp32
+    mixture, sources = mixture.double(), sources.double()
+    assert not model.kernel_path_problems()
+    net = torch.nn.parallel.DistributedDataParallel(model) if ddp else model
+    crit = PIT1d(NegSISDR(), n_sources=2)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    losses = []
+    for _ in range(nsteps):
+        opt.zero_grad()
+        loss, _ = crit(net(mixture), sources)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+        opt.step()
+        losses.append(loss.item())
+    return torch.cat([p.detach().reshape(-1) for p in model.parameters()]), losses
+
+
+def _dual_path_worker(rank, world, port, out_dir):
+    _setup_paths()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    mixture, sources = _data()
+    per = mixture.shape[0] // world
+    sl = slice(rank * per, (rank + 1) * per)
+    flat, losses = _dual_path_steps(mixture[sl], sources[sl], 2, True)
+    torch.save({"flat": flat, "losses": losses}, os.path.join(out_dir, "dp_rank{}.pt".format(rank)))
+    dist.destroy_process_group()
+
+
+def test_dual_path_separator_under_distributed_data_parallel(tmp_path):
+    _setup_paths()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_dual_path_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "dp_rank0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "dp_rank1.pt"))
+    assert torch.equal(r0["flat"], r1["flat"])                     # replicas stay in lock-step
+    import sepkernels
+    old = sepkernels.backend()
+    try:
+        mixture, sources = _data()
+        flat, losses = _dual_path_steps(mixture, sources, 2, False)      # single process, global batch
+    finally:
+        sepkernels._set_backend_for_tests(old)
+    assert torch.allclose(flat, r0["flat"], rtol=0, atol=1e-9), (flat - r0["flat"]).abs().max()
+    for k in range(2):                                              # global mean loss == mean of the two rank means
+        assert abs(0.5 * (r0["losses"][k] + r1["losses"][k]) - losses[k]) < 1e-9
