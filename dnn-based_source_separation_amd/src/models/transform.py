@@ -3,7 +3,6 @@ libsepkernels (sep_segment / sep_overlap_add): no unfold/fold buffers, no permut
 import torch
 import torch.nn as nn
 
-import sepkernels
 from sepkernels.functional import SegmentFn, OverlapAddFn
 
 

@@ -38,7 +38,6 @@ Reference lines each function follows (all under /root/reference/src):
   sinkpit              criterion/pit.py:163-213
 """
 import itertools
-import math
 
 import torch
 

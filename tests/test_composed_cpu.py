@@ -9,7 +9,6 @@ import os
 import numpy as np
 import pytest
 import torch
-import torch.nn as nn
 
 import sepkernels
 from emulator import EmuBackend

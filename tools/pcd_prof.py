@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(ROOT, "dnn-based_source_separation_amd", "src"))
 import numpy as np
 import torch
 import sepkernels
-from sepkernels import EPI_RESIDUAL, EPI_PRELU_BWD, EPI_ROWSUMS, EPI_ROWSUMS_PRELU, EPI_STATS_PRELU, PRO_GLN, PRO_GLN_PRELU, STATS_SLOTS
+from sepkernels import EPI_RESIDUAL, EPI_ROWSUMS, EPI_ROWSUMS_PRELU, EPI_STATS_PRELU, PRO_GLN, PRO_GLN_PRELU, STATS_SLOTS
 K = sepkernels.HipBackend()
 lib = ctypes.CDLL(sepkernels.LIB_PATH)
 B, T, ldt, H, Bn, Sc, N = 16, 3999, 4096, 512, 128, 128, 512

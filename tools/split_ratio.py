@@ -1,6 +1,6 @@
 """Development tool: error of the stand-alone f16x3 / bf16x6 GEMM paths relative to the fp32-MFMA path over 12 operand draws per
 shape (the distribution behind the gate of tests/test_gpu_kernels.py::test_gemm_split_arithmetic_is_as_accurate_as_fp32_mfma)."""
-import sys, os
+import sys
 sys.path.insert(0, "dnn-based_source_separation_amd/src")
 import torch, sepkernels
 HIP = sepkernels.HipBackend()
