@@ -12,6 +12,7 @@
 // gates of (unit, sequence) in ONE lane, so the cell update is register-local; only h_t crosses waves (one barrier per
 // step).  The backward sweep is the mirror image with W_hh^T slices and the 4H x 16 gate-gradient panel in LDS.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -192,13 +193,232 @@ __global__ __launch_bounds__(H * 4) void lstm_bwd_kernel(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// FEW sequences (the recipes' batch sizes: 510 of them in DPRNN-TasNet's intra path at B = 2, 316 in GALRNet's): with 16 sequences per
+// workgroup the sweep occupies nseq / 16 compute units and every step costs the full 16-column MFMA time of W_hh h (4H x H x 16
+// MACs = 256 v_mfma_f32_16x16x4_f32 per SIMD at H = 128, ~8200 cycles) however few workgroups exist.  The variant below gives a
+// workgroup FOUR sequences on v_mfma_f32_4x4x1_16b_f32 (16 independent 4 x 4 x 1 products per instruction, 8 cycles): the 64 rows a
+// wave owns are the 16 blocks x 4 columns of B, the 4 sequences are the 4 rows of A (the same in every block), so a step costs a
+// quarter of the MFMA cycles and four times as many compute units take part.  Lane l of a wave has two roles:
+//   * ROW owner  (MFMA layout): row l of the wave's 64 = gate l / 16, unit 16 w + l % 16; the accumulator's four registers are the
+//     four sequences.  Operand B = that row of W_hh, register-resident (H registers); operand A = h_{t-1}[sequence l % 4][k].
+//   * CELL owner (update layout): (sequence l / 16, unit 16 w + l % 16) -- one cell per lane, so the transcendental work per lane is
+//     5 evaluations per step instead of 20.  The two layouts are exchanged through 320 floats of wave-private LDS.
+// Assumed operand layout of v_mfma_f32_4x4x1_16b_f32 (checked on the device by tools/mfma4x4_probe.hip before this path is enabled):
+// lane l supplies A[block l / 4][row l % 4] and B[block l / 4][column l % 4] and receives D[block l / 4][row v][column l % 4] in
+// register v.  Selected by SEPK_LSTM_NS4 (0 = off, the default until measured; 1 = always; 2 = when 16-sequence workgroups would
+// leave compute units idle).
+constexpr int NS4 = 4;
+constexpr int XCH = 80;         // sequence stride of the layout-exchange scratch: (seq * 80 + part * 16 + unit) is conflict-free both ways
+
+__device__ __forceinline__ f32x4 mfma4(const float a, const float b, const f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+
+template <int H>
+__global__ __launch_bounds__(H * 4) void lstm_fwd4_kernel(const float* __restrict__ xg, const float* __restrict__ whh,
+                                                          float* __restrict__ hout, float* __restrict__ gates,
+                                                          float* __restrict__ cstate, int nseq, int L, int dirs) {
+    constexpr int HS = H + 4;                  // row stride of the h panel: rows 16-byte aligned and on different bank groups
+    const int dir = dirs == 2 ? (int)blockIdx.y : 0;
+    const int reverse = dirs == 2 ? dir : dirs;
+    {
+        const size_t rows = (size_t)nseq * L;
+        xg += dir * rows * 4 * H; whh += (size_t)dir * 4 * H * H; hout += dir * rows * H;
+        if (gates) gates += dir * rows * 4 * H;
+        if (cstate) cstate += dir * rows * H;
+    }
+    __shared__ __attribute__((aligned(16))) float hs[2][NS4 * HS];        // h_{t-1} / h_t as [sequence][unit]
+    __shared__ float xch[H / 16][NS4 * XCH];                             // per wave: activated gates, [sequence][gate][unit of the wave]
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ul = lane & 15, hi = lane >> 4, sj = lane & 3;
+    const int u = 16 * w + ul;                 // hidden unit of this lane in both roles
+    const int seq0 = blockIdx.x * NS4;
+
+    float wf[H];                               // B operand: row (gate hi, unit u) of W_hh
+    {
+        const float* wr = whh + (size_t)(hi * H + u) * H;
+#pragma unroll
+        for (int k = 0; k < H; k += 4) {
+            const float4 v = ld4g(wr + k);
+            wf[k] = v.x; wf[k + 1] = v.y; wf[k + 2] = v.z; wf[k + 3] = v.w;
+        }
+    }
+    for (int i = threadIdx.x; i < NS4 * HS; i += H * 4) hs[0][i] = 0.f;
+    float c = 0.f;                             // cell owner: c of (sequence hi, unit u)
+    __syncthreads();
+
+    size_t xrow[NS4];                          // row owner: first row of each of the four sequences in xg / gates
+    bool xlive[NS4];
+#pragma unroll
+    for (int v = 0; v < NS4; ++v) {
+        xlive[v] = seq0 + v < nseq;
+        xrow[v] = (size_t)(xlive[v] ? seq0 + v : nseq - 1) * L;
+    }
+    const bool live = seq0 + hi < nseq;        // cell owner
+    const size_t crow = (size_t)(live ? seq0 + hi : nseq - 1) * L;
+    // one evaluation serves both activations: r = 1 / (1 + 2^(kappa x)); sigmoid(x) = r with kappa = -log2 e, tanh(x) = 1 - 2 r with kappa = 2 log2 e
+    const bool is_g = hi == 2;
+    const float kappa = is_g ? 2.8853900817779268f : -1.4426950408889634f;
+
+    auto load_x = [&](int t, float (&dst)[NS4]) {
+#pragma unroll
+        for (int v = 0; v < NS4; ++v) dst[v] = xg[(xrow[v] + t) * 4 * H + hi * H + u];
+    };
+    float xc[NS4], xn[NS4];
+    load_x(reverse ? L - 1 : 0, xc);
+    float* ex = xch[w];
+    for (int step = 0; step < L; ++step) {
+        const int t = reverse ? L - 1 - step : step;
+        const int cur = step & 1;
+        if (step + 1 < L) load_x(reverse ? t - 1 : t + 1, xn);          // next step's projection, in flight under the MFMAs
+        f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;    // four chains: no MFMA waits for the one before it
+        const float* hp = hs[cur] + sj * HS;
+#pragma unroll
+        for (int k = 0; k < H; k += 4) {
+            const float4 hv = *reinterpret_cast<const float4*>(hp + k);
+            a0 = mfma4(hv.x, wf[k], a0);
+            a1 = mfma4(hv.y, wf[k + 1], a1);
+            a2 = mfma4(hv.z, wf[k + 2], a2);
+            a3 = mfma4(hv.w, wf[k + 3], a3);
+        }
+        float act[NS4];                        // row owner: activated gate hi of unit u for the four sequences
+#pragma unroll
+        for (int v = 0; v < NS4; ++v) {
+            const float pre = (a0[v] + a1[v]) + (a2[v] + a3[v]) + xc[v];
+            const float r = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(kappa * pre));
+            act[v] = is_g ? 1.f - 2.f * r : r;
+            ex[v * XCH + hi * 16 + ul] = act[v];
+        }
+        if (gates) {
+#pragma unroll
+            for (int v = 0; v < NS4; ++v)
+                if (xlive[v]) gates[(xrow[v] + t) * 4 * H + hi * H + u] = act[v];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // the exchange is wave-private: LDS executes a wave's accesses in order
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // cell owner: the four gates of (sequence hi, unit u)
+        const float gi = ex[hi * XCH + 0 * 16 + ul], gf = ex[hi * XCH + 1 * 16 + ul];
+        const float gg = ex[hi * XCH + 2 * 16 + ul], go = ex[hi * XCH + 3 * 16 + ul];
+        c = fmaf(gf, c, gi * gg);
+        const float hn = go * tanh_f(c);
+        hs[cur ^ 1][hi * HS + u] = hn;
+        if (live) {
+            hout[(crow + t) * H + u] = hn;
+            if (cstate) cstate[(crow + t) * H + u] = c;
+        }
+#pragma unroll
+        for (int v = 0; v < NS4; ++v) xc[v] = xn[v];
+        __syncthreads();                       // h_t complete in hs[cur^1]; everyone is done reading hs[cur] and the exchange scratch
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(H * 4) void lstm_bwd4_kernel(const float* __restrict__ dhout, const float* __restrict__ gates,
+                                                          const float* __restrict__ cstate, const float* __restrict__ whh,
+                                                          float* __restrict__ dxg, int nseq, int L, int dirs) {
+    constexpr int HG = H + 16;                 // gate stride of the d(pre-activation) panel
+    constexpr int DS = 4 * HG + 4;             // its sequence stride
+    const int dir = dirs == 2 ? (int)blockIdx.y : 0;
+    const int reverse = dirs == 2 ? dir : dirs;
+    {
+        const size_t rows = (size_t)nseq * L;
+        dhout += dir * rows * H; gates += dir * rows * 4 * H; cstate += dir * rows * H; whh += (size_t)dir * 4 * H * H;
+        dxg += dir * rows * 4 * H;
+    }
+    __shared__ __attribute__((aligned(16))) float das[NS4 * DS];         // d(pre-activation) of the current step as [sequence][gate][unit]
+    __shared__ float xch[H / 16][NS4 * XCH];                             // per wave: the four partial sums of W_hh^T da, [sequence][part][unit]
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ul = lane & 15, hi = lane >> 4, sj = lane & 3;
+    const int u = 16 * w + ul;
+    const int seq0 = blockIdx.x * NS4;
+
+    // dh_{t-1}[seq][u] = sum over the 4H gate rows r of W_hh[r][u] da[seq][r].  The 16 blocks of the MFMA are (quarter hi of the
+    // contraction = gate hi) x (unit quad): B operand = W_hh[hi * H + m][u], m = 0 .. H-1; the four quarters are summed afterwards.
+    float wt[H];
+#pragma unroll
+    for (int m = 0; m < H; ++m) wt[m] = whh[(size_t)(hi * H + m) * H + u];
+    const bool live = seq0 + hi < nseq;        // cell owner: (sequence hi, unit u)
+    const size_t crow = (size_t)(live ? seq0 + hi : nseq - 1) * L;
+    float dhr = 0.f, dc = 0.f;
+    float* ex = xch[w];
+
+    struct StepIn { float dh, i, f, g, o, cp; };
+    auto load_step = [&](int t, StepIn& d) {
+        const int tprev = reverse ? t + 1 : t - 1;
+        const size_t o = crow + t;
+        d.dh = dhout[o * H + u];
+        const float* gp = gates + o * 4 * H + u;
+        d.i = gp[0]; d.f = gp[H]; d.g = gp[2 * H]; d.o = gp[3 * H];
+        d.cp = (tprev >= 0 && tprev < L) ? cstate[(crow + tprev) * H + u] : 0.f;
+    };
+    StepIn in, nx;
+    const int t_first = reverse ? 0 : L - 1;
+    load_step(t_first, in);
+    float cc = cstate[(crow + t_first) * H + u];                         // c_t; the next step's c_t is this step's c_{t-1}
+    for (int step = 0; step < L; ++step) {
+        const int t = reverse ? step : L - 1 - step;                     // the forward sweep's LAST step first
+        if (step + 1 < L) load_step(reverse ? t + 1 : t - 1, nx);        // in flight under this step's arithmetic
+        const float dh = in.dh + dhr;
+        const float tc = tanh_f(cc);
+        const float dcc = fmaf(dh * in.o, 1.f - tc * tc, dc);
+        const float dao = dh * tc * in.o * (1.f - in.o);
+        const float dai = dcc * in.g * in.i * (1.f - in.i);
+        const float daf = dcc * in.cp * in.f * (1.f - in.f);
+        const float dag = dcc * in.i * (1.f - in.g * in.g);
+        dc = dcc * in.f;
+        float* dp = das + hi * DS + u;
+        dp[0] = dai; dp[HG] = daf; dp[2 * HG] = dag; dp[3 * HG] = dao;
+        if (live) {
+            float* gp = dxg + (crow + t) * 4 * H + u;
+            gp[0] = dai; gp[H] = daf; gp[2 * H] = dag; gp[3 * H] = dao;
+        }
+        __syncthreads();
+        f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+        const float* ap = das + sj * DS + hi * HG;                       // A operand: da[sequence l % 4][gate hi][m]
+#pragma unroll
+        for (int m = 0; m < H; m += 4) {
+            const float4 dv = *reinterpret_cast<const float4*>(ap + m);
+            a0 = mfma4(dv.x, wt[m], a0);
+            a1 = mfma4(dv.y, wt[m + 1], a1);
+            a2 = mfma4(dv.z, wt[m + 2], a2);
+            a3 = mfma4(dv.w, wt[m + 3], a3);
+        }
+#pragma unroll
+        for (int v = 0; v < NS4; ++v) ex[v * XCH + hi * 16 + ul] = (a0[v] + a1[v]) + (a2[v] + a3[v]);   // quarter hi of (sequence v, unit u)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        dhr = (ex[hi * XCH + ul] + ex[hi * XCH + 16 + ul]) + (ex[hi * XCH + 32 + ul] + ex[hi * XCH + 48 + ul]);   // cell owner again
+        cc = in.cp;
+        in = nx;
+        __syncthreads();                       // das and the exchange scratch are rewritten next step
+    }
+}
+
+// SEPK_LSTM_NS4: 0 (default) 16 sequences per workgroup always; 1 four per workgroup always; 2 four when sixteen would leave units idle
+bool few_sequences(int nseq, int reverse) {
+    static const int mode = getenv("SEPK_LSTM_NS4") ? atoi(getenv("SEPK_LSTM_NS4")) : 0;
+    if (mode == 1) return true;
+    return mode == 2 && ((nseq + LSTM_NS - 1) / LSTM_NS) * (reverse == 2 ? 2 : 1) < 256;
+}
+
 template <int H>
 int launch_fwd(const float* xg, const float* whh, float* hout, float* gates, float* cstate, int nseq, int L, int reverse, hipStream_t st) {
+    if (few_sequences(nseq, reverse)) {
+        hipLaunchKernelGGL((lstm_fwd4_kernel<H>), dim3((nseq + NS4 - 1) / NS4, reverse == 2 ? 2 : 1), dim3(H * 4), 0, st, xg, whh, hout, gates, cstate, nseq, L, reverse);
+        return 0;
+    }
     hipLaunchKernelGGL((lstm_fwd_kernel<H>), dim3((nseq + LSTM_NS - 1) / LSTM_NS, reverse == 2 ? 2 : 1), dim3(H * 4), 0, st, xg, whh, hout, gates, cstate, nseq, L, reverse);
     return 0;
 }
 template <int H>
 int launch_bwd(const float* dhout, const float* gates, const float* cstate, const float* whh, float* dxg, int nseq, int L, int reverse, hipStream_t st) {
+    if (few_sequences(nseq, reverse)) {
+        hipLaunchKernelGGL((lstm_bwd4_kernel<H>), dim3((nseq + NS4 - 1) / NS4, reverse == 2 ? 2 : 1), dim3(H * 4), 0, st, dhout, gates, cstate, whh, dxg, nseq, L, reverse);
+        return 0;
+    }
     hipLaunchKernelGGL((lstm_bwd_kernel<H>), dim3((nseq + LSTM_NS - 1) / LSTM_NS, reverse == 2 ? 2 : 1), dim3(H * 4), 0, st, dhout, gates, cstate, whh, dxg, nseq, L, reverse);
     return 0;
 }
