@@ -71,6 +71,8 @@ def pit(criterion, input, target, n_sources=None, patterns=None, batch_mean=True
         if n_sources is None:
             n_sources = input.size(1)
         patterns = torch.tensor(list(itertools.permutations(range(n_sources))), dtype=torch.long)
+    if input.shape != target.shape and input.dim() == target.dim():
+        input, target = torch.broadcast_tensors(input, target)      # e.g. the mixture (B, 1, T) scored against (B, n, T) sources (driver.py:283)
     if _is_sisdr(criterion, input):
         return _fused_pit(criterion, input, target, patterns, batch_mean)
     # generic criterion: one evaluation per permutation

@@ -48,6 +48,8 @@ class _SISDRPairsFn(torch.autograd.Function):
 
 
 def _prep(input, target):
+    if input.shape != target.shape:        # the reference's formulas broadcast: its tester scores the mixture (B, 1, T) against (B, n, T) sources
+        input, target = torch.broadcast_tensors(input, target)
     if input.dtype != torch.float32 and sepkernels.backend().name == "hip":
         input = input.float()
     return input, target.to(input.dtype)

@@ -211,3 +211,31 @@ def test_depthwise_separable_conv1d_module(emu):
     for a, b in [(mod.depthwise_conv1d.weight, ref_dw.weight), (mod.depthwise_conv1d.bias, ref_dw.bias),
                  (mod.pointwise_conv1d.weight, ref_pw.weight), (mod.pointwise_conv1d.bias, ref_pw.bias)]:
         assert torch.allclose(a.grad, b.grad, atol=1e-8)
+
+
+def test_criteria_broadcast_and_clip_like_the_reference(emu):
+    """The reference's formulas broadcast, and its tester relies on it: `pit_criterion(mixture (B, 1, T), sources (B, n, T))`
+    (egs/wsj0-mix/common/src/driver.py:283) is the loss of the unprocessed mixture against every source.  Also the clipped SI-SDR
+    variants of the SepFormer recipe, on the fused pair-matrix route of PIT: the clip applies per (estimate, target) pair."""
+    from criterion.sdr import ClippedNegSISDR, ClippedSISDR
+    torch.manual_seed(0)
+    mix = torch.randn(2, 1, 300, dtype=torch.float64)
+    src = torch.randn(2, 3, 300, dtype=torch.float64)
+
+    def sisdr_formula(x, t):
+        a = (x * t).sum(-1, keepdim=True) / ((t * t).sum(-1, keepdim=True) + 1e-12)
+        return 10 * torch.log10(((a * t) ** 2).sum(-1) + 1e-12) - 10 * torch.log10(((x - a * t) ** 2).sum(-1) + 1e-12)
+    want = -sisdr_formula(mix.expand(2, 3, 300), src).mean(1)
+    assert torch.allclose(NegSISDR()(mix, src, batch_mean=False), want, rtol=1e-9)
+    loss, perm = PIT1d(NegSISDR(), n_sources=3)(mix, src, batch_mean=False)
+    assert torch.allclose(loss, want, rtol=1e-9) and perm.shape == (2, 3)
+    # clipped: estimates close to permuted targets -> some pairs beyond the clip
+    est = (src[:, [2, 0, 1]] + torch.tensor([1e-3, 0.5]).view(2, 1, 1) * torch.randn(2, 3, 300, dtype=torch.float64)).requires_grad_(True)
+    per_pair = -sisdr_formula(est.unsqueeze(2), src.unsqueeze(1))                           # (B, n, n): [b, i, j]
+    for clip in (30.0, 5.0):
+        loss, perm = PIT1d(ClippedNegSISDR(min=-clip), n_sources=3)(est, src, batch_mean=False)
+        assert torch.equal(perm, torch.tensor([[2, 0, 1], [2, 0, 1]]))
+        picked = torch.stack([per_pair[:, i, perm[0, i]] for i in range(3)], 1).clamp(min=-clip).mean(1)
+        assert torch.allclose(loss, picked, rtol=1e-9)
+        assert torch.allclose(ClippedSISDR(max=clip)(est, src[:, [2, 0, 1]], batch_mean=False), -picked, rtol=1e-9)
+    assert (per_pair[0, 0, 2] < -30).item()                                                  # the clip at 30 dB was really active

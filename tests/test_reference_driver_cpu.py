@@ -283,3 +283,66 @@ def test_sinkpit_tutorial_recipe_runs_end_to_end(tmp_path):
     assert ck["epoch"] == 2 and ck["n_sources"] == 4
     from models.conv_tasnet import ConvTasNet
     assert ConvTasNet.build_model(os.path.join(out, "model", "last.pth"), load_state_dict=True).n_sources == 4
+
+
+TEST_SCRIPT = textwrap.dedent('''
+    import os, sys, types, runpy
+    sys.path[:0] = [{src!r}, {tests!r}, {root!r}]
+    sys.path += [{ref_src!r}, {ref_common!r}, {ref_recipe_src!r}]
+    import numpy as np
+    import torch
+    from recipes.audio_io import install_torchaudio_shim
+    install_torchaudio_shim()
+
+    def bss_eval_sources(reference_sources, estimated_sources, **kw):          # stand-in for mir_eval (absent): plain SDR, identity order
+        err = ((reference_sources - estimated_sources) ** 2).sum(-1) + 1e-12
+        sdr = 10 * np.log10((reference_sources ** 2).sum(-1) / err)
+        return sdr, sdr.copy(), sdr.copy(), np.arange(len(sdr))
+    me = types.ModuleType("mir_eval"); sep = types.ModuleType("mir_eval.separation")
+    sep.bss_eval_sources = bss_eval_sources
+    me.separation = sep; sys.modules["mir_eval"] = me; sys.modules["mir_eval.separation"] = sep
+    import matplotlib; matplotlib.use("Agg")
+    import sepkernels
+    from emulator import EmuBackend
+    sepkernels._set_backend_for_tests(EmuBackend())
+    sys.argv = {argv!r}
+    runpy.run_path({test_py!r}, run_name="__main__")
+''')
+
+
+@pytest.mark.parametrize("recipe_name", ["conv-tasnet", "dptnet"])
+def test_reference_recipe_test_py_runs_end_to_end(tmp_path, recipe_name):
+    """SURVEY.md section 8 row f2 through the reference's own evaluation script: egs/wsj0-mix/<recipe>/local/test.py (build_model from
+    the checkpoint its train.py wrote -> TesterBase.run: variable-length B = 1 inference, PIT loss and its improvement over the
+    mixture, BSS-eval, PESQ, example wavs), unmodified, on this tree's classes.  mir_eval and the PESQ binary are evaluation-only
+    externals: a plain-SDR stand-in and a one-line script take their places."""
+    model_args, _, _ = RECIPES[recipe_name]
+    sys.path.insert(0, os.path.join(ROOT, "dnn-based_source_separation_amd", "src"))
+    tr, cv = str(tmp_path / "tr"), str(tmp_path / "cv")
+    tr_list, cv_list = _wav_tree(tr, 3, 1), _wav_tree(cv, 2, 2)
+    out = str(tmp_path / "exp")
+    recipe = os.path.join(REF, "egs", "wsj0-mix", recipe_name)
+    paths = dict(src=os.path.join(ROOT, "dnn-based_source_separation_amd", "src"), tests=os.path.join(ROOT, "tests"), root=ROOT,
+                 ref_src=os.path.join(REF, "src"), ref_common=os.path.join(REF, "egs", "wsj0-mix", "common", "src"),
+                 ref_recipe_src=os.path.join(recipe, "src"))
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    tail = [("1" if _COMMON_TAIL[i - 1] == "--epochs" else a) for i, a in enumerate(_COMMON_TAIL)]
+    argv = ["train.py", "--train_wav_root", tr, "--valid_wav_root", cv, "--train_list_path", tr_list, "--valid_list_path", cv_list,
+            "--sample_rate", "8000", "--duration", "0.2", "--valid_duration", "0.5"] + model_args + tail + \
+           ["--model_dir", out + "/model", "--loss_dir", out + "/loss", "--sample_dir", out + "/sample"]
+    r = subprocess.run([sys.executable, "-c", TRAIN_SCRIPT.format(argv=argv, train_py=os.path.join(recipe, "local", "train.py"), **paths)],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    pesq = tmp_path / "PESQ"
+    pesq.write_text("#!/bin/sh\necho 'Prediction : PESQ_MOS = 2.5'\n")
+    pesq.chmod(0o755)
+    argv = ["test.py", "--test_wav_root", cv, "--test_list_path", cv_list, "--sample_rate", "8000", "--n_sources", "2", "--criterion", "sisdr",
+            "--out_dir", out + "/test", "--model_path", out + "/model/best.pth", "--use_cuda", "0", "--overwrite", "0", "--seed", "111"]
+    r = subprocess.run([sys.executable, "-c", TEST_SCRIPT.format(argv=argv, test_py=os.path.join(recipe, "local", "test.py"), **paths)],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    summary = [l for l in r.stdout.splitlines() if l.startswith("Loss: ")]
+    assert len(summary) == 1 and "PESQ: 2.500" in summary[0], r.stdout[-1500:]
+    rows = [l for l in r.stdout.splitlines() if l.startswith("utt0")]
+    assert len(rows) == 2 and all(len(l.split(", ")) == 7 for l in rows)          # ID, loss, improvement, SDRi, SIRi, SAR, PESQ per utterance
+    assert os.path.exists(os.path.join(out, "test", "utt00.wav")) and os.path.exists(os.path.join(out, "test", "utt00_1-estimated.wav"))
