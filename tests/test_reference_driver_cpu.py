@@ -109,7 +109,7 @@ TRAIN_SCRIPT = textwrap.dedent('''
 ''')
 
 
-def _wav_tree(root, n_utt, seed, mixed_numbers=False, wham=False):
+def _wav_tree(root, n_utt, seed, mixed_numbers=False, wham=False, n_speakers=2):
     """wsj0-mix layout: <root>/(mix|s1|s2[|s3])/<ID>.wav + a list file of IDs (mixed_numbers: every other utterance has three sources,
     the tree of the one-and-rest recipe)."""
     import torch
@@ -119,7 +119,7 @@ def _wav_tree(root, n_utt, seed, mixed_numbers=False, wham=False):
     for k in range(n_utt):
         ID = "utt%02d" % k
         T = 2400 + 160 * k
-        n = 3 if (mixed_numbers and k % 2) else 2
+        n = 3 if (mixed_numbers and k % 2) else n_speakers
         s = 0.1 * torch.randn(n, T, generator=g)
         stems = [("s%d" % (i + 1), s[i:i + 1]) for i in range(n)] + [("mix", s.sum(0, keepdim=True))]
         if wham:                                                        # egs/wham: two speakers + noise, noisy mixtures of one and of both
@@ -310,23 +310,31 @@ TEST_SCRIPT = textwrap.dedent('''
 ''')
 
 
-@pytest.mark.parametrize("recipe_name", ["conv-tasnet", "dptnet"])
+@pytest.mark.parametrize("recipe_name", ["conv-tasnet", "dptnet", "orpit_conv-tasnet"])
 def test_reference_recipe_test_py_runs_end_to_end(tmp_path, recipe_name):
     """SURVEY.md section 8 row f2 through the reference's own evaluation script: egs/wsj0-mix/<recipe>/local/test.py (build_model from
     the checkpoint its train.py wrote -> TesterBase.run: variable-length B = 1 inference, PIT loss and its improvement over the
     mixture, BSS-eval, PESQ, example wavs), unmodified, on this tree's classes.  mir_eval and the PESQ binary are evaluation-only
-    externals: a plain-SDR stand-in and a one-line script take their places."""
+    externals: a plain-SDR stand-in and a one-line script take their places.  `orpit_conv-tasnet`: its own tester (adhoc_driver.py:
+    165-311) peels THREE speakers off the mixture with the two-output model, one and the rest at a time."""
     model_args, _, _ = RECIPES[recipe_name]
+    orpit = recipe_name.startswith("orpit")
     sys.path.insert(0, os.path.join(ROOT, "dnn-based_source_separation_amd", "src"))
     tr, cv = str(tmp_path / "tr"), str(tmp_path / "cv")
-    tr_list, cv_list = _wav_tree(tr, 3, 1), _wav_tree(cv, 2, 2)
+    tr_list, cv_list = _wav_tree(tr, 3, 1, mixed_numbers=orpit), _wav_tree(cv, 2, 2, mixed_numbers=orpit)
+    n_test, ckpt = ("3", "last.pth") if orpit else ("2", "best.pth")
+    if orpit:                                                      # the evaluation set: every utterance has three speakers
+        tt = str(tmp_path / "tt")
+        tt_list = _wav_tree(tt, 2, 3, n_speakers=3)
+    else:
+        tt, tt_list = cv, cv_list
     out = str(tmp_path / "exp")
     recipe = os.path.join(REF, "egs", "wsj0-mix", recipe_name)
     paths = dict(src=os.path.join(ROOT, "dnn-based_source_separation_amd", "src"), tests=os.path.join(ROOT, "tests"), root=ROOT,
                  ref_src=os.path.join(REF, "src"), ref_common=os.path.join(REF, "egs", "wsj0-mix", "common", "src"),
                  ref_recipe_src=os.path.join(recipe, "src"))
     env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
-    tail = [("1" if _COMMON_TAIL[i - 1] == "--epochs" else a) for i, a in enumerate(_COMMON_TAIL)]
+    tail = [("1" if _COMMON_TAIL[i - 1] == "--epochs" else ("2+3" if orpit and _COMMON_TAIL[i - 1] == "--n_sources" else a)) for i, a in enumerate(_COMMON_TAIL)]
     argv = ["train.py", "--train_wav_root", tr, "--valid_wav_root", cv, "--train_list_path", tr_list, "--valid_list_path", cv_list,
             "--sample_rate", "8000", "--duration", "0.2", "--valid_duration", "0.5"] + model_args + tail + \
            ["--model_dir", out + "/model", "--loss_dir", out + "/loss", "--sample_dir", out + "/sample"]
@@ -336,8 +344,8 @@ def test_reference_recipe_test_py_runs_end_to_end(tmp_path, recipe_name):
     pesq = tmp_path / "PESQ"
     pesq.write_text("#!/bin/sh\necho 'Prediction : PESQ_MOS = 2.5'\n")
     pesq.chmod(0o755)
-    argv = ["test.py", "--test_wav_root", cv, "--test_list_path", cv_list, "--sample_rate", "8000", "--n_sources", "2", "--criterion", "sisdr",
-            "--out_dir", out + "/test", "--model_path", out + "/model/best.pth", "--use_cuda", "0", "--overwrite", "0", "--seed", "111"]
+    argv = ["test.py", "--test_wav_root", tt, "--test_list_path", tt_list, "--sample_rate", "8000", "--n_sources", n_test, "--criterion", "sisdr",
+            "--out_dir", out + "/test", "--model_path", out + "/model/" + ckpt, "--use_cuda", "0", "--overwrite", "0", "--seed", "111"]
     r = subprocess.run([sys.executable, "-c", TEST_SCRIPT.format(argv=argv, test_py=os.path.join(recipe, "local", "test.py"), **paths)],
                        capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
