@@ -238,10 +238,25 @@ def test_names_hidden_by_shadowing_modules_fall_through_to_the_reference(tmp_pat
     assert r.returncode == 0 and "MERGED-OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 
 
-def test_sinkpit_tutorial_recipe_runs_end_to_end(tmp_path):
-    """BASELINE.json configs[4]'s caller: the reference's egs/tutorials/sinkpit_conv-tasnet/local/train.py (json-described
-    LibriSpeech-style mixtures of FOUR speakers -> ConvTasNet(n_sources=4) -> SinkPIT(NegSISDR(), coldness, iteration) -> the
-    tutorials' Trainer), unmodified, on a synthetic tree, with this repository's src/ in front of the reference's."""
+TUTORIALS = {
+    # tutorial recipe -> (model / criterion arguments of ITS train.py, number of speakers, class that reloads the checkpoint)
+    "sinkpit_conv-tasnet": (["--enc_nonlinear", "relu", "-N", "64", "-L", "16", "-B", "64", "-H", "128", "-Sc", "64", "-P", "3", "-X", "2", "-R", "1",
+                             "--dilated", "1", "--separable", "1", "--causal", "0", "--sep_nonlinear", "prelu", "--sep_norm", "1",
+                             "--mask_nonlinear", "sigmoid", "--coldness", "1", "-k", "20"], 4, "models.conv_tasnet:ConvTasNet"),
+    "conv-tasnet": (["--enc_nonlinear", "relu", "-N", "64", "-L", "16", "-B", "64", "-H", "128", "-Sc", "64", "-P", "3", "-X", "2", "-R", "1",
+                     "--dilated", "1", "--separable", "1", "--causal", "0", "--sep_nonlinear", "prelu", "--sep_norm", "1",
+                     "--mask_nonlinear", "sigmoid"], 2, "models.conv_tasnet:ConvTasNet"),
+    "dprnn-tasnet": (["-N", "32", "-L", "4", "-F", "32", "-H", "16", "-K", "20", "-P", "10", "-B", "1", "--causal", "0", "--sep_norm", "1",
+                      "--mask_nonlinear", "sigmoid"], 2, "models.dprnn_tasnet:DPRNNTasNet"),
+}
+
+
+@pytest.mark.parametrize("tutorial", sorted(TUTORIALS))
+def test_tutorial_recipe_runs_end_to_end(tmp_path, tutorial):
+    """The reference's egs/tutorials/<recipe>/local/train.py (json-described LibriSpeech-style mixtures -> the model class -> the
+    tutorials' Trainer), unmodified, on a synthetic tree, with this repository's src/ in front of the reference's.
+    `sinkpit_conv-tasnet` is BASELINE.json configs[4]'s caller: FOUR speakers, SinkPIT(NegSISDR(), coldness, iteration)."""
+    model_args, n_speakers, loader = TUTORIALS[tutorial]
     import json
     import torch
     sys.path.insert(0, os.path.join(ROOT, "dnn-based_source_separation_amd", "src"))
@@ -256,7 +271,7 @@ def test_sinkpit_tutorial_recipe_runs_end_to_end(tmp_path):
         rng = torch.Generator().manual_seed(seed)
         out = []
         for i in range(n):
-            who = torch.randperm(8, generator=rng)[:4].tolist()
+            who = torch.randperm(8, generator=rng)[:n_speakers].tolist()
             start = 100 * i
             out.append({"sources": {"source-%d" % j: {"path": "spk%d.wav" % w, "start": start, "end": start + 1600, "utterance-ID": "spk%d" % w}
                                     for j, w in enumerate(who)}})
@@ -266,12 +281,10 @@ def test_sinkpit_tutorial_recipe_runs_end_to_end(tmp_path):
     json.dump(items(2, 2), open(cv_json, "w"))
     out = str(tmp_path / "exp")
     argv = ["train.py", "--wav_root", wav_root, "--train_json_path", tr_json, "--valid_json_path", cv_json, "--sample_rate", "8000",
-            "--enc_basis", "trainable", "--dec_basis", "trainable", "--enc_nonlinear", "relu", "-N", "64", "-L", "16", "-B", "64", "-H", "128",
-            "-Sc", "64", "-P", "3", "-X", "2", "-R", "1", "--dilated", "1", "--separable", "1", "--causal", "0", "--sep_nonlinear", "prelu",
-            "--sep_norm", "1", "--mask_nonlinear", "sigmoid", "--n_sources", "4", "--criterion", "sisdr", "--coldness", "1", "-k", "20",
+            "--enc_basis", "trainable", "--dec_basis", "trainable"] + model_args + ["--n_sources", str(n_speakers), "--criterion", "sisdr",
             "--optimizer", "adam", "--lr", "1e-3", "--max_norm", "5", "--batch_size", "2", "--epochs", "2", "--use_cuda", "0", "--overwrite", "0",
             "--seed", "111", "--model_dir", out + "/model", "--loss_dir", out + "/loss", "--sample_dir", out + "/sample"]
-    recipe = os.path.join(REF, "egs", "tutorials", "sinkpit_conv-tasnet")
+    recipe = os.path.join(REF, "egs", "tutorials", tutorial)
     code = TRAIN_SCRIPT.format(src=os.path.join(ROOT, "dnn-based_source_separation_amd", "src"), tests=os.path.join(ROOT, "tests"), root=ROOT,
                                ref_src=os.path.join(REF, "src"), ref_common=os.path.join(REF, "egs", "tutorials", "common", "src"),
                                ref_recipe_src=os.path.join(recipe, "src"), argv=argv, train_py=os.path.join(recipe, "local", "train.py"))
@@ -280,9 +293,11 @@ def test_sinkpit_tutorial_recipe_runs_end_to_end(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "[Epoch 2/2]" in r.stdout and "# Parameters: " in r.stdout, r.stdout[-1500:]
     ck = torch.load(os.path.join(out, "model", "last.pth"), map_location="cpu", weights_only=False)
-    assert ck["epoch"] == 2 and ck["n_sources"] == 4
-    from models.conv_tasnet import ConvTasNet
-    assert ConvTasNet.build_model(os.path.join(out, "model", "last.pth"), load_state_dict=True).n_sources == 4
+    assert ck["epoch"] == 2 and ck["n_sources"] == n_speakers
+    import importlib
+    mod, cls = loader.split(":")
+    model = getattr(importlib.import_module(mod), cls).build_model(os.path.join(out, "model", "last.pth"), load_state_dict=True)
+    assert model.n_sources == n_speakers and type(model).__module__ == mod
 
 
 TEST_SCRIPT = textwrap.dedent('''
