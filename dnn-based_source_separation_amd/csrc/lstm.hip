@@ -401,7 +401,9 @@ __global__ __launch_bounds__(H * 4) void lstm_bwd4_kernel(const float* __restric
 bool few_sequences(int nseq, int reverse) {
     static const int mode = getenv("SEPK_LSTM_NS4") ? atoi(getenv("SEPK_LSTM_NS4")) : 0;
     if (mode == 1) return true;
-    return mode == 2 && ((nseq + LSTM_NS - 1) / LSTM_NS) * (reverse == 2 ? 2 : 1) < 256;
+    // four-sequence workgroups take up to four rounds on the 256 compute units where sixteen-sequence ones take one: worth it while four
+    // rounds of the short step (estimated 1.5 us) stay below one long step (5.5 us measured), i.e. up to three rounds
+    return mode == 2 && ((nseq + LSTM_NS - 1) / LSTM_NS) * (reverse == 2 ? 2 : 1) <= 192;
 }
 
 template <int H>
