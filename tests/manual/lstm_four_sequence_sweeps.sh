@@ -1,7 +1,7 @@
 #!/bin/bash
 # NOT part of the test suite: the enabling procedure of the four-sequence LSTM sweeps (csrc/lstm.hip: lstm_fwd4_kernel /
 # lstm_bwd4_kernel on v_mfma_f32_4x4x1_16b_f32), written without a GPU at hand and OFF by default (SEPK_LSTM_NS4 unset); their source has
-# been executed on the host against the restatement (tools/lstm_hostsim.py), what remains is the instruction's operand layout and timing.
+# been executed on the host against the restatement (tests/test_kernel_source_on_host_cpu.py), what remains is the instruction's operand layout and timing.
 # On an MI355X, from the repository root (about 40 s):
 #   1. the operand layout the kernels assume            -> "layout: PASS"
 #   2. the LSTM kernel tests and the DPRNN-TasNet / GALRNet / DPTNet model tests with the variant forced on

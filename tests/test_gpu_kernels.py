@@ -75,6 +75,20 @@ def stats_of(x, T):
     return (tot.unsqueeze(1) * w.view(1, SLOTS, 1)).contiguous()
 
 
+def to_device(t):
+    """where the second copy of every buffer lives (tests/test_kernel_source_on_host_cpu.py swaps HIP, to_device and device_sync to run
+    these same cases on the host simulation of the kernel sources)"""
+    return t.cuda()
+
+
+def device_sync():
+    torch.cuda.synchronize()
+
+
+def device_name():
+    return "cuda"
+
+
 def both(op, args, kwargs=None, tol=2e-4, names=None):
     """Run `op` on the emulator (CPU tensors) and on HIP (cuda clones); compare every tensor argument afterwards."""
     kwargs = kwargs or {}
@@ -84,7 +98,7 @@ def both(op, args, kwargs=None, tol=2e-4, names=None):
         if not torch.is_tensor(v):
             return v
         if id(v) not in memo:
-            memo[id(v)] = v.cuda()
+            memo[id(v)] = to_device(v)
         return memo[id(v)]
     gargs = [to_gpu(a) for a in args]
     gkw = {k: to_gpu(v) for k, v in kwargs.items()}
@@ -92,7 +106,7 @@ def both(op, args, kwargs=None, tol=2e-4, names=None):
     if op == "pw_gemm" and PACKED[0] and gkw["K"] % 16 == 0:
         gkw["A_pk"] = packed_operand(gkw)
     getattr(HIP, op)(*gargs, **gkw)
-    torch.cuda.synchronize()
+    device_sync()
     items = list(enumerate(zip(args, gargs))) + [(k, (kwargs[k], gkw[k])) for k in kwargs]      # (A_pk exists on one side only)
     for key, (c, g) in items:
         if not torch.is_tensor(c):
@@ -288,14 +302,14 @@ def test_gemm_packed_weights_model_shapes(M, K, T):
     err = {}
     for name in ("f32", "packed"):
         Y = torch.full((B, M, ldt), float("nan"), device="cuda")
-        Ag = A.cuda()
-        kw = dict(B=B, M=M, K=K, T=T, ldt=ldt, A=Ag, X=X.cuda(), Y=Y, bias=bias.cuda())
+        Ag = to_device(A)
+        kw = dict(B=B, M=M, K=K, T=T, ldt=ldt, A=Ag, X=to_device(X), Y=Y, bias=to_device(bias))
         if name == "packed":
             kw.update(arith=sepkernels.ARITH_F16X3, A_pk=HIP.pack_weights([(Ag, M, K, 0)])[0])
         else:
             kw.update(arith=sepkernels.ARITH_F32)
         HIP.pw_gemm(**kw)
-        torch.cuda.synchronize()
+        device_sync()
         assert torch.isfinite(Y).all()
         assert (Y[..., T:] == 0).all()
         err[name] = (((Y.cpu().double() - ref)[..., :T]).abs() / scale).max().item()
@@ -330,11 +344,11 @@ def test_gemm_packed_adversarial_operands(case):
     err = {}
     for name in ("f32", "packed"):
         Y = torch.full((B, M, ldt), float("nan"), device="cuda")
-        Ag = A.cuda()
-        kw = dict(B=B, M=M, K=K, T=T, ldt=ldt, A=Ag, X=X.cuda(), Y=Y)
+        Ag = to_device(A)
+        kw = dict(B=B, M=M, K=K, T=T, ldt=ldt, A=Ag, X=to_device(X), Y=Y)
         kw.update(arith=sepkernels.ARITH_F16X3, A_pk=HIP.pack_weights([(Ag, M, K, 0)])[0]) if name == "packed" else kw.update(arith=sepkernels.ARITH_F32)
         HIP.pw_gemm(**kw)
-        torch.cuda.synchronize()
+        device_sync()
         assert torch.isfinite(Y).all()
         e = ((Y.cpu().double() - ref)[..., :T]).abs()
         err[name] = (e / (scale + floor + 1e-300)).max().item()
@@ -349,8 +363,8 @@ def test_pack_weights_reproduces_the_weights():
     W = rnd(96, 64) * torch.exp(5 * rnd(96, 1))
     W[5] = 0
     for trans in (0, 1):
-        pk = HIP.pack_weights([(W.cuda(), 96, 64, trans)])[0]
-        torch.cuda.synchronize()
+        pk = HIP.pack_weights([(to_device(W), 96, 64, trans)])[0]
+        device_sync()
         M, K = pk.M, pk.K
         # operand-block layout: [m / 32][k / 16][hi | lo][lane = 32 * ((k >> 3) & 1) + (m & 31)][8 fp16]
         h = pk.data.view(torch.float16).view(M // 32, K // 16, 2, 2, 32, 8).float().cpu()
@@ -373,10 +387,10 @@ def _reduce_check(part_c, part_g, tol=3e-4):
 def _wgrad_both(kw, tol=3e-4):
     """Slab contents differ by construction (the emulator puts everything in slab 0): compare the slab sums."""
     ck = dict(kw)
-    gk = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in kw.items()}
+    gk = {k: (to_device(v) if torch.is_tensor(v) else v) for k, v in kw.items()}
     EMU.pw_wgrad(**ck)
     HIP.pw_wgrad(**gk)
-    torch.cuda.synchronize()
+    device_sync()
     assert torch.isfinite(gk["partial"]).all()
     _reduce_check(ck["partial"], gk["partial"], tol)
     if kw.get("partial_bias") is not None:
@@ -401,8 +415,8 @@ def test_gemm_split_arithmetic_is_as_accurate_as_fp32_mfma(K, scale):
     err = {}
     for name in ("f32", "bf16x6", "f16x3"):
         Y = torch.full((B, M, ldt), float("nan"), device="cuda")
-        HIP.pw_gemm(B=B, M=M, K=K, T=T, ldt=ldt, A=A.cuda(), X=X.cuda(), Y=Y, arith=sepkernels.arith_code(name))
-        torch.cuda.synchronize()
+        HIP.pw_gemm(B=B, M=M, K=K, T=T, ldt=ldt, A=to_device(A), X=to_device(X), Y=Y, arith=sepkernels.arith_code(name))
+        device_sync()
         d = (Y.cpu().double() - ref)[..., :T]
         err[name] = (d.abs().max().item() / ref.abs().max().item(), (d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item())
     assert err["bf16x6"][0] <= max(2 * err["f32"][0], 2e-7), err
@@ -450,7 +464,7 @@ def test_wgrad_latent_product_and_prelu(arith):
 def test_reduce_slabs_and_f64():
     src = rnd(6, 1000)
     segs_c = [(src, 0, nan(300), 300, 6, 1000, 0, 1.0), (src, 300, torch.ones(700), 700, 5, 1000, 1, 0.5)]
-    segs_g = [(s.cuda(), o, d.cuda(), n, k, st, a, sc) for (s, o, d, n, k, st, a, sc) in segs_c]
+    segs_g = [(to_device(s), o, to_device(d), n, k, st, a, sc) for (s, o, d, n, k, st, a, sc) in segs_c]
     EMU.reduce_slabs(segs_c)
     HIP.reduce_slabs(segs_g)
     for c, g in zip(segs_c, segs_g):
@@ -475,10 +489,10 @@ def test_dwconv_fwd_bwd(T, d):
     dv2 = padded(B, C, T, ldt)
     ntile = (ldt + 1023) // 1024
     args = [dv2, z, a, st1, g1, b1, a1, st2, rnd(C) + 1, a2, rnd(B, 2, scale=0.01), wd, nan(B, C, ldt), nan(B, C, ntile, 8), B, C, T, ldt, d, 1e-12]
-    gargs = [v.cuda() if torch.is_tensor(v) else v for v in args]
+    gargs = [to_device(v) if torch.is_tensor(v) else v for v in args]
     EMU.dwconv_bwd(*args)
     HIP.dwconv_bwd(*gargs)
-    torch.cuda.synchronize()
+    device_sync()
     assert torch.isfinite(gargs[12]).all() and torch.isfinite(gargs[13]).all()
     assert (args[12] - gargs[12].cpu()).abs().max() <= 2e-4 * args[12].abs().max()
     rc, rg = args[13].double().sum(2), gargs[13].cpu().double().sum(2)          # per-tile partials -> per-row totals
@@ -543,9 +557,9 @@ def test_gln_standalone_and_repack():
     both("gln_apply", [x, st, gamma, beta, nan(B, C, ldt), B, C, T, ldt, C * float(T), 1e-12])
     dy = padded(B, C, T, ldt)
     ntile = (ldt + 1023) // 1024
-    rp, rpg = nan(B, C, ntile, 2), nan(B, C, ntile, 2).cuda()
+    rp, rpg = nan(B, C, ntile, 2), to_device(nan(B, C, ntile, 2))
     EMU.gln_bwd_rowsums(dy, x, rp, B, C, T, ldt)
-    HIP.gln_bwd_rowsums(dy.cuda(), x.cuda(), rpg, B, C, T, ldt)
+    HIP.gln_bwd_rowsums(to_device(dy), to_device(x), rpg, B, C, T, ldt)
     assert torch.isfinite(rpg).all()          # per-tile partials differ by construction: compare the row totals
     assert (rp.double().sum(2) - rpg.cpu().double().sum(2)).abs().max() <= 2e-4 * rp.abs().max()
     both("gln_bwd_apply", [dy, x, st, gamma, rnd(B, 2, scale=0.01), nan(B, C, ldt), B, C, T, ldt, C * float(T), 1e-12])
@@ -571,13 +585,13 @@ def test_cln_fwd_bwd(B, C, T):
     v = (x64 * x64).sum(1).cumsum(1) / n - m * m
     y64 = (x64 - m.unsqueeze(1)) / (v.sqrt().unsqueeze(1) + eps) * g64.view(1, C, 1) + b64.view(1, C, 1)
     (y64 * dy[..., :T].double()).sum().backward()
-    f32 = dict(device="cuda", dtype=torch.float32)
+    f32 = dict(device=device_name(), dtype=torch.float32)
     y, mean, rstd = torch.full((B, C, ldt), float("nan"), **f32), torch.empty(B, T, **f32), torch.empty(B, T, **f32)
-    ws = torch.empty(B, 2, T, device="cuda", dtype=torch.float64)
-    HIP.cln_fwd(x.cuda(), gamma.cuda(), beta.cuda(), y, mean, rstd, ws, B, C, T, ldt, eps)
+    ws = torch.empty(B, 2, T, device=device_name(), dtype=torch.float64)
+    HIP.cln_fwd(to_device(x), to_device(gamma), to_device(beta), y, mean, rstd, ws, B, C, T, ldt, eps)
     dx, pg, pb = torch.full((B, C, ldt), float("nan"), **f32), torch.empty(B, C, **f32), torch.empty(B, C, **f32)
-    HIP.cln_bwd(dy.cuda(), x.cuda(), gamma.cuda(), mean, rstd, dx, pg, pb, ws, B, C, T, ldt, eps)
-    torch.cuda.synchronize()
+    HIP.cln_bwd(to_device(dy), to_device(x), to_device(gamma), mean, rstd, dx, pg, pb, ws, B, C, T, ldt, eps)
+    device_sync()
     y, dx = y.cpu(), dx.cpu()
     assert torch.isfinite(y).all() and torch.isfinite(dx).all()
     assert (y[..., T:] == 0).all() and (dx[..., T:] == 0).all()
@@ -634,8 +648,8 @@ def test_rowdiff_sums_and_bwd(rows, T):
     both("rowdiff_bwd", [x, t, None, cs, nan(rows, T), rows, T], tol=1e-6)
     # rows that start off a 16-byte boundary take the scalar path
     xo, to = rnd(rows * T + 1)[1:].reshape(rows, T), rnd(rows * T + 1)[1:].reshape(rows, T)
-    gx, gt = torch.empty(rows * T + 1, device="cuda")[1:].reshape(rows, T).copy_(xo), torch.empty(rows * T + 1, device="cuda")[1:].reshape(rows, T).copy_(to)
-    sc, sg = torch.empty(rows, 3, dtype=torch.float64), torch.empty(rows, 3, dtype=torch.float64, device="cuda")
+    gx, gt = torch.empty(rows * T + 1, device=device_name())[1:].reshape(rows, T).copy_(xo), torch.empty(rows * T + 1, device=device_name())[1:].reshape(rows, T).copy_(to)
+    sc, sg = torch.empty(rows, 3, dtype=torch.float64), torch.empty(rows, 3, dtype=torch.float64, device=device_name())
     EMU.rowdiff_sums(xo, to, sc, rows, T)
     HIP.rowdiff_sums(gx, gt, sg, rows, T)
     assert (sg.cpu() - sc).abs().max() <= 1e-5 * sc.abs().max()

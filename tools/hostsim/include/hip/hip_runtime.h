@@ -1,0 +1,169 @@
+// Development / test tool (tools/hostsim.py): the pieces of the HIP programming model that the asm-free kernel files of csrc/ use
+// (stream.hip, cln.hip, loss.hip, lstm.hip), restated for the HOST, so that the kernels' own source -- compiled as plain C++ with this
+// directory in front of the include path -- runs as ordinary threads: one thread per lane of a workgroup, a pthread barrier per workgroup
+// and per wave, wave shuffles and the MFMA instructions as collective operations of a wave.  Not a general HIP emulator.  Known limits:
+// collectives must be reached by every lane of the wave / workgroup (true of these kernels; divergent shuffles would deadlock here),
+// `__shared__` is a function-local static (one workgroup runs at a time), no streams (launches complete before they return).
+#pragma once
+#include <math.h>
+#include <pthread.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <thread>
+#include <vector>
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "host simulation"; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+
+struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct double2 { double x, y; };
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline double2 make_double2(double x, double y) { return double2{x, y}; }
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __restrict__
+#define __shared__ static
+
+struct SimCtx {
+    std::vector<unsigned long long> dynamic_lds;      // `extern __shared__ T name[]` -- tools/hostsim.py rewrites that one declaration form
+    pthread_barrier_t block_barrier;
+    std::vector<pthread_barrier_t> wave_barrier;
+    std::vector<unsigned long long> slot, slot2;      // exchange slots, one (pair) per thread of the workgroup
+};
+extern SimCtx* g_sim;
+extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+#define warpSize 64
+static inline void* sim_dynamic_lds() { return g_sim->dynamic_lds.data(); }
+
+static inline void __syncthreads() { pthread_barrier_wait(&g_sim->block_barrier); }
+static inline void sim_wave_sync() { pthread_barrier_wait(&g_sim->wave_barrier[threadIdx.x >> 6]); }
+
+template <typename T>
+static inline T sim_read_lane(T v, int src_lane) {                     // every lane of the wave publishes v, then reads lane src_lane's
+    static_assert(sizeof(T) <= 8, "shuffle of a type wider than 8 bytes");
+    const unsigned t = threadIdx.x, base = t & ~63u;
+    unsigned long long w = 0;
+    memcpy(&w, &v, sizeof(T));
+    g_sim->slot[t] = w;
+    sim_wave_sync();
+    const unsigned src = base + (unsigned)(src_lane & 63);
+    const unsigned long long r = src < g_sim->slot.size() ? g_sim->slot[src] : w;
+    sim_wave_sync();
+    T out;
+    memcpy(&out, &r, sizeof(T));
+    return out;
+}
+template <typename T> static inline T __shfl(T v, int src, int width = 64) { const int l = threadIdx.x & 63; return sim_read_lane(v, (l & ~(width - 1)) + (src & (width - 1))); }
+template <typename T> static inline T __shfl_xor(T v, int mask, int width = 64) { const int l = threadIdx.x & 63; (void)width; return sim_read_lane(v, l ^ mask); }
+template <typename T> static inline T __shfl_up(T v, unsigned delta, int width = 64) {
+    const int l = threadIdx.x & 63, in_seg = l & (width - 1);
+    const T got = sim_read_lane(v, in_seg >= (int)delta ? l - (int)delta : l);
+    return got;
+}
+template <typename T> static inline T __shfl_down(T v, unsigned delta, int width = 64) {
+    const int l = threadIdx.x & 63, in_seg = l & (width - 1);
+    return sim_read_lane(v, in_seg + (int)delta < width ? l + (int)delta : l);
+}
+
+static inline float atomicAdd(float* p, float v) {
+    uint32_t* q = reinterpret_cast<uint32_t*>(p);
+    uint32_t old = __atomic_load_n(q, __ATOMIC_RELAXED), want;
+    float f;
+    do { memcpy(&f, &old, 4); f += v; memcpy(&want, &f, 4); } while (!__atomic_compare_exchange_n(q, &old, want, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+    memcpy(&f, &old, 4);
+    return f;
+}
+static inline double atomicAdd(double* p, double v) {
+    uint64_t* q = reinterpret_cast<uint64_t*>(p);
+    uint64_t old = __atomic_load_n(q, __ATOMIC_RELAXED), want;
+    double f;
+    do { memcpy(&f, &old, 8); f += v; memcpy(&want, &f, 8); } while (!__atomic_compare_exchange_n(q, &old, want, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+    memcpy(&f, &old, 8);
+    return f;
+}
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+
+static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }          // only used on wave-uniform values
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.f / x; }
+static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
+static inline float __builtin_amdgcn_rsqf(float x) { return 1.f / sqrtf(x); }
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+static inline void __builtin_amdgcn_wave_barrier() { sim_wave_sync(); }        // lanes are threads here: the hardware's lock-step is a barrier
+static inline float __fdividef(float a, float b) { return a / b; }
+static inline unsigned __float_as_uint(float x) { unsigned u; memcpy(&u, &x, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float x; memcpy(&x, &u, 4); return x; }
+static inline int __float_as_int(float x) { int u; memcpy(&u, &x, 4); return u; }
+static inline float __int_as_float(int u) { float x; memcpy(&x, &u, 4); return x; }
+
+typedef float sim_f32x4 __attribute__((ext_vector_type(4)));
+// v_mfma_f32_4x4x1_16b_f32: D_l[v] = C_l[v] + A_{4 (l / 4) + v} * B_l
+static inline sim_f32x4 __builtin_amdgcn_mfma_f32_4x4x1f32(float a, float b, sim_f32x4 c, int, int, int) {
+    const unsigned t = threadIdx.x, base = t & ~63u, l = t & 63u;
+    memcpy(&g_sim->slot[t], &a, 4); memcpy(&g_sim->slot2[t], &b, 4);
+    sim_wave_sync();
+    sim_f32x4 d = c;
+    float bv; memcpy(&bv, &g_sim->slot2[t], 4);
+    for (int v = 0; v < 4; ++v) { float av; memcpy(&av, &g_sim->slot[base + 4 * (l / 4) + v], 4); d[v] += av * bv; }
+    sim_wave_sync();
+    return d;
+}
+// v_mfma_f32_16x16x4_f32: A[i = l % 16][k = l / 16], B[k = l / 16][j = l % 16], D[i = 4 (l / 16) + v][j = l % 16]
+static inline sim_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, sim_f32x4 c, int, int, int) {
+    const unsigned t = threadIdx.x, base = t & ~63u, l = t & 63u;
+    memcpy(&g_sim->slot[t], &a, 4); memcpy(&g_sim->slot2[t], &b, 4);
+    sim_wave_sync();
+    sim_f32x4 d = c;
+    for (int v = 0; v < 4; ++v)
+        for (int k = 0; k < 4; ++k) {
+            float av, bv;
+            memcpy(&av, &g_sim->slot[base + 16 * k + 4 * (l / 16) + v], 4); memcpy(&bv, &g_sim->slot2[base + 16 * k + (l % 16)], 4);
+            d[v] += av * bv;
+        }
+    sim_wave_sync();
+    return d;
+}
+
+// one host thread per lane; the threads walk the grid together, one workgroup at a time
+template <typename K, typename... A>
+static void sim_launch(K kernel, dim3 grid, dim3 block, size_t shmem, A... args) {
+    const unsigned nt = block.x * block.y * block.z, nw = (nt + 63) / 64;
+    SimCtx ctx;
+    ctx.dynamic_lds.assign(shmem / 8 + 2, 0);
+    pthread_barrier_init(&ctx.block_barrier, nullptr, nt);
+    ctx.wave_barrier.resize(nw);
+    for (unsigned w = 0; w < nw; ++w) pthread_barrier_init(&ctx.wave_barrier[w], nullptr, (w + 1) * 64 <= nt ? 64 : nt - w * 64);
+    ctx.slot.assign(nt, 0); ctx.slot2.assign(nt, 0);
+    g_sim = &ctx;
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t)
+        th.emplace_back([=]() {
+            blockDim = block; gridDim = grid;
+            threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+            for (unsigned bz = 0; bz < grid.z; ++bz)
+                for (unsigned by = 0; by < grid.y; ++by)
+                    for (unsigned bx = 0; bx < grid.x; ++bx) {
+                        blockIdx = dim3(bx, by, bz);
+                        kernel(args...);
+                        pthread_barrier_wait(&g_sim->block_barrier);        // the workgroup's statics (its LDS) are free for the next one
+                    }
+        });
+    for (auto& x : th) x.join();
+    g_sim = nullptr;
+}
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) sim_launch(kernel, dim3(grid), dim3(block), (size_t)(shmem), __VA_ARGS__)
