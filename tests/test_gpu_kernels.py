@@ -499,6 +499,19 @@ def test_dwconv_fwd_bwd(T, d):
     assert (rc - rg).abs().max() <= 3e-4 * rc.abs().max()
 
 
+@pytest.mark.parametrize("Kw,stride,pad,dil,Tin", [(3, 1, 1, 1, 300), (5, 2, 4, 2, 257), (4, 4, 0, 1, 64), (3, 1, 8, 8, 1000), (16, 8, 0, 1, 403)])
+def test_depthwise_generic(Kw, stride, pad, dil, Tin):
+    """sep_depthwise_fwd / bwd_input / bwd_weight (modules/conv.py's depthwise half: any kernel size, stride, padding, dilation)"""
+    B, C = 2, 24
+    Tout = (Tin + 2 * pad - dil * (Kw - 1) - 1) // stride + 1
+    x, w, bias = rnd(B, C, Tin), rnd(C, 1, Kw), rnd(C)
+    both("depthwise_fwd", [x, w, bias, nan(B, C, Tout), B, C, Tin, Tout, Kw, stride, pad, dil])
+    both("depthwise_fwd", [x, w, None, nan(B, C, Tout), B, C, Tin, Tout, Kw, stride, pad, dil])
+    dy = rnd(B, C, Tout)
+    both("depthwise_bwd_input", [dy, w, nan(B, C, Tin), B, C, Tin, Tout, Kw, stride, pad, dil])
+    both("depthwise_bwd_weight", [dy, x, nan(B, C, Kw + 1), B, C, Tin, Tout, Kw, stride, pad, dil])
+
+
 @pytest.mark.parametrize("nq,ntile", [(2, 8), (8, 4), (8, 1), (2, 64)])
 def test_gln_bwd_finalize(nq, ntile):
     B, C = 3, 96
