@@ -26,24 +26,32 @@ def compiler():
     return None
 
 
-def build(workdir):
-    """-> path of libsepkernels_hostsim.so, built in `workdir`"""
+def build(workdir, sanitize=False):
+    """-> path of libsepkernels_hostsim.so, built in `workdir`; sanitize: with AddressSanitizer (the process that loads it must run
+    with the ASan runtime preloaded, see `python tools/hostsim.py --asan`)"""
     cxx = compiler()
     if cxx is None:
         raise RuntimeError("hostsim needs clang++")
     inc = os.path.join(ROOT, "tools", "hostsim", "include")
+    san = ["-g", "-fsanitize=address", "-fno-omit-frame-pointer"] if sanitize else []
     objs = []
     for f in FILES:
         src = open(os.path.join(CSRC, f + ".hip")).read()
         cpp = os.path.join(workdir, f + ".cpp")
         open(cpp, "w").write(_DYN.sub(r"\1* \2 = (\1*)sim_dynamic_lds();", src))
         objs.append(os.path.join(workdir, f + ".o"))
-        subprocess.check_call([cxx, "-std=c++17", "-O1", "-fPIC", "-pthread", "-I", inc, "-I", CSRC, "-c", cpp, "-o", objs[-1]])
+        subprocess.check_call([cxx, "-std=c++17", "-O1", "-fPIC", "-pthread"] + san + ["-I", inc, "-I", CSRC, "-c", cpp, "-o", objs[-1]])
     objs.append(os.path.join(workdir, "sim_main.o"))
-    subprocess.check_call([cxx, "-std=c++17", "-O1", "-fPIC", "-pthread", "-I", inc, "-c", os.path.join(ROOT, "tools", "hostsim", "sim_main.cpp"), "-o", objs[-1]])
+    subprocess.check_call([cxx, "-std=c++17", "-O1", "-fPIC", "-pthread"] + san + ["-I", inc, "-c", os.path.join(ROOT, "tools", "hostsim", "sim_main.cpp"), "-o", objs[-1]])
     so = os.path.join(workdir, "libsepkernels_hostsim.so")
-    subprocess.check_call([cxx, "-shared", "-pthread", "-o", so] + objs)
+    subprocess.check_call([cxx, "-shared", "-pthread"] + (["-shared-libasan", "-fsanitize=address"] if sanitize else []) + ["-o", so] + objs)
     return so
+
+
+def asan_runtime():
+    cxx = compiler()
+    out = subprocess.check_output([cxx, "-print-file-name=libclang_rt.asan-x86_64.so"], text=True).strip()
+    return out if os.path.isabs(out) and os.path.exists(out) else None
 
 
 class HostSimBackend:
@@ -74,3 +82,50 @@ class HostSimBackend:
     def __exit__(self, *exc):
         import sepkernels
         sepkernels._lib, sepkernels._ptr, sepkernels._stream = self._saved
+
+
+_ASAN_CHILD = r"""
+import sys, time
+sys.path[:0] = {paths!r}
+import hostsim
+import test_gpu_kernels as GK
+import test_kernel_source_on_host_cpu as H
+with hostsim.HostSimBackend({so!r}) as K:
+    GK.HIP, GK.to_device, GK.device_sync, GK.device_name = K, (lambda t: t.clone()), (lambda: None), (lambda: "cpu")
+    for name, params in H.CASES:
+        for p in params:
+            t0 = time.time()
+            getattr(GK, name)(*p)
+            print("  {{:34s}} {{:28s}} {{:5.1f}} s".format(name, str(p), time.time() - t0), flush=True)
+print("ASAN-RUN-COMPLETE")
+"""
+
+
+def main():
+    """python tools/hostsim.py --asan : the kernel cases of the CPU tier once more, with the kernel sources compiled under
+    AddressSanitizer -- out-of-bounds reads / writes of global buffers (torch's allocations go through the intercepted allocator) and of
+    the workgroup's LDS (function-local statics here) that happen to be harmless on the device show up as reports."""
+    import sys
+    import tempfile
+    if "--asan" not in sys.argv:
+        print(main.__doc__)
+        return 0
+    rt = asan_runtime()
+    if rt is None:
+        print("no ASan runtime next to", compiler())
+        return 1
+    with tempfile.TemporaryDirectory() as d:
+        so = build(d, sanitize=True)
+        paths = [os.path.join(ROOT, "tools"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "dnn-based_source_separation_amd", "src"), ROOT]
+        env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:halt_on_error=0")
+        r = subprocess.run([sys.executable, "-c", _ASAN_CHILD.format(paths=paths, so=so)], env=env, capture_output=True, text=True)
+    reports = r.stderr.count("ERROR: AddressSanitizer")
+    print(r.stdout[-6000:])
+    if reports or "ASAN-RUN-COMPLETE" not in r.stdout:
+        print(r.stderr[-6000:])
+    print("AddressSanitizer reports:", reports)
+    return 1 if reports or r.returncode else 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())
