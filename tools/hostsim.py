@@ -26,14 +26,14 @@ def compiler():
     return None
 
 
-def build(workdir, sanitize=False):
-    """-> path of libsepkernels_hostsim.so, built in `workdir`; sanitize: with AddressSanitizer (the process that loads it must run
-    with the ASan runtime preloaded, see `python tools/hostsim.py --asan`)"""
+def build(workdir, sanitize=None):
+    """-> path of libsepkernels_hostsim.so, built in `workdir`; sanitize: None, "address" or "thread" (the process that loads a
+    sanitized build must run with that sanitizer's runtime preloaded, see `python tools/hostsim.py --asan | --tsan`)"""
     cxx = compiler()
     if cxx is None:
         raise RuntimeError("hostsim needs clang++")
     inc = os.path.join(ROOT, "tools", "hostsim", "include")
-    san = ["-g", "-fsanitize=address", "-fno-omit-frame-pointer"] if sanitize else []
+    san = ["-g", "-fsanitize=" + sanitize, "-fno-omit-frame-pointer"] if sanitize else []
     objs = []
     for f in FILES:
         src = open(os.path.join(CSRC, f + ".hip")).read()
@@ -44,13 +44,14 @@ def build(workdir, sanitize=False):
     objs.append(os.path.join(workdir, "sim_main.o"))
     subprocess.check_call([cxx, "-std=c++17", "-O1", "-fPIC", "-pthread"] + san + ["-I", inc, "-c", os.path.join(ROOT, "tools", "hostsim", "sim_main.cpp"), "-o", objs[-1]])
     so = os.path.join(workdir, "libsepkernels_hostsim.so")
-    subprocess.check_call([cxx, "-shared", "-pthread"] + (["-shared-libasan", "-fsanitize=address"] if sanitize else []) + ["-o", so] + objs)
+    subprocess.check_call([cxx, "-shared", "-pthread"] + (["-shared-libsan", "-fsanitize=" + sanitize] if sanitize else []) + ["-o", so] + objs)
     return so
 
 
-def asan_runtime():
+def sanitizer_runtime(kind):
+    """kind: "asan" or "tsan" -> path of the shared runtime next to the compiler, or None"""
     cxx = compiler()
-    out = subprocess.check_output([cxx, "-print-file-name=libclang_rt.asan-x86_64.so"], text=True).strip()
+    out = subprocess.check_output([cxx, "-print-file-name=libclang_rt.{}-x86_64.so".format(kind)], text=True).strip()
     return out if os.path.isabs(out) and os.path.exists(out) else None
 
 
@@ -84,9 +85,11 @@ class HostSimBackend:
         sepkernels._lib, sepkernels._ptr, sepkernels._stream = self._saved
 
 
-_ASAN_CHILD = r"""
+_SANITIZED_CHILD = r"""
 import sys, time
 sys.path[:0] = {paths!r}
+import torch
+torch.set_num_threads(1)
 import hostsim
 import test_gpu_kernels as GK
 import test_kernel_source_on_host_cpu as H
@@ -97,33 +100,37 @@ with hostsim.HostSimBackend({so!r}) as K:
             t0 = time.time()
             getattr(GK, name)(*p)
             print("  {{:34s}} {{:28s}} {{:5.1f}} s".format(name, str(p), time.time() - t0), flush=True)
-print("ASAN-RUN-COMPLETE")
+print("SANITIZED-RUN-COMPLETE")
 """
 
 
 def main():
-    """python tools/hostsim.py --asan : the kernel cases of the CPU tier once more, with the kernel sources compiled under
-    AddressSanitizer -- out-of-bounds reads / writes of global buffers (torch's allocations go through the intercepted allocator) and of
-    the workgroup's LDS (function-local statics here) that happen to be harmless on the device show up as reports."""
+    """python tools/hostsim.py --asan | --tsan : the kernel cases of the CPU tier once more, with the kernel sources compiled under a
+    sanitizer.  --asan: out-of-bounds reads / writes of global buffers (torch's allocations go through the intercepted allocator) and of
+    the workgroup's LDS (function-local statics here) that happen to be harmless on the device.  --tsan: data races on LDS or global
+    memory between the lanes of a workgroup -- a missing __syncthreads(), or code that silently relies on the lock-step of a wave (here
+    every lane is a thread of its own, only barriers and the wave collectives order them)."""
     import sys
     import tempfile
-    if "--asan" not in sys.argv:
+    kind = "asan" if "--asan" in sys.argv else "tsan" if "--tsan" in sys.argv else None
+    if kind is None:
         print(main.__doc__)
         return 0
-    rt = asan_runtime()
+    rt = sanitizer_runtime(kind)
     if rt is None:
-        print("no ASan runtime next to", compiler())
+        print("no", kind, "runtime next to", compiler())
         return 1
+    marker = "ERROR: AddressSanitizer" if kind == "asan" else "WARNING: ThreadSanitizer"
     with tempfile.TemporaryDirectory() as d:
-        so = build(d, sanitize=True)
+        so = build(d, sanitize="address" if kind == "asan" else "thread")
         paths = [os.path.join(ROOT, "tools"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "dnn-based_source_separation_amd", "src"), ROOT]
-        env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:halt_on_error=0")
-        r = subprocess.run([sys.executable, "-c", _ASAN_CHILD.format(paths=paths, so=so)], env=env, capture_output=True, text=True)
-    reports = r.stderr.count("ERROR: AddressSanitizer")
+        env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:halt_on_error=0", TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0")
+        r = subprocess.run([sys.executable, "-c", _SANITIZED_CHILD.format(paths=paths, so=so)], env=env, capture_output=True, text=True)
+    reports = r.stderr.count(marker)
     print(r.stdout[-6000:])
-    if reports or "ASAN-RUN-COMPLETE" not in r.stdout:
-        print(r.stderr[-6000:])
-    print("AddressSanitizer reports:", reports)
+    if reports or "SANITIZED-RUN-COMPLETE" not in r.stdout:
+        print(r.stderr[-8000:])
+    print("{} reports: {}".format(marker.split(": ")[1], reports))
     return 1 if reports or r.returncode else 0
 
 
