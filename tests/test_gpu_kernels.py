@@ -301,7 +301,7 @@ def test_gemm_packed_weights_model_shapes(M, K, T):
     scale = torch.einsum("mk,bkt->bmt", A.double().abs(), X.double().abs())[..., :T] + bias.double().abs().view(1, M, 1) + 1e-30
     err = {}
     for name in ("f32", "packed"):
-        Y = torch.full((B, M, ldt), float("nan"), device="cuda")
+        Y = torch.full((B, M, ldt), float("nan"), device=device_name())
         Ag = to_device(A)
         kw = dict(B=B, M=M, K=K, T=T, ldt=ldt, A=Ag, X=to_device(X), Y=Y, bias=to_device(bias))
         if name == "packed":
@@ -343,7 +343,7 @@ def test_gemm_packed_adversarial_operands(case):
     floor = 1.4e-45 * A.double().abs().sum(1).view(1, M, 1)          # one fp32 ulp at the bottom of the subnormal range per term
     err = {}
     for name in ("f32", "packed"):
-        Y = torch.full((B, M, ldt), float("nan"), device="cuda")
+        Y = torch.full((B, M, ldt), float("nan"), device=device_name())
         Ag = to_device(A)
         kw = dict(B=B, M=M, K=K, T=T, ldt=ldt, A=Ag, X=to_device(X), Y=Y)
         kw.update(arith=sepkernels.ARITH_F16X3, A_pk=HIP.pack_weights([(Ag, M, K, 0)])[0]) if name == "packed" else kw.update(arith=sepkernels.ARITH_F32)
@@ -414,7 +414,7 @@ def test_gemm_split_arithmetic_is_as_accurate_as_fp32_mfma(K, scale):
     ref = torch.einsum("mk,bkt->bmt", A.double(), X.double())
     err = {}
     for name in ("f32", "bf16x6", "f16x3"):
-        Y = torch.full((B, M, ldt), float("nan"), device="cuda")
+        Y = torch.full((B, M, ldt), float("nan"), device=device_name())
         HIP.pw_gemm(B=B, M=M, K=K, T=T, ldt=ldt, A=to_device(A), X=to_device(X), Y=Y, arith=sepkernels.arith_code(name))
         device_sync()
         d = (Y.cpu().double() - ref)[..., :T]

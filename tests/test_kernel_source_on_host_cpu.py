@@ -1,12 +1,14 @@
-"""CPU: the HIP kernel files' OWN SOURCE executed on the host.  tools/hostsim.py compiles the asm-free files of csrc/ (stream.hip,
-cln.hip, loss.hip, lstm.hip) as plain C++ against a stand-in for the few pieces of the HIP programming model they use (one host thread
-per lane, pthread barriers for workgroup and wave, shuffles and the MFMA instructions as collective operations of a wave) into a library
-with the same C ABI, and the kernel cases of tests/test_gpu_kernels.py -- the very functions that run on the MI355X, at their own sizes
--- are run against it here: encoder / unfold, depthwise forward / backward, gLN statistics / apply / backward pieces, head backward,
+"""CPU: the HIP kernel files' OWN SOURCE executed on the host.  tools/hostsim.py compiles every file of csrc/ as plain C++ against a
+stand-in for the pieces of the HIP programming model they use (one host thread per lane, pthread barriers for workgroup and wave;
+shuffles, DPP, ballots and the MFMA instructions as collective operations of a wave; LDS-DMA as a wave-wide copy; the GEMM files' few
+inline-assembly helpers get a C++ body in the compiled copy) into a library with the same C ABI -- all 42 entry points -- and the kernel
+cases of tests/test_gpu_kernels.py -- the very functions that run on the MI355X -- are run against it here: encoder / unfold, depthwise forward / backward, gLN statistics / apply / backward pieces, head backward,
 decoder forward / backward, channel softmax, cLN, SI-SDR, PIT search, Sinkhorn, row distances, squared norm + Adam, chunking /
 overlap-add, the LSTM sweeps (16 sequences per workgroup, and the four-sequence variant prepared behind SEPK_LSTM_NS4).
+and the GEMM family in its three arithmetics and the packed-weight form (per-wave split kernels, the cooperative and the producer /
+consumer kernels with their flag synchronisation, the weight-gradient kernels, prologues / epilogues, ragged tiles).
 It catches indexing / synchronisation / unwritten-output mistakes in the kernel source before any GPU minute is spent.  It cannot see
-timing, the hardware's operand layouts themselves (tools/mfma4x4_probe.hip) or the GEMM files (inline assembly, LDS-DMA)."""
+timing, asynchrony (DMA lands at once, waits are no-ops) or the hardware's operand layouts themselves (tools/mfma4x4_probe.hip)."""
 import os
 import subprocess
 import sys
@@ -32,13 +34,31 @@ CASES = [
     ("test_softmax_over_channels", [(2, 128, 300), (3, 50, 64), (2, 7, 1)]),
     ("test_gln_standalone_and_repack", [()]),
     ("test_cln_fwd_bwd", [(2, 24, 203), (3, 128, 3999)]),
-    ("test_sisdr_kernels", [(1, 0), (2, 1)]),
+    ("test_sisdr_kernels", [(1, 0)]),
     ("test_pit_search", [(2, 0, 1), (3, 1, 1), (4, 0, 0)]),
     ("test_sinkhorn", [(3, 10, 1.0), (5, 200, 1.0), (10, 5, 0.5)]),
     ("test_rowdiff_sums_and_bwd", [(8, 32000), (1, 5)]),
     ("test_sqnorm_and_adam", [()]),
     ("test_segment_overlap_add", [(812, 20, 10), (3999, 250, 125), (100, 16, 4), (64, 64, 64)]),
-    ("test_lstm_sweeps", [(16, 5, 7, 0), (32, 37, 23, 1)]),
+    ("test_lstm_sweeps", [(16, 5, 7, 0), (32, 37, 5, 1)]),
+]
+
+
+# (arithmetic, test function, arguments without the trailing `arith`); "f16x3-packed" hands over weights split by sep_pack_weights
+GEMM_CASES = [
+    ("f32", "test_gemm_plain_bias", (2, 64, 128, 300)),
+    ("f16x3", "test_gemm_plain_bias", (3, 128, 64, 129)),
+    ("f16x3-packed", "test_gemm_plain_bias", (2, 64, 128, 300)),
+    ("bf16x6", "test_gemm_plain_bias", (3, 128, 64, 129)),
+    ("f16x3", "test_gemm_small_widths_of_the_dual_path_separators", (48, 48, 77)),
+    ("f16x3-packed", "test_gemm_prelu_prologue_sigmoid", ()),
+    ("f16x3-packed", "test_gemm_gln_bwd_prologue", (1,)),
+    ("f16x3", "test_wgrad_plain", (2, 256, 128, 300, 3)),
+    ("bf16x6", "test_wgrad_plain", (2, 128, 256, 130, 1)),
+    ("f32", "test_wgrad_plain", (2, 32, 4, 201, 2)),
+    (None, "test_gemm_packed_weights_model_shapes", (128, 512, 130)),        # producer / consumer kernel, 256-column workgroup tile
+    (None, "test_pack_weights_reproduces_the_weights", ()),
+    (None, "test_reduce_slabs_and_f64", ()),
 ]
 
 
@@ -65,6 +85,20 @@ def test_kernel_source_on_the_host_matches_the_restatement(on_host, name, params
         getattr(GK, name)(*p)
 
 
+@pytest.mark.parametrize("arith,name,args", GEMM_CASES, ids=["{}-{}-{}".format(a or "", n[5:30], "x".join(map(str, g))) for a, n, g in GEMM_CASES])
+def test_gemm_kernel_source_on_the_host_matches_the_restatement(on_host, arith, name, args):
+    import sepkernels
+    if arith is None:
+        return getattr(GK, name)(*args)
+    prev = sepkernels.set_gemm_arith(arith.split("-")[0])
+    GK.PACKED[0] = arith.endswith("packed")
+    try:
+        getattr(GK, name)(*args, arith)
+    finally:
+        GK.PACKED[0] = False
+        sepkernels.set_gemm_arith(prev)
+
+
 def test_the_comparison_is_not_vacuous(on_host):
     """the same harness fails when the device side computes something else (here: a gain 1 % off)"""
     class Skewed:
@@ -89,7 +123,7 @@ import hostsim
 import test_gpu_kernels as GK
 with hostsim.HostSimBackend({so!r}) as K:
     GK.HIP, GK.to_device, GK.device_sync, GK.device_name = K, (lambda t: t.clone()), (lambda: None), (lambda: "cpu")
-    for case in [(16, 5, 7, 0), (16, 6, 3, 1), (32, 9, 11, 0), (64, 5, 4, 1), (128, 6, 3, 0)]:
+    for case in [(16, 5, 7, 0), (32, 9, 5, 1), (128, 6, 3, 0)]:
         GK.test_lstm_sweeps(*case)
     H, nseq, L = 32, 7, 5                                  # both directions in one launch, ragged last workgroup
     xg, w_hh = GK.rnd(2, nseq, L, 4 * H), GK.rnd(2, 4 * H, H, scale=H ** -0.5)

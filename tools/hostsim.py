@@ -1,9 +1,11 @@
-"""Development / test tool: the asm-free kernel files of csrc/ (stream.hip, cln.hip, loss.hip, lstm.hip) compiled as plain C++ against a
-stand-in for the few pieces of the HIP programming model they use (tools/hostsim/include/hip/hip_runtime.h: one host thread per lane,
-pthread barriers for workgroup and wave, shuffles and the MFMA instructions as wave collectives) into a shared library with the SAME
-C ABI as libsepkernels.so, so that the kernels' own source can be run -- slowly -- on CPU tensors through the same Python binding.
-One mechanical rewrite is applied to the copies that get compiled: `extern __shared__ T name[];` (dynamic LDS) becomes a pointer to a
-per-launch buffer.  The GEMM files use inline assembly and LDS-DMA and are out of reach.
+"""Development / test tool: every kernel file of csrc/ compiled as plain C++ against a stand-in for the pieces of the HIP programming
+model they use (tools/hostsim/include/hip/hip_runtime.h: one host thread per lane, pthread barriers for workgroup and wave; shuffles,
+DPP, ballots and the MFMA instructions as wave collectives; LDS-DMA as a wave-wide copy) into a shared library with the SAME C ABI as
+libsepkernels.so, so that the kernels' own source can be run -- slowly -- on CPU tensors through the same Python binding.
+Mechanical rewrites applied to the copies that get compiled (host_copy): `extern __shared__ T name[];` (dynamic LDS) becomes a pointer
+to a per-launch buffer; empty asm statements (compiler fences with AMDGPU register constraints) and address-space attributes go; the
+GEMM files' helpers whose body is inline assembly (LDS-DMA issue, v_max_f32 / v_max_f32_dpp / v_fma_mix_f32 one-liners) or rests on a
+wave's lock-step (the flag stores of the producer / consumer protocol) get an equivalent C++ body (_HELPERS).
 
     from hostsim import build, HostSimBackend          (tests/test_kernel_source_on_host_cpu.py)
 """
@@ -15,8 +17,52 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "dnn-based_source_separation_amd", "csrc")
-FILES = ("stream", "cln", "loss", "lstm")
+FILES = ("stream", "cln", "loss", "lstm", "gemm", "gemm_coop", "gemm_pc", "wgrad_pc")
 _DYN = re.compile(r"extern __shared__ (?:__attribute__\(\(aligned\(\d+\)\)\) )?(\w+) (\w+)\[\];")
+
+# The GEMM files: helper functions whose bodies are inline assembly (or address-space casts) get a C++ body in the compiled copies.
+_SPLIT2 = """static inline void {n}(const float x0, const float x1, unsigned& hi, unsigned& lo) {{
+    const fp16x2_t h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+    hi = __builtin_bit_cast(unsigned, h);
+    _Float16 hh[2]; memcpy(hh, &hi, 4);
+    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0 - (float)hh[0], x1 - (float)hh[1]));      // v_fma_mix_f32: exact in fp32
+}}
+"""
+_HELPERS = {
+    "gemm_common.hpp": [
+        ("glds16_asm", "static inline void glds16_asm(const float* base, unsigned voff, unsigned lds_dst) { sim_glds16((const char*)base + voff, lds_dst); }\n"),
+        ("glds16_asm_v", "static inline void glds16_asm_v(const float* gsrc, unsigned lds_dst) { sim_glds16(gsrc, lds_dst); }\n"),
+        ("lds_addr", "static inline unsigned lds_addr(const float* p) { return sim_lds_addr(p); }\n")],
+    "gemm_pc.hip": [
+        # the flag protocol between producer and consumer waves rests on the LDS executing ONE WAVE's accesses in order (every lane's panel
+        # write precedes the wave's flag store).  Lanes are threads here: the wave meets before its flag store, and the flags are atomics.
+        ("pcd_load4", "static inline pcd_i4 pcd_load4(const int* c) { pcd_i4 v; for (int i = 0; i < 4; ++i) v[i] = __atomic_load_n(c + i, __ATOMIC_ACQUIRE); return v; }\n"),
+        ("pcd_post", "static inline void pcd_post(int* c, const int value) { sim_wave_sync(); __atomic_store_n(c, value, __ATOMIC_RELEASE); }\n"),
+        ("pcd_vmax", "static inline float pcd_vmax(const float a, const float b) { return a > b ? a : b; }\n"),
+        ("pcd_max_quad_neighbour", "static inline float pcd_max_quad_neighbour(const float m) { const float o = sim_read_lane(m, (threadIdx.x & 63) ^ 1); return m > o ? m : o; }\n"),
+        ("pcd_split2_pair", _SPLIT2.format(n="pcd_split2_pair"))],
+    "gemm_coop.hip": [
+        ("co_vmax", "static inline float co_vmax(const float a, const float b) { return a > b ? a : b; }\n"),
+        ("co_quad_max", "static inline float co_quad_max(const float m) { float o = sim_read_lane(m, (threadIdx.x & 63) ^ 1); const float t = m > o ? m : o; "
+                        "o = sim_read_lane(t, (threadIdx.x & 63) ^ 2); return t > o ? t : o; }\n"),
+        ("co_split2_pair", _SPLIT2.format(n="co_split2_pair"))],
+}
+
+
+def host_copy(fname):
+    """the text of csrc/<fname> as it is compiled for the host: dynamic LDS declarations, empty asm statements (compiler fences with
+    AMDGPU register constraints), address-space attributes and the helpers of _HELPERS are rewritten; nothing else"""
+    src = open(os.path.join(CSRC, fname)).read()
+    for name, body in _HELPERS.get(fname, []):
+        m = re.search(r"^__device__ __forceinline__ [\w\s\*]*\b%s\(" % re.escape(name), src, re.M)
+        assert m, (fname, name)
+        end = src.index("\n}\n", m.start()) + 3
+        src = src[:m.start()] + body + src[end:]
+    src = _DYN.sub(r"\1* \2 = (\1*)sim_dynamic_lds();", src)
+    src = re.sub(r'asm volatile\(""[^;]*\);', ";", src)
+    src = re.sub(r"__attribute__\(\(address_space\(\d\)\)\)[ \t]*", "", src)
+    src = re.sub(r"\*\(const PCD_LDS int\*\)\((be_addr[^;]*)\);", r"*(const int*)sim_lds_ptr(\1);", src)      # an LDS BYTE ADDRESS used as a pointer
+    return src
 
 
 def compiler():
@@ -35,12 +81,16 @@ def build(workdir, sanitize=None):
     inc = os.path.join(ROOT, "tools", "hostsim", "include")
     san = ["-g", "-fsanitize=" + sanitize, "-fno-omit-frame-pointer"] if sanitize else []
     objs = []
+    open(os.path.join(workdir, "gemm_common.hpp"), "w").write(host_copy("gemm_common.hpp"))      # found before csrc/'s by the quoted includes
+    procs = []
     for f in FILES:
-        src = open(os.path.join(CSRC, f + ".hip")).read()
         cpp = os.path.join(workdir, f + ".cpp")
-        open(cpp, "w").write(_DYN.sub(r"\1* \2 = (\1*)sim_dynamic_lds();", src))
+        open(cpp, "w").write(host_copy(f + ".hip"))
         objs.append(os.path.join(workdir, f + ".o"))
-        subprocess.check_call([cxx, "-std=c++17", "-O1", "-fPIC", "-pthread"] + san + ["-I", inc, "-I", CSRC, "-c", cpp, "-o", objs[-1]])
+        procs.append(subprocess.Popen([cxx, "-std=c++17", "-O1", "-fPIC", "-pthread"] + san + ["-I", workdir, "-I", inc, "-I", CSRC, "-c", cpp, "-o", objs[-1]]))
+    for pr in procs:
+        if pr.wait() != 0:
+            raise RuntimeError("hostsim: compiling a kernel file for the host failed")
     objs.append(os.path.join(workdir, "sim_main.o"))
     subprocess.check_call([cxx, "-std=c++17", "-O1", "-fPIC", "-pthread"] + san + ["-I", inc, "-c", os.path.join(ROOT, "tools", "hostsim", "sim_main.cpp"), "-o", objs[-1]])
     so = os.path.join(workdir, "libsepkernels_hostsim.so")
@@ -100,6 +150,16 @@ with hostsim.HostSimBackend({so!r}) as K:
             t0 = time.time()
             getattr(GK, name)(*p)
             print("  {{:34s}} {{:28s}} {{:5.1f}} s".format(name, str(p), time.time() - t0), flush=True)
+    import sepkernels
+    for arith, name, args in H.GEMM_CASES:
+        t0 = time.time()
+        if arith is None:
+            getattr(GK, name)(*args)
+        else:
+            prev = sepkernels.set_gemm_arith(arith.split("-")[0]); GK.PACKED[0] = arith.endswith("packed")
+            getattr(GK, name)(*args, arith)
+            GK.PACKED[0] = False; sepkernels.set_gemm_arith(prev)
+        print("  {{:12s}} {{:34s}} {{:24s}} {{:5.1f}} s".format(str(arith), name[:34], str(args), time.time() - t0), flush=True)
 print("SANITIZED-RUN-COMPLETE")
 """
 

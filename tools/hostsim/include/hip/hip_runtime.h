@@ -26,6 +26,12 @@ struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c 
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 struct double2 { double x, y; };
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+template <typename T> static inline T min(T a, T b) { return b < a ? b : a; }
+template <typename T> static inline T max(T a, T b) { return a < b ? b : a; }
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline double2 make_double2(double x, double y) { return double2{x, y}; }
@@ -43,6 +49,7 @@ struct SimCtx {
     pthread_barrier_t block_barrier;
     std::vector<pthread_barrier_t> wave_barrier;
     std::vector<unsigned long long> slot, slot2;      // exchange slots, one (pair) per thread of the workgroup
+    std::vector<unsigned long long> wide, wide2;      // 16-byte slots (the packed MFMA operands)
 };
 extern SimCtx* g_sim;
 extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
@@ -149,6 +156,7 @@ static void sim_launch(K kernel, dim3 grid, dim3 block, size_t shmem, A... args)
     ctx.wave_barrier.resize(nw);
     for (unsigned w = 0; w < nw; ++w) pthread_barrier_init(&ctx.wave_barrier[w], nullptr, (w + 1) * 64 <= nt ? 64 : nt - w * 64);
     ctx.slot.assign(nt, 0); ctx.slot2.assign(nt, 0);
+    ctx.wide.assign(2 * nt, 0); ctx.wide2.assign(2 * nt, 0);
     g_sim = &ctx;
     std::vector<std::thread> th;
     for (unsigned t = 0; t < nt; ++t)
@@ -167,3 +175,115 @@ static void sim_launch(K kernel, dim3 grid, dim3 block, size_t shmem, A... args)
     g_sim = nullptr;
 }
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) sim_launch(kernel, dim3(grid), dim3(block), (size_t)(shmem), __VA_ARGS__)
+
+// =====================================================================================================================================
+// The GEMM files (gemm.hip, gemm_coop.hip, gemm_pc.hip, wgrad_pc.hip) use more of the machine: LDS-DMA, DPP, byte permutes, packed
+// conversions, the 32x32 MFMA shapes, hand-placed waits.  tools/hostsim.py rewrites a few helper bodies in the copies it compiles
+// (the inline-assembly ones); everything else is restated here.  LDS-DMA lands immediately (the hardware's asynchrony is not modelled:
+// waits are no-ops), LDS byte addresses are offsets from an anchor object of the library.
+#include <sched.h>
+extern char g_lds_anchor;
+static inline unsigned sim_lds_addr(const void* p) { return (unsigned)(int)((const char*)p - &g_lds_anchor); }
+static inline char* sim_lds_ptr(unsigned a) { return &g_lds_anchor + (int)a; }
+static inline void sim_glds16(const void* src_lane, unsigned lds_dst) {       // one DMA instruction of a wave: no lane is ahead of or behind it
+    sim_wave_sync();
+    memcpy(sim_lds_ptr(lds_dst) + 16 * (threadIdx.x & 63u), src_lane, 16);
+    sim_wave_sync();
+}
+
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+static inline void __builtin_amdgcn_s_barrier() { __syncthreads(); }
+static inline void __builtin_amdgcn_s_sleep(int) { sched_yield(); }
+static inline int __builtin_amdgcn_frexp_expf(float x) { int e = 0; if (x != 0.f && isfinite(x)) frexpf(x, &e); return e; }
+static inline unsigned __builtin_amdgcn_perm(unsigned s0, unsigned s1, unsigned sel) {
+    const unsigned long long src = ((unsigned long long)s0 << 32) | s1;
+    unsigned r = 0;
+    for (int i = 0; i < 4; ++i) {
+        const unsigned b = (sel >> (8 * i)) & 0xffu;
+        const unsigned byte = b <= 7 ? (unsigned)((src >> (8 * b)) & 0xffu) : (b >= 0x0du ? 0xffu : 0u);
+        r |= byte << (8 * i);
+    }
+    return r;
+}
+static inline void __builtin_amdgcn_global_load_lds(const void* g, void* lds_wave_base, int size, int, int) {
+    sim_wave_sync();
+    memcpy((char*)lds_wave_base + size * (threadIdx.x & 63u), g, size);
+    sim_wave_sync();
+}
+
+typedef __fp16 sim_fp16x2 __attribute__((ext_vector_type(2)));
+static inline uint16_t sim_f2h_rtz(float f) {                                  // float -> half bits, round toward zero
+    _Float16 h = (_Float16)f;                                                   // nearest-even first
+    const float back = (float)h;
+    uint16_t bits; memcpy(&bits, &h, 2);
+    if (f == f && fabsf(back) > fabsf(f)) bits -= 1;                            // one step back toward zero (also inf -> 65504)
+    return bits;
+}
+static inline sim_fp16x2 __builtin_amdgcn_cvt_pkrtz(float a, float b) {
+    const uint16_t h[2] = {sim_f2h_rtz(a), sim_f2h_rtz(b)};
+    sim_fp16x2 r; memcpy(&r, h, 4);
+    return r;
+}
+
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool) {
+    const int l = threadIdx.x & 63;
+    int from;
+    if (ctrl < 0x100) from = (l & ~3) + ((ctrl >> (2 * (l & 3))) & 3);           // quad_perm
+    else if (ctrl == 0x140) from = (l & ~15) + 15 - (l & 15);                    // row_mirror
+    else if (ctrl == 0x141) from = (l & ~7) + 7 - (l & 7);                       // row_half_mirror
+    else { fprintf(stderr, "hostsim: DPP control 0x%x is not modelled\n", ctrl); abort(); }
+    (void)old;
+    return sim_read_lane(src, from);
+}
+static inline unsigned long long __builtin_amdgcn_ballot_w64(bool p) {
+    const unsigned t = threadIdx.x, base = t & ~63u;
+    g_sim->slot[t] = p ? 1ull : 0ull;
+    sim_wave_sync();
+    unsigned long long m = 0;
+    for (unsigned i = 0; i < 64 && base + i < g_sim->slot.size(); ++i) m |= g_sim->slot[base + i] << i;
+    sim_wave_sync();
+    return m;
+}
+
+typedef float sim_f32x16 __attribute__((ext_vector_type(16)));
+// 32 x 32 accumulator layout: register r of lane l is D[(r % 4) + 8 (r / 4) + 4 (l / 32)][l % 32]
+static inline sim_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, sim_f32x16 c, int, int, int) {   // A[i = l % 32][k = l / 32], B[k][j = l % 32]
+    const unsigned t = threadIdx.x, base = t & ~63u, l = t & 63u;
+    memcpy(&g_sim->slot[t], &a, 4); memcpy(&g_sim->slot2[t], &b, 4);
+    sim_wave_sync();
+    sim_f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const unsigned i = (r % 4) + 8 * (r / 4) + 4 * (l / 32), j = l % 32;
+        for (unsigned k = 0; k < 2; ++k) { float av, bv; memcpy(&av, &g_sim->slot[base + i + 32 * k], 4); memcpy(&bv, &g_sim->slot2[base + j + 32 * k], 4); d[r] += av * bv; }
+    }
+    sim_wave_sync();
+    return d;
+}
+template <typename V, typename ToFloat>
+static inline sim_f32x16 sim_mfma_32x32x16(V a, V b, sim_f32x16 c, ToFloat tof) {           // lane l holds A[i = l % 32][8 (l / 32) + 0..7], B likewise
+    const unsigned t = threadIdx.x, base = t & ~63u, l = t & 63u;
+    memcpy(&g_sim->wide[2 * t], &a, 16); memcpy(&g_sim->wide2[2 * t], &b, 16);
+    sim_wave_sync();
+    sim_f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const unsigned i = (r % 4) + 8 * (r / 4) + 4 * (l / 32), j = l % 32;
+        float s = 0.f;
+        for (unsigned k = 0; k < 16; ++k) {
+            V av, bv;
+            memcpy(&av, &g_sim->wide[2 * (base + i + 32 * (k / 8))], 16); memcpy(&bv, &g_sim->wide2[2 * (base + j + 32 * (k / 8))], 16);
+            s += tof(av, k % 8) * tof(bv, k % 8);
+        }
+        d[r] += s;
+    }
+    sim_wave_sync();
+    return d;
+}
+typedef _Float16 sim_f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 sim_bf16x8;
+static inline sim_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16(sim_f16x8 a, sim_f16x8 b, sim_f32x16 c, int, int, int) {
+    return sim_mfma_32x32x16(a, b, c, [](const sim_f16x8& v, unsigned e) { return (float)v[e]; });
+}
+static inline sim_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(sim_bf16x8 a, sim_bf16x8 b, sim_f32x16 c, int, int, int) {
+    return sim_mfma_32x32x16(a, b, c, [](const sim_bf16x8& v, unsigned e) { uint16_t h; memcpy(&h, (const char*)&v + 2 * e, 2); uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; });
+}
