@@ -25,14 +25,12 @@ pytestmark = pytest.mark.skipif(hostsim.compiler() is None, reason="needs clang+
 
 CASES = [
     ("test_encoder_and_unfold", [(1, 16, 8, 0, 0), (1, 16, 8, 1, 3), (2, 20, 10, 1, 4), (1, 2, 1, 0, 0)]),
-    ("test_dwconv_fwd_bwd", [(300, 8), (1030, 64)]),
+    ("test_dwconv_fwd_bwd", [(1030, 64)]),
     ("test_depthwise_generic", [(5, 2, 4, 2, 130), (4, 4, 0, 1, 64)]),
     ("test_gln_bwd_finalize", [(2, 8), (8, 1)]),
     ("test_head_bwd", [(0,), (1,)]),
-    ("test_decoder_fwd_bwd", [(2, 1, 16, 8, 0, True), (3, 1, 16, 8, 3, False), (4, 1, 16, 8, 5, True), (2, 2, 20, 10, 4, True),
-                              (2, 1, 2, 1, 0, False), (1, 1, 64, 16, 0, False)]),
+    ("test_decoder_fwd_bwd", [(3, 1, 16, 8, 3, False), (4, 1, 16, 8, 5, True), (2, 2, 20, 10, 4, True), (2, 1, 2, 1, 0, False)]),
     ("test_softmax_over_channels", [(2, 128, 300), (3, 50, 64), (2, 7, 1)]),
-    ("test_gln_standalone_and_repack", [()]),
     ("test_cln_fwd_bwd", [(2, 24, 203), (3, 128, 3999)]),
     ("test_sisdr_kernels", [(1, 0)]),
     ("test_pit_search", [(2, 0, 1), (3, 1, 1), (4, 0, 0)]),
@@ -46,9 +44,7 @@ CASES = [
 
 # (arithmetic, test function, arguments without the trailing `arith`); "f16x3-packed" hands over weights split by sep_pack_weights
 GEMM_CASES = [
-    ("f32", "test_gemm_plain_bias", (2, 64, 128, 300)),
-    ("f16x3", "test_gemm_plain_bias", (3, 128, 64, 129)),
-    ("f16x3-packed", "test_gemm_plain_bias", (2, 64, 128, 300)),
+    ("f32", "test_gemm_plain_bias", (3, 128, 64, 129)),
     ("bf16x6", "test_gemm_plain_bias", (3, 128, 64, 129)),
     ("f16x3", "test_gemm_small_widths_of_the_dual_path_separators", (48, 48, 77)),
     ("f16x3-packed", "test_gemm_prelu_prologue_sigmoid", ()),
@@ -97,6 +93,46 @@ def test_gemm_kernel_source_on_the_host_matches_the_restatement(on_host, arith, 
     finally:
         GK.PACKED[0] = False
         sepkernels.set_gemm_arith(prev)
+
+
+def test_whole_fused_conv_tasnet_through_the_kernel_sources(on_host, golden_dir):
+    """End to end: the fused Conv-TasNet of the product (models/conv_tasnet.py -> sepkernels/net.py orchestration -> C ABI) with the
+    host simulation of the kernel sources behind the ABI, on the reference's golden vectors (BASELINE.json configs[0] family: tiny, ReLU
+    encoder, 2 speakers): forward, PIT loss, permutation and every parameter gradient.  ~30 kernel launches forward, ~60 backward --
+    encoder, packed-weight GEMMs with gLN / PReLU prologues and statistics / residual epilogues, depthwise forward / backward, gLN
+    finalisation, decoder, weight gradients, slab reduction, SI-SDR pair matrix, permutation search -- none of them emulated."""
+    import numpy as np
+    import sepkernels
+    from oracle.make_golden import CONFIGS
+    from models.conv_tasnet import ConvTasNet
+    from criterion.sdr import NegSISDR
+    from criterion.pit import PIT1d
+
+    class Named:                                   # the binding object under a name the modules do not take for the GPU build
+        name = "hostsim"
+
+        def __getattr__(self, attr):
+            return getattr(on_host, attr)
+    g = np.load(os.path.join(golden_dir, "convtasnet_tiny.npz"))
+    model = ConvTasNet(**CONFIGS["tiny"])
+    model.load_state_dict({k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param/")})
+    assert model.fused
+    old = sepkernels._set_backend_for_tests(Named())
+    try:
+        est = model(torch.from_numpy(g["mixture"]))
+        ref = torch.from_numpy(g["output_f64"])
+        assert (est.double() - ref).abs().max() <= 1e-5 * ref.abs().max()
+        loss, pattern = PIT1d(NegSISDR(), n_sources=2)(est, torch.from_numpy(g["sources"]))
+        assert abs(loss.item() - float(g["loss_f64"])) <= 1e-5 * abs(float(g["loss_f64"]))
+        assert np.array_equal(pattern.numpy(), g["pattern"])
+        loss.backward()
+    finally:
+        sepkernels._set_backend_for_tests(old)
+    worst = scale = 0.0
+    for k, p in model.named_parameters():
+        r = torch.from_numpy(g["grad/" + k]).double()
+        worst, scale = max(worst, (p.grad.double() - r).abs().max().item()), max(scale, r.abs().max().item())
+    assert worst <= 1e-4 * scale, (worst, scale)
 
 
 def test_the_comparison_is_not_vacuous(on_host):
