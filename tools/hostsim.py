@@ -62,6 +62,9 @@ def host_copy(fname):
     src = re.sub(r'asm volatile\(""[^;]*\);', ";", src)
     src = re.sub(r"__attribute__\(\(address_space\(\d\)\)\)[ \t]*", "", src)
     src = re.sub(r"\*\(const PCD_LDS int\*\)\((be_addr[^;]*)\);", r"*(const int*)sim_lds_ptr(\1);", src)      # an LDS BYTE ADDRESS used as a pointer
+    # the two lanes holding the row halves of a column store the SAME exponent word: one instruction on the device, two racing threads here
+    src = src.replace("sm.be[pb][colb + 128 * cc] = bexp[cc];", "__atomic_store_n(&sm.be[pb][colb + 128 * cc], bexp[cc], __ATOMIC_RELAXED);")
+    src = src.replace("sm.be[pb][col_s] = bexp;", "__atomic_store_n(&sm.be[pb][col_s], bexp, __ATOMIC_RELAXED);")             # gemm_coop.hip: the four lanes of a quad
     return src
 
 
