@@ -25,27 +25,38 @@ pytestmark = pytest.mark.skipif(hostsim.compiler() is None, reason="needs clang+
 
 CASES = [
     ("test_encoder_and_unfold", [(1, 16, 8, 0, 0), (1, 16, 8, 1, 3), (2, 20, 10, 1, 4), (1, 2, 1, 0, 0)]),
-    ("test_dwconv_fwd_bwd", [(1030, 64)]),
+    ("test_dwconv_fwd_bwd", [(300, 8), (1030, 64), (2100, 256)]),
     ("test_depthwise_generic", [(5, 2, 4, 2, 130), (4, 4, 0, 1, 64)]),
     ("test_gln_bwd_finalize", [(2, 8), (8, 1)]),
     ("test_head_bwd", [(0,), (1,)]),
-    ("test_decoder_fwd_bwd", [(3, 1, 16, 8, 3, False), (4, 1, 16, 8, 5, True), (2, 2, 20, 10, 4, True), (2, 1, 2, 1, 0, False)]),
+    ("test_decoder_fwd_bwd", [(2, 1, 16, 8, 0, True), (3, 1, 16, 8, 3, False), (5, 1, 16, 8, 0, False), (4, 1, 16, 8, 5, True), (2, 2, 20, 10, 4, True),
+                              (2, 1, 2, 1, 0, False), (1, 1, 64, 16, 0, False)]),
     ("test_softmax_over_channels", [(2, 128, 300), (3, 50, 64), (2, 7, 1)]),
+    ("test_gln_standalone_and_repack", [()]),
     ("test_cln_fwd_bwd", [(2, 24, 203), (3, 128, 3999)]),
-    ("test_sisdr_kernels", [(1, 0)]),
+    ("test_sisdr_kernels", [(1, 0), (2, 1), (3, 0)]),
     ("test_pit_search", [(2, 0, 1), (3, 1, 1), (4, 0, 0)]),
     ("test_sinkhorn", [(3, 10, 1.0), (5, 200, 1.0), (10, 5, 0.5)]),
     ("test_rowdiff_sums_and_bwd", [(8, 32000), (1, 5)]),
     ("test_sqnorm_and_adam", [()]),
     ("test_segment_overlap_add", [(812, 20, 10), (3999, 250, 125), (100, 16, 4), (64, 64, 64)]),
-    ("test_lstm_sweeps", [(16, 5, 7, 0), (32, 37, 5, 1)]),
+    ("test_lstm_sweeps", [(16, 5, 7, 0), (32, 37, 23, 1), (64, 16, 40, 0), (128, 50, 31, 1)]),
 ]
 
 
 # (arithmetic, test function, arguments without the trailing `arith`); "f16x3-packed" hands over weights split by sep_pack_weights
 GEMM_CASES = [
-    ("f32", "test_gemm_plain_bias", (3, 128, 64, 129)),
+    ("f32", "test_gemm_plain_bias", (2, 64, 128, 300)),
+    ("f16x3", "test_gemm_plain_bias", (3, 128, 64, 129)),
+    ("f16x3-packed", "test_gemm_plain_bias", (2, 64, 128, 300)),
     ("bf16x6", "test_gemm_plain_bias", (3, 128, 64, 129)),
+    ("f16x3-packed", "test_gemm_gln_prologue_and_stats_epilogue", ()),
+    ("f16x3-packed", "test_gemm_dgrad_two_sources_rowsums", ()),
+    ("f16x3-packed", "test_gemm_dgrad_prelu_bwd", ()),
+    ("f16x3-packed", "test_gemm_packed_heads_residual_accumulate", ()),
+    ("f32", "test_gemm_gln_bwd_prologue", (0,)),
+    ("bf16x6", "test_wgrad_two_sources_gln_prelu", ()),
+    ("f16x3", "test_wgrad_latent_product_and_prelu", ()),
     ("f16x3", "test_gemm_small_widths_of_the_dual_path_separators", (48, 48, 77)),
     ("f16x3-packed", "test_gemm_prelu_prologue_sigmoid", ()),
     ("f16x3-packed", "test_gemm_gln_bwd_prologue", (1,)),
@@ -53,6 +64,10 @@ GEMM_CASES = [
     ("bf16x6", "test_wgrad_plain", (2, 128, 256, 130, 1)),
     ("f32", "test_wgrad_plain", (2, 32, 4, 201, 2)),
     (None, "test_gemm_packed_weights_model_shapes", (128, 512, 130)),        # producer / consumer kernel, 256-column workgroup tile
+    (None, "test_gemm_packed_weights_model_shapes", (512, 128, 130)),        # cooperative kernel
+    (None, "test_gemm_packed_weights_model_shapes", (1024, 128, 130)),       # producer / consumer kernel, 4 x 1 consumer waves
+    (None, "test_gemm_packed_adversarial_operands", ("late_jump_k1024",)),
+    (None, "test_gemm_prelu_prologues_any_slope", (-0.3,)),
     (None, "test_pack_weights_reproduces_the_weights", ()),
     (None, "test_reduce_slabs_and_f64", ()),
 ]
@@ -159,7 +174,7 @@ import hostsim
 import test_gpu_kernels as GK
 with hostsim.HostSimBackend({so!r}) as K:
     GK.HIP, GK.to_device, GK.device_sync, GK.device_name = K, (lambda t: t.clone()), (lambda: None), (lambda: "cpu")
-    for case in [(16, 5, 7, 0), (32, 9, 5, 1), (128, 6, 3, 0)]:
+    for case in [(16, 5, 7, 0), (32, 37, 23, 1), (64, 16, 40, 0), (128, 50, 31, 1)]:
         GK.test_lstm_sweeps(*case)
     H, nseq, L = 32, 7, 5                                  # both directions in one launch, ragged last workgroup
     xg, w_hh = GK.rnd(2, nseq, L, 4 * H), GK.rnd(2, 4 * H, H, scale=H ** -0.5)

@@ -7,6 +7,7 @@
 #pragma once
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -44,10 +45,29 @@ static inline double2 make_double2(double x, double y) { return double2{x, y}; }
 #define __restrict__
 #define __shared__ static
 
+// A barrier for many more threads than cores: arrivals are counted, waiters yield until the generation changes (pthread barriers put every
+// waiter to sleep on a futex and wake them one by one: several times slower at 256 - 512 threads per workgroup).
+struct SimBarrier {
+    int n = 1;
+    int count = 0;
+    int generation = 0;
+    void init(int threads) { n = threads; count = 0; generation = 0; }
+    void wait() {
+        const int g = __atomic_load_n(&generation, __ATOMIC_ACQUIRE);
+        if (__atomic_add_fetch(&count, 1, __ATOMIC_ACQ_REL) == n) {
+            __atomic_store_n(&count, 0, __ATOMIC_RELAXED);
+            __atomic_store_n(&generation, g + 1, __ATOMIC_RELEASE);
+        } else {
+            int spins = 0;
+            while (__atomic_load_n(&generation, __ATOMIC_ACQUIRE) == g) { if (++spins > 64) sched_yield(); }
+        }
+    }
+};
+
 struct SimCtx {
     std::vector<unsigned long long> dynamic_lds;      // `extern __shared__ T name[]` -- tools/hostsim.py rewrites that one declaration form
-    pthread_barrier_t block_barrier;
-    std::vector<pthread_barrier_t> wave_barrier;
+    SimBarrier block_barrier;
+    std::vector<SimBarrier> wave_barrier;
     std::vector<unsigned long long> slot, slot2;      // exchange slots, one (pair) per thread of the workgroup
     std::vector<unsigned long long> wide, wide2;      // 16-byte slots (the packed MFMA operands)
 };
@@ -56,8 +76,8 @@ extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 #define warpSize 64
 static inline void* sim_dynamic_lds() { return g_sim->dynamic_lds.data(); }
 
-static inline void __syncthreads() { pthread_barrier_wait(&g_sim->block_barrier); }
-static inline void sim_wave_sync() { pthread_barrier_wait(&g_sim->wave_barrier[threadIdx.x >> 6]); }
+static inline void __syncthreads() { g_sim->block_barrier.wait(); }
+static inline void sim_wave_sync() { g_sim->wave_barrier[threadIdx.x >> 6].wait(); }
 
 template <typename T>
 static inline T sim_read_lane(T v, int src_lane) {                     // every lane of the wave publishes v, then reads lane src_lane's
@@ -152,9 +172,9 @@ static void sim_launch(K kernel, dim3 grid, dim3 block, size_t shmem, A... args)
     const unsigned nt = block.x * block.y * block.z, nw = (nt + 63) / 64;
     SimCtx ctx;
     ctx.dynamic_lds.assign(shmem / 8 + 2, 0);
-    pthread_barrier_init(&ctx.block_barrier, nullptr, nt);
+    ctx.block_barrier.init(nt);
     ctx.wave_barrier.resize(nw);
-    for (unsigned w = 0; w < nw; ++w) pthread_barrier_init(&ctx.wave_barrier[w], nullptr, (w + 1) * 64 <= nt ? 64 : nt - w * 64);
+    for (unsigned w = 0; w < nw; ++w) ctx.wave_barrier[w].init((w + 1) * 64 <= nt ? 64 : nt - w * 64);
     ctx.slot.assign(nt, 0); ctx.slot2.assign(nt, 0);
     ctx.wide.assign(2 * nt, 0); ctx.wide2.assign(2 * nt, 0);
     g_sim = &ctx;
@@ -168,7 +188,7 @@ static void sim_launch(K kernel, dim3 grid, dim3 block, size_t shmem, A... args)
                     for (unsigned bx = 0; bx < grid.x; ++bx) {
                         blockIdx = dim3(bx, by, bz);
                         kernel(args...);
-                        pthread_barrier_wait(&g_sim->block_barrier);        // the workgroup's statics (its LDS) are free for the next one
+                        g_sim->block_barrier.wait();        // the workgroup's statics (its LDS) are free for the next one
                     }
         });
     for (auto& x : th) x.join();
