@@ -954,21 +954,26 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(const sep_wgrad_desc d
         c = cn;
     }
 
-    float* out = d.partial + (size_t)s * d.M * d.N;
+    auto put_tile = [&](auto atomic_c) {                // accumulate: onto slab 0 with atomics; else a plain store into slab s
+        constexpr bool AT = decltype(atomic_c)::value;
+        float* out = d.partial + (AT ? 0 : (size_t)s * d.M * d.N);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            if (row < d.M) {
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (row < d.M) {
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const int col = n0 + wc * 64 + ni * 32 + l31;
-                    if (col < d.N) out[(size_t)row * d.N + col] = acc[mi][ni][r];
+                    for (int ni = 0; ni < 2; ++ni) {
+                        const int col = n0 + wc * 64 + ni * 32 + l31;
+                        if (col < d.N) wg_put<AT>(out + (size_t)row * d.N + col, acc[mi][ni][r]);
+                    }
                 }
             }
-        }
-    if (do_bias && tid < BM && (m0 + tid) < d.M) d.partial_bias[(size_t)s * d.M + m0 + tid] = bias_acc;
+        if (do_bias && tid < BM && (m0 + tid) < d.M) wg_put<AT>(d.partial_bias + (AT ? 0 : (size_t)s * d.M) + m0 + tid, bias_acc);
+    };
+    if (d.accumulate) put_tile(std::true_type{});
+    else put_tile(std::false_type{});
 }
 
 
@@ -1211,23 +1216,28 @@ __global__ __launch_bounds__(512, 4) void pw_wgrad_direct_kernel(const sep_wgrad
     WPROF(5);
     auto finish = [&](f32x16 (&keep)[2], const float bias_keep, const float* bias_slot, const int mi) {
         const float* theirs = red + (1 - grp) * 8192;
-        float* out = d.partial + (size_t)s * d.M * d.N;
+        auto put_tile = [&](auto atomic_c) {
+            constexpr bool AT = decltype(atomic_c)::value;
+            float* out = d.partial + (AT ? 0 : (size_t)s * d.M * d.N);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int col = n0 + wc * 64 + ni * 32 + l31;
-                const float v = keep[ni][r] + theirs[(ni * 16 + r) * 256 + tg];
-                if (row < d.M && col < d.N) out[(size_t)row * d.N + col] = v;
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int col = n0 + wc * 64 + ni * 32 + l31;
+                    const float v = keep[ni][r] + theirs[(ni * 16 + r) * 256 + tg];
+                    if (row < d.M && col < d.N) wg_put<AT>(out + (size_t)row * d.N + col, v);
+                }
             }
-        }
-        if (do_bias) {
-            const float mine_b = bias_keep + bias_slot[tg];
-            const float tot = mine_b + __shfl_xor(mine_b, 32, 64);     // the two lane halves own different frames
-            const int row = m0 + wr * 64 + mi * 32 + l31;
-            if (lk == 0 && row < d.M) d.partial_bias[(size_t)s * d.M + row] = tot;
-        }
+            if (do_bias) {
+                const float mine_b = bias_keep + bias_slot[tg];
+                const float tot = mine_b + __shfl_xor(mine_b, 32, 64);     // the two lane halves own different frames
+                const int row = m0 + wr * 64 + mi * 32 + l31;
+                if (lk == 0 && row < d.M) wg_put<AT>(d.partial_bias + (AT ? 0 : (size_t)s * d.M) + row, tot);
+            }
+        };
+        if (d.accumulate) put_tile(std::true_type{});
+        else put_tile(std::false_type{});
     };
     if (grp == 0) finish(acc[0], bias_acc[0], sm.rstd, 0);
     else finish(acc[1], bias_acc[1], sm.mu, 1);
@@ -1457,26 +1467,31 @@ __global__ __launch_bounds__(256, 3) void pw_wgrad_split_kernel(const sep_wgrad_
     asm volatile("" : "+v"(etid), "+s"(es), "+s"(em0), "+s"(en0));
     const int ewid = __builtin_amdgcn_readfirstlane(etid >> 6);
     const int ewr = ewid >> 1, ewc = ewid & 1, elk = (etid >> 5) & 1, el31 = etid & 31;
-    float* out = d.partial + (size_t)es * d.M * d.N;
+    auto put_tile = [&](auto atomic_c) {
+        constexpr bool AT = decltype(atomic_c)::value;
+        float* out = d.partial + (AT ? 0 : (size_t)es * d.M * d.N);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = em0 + ewr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * elk;
+            for (int r = 0; r < 16; ++r) {
+                const int row = em0 + ewr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * elk;
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int col = en0 + ewc * 64 + ni * 32 + el31;
-                if (row < d.M && col < d.N) out[(size_t)row * d.N + col] = acc[mi][ni][r];
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int col = en0 + ewc * 64 + ni * 32 + el31;
+                    if (row < d.M && col < d.N) wg_put<AT>(out + (size_t)row * d.N + col, acc[mi][ni][r]);
+                }
+            }
+        if (do_bias) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const float tot = bias_acc[mi] + __shfl_xor(bias_acc[mi], 32, 64);     // the two lane halves own different frames
+                const int row = em0 + ewr * 64 + mi * 32 + el31;
+                if (elk == 0 && row < d.M) wg_put<AT>(d.partial_bias + (AT ? 0 : (size_t)es * d.M) + row, tot);
             }
         }
-    if (do_bias) {
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const float tot = bias_acc[mi] + __shfl_xor(bias_acc[mi], 32, 64);     // the two lane halves own different frames
-            const int row = em0 + ewr * 64 + mi * 32 + el31;
-            if (elk == 0 && row < d.M) d.partial_bias[(size_t)es * d.M + row] = tot;
-        }
-    }
+    };
+    if (d.accumulate) put_tile(std::true_type{});
+    else put_tile(std::false_type{});
 }
 
 // ======================================================================================
@@ -1632,6 +1647,7 @@ extern "C" int sep_pw_wgrad(const sep_wgrad_desc* d, sep_stream_t stream) {
     SEP_REQUIRE(d->nsplit > 0 && (long)d->nsplit <= (long)d->B * (d->ldt / WK), "sep_pw_wgrad: bad nsplit=%d", d->nsplit);
     SEP_REQUIRE(d->g_split % BM == 0 && d->g_split < d->M, "sep_pw_wgrad: bad g_split=%d", d->g_split);
     SEP_REQUIRE(d->G && d->X && d->partial, "sep_pw_wgrad: null operand");
+    SEP_REQUIRE(d->accumulate == 0 || d->accumulate == 1, "sep_pw_wgrad: accumulate must be 0 or 1 (got %d)", d->accumulate);
     SEP_REQUIRE(!d->g_split || d->G2, "sep_pw_wgrad: g_split without G2");
     SEP_REQUIRE(!d->g_mul || (d->Gaux && d->g_div > 0 && !d->g_split), "sep_pw_wgrad: g_mul needs Gaux/g_div");
     SEP_REQUIRE(d->x_div > 0, "sep_pw_wgrad: x_div must be >= 1");

@@ -353,7 +353,10 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc_kernel(const sep_wgrad_des
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
                 const float tot = bias_acc[mi] + __shfl_xor(bias_acc[mi], 32, 64);     // the two lane halves own different frames
-                if (lk == 0) d.partial_bias[(size_t)s * d.M + m0 + 64 * wr + 32 * mi + l31] = tot;
+                if (lk == 0) {
+                    if (d.accumulate) wg_put<true>(d.partial_bias + m0 + 64 * wr + 32 * mi + l31, tot);
+                    else wg_put<false>(d.partial_bias + (size_t)s * d.M + m0 + 64 * wr + 32 * mi + l31, tot);
+                }
             }
         }
     }
@@ -363,20 +366,25 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc_kernel(const sep_wgrad_des
         asm volatile("" : "+v"(etid), "+s"(es), "+s"(em0), "+s"(en0));
         const int ewid = __builtin_amdgcn_readfirstlane(etid >> 6);
         const int ewr = ewid / WC, ewc = ewid % WC, elk = (etid >> 5) & 1, el31 = etid & 31;
-        float* out = d.partial + (size_t)es * d.M * d.N;
+        auto put_tile = [&](auto atomic_c) {                // accumulate: onto slab 0 with atomics; else a plain store into slab s
+            constexpr bool AT = decltype(atomic_c)::value;
+            float* out = d.partial + (AT ? 0 : (size_t)es * d.M * d.N);
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = em0 + ewr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * elk;
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = em0 + ewr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * elk;
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        const int col = en0 + ewc * 128 + h * 64 + n * 32 + el31;
-                        out[(size_t)row * d.N + col] = nk > 0 ? acc[h][mi][n][r] : 0.f;
+                        for (int n = 0; n < 2; ++n) {
+                            const int col = en0 + ewc * 128 + h * 64 + n * 32 + el31;
+                            wg_put<AT>(out + (size_t)row * d.N + col, nk > 0 ? acc[h][mi][n][r] : 0.f);
+                        }
                     }
-                }
+        };
+        if (!d.accumulate) put_tile(std::false_type{});
+        else if (nk > 0) put_tile(std::true_type{});            // an empty slab has nothing to add
     }
 }
 

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("SEPKERNELS_LIB", os.path.normpath(os.path.join(_HERE,
 # ---- constants mirrored from include/sepkernels.h -------------------------------------------------
 PRO_NONE, PRO_PRELU, PRO_GLN, PRO_GLN_PRELU, PRO_GLN_BWD = 0, 1, 2, 3, 4
 EPI_STATS_PRELU, EPI_RESIDUAL, EPI_SIGMOID, EPI_PRELU_BWD, EPI_ROWSUMS, EPI_ROWSUMS_PRELU = 1, 2, 4, 8, 16, 32
-ABI_VERSION = 10
+ABI_VERSION = 11
 STATS_SLOTS = 16   # SEP_STATS_SLOTS: gLN statistics are double[B][STATS_SLOTS][2]
 ARITH_F32, ARITH_BF16X6, ARITH_F16X3 = 0, 1, 2     # SEP_ARITH_*: how sep_pw_gemm forms its fp32 products (include/sepkernels.h)
 _ARITH_NAMES = {"f32": ARITH_F32, "bf16x6": ARITH_BF16X6, "f16x3": ARITH_F16X3}
@@ -75,7 +75,7 @@ class GemmDesc(ctypes.Structure):
 
 
 class WgradDesc(ctypes.Structure):
-    _fields_ = [(n, _i32) for n in ("B", "M", "N", "T", "ldt", "g_split", "g_mul", "g_div", "x_mode", "x_div", "nsplit", "arith")] + \
+    _fields_ = [(n, _i32) for n in ("B", "M", "N", "T", "ldt", "g_split", "g_mul", "g_div", "x_mode", "x_div", "nsplit", "arith", "accumulate")] + \
                [("eps", ctypes.c_float), ("count", ctypes.c_double)] + \
                [(n, _vp) for n in ("G", "G2", "Gaux", "X", "x_alpha", "x_stats", "x_gamma", "x_beta", "partial", "partial_bias")]
 
@@ -257,8 +257,8 @@ class HipBackend:
 
     def pw_wgrad(self, *, B, M, N, T, ldt, G, X, partial, nsplit, G2=None, g_split=0, Gaux=None, g_mul=0, g_div=1,
                  x_mode=PRO_NONE, x_div=1, eps=1e-12, count=0.0, x_alpha=None, x_stats=None, x_gamma=None, x_beta=None,
-                 partial_bias=None, arith=None):
-        d = WgradDesc(B=B, M=M, N=N, T=T, ldt=ldt, g_split=g_split, g_mul=g_mul, g_div=g_div, x_mode=x_mode, x_div=x_div,
+                 partial_bias=None, arith=None, accumulate=0):
+        d = WgradDesc(B=B, M=M, N=N, T=T, ldt=ldt, g_split=g_split, g_mul=g_mul, g_div=g_div, x_mode=x_mode, x_div=x_div, accumulate=int(accumulate),
                       nsplit=nsplit, arith=gemm_arith() if arith is None else arith, eps=eps, count=float(count), G=_ptr(G, _f32), G2=_ptr(G2, _f32), Gaux=_ptr(Gaux, _f32),
                       X=_ptr(X, _f32), x_alpha=_ptr(x_alpha, _f32), x_stats=_ptr(x_stats, _f64), x_gamma=_ptr(x_gamma, _f32),
                       x_beta=_ptr(x_beta, _f32), partial=_ptr(partial, _f32), partial_bias=_ptr(partial_bias, _f32))

@@ -198,10 +198,23 @@ def tail_forward(cfg, P, geo, w, core, mixture_shape, want_latent, PK=None):
     return est, latent, m
 
 
+WGRAD_ATOMIC = os.environ.get("SEPK_WGRAD_ATOMIC", "0") == "1"     # experiment switch, see _wgrad
+
+
 def _wgrad(K, B, F, ldt, eps, f32, M, Nn, Gt, Xt, want_bias, Bq=None, weps=None, **kw):
+    """One weight-gradient product -> (partial slabs, partial bias slabs, number of slabs the caller reduces).
+    Default: `ns` slabs, summed afterwards by sep_reduce_slabs in a fixed order.  SEPK_WGRAD_ATOMIC=1 (off by default: not yet timed
+    on the device, and the order of the additions varies from run to run): the workgroups of all slabs add onto ONE zeroed slab
+    (sep_wgrad_desc.accumulate), so the slabs are neither written nor re-read -- 3.4 GB of the step's 73."""
     Bq = B if Bq is None else Bq
     ch = Bq * (ldt // 32)
     ns = _nsplit(M, Nn, ch)
+    if WGRAD_ATOMIC:
+        part = torch.zeros(1, M, Nn, **f32)
+        pb = torch.zeros(1, M, **f32) if want_bias else None
+        K.pw_wgrad(B=Bq, M=M, N=Nn, T=F, ldt=ldt, G=Gt, X=Xt, partial=part, partial_bias=pb, nsplit=ns, accumulate=1,
+                   eps=(eps if weps is None else weps), **kw)
+        return part, pb, 1
     part = torch.empty(ns, M, Nn, **f32)
     pb = torch.empty(ns, M, **f32) if want_bias else None
     K.pw_wgrad(B=Bq, M=M, N=Nn, T=F, ldt=ldt, G=Gt, X=Xt, partial=part, partial_bias=pb, nsplit=ns,

@@ -33,7 +33,7 @@ extern "C" {
 
 typedef void* sep_stream_t; /* hipStream_t */
 
-#define SEP_ABI_VERSION 10
+#define SEP_ABI_VERSION 11
 #define SEP_STATS_SLOTS 16
 
 int sep_version(void);
@@ -152,6 +152,9 @@ typedef struct sep_wgrad_desc {
     int32_t x_div;  /* X (and its gLN stats) are indexed with b / x_div */
     int32_t nsplit; /* number of partial slabs, <= B*ldt/32 */
     int32_t arith;  /* SEP_ARITH_* */
+    int32_t accumulate; /* 0: slab s is written to partial[s] (deterministic second stage: sep_reduce_slabs over nsplit slabs);
+                         * 1: every slab is ADDED onto partial[0] / partial_bias[0] with fp32 atomics -- the caller zeroes slab 0 and
+                         *    reduces ONE slab; nsplit still partitions the frames; the order of the additions is not fixed */
     float eps;
     double count;
     const float* G;

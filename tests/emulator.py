@@ -138,7 +138,7 @@ class EmuBackend:
 
     def pw_wgrad(self, *, B, M, N, T, ldt, G, X, partial, nsplit, G2=None, g_split=0, Gaux=None, g_mul=0, g_div=1,
                  x_mode=PRO_NONE, x_div=1, eps=1e-12, count=0.0, x_alpha=None, x_stats=None, x_gamma=None, x_beta=None,
-                 partial_bias=None, arith=None):
+                 partial_bias=None, arith=None, accumulate=0):
         dt = G.dtype
         m1 = g_split if g_split else M
         Gf = G.reshape(B, m1, ldt)
@@ -157,6 +157,11 @@ class EmuBackend:
             Xp = u * sc + (x_beta.view(1, N, 1) - mu * sc)
         else:
             Xp = Xf
+        if accumulate:                      # every slab is added onto slab 0, which the caller zeroed (or pre-loaded): only slab 0 exists
+            partial.reshape(-1)[:M * N].reshape(M, N).add_(torch.einsum("bmt,bnt->mn", Gf, Xp))
+            if partial_bias is not None:
+                partial_bias.reshape(-1)[:M].add_(Gf.sum((0, 2)))
+            return
         partial.zero_()
         partial.reshape(nsplit, M, N)[0] = torch.einsum("bmt,bnt->mn", Gf, Xp)
         if partial_bias is not None:

@@ -434,6 +434,24 @@ def test_wgrad_plain(B, M, N, T, ns, arith):
     _wgrad_both(dict(B=B, M=M, N=N, T=T, ldt=ldt, G=padded(B, M, T, ldt), X=padded(B, N, T, ldt), partial=part, partial_bias=pb, nsplit=ns))
 
 
+@pytest.mark.parametrize("B,M,N,T,ns", [(2, 256, 128, 999, 7), (1, 128, 16, 300, 3), (2, 512, 128, 700, 12), (2, 32, 4, 201, 2)])
+def test_wgrad_accumulated_onto_one_slab(B, M, N, T, ns, arith):
+    """sep_wgrad_desc.accumulate: the workgroups of all `ns` slabs ADD their tiles (and bias sums) onto slab 0 with fp32 atomics instead of
+    writing `ns` slabs -- here onto a slab that already holds values, so that a plain store would be caught.  Every kernel behind
+    sep_pw_wgrad: the producer / consumer one, the per-wave split and fp32 ones, the register-staged fallback (N = 4)."""
+    ldt = (T + 127) // 128 * 128
+    G_, X_ = padded(B, M, T, ldt), padded(B, N, T, ldt)
+    base, base_b = rnd(1, M, N), rnd(1, M)
+    part_c, pb_c, part_g, pb_g = base.clone(), base_b.clone(), to_device(base), to_device(base_b)
+    kw = dict(B=B, M=M, N=N, T=T, ldt=ldt, nsplit=ns, accumulate=1)
+    EMU.pw_wgrad(G=G_, X=X_, partial=part_c, partial_bias=pb_c, **kw)
+    HIP.pw_wgrad(G=to_device(G_), X=to_device(X_), partial=part_g, partial_bias=pb_g, **kw)
+    device_sync()
+    scale = (part_c - base).abs().max().item()
+    assert (part_g.cpu() - part_c).abs().max().item() <= 2e-4 * scale
+    assert (pb_g.cpu() - pb_c).abs().max().item() <= 2e-4 * (pb_c - base_b).abs().max().item()
+
+
 def test_wgrad_two_sources_gln_prelu(arith):
     B, Bn, Sc, H, T, ns = 2, 128, 64, 256, 640, 5
     ldt = 640

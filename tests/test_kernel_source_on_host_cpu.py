@@ -63,6 +63,10 @@ GEMM_CASES = [
     ("f16x3", "test_wgrad_plain", (2, 256, 128, 300, 3)),
     ("bf16x6", "test_wgrad_plain", (2, 128, 256, 130, 1)),
     ("f32", "test_wgrad_plain", (2, 32, 4, 201, 2)),
+    ("f16x3", "test_wgrad_accumulated_onto_one_slab", (2, 256, 128, 300, 7)),      # producer / consumer kernel
+    ("bf16x6", "test_wgrad_accumulated_onto_one_slab", (1, 128, 16, 300, 3)),      # per-wave split kernel
+    ("f32", "test_wgrad_accumulated_onto_one_slab", (2, 128, 64, 200, 5)),         # fp32 direct kernel
+    ("f32", "test_wgrad_accumulated_onto_one_slab", (2, 32, 4, 201, 2)),           # small widths
     (None, "test_gemm_packed_weights_model_shapes", (128, 512, 130)),        # producer / consumer kernel, 256-column workgroup tile
     (None, "test_gemm_packed_weights_model_shapes", (512, 128, 130)),        # cooperative kernel
     (None, "test_gemm_packed_weights_model_shapes", (1024, 128, 130)),       # producer / consumer kernel, 4 x 1 consumer waves
@@ -110,8 +114,8 @@ def test_gemm_kernel_source_on_the_host_matches_the_restatement(on_host, arith, 
         sepkernels.set_gemm_arith(prev)
 
 
-@pytest.mark.parametrize("config", ["tiny", "softmax"])
-def test_whole_fused_conv_tasnet_through_the_kernel_sources(on_host, golden_dir, config):
+@pytest.mark.parametrize("config,atomic_slabs", [("tiny", False), ("softmax", False), ("tiny", True)])
+def test_whole_fused_conv_tasnet_through_the_kernel_sources(on_host, golden_dir, monkeypatch, config, atomic_slabs):
     """End to end: the fused Conv-TasNet of the product (models/conv_tasnet.py -> sepkernels/net.py orchestration -> C ABI) with the
     host simulation of the kernel sources behind the ABI, on the reference's golden vectors (BASELINE.json configs[0] family: tiny, ReLU
     encoder, 2 speakers; and the same with the channel-softmax mask): forward, PIT loss, permutation and every parameter gradient.
@@ -124,6 +128,8 @@ def test_whole_fused_conv_tasnet_through_the_kernel_sources(on_host, golden_dir,
     from models.conv_tasnet import ConvTasNet
     from criterion.sdr import NegSISDR
     from criterion.pit import PIT1d
+    from sepkernels import net
+    monkeypatch.setattr(net, "WGRAD_ATOMIC", atomic_slabs)      # True: weight gradients accumulated onto one slab (SEPK_WGRAD_ATOMIC=1)
 
     class Named:                                   # the binding object under a name the modules do not take for the GPU build
         name = "hostsim"

@@ -122,6 +122,7 @@ static inline double atomicAdd(double* p, double v) {
     memcpy(&f, &old, 8);
     return f;
 }
+static inline float unsafeAtomicAdd(float* p, float v) { return atomicAdd(p, v); }          // the hardware fp32 atomic of the device build
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
