@@ -167,6 +167,43 @@ print("SANITIZED-RUN-COMPLETE")
 """
 
 
+def run_case(argv):
+    """python tools/hostsim.py --run <test function of tests/test_gpu_kernels.py> [its arguments ...] [--arith f32|f16x3|f16x3-packed|bf16x6]
+    e.g.  --run test_gemm_packed_weights_model_shapes 128 512 130      --run test_wgrad_plain 2 256 128 300 3 --arith f16x3
+    One kernel case on the host simulation of the CURRENT sources (rebuilt on every call, ~20 s): the pre-check of a kernel edit."""
+    import ast
+    import sys
+    import tempfile
+    import time
+    for p in (os.path.join(ROOT, "tests"), os.path.join(ROOT, "dnn-based_source_separation_amd", "src"), ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    arith = None
+    if "--arith" in argv:
+        i = argv.index("--arith")
+        arith, argv = argv[i + 1], argv[:i] + argv[i + 2:]
+    name, args = argv[0], []
+    for a in argv[1:]:
+        try:
+            args.append(ast.literal_eval(a))
+        except (ValueError, SyntaxError):
+            args.append(a)
+    import sepkernels
+    import test_gpu_kernels as GK
+    with tempfile.TemporaryDirectory() as d:
+        so = build(d)
+        with HostSimBackend(so) as K:
+            GK.HIP, GK.to_device, GK.device_sync, GK.device_name = K, (lambda t: t.clone()), (lambda: None), (lambda: "cpu")
+            if arith:
+                sepkernels.set_gemm_arith(arith.split("-")[0])
+                GK.PACKED[0] = arith.endswith("packed")
+                args.append(arith)
+            t0 = time.time()
+            getattr(GK, name)(*args)
+            print("{}{} on the host simulation: ok, {:.1f} s".format(name, tuple(args), time.time() - t0))
+    return 0
+
+
 def main():
     """python tools/hostsim.py --asan | --tsan : the kernel cases of the CPU tier once more, with the kernel sources compiled under a
     sanitizer.  --asan: out-of-bounds reads / writes of global buffers (torch's allocations go through the intercepted allocator) and of
@@ -175,9 +212,12 @@ def main():
     every lane is a thread of its own, only barriers and the wave collectives order them)."""
     import sys
     import tempfile
+    if "--run" in sys.argv:
+        return run_case(sys.argv[sys.argv.index("--run") + 1:])
     kind = "asan" if "--asan" in sys.argv else "tsan" if "--tsan" in sys.argv else None
     if kind is None:
         print(main.__doc__)
+        print(run_case.__doc__)
         return 0
     rt = sanitizer_runtime(kind)
     if rt is None:
