@@ -158,6 +158,17 @@ def test_whole_fused_conv_tasnet_through_the_kernel_sources(on_host, golden_dir,
     assert worst <= 1e-4 * scale, (worst, scale)
 
 
+def test_random_small_shapes_through_the_kernel_sources(on_host):
+    """tools/hostsim_fuzz.py with a fixed seed: ragged frame counts and widths off every tile size through GEMMs (four arithmetics incl.
+    packed weights, transposed / bias / PReLU prologue / sigmoid epilogue), weight gradients (slabs and one-slab accumulation), encoder /
+    decoder forward / backward at random hop geometries, gLN / cLN, chunking, LSTM sweeps.  (Thousands of such cases were run while this
+    was written -- 0 failures; the tool takes a duration and a seed.)"""
+    import hostsim_fuzz
+    n, failures = hostsim_fuzz.run_cases(seed=7, max_cases=120)
+    assert not failures, failures[:3]
+    assert n == 120
+
+
 def test_the_comparison_is_not_vacuous(on_host):
     """the same harness fails when the device side computes something else (here: a gain 1 % off)"""
     class Skewed:

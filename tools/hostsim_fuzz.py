@@ -1,0 +1,173 @@
+"""Development tool: random small shapes through the kernel sources on the host simulation (tools/hostsim.py), against the restatement of
+tests/emulator.py -- ragged frame counts, widths off every tile size, each arithmetic.  The fixed cases of tests/test_gpu_kernels.py
+cover the shapes the models use; this looks for the ones nobody thought of.  A failure here is a failure on the device too (same source).
+
+    python tools/hostsim_fuzz.py [seconds] [seed]
+"""
+import os
+import random
+import sys
+import tempfile
+import time
+import traceback
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "tools"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "dnn-based_source_separation_amd", "src"), ROOT]
+import hostsim                      # noqa: E402
+import sepkernels                   # noqa: E402
+import test_gpu_kernels as GK       # noqa: E402
+from sepkernels import PRO_PRELU, EPI_SIGMOID      # noqa: E402
+
+
+def up(a, b):
+    return (a + b - 1) // b * b
+
+
+def case_gemm(R):
+    arith = R.choice(["f32", "f16x3", "bf16x6", "f16x3-packed"])
+    B, T = R.randint(1, 3), R.randint(1, 300)
+    M, K = 4 * R.randint(1, 70), 16 * R.randint(1, 9)
+    if arith.endswith("packed"):                       # weights split beforehand by sep_pack_weights: 32-row blocks; long contractions and
+        M = 32 * R.randint(1, 10)                      # tall outputs reach the producer / consumer kernel
+        K = R.choice([16, 64, 128, 256, 512, 640])
+    trans = R.random() < 0.4
+    ldt = up(T, 128)
+    X = GK.padded(B, K, T, ldt)
+    A = GK.rnd(K, M, scale=K ** -0.5) if trans else GK.rnd(M, K, scale=K ** -0.5)
+    kw = dict(B=B, M=M, K=K, T=T, ldt=ldt, A=A, X=X, Y=GK.nan(B, M, ldt), trans_a=int(trans))
+    if R.random() < 0.6:
+        kw["bias"] = GK.rnd(M)
+    if R.random() < 0.3:
+        kw.update(pro_mode=PRO_PRELU, pro_alpha=torch.tensor([R.uniform(-0.5, 1.5)]))
+    if R.random() < 0.2 and not trans:
+        kw["epi_flags"] = EPI_SIGMOID
+    prev = sepkernels.set_gemm_arith(arith.split("-")[0])
+    GK.PACKED[0] = arith.endswith("packed")
+    try:
+        GK.both("pw_gemm", [], kw)
+    finally:
+        GK.PACKED[0] = False
+        sepkernels.set_gemm_arith(prev)
+    return "pw_gemm {} B={} M={} K={} T={} trans={} {}".format(arith, B, M, K, T, trans, sorted(k for k in kw if k in ("bias", "pro_mode", "epi_flags")))
+
+
+def case_wgrad(R):
+    arith = R.choice(["f32", "f16x3", "bf16x6"])
+    B, T = R.randint(1, 3), R.randint(1, 300)
+    M, N = R.choice([4, 16, 24, 32, 64, 96, 128, 160, 256]), R.choice([2, 4, 16, 20, 32, 64, 128, 256])
+    ldt = up(T, 128)
+    ns = R.randint(1, min(12, B * (ldt // 32)))
+    acc = R.random() < 0.4
+    part, pb = (GK.rnd(1, M, N), GK.rnd(1, M)) if acc else (GK.nan(ns, M, N), GK.nan(ns, M))
+    prev = sepkernels.set_gemm_arith(arith)
+    try:
+        kw = dict(B=B, M=M, N=N, T=T, ldt=ldt, G=GK.padded(B, M, T, ldt), X=GK.padded(B, N, T, ldt), partial=part, partial_bias=pb, nsplit=ns, accumulate=int(acc))
+        if acc:
+            GK.both("pw_wgrad", [], kw)
+        else:
+            GK._wgrad_both(kw)
+    finally:
+        sepkernels.set_gemm_arith(prev)
+    return "pw_wgrad {} B={} M={} N={} T={} ns={} accumulate={}".format(arith, B, M, N, T, ns, acc)
+
+
+def case_codec(R):
+    B, Cin = R.randint(1, 2), R.randint(1, 2)
+    S = R.choice([1, 2, 4, 8, 10])
+    L = S * R.choice([1, 2, 4])
+    N = R.choice([4, 16, 24, 32, 64])
+    Tin = R.randint(L, L + 1500)                        # the TasNet forwards' geometry (conv_tasnet.py:145-149): pad to a whole number of hops
+    padding = (S - (Tin - L) % S) % S
+    pad_left = padding // 2
+    F = (Tin + padding - L) // S + 1
+    ldt = up(F, 128)
+    relu = R.randint(0, 1)
+    x, E = GK.rnd(B, Cin, Tin), GK.rnd(N, Cin, L)
+    GK.both("encoder_fwd", [x, E, GK.nan(B, N, ldt), GK.zstats(B), B, Cin, Tin, N, L, S, F, ldt, pad_left, relu])
+    n_src = R.randint(1, 4)
+    w, m, D = GK.padded(B, N, F, ldt), GK.padded(B, n_src * N, F, ldt), GK.rnd(N, Cin, L)
+    Tout = Tin
+    GK.both("decoder_fwd", [w, m, D, GK.nan(B, n_src, Cin, Tout), None, B, n_src, N, Cin, L, S, F, ldt, Tout, pad_left])
+    GK.both("decoder_bwd", [GK.rnd(B, n_src, Cin, Tout), w, m, D, GK.nan(B, n_src * N, ldt), GK.nan(B, N, ldt), B, n_src, N, Cin, L, S, F, ldt, Tout, pad_left],
+            dict(raw_mask=R.randint(0, 1)))
+    return "codec B={} Cin={} N={} L={} S={} F={} Tin={} pad_left={} n_src={}".format(B, Cin, N, L, S, F, Tin, pad_left, n_src)
+
+
+def case_norms(R):
+    B, C, T = R.randint(1, 3), R.choice([1, 3, 8, 20, 64]), R.randint(1, 700)
+    ldt = up(T, 4)
+    x = GK.padded(B, C, T, ldt)
+    st = GK.zstats(B)
+    GK.both("gln_stats", [x, st, B, C, T, ldt])
+    GK.both("gln_apply", [x, GK.stats_of(x, T), GK.rnd(C) + 1, GK.rnd(C), GK.nan(B, C, ldt), B, C, T, ldt, C * float(T), 1e-12])
+    if C >= 3:          # (one channel: the first frame has zero variance and 1 / (sigma + eps) = 1e12 either way -- nothing to compare)
+        xs = x * 2 + 0.1 * (x != 0)
+        ye, me, re_ = GK.nan(B, C, ldt), torch.empty(B, T), torch.empty(B, T)
+        ys, ms, rs = GK.nan(B, C, ldt), torch.empty(B, T), torch.empty(B, T)
+        gamma, beta = GK.rnd(C) + 1, GK.rnd(C)
+        GK.EMU.cln_fwd(xs, gamma, beta, ye, me, re_, torch.empty(B, 2, T, dtype=torch.float64), B, C, T, ldt, 1e-12)
+        GK.HIP.cln_fwd(xs.clone(), gamma.clone(), beta.clone(), ys, ms, rs, torch.empty(B, 2, T, dtype=torch.float64), B, C, T, ldt, 1e-12)   # the workspace is scratch
+        assert torch.isfinite(ys).all() and (ys - ye).abs().max() <= 5e-4 * ye.abs().max() and (ms - me).abs().max() <= 1e-5 * (1 + me.abs().max())
+    return "norms B={} C={} T={}".format(B, C, T)
+
+
+def case_chunks(R):
+    B, C = R.randint(1, 2), R.randint(1, 5)
+    hop = R.randint(1, 40)
+    chunk = hop * R.randint(1, 3) if R.random() < 0.7 else R.randint(hop, 3 * hop)
+    T = R.randint(1, 500)
+    from sepkernels.functional import segment_geometry
+    pad_left, _, S = segment_geometry(T, chunk, hop)
+    if S < 1:
+        return "chunks skipped"
+    ldt = up(T, 4)
+    x = GK.padded(B, C, T, ldt)
+    GK.both("segment", [x, GK.nan(B, C, S, chunk), B * C, T, ldt, S, chunk, hop, pad_left], tol=0.0)
+    GK.both("overlap_add", [GK.rnd(B, C, S, chunk), GK.nan(B, C, ldt), B * C, T, ldt, S, chunk, hop, pad_left], tol=1e-6)
+    return "chunks B={} C={} T={} chunk={} hop={} S={}".format(B, C, T, chunk, hop, S)
+
+
+def case_lstm(R):
+    H, nseq, L, rev = R.choice([16, 32]), R.randint(1, 40), R.randint(1, 12), R.randint(0, 1)
+    GK.test_lstm_sweeps(H, nseq, L, rev)
+    return "lstm H={} nseq={} L={} reverse={}".format(H, nseq, L, rev)
+
+
+CASES = [case_gemm, case_gemm, case_wgrad, case_wgrad, case_codec, case_norms, case_chunks, case_lstm]
+
+
+def run_cases(seed, seconds=None, max_cases=None):
+    """random cases on whatever backend tests/test_gpu_kernels.py's hooks point at -> (number run, failures)"""
+    R = random.Random(seed)
+    GK.G.manual_seed(seed)
+    failures, n = [], 0
+    t_end = time.time() + (seconds or 1e9)
+    while time.time() < t_end and (max_cases is None or n + len(failures) < max_cases):
+        fn = R.choice(CASES)
+        try:
+            fn(R)
+            n += 1
+        except Exception as e:           # noqa: BLE001
+            failures.append((fn.__name__, repr(e)[:300], traceback.format_exc(limit=3)))
+    return n, failures
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    with tempfile.TemporaryDirectory() as d:
+        so = hostsim.build(d)
+        with hostsim.HostSimBackend(so) as K:
+            GK.HIP, GK.to_device, GK.device_sync, GK.device_name = K, (lambda t: t.clone()), (lambda: None), (lambda: "cpu")
+            n, failures = run_cases(seed, seconds=seconds)
+    print("{} cases, {} failures (seed {})".format(n, len(failures), seed))
+    for f in failures[:10]:
+        print(f[0], f[1])
+        print(f[2])
+    return 1 if failures else 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())
