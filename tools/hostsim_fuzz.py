@@ -135,7 +135,41 @@ def case_lstm(R):
     return "lstm H={} nseq={} L={} reverse={}".format(H, nseq, L, rev)
 
 
-CASES = [case_gemm, case_gemm, case_wgrad, case_wgrad, case_codec, case_norms, case_chunks, case_lstm]
+def case_test_functions(R):
+    """the parametrised kernel tests of tests/test_gpu_kernels.py at random parameters"""
+    pick = R.randint(0, 6)
+    if pick == 0:
+        T, d = R.randint(1, 1500), R.choice([1, 2, 4, 8, 16, 32, 64, 128, 256])
+        GK.test_dwconv_fwd_bwd(T, d)
+        return "dwconv T={} d={}".format(T, d)
+    if pick == 1:
+        B, C, T = R.randint(1, 3), R.randint(1, 300), R.randint(1, 400)
+        GK.test_softmax_over_channels(B, C, T)
+        return "softmax {} {} {}".format(B, C, T)
+    if pick == 2:
+        n, mx, mean = R.randint(1, 5), R.randint(0, 1), R.randint(0, 1)
+        GK.test_pit_search(n, mx, mean)
+        return "pit_search {} {} {}".format(n, mx, mean)
+    if pick == 3:
+        n, it, beta = R.randint(1, 8), R.randint(1, 30), R.choice([0.5, 1.0, 2.0])
+        GK.test_sinkhorn(n, it, beta)
+        return "sinkhorn {} {} {}".format(n, it, beta)
+    if pick == 4:
+        rows, T = R.randint(1, 20), R.randint(1, 3000)
+        GK.test_rowdiff_sums_and_bwd(rows, T)
+        return "rowdiff {} {}".format(rows, T)
+    if pick == 5:
+        Kw, stride, dil = R.randint(1, 7), R.randint(1, 4), R.randint(1, 4)
+        pad = R.randint(0, 6)
+        Tin = R.randint(dil * (Kw - 1) + 1, 300)
+        GK.test_depthwise_generic(Kw, stride, pad, dil, Tin)
+        return "depthwise Kw={} stride={} pad={} dil={} Tin={}".format(Kw, stride, pad, dil, Tin)
+    B, C, T = R.randint(1, 3), R.choice([3, 8, 24, 64]), R.randint(2, 600)
+    GK.test_cln_fwd_bwd(B, C, T)
+    return "cln fwd+bwd {} {} {}".format(B, C, T)
+
+
+CASES = [case_gemm, case_gemm, case_wgrad, case_wgrad, case_codec, case_norms, case_chunks, case_lstm, case_test_functions, case_test_functions]
 
 
 def run_cases(seed, seconds=None, max_cases=None):
@@ -150,7 +184,7 @@ def run_cases(seed, seconds=None, max_cases=None):
             fn(R)
             n += 1
         except Exception as e:           # noqa: BLE001
-            failures.append((fn.__name__, repr(e)[:300], traceback.format_exc(limit=3)))
+            failures.append((fn.__name__, repr(e)[:300], traceback.format_exc(limit=4)))
     return n, failures
 
 
