@@ -150,7 +150,9 @@ def pack_weights(cfg, P, need_bwd):
         else:
             add("skip.{}".format(li), Ws, Sc, H)
     add("mask", P["separator.mask_conv1d.weight"], n_src * N, Sc)
-    keep = [i for i, (_, r, c, t) in enumerate(specs) if (r if t else c) % 16 == 0]     # contraction length the kernel takes
+    # what sep_pack_weights takes: contraction length in 16-column groups, output rows in 32-row blocks (widths like 48 or 80 -- multiples
+    # of 16 the model accepts -- are not: those products hand the fp32 weights to sep_pw_gemm, which splits them itself)
+    keep = [i for i, (_, r, c, t) in enumerate(specs) if (r if t else c) % 16 == 0 and (c if t else r) % 32 == 0]
     packs = K.pack_weights([specs[i] for i in keep])
     return {names[i]: pk for i, pk in zip(keep, packs)}
 

@@ -55,6 +55,10 @@ class EmuBackend:
     def pack_weights(self, specs):
         """No arithmetic here: the emulator multiplies with the fp32 weights; the PackedA only remembers its source so that
         pw_gemm can check that the host code pairs every product with the right pack."""
+        for W, r, c, t in specs:            # the same refusals as sep_pack_weights (csrc/gemm_coop.hip): found the hard way, see
+            M, K = (c if t else r), (r if t else c)      # test_modules_cpu.py::test_widths_in_odd_multiples_of_16
+            if K % 16 or M % 32:
+                raise sepkernels.SepKernelsError("sep_pack_weights: bad segment (M={} K={})".format(M, K))
         return [sepkernels.PackedA(None, None, (c if t else r), (r if t else c), src=(W, r, c, t)) for W, r, c, t in specs]
 
     def pw_gemm(self, *, B, M, K, T, ldt, A, X, Y, trans_a=0, A2=None, X2=None, k_split=0, Y2=None, m_split=0,

@@ -385,6 +385,31 @@ def test_sibling_separators_golden(golden_dir, name):
     assert flat_rel <= 2e-3, "flat gradient rel-inf {:.3e}, worst tensor {}".format(flat_rel, worst)
 
 
+@pytest.mark.parametrize("widths", [(48, 48, 80, 16), (80, 16, 48, 48)])
+def test_widths_in_odd_multiples_of_16_against_oracle(widths):
+    """N / B / H / Sc in multiples of 16 that are not multiples of 32: the weight packer works in 32-row blocks, those products take the
+    fp32 weights (the step used to die in sep_pack_weights; tests/test_modules_cpu.py::test_widths_in_odd_multiples_of_16)."""
+    N, Bn, H, Sc = widths
+    cfg = dict(n_basis=N, kernel_size=8, stride=4, enc_basis="trainable", dec_basis="trainable", enc_nonlinear="relu", sep_hidden_channels=H,
+               sep_bottleneck_channels=Bn, sep_skip_channels=Sc, sep_kernel_size=3, sep_num_blocks=2, sep_num_layers=2, dilated=True, separable=True,
+               causal=False, sep_nonlinear="prelu", sep_norm=True, mask_nonlinear="sigmoid", n_sources=2)
+    torch.manual_seed(3)
+    model = ConvTasNet(**cfg)
+    assert model.fused
+    sources = 0.1 * torch.randn(2, 2, 700)
+    mixture = sources.sum(1, keepdim=True)
+    p64 = {k: v.detach().double() for k, v in model.state_dict().items()}
+    ref_out, ref_loss, ref_pat, ref_grads = FP.train_step(p64, cfg, mixture, sources, dtype=torch.float64)
+    model.cuda()
+    est = model(mixture.cuda())
+    assert _rel(est, ref_out) <= TOL
+    loss, pattern = PIT1d(NegSISDR(), n_sources=2)(est, sources.cuda())
+    assert torch.equal(pattern.cpu(), ref_pat) and abs(loss.item() - ref_loss.item()) <= TOL * abs(ref_loss.item())
+    loss.backward()
+    flat_rel, worst = _grad_report(model, ref_grads)
+    assert flat_rel <= 2e-3, "flat gradient rel-inf {:.3e}, worst tensor {}".format(flat_rel, worst)
+
+
 def test_dptnet_full_width_step():
     """DPTNet at the widths of its paper (N = 64, L = 2, 64 bottleneck channels, chunks of 100 frames) on 4 x 2 s @ 8 kHz:
     320 chunks per utterance, i.e. 1280 x 64 rows in every intra-chunk gLN -- more than one launch takes (the module splits the

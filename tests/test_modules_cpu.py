@@ -257,3 +257,30 @@ def test_weight_gradients_accumulated_onto_one_slab_give_the_same_gradients(gold
     for k, p in model.named_parameters():
         r = torch.from_numpy(g["grad/" + k]).double()
         assert (p.grad - r).abs().max() <= 2e-6 * max(r.abs().max().item(), 1e-6), k
+
+
+@pytest.mark.parametrize("widths", [(48, 48, 80, 16), (80, 16, 48, 48), (16, 48, 16, 80)])
+def test_widths_in_odd_multiples_of_16(emu, widths):
+    """Widths the fused family accepts (multiples of 16) but the weight packer does not (32-row blocks): 48, 80, ...  The step used to
+    die in sep_pack_weights for them in the default arithmetic (found by running random configurations through the kernel sources on
+    the host, tools/hostsim.py); such products now take the fp32 weights.  Forward / loss / gradients against the fp64 oracle."""
+    from oracle import fast_port as FP
+    N, Bn, H, Sc = widths
+    cfg = dict(n_basis=N, kernel_size=8, stride=4, enc_basis="trainable", dec_basis="trainable", enc_nonlinear="relu", sep_hidden_channels=H,
+               sep_bottleneck_channels=Bn, sep_skip_channels=Sc, sep_kernel_size=3, sep_num_blocks=2, sep_num_layers=2, dilated=True, separable=True,
+               causal=False, sep_nonlinear="prelu", sep_norm=True, mask_nonlinear="sigmoid", n_sources=2)
+    torch.manual_seed(3)
+    model = ConvTasNet(**cfg)
+    assert model.fused and sepkernels.gemm_arith_name() == "f16x3"           # the packed-weight arithmetic is the default
+    sources = 0.1 * torch.randn(2, 2, 700)
+    mixture = sources.sum(1, keepdim=True)
+    p64 = {k: v.detach().double() for k, v in model.state_dict().items()}
+    ref_out, ref_loss, ref_pat, ref_grads = FP.train_step(p64, cfg, mixture, sources, dtype=torch.float64)
+    model.double()
+    est = model(mixture.double())
+    assert (est - ref_out).abs().max() <= 1e-9 * ref_out.abs().max()
+    loss, pat = PIT1d(NegSISDR(), n_sources=2)(est, sources.double())
+    assert torch.equal(pat, ref_pat) and abs(loss.item() - ref_loss.item()) <= 1e-9 * abs(ref_loss.item())
+    loss.backward()
+    for k, p in model.named_parameters():
+        assert (p.grad - ref_grads[k]).abs().max() <= 1e-8 * max(ref_grads[k].abs().max().item(), 1e-9), k
