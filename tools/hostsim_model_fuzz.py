@@ -1,0 +1,67 @@
+"""Development tool: random small Conv-TasNet CONFIGURATIONS -- widths in any multiple of 16, 1 - 3 speakers, window / hop pairs, blocks x
+layers, ReLU or linear encoder, sigmoid or softmax mask, ragged lengths -- through the product's fused path with the host simulation of
+the kernel sources behind the C ABI (tools/hostsim.py), against the fp64 oracle (oracle/fast_port.py): forward, permutation, every
+gradient.  The first run of this found the sep_pack_weights refusal for widths like 48 / 80 (tests/test_modules_cpu.py::
+test_widths_in_odd_multiples_of_16).
+
+    python tools/hostsim_model_fuzz.py [seed] [count]
+"""
+import os
+import random
+import sys
+import tempfile
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "tools"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "dnn-based_source_separation_amd", "src"), ROOT]
+import hostsim, sepkernels
+from oracle import fast_port as FP
+from models.conv_tasnet import ConvTasNet
+from criterion.sdr import NegSISDR
+from criterion.pit import PIT1d
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+so = hostsim.build(tempfile.mkdtemp())
+failed = 0
+R = random.Random(seed)
+with hostsim.HostSimBackend(so) as K:
+    class Named:
+        name = "hostsim"
+        def __getattr__(self, n): return getattr(K, n)
+    old = sepkernels._set_backend_for_tests(Named())
+    try:
+        for it in range(count):
+            S = R.choice([2, 4, 8]); L = S * R.choice([1, 2])
+            cfg = dict(n_basis=16 * R.randint(1, 5), kernel_size=L, stride=S, enc_basis="trainable", dec_basis="trainable", enc_nonlinear=R.choice([None, "relu"]),
+                       sep_hidden_channels=16 * R.randint(1, 6), sep_bottleneck_channels=16 * R.randint(1, 4), sep_skip_channels=16 * R.randint(1, 4), sep_kernel_size=3,
+                       sep_num_blocks=R.randint(1, 2), sep_num_layers=R.randint(1, 4), dilated=True, separable=True, causal=False, sep_nonlinear="prelu", sep_norm=True,
+                       mask_nonlinear=R.choice(["sigmoid", "softmax"]), n_sources=R.randint(1, 3))
+            if (cfg["n_sources"] * cfg["n_basis"]) % 16: continue
+            B, T = R.randint(1, 3), R.randint(L + 5, 1500)
+            torch.manual_seed(seed * 100 + it)
+            model = ConvTasNet(**cfg)
+            assert model.fused, model.fused_reason
+            with torch.no_grad():
+                for k, p in model.named_parameters():
+                    if "norm" in k or k.endswith("nonlinear1d.weight") or k.endswith("prelu.weight"):
+                        p.add_(0.1 * torch.randn_like(p))
+            src = 0.1 * torch.randn(B, cfg["n_sources"], T); mix = src.sum(1, keepdim=True)
+            t0 = time.time()
+            est = model(mix)
+            loss, pat = PIT1d(NegSISDR(), n_sources=cfg["n_sources"])(est, src)
+            loss.backward()
+            p64 = {k: v.detach().double() for k, v in model.state_dict().items()}
+            ref_out, ref_loss, ref_pat, ref_grads = FP.train_step(p64, cfg, mix, src, dtype=torch.float64)
+            e_out = ((est.double() - ref_out).abs().max() / ref_out.abs().max()).item()
+            num = den = 0.0
+            for k, p in model.named_parameters():
+                r = ref_grads[k].double(); num = max(num, (p.grad.double() - r).abs().max().item()); den = max(den, r.abs().max().item())
+            ok = e_out < 1e-4 and num / den < 1e-3 and torch.equal(pat, ref_pat)
+            failed += not ok
+            print("%s N=%d B=%d H=%d Sc=%d X=%d R=%d L=%d S=%d n_src=%d %s %s batch=%d T=%d  fwd %.1e grad %.1e  %.0f s" % ("ok  " if ok else "FAIL", cfg["n_basis"], cfg["sep_bottleneck_channels"], cfg["sep_hidden_channels"], cfg["sep_skip_channels"], cfg["sep_num_layers"], cfg["sep_num_blocks"], L, S, cfg["n_sources"], cfg["enc_nonlinear"], cfg["mask_nonlinear"], B, T, e_out, num / den, time.time() - t0), flush=True)
+    finally:
+        sepkernels._set_backend_for_tests(old)
+print("{} configurations failed".format(failed))
+raise SystemExit(1 if failed else 0)
