@@ -33,11 +33,12 @@ with hostsim.HostSimBackend(so) as K:
     old = sepkernels._set_backend_for_tests(Named())
     try:
         for it in range(count):
-            S = R.choice([2, 4, 8]); L = S * R.choice([1, 2])
+            S = R.choice([2, 3, 4, 8, 10]); L = S * R.choice([1, 2, 4])
+            cin = R.choice([1, 1, 2])                    # stereo: the music recipes
             cfg = dict(n_basis=16 * R.randint(1, 5), kernel_size=L, stride=S, enc_basis="trainable", dec_basis="trainable", enc_nonlinear=R.choice([None, "relu"]),
                        sep_hidden_channels=16 * R.randint(1, 6), sep_bottleneck_channels=16 * R.randint(1, 4), sep_skip_channels=16 * R.randint(1, 4), sep_kernel_size=3,
                        sep_num_blocks=R.randint(1, 2), sep_num_layers=R.randint(1, 4), dilated=True, separable=True, causal=False, sep_nonlinear="prelu", sep_norm=True,
-                       mask_nonlinear=R.choice(["sigmoid", "softmax"]), n_sources=R.randint(1, 3))
+                       mask_nonlinear=R.choice(["sigmoid", "softmax"]), n_sources=R.randint(1, 3), in_channels=cin)
             if (cfg["n_sources"] * cfg["n_basis"]) % 16: continue
             B, T = R.randint(1, 3), R.randint(L + 5, 1500)
             torch.manual_seed(seed * 100 + it)
@@ -47,13 +48,27 @@ with hostsim.HostSimBackend(so) as K:
                 for k, p in model.named_parameters():
                     if "norm" in k or k.endswith("nonlinear1d.weight") or k.endswith("prelu.weight"):
                         p.add_(0.1 * torch.randn_like(p))
-            src = 0.1 * torch.randn(B, cfg["n_sources"], T); mix = src.sum(1, keepdim=True)
+            if cin == 1:
+                src = 0.1 * torch.randn(B, cfg["n_sources"], T); mix = src.sum(1, keepdim=True)
+            else:
+                src = 0.1 * torch.randn(B, cfg["n_sources"], cin, T); mix = src.sum(1, keepdim=True)
             t0 = time.time()
             est = model(mix)
-            loss, pat = PIT1d(NegSISDR(), n_sources=cfg["n_sources"])(est, src)
-            loss.backward()
             p64 = {k: v.detach().double() for k, v in model.state_dict().items()}
-            ref_out, ref_loss, ref_pat, ref_grads = FP.train_step(p64, cfg, mix, src, dtype=torch.float64)
+            if cin == 1:
+                loss, pat = PIT1d(NegSISDR(), n_sources=cfg["n_sources"])(est, src)
+                loss.backward()
+                ref_out, ref_loss, ref_pat, ref_grads = FP.train_step(p64, cfg, mix, src, dtype=torch.float64)
+            else:                                        # stereo: a fixed linear functional of the estimate instead of the PIT loss (the oracle's is mono)
+                Wr = torch.randn(est.shape)
+                (est * Wr).sum().backward()
+                pp = {k: v.clone().requires_grad_(True) for k, v in p64.items()}
+                ref_out, _ = FP.conv_tasnet(mix.view(B, cin, T).double(), pp, cfg)
+                ref_out = ref_out.view(est.shape)
+                (ref_out * Wr.double()).sum().backward()
+                ref_grads = {k: v.grad for k, v in pp.items() if v.grad is not None}
+                ref_out = ref_out.detach()
+                pat = ref_pat = torch.zeros(1)
             e_out = ((est.double() - ref_out).abs().max() / ref_out.abs().max()).item()
             num = den = 0.0
             for k, p in model.named_parameters():
