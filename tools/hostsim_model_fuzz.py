@@ -23,7 +23,7 @@ from criterion.sdr import NegSISDR
 from criterion.pit import PIT1d
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-so = hostsim.build(tempfile.mkdtemp())
+so = os.environ.get("HOSTSIM_LIB") or hostsim.build(tempfile.mkdtemp())      # HOSTSIM_LIB: a prebuilt (e.g. sanitized) library
 failed = 0
 R = random.Random(seed)
 with hostsim.HostSimBackend(so) as K:

@@ -98,7 +98,7 @@ def main():
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     R = random.Random(seed)
-    so = hostsim.build(tempfile.mkdtemp())
+    so = os.environ.get("HOSTSIM_LIB") or hostsim.build(tempfile.mkdtemp())      # HOSTSIM_LIB: a prebuilt (e.g. sanitized) library
     failed = done = 0
     with hostsim.HostSimBackend(so) as K:
         class Named:
