@@ -36,7 +36,7 @@ with hostsim.HostSimBackend(so) as K:
             S = R.choice([2, 3, 4, 8, 10]); L = S * R.choice([1, 2, 4])
             cin = R.choice([1, 1, 2])                    # stereo: the music recipes
             cfg = dict(n_basis=16 * R.randint(1, 5), kernel_size=L, stride=S, enc_basis="trainable", dec_basis="trainable", enc_nonlinear=R.choice([None, "relu"]),
-                       sep_hidden_channels=16 * R.randint(1, 6), sep_bottleneck_channels=16 * R.randint(1, 4), sep_skip_channels=16 * R.randint(1, 4), sep_kernel_size=3,
+                       sep_hidden_channels=16 * R.randint(1, 6), sep_bottleneck_channels=R.choice([16, 32, 48, 64, 128, 128]), sep_skip_channels=16 * R.randint(1, 4), sep_kernel_size=3,
                        sep_num_blocks=R.randint(1, 2), sep_num_layers=R.randint(1, 4), dilated=True, separable=True, causal=False, sep_nonlinear="prelu", sep_norm=True,
                        mask_nonlinear=R.choice(["sigmoid", "softmax"]), n_sources=R.randint(1, 3), in_channels=cin)
             if (cfg["n_sources"] * cfg["n_basis"]) % 16: continue
@@ -73,9 +73,19 @@ with hostsim.HostSimBackend(so) as K:
             num = den = 0.0
             for k, p in model.named_parameters():
                 r = ref_grads[k].double(); num = max(num, (p.grad.double() - r).abs().max().item()); den = max(den, r.abs().max().item())
-            ok = e_out < 1e-4 and num / den < 1e-3 and torch.equal(pat, ref_pat)
+            floor = 0.0                                  # how ill-conditioned is this draw?  the fp32 oracle against the fp64 one
+            if cin == 1:
+                _, _, _, g32 = FP.train_step(p64, cfg, mix, src, dtype=torch.float32)
+                floor = max((g32[k].double() - ref_grads[k]).abs().max().item() for k in ref_grads) / den
+            ok = e_out < 1e-4 and num / den < max(1e-3, 30 * floor) and torch.equal(pat, ref_pat)
             failed += not ok
-            print("%s N=%d B=%d H=%d Sc=%d X=%d R=%d L=%d S=%d n_src=%d %s %s batch=%d T=%d  fwd %.1e grad %.1e  %.0f s" % ("ok  " if ok else "FAIL", cfg["n_basis"], cfg["sep_bottleneck_channels"], cfg["sep_hidden_channels"], cfg["sep_skip_channels"], cfg["sep_num_layers"], cfg["sep_num_blocks"], L, S, cfg["n_sources"], cfg["enc_nonlinear"], cfg["mask_nonlinear"], B, T, e_out, num / den, time.time() - t0), flush=True)
+            if not ok:                                   # which tensors
+                for k, pth in model.named_parameters():
+                    r = ref_grads[k].double()
+                    e = (pth.grad.double() - r).abs().max().item()
+                    if e > 1e-4 * den:
+                        print("     %-70s err %.2e of its %.2e (largest gradient %.2e)" % (k, e, r.abs().max().item(), den), flush=True)
+            print("%s in_channels=%d N=%d B=%d H=%d Sc=%d X=%d R=%d L=%d S=%d n_src=%d %s %s batch=%d T=%d  fwd %.1e grad %.1e (fp32 oracle %.1e)  %.0f s" % ("ok  " if ok else "FAIL", cin, cfg["n_basis"], cfg["sep_bottleneck_channels"], cfg["sep_hidden_channels"], cfg["sep_skip_channels"], cfg["sep_num_layers"], cfg["sep_num_blocks"], L, S, cfg["n_sources"], cfg["enc_nonlinear"], cfg["mask_nonlinear"], B, T, e_out, num / den, floor, time.time() - t0), flush=True)
     finally:
         sepkernels._set_backend_for_tests(old)
 print("{} configurations failed".format(failed))
