@@ -1559,6 +1559,8 @@ extern "C" int sep_pw_gemm(const sep_gemm_desc* d, sep_stream_t stream) {
         SEP_REQUIRE(d->pro_stats && d->pro_gamma && (d->pro_mode == SEP_PRO_GLN_BWD || d->pro_beta) && d->count > 0, "sep_pw_gemm: gLN prologue needs stats/gamma/beta/count");
     if (d->pro_mode == SEP_PRO_GLN_BWD)
         SEP_REQUIRE(d->pro_aux && d->pro_bsum && d->pro_store && d->pro_dalpha && !d->k_split, "sep_pw_gemm: GLN_BWD prologue needs aux/bsum/store/dalpha");
+    if (d->pro_mode == SEP_PRO_GLN_BWD)      // row tile 0 stores da while the other row tiles still read X: in place only with one row tile
+        SEP_REQUIRE(d->pro_store != d->X || d->M <= BM, "sep_pw_gemm: pro_store may alias X only when M <= %d (one row tile)", BM);
     if (d->epi_flags & SEP_EPI_STATS_PRELU) SEP_REQUIRE(d->epi_stats && d->epi_alpha, "sep_pw_gemm: STATS_PRELU needs epi_stats/epi_alpha");
     if (d->epi_flags & SEP_EPI_RESIDUAL) SEP_REQUIRE(d->epi_res, "sep_pw_gemm: RESIDUAL needs epi_res");
     if (d->epi_flags & SEP_EPI_PRELU_BWD) SEP_REQUIRE(d->epi_aux && d->epi_alpha && d->epi_dalpha, "sep_pw_gemm: PRELU_BWD needs aux/alpha/dalpha");

@@ -46,7 +46,8 @@ const char* sep_last_error(void);
 #define SEP_PRO_GLN_PRELU 3 /* x -> gLN(PReLU(x; alpha))                    tdcn.py:113-116,182-186 */
 #define SEP_PRO_GLN_BWD 4   /* X = d(gLN out); uses pro_aux = pre-activation a:
                                da = rstd*(gamma*X - mg - xhat*mgx) * PReLU'(a); da is also stored to pro_store
-                               and sum(du * a * [a<=0]) is accumulated into pro_dalpha */
+                               and sum(du * a * [a<=0]) is accumulated into pro_dalpha.  pro_store may be X itself (in place)
+                               only when M <= 128: with several 128-row tiles the others still read the untouched X */
 
 /* ---- epilogue flags ----------------------------------------------------------------- */
 #define SEP_EPI_STATS_PRELU 1 /* accumulate sum/sumsq of PReLU(y; epi_alpha) into epi_stats (y itself is stored) */

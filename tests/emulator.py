@@ -97,6 +97,8 @@ class EmuBackend:
             sh = pro_beta.view(1, K, 1) - mu * sc
             Xp = u * sc + sh
         elif pro_mode == PRO_GLN_BWD:
+            if pro_store.data_ptr() == X.data_ptr() and M > 128:       # the library's refusal (sep_pw_gemm): in place only with one row tile
+                raise RuntimeError("sep_pw_gemm: pro_store may alias X only when M <= 128 (one row tile)")
             a = pro_aux.reshape(B, K, ldt)
             u = _prelu(a, pro_alpha)
             xh = (u - mu) * rstd

@@ -258,6 +258,26 @@ def test_gemm_gln_bwd_prologue(residual, arith):
     both("pw_gemm", [], kw)
 
 
+@pytest.mark.parametrize("M,K", [(256, 64), (192, 48)])
+def test_gemm_gln_bwd_prologue_several_row_tiles(M, K, arith):
+    """more than one 128-row tile: da goes to its own buffer (row tile 0 stores it, every tile recomputes it from the untouched X),
+    and handing X over as pro_store is refused -- by the library and by the restatement alike"""
+    B, T, ldt = 2, 300, 512
+    a = padded(B, K, T, ldt)
+    dv = padded(B, K, T, ldt)
+    kw = dict(B=B, M=M, K=K, T=T, ldt=ldt, trans_a=1, A=rnd(K, M, scale=0.1), X=dv, Y=nan(B, M, ldt), pro_mode=PRO_GLN_BWD,
+              pro_stats=stats_of(torch.where(a > 0, a, 0.2 * a), T), pro_gamma=rnd(K) + 1, pro_alpha=torch.tensor([0.2]), pro_aux=a,
+              pro_bsum=rnd(B, 2, scale=0.01), pro_store=nan(B, K, ldt), pro_dalpha=torch.full((1,), 100.0, dtype=torch.float64), count=K * T, eps=1e-12,
+              epi_flags=EPI_RESIDUAL, epi_res=padded(B, M, T, ldt))
+    both("pw_gemm", [], kw)
+    kw["pro_store"] = kw["X"]
+    with pytest.raises(RuntimeError, match="one row tile"):
+        both("pw_gemm", [], kw)
+    dev = to_device(dv)
+    with pytest.raises(RuntimeError, match="one row tile"):
+        HIP.pw_gemm(**{k: (dev if v is dv else to_device(v) if torch.is_tensor(v) else v) for k, v in kw.items()})
+
+
 @pytest.mark.parametrize("alpha", [-0.3, 0.0, 1.0, 1.7])
 def test_gemm_prelu_prologues_any_slope(alpha):
     """The producer / consumer kernel has a two-instruction PReLU (max(x, alpha x)) for 0 <= alpha <= 1 and the general form

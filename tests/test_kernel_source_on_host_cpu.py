@@ -60,6 +60,8 @@ GEMM_CASES = [
     ("f16x3", "test_gemm_small_widths_of_the_dual_path_separators", (48, 48, 77)),
     ("f16x3-packed", "test_gemm_prelu_prologue_sigmoid", ()),
     ("f16x3-packed", "test_gemm_gln_bwd_prologue", (1,)),
+    ("f16x3-packed", "test_gemm_gln_bwd_prologue_several_row_tiles", (256, 64)),
+    ("f16x3", "test_gemm_gln_bwd_prologue_several_row_tiles", (192, 48)),
     ("f16x3", "test_wgrad_plain", (2, 256, 128, 300, 3)),
     ("bf16x6", "test_wgrad_plain", (2, 128, 256, 130, 1)),
     ("f32", "test_wgrad_plain", (2, 32, 4, 201, 2)),

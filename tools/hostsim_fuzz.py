@@ -53,6 +53,80 @@ def case_gemm(R):
     return "pw_gemm {} B={} M={} K={} T={} trans={} {}".format(arith, B, M, K, T, trans, sorted(k for k in kw if k in ("bias", "pro_mode", "epi_flags")))
 
 
+def walk(n_terms):
+    """start value of a slope-gradient accumulator: the kernels add onto it, and a sum of n signed terms is only known to
+    about sqrt(n) of a term -- a zero start would gate the comparison on whatever the terms happen to cancel to"""
+    return torch.full((1,), float(n_terms) ** 0.5, dtype=torch.float64)
+
+
+def case_gemm_forms(R):
+    """the prologue / epilogue forms of the model's products at random sizes: gLN (+PReLU) prologue with statistics or residual epilogue
+    (optionally two outputs + accumulation), input gradients from two sources with row sums, PReLU-derivative epilogue, gLN-backward
+    prologue -- fp32 weights or packed ones"""
+    from sepkernels import EPI_PRELU_BWD, EPI_RESIDUAL, EPI_ROWSUMS, EPI_ROWSUMS_PRELU, EPI_STATS_PRELU, PRO_GLN, PRO_GLN_BWD, PRO_GLN_PRELU
+    arith = R.choice(["f32", "f16x3", "bf16x6", "f16x3-packed"])
+    packed = arith.endswith("packed")
+    B, T = R.randint(1, 2), R.randint(1, 400)
+    ldt = up(T, 128)
+    unit = 32 if packed else 16
+    form = R.randint(0, 4)
+    al = torch.tensor([R.choice([0.25, -0.3, 1.0, 1.7, 0.0])])
+    if form == 0:          # conv1: statistics of PReLU(y) in the epilogue, optionally behind the gLN prologue
+        M, K = unit * R.randint(1, 12), 16 * R.randint(1, 8)
+        X = GK.padded(B, K, T, ldt) * 2 + 0.3
+        X[..., T:] = 0
+        kw = dict(B=B, M=M, K=K, T=T, ldt=ldt, A=GK.rnd(M, K, scale=K ** -0.5), X=X, Y=GK.nan(B, M, ldt), bias=GK.rnd(M), epi_flags=EPI_STATS_PRELU,
+                  epi_alpha=al, epi_stats=GK.zstats(B), eps=1e-12)
+        if R.random() < 0.5:
+            kw.update(pro_mode=PRO_GLN, pro_stats=GK.stats_of(X, T), pro_gamma=GK.rnd(K) + 1, pro_beta=GK.rnd(K), count=K * T)
+    elif form == 1:        # heads: gLN + PReLU prologue, residual, optionally [out; skip] with accumulation into the skip sum
+        K = 16 * R.randint(1, 8)
+        z = GK.padded(B, K, T, ldt) * 1.5 + 0.2
+        z[..., T:] = 0
+        st = GK.stats_of(torch.where(z > 0, z, al * z), T)
+        common = dict(B=B, K=K, T=T, ldt=ldt, X=z, pro_mode=PRO_GLN_PRELU, pro_stats=st, pro_gamma=GK.rnd(K) + 1, pro_beta=GK.rnd(K), pro_alpha=al, count=K * T, eps=1e-12)
+        if R.random() < 0.5:
+            Bn, Sc = 128 * R.randint(1, 2), unit * R.randint(1, 4)
+            kw = dict(common, M=Bn + Sc, A=GK.rnd(Bn + Sc, K, scale=K ** -0.5), Y=GK.nan(B, Bn, ldt), Y2=GK.padded(B, Sc, T, ldt), m_split=Bn, bias=GK.rnd(Bn + Sc),
+                      accumulate=1, epi_flags=EPI_RESIDUAL, epi_res=GK.padded(B, Bn, T, ldt))
+        else:
+            M = unit * R.randint(1, 8)
+            kw = dict(common, M=M, A=GK.rnd(M, K, scale=K ** -0.5), Y=GK.nan(B, M, ldt), bias=GK.rnd(M))
+            if R.random() < 0.5:
+                kw.update(epi_flags=EPI_RESIDUAL, epi_res=GK.padded(B, M, T, ldt))
+    elif form == 2:        # heads^T: two sources, row sums for the gLN backward
+        Bn, Sc, H = 16 * R.randint(1, 8), 16 * R.randint(1, 4), unit * R.randint(1, 8)
+        kw = dict(B=B, M=H, K=Bn + Sc, T=T, ldt=ldt, trans_a=1, A=GK.rnd(Bn, H, scale=0.1), A2=GK.rnd(Sc, H, scale=0.1), X=GK.padded(B, Bn, T, ldt), X2=GK.padded(B, Sc, T, ldt),
+                  k_split=Bn, Y=GK.nan(B, H, ldt), epi_flags=EPI_ROWSUMS | EPI_ROWSUMS_PRELU, epi_aux=GK.padded(B, H, T, ldt), epi_alpha=al, epi_rowpart=GK.nan(B, H, ldt // 64, 2))
+        if R.random() < 0.3:
+            kw.update(epi_flags=EPI_ROWSUMS)
+    elif form == 3:        # mask^T: PReLU-derivative epilogue with the slope gradient
+        M, K = unit * R.randint(1, 6), 16 * R.randint(1, 12)
+        kw = dict(B=B, M=M, K=K, T=T, ldt=ldt, trans_a=1, A=GK.rnd(K, M, scale=0.1), X=GK.padded(B, K, T, ldt), Y=GK.nan(B, M, ldt), epi_flags=EPI_PRELU_BWD,
+                  epi_aux=GK.padded(B, M, T, ldt), epi_alpha=al, epi_dalpha=walk(B * M * T))
+    else:                  # conv1^T: gLN-backward prologue (stores d(pre-activation), accumulates the slope gradient), optional residual
+        M, K = unit * R.randint(1, 6), 16 * R.randint(1, 10)
+        a = GK.padded(B, K, T, ldt)
+        dv = GK.padded(B, K, T, ldt)
+        kw = dict(B=B, M=M, K=K, T=T, ldt=ldt, trans_a=1, A=GK.rnd(K, M, scale=0.1), X=dv, Y=GK.nan(B, M, ldt), pro_mode=PRO_GLN_BWD,
+                  pro_stats=GK.stats_of(torch.where(a > 0, a, al * a), T), pro_gamma=GK.rnd(K) + 1, pro_alpha=al, pro_aux=a, pro_bsum=GK.rnd(B, 2, scale=0.01), pro_store=dv if M <= 128 else GK.nan(B, K, ldt),     # in place only with one row tile (sepkernels.h)
+                  pro_dalpha=walk(B * K * T), count=K * T, eps=1e-12)
+        if R.random() < 0.5:
+            kw.update(epi_flags=EPI_RESIDUAL, epi_res=GK.padded(B, M, T, ldt))
+    what = "gemm form {} {} B={} M={} K={} T={} k_split={} m_split={} flags={} pro={}".format(
+        form, arith, B, kw["M"], kw["K"], T, kw.get("k_split", 0), kw.get("m_split", 0), kw.get("epi_flags", 0), kw.get("pro_mode", 0))
+    prev = sepkernels.set_gemm_arith(arith.split("-")[0])
+    GK.PACKED[0] = packed
+    try:
+        GK.both("pw_gemm", [], kw)
+    except AssertionError as e:
+        raise AssertionError("{}: {}".format(what, e)) from None
+    finally:
+        GK.PACKED[0] = False
+        sepkernels.set_gemm_arith(prev)
+    return what
+
+
 def case_wgrad(R):
     arith = R.choice(["f32", "f16x3", "bf16x6"])
     B, T = R.randint(1, 3), R.randint(1, 300)
@@ -169,7 +243,7 @@ def case_test_functions(R):
     return "cln fwd+bwd {} {} {}".format(B, C, T)
 
 
-CASES = [case_gemm, case_gemm, case_wgrad, case_wgrad, case_codec, case_norms, case_chunks, case_lstm, case_test_functions, case_test_functions]
+CASES = [case_gemm, case_gemm, case_gemm_forms, case_gemm_forms, case_wgrad, case_wgrad, case_codec, case_norms, case_chunks, case_lstm, case_test_functions, case_test_functions]
 
 
 def run_cases(seed, seconds=None, max_cases=None):
