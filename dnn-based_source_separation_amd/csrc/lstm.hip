@@ -206,8 +206,7 @@ __global__ __launch_bounds__(H * 4) void lstm_bwd_kernel(const float* __restrict
 //     5 evaluations per step instead of 20.  The two layouts are exchanged through 320 floats of wave-private LDS.
 // Assumed operand layout of v_mfma_f32_4x4x1_16b_f32 (checked on the device by tools/mfma4x4_probe.hip before this path is enabled):
 // lane l supplies A[block l / 4][row l % 4] and B[block l / 4][column l % 4] and receives D[block l / 4][row v][column l % 4] in
-// register v.  Selected by SEPK_LSTM_NS4 (0 = off, the default until measured; 1 = always; 2 = when 16-sequence workgroups would
-// leave compute units idle).
+// register v (confirmed on the device by that probe, round 3: "layout: PASS").  Selection: few_sequences() below.
 constexpr int NS4 = 4;
 constexpr int XCH = 80;         // sequence stride of the layout-exchange scratch: (seq * 80 + part * 16 + unit) is conflict-free both ways
 
@@ -397,18 +396,22 @@ __global__ __launch_bounds__(H * 4) void lstm_bwd4_kernel(const float* __restric
     }
 }
 
-// SEPK_LSTM_NS4: 0 (default) 16 sequences per workgroup always; 1 four per workgroup always; 2 four when sixteen would leave units idle
-bool few_sequences(int nseq, int reverse) {
-    static const int mode = getenv("SEPK_LSTM_NS4") ? atoi(getenv("SEPK_LSTM_NS4")) : 0;
-    if (mode == 1) return true;
-    // four-sequence workgroups take up to four rounds on the 256 compute units where sixteen-sequence ones take one: worth it while four
-    // rounds of the short step (estimated 1.5 us) stay below one long step (5.5 us measured), i.e. up to three rounds
-    return mode == 2 && ((nseq + LSTM_NS - 1) / LSTM_NS) * (reverse == 2 ? 2 : 1) <= 192;
+// Which sweep kernel: four sequences per workgroup while those workgroups still fit ONE round on the 256 compute units, else sixteen.
+// Measured on MI355X (tools/lstm_bench.py, bi-directional fwd + bwd, H = 128, profiles/r03a_lstm4.txt): 510 sequences x 250 steps
+// (DPRNN-TasNet's inter-chunk path at B = 2: 256 four-sequence workgroups against 64 sixteen-sequence ones) 3.74 ms against 5.45;
+// 2040 sequences (1020 workgroups = four rounds against one) 11.85 ms against 10.73.  SEPK_LSTM_NS4 = 0 / 1 forces sixteen / four.
+// The caller can force either one per call: bits 8-9 of `reverse` (SEP_LSTM_FORCE16 / SEP_LSTM_FORCE4, include/sepkernels.h) -- the tests
+// run every case through both.
+bool few_sequences(int nseq, int reverse, int force) {
+    static const int mode = getenv("SEPK_LSTM_NS4") ? atoi(getenv("SEPK_LSTM_NS4")) : 2;
+    if (force == 1 || force == 2) return force == 2;
+    if (mode == 0 || mode == 1) return mode == 1;
+    return ((nseq + NS4 - 1) / NS4) * (reverse == 2 ? 2 : 1) <= 256;
 }
 
 template <int H>
-int launch_fwd(const float* xg, const float* whh, float* hout, float* gates, float* cstate, int nseq, int L, int reverse, hipStream_t st) {
-    if (few_sequences(nseq, reverse)) {
+int launch_fwd(const float* xg, const float* whh, float* hout, float* gates, float* cstate, int nseq, int L, int reverse, int force, hipStream_t st) {
+    if (few_sequences(nseq, reverse, force)) {
         hipLaunchKernelGGL((lstm_fwd4_kernel<H>), dim3((nseq + NS4 - 1) / NS4, reverse == 2 ? 2 : 1), dim3(H * 4), 0, st, xg, whh, hout, gates, cstate, nseq, L, reverse);
         return 0;
     }
@@ -416,8 +419,8 @@ int launch_fwd(const float* xg, const float* whh, float* hout, float* gates, flo
     return 0;
 }
 template <int H>
-int launch_bwd(const float* dhout, const float* gates, const float* cstate, const float* whh, float* dxg, int nseq, int L, int reverse, hipStream_t st) {
-    if (few_sequences(nseq, reverse)) {
+int launch_bwd(const float* dhout, const float* gates, const float* cstate, const float* whh, float* dxg, int nseq, int L, int reverse, int force, hipStream_t st) {
+    if (few_sequences(nseq, reverse, force)) {
         hipLaunchKernelGGL((lstm_bwd4_kernel<H>), dim3((nseq + NS4 - 1) / NS4, reverse == 2 ? 2 : 1), dim3(H * 4), 0, st, dhout, gates, cstate, whh, dxg, nseq, L, reverse);
         return 0;
     }
@@ -430,13 +433,15 @@ int launch_bwd(const float* dhout, const float* gates, const float* cstate, cons
 extern "C" int sep_lstm_fwd(const float* xg, const float* w_hh, float* h_out, float* gates, float* cstate, int nseq, int L,
                             int H, int reverse, sep_stream_t stream) {
     SEP_REQUIRE(xg && w_hh && h_out, "sep_lstm_fwd: null pointer");
-    SEP_REQUIRE(nseq > 0 && L > 0 && reverse >= 0 && reverse <= 2, "sep_lstm_fwd: bad sizes / direction");
+    const int force = (reverse >> 8) & 3;
+    reverse &= 0xff;
+    SEP_REQUIRE(nseq > 0 && L > 0 && reverse >= 0 && reverse <= 2 && force <= 2, "sep_lstm_fwd: bad sizes / direction");
     hipStream_t st = (hipStream_t)stream;
     switch (H) {
-        case 16: launch_fwd<16>(xg, w_hh, h_out, gates, cstate, nseq, L, reverse, st); break;
-        case 32: launch_fwd<32>(xg, w_hh, h_out, gates, cstate, nseq, L, reverse, st); break;
-        case 64: launch_fwd<64>(xg, w_hh, h_out, gates, cstate, nseq, L, reverse, st); break;
-        case 128: launch_fwd<128>(xg, w_hh, h_out, gates, cstate, nseq, L, reverse, st); break;
+        case 16: launch_fwd<16>(xg, w_hh, h_out, gates, cstate, nseq, L, reverse, force, st); break;
+        case 32: launch_fwd<32>(xg, w_hh, h_out, gates, cstate, nseq, L, reverse, force, st); break;
+        case 64: launch_fwd<64>(xg, w_hh, h_out, gates, cstate, nseq, L, reverse, force, st); break;
+        case 128: launch_fwd<128>(xg, w_hh, h_out, gates, cstate, nseq, L, reverse, force, st); break;
         default: SEP_REQUIRE(false, "sep_lstm_fwd: hidden size %d not supported (16, 32, 64, 128)", H);
     }
     SEP_CHECK_LAUNCH("sep_lstm_fwd");
@@ -446,13 +451,15 @@ extern "C" int sep_lstm_fwd(const float* xg, const float* w_hh, float* h_out, fl
 extern "C" int sep_lstm_bwd(const float* dh_out, const float* gates, const float* cstate, const float* w_hh, float* dxg,
                             int nseq, int L, int H, int reverse, sep_stream_t stream) {
     SEP_REQUIRE(dh_out && gates && cstate && w_hh && dxg, "sep_lstm_bwd: null pointer");
-    SEP_REQUIRE(nseq > 0 && L > 0 && reverse >= 0 && reverse <= 2, "sep_lstm_bwd: bad sizes / direction");
+    const int force = (reverse >> 8) & 3;
+    reverse &= 0xff;
+    SEP_REQUIRE(nseq > 0 && L > 0 && reverse >= 0 && reverse <= 2 && force <= 2, "sep_lstm_bwd: bad sizes / direction");
     hipStream_t st = (hipStream_t)stream;
     switch (H) {
-        case 16: launch_bwd<16>(dh_out, gates, cstate, w_hh, dxg, nseq, L, reverse, st); break;
-        case 32: launch_bwd<32>(dh_out, gates, cstate, w_hh, dxg, nseq, L, reverse, st); break;
-        case 64: launch_bwd<64>(dh_out, gates, cstate, w_hh, dxg, nseq, L, reverse, st); break;
-        case 128: launch_bwd<128>(dh_out, gates, cstate, w_hh, dxg, nseq, L, reverse, st); break;
+        case 16: launch_bwd<16>(dh_out, gates, cstate, w_hh, dxg, nseq, L, reverse, force, st); break;
+        case 32: launch_bwd<32>(dh_out, gates, cstate, w_hh, dxg, nseq, L, reverse, force, st); break;
+        case 64: launch_bwd<64>(dh_out, gates, cstate, w_hh, dxg, nseq, L, reverse, force, st); break;
+        case 128: launch_bwd<128>(dh_out, gates, cstate, w_hh, dxg, nseq, L, reverse, force, st); break;
         default: SEP_REQUIRE(false, "sep_lstm_bwd: hidden size %d not supported (16, 32, 64, 128)", H);
     }
     SEP_CHECK_LAUNCH("sep_lstm_bwd");

@@ -352,7 +352,12 @@ int sep_adam_step_dev(float* p, float* g, float* m, float* v, const double* sqno
  *           The caller forms dW_ih = dxg^T x, dW_hh = dxg^T h_{t-1}, db = sum dxg, dx = dxg W_ih (plain GEMMs).
  * H in {16, 32, 64, 128}; w_hh is [4H][H] row-major.
  * reverse = 2 runs BOTH directions in one launch (a sweep occupies only nseq/16 compute units): every buffer then holds
- * two slabs back to back, slab 0 = forward in time, slab 1 = backward in time (xg [2][nseq][L][4H], w_hh [2][4H][H], ...). */
+ * two slabs back to back, slab 0 = forward in time, slab 1 = backward in time (xg [2][nseq][L][4H], w_hh [2][4H][H], ...).
+ * Two sweep kernels exist: sixteen sequences per workgroup (v_mfma_f32_16x16x4_f32) and four (v_mfma_f32_4x4x1_16b_f32); the
+ * library picks four while those workgroups fit one round on the chip.  OR-ing SEP_LSTM_FORCE16 / SEP_LSTM_FORCE4 into
+ * `reverse` forces one of them for the call (tests). */
+#define SEP_LSTM_FORCE16 0x100
+#define SEP_LSTM_FORCE4 0x200
 int sep_lstm_fwd(const float* xg, const float* w_hh, float* h_out, float* gates, float* cstate, int nseq, int L, int H,
                  int reverse, sep_stream_t stream);
 int sep_lstm_bwd(const float* dh_out, const float* gates, const float* cstate, const float* w_hh, float* dxg, int nseq,

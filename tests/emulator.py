@@ -534,6 +534,7 @@ class EmuBackend:
         out += (g.reshape(-1)[:n].double() ** 2).sum()
 
     def lstm_fwd(self, xg, w_hh, h_out, gates, cstate, nseq, L, H, reverse):
+        reverse = int(reverse) & 0xff        # bits 8-9 choose between the device's two sweep kernels: same arithmetic
         if int(reverse) == 2:          # both directions: two slabs per buffer
             for d in range(2):
                 self.lstm_fwd(xg.reshape(2, -1)[d], w_hh.reshape(2, 4 * H, H)[d], h_out.reshape(2, -1)[d],
@@ -557,6 +558,7 @@ class EmuBackend:
                 cstate.reshape(nseq, L, H)[:, t] = c
 
     def lstm_bwd(self, dh_out, gates, cstate, w_hh, dxg, nseq, L, H, reverse):
+        reverse = int(reverse) & 0xff
         if int(reverse) == 2:
             for d in range(2):
                 self.lstm_bwd(dh_out.reshape(2, -1)[d], gates.reshape(2, -1)[d], cstate.reshape(2, -1)[d], w_hh.reshape(2, 4 * H, H)[d],

@@ -728,9 +728,14 @@ def test_segment_overlap_add(T, chunk, hop):
 
 
 # ------------------------------------------------------------------------------------------- LSTM recurrence (DPRNN)
+LSTM_KERNELS = {"sixteen": 0x100, "four": 0x200}      # SEP_LSTM_FORCE16 / SEP_LSTM_FORCE4: every case runs on both sweep kernels
+
+
+@pytest.mark.parametrize("kernel", sorted(LSTM_KERNELS))
 @pytest.mark.parametrize("H,nseq,L,reverse", [(16, 5, 7, 0), (32, 37, 23, 1), (64, 16, 40, 0), (128, 50, 31, 1), (128, 33, 250, 0)])
-def test_lstm_sweeps(H, nseq, L, reverse):
-    """sep_lstm_fwd / sep_lstm_bwd against the step-by-step CPU restatement (ragged last workgroup: nseq % 16 != 0)."""
+def test_lstm_sweeps(H, nseq, L, reverse, kernel):
+    """sep_lstm_fwd / sep_lstm_bwd against the step-by-step CPU restatement (ragged last workgroup: nseq % 16 != 0, nseq % 4 != 0)."""
+    reverse |= LSTM_KERNELS[kernel]
     xg = rnd(nseq, L, 4 * H)
     w_hh = rnd(4 * H, H, scale=H ** -0.5)
     h, gates, cst = nan(nseq, L, H), nan(nseq, L, 4 * H), nan(nseq, L, H)
@@ -740,12 +745,14 @@ def test_lstm_sweeps(H, nseq, L, reverse):
     both("lstm_bwd", [rnd(nseq, L, H), gates, cst, w_hh, nan(nseq, L, 4 * H), nseq, L, H, reverse], tol=tol)
 
 
-def test_lstm_sweeps_both_directions_one_launch():
+@pytest.mark.parametrize("kernel", sorted(LSTM_KERNELS))
+def test_lstm_sweeps_both_directions_one_launch(kernel):
     """reverse = 2: two slabs per buffer, grid.y = direction."""
     H, nseq, L = 128, 21, 40
+    two = 2 | LSTM_KERNELS[kernel]
     xg = rnd(2, nseq, L, 4 * H)
     w_hh = rnd(2, 4 * H, H, scale=H ** -0.5)
     h, gates, cst = nan(2, nseq, L, H), nan(2, nseq, L, 4 * H), nan(2, nseq, L, H)
-    both("lstm_fwd", [xg, w_hh, h, gates, cst, nseq, L, H, 2])
-    both("lstm_bwd", [rnd(2, nseq, L, H), gates, cst, w_hh, nan(2, nseq, L, 4 * H), nseq, L, H, 2])
+    both("lstm_fwd", [xg, w_hh, h, gates, cst, nseq, L, H, two])
+    both("lstm_bwd", [rnd(2, nseq, L, H), gates, cst, w_hh, nan(2, nseq, L, 4 * H), nseq, L, H, two])
 

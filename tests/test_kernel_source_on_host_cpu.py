@@ -4,7 +4,7 @@ shuffles, DPP, ballots and the MFMA instructions as collective operations of a w
 inline-assembly helpers get a C++ body in the compiled copy) into a library with the same C ABI -- all 42 entry points -- and the kernel
 cases of tests/test_gpu_kernels.py -- the very functions that run on the MI355X -- are run against it here: encoder / unfold, depthwise forward / backward, gLN statistics / apply / backward pieces, head backward,
 decoder forward / backward, channel softmax, cLN, SI-SDR, PIT search, Sinkhorn, row distances, squared norm + Adam, chunking /
-overlap-add, the LSTM sweeps (16 sequences per workgroup, and the four-sequence variant prepared behind SEPK_LSTM_NS4).
+overlap-add, the LSTM sweeps (both kernels: sixteen and four sequences per workgroup, forced per call),
 and the GEMM family in its three arithmetics and the packed-weight form (per-wave split kernels, the cooperative and the producer /
 consumer kernels with their flag synchronisation, the weight-gradient kernels, prologues / epilogues, ragged tiles).
 It catches indexing / synchronisation / unwritten-output mistakes in the kernel source before any GPU minute is spent.  It cannot see
@@ -40,7 +40,9 @@ CASES = [
     ("test_rowdiff_sums_and_bwd", [(8, 32000), (1, 5)]),
     ("test_sqnorm_and_adam", [()]),
     ("test_segment_overlap_add", [(812, 20, 10), (3999, 250, 125), (100, 16, 4), (64, 64, 64)]),
-    ("test_lstm_sweeps", [(16, 5, 7, 0), (32, 37, 23, 1), (64, 16, 40, 0), (128, 50, 31, 1)]),
+    ("test_lstm_sweeps", [(16, 5, 7, 0, "sixteen"), (32, 37, 23, 1, "sixteen"), (64, 16, 40, 0, "sixteen"), (128, 50, 31, 1, "sixteen"),
+                          (16, 5, 7, 0, "four"), (32, 37, 23, 1, "four"), (64, 16, 40, 0, "four"), (128, 50, 31, 1, "four")]),
+    ("test_lstm_sweeps_both_directions_one_launch", [("sixteen",), ("four",)]),
 ]
 
 
@@ -186,30 +188,3 @@ def test_the_comparison_is_not_vacuous(on_host):
     GK.HIP = Skewed()
     with pytest.raises(AssertionError):
         GK.both("gln_apply", list(args))
-
-
-NS4_SCRIPT = r'''
-import sys
-sys.path[:0] = {paths!r}
-import hostsim
-import test_gpu_kernels as GK
-with hostsim.HostSimBackend({so!r}) as K:
-    GK.HIP, GK.to_device, GK.device_sync, GK.device_name = K, (lambda t: t.clone()), (lambda: None), (lambda: "cpu")
-    for case in [(16, 5, 7, 0), (32, 37, 23, 1), (64, 16, 40, 0), (128, 50, 31, 1)]:
-        GK.test_lstm_sweeps(*case)
-    H, nseq, L = 32, 7, 5                                  # both directions in one launch, ragged last workgroup
-    xg, w_hh = GK.rnd(2, nseq, L, 4 * H), GK.rnd(2, 4 * H, H, scale=H ** -0.5)
-    h, gates, cst = GK.nan(2, nseq, L, H), GK.nan(2, nseq, L, 4 * H), GK.nan(2, nseq, L, H)
-    GK.both("lstm_fwd", [xg, w_hh, h, gates, cst, nseq, L, H, 2])
-    GK.both("lstm_bwd", [GK.rnd(2, nseq, L, H), gates, cst, w_hh, GK.nan(2, nseq, L, 4 * H), nseq, L, H, 2])
-print("NS4-OK")
-'''
-
-
-def test_four_sequence_lstm_sweeps_on_the_host(sim_library):
-    """lstm_fwd4_kernel / lstm_bwd4_kernel (v_mfma_f32_4x4x1_16b_f32, four sequences per workgroup; OFF by default, written without a GPU
-    at hand): SEPK_LSTM_NS4 is read once per process, hence the child process."""
-    paths = [os.path.join(ROOT, "tools"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "dnn-based_source_separation_amd", "src"), ROOT]
-    env = dict(os.environ, SEPK_LSTM_NS4="1")
-    r = subprocess.run([sys.executable, "-c", NS4_SCRIPT.format(paths=paths, so=sim_library)], capture_output=True, text=True, timeout=900, env=env)
-    assert r.returncode == 0 and "NS4-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
