@@ -78,15 +78,34 @@ __device__ __forceinline__ float prelu_grad(float x, float a) { return x > 0.f ?
 #endif
 
 // mean / rstd of a gLN from its slots -- biased variance like nn.GroupNorm.  st points at the sample's first slot.
-__device__ __forceinline__ void gln_mu_rstd(const double* st, double count, float eps, float& mu, float& rstd) {
+__device__ __forceinline__ void gln_mu_rstd_d(const double* st, double count, float eps, double& m, double& r) {
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll
     for (int k = 0; k < SEP_STATS_SLOTS; ++k) { s0 += st[2 * k]; s1 += st[2 * k + 1]; }
-    const double m = s0 / count;
+    m = s0 / count;
     double var = s1 / count - m * m;
     if (var < 0.0) var = 0.0;
+    r = 1.0 / sqrt(var + (double)eps);
+}
+__device__ __forceinline__ void gln_mu_rstd(const double* st, double count, float eps, float& mu, float& rstd) {
+    double m, r;
+    gln_mu_rstd_d(st, count, eps, m, r);
     mu = (float)m;
-    rstd = (float)(1.0 / sqrt(var + (double)eps));
+    rstd = (float)r;
+}
+// gLN backward: the two per-sample means every input gradient needs,
+//     mg = mean_{c,t}(gamma_c g),   mgx = mean_{c,t}(gamma_c g xhat),   xhat = (u - mu) rstd,
+// from the RAW sums the kernel that produced g accumulated with fp64 atomics into SEP_STATS_SLOTS slots per sample, exactly like the
+// forward statistics:  acc[slot] = { sum_c gamma_c sum_t g , sum_c gamma_c sum_t g u }.  Both are linear in the row sums, so they need
+// neither mu nor rstd when they are accumulated, and no second-stage kernel sits between producer and consumer (round 2 had two
+// launches there, 98 per step on the critical path).  acc / st point at the sample's first slot.
+__device__ __forceinline__ void gln_bwd_means(const double* acc, const double* st, double count, float eps, float& mg, float& mgx) {
+    double s1 = 0.0, s2 = 0.0, m, r;
+#pragma unroll
+    for (int k = 0; k < SEP_STATS_SLOTS; ++k) { s1 += acc[2 * k]; s2 += acc[2 * k + 1]; }
+    gln_mu_rstd_d(st, count, eps, m, r);
+    mg = (float)(s1 / count);
+    mgx = (float)(r * (s2 - m * s1) / count);
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -92,7 +92,8 @@ __device__ __forceinline__ void gemm_epilogue(const sep_gemm_desc& d, f32x16 (&a
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ef = EF >= 0 ? EF : d.epi_flags;
     const float alpha_e = (ef & (SEP_EPI_STATS_PRELU | SEP_EPI_PRELU_BWD | SEP_EPI_ROWSUMS_PRELU)) ? d.epi_alpha[0] : 0.f;
-    float st_s = 0.f, st_ss = 0.f, dalpha_e = 0.f;
+    float st_s = 0.f, st_ss = 0.f, dalpha_e = 0.f, ba1 = 0.f, ba2 = 0.f;
+    const bool do_bacc = (ef & SEP_EPI_ROWSUMS) && d.epi_bacc != nullptr;       // block-uniform
     const int Mfirst = d.m_split ? d.m_split : d.M;
     const int wrow = m0 + wr * (32 * MI);                    // first output row of this wave
     const bool second = d.m_split && wrow >= d.m_split;      // wave-uniform: m_split is a multiple of 128, wrow of 32*MI
@@ -220,6 +221,10 @@ struct GrpOps { float4 ext[GRP], aux[GRP], old[GRP]; float bs[GRP], rs[GRP]; };
                     if (c4 == 0 && ok[j]) {
                         float* rp = d.epi_rowpart + (((size_t)b * d.M + wrow + mi * 32 + (g4 + j) * 4 + rsub) * (d.ldt / 64) + (t0 + wc * 64) / 64) * 2;
                         rp[0] = rs1; rp[1] = rs2;
+                        if (do_bacc) {          // the sample's gamma-weighted totals, for the consumer's gln_bwd_means (common.hpp)
+                            const float gm = d.epi_gamma[wrow + mi * 32 + (g4 + j) * 4 + rsub];
+                            ba1 = fmaf(gm, rs1, ba1); ba2 = fmaf(gm, rs2, ba2);
+                        }
                     }
                 }
             }
@@ -289,6 +294,11 @@ struct GrpOps { float4 ext[GRP], aux[GRP], old[GRP]; float bs[GRP], rs[GRP]; };
     if (ef & SEP_EPI_PRELU_BWD) {
         const double s = block_sum_n<double, NW>((double)dalpha_e, red);
         if (tid == 0) atomicAdd(d.epi_dalpha, s);
+    }
+    if (do_bacc) {
+        const double s1 = block_sum_n<double, NW>((double)ba1, red);
+        const double s2 = block_sum_n<double, NW>((double)ba2, red);
+        if (tid == 0) { double* ba = d.epi_bacc + ((size_t)b * SEP_STATS_SLOTS + (blockIdx.x & (SEP_STATS_SLOTS - 1))) * 2; atomicAdd(ba, s1); atomicAdd(ba + 1, s2); }
     }
 }
 

@@ -295,8 +295,8 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(
     const float* __restrict__ dv2, const float* __restrict__ z, const float* __restrict__ a,
     const double* __restrict__ stats1, const float* __restrict__ gamma1, const float* __restrict__ beta1,
     const float* __restrict__ alpha1, const double* __restrict__ stats2, const float* __restrict__ gamma2,
-    const float* __restrict__ alpha2, const float* __restrict__ bsum2, const float* __restrict__ wd,
-    float* __restrict__ dv1, float* __restrict__ rowpart, int B, int C, int T, int ldt, int d, int dpad, float eps) {
+    const float* __restrict__ alpha2, const double* __restrict__ bacc2, const float* __restrict__ wd,
+    float* __restrict__ dv1, float* __restrict__ rowpart, double* __restrict__ bacc1, int B, int C, int T, int ldt, int d, int dpad, float eps) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ntile = (ldt + DW_TT - 1) / DW_TT;
@@ -321,7 +321,8 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(
         const float a1 = alpha1[0], a2 = alpha2[0];
         sc1 = gamma1[c] * r1; sh1 = beta1[c] - mu1 * sc1;
         const float g2 = gamma2[c];
-        const float mg = bsum2[2 * b], mgx = bsum2[2 * b + 1];
+        float mg, mgx;
+        gln_bwd_means(bacc2 + (size_t)b * SEP_STATS_SLOTS * 2, stats2 + (size_t)b * SEP_STATS_SLOTS * 2, (double)C * T, eps, mg, mgx);
         const size_t rowoff = ((size_t)b * C + c) * ldt;
         for (int q = lane; q < wlen / 4; q += 64) {
             const int tp = t0 - dpad + 4 * q;
@@ -381,6 +382,11 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(
     if (active && lane == 0) {
         float* rp = rowpart + (((size_t)b * C + c) * ntile + tile) * 8;
         rp[0] = q0; rp[1] = q1; rp[2] = q2; rp[3] = q3; rp[4] = q4; rp[5] = q5; rp[6] = q_dal; rp[7] = 0.f;
+        if (bacc1) {        // gLN1's gamma-weighted totals for the consumer of dv1 (gln_bwd_means)
+            double* ba = bacc1 + ((size_t)b * SEP_STATS_SLOTS + (g & (SEP_STATS_SLOTS - 1))) * 2;
+            const float g1 = gamma1[c];
+            atomicAdd(ba, (double)(g1 * q0)); atomicAdd(ba + 1, (double)(g1 * q1));
+        }
     }
 }
 
@@ -399,8 +405,8 @@ __global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
     const float* __restrict__ dv2, const float* __restrict__ z, const float* __restrict__ a,
     const double* __restrict__ stats1, const float* __restrict__ gamma1, const float* __restrict__ beta1,
     const float* __restrict__ alpha1, const double* __restrict__ stats2, const float* __restrict__ gamma2,
-    const float* __restrict__ alpha2, const float* __restrict__ bsum2, const float* __restrict__ wd,
-    float* __restrict__ dv1, float* __restrict__ rowpart, int C, int T, int ldt, int d, float eps) {
+    const float* __restrict__ alpha2, const double* __restrict__ bacc2, const float* __restrict__ wd,
+    float* __restrict__ dv1, float* __restrict__ rowpart, double* __restrict__ bacc1, int C, int T, int ldt, int d, float eps) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float part[4][8];
     float* dzs = lds;
@@ -413,7 +419,8 @@ __global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
     const float a1 = alpha1[0], a2 = alpha2[0];
     const float sc1 = gamma1[c] * r1, sh1 = beta1[c] - mu1 * sc1;
     const float g2 = gamma2[c];
-    const float mg = bsum2[2 * b], mgx = bsum2[2 * b + 1];
+    float mg, mgx;
+    gln_bwd_means(bacc2 + (size_t)b * SEP_STATS_SLOTS * 2, stats2 + (size_t)b * SEP_STATS_SLOTS * 2, (double)C * T, eps, mg, mgx);
     const size_t rowoff = (size_t)row * ldt;
     const int nq4 = ldt / 4;
     float q_dal = 0.f;
@@ -507,6 +514,11 @@ __global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
     float* rp = rowpart + (size_t)row * ntile * 8;
     for (int i = threadIdx.x; i < ntile * 8; i += 256)
         rp[i] = i < 8 ? (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]) : 0.f;
+    if (bacc1 && threadIdx.x < 2) {      // gLN1's gamma-weighted totals for the consumer of dv1 (gln_bwd_means)
+        const int i = threadIdx.x;
+        const float tot = (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]);
+        atomicAdd(bacc1 + ((size_t)b * SEP_STATS_SLOTS + (row & (SEP_STATS_SLOTS - 1))) * 2 + i, (double)(gamma1[c] * tot));
+    }
 }
 
 // =====================================================================================
@@ -564,8 +576,10 @@ __global__ __launch_bounds__(256) void gln_bwd_finalize_sample_kernel(const floa
     const double tgx = block_sum_256<double>(sgx, red);
     const double tal = block_sum_256<double>(sal, red);
     if (threadIdx.x == 0) {
-        bsum[2 * b] = (float)(tg / count);
-        bsum[2 * b + 1] = (float)(tgx / count);
+        if (bsum) {
+            bsum[2 * b] = (float)(tg / count);
+            bsum[2 * b + 1] = (float)(tgx / count);
+        }
         if (palpha) palpha[b] = (float)tal;
     }
 }
@@ -573,7 +587,7 @@ __global__ __launch_bounds__(256) void gln_bwd_finalize_sample_kernel(const floa
 // dw = r0*(gamma*dvw - mg - xhat*mgx) + dwm  [* (w>0)]   in place on dvw
 __global__ __launch_bounds__(256) void head_bwd_kernel(float* __restrict__ dvw, const float* __restrict__ w,
                                                        const float* __restrict__ dwm, const double* __restrict__ stats0,
-                                                       const float* __restrict__ gamma0, const float* __restrict__ bsum0,
+                                                       const float* __restrict__ gamma0, const double* __restrict__ bacc0,
                                                        int C, int T, int ldt, double count, float eps, int relu) {
     const int row = blockIdx.y;            // b*C + c
     const int b = row / C, c = row % C;
@@ -581,7 +595,9 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(float* __restrict__ dvw, 
     if (t4 >= ldt) return;
     float mu, rstd;
     gln_mu_rstd(stats0 + (size_t)b * SEP_STATS_SLOTS * 2, count, eps, mu, rstd);
-    const float gc = gamma0[c], mg = bsum0[2 * b], mgx = bsum0[2 * b + 1];
+    const float gc = gamma0[c];
+    float mg, mgx;
+    gln_bwd_means(bacc0 + (size_t)b * SEP_STATS_SLOTS * 2, stats0 + (size_t)b * SEP_STATS_SLOTS * 2, count, eps, mg, mgx);
     const size_t off = (size_t)row * ldt + t4;
     const float4 g = ld4(dvw + off), ww = ld4(w + off), dm = ld4(dwm + off);
     const float g4[4] = {g.x, g.y, g.z, g.w}, w4[4] = {ww.x, ww.y, ww.z, ww.w}, m4[4] = {dm.x, dm.y, dm.z, dm.w};
@@ -1048,16 +1064,16 @@ extern "C" int sep_dwconv_fwd(const float* a, const double* stats1, const float*
 
 extern "C" int sep_dwconv_bwd(const float* dv2, const float* z, const float* a, const double* stats1, const float* gamma1,
                               const float* beta1, const float* alpha1, const double* stats2, const float* gamma2,
-                              const float* alpha2, const float* bsum2, const float* wd, float* dv1, float* rowpart,
-                              int B, int C, int T, int ldt, int dilation, float eps, sep_stream_t stream) {
-    SEP_REQUIRE(dv2 && z && a && stats1 && gamma1 && beta1 && alpha1 && stats2 && gamma2 && alpha2 && bsum2 && wd && dv1 && rowpart, "sep_dwconv_bwd: null pointer");
+                              const float* alpha2, const double* bacc2, const float* wd, float* dv1, float* rowpart,
+                              double* bacc1, int B, int C, int T, int ldt, int dilation, float eps, sep_stream_t stream) {
+    SEP_REQUIRE(dv2 && z && a && stats1 && gamma1 && beta1 && alpha1 && stats2 && gamma2 && alpha2 && bacc2 && wd && dv1 && rowpart, "sep_dwconv_bwd: null pointer");
     SEP_REQUIRE(B > 0 && C > 0 && T > 0 && ldt % 128 == 0 && ldt >= T, "sep_dwconv_bwd: bad sizes");
     SEP_REQUIRE(dilation >= 1 && dilation <= 2048, "sep_dwconv_bwd: dilation %d out of range [1, 2048]", dilation);
     static const bool force_tiles = getenv("SEPK_DWCONV_LDS") != nullptr;
     if (!force_tiles && ldt <= 8192 && (long)B * C <= 0x7fffffffL) {        // the row (ldt floats of LDS, ldt / 1024 float4 triples in registers)
         const size_t rsmem = (size_t)ldt * sizeof(float);
         const dim3 grid((unsigned)((long)B * C));
-#define SEP_DWB(AL, NIT) hipLaunchKernelGGL((dwconv_bwd_row_kernel<AL, NIT>), grid, dim3(256), rsmem, (hipStream_t)stream, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bsum2, wd, dv1, rowpart, C, T, ldt, dilation, eps)
+#define SEP_DWB(AL, NIT) hipLaunchKernelGGL((dwconv_bwd_row_kernel<AL, NIT>), grid, dim3(256), rsmem, (hipStream_t)stream, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bacc2, wd, dv1, rowpart, bacc1, C, T, ldt, dilation, eps)
         if (dilation % 4 == 0) { if (ldt <= 4096) SEP_DWB(true, 4); else SEP_DWB(true, 8); }
         else { if (ldt <= 4096) SEP_DWB(false, 4); else SEP_DWB(false, 8); }
 #undef SEP_DWB
@@ -1067,7 +1083,7 @@ extern "C" int sep_dwconv_bwd(const float* dv2, const float* z, const float* a, 
     const int dpad = (dilation + 3) & ~3;
     const size_t smem = 4 * 2 * (size_t)(DW_TT + 2 * dpad) * sizeof(float);
     const long total = (long)B * C * ceil_div(ldt, DW_TT);
-    hipLaunchKernelGGL(dwconv_bwd_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), smem, (hipStream_t)stream, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bsum2, wd, dv1, rowpart, B, C, T, ldt, dilation, dpad, eps);
+    hipLaunchKernelGGL(dwconv_bwd_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), smem, (hipStream_t)stream, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bacc2, wd, dv1, rowpart, bacc1, B, C, T, ldt, dilation, dpad, eps);
     SEP_CHECK_LAUNCH("sep_dwconv_bwd");
     return 0;
 }
@@ -1075,7 +1091,7 @@ extern "C" int sep_dwconv_bwd(const float* dv2, const float* z, const float* a, 
 extern "C" int sep_gln_bwd_finalize(const float* rowpart, int ntile, int nq, const double* stats, const float* gamma,
                                     double count, float eps, float* bsum, float* pbeta, float* pgamma, float* pextra,
                                     int B, int C, sep_stream_t stream) {
-    SEP_REQUIRE(rowpart && stats && gamma && bsum && pbeta && pgamma, "sep_gln_bwd_finalize: null pointer");
+    SEP_REQUIRE(rowpart && stats && gamma && pbeta && pgamma, "sep_gln_bwd_finalize: null pointer");
     SEP_REQUIRE(nq == 2 || nq == 8, "sep_gln_bwd_finalize: nq must be 2 or 8 (got %d)", nq);
     SEP_REQUIRE(nq == 2 || pextra, "sep_gln_bwd_finalize: nq == 8 needs pextra");
     // pextra layout for nq == 8: B slabs of 4C floats [db[C] | dw[C][3]], then palpha[B], then B*C floats of scratch
@@ -1083,18 +1099,19 @@ extern "C" int sep_gln_bwd_finalize(const float* rowpart, int ntile, int nq, con
     float* scratch = (nq == 8) ? palpha + B : nullptr;
     const long rows = (long)B * C;
     hipLaunchKernelGGL(gln_bwd_finalize_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rowpart, ntile, nq, stats, count, eps, pbeta, pgamma, pextra, scratch, B, C);
-    hipLaunchKernelGGL(gln_bwd_finalize_sample_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pbeta, pgamma, gamma, scratch, count, bsum, palpha, C);
+    if (bsum || palpha)      // the per-sample stage: the means (stand-alone gLN backward) and / or the PReLU slope partials
+        hipLaunchKernelGGL(gln_bwd_finalize_sample_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pbeta, pgamma, gamma, scratch, count, bsum, palpha, C);
     SEP_CHECK_LAUNCH("sep_gln_bwd_finalize");
     return 0;
 }
 
 extern "C" int sep_head_bwd(float* dvw, const float* w, const float* dwm, const double* stats0, const float* gamma0,
-                            const float* bsum0, int B, int C, int T, int ldt, double count, float eps, int relu,
+                            const double* bacc0, int B, int C, int T, int ldt, double count, float eps, int relu,
                             sep_stream_t stream) {
-    SEP_REQUIRE(dvw && w && dwm && stats0 && gamma0 && bsum0 && ldt % 4 == 0, "sep_head_bwd: bad arguments");
+    SEP_REQUIRE(dvw && w && dwm && stats0 && gamma0 && bacc0 && ldt % 4 == 0, "sep_head_bwd: bad arguments");
     SEP_REQUIRE((long)B * C <= 65535, "sep_head_bwd: B*C too large for grid.y");
     dim3 grid(ceil_div(ldt, 1024), B * C);
-    hipLaunchKernelGGL(head_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dvw, w, dwm, stats0, gamma0, bsum0, C, T, ldt, count, eps, relu);
+    hipLaunchKernelGGL(head_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dvw, w, dwm, stats0, gamma0, bacc0, C, T, ldt, count, eps, relu);
     SEP_CHECK_LAUNCH("sep_head_bwd");
     return 0;
 }

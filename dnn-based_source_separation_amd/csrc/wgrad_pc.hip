@@ -392,7 +392,11 @@ template <int WR, int WC, int XMODE>
 void launch_wpc(const sep_wgrad_desc& d, hipStream_t stream) {
     const int ntiles = (d.M / (64 * WR)) * (d.N / (128 * WC));
     const int grid = 8 * ntiles * ceil_div(d.nsplit, 8);
-    hipLaunchKernelGGL((pw_wgrad_pc_kernel<WR, WC, XMODE, 2>), dim3(grid), dim3(512), 0, stream, d);
+    // raw-ring depth NS: a DMA has NS - 1 chunk periods to land (SEPK_WPC_NS = 2 | 3 | 4 for A/B runs)
+    static const int ns = getenv("SEPK_WPC_NS") ? atoi(getenv("SEPK_WPC_NS")) : 2;
+    if (ns == 4) hipLaunchKernelGGL((pw_wgrad_pc_kernel<WR, WC, XMODE, 4>), dim3(grid), dim3(512), 0, stream, d);
+    else if (ns == 3) hipLaunchKernelGGL((pw_wgrad_pc_kernel<WR, WC, XMODE, 3>), dim3(grid), dim3(512), 0, stream, d);
+    else hipLaunchKernelGGL((pw_wgrad_pc_kernel<WR, WC, XMODE, 2>), dim3(grid), dim3(512), 0, stream, d);
 }
 
 }  // namespace

@@ -257,8 +257,9 @@ def tail_backward(cfg, P, geo, w, core, m, mixture_shape, d_est, G, dalpha_slot,
     return dcore, dwm
 
 
-def head_backward(cfg, P, geo, stats0, w, mixture, dx0, dwm, G, PK=None):
-    """Backward of head_forward given dx0 = d(bottleneck output) and dwm = d(w) arriving through mask*w."""
+def head_backward(cfg, P, geo, stats0, w, mixture, dx0, dwm, G, PK=None, bacc0=None):
+    """Backward of head_forward given dx0 = d(bottleneck output) and dwm = d(w) arriving through mask*w.
+    bacc0 (B, SLOTS, 2) fp64 zeros: receives the gamma-weighted row-sum totals of the first gLN's backward (see _backward)."""
     K = backend()
     B, Cin, T_in = mixture.shape
     N, L, S = cfg["n_basis"], cfg["kernel_size"], cfg["stride"]
@@ -274,17 +275,18 @@ def head_backward(cfg, P, geo, stats0, w, mixture, dx0, dwm, G, PK=None):
     part, pb, ns = _wgrad(K, B, F, ldt, eps, f32, Bn, N, dx0, w, True, x_mode=PRO_GLN, x_stats=stats0, x_gamma=g0, x_beta=b0, count=cnt0)
     dvw = torch.empty(B, N, ldt, **f32)
     rp0 = torch.empty(B, N, nt64, 2, **f32)
+    if bacc0 is None:
+        bacc0 = torch.zeros(B, STATS_SLOTS, 2, device=w.device, dtype=torch.float64)
     K.pw_gemm(B=B, M=N, K=Bn, T=F, ldt=ldt, trans_a=1, A=Wb, A_pk=(PK or {}).get("bottleneck^T"), X=dx0, Y=dvw, epi_flags=EPI_ROWSUMS, epi_aux=w,
-              epi_rowpart=rp0, eps=eps)
-    bsum0 = torch.empty(B, 2, **f32)
+              epi_rowpart=rp0, epi_gamma=g0, epi_bacc=bacc0, eps=eps)
+    K.head_bwd(dvw, w, dwm, stats0, g0, bacc0, B, N, F, ldt, cnt0, eps, relu)
     pbeta0 = torch.empty(B, N, **f32)
     pgamma0 = torch.empty(B, N, **f32)
-    K.gln_bwd_finalize(rp0, nt64, 2, stats0, g0, cnt0, eps, bsum0, pbeta0, pgamma0, None, B, N)
+    K.gln_bwd_finalize(rp0, nt64, 2, stats0, g0, cnt0, eps, None, pbeta0, pgamma0, None, B, N)      # parameter gradients only
     K.reduce_slabs([(part, 0, G["separator.bottleneck_conv1d.weight"], Bn * N, ns, Bn * N, 0, 1.0),
                     (pb, 0, G["separator.bottleneck_conv1d.bias"], Bn, ns, Bn, 0, 1.0),
                     (pbeta0, 0, G["separator.norm1d.norm.bias"], N, B, N, 0, 1.0),
                     (pgamma0, 0, G["separator.norm1d.norm.weight"], N, B, N, 0, 1.0)])
-    K.head_bwd(dvw, w, dwm, stats0, g0, bsum0, B, N, F, ldt, cnt0, eps, relu)
     Fx = torch.empty(B, Cin * L, ldt, **f32)
     K.unfold(mixture, Fx, B, Cin, T_in, L, S, F, ldt, geo.pad_left)
     part, _, ns = _wgrad(K, B, F, ldt, eps, f32, N, Cin * L, dvw, Fx, False)
@@ -455,6 +457,12 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
     chunks = B * (ldt // 32)
     nt64, nt1024 = ldt // 64, (ldt + 1023) // 1024
     dalpha = torch.zeros(nl + 1, device=dev, dtype=torch.float64)   # [layer alpha1 ..., mask prelu]
+    # gLN backward needs two per-sample means of the incoming gradient (mean(gamma g), mean(gamma g xhat)) before any element of the
+    # input gradient can be formed.  The kernel that PRODUCES g accumulates the raw gamma-weighted row-sum totals into these slots
+    # (fp64 atomics, laid out like `stats`: [0] first gLN, [1 + 2 li] / [2 + 2 li] gLN1 / gLN2 of layer li) and the kernel that consumes
+    # g forms the means itself (gln_bwd_means, csrc/common.hpp): no second-stage launch between them.  sep_gln_bwd_finalize still turns
+    # the row partials into the parameter gradients, as a leaf on the side stream.
+    bacc = torch.zeros(2 * nl + 1, B, STATS_SLOTS, 2, device=dev, dtype=torch.float64)
 
     def wgrad(M, Nn, Gt, Xt, dW, dbias=None, Bq=B, weps=None, **kw):
         return _wgrad(K, B, F, ldt, eps, f32, M, Nn, Gt, Xt, dbias is not None, Bq=Bq, weps=weps, **kw)
@@ -486,7 +494,7 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
         # dv2 = Wo^T dout + Ws^T dS, with the row sums the gLN2 backward needs
         dv2 = torch.empty(B, H, ldt, **f32)
         rp2 = torch.empty(B, H, nt64, 2, **f32)
-        epi = dict(epi_flags=EPI_ROWSUMS | EPI_ROWSUMS_PRELU, epi_aux=z, epi_alpha=al2, epi_rowpart=rp2, eps=teps)
+        epi = dict(epi_flags=EPI_ROWSUMS | EPI_ROWSUMS_PRELU, epi_aux=z, epi_alpha=al2, epi_rowpart=rp2, epi_gamma=g2, epi_bacc=bacc[2 + 2 * li], eps=teps)
         if dual:
             Wo = P[sp + "output_pointwise_conv1d.weight"]
             if "heads.{}^T".format(li) in PK:
@@ -496,10 +504,8 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
                 K.pw_gemm(B=B, M=H, K=Bn + Sc, T=F, ldt=ldt, trans_a=1, A=Wo, A2=Ws, X=dout, X2=dS, k_split=Bn, Y=dv2, **epi)
         else:
             K.pw_gemm(B=B, M=H, K=Sc, T=F, ldt=ldt, trans_a=1, A=Ws, A_pk=PK.get("skip.{}^T".format(li)), X=dS, Y=dv2, **epi)
-        bsum2 = torch.empty(B, 2, **f32)
         pbeta2 = torch.empty(B, H, **f32)
         pgamma2 = torch.empty(B, H, **f32)
-        K.gln_bwd_finalize(rp2, nt64, 2, st2, g2, cnt, teps, bsum2, pbeta2, pgamma2, None, B, H)
 
         # head weight gradients: dWo = sum dout v2^T, dWs = sum dS v2^T   (v2 = gLN2(PReLU(z)) rebuilt on load).
         # Leaves of the graph: they run on the side stream, under this layer's input-gradient chain.
@@ -529,13 +535,11 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
         # depthwise^T and everything hanging off it
         dv1 = torch.empty(B, H, ldt, **f32)
         rp1 = torch.empty(B, H, nt1024, 8, **f32)
-        K.dwconv_bwd(dv2, z, a, st1, g1, b1, al1, st2, g2, al2, bsum2, P[sp + "depthwise_conv1d.weight"], dv1, rp1,
-                     B, H, F, ldt, dil, teps)
-        bsum1 = torch.empty(B, 2, **f32)
+        K.dwconv_bwd(dv2, z, a, st1, g1, b1, al1, st2, g2, al2, bacc[2 + 2 * li], P[sp + "depthwise_conv1d.weight"], dv1, rp1,
+                     bacc[1 + 2 * li], B, H, F, ldt, dil, teps)
         pbeta1 = torch.empty(B, H, **f32)
         pgamma1 = torch.empty(B, H, **f32)
         pextra = torch.empty(B * 4 * H + B + B * H, **f32)
-        K.gln_bwd_finalize(rp1, nt1024, 8, st1, g1, cnt, teps, bsum1, pbeta1, pgamma1, pextra, B, H)
         pending += [
             (pbeta2, 0, G[sp + "norm1d.norm.bias"], H, B, H, 0, 1.0),
             (pgamma2, 0, G[sp + "norm1d.norm.weight"], H, B, H, 0, 1.0),
@@ -552,13 +556,16 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
         # with several row tiles the other tiles still need the untouched dv1, so da goes to its own buffer
         da = dv1 if Bn <= 128 else torch.empty_like(dv1)
         K.pw_gemm(B=B, M=Bn, K=H, T=F, ldt=ldt, trans_a=1, A=P[pre + "bottleneck_conv1d.weight"], A_pk=PK.get("conv1.{}^T".format(li)),
-                  X=dv1, Y=dx, pro_mode=PRO_GLN_BWD, pro_stats=st1, pro_gamma=g1, pro_alpha=al1, pro_aux=a, pro_bsum=bsum1,
+                  X=dv1, Y=dx, pro_mode=PRO_GLN_BWD, pro_stats=st1, pro_gamma=g1, pro_alpha=al1, pro_aux=a, pro_bacc=bacc[1 + 2 * li],
                   pro_store=da, pro_dalpha=dalpha[li:li + 1], count=cnt, eps=teps,
                   epi_flags=(EPI_RESIDUAL if dout is not None else 0), epi_res=dout)
         # da and dx now exist: the side stream may go on (this layer's dW1, the next layer's head gradients)
         side.fork()
-        side.keep(da, dx)
+        side.keep(da, dx, rp2, rp1, pbeta2, pgamma2, pbeta1, pgamma1, pextra)
         with side:
+            # second stage of the two gLN backwards of this layer: parameter gradients only, nothing in the chain waits for it
+            K.gln_bwd_finalize(rp2, nt64, 2, st2, g2, cnt, teps, None, pbeta2, pgamma2, None, B, H)
+            K.gln_bwd_finalize(rp1, nt1024, 8, st1, g1, cnt, teps, None, pbeta1, pgamma1, pextra, B, H)
             part, pb, ns = wgrad(H, Bn, da, x, True, True)
             segs = [(part, 0, G[pre + "bottleneck_conv1d.weight"], H * Bn, ns, H * Bn, 0, 1.0),
                     (pb, 0, G[pre + "bottleneck_conv1d.bias"], H, ns, H, 0, 1.0)]
@@ -596,4 +603,4 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
     K.reduce_slabs(pending)
 
     # ---- head: bottleneck conv, first gLN, encoder ------------------------------------------------------
-    head_backward(cfg, P, geo, stats[0], w, mixture, dout, dwm, G, PK)
+    head_backward(cfg, P, geo, stats[0], w, mixture, dout, dwm, G, PK, bacc[0])

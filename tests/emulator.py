@@ -48,6 +48,16 @@ def _mu_rstd(stats, count, eps, dtype):
     return m.to(dtype).view(-1, 1, 1), (1.0 / torch.sqrt(var + eps)).to(dtype).view(-1, 1, 1)
 
 
+def _bwd_means(bacc, stats, count, eps, dtype):
+    """gln_bwd_means of csrc/common.hpp: mean(gamma g), mean(gamma g xhat) per sample from the producers' raw slotted sums
+    {sum_c gamma_c sum_t g, sum_c gamma_c sum_t g u} and the gLN's statistics, in fp64"""
+    st, ba = _tot(stats), _tot(bacc)
+    m = st[:, 0] / count
+    var = (st[:, 1] / count - m * m).clamp_min(0.0)
+    r = 1.0 / torch.sqrt(var + eps)
+    return (ba[:, 0] / count).to(dtype).view(-1, 1, 1), (r * (ba[:, 1] - m * ba[:, 0]) / count).to(dtype).view(-1, 1, 1)
+
+
 class EmuBackend:
     name = "emulator"
 
@@ -63,9 +73,9 @@ class EmuBackend:
 
     def pw_gemm(self, *, B, M, K, T, ldt, A, X, Y, trans_a=0, A2=None, X2=None, k_split=0, Y2=None, m_split=0,
                 pro_mode=PRO_NONE, epi_flags=0, accumulate=0, eps=1e-12, count=0.0, bias=None, pro_alpha=None,
-                pro_stats=None, pro_gamma=None, pro_beta=None, pro_aux=None, pro_bsum=None, pro_store=None,
+                pro_stats=None, pro_gamma=None, pro_beta=None, pro_aux=None, pro_bacc=None, pro_store=None,
                 pro_dalpha=None, epi_alpha=None, epi_stats=None, epi_res=None, epi_aux=None, epi_dalpha=None,
-                epi_rowpart=None, arith=None, a_amax=None, A_pk=None):
+                epi_rowpart=None, epi_gamma=None, epi_bacc=None, arith=None, a_amax=None, A_pk=None):
         dt = X.dtype
         k1 = k_split if k_split else K
         if trans_a:
@@ -102,7 +112,7 @@ class EmuBackend:
             a = pro_aux.reshape(B, K, ldt)
             u = _prelu(a, pro_alpha)
             xh = (u - mu) * rstd
-            mg, mgx = pro_bsum[:, 0].view(B, 1, 1), pro_bsum[:, 1].view(B, 1, 1)
+            mg, mgx = _bwd_means(pro_bacc, pro_stats, count, eps, dt)
             du = rstd * (pro_gamma.view(1, K, 1) * Xf - mg - xh * mgx)
             da = torch.where(valid, du * _prelu_grad(a, pro_alpha), torch.zeros_like(du))
             pro_dalpha += torch.where(valid & (a <= 0), du * a, torch.zeros_like(du)).sum().double()
@@ -133,6 +143,9 @@ class EmuBackend:
             rp = epi_rowpart.reshape(B, M, ldt // 64, 2)
             rp[..., 0] = yv.reshape(B, M, ldt // 64, 64).sum(-1)
             rp[..., 1] = (yv * u).reshape(B, M, ldt // 64, 64).sum(-1)
+            if epi_bacc is not None:
+                gm = epi_gamma.reshape(1, M, 1).to(dt)
+                _acc(epi_bacc, (gm * yv).sum((1, 2)), (gm * yv * u).sum((1, 2)))
         y = torch.where(valid, y, torch.zeros_like(y))
         if m_split:
             Y.reshape(B, Mf, ldt).copy_(y[:, :Mf])
@@ -270,7 +283,7 @@ class EmuBackend:
         u = _prelu(zz, alpha2)
         _acc(stats2, u.sum((1, 2)), (u * u).sum((1, 2)))
 
-    def dwconv_bwd(self, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bsum2, wd, dv1, rowpart, B, C, T,
+    def dwconv_bwd(self, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bacc2, wd, dv1, rowpart, bacc1, B, C, T,
                    ldt, dilation, eps):
         dt = a.dtype
         d = dilation
@@ -282,7 +295,8 @@ class EmuBackend:
         g = dv2.reshape(B, C, ldt)[:, :, :T]
         u2 = _prelu(zz, alpha2)
         xh = (u2 - mu2) * r2
-        du2 = r2 * (gamma2.view(1, C, 1) * g - bsum2[:, 0].view(B, 1, 1) - xh * bsum2[:, 1].view(B, 1, 1))
+        mg2, mgx2 = _bwd_means(bacc2, stats2, cnt, eps, dt)
+        du2 = r2 * (gamma2.view(1, C, 1) * g - mg2 - xh * mgx2)
         dz = du2 * _prelu_grad(zz, alpha2)
         dal = torch.where(zz <= 0, du2 * zz, torch.zeros_like(zz)).sum(2)
         u1 = _prelu(aa, alpha1)
@@ -308,6 +322,9 @@ class EmuBackend:
         rp[:, :, 0, 4] = (dz * v1).sum(2)
         rp[:, :, 0, 5] = (dz * v1p[:, :, 2 * d:2 * d + T]).sum(2)
         rp[:, :, 0, 6] = dal
+        if bacc1 is not None:
+            g1 = gamma1.view(1, C, 1).to(dt)
+            _acc(bacc1, (g1 * dv).sum((1, 2)), (g1 * dv * u1).sum((1, 2)))
 
     def gln_bwd_finalize(self, rowpart, ntile, nq, stats, gamma, count, eps, bsum, pbeta, pgamma, pextra, B, C):
         dt = rowpart.dtype
@@ -317,8 +334,9 @@ class EmuBackend:
         pg = rstd.view(B, 1) * (R2 - mu.view(B, 1) * R1)
         pbeta.reshape(B, C).copy_(R1)
         pgamma.reshape(B, C).copy_(pg)
-        bsum.reshape(B, 2)[:, 0] = (gamma.view(1, C) * R1).sum(1) / count
-        bsum.reshape(B, 2)[:, 1] = (gamma.view(1, C) * pg).sum(1) / count
+        if bsum is not None:
+            bsum.reshape(B, 2)[:, 0] = (gamma.view(1, C) * R1).sum(1) / count
+            bsum.reshape(B, 2)[:, 1] = (gamma.view(1, C) * pg).sum(1) / count
         if nq == 8:
             pe = pextra.reshape(-1)
             slab = pe[:B * 4 * C].reshape(B, 4 * C)
@@ -327,13 +345,14 @@ class EmuBackend:
             pe[B * 4 * C:B * 4 * C + B] = rp[..., 6].sum(1)
             pe[B * 4 * C + B:B * 4 * C + B + B * C] = rp[..., 6].reshape(-1)      # per-row scratch of the two-kernel finalize
 
-    def head_bwd(self, dvw, w, dwm, stats0, gamma0, bsum0, B, C, T, ldt, count, eps, relu):
+    def head_bwd(self, dvw, w, dwm, stats0, gamma0, bacc0, B, C, T, ldt, count, eps, relu):
         dt = w.dtype
         mu, rstd = _mu_rstd(stats0, count, eps, dt)
         g = dvw.reshape(B, C, ldt)
         wv = w.reshape(B, C, ldt)
         xh = (wv - mu) * rstd
-        v = rstd * (gamma0.view(1, C, 1) * g - bsum0[:, 0].view(B, 1, 1) - xh * bsum0[:, 1].view(B, 1, 1)) + dwm.reshape(B, C, ldt)
+        mg, mgx = _bwd_means(bacc0, stats0, count, eps, dt)
+        v = rstd * (gamma0.view(1, C, 1) * g - mg - xh * mgx) + dwm.reshape(B, C, ldt)
         if relu:
             v = torch.where(wv > 0, v, torch.zeros_like(v))
         v[:, :, T:] = 0

@@ -75,6 +75,15 @@ def stats_of(x, T):
     return (tot.unsqueeze(1) * w.view(1, SLOTS, 1)).contiguous()
 
 
+def bacc_rand(B, count, scale=0.01):
+    """slotted gLN-backward accumulators (sep_gemm_desc.pro_bacc / epi_bacc): random raw sums {sum gamma g, sum gamma g u} of the size
+    `scale * count`, spread unevenly over the slots"""
+    tot = (torch.randn(B, 2, generator=G) * scale * count).double()
+    w = torch.rand(SLOTS, generator=G).double()
+    w = w / w.sum()
+    return (tot.unsqueeze(1) * w.view(1, SLOTS, 1)).contiguous()
+
+
 def to_device(t):
     """where the second copy of every buffer lives (tests/test_kernel_source_on_host_cpu.py swaps HIP, to_device and device_sync to run
     these same cases on the host simulation of the kernel sources)"""
@@ -228,7 +237,9 @@ def test_gemm_dgrad_two_sources_rowsums(arith):
     dout, dS, z = padded(B, Bn, T, ldt), padded(B, Sc, T, ldt), padded(B, H, T, ldt)
     kw = dict(B=B, M=H, K=Bn + Sc, T=T, ldt=ldt, trans_a=1, A=Wo, A2=Ws, X=dout, X2=dS, k_split=Bn, Y=nan(B, H, ldt),
               epi_flags=EPI_ROWSUMS | EPI_ROWSUMS_PRELU, epi_aux=z, epi_alpha=torch.tensor([0.15]),
-              epi_rowpart=nan(B, H, ldt // 64, 2))
+              epi_rowpart=nan(B, H, ldt // 64, 2), epi_gamma=rnd(H) + 1, epi_bacc=zstats(B))
+    both("pw_gemm", [], kw)
+    kw.update(Y=nan(B, H, ldt), epi_rowpart=nan(B, H, ldt // 64, 2), epi_gamma=None, epi_bacc=None)      # the stand-alone form: row partials only
     both("pw_gemm", [], kw)
 
 
@@ -251,7 +262,7 @@ def test_gemm_gln_bwd_prologue(residual, arith):
     st = stats_of(u, T)
     dv = padded(B, K, T, ldt)
     kw = dict(B=B, M=M, K=K, T=T, ldt=ldt, trans_a=1, A=W1, X=dv, Y=nan(B, M, ldt), pro_mode=PRO_GLN_BWD, pro_stats=st,
-              pro_gamma=rnd(K) + 1, pro_alpha=torch.tensor([0.2]), pro_aux=a, pro_bsum=rnd(B, 2, scale=0.01), pro_store=dv,
+              pro_gamma=rnd(K) + 1, pro_alpha=torch.tensor([0.2]), pro_aux=a, pro_bacc=bacc_rand(B, K * T), pro_store=dv,
               pro_dalpha=torch.zeros(1, dtype=torch.float64), count=K * T, eps=1e-12)
     if residual:
         kw.update(epi_flags=EPI_RESIDUAL, epi_res=padded(B, M, T, ldt))
@@ -267,7 +278,7 @@ def test_gemm_gln_bwd_prologue_several_row_tiles(M, K, arith):
     dv = padded(B, K, T, ldt)
     kw = dict(B=B, M=M, K=K, T=T, ldt=ldt, trans_a=1, A=rnd(K, M, scale=0.1), X=dv, Y=nan(B, M, ldt), pro_mode=PRO_GLN_BWD,
               pro_stats=stats_of(torch.where(a > 0, a, 0.2 * a), T), pro_gamma=rnd(K) + 1, pro_alpha=torch.tensor([0.2]), pro_aux=a,
-              pro_bsum=rnd(B, 2, scale=0.01), pro_store=nan(B, K, ldt), pro_dalpha=torch.full((1,), 100.0, dtype=torch.float64), count=K * T, eps=1e-12,
+              pro_bacc=bacc_rand(B, K * T), pro_store=nan(B, K, ldt), pro_dalpha=torch.full((1,), 100.0, dtype=torch.float64), count=K * T, eps=1e-12,
               epi_flags=EPI_RESIDUAL, epi_res=padded(B, M, T, ldt))
     both("pw_gemm", [], kw)
     kw["pro_store"] = kw["X"]
@@ -300,7 +311,7 @@ def test_gemm_prelu_prologues_any_slope(alpha):
         dv = padded(B, K, T, ldt)
         both("pw_gemm", [], dict(B=B, M=M, K=K, T=T, ldt=ldt, trans_a=1, A=rnd(K, M, scale=0.1), X=dv, Y=nan(B, M, ldt), pro_mode=PRO_GLN_BWD,
                                  pro_stats=stats_of(torch.where(a > 0, a, alpha * a), T), pro_gamma=rnd(K) + 1, pro_alpha=al, pro_aux=a,
-                                 pro_bsum=rnd(B, 2, scale=0.01), pro_store=dv, pro_dalpha=torch.zeros(1, dtype=torch.float64), count=K * T, eps=1e-12,
+                                 pro_bacc=bacc_rand(B, K * T), pro_store=dv, pro_dalpha=torch.zeros(1, dtype=torch.float64), count=K * T, eps=1e-12,
                                  epi_flags=EPI_RESIDUAL, epi_res=padded(B, M, T, ldt)))
     finally:
         PACKED[0] = False
@@ -526,7 +537,7 @@ def test_dwconv_fwd_bwd(T, d):
     # backward on the emulator's z / stats2 (identical inputs for both)
     dv2 = padded(B, C, T, ldt)
     ntile = (ldt + 1023) // 1024
-    args = [dv2, z, a, st1, g1, b1, a1, st2, rnd(C) + 1, a2, rnd(B, 2, scale=0.01), wd, nan(B, C, ldt), nan(B, C, ntile, 8), B, C, T, ldt, d, 1e-12]
+    args = [dv2, z, a, st1, g1, b1, a1, st2, rnd(C) + 1, a2, bacc_rand(B, C * T), wd, nan(B, C, ldt), nan(B, C, ntile, 8), zstats(B), B, C, T, ldt, d, 1e-12]
     gargs = [to_device(v) if torch.is_tensor(v) else v for v in args]
     EMU.dwconv_bwd(*args)
     HIP.dwconv_bwd(*gargs)
@@ -535,6 +546,9 @@ def test_dwconv_fwd_bwd(T, d):
     assert (args[12] - gargs[12].cpu()).abs().max() <= 2e-4 * args[12].abs().max()
     rc, rg = args[13].double().sum(2), gargs[13].cpu().double().sum(2)          # per-tile partials -> per-row totals
     assert (rc - rg).abs().max() <= 3e-4 * rc.abs().max()
+    bc, bg = args[14].sum(1), gargs[14].cpu().sum(1)                              # gLN1's gamma-weighted totals (slots -> totals)
+    assert (bc - bg).abs().max() <= 3e-4 * bc.abs().max()
+    assert torch.allclose(bc[:, 0], (g1.view(1, C).double() * rc[..., 0]).sum(1), rtol=1e-5, atol=1e-6 * bc.abs().max().item())
 
 
 @pytest.mark.parametrize("Kw,stride,pad,dil,Tin", [(3, 1, 1, 1, 300), (5, 2, 4, 2, 257), (4, 4, 0, 1, 64), (3, 1, 8, 8, 1000), (16, 8, 0, 1, 403)])
@@ -558,13 +572,14 @@ def test_gln_bwd_finalize(nq, ntile):
     st = stats_of(x, 50)
     pextra = nan(B * 4 * C + B + B * C) if nq == 8 else None
     both("gln_bwd_finalize", [rp, ntile, nq, st, rnd(C) + 1, C * 50.0, 1e-12, nan(B, 2), nan(B, C), nan(B, C), pextra, B, C])
+    both("gln_bwd_finalize", [rp, ntile, nq, st, rnd(C) + 1, C * 50.0, 1e-12, None, nan(B, C), nan(B, C), pextra, B, C])      # without the means
 
 
 @pytest.mark.parametrize("relu", [0, 1])
 def test_head_bwd(relu):
     B, C, T, ldt = 2, 64, 300, 384
     w = padded(B, C, T, ldt)
-    both("head_bwd", [padded(B, C, T, ldt), w, padded(B, C, T, ldt), stats_of(w, T), rnd(C) + 1, rnd(B, 2, scale=0.01), B, C, T, ldt, C * float(T), 1e-12, relu])
+    both("head_bwd", [padded(B, C, T, ldt), w, padded(B, C, T, ldt), stats_of(w, T), rnd(C) + 1, bacc_rand(B, C * T), B, C, T, ldt, C * float(T), 1e-12, relu])
 
 
 # ------------------------------------------------------------------------------------------- decoder
