@@ -954,7 +954,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(const sep_wgrad_desc d
         c = cn;
     }
 
-    auto put_tile = [&](auto atomic_c) {                // accumulate: onto slab 0 with atomics; else a plain store into slab s
+    auto put_tile = [&](auto atomic_c) {                // a plain store into slab s
         constexpr bool AT = decltype(atomic_c)::value;
         float* out = d.partial + (AT ? 0 : (size_t)s * d.M * d.N);
 #pragma unroll
@@ -972,8 +972,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(const sep_wgrad_desc d
             }
         if (do_bias && tid < BM && (m0 + tid) < d.M) wg_put<AT>(d.partial_bias + (AT ? 0 : (size_t)s * d.M) + m0 + tid, bias_acc);
     };
-    if (d.accumulate) put_tile(std::true_type{});
-    else put_tile(std::false_type{});
+    put_tile(std::false_type{});
 }
 
 
@@ -1236,8 +1235,7 @@ __global__ __launch_bounds__(512, 4) void pw_wgrad_direct_kernel(const sep_wgrad
                 if (lk == 0 && row < d.M) wg_put<AT>(d.partial_bias + (AT ? 0 : (size_t)s * d.M) + row, tot);
             }
         };
-        if (d.accumulate) put_tile(std::true_type{});
-        else put_tile(std::false_type{});
+        put_tile(std::false_type{});
     };
     if (grp == 0) finish(acc[0], bias_acc[0], sm.rstd, 0);
     else finish(acc[1], bias_acc[1], sm.mu, 1);
@@ -1490,8 +1488,7 @@ __global__ __launch_bounds__(256, 3) void pw_wgrad_split_kernel(const sep_wgrad_
             }
         }
     };
-    if (d.accumulate) put_tile(std::true_type{});
-    else put_tile(std::false_type{});
+    put_tile(std::false_type{});
 }
 
 // ======================================================================================
@@ -1650,7 +1647,6 @@ extern "C" int sep_pw_wgrad(const sep_wgrad_desc* d, sep_stream_t stream) {
     SEP_REQUIRE(d->nsplit > 0 && (long)d->nsplit <= (long)d->B * (d->ldt / WK), "sep_pw_wgrad: bad nsplit=%d", d->nsplit);
     SEP_REQUIRE(d->g_split % BM == 0 && d->g_split < d->M, "sep_pw_wgrad: bad g_split=%d", d->g_split);
     SEP_REQUIRE(d->G && d->X && d->partial, "sep_pw_wgrad: null operand");
-    SEP_REQUIRE(d->accumulate == 0 || d->accumulate == 1, "sep_pw_wgrad: accumulate must be 0 or 1 (got %d)", d->accumulate);
     SEP_REQUIRE(!d->g_split || d->G2, "sep_pw_wgrad: g_split without G2");
     SEP_REQUIRE(!d->g_mul || (d->Gaux && d->g_div > 0 && !d->g_split), "sep_pw_wgrad: g_mul needs Gaux/g_div");
     SEP_REQUIRE(d->x_div > 0, "sep_pw_wgrad: x_div must be >= 1");

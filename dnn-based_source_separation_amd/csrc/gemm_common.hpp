@@ -23,15 +23,14 @@ __device__ __forceinline__ float row16_sum(float x) {
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));   // row_mirror
     return x;
 }
-// Slab store of the weight-gradient kernels: into the caller's own slab -- or, with sep_wgrad_desc.accumulate, ADDED onto slab 0
-// (zeroed by the caller) with the hardware fp32 atomic, so that the nsplit slabs never exist in HBM and the second-stage reduction
-// reads one slab (3.4 GB of the step's traffic are slabs written and re-read).  The sum order then varies from run to run.
-// The two forms are two copies of the store loops behind ONE wave-uniform branch (wg_store_tile below / the lambdas at the call sites):
-// a per-element choice makes hipcc emit a branch per store.
+// Slab store of the weight-gradient kernels.  (Round 2 prepared a second form that ADDED every slab onto one zeroed slab with the
+// hardware fp32 atomic, so that the slabs would never exist in HBM; measured on MI355X in round 3 it is slower -- 100 vs 82 us per launch,
+// 17.85 vs 17.29 ms per step, profiles/r03a_wgrad_atomic.txt: the atomics of 64 workgroups on one address resolve at the memory side
+// across the eight XCDs -- and it is gone.)
 template <bool ATOMIC>
 __device__ __forceinline__ void wg_put(float* p, const float v) {
-    if constexpr (ATOMIC) unsafeAtomicAdd(p, v);
-    else *p = v;
+    static_assert(!ATOMIC, "the atomic slab accumulation was removed");
+    *p = v;
 }
 // output tile store of the GEMM epilogue
 __device__ __forceinline__ void st4_out(float* p, float4 v) {

@@ -584,6 +584,73 @@ __global__ __launch_bounds__(256) void gln_bwd_finalize_sample_kernel(const floa
     }
 }
 
+// =====================================================================================
+// gLN backward statistics FROM the weight gradient.  For a product y = W v (1x1 convolution) behind v = gLN(u), u = PReLU(z), the
+// gradient arriving at v is dv = W^T g, and the two row sums the gLN backward needs are contractions the weight gradient has
+// already done:
+//     R1[n] = sum_t dv[n][t]        = sum_m W[m][n] * (sum_t g[m][t])            = sum_m W[m][n] * gs[m]
+//     R2[n] = sum_t dv[n][t] u[n][t] = sum_m W[m][n] * (sum_t g[m][t] u[n][t])    = sum_m W[m][n] * raw[m][n]
+// with raw = the weight gradient taken against u instead of v (sep_pw_wgrad with x_mode = PRELU) and gs the bias gradient, both PER
+// SAMPLE (sample-aligned slabs).  So the input-gradient product dv = W^T g needs no row-sum epilogue and does not read z at all (one
+// H-tensor less per layer and step), and no second-stage kernel runs for this gLN.  The gain / shift of the normalisation, which
+// the raw gradient skipped, is applied here on the small matrices:  dW_b[m][n] = sc_bn raw_b[m][n] + sh_bn gs_b[m].
+// grid (ceil(N / 64), B), 256 threads: lane = column n, wave w = rows w, w + 4, ...
+// =====================================================================================
+__global__ __launch_bounds__(256) void gln_bwd_from_wgrad_kernel(const float* __restrict__ part, const float* __restrict__ part_bias,
+                                                                 const float* __restrict__ W, const double* __restrict__ stats,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 double count, float eps, float* __restrict__ dW_b,
+                                                                 float* __restrict__ pbeta, float* __restrict__ pgamma,
+                                                                 double* __restrict__ bacc, int M, int N, int sps, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // gs[M] | red[4][64][2]
+    float* gs = lds;
+    float* red = lds + M;
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    const bool live = n < N;
+    for (int m = threadIdx.x; m < M; m += 256) {
+        float t = 0.f;
+        for (int k = 0; k < sps; ++k) t += part_bias[(size_t)(b * sps + k) * M + m];
+        gs[m] = t;
+    }
+    float mu, rstd;
+    gln_mu_rstd(stats + (size_t)b * SEP_STATS_SLOTS * 2, count, eps, mu, rstd);
+    const float gm = live ? gamma[n] : 0.f;
+    const float sc = gm * rstd, sh = live ? beta[n] - mu * sc : 0.f;
+    __syncthreads();
+    float r1 = 0.f, r2 = 0.f;
+    if (live) {
+        const size_t slab = (size_t)M * N;
+        const float* p0 = part + (size_t)b * sps * slab + n;
+        for (int m = wv; m < M; m += 4) {
+            float raw = 0.f;
+            for (int k = 0; k < sps; ++k) raw += p0[k * slab + (size_t)m * N];
+            const float w = W[(size_t)m * N + n], g = gs[m];
+            r1 = fmaf(w, g, r1);
+            r2 = fmaf(w, raw, r2);
+            dW_b[((size_t)b * M + m) * N + n] = fmaf(sc, raw, sh * g);
+        }
+    }
+    red[(wv * 64 + lane) * 2] = r1;
+    red[(wv * 64 + lane) * 2 + 1] = r2;
+    __syncthreads();
+    if (wv == 0) {
+        const float R1 = (red[lane * 2] + red[(64 + lane) * 2]) + (red[(128 + lane) * 2] + red[(192 + lane) * 2]);
+        const float R2 = (red[lane * 2 + 1] + red[(64 + lane) * 2 + 1]) + (red[(128 + lane) * 2 + 1] + red[(192 + lane) * 2 + 1]);
+        if (live) {
+            const float pg = rstd * (R2 - mu * R1);
+            if (accumulate) { pbeta[(size_t)b * N + n] += R1; pgamma[(size_t)b * N + n] += pg; }
+            else { pbeta[(size_t)b * N + n] = R1; pgamma[(size_t)b * N + n] = pg; }
+        }
+        const float a = wave_sum(gm * R1), c = wave_sum(gm * R2);
+        if (lane == 0) {
+            double* ba = bacc + ((size_t)b * SEP_STATS_SLOTS + (blockIdx.x & (SEP_STATS_SLOTS - 1))) * 2;
+            atomicAdd(ba, (double)a); atomicAdd(ba + 1, (double)c);
+        }
+    }
+}
+
 // dw = r0*(gamma*dvw - mg - xhat*mgx) + dwm  [* (w>0)]   in place on dvw
 __global__ __launch_bounds__(256) void head_bwd_kernel(float* __restrict__ dvw, const float* __restrict__ w,
                                                        const float* __restrict__ dwm, const double* __restrict__ stats0,
@@ -1102,6 +1169,18 @@ extern "C" int sep_gln_bwd_finalize(const float* rowpart, int ntile, int nq, con
     if (bsum || palpha)      // the per-sample stage: the means (stand-alone gLN backward) and / or the PReLU slope partials
         hipLaunchKernelGGL(gln_bwd_finalize_sample_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pbeta, pgamma, gamma, scratch, count, bsum, palpha, C);
     SEP_CHECK_LAUNCH("sep_gln_bwd_finalize");
+    return 0;
+}
+
+extern "C" int sep_gln_bwd_from_wgrad(const float* part, const float* part_bias, const float* W, const double* stats, const float* gamma,
+                                      const float* beta, double count, float eps, float* dW_b, float* pbeta, float* pgamma, double* bacc,
+                                      int B, int M, int N, int slabs_per_sample, int accumulate, sep_stream_t stream) {
+    SEP_REQUIRE(part && part_bias && W && stats && gamma && beta && dW_b && pbeta && pgamma && bacc, "sep_gln_bwd_from_wgrad: null pointer");
+    SEP_REQUIRE(B > 0 && B <= 65535 && M > 0 && M <= 8192 && N > 0 && slabs_per_sample > 0, "sep_gln_bwd_from_wgrad: bad sizes");
+    const size_t smem = ((size_t)M + 4 * 64 * 2) * sizeof(float);
+    hipLaunchKernelGGL(gln_bwd_from_wgrad_kernel, dim3(ceil_div(N, 64), B), dim3(256), smem, (hipStream_t)stream, part, part_bias, W, stats, gamma,
+                       beta, count, eps, dW_b, pbeta, pgamma, bacc, M, N, slabs_per_sample, accumulate);
+    SEP_CHECK_LAUNCH("sep_gln_bwd_from_wgrad");
     return 0;
 }
 

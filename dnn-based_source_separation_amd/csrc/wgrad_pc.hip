@@ -354,8 +354,7 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc_kernel(const sep_wgrad_des
             for (int mi = 0; mi < 2; ++mi) {
                 const float tot = bias_acc[mi] + __shfl_xor(bias_acc[mi], 32, 64);     // the two lane halves own different frames
                 if (lk == 0) {
-                    if (d.accumulate) wg_put<true>(d.partial_bias + m0 + 64 * wr + 32 * mi + l31, tot);
-                    else wg_put<false>(d.partial_bias + (size_t)s * d.M + m0 + 64 * wr + 32 * mi + l31, tot);
+                    d.partial_bias[(size_t)s * d.M + m0 + 64 * wr + 32 * mi + l31] = tot;
                 }
             }
         }
@@ -366,7 +365,7 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc_kernel(const sep_wgrad_des
         asm volatile("" : "+v"(etid), "+s"(es), "+s"(em0), "+s"(en0));
         const int ewid = __builtin_amdgcn_readfirstlane(etid >> 6);
         const int ewr = ewid / WC, ewc = ewid % WC, elk = (etid >> 5) & 1, el31 = etid & 31;
-        auto put_tile = [&](auto atomic_c) {                // accumulate: onto slab 0 with atomics; else a plain store into slab s
+        auto put_tile = [&](auto atomic_c) {                // a plain store into slab s
             constexpr bool AT = decltype(atomic_c)::value;
             float* out = d.partial + (AT ? 0 : (size_t)es * d.M * d.N);
 #pragma unroll
@@ -383,8 +382,7 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc_kernel(const sep_wgrad_des
                         }
                     }
         };
-        if (!d.accumulate) put_tile(std::false_type{});
-        else if (nk > 0) put_tile(std::true_type{});            // an empty slab has nothing to add
+        put_tile(std::false_type{});
     }
 }
 

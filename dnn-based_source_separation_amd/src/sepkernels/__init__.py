@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("SEPKERNELS_LIB", os.path.normpath(os.path.join(_HERE,
 # ---- constants mirrored from include/sepkernels.h -------------------------------------------------
 PRO_NONE, PRO_PRELU, PRO_GLN, PRO_GLN_PRELU, PRO_GLN_BWD = 0, 1, 2, 3, 4
 EPI_STATS_PRELU, EPI_RESIDUAL, EPI_SIGMOID, EPI_PRELU_BWD, EPI_ROWSUMS, EPI_ROWSUMS_PRELU = 1, 2, 4, 8, 16, 32
-ABI_VERSION = 12
+ABI_VERSION = 13
 STATS_SLOTS = 16   # SEP_STATS_SLOTS: gLN statistics are double[B][STATS_SLOTS][2]
 ARITH_F32, ARITH_BF16X6, ARITH_F16X3 = 0, 1, 2     # SEP_ARITH_*: how sep_pw_gemm forms its fp32 products (include/sepkernels.h)
 _ARITH_NAMES = {"f32": ARITH_F32, "bf16x6": ARITH_BF16X6, "f16x3": ARITH_F16X3}
@@ -75,7 +75,7 @@ class GemmDesc(ctypes.Structure):
 
 
 class WgradDesc(ctypes.Structure):
-    _fields_ = [(n, _i32) for n in ("B", "M", "N", "T", "ldt", "g_split", "g_mul", "g_div", "x_mode", "x_div", "nsplit", "arith", "accumulate")] + \
+    _fields_ = [(n, _i32) for n in ("B", "M", "N", "T", "ldt", "g_split", "g_mul", "g_div", "x_mode", "x_div", "nsplit", "arith")] + \
                [("eps", ctypes.c_float), ("count", ctypes.c_double)] + \
                [(n, _vp) for n in ("G", "G2", "Gaux", "X", "x_alpha", "x_stats", "x_gamma", "x_beta", "partial", "partial_bias")]
 
@@ -114,6 +114,7 @@ SIGNATURES = {
     "sep_dwconv_fwd": [_vp] * 10 + [_I] * 5 + [_F, _vp],
     "sep_dwconv_bwd": [_vp] * 15 + [_I] * 5 + [_F, _vp],
     "sep_gln_bwd_finalize": [_vp, _I, _I, _vp, _vp, _D, _F, _vp, _vp, _vp, _vp, _I, _I, _vp],
+    "sep_gln_bwd_from_wgrad": [_vp] * 6 + [_D, _F] + [_vp] * 4 + [_I] * 5 + [_vp],
     "sep_head_bwd": [_vp] * 6 + [_I] * 4 + [_D, _F, _I, _vp],
     "sep_decoder_fwd": [_vp] * 5 + [_I] * 10 + [_vp],
     "sep_decoder_bwd": [_vp] * 6 + [_I] * 11 + [_vp],
@@ -257,8 +258,8 @@ class HipBackend:
 
     def pw_wgrad(self, *, B, M, N, T, ldt, G, X, partial, nsplit, G2=None, g_split=0, Gaux=None, g_mul=0, g_div=1,
                  x_mode=PRO_NONE, x_div=1, eps=1e-12, count=0.0, x_alpha=None, x_stats=None, x_gamma=None, x_beta=None,
-                 partial_bias=None, arith=None, accumulate=0):
-        d = WgradDesc(B=B, M=M, N=N, T=T, ldt=ldt, g_split=g_split, g_mul=g_mul, g_div=g_div, x_mode=x_mode, x_div=x_div, accumulate=int(accumulate),
+                 partial_bias=None, arith=None):
+        d = WgradDesc(B=B, M=M, N=N, T=T, ldt=ldt, g_split=g_split, g_mul=g_mul, g_div=g_div, x_mode=x_mode, x_div=x_div,
                       nsplit=nsplit, arith=gemm_arith() if arith is None else arith, eps=eps, count=float(count), G=_ptr(G, _f32), G2=_ptr(G2, _f32), Gaux=_ptr(Gaux, _f32),
                       X=_ptr(X, _f32), x_alpha=_ptr(x_alpha, _f32), x_stats=_ptr(x_stats, _f64), x_gamma=_ptr(x_gamma, _f32),
                       x_beta=_ptr(x_beta, _f32), partial=_ptr(partial, _f32), partial_bias=_ptr(partial_bias, _f32))
@@ -301,6 +302,12 @@ class HipBackend:
         _check(load().sep_gln_bwd_finalize(_ptr(rowpart, _f32), ntile, nq, _ptr(stats, _f64), _ptr(gamma, _f32), float(count), eps,
                                            _ptr(bsum, _f32), _ptr(pbeta, _f32), _ptr(pgamma, _f32), _ptr(pextra, _f32), B, C,
                                            _stream()), "sep_gln_bwd_finalize")
+
+    def gln_bwd_from_wgrad(self, part, part_bias, W, stats, gamma, beta, count, eps, dW_b, pbeta, pgamma, bacc, B, M, N, slabs_per_sample,
+                           accumulate=0):
+        _check(load().sep_gln_bwd_from_wgrad(_ptr(part, _f32), _ptr(part_bias, _f32), _ptr(W, _f32), _ptr(stats, _f64), _ptr(gamma, _f32),
+                                             _ptr(beta, _f32), float(count), eps, _ptr(dW_b, _f32), _ptr(pbeta, _f32), _ptr(pgamma, _f32),
+                                             _ptr(bacc, _f64), B, M, N, slabs_per_sample, int(accumulate), _stream()), "sep_gln_bwd_from_wgrad")
 
     def head_bwd(self, dvw, w, dwm, stats0, gamma0, bacc0, B, C, T, ldt, count, eps, relu):
         _check(load().sep_head_bwd(_ptr(dvw, _f32), _ptr(w, _f32), _ptr(dwm, _f32), _ptr(stats0, _f64), _ptr(gamma0, _f32),

@@ -200,23 +200,24 @@ def tail_forward(cfg, P, geo, w, core, mixture_shape, want_latent, PK=None):
     return est, latent, m
 
 
-WGRAD_ATOMIC = os.environ.get("SEPK_WGRAD_ATOMIC", "0") == "1"     # experiment switch, see _wgrad
+def _nsplit_aligned(M, N, Bq, ldt, target_blocks=512):
+    """slab count B * k with k a divisor of ldt / 32: every slab then holds frames of ONE sample (slab s -> sample s // k), whichever
+    chunk size the weight-gradient kernel works in (sep_gln_bwd_from_wgrad needs that); as close to _nsplit's count as that allows"""
+    ntiles = ((M + 127) // 128) * ((N + 127) // 128)
+    want = max(1, target_blocks // ntiles)
+    cps = ldt // 32
+    k = max([q for q in range(1, cps + 1) if cps % q == 0 and Bq * q <= want] or [1])
+    return Bq * k
 
 
-def _wgrad(K, B, F, ldt, eps, f32, M, Nn, Gt, Xt, want_bias, Bq=None, weps=None, **kw):
-    """One weight-gradient product -> (partial slabs, partial bias slabs, number of slabs the caller reduces).
-    Default: `ns` slabs, summed afterwards by sep_reduce_slabs in a fixed order.  SEPK_WGRAD_ATOMIC=1 (off by default: not yet timed
-    on the device, and the order of the additions varies from run to run): the workgroups of all slabs add onto ONE zeroed slab
-    (sep_wgrad_desc.accumulate), so the slabs are neither written nor re-read -- 3.4 GB of the step's 73."""
+def _wgrad(K, B, F, ldt, eps, f32, M, Nn, Gt, Xt, want_bias, Bq=None, weps=None, aligned=False, **kw):
+    """One weight-gradient product -> (partial slabs, partial bias slabs, number of slabs): `ns` slabs, summed afterwards in a fixed
+    order (sep_reduce_slabs, or sep_gln_bwd_from_wgrad for sample-aligned slabs).  Adding every slab onto ONE with fp32 atomics
+    instead (sep_wgrad_desc.accumulate) was measured on MI355X and is slower -- 100 vs 82 us per launch, 17.85 vs 17.29 ms per step
+    (profiles/r03a_wgrad_atomic.txt): the atomics resolve at the memory side across the eight XCDs."""
     Bq = B if Bq is None else Bq
     ch = Bq * (ldt // 32)
-    ns = _nsplit(M, Nn, ch)
-    if WGRAD_ATOMIC:
-        part = torch.zeros(1, M, Nn, **f32)
-        pb = torch.zeros(1, M, **f32) if want_bias else None
-        K.pw_wgrad(B=Bq, M=M, N=Nn, T=F, ldt=ldt, G=Gt, X=Xt, partial=part, partial_bias=pb, nsplit=ns, accumulate=1,
-                   eps=(eps if weps is None else weps), **kw)
-        return part, pb, 1
+    ns = _nsplit_aligned(M, Nn, Bq, ldt) if aligned else _nsplit(M, Nn, ch)
     part = torch.empty(ns, M, Nn, **f32)
     pb = torch.empty(ns, M, **f32) if want_bias else None
     K.pw_wgrad(B=Bq, M=M, N=Nn, T=F, ldt=ldt, G=Gt, X=Xt, partial=part, partial_bias=pb, nsplit=ns,
@@ -491,46 +492,44 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
         Ws = P[sp + "skip_pointwise_conv1d.weight"]
         cnt = H * F
 
-        # dv2 = Wo^T dout + Ws^T dS, with the row sums the gLN2 backward needs
-        dv2 = torch.empty(B, H, ldt, **f32)
-        rp2 = torch.empty(B, H, nt64, 2, **f32)
-        epi = dict(epi_flags=EPI_ROWSUMS | EPI_ROWSUMS_PRELU, epi_aux=z, epi_alpha=al2, epi_rowpart=rp2, epi_gamma=g2, epi_bacc=bacc[2 + 2 * li], eps=teps)
-        if dual:
-            Wo = P[sp + "output_pointwise_conv1d.weight"]
-            if "heads.{}^T".format(li) in PK:
-                K.pw_gemm(B=B, M=H, K=Bn + Sc, T=F, ldt=ldt, trans_a=1, A=Wo, A2=Ws, A_pk=PK["heads.{}^T".format(li)], X=dout, X2=dS,
-                          k_split=Bn, Y=dv2, **epi)
-            else:
-                K.pw_gemm(B=B, M=H, K=Bn + Sc, T=F, ldt=ldt, trans_a=1, A=Wo, A2=Ws, X=dout, X2=dS, k_split=Bn, Y=dv2, **epi)
-        else:
-            K.pw_gemm(B=B, M=H, K=Sc, T=F, ldt=ldt, trans_a=1, A=Ws, A_pk=PK.get("skip.{}^T".format(li)), X=dS, Y=dv2, **epi)
+        # The heads' weight gradients first, taken against u2 = PReLU(z) (the gain and shift of gLN2 left out) on sample-aligned slabs:
+        # their contractions ARE the row sums gLN2's backward needs (sep_gln_bwd_from_wgrad: R1 = W^T gs, R2 = sum_m W * raw), so the
+        # input-gradient product below has no row-sum epilogue and never reads z, and no second-stage kernel runs for this gLN.
         pbeta2 = torch.empty(B, H, **f32)
         pgamma2 = torch.empty(B, H, **f32)
+        xkw = dict(x_mode=PRO_PRELU, x_alpha=al2, weps=teps, aligned=True)
+        heads = []      # (G, G2, g_split, rows, W as one [rows][H] matrix, [(gradient tensor, first row, rows)], [(bias gradient, first row, rows)])
+        if dual:
+            Wo = P[sp + "output_pointwise_conv1d.weight"]
+            if Bn % 128 == 0 and _adjacent(Wo, Ws):
+                heads.append((dout, dS, Bn, Bn + Sc, Wo.as_strided((Bn + Sc, H), (H, 1)),
+                              [(sp + "output_pointwise_conv1d.weight", 0, Bn), (sp + "skip_pointwise_conv1d.weight", Bn, Sc)],
+                              [(sp + "output_pointwise_conv1d.bias", 0, Bn), (sp + "skip_pointwise_conv1d.bias", Bn, Sc)]))
+            else:
+                heads.append((dout, None, 0, Bn, Wo, [(sp + "output_pointwise_conv1d.weight", 0, Bn)], [(sp + "output_pointwise_conv1d.bias", 0, Bn)]))
+                heads.append((dS, None, 0, Sc, Ws, [(sp + "skip_pointwise_conv1d.weight", 0, Sc)], [(sp + "skip_pointwise_conv1d.bias", 0, Sc)]))
+        else:
+            heads.append((dS, None, 0, Sc, Ws, [(sp + "skip_pointwise_conv1d.weight", 0, Sc)], [(sp + "skip_pointwise_conv1d.bias", 0, Sc)]))
+        segs = []
+        for hi, (Gt, G2t, gsp, rows, Wmat, wnames, bnames) in enumerate(heads):
+            part, pb, ns = wgrad(rows, H, Gt, z, True, True, G2=G2t, g_split=gsp, **xkw)
+            dWb = torch.empty(B, rows, H, **f32)
+            K.gln_bwd_from_wgrad(part, pb, Wmat, st2, g2, b2, cnt, teps, dWb, pbeta2, pgamma2, bacc[2 + 2 * li], B, rows, H, ns // B,
+                                 accumulate=int(hi > 0))
+            segs += [(dWb, r0 * H, G[nm], nr * H, B, rows * H, 0, 1.0) for nm, r0, nr in wnames]
+            segs += [(pb, r0, G[nm], nr, ns, rows, 0, 1.0) for nm, r0, nr in bnames]
+        pending += segs
 
-        # head weight gradients: dWo = sum dout v2^T, dWs = sum dS v2^T   (v2 = gLN2(PReLU(z)) rebuilt on load).
-        # Leaves of the graph: they run on the side stream, under this layer's input-gradient chain.
-        xkw = dict(x_mode=PRO_GLN_PRELU, x_stats=st2, x_gamma=g2, x_beta=b2, x_alpha=al2, count=cnt, weps=teps)
-        with side:
-            segs = []
-            if dual and Bn % 128 == 0:
-                part, pb, ns = wgrad(Bn + Sc, H, dout, z, True, True, G2=dS, g_split=Bn, **xkw)
-                st = (Bn + Sc) * H
-                segs += [(part, 0, G[sp + "output_pointwise_conv1d.weight"], Bn * H, ns, st, 0, 1.0),
-                         (part, Bn * H, G[sp + "skip_pointwise_conv1d.weight"], Sc * H, ns, st, 0, 1.0),
-                         (pb, 0, G[sp + "output_pointwise_conv1d.bias"], Bn, ns, Bn + Sc, 0, 1.0),
-                         (pb, Bn, G[sp + "skip_pointwise_conv1d.bias"], Sc, ns, Bn + Sc, 0, 1.0)]
+        # dv2 = Wo^T dout + Ws^T dS
+        dv2 = torch.empty(B, H, ldt, **f32)
+        if dual:
+            if "heads.{}^T".format(li) in PK:
+                K.pw_gemm(B=B, M=H, K=Bn + Sc, T=F, ldt=ldt, trans_a=1, A=Wo, A2=Ws, A_pk=PK["heads.{}^T".format(li)], X=dout, X2=dS,
+                          k_split=Bn, Y=dv2, eps=teps)
             else:
-                if dual:
-                    part, pb, ns = wgrad(Bn, H, dout, z, True, True, **xkw)
-                    segs += [(part, 0, G[sp + "output_pointwise_conv1d.weight"], Bn * H, ns, Bn * H, 0, 1.0),
-                             (pb, 0, G[sp + "output_pointwise_conv1d.bias"], Bn, ns, Bn, 0, 1.0)]
-                part, pb, ns = wgrad(Sc, H, dS, z, True, True, **xkw)
-                segs += [(part, 0, G[sp + "skip_pointwise_conv1d.weight"], Sc * H, ns, Sc * H, 0, 1.0),
-                         (pb, 0, G[sp + "skip_pointwise_conv1d.bias"], Sc, ns, Sc, 0, 1.0)]
-            if side.on:
-                K.reduce_slabs(segs)
-            else:
-                pending += segs
+                K.pw_gemm(B=B, M=H, K=Bn + Sc, T=F, ldt=ldt, trans_a=1, A=Wo, A2=Ws, X=dout, X2=dS, k_split=Bn, Y=dv2, eps=teps)
+        else:
+            K.pw_gemm(B=B, M=H, K=Sc, T=F, ldt=ldt, trans_a=1, A=Ws, A_pk=PK.get("skip.{}^T".format(li)), X=dS, Y=dv2, eps=teps)
 
         # depthwise^T and everything hanging off it
         dv1 = torch.empty(B, H, ldt, **f32)
@@ -561,10 +560,9 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
                   epi_flags=(EPI_RESIDUAL if dout is not None else 0), epi_res=dout)
         # da and dx now exist: the side stream may go on (this layer's dW1, the next layer's head gradients)
         side.fork()
-        side.keep(da, dx, rp2, rp1, pbeta2, pgamma2, pbeta1, pgamma1, pextra)
+        side.keep(da, dx, rp1, pbeta1, pgamma1, pextra)
         with side:
-            # second stage of the two gLN backwards of this layer: parameter gradients only, nothing in the chain waits for it
-            K.gln_bwd_finalize(rp2, nt64, 2, st2, g2, cnt, teps, None, pbeta2, pgamma2, None, B, H)
+            # second stage of gLN1's backward: parameter gradients only, nothing in the chain waits for it
             K.gln_bwd_finalize(rp1, nt1024, 8, st1, g1, cnt, teps, None, pbeta1, pgamma1, pextra, B, H)
             part, pb, ns = wgrad(H, Bn, da, x, True, True)
             segs = [(part, 0, G[pre + "bottleneck_conv1d.weight"], H * Bn, ns, H * Bn, 0, 1.0),

@@ -33,7 +33,7 @@ extern "C" {
 
 typedef void* sep_stream_t; /* hipStream_t */
 
-#define SEP_ABI_VERSION 12
+#define SEP_ABI_VERSION 13
 #define SEP_STATS_SLOTS 16
 
 int sep_version(void);
@@ -156,11 +156,10 @@ typedef struct sep_wgrad_desc {
     int32_t g_div;
     int32_t x_mode; /* SEP_PRO_NONE / PRELU / GLN / GLN_PRELU */
     int32_t x_div;  /* X (and its gLN stats) are indexed with b / x_div */
-    int32_t nsplit; /* number of partial slabs, <= B*ldt/32 */
+    int32_t nsplit; /* number of partial slabs, <= B*ldt/32; slab s covers the chunk range [s*ceil(C/nsplit), (s+1)*ceil(C/nsplit)) of the C = B*ldt/q
+                      * frame chunks (q = 16 or 32, the kernel's choice).  SAMPLE-ALIGNED slabs: with nsplit = B*k and k a divisor of ldt/32,
+                      * slab s holds frames of sample s/k only, in every kernel */
     int32_t arith;  /* SEP_ARITH_* */
-    int32_t accumulate; /* 0: slab s is written to partial[s] (deterministic second stage: sep_reduce_slabs over nsplit slabs);
-                         * 1: every slab is ADDED onto partial[0] / partial_bias[0] with fp32 atomics -- the caller zeroes slab 0 and
-                         *    reduces ONE slab; nsplit still partitions the frames; the order of the additions is not fixed */
     float eps;
     double count;
     const float* G;
@@ -236,6 +235,21 @@ int sep_dwconv_bwd(const float* dv2, const float* z, const float* a, const doubl
 int sep_gln_bwd_finalize(const float* rowpart, int ntile, int nq, const double* stats, const float* gamma, double count,
                          float eps, float* bsum, float* pbeta, float* pgamma, float* pextra, int B, int C,
                          sep_stream_t stream);
+
+/* gLN backward statistics FROM the weight gradient (round 3).  For y = W v with v = gLN(u), u = PReLU(z): the gradient at v is
+ * dv = W^T g, and the row sums its gLN backward needs are contractions the weight gradient has already done,
+ *     R1[n] = sum_t dv[n][t] = sum_m W[m][n] gs[m],        R2[n] = sum_t dv[n][t] u[n][t] = sum_m W[m][n] raw[m][n],
+ * raw = sum_t g[m][t] u[n][t] (sep_pw_wgrad with x_mode = SEP_PRO_PRELU: the gain and shift of the norm left out), gs = sum_t g (its
+ * bias slabs), both per sample -- the slabs must be SAMPLE-ALIGNED: nsplit = B * slabs_per_sample with slabs_per_sample dividing ldt / 32,
+ * so that slab s holds frames of sample s / slabs_per_sample only.  Then the input-gradient product W^T g needs no ROWSUMS epilogue
+ * and does not read z (reference tdcn.py:173-175 backward + modules/norm.py:18,27 backward).  Outputs:
+ *     dW_b[b][m][n] = sc_bn raw_b[m][n] + sh_bn gs_b[m]      (the true per-sample weight gradient; sum over b with sep_reduce_slabs)
+ *     pbeta[b][n] (+)= R1,  pgamma[b][n] (+)= rstd_b (R2 - mu_b R1)      (accumulate = 1 adds: a second product feeding the same gLN)
+ *     bacc[b][slot] += { sum_n gamma_n R1, sum_n gamma_n R2 }           (what the consumer's prologue turns into the two means)
+ * W is [M][N] row-major (rows of adjacent matrices may be handed over as one, e.g. [Wo; Ws]). */
+int sep_gln_bwd_from_wgrad(const float* part, const float* part_bias, const float* W, const double* stats, const float* gamma,
+                           const float* beta, double count, float eps, float* dW_b, float* pbeta, float* pgamma, double* bacc,
+                           int B, int M, int N, int slabs_per_sample, int accumulate, sep_stream_t stream);
 
 /* Backward tail of the separator head: dw = r0*(gamma0*dvw - mg - xhat*mgx) + dwm, times [w>0] if the encoder has ReLU
  * (mg, mgx from bacc0 [B][SEP_STATS_SLOTS][2] = the epi_bacc sums of the bottleneck^T product, and stats0).

@@ -157,7 +157,7 @@ class EmuBackend:
 
     def pw_wgrad(self, *, B, M, N, T, ldt, G, X, partial, nsplit, G2=None, g_split=0, Gaux=None, g_mul=0, g_div=1,
                  x_mode=PRO_NONE, x_div=1, eps=1e-12, count=0.0, x_alpha=None, x_stats=None, x_gamma=None, x_beta=None,
-                 partial_bias=None, arith=None, accumulate=0):
+                 partial_bias=None, arith=None):
         dt = G.dtype
         m1 = g_split if g_split else M
         Gf = G.reshape(B, m1, ldt)
@@ -176,16 +176,19 @@ class EmuBackend:
             Xp = u * sc + (x_beta.view(1, N, 1) - mu * sc)
         else:
             Xp = Xf
-        if accumulate:                      # every slab is added onto slab 0, which the caller zeroed (or pre-loaded): only slab 0 exists
-            partial.reshape(-1)[:M * N].reshape(M, N).add_(torch.einsum("bmt,bnt->mn", Gf, Xp))
-            if partial_bias is not None:
-                partial_bias.reshape(-1)[:M].add_(Gf.sum((0, 2)))
-            return
         partial.zero_()
-        partial.reshape(nsplit, M, N)[0] = torch.einsum("bmt,bnt->mn", Gf, Xp)
         if partial_bias is not None:
             partial_bias.zero_()
-            partial_bias.reshape(nsplit, M)[0] = Gf.sum((0, 2))
+        k = nsplit // B if nsplit % B == 0 else 0
+        if k and (ldt // 32) % k == 0:
+            # sample-aligned slabs (include/sepkernels.h, sep_gln_bwd_from_wgrad): slab b * k + j holds frames [j ldt / k, (j + 1) ldt / k) of sample b
+            partial.reshape(B, k, M, N).copy_(torch.einsum("bmkt,bnkt->bkmn", Gf.reshape(B, M, k, ldt // k), Xp.reshape(B, N, k, ldt // k)))
+            if partial_bias is not None:
+                partial_bias.reshape(B, k, M).copy_(Gf.reshape(B, M, k, ldt // k).sum(3).permute(0, 2, 1))
+        else:       # how the frames are spread over the slabs is the kernel's business: everything in slab 0
+            partial.reshape(nsplit, M, N)[0] = torch.einsum("bmt,bnt->mn", Gf, Xp)
+            if partial_bias is not None:
+                partial_bias.reshape(nsplit, M)[0] = Gf.sum((0, 2))
 
     def reduce_slabs(self, segs):
         for (src, off, dst, n, nslab, stride, acc, scale) in segs:
@@ -344,6 +347,28 @@ class EmuBackend:
             slab[:, C:] = rp[..., 3:6].reshape(B, 3 * C)
             pe[B * 4 * C:B * 4 * C + B] = rp[..., 6].sum(1)
             pe[B * 4 * C + B:B * 4 * C + B + B * C] = rp[..., 6].reshape(-1)      # per-row scratch of the two-kernel finalize
+
+    def gln_bwd_from_wgrad(self, part, part_bias, W, stats, gamma, beta, count, eps, dW_b, pbeta, pgamma, bacc, B, M, N, slabs_per_sample,
+                           accumulate=0):
+        dt = part.dtype
+        raw = part.reshape(B, slabs_per_sample, M, N).sum(1)
+        gs = part_bias.reshape(B, slabs_per_sample, M).sum(1)
+        Wm = W.reshape(-1)[:M * N].reshape(M, N).to(dt)
+        mu, rstd = _mu_rstd(stats, count, eps, dt)
+        mu, rstd = mu.view(B, 1), rstd.view(B, 1)
+        R1 = torch.einsum("mn,bm->bn", Wm, gs)
+        R2 = (Wm.unsqueeze(0) * raw).sum(1)
+        sc = gamma.view(1, N) * rstd
+        sh = beta.view(1, N) - mu * sc
+        dW_b.reshape(B, M, N).copy_(sc.unsqueeze(1) * raw + sh.unsqueeze(1) * gs.unsqueeze(2))
+        pb, pg = pbeta.reshape(B, N), pgamma.reshape(B, N)
+        if accumulate:
+            pb += R1
+            pg += rstd * (R2 - mu * R1)
+        else:
+            pb.copy_(R1)
+            pg.copy_(rstd * (R2 - mu * R1))
+        _acc(bacc, (gamma.view(1, N) * R1).sum(1), (gamma.view(1, N) * R2).sum(1))
 
     def head_bwd(self, dvw, w, dwm, stats0, gamma0, bacc0, B, C, T, ldt, count, eps, relu):
         dt = w.dtype

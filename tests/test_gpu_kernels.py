@@ -427,6 +427,15 @@ def _wgrad_both(kw, tol=3e-4):
     if kw.get("partial_bias") is not None:
         assert torch.isfinite(gk["partial_bias"]).all()
         _reduce_check(ck["partial_bias"], gk["partial_bias"], tol)
+    B, ns, ldt = kw["B"], kw["nsplit"], kw["ldt"]
+    if ns % B == 0 and (ldt // 32) % (ns // B) == 0:
+        # sample-aligned slabs (sepkernels.h): slab s holds frames of sample s // k only -- compare sample by sample
+        k = ns // B
+        pc, pg = ck["partial"].reshape(B, k, -1).sum(1).double(), gk["partial"].cpu().reshape(B, k, -1).sum(1).double()
+        assert (pc - pg).abs().max() <= tol * pc.abs().max() + 1e-30, "per-sample slab sums differ"
+        if kw.get("partial_bias") is not None:
+            bc, bg = ck["partial_bias"].reshape(B, k, -1).sum(1).double(), gk["partial_bias"].cpu().reshape(B, k, -1).sum(1).double()
+            assert (bc - bg).abs().max() <= tol * bc.abs().max() + 1e-30, "per-sample bias slab sums differ"
 
 
 @pytest.mark.parametrize("K,scale", [(128, 1.0), (512, 1.0), (1024, 1e-3), (512, 1e4)])
@@ -465,22 +474,31 @@ def test_wgrad_plain(B, M, N, T, ns, arith):
     _wgrad_both(dict(B=B, M=M, N=N, T=T, ldt=ldt, G=padded(B, M, T, ldt), X=padded(B, N, T, ldt), partial=part, partial_bias=pb, nsplit=ns))
 
 
-@pytest.mark.parametrize("B,M,N,T,ns", [(2, 256, 128, 999, 7), (1, 128, 16, 300, 3), (2, 512, 128, 700, 12), (2, 32, 4, 201, 2)])
-def test_wgrad_accumulated_onto_one_slab(B, M, N, T, ns, arith):
-    """sep_wgrad_desc.accumulate: the workgroups of all `ns` slabs ADD their tiles (and bias sums) onto slab 0 with fp32 atomics instead of
-    writing `ns` slabs -- here onto a slab that already holds values, so that a plain store would be caught.  Every kernel behind
-    sep_pw_wgrad: the producer / consumer one, the per-wave split and fp32 ones, the register-staged fallback (N = 4)."""
+@pytest.mark.parametrize("B,M,N,T,k", [(2, 256, 128, 999, 4), (3, 128, 256, 300, 3), (2, 64, 48, 130, 1), (1, 256, 512, 1000, 8), (3, 32, 20, 500, 2)])
+def test_wgrad_sample_aligned_slabs_and_gln_sums_from_them(B, M, N, T, k, arith):
+    """The heads' weight gradient as the model's backward takes it: against u = PReLU(z) on nsplit = B * k sample-aligned slabs, then
+    sep_gln_bwd_from_wgrad turns slabs + weights into the gLN backward's row sums, the consumer's two totals and the per-sample weight
+    gradient of the normalised product; checked against the restatement AND against the sums formed the direct way (dv = W^T g)."""
     ldt = (T + 127) // 128 * 128
-    G_, X_ = padded(B, M, T, ldt), padded(B, N, T, ldt)
-    base, base_b = rnd(1, M, N), rnd(1, M)
-    part_c, pb_c, part_g, pb_g = base.clone(), base_b.clone(), to_device(base), to_device(base_b)
-    kw = dict(B=B, M=M, N=N, T=T, ldt=ldt, nsplit=ns, accumulate=1)
-    EMU.pw_wgrad(G=G_, X=X_, partial=part_c, partial_bias=pb_c, **kw)
-    HIP.pw_wgrad(G=to_device(G_), X=to_device(X_), partial=part_g, partial_bias=pb_g, **kw)
-    device_sync()
-    scale = (part_c - base).abs().max().item()
-    assert (part_g.cpu() - part_c).abs().max().item() <= 2e-4 * scale
-    assert (pb_g.cpu() - pb_c).abs().max().item() <= 2e-4 * (pb_c - base_b).abs().max().item()
+    ns = B * k
+    z, g = padded(B, N, T, ldt), padded(B, M, T, ldt)
+    al = torch.tensor([0.15])
+    u = torch.where(z > 0, z, al * z)
+    part, pb = _wg_out(ns, M, N)
+    kw = dict(B=B, M=M, N=N, T=T, ldt=ldt, G=g, X=z, x_mode=PRO_PRELU, x_alpha=al, partial=part, partial_bias=pb, nsplit=ns)
+    _wgrad_both(kw)
+    W, gamma, beta, st = rnd(M, N, scale=N ** -0.5), rnd(N) + 1, rnd(N), stats_of(u, T)
+    args = [part, pb, W, st, gamma, beta, N * float(T), 1e-12, nan(B, M, N), nan(B, N), nan(B, N), zstats(B), B, M, N, k, 0]
+    both("gln_bwd_from_wgrad", args, tol=3e-4)       # `part` / `pb` now hold the emulator's slabs on both sides
+    dv = torch.einsum("mn,bmt->bnt", W.double(), g.double())
+    R1, R2 = dv.sum(2), (dv * u.double()).sum(2)
+    assert (args[9].double() - R1).abs().max() <= 1e-4 * R1.abs().max()
+    tot = args[11].sum(1)
+    assert torch.allclose(tot[:, 0], (gamma.double() * R1).sum(1), rtol=1e-3, atol=1e-4 * R1.abs().max().item() * N ** 0.5)
+    assert torch.allclose(tot[:, 1], (gamma.double() * R2).sum(1), rtol=1e-3, atol=1e-4 * R2.abs().max().item() * N ** 0.5)
+    args2 = list(args)
+    args2[-1] = 1                                      # accumulate: a second product feeding the same gLN adds its sums
+    both("gln_bwd_from_wgrad", args2, tol=3e-4)
 
 
 def test_wgrad_two_sources_gln_prelu(arith):

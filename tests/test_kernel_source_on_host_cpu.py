@@ -65,12 +65,10 @@ GEMM_CASES = [
     ("f16x3-packed", "test_gemm_gln_bwd_prologue_several_row_tiles", (256, 64)),
     ("f16x3", "test_gemm_gln_bwd_prologue_several_row_tiles", (192, 48)),
     ("f16x3", "test_wgrad_plain", (2, 256, 128, 300, 3)),
+    ("bf16x6", "test_wgrad_sample_aligned_slabs_and_gln_sums_from_them", (2, 256, 128, 300, 3)),      # producer / consumer kernel
+    ("f32", "test_wgrad_sample_aligned_slabs_and_gln_sums_from_them", (3, 32, 20, 500, 2)),
     ("bf16x6", "test_wgrad_plain", (2, 128, 256, 130, 1)),
     ("f32", "test_wgrad_plain", (2, 32, 4, 201, 2)),
-    ("f16x3", "test_wgrad_accumulated_onto_one_slab", (2, 256, 128, 300, 7)),      # producer / consumer kernel
-    ("bf16x6", "test_wgrad_accumulated_onto_one_slab", (1, 128, 16, 300, 3)),      # per-wave split kernel
-    ("f32", "test_wgrad_accumulated_onto_one_slab", (2, 128, 64, 200, 5)),         # fp32 direct kernel
-    ("f32", "test_wgrad_accumulated_onto_one_slab", (2, 32, 4, 201, 2)),           # small widths
     (None, "test_gemm_packed_weights_model_shapes", (128, 512, 130)),        # producer / consumer kernel, 256-column workgroup tile
     (None, "test_gemm_packed_weights_model_shapes", (512, 128, 130)),        # cooperative kernel
     (None, "test_gemm_packed_weights_model_shapes", (1024, 128, 130)),       # producer / consumer kernel, 4 x 1 consumer waves
@@ -118,8 +116,8 @@ def test_gemm_kernel_source_on_the_host_matches_the_restatement(on_host, arith, 
         sepkernels.set_gemm_arith(prev)
 
 
-@pytest.mark.parametrize("config,atomic_slabs", [("tiny", False), ("softmax", False), ("tiny", True)])
-def test_whole_fused_conv_tasnet_through_the_kernel_sources(on_host, golden_dir, monkeypatch, config, atomic_slabs):
+@pytest.mark.parametrize("config", ["tiny", "softmax"])
+def test_whole_fused_conv_tasnet_through_the_kernel_sources(on_host, golden_dir, config):
     """End to end: the fused Conv-TasNet of the product (models/conv_tasnet.py -> sepkernels/net.py orchestration -> C ABI) with the
     host simulation of the kernel sources behind the ABI, on the reference's golden vectors (BASELINE.json configs[0] family: tiny, ReLU
     encoder, 2 speakers; and the same with the channel-softmax mask): forward, PIT loss, permutation and every parameter gradient.
@@ -133,7 +131,6 @@ def test_whole_fused_conv_tasnet_through_the_kernel_sources(on_host, golden_dir,
     from criterion.sdr import NegSISDR
     from criterion.pit import PIT1d
     from sepkernels import net
-    monkeypatch.setattr(net, "WGRAD_ATOMIC", atomic_slabs)      # True: weight gradients accumulated onto one slab (SEPK_WGRAD_ATOMIC=1)
 
     class Named:                                   # the binding object under a name the modules do not take for the GPU build
         name = "hostsim"

@@ -241,24 +241,6 @@ def test_criteria_broadcast_and_clip_like_the_reference(emu):
     assert (per_pair[0, 0, 2] < -30).item()                                                  # the clip at 30 dB was really active
 
 
-def test_weight_gradients_accumulated_onto_one_slab_give_the_same_gradients(golden_dir, emu, monkeypatch):
-    """SEPK_WGRAD_ATOMIC=1 (sepkernels/net.py::_wgrad): one zeroed slab per weight gradient, every workgroup adds onto it, the second-stage
-    reduction reads one slab.  Host orchestration through the emulator: the golden gradients of the reference come out the same."""
-    from sepkernels import net
-    monkeypatch.setattr(net, "WGRAD_ATOMIC", True)
-    name = "tiny"
-    g = np.load(os.path.join(golden_dir, "convtasnet_{}.npz".format(name)))
-    model = ConvTasNet(**CONFIGS[name])
-    model.load_state_dict({k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param/")})
-    model.double()
-    est = model(torch.from_numpy(g["mixture"]).double())
-    loss, _ = PIT1d(NegSISDR(), n_sources=2)(est, torch.from_numpy(g["sources"]).double())
-    loss.backward()
-    for k, p in model.named_parameters():
-        r = torch.from_numpy(g["grad/" + k]).double()
-        assert (p.grad - r).abs().max() <= 2e-6 * max(r.abs().max().item(), 1e-6), k
-
-
 @pytest.mark.parametrize("widths", [(48, 48, 80, 16), (80, 16, 48, 48), (16, 48, 16, 80)])
 def test_widths_in_odd_multiples_of_16(emu, widths):
     """Widths the fused family accepts (multiples of 16) but the weight packer does not (32-row blocks): 48, 80, ...  The step used to

@@ -135,18 +135,16 @@ def case_wgrad(R):
     M, N = R.choice([4, 16, 24, 32, 64, 96, 128, 160, 256]), R.choice([2, 4, 16, 20, 32, 64, 128, 256])
     ldt = up(T, 128)
     ns = R.randint(1, min(12, B * (ldt // 32)))
-    acc = R.random() < 0.4
-    part, pb = (GK.rnd(1, M, N), GK.rnd(1, M)) if acc else (GK.nan(ns, M, N), GK.nan(ns, M))
+    if R.random() < 0.4:       # sample-aligned slabs (what sep_gln_bwd_from_wgrad takes): B * k with k a divisor of ldt / 32
+        ns = B * R.choice([q for q in range(1, ldt // 32 + 1) if (ldt // 32) % q == 0])
+    part, pb = GK.nan(ns, M, N), GK.nan(ns, M)
     prev = sepkernels.set_gemm_arith(arith)
     try:
-        kw = dict(B=B, M=M, N=N, T=T, ldt=ldt, G=GK.padded(B, M, T, ldt), X=GK.padded(B, N, T, ldt), partial=part, partial_bias=pb, nsplit=ns, accumulate=int(acc))
-        if acc:
-            GK.both("pw_wgrad", [], kw)
-        else:
-            GK._wgrad_both(kw)
+        kw = dict(B=B, M=M, N=N, T=T, ldt=ldt, G=GK.padded(B, M, T, ldt), X=GK.padded(B, N, T, ldt), partial=part, partial_bias=pb, nsplit=ns)
+        GK._wgrad_both(kw)
     finally:
         sepkernels.set_gemm_arith(prev)
-    return "pw_wgrad {} B={} M={} N={} T={} ns={} accumulate={}".format(arith, B, M, N, T, ns, acc)
+    return "pw_wgrad {} B={} M={} N={} T={} ns={}".format(arith, B, M, N, T, ns)
 
 
 def case_codec(R):
