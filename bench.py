@@ -41,49 +41,144 @@ MFMA_PER_PRODUCT = {"f16x3": (3, F16_MFMA_PEAK_TFLOPS), "bf16x6": (6, F16_MFMA_P
 
 
 class TimedBackend:
-    """Wraps the kernel facade: brackets every launch of the two MFMA kernels with HIP events (recorded on the
-    current stream = the launch stream) and tallies their algorithmic FLOPs."""
+    """Wraps the kernel facade: in the instrumented pass EVERY launch is bracketed with HIP events (recorded on the current stream =
+    the launch stream) and booked under its launch class with its algorithmic work:
+      flop        algorithmic fp32 FLOP (the two MFMA kernels)
+      bytes_seq   algorithmic HBM bytes of THIS kernel sequence: every tensor the launch has to read or write, once, fp32, valid
+                  frames only (weights and per-row vectors not counted)
+      bytes_8d    the same launch under SURVEY.md section 8d's convention: forward = 2Bn + 4H + 2Sc rows per layer (conv1: Bn + H, depthwise:
+                  2H, heads: H + Bn + 2Sc) and head / tail 2N + Bn + 2 n_src N + n_src S; backward = 2 x forward, booked as input-gradient kernel
+                  = its forward counterpart, weight-gradient kernel = its forward counterpart, depthwise backward = 2 x depthwise forward
+    """
 
     def __init__(self, inner):
         self._inner = inner
         self.enabled = False
-        self.records = {"pw_gemm": [], "pw_wgrad": []}
+        self.records = []
         self.name = inner.name
 
     def __getattr__(self, item):
-        return getattr(self._inner, item)
+        fn = getattr(self._inner, item)
+        if not callable(fn) or item.startswith("_"):
+            return fn
 
-    def _timed(self, key, flops, nbytes, fn, kw):
-        if not self.enabled:
-            return fn(**kw)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        fn(**kw)
-        e1.record()
-        self.records[key].append((e0, e1, flops, nbytes))
+        def call(*a, **kw):
+            if not self.enabled:
+                return fn(*a, **kw)
+            cls, flop, bseq, b8d = self._classify(item, a, kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **kw)
+            e1.record()
+            self.records.append((e0, e1, cls, flop, bseq, b8d))
+            return out
+        return call
 
-    def pw_gemm(self, **kw):
-        # algorithmic HBM bytes of this launch (SURVEY.md 8d convention): every activation row once, fp32, valid frames only;
-        # the weights (<= 1 MB, L2-resident) are not counted
-        M, K = kw["M"], kw["K"]
-        msp = kw.get("m_split", 0)
-        rows = K + M                                                     # X in, Y out
-        rows += (M - msp if kw.get("accumulate") else 0)                 # accumulated part read back
-        rows += ((msp or M) if kw.get("epi_res") is not None else 0)     # residual
-        rows += (M if kw.get("epi_aux") is not None else 0)              # PReLU-bwd / row-sum operand
-        rows += (2 * K if kw.get("pro_store") is not None else 0)        # gLN-bwd: pre-activation in, d(pre-activation) out
-        self._timed("pw_gemm", 2.0 * M * K * kw["B"] * kw["T"], 4.0 * rows * kw["B"] * kw["T"], self._inner.pw_gemm, kw)
-
-    def pw_wgrad(self, **kw):
-        rows = kw["M"] + kw["N"]                                         # both operands once; the slabs are written + re-read: not algorithmic
-        self._timed("pw_wgrad", 2.0 * kw["M"] * kw["N"] * kw["B"] * kw["T"], 4.0 * rows * kw["B"] * kw["T"], self._inner.pw_wgrad, kw)
+    @staticmethod
+    def _classify(name, a, kw):
+        """(launch class, flop, bytes_seq, bytes_8d) -- None where a notion does not apply (latency-bound helpers)"""
+        if name == "pw_gemm":
+            B, M, K, T = kw["B"], kw["M"], kw["K"], kw["T"]
+            col = 4.0 * B * T
+            msp = kw.get("m_split", 0)
+            rows = K + M
+            rows += (M - msp if kw.get("accumulate") else 0)
+            rows += ((msp or M) if kw.get("epi_res") is not None else 0)
+            rows += (M if kw.get("epi_aux") is not None else 0)
+            rows += (2 * K if kw.get("pro_store") is not None else 0)
+            pro, ef, tr = kw.get("pro_mode", 0), kw.get("epi_flags", 0), kw.get("trans_a", 0)
+            if not tr:
+                cls = {0: "conv1", 1: "mask", 2: "bottleneck", 3: "heads"}.get(pro, "gemm")
+                r8 = K + M + (M - msp if kw.get("accumulate") else 0)          # 8d: in + out (+ the skip sum read back)
+            else:
+                cls = "conv1^T" if pro == 4 else "mask^T" if ef & 8 else "heads^T" if kw.get("k_split") or (ef == 0 and M > K) else \
+                    "bottleneck^T" if ef & 16 else "gemm^T"
+                r8 = K + M                                                       # 8d: the forward counterpart's in + out
+                r8 += (K - kw["k_split"]) if kw.get("k_split") else 0            # heads: + the skip sum read back
+            return "gemm " + cls, 2.0 * M * K * B * T, rows * col, r8 * col
+        if name == "pw_wgrad":
+            B, M, N, T = kw["B"], kw["M"], kw["N"], kw["T"]
+            col = 4.0 * B * T
+            cls = "decoder basis" if kw.get("g_mul") else "heads" if kw.get("x_mode", 0) in (1, 3) and N >= M else \
+                "mask" if kw.get("x_mode", 0) == 1 else "bottleneck" if kw.get("x_mode", 0) == 2 else "conv1" if M > N and N >= 64 else "basis / other"
+            rows = M + N + (M if kw.get("g_mul") else 0) // max(1, kw.get("g_div", 1))
+            return "wgrad " + cls, 2.0 * M * N * B * T, rows * col, (M + N) * col
+        if name == "dwconv_fwd":
+            B, C, T = a[10], a[11], a[12]
+            return "depthwise fwd", None, 2.0 * C * 4 * B * T, 2.0 * C * 4 * B * T
+        if name == "dwconv_bwd":
+            B, C, T = a[15], a[16], a[17]
+            return "depthwise bwd", None, 4.0 * C * 4 * B * T, 4.0 * C * 4 * B * T
+        if name == "encoder_fwd":
+            B, Tin, N, F = a[4], a[6], a[7], a[10]
+            return "encoder fwd", None, 4.0 * B * (N * F + Tin), 4.0 * B * N * F
+        if name == "decoder_fwd":
+            B, ns, N, F, Tout = a[5], a[6], a[7], a[11], a[13]
+            return "decoder fwd", None, 4.0 * B * ((ns + 1) * N * F + ns * Tout), 4.0 * B * (ns * N * F + ns * Tout)
+        if name == "decoder_bwd":
+            B, ns, N, F, Tout = a[6], a[7], a[8], a[12], a[14]
+            return "decoder bwd", None, 4.0 * B * ((2 * ns + 2) * N * F + ns * Tout), 2 * 4.0 * B * (ns * N * F + ns * Tout)
+        if name == "head_bwd":
+            B, C, T = a[6], a[7], a[8]
+            return "head bwd", None, 4.0 * 4 * B * C * T, 4.0 * B * C * T
+        if name == "reduce_slabs":
+            return "reduce_slabs", None, 4.0 * sum(sg[3] * (sg[4] + 1) for sg in a[0]), None
+        if name == "gln_bwd_from_wgrad":
+            B, M, N, sps = a[12], a[13], a[14], a[15]
+            return "gln sums from wgrad", None, 4.0 * B * M * N * (sps + 1), None
+        if name in ("gln_bwd_finalize", "f64_to_f32", "pack_weights", "unfold", "sqnorm", "adam_step", "adam_step_dev", "softmax_ch_fwd", "softmax_ch_bwd"):
+            return name, None, None, None
+        return name, None, None, None
 
     def reset(self):
-        self.records = {"pw_gemm": [], "pw_wgrad": []}
+        self.records = []
+
+    def by_class(self):
+        out = {}
+        for e0, e1, cls, flop, bseq, b8d in self.records:
+            r = out.setdefault(cls, {"n": 0, "ms": 0.0, "flop": 0.0, "bytes_seq": 0.0, "bytes_8d": 0.0, "has_bytes": bseq is not None, "has_8d": b8d is not None})
+            r["n"] += 1
+            r["ms"] += e0.elapsed_time(e1)
+            r["flop"] += flop or 0.0
+            r["bytes_seq"] += bseq or 0.0
+            r["bytes_8d"] += b8d or 0.0
+        return out
 
     def summary(self, key):
-        ms = sum(r[0].elapsed_time(r[1]) for r in self.records[key])
-        return len(self.records[key]), ms, sum(r[2] for r in self.records[key]), sum(r[3] for r in self.records[key])
+        """(launches, ms, flop, bytes_seq) of a group: key = "pw_gemm" | "pw_wgrad" """
+        pre = "gemm " if key == "pw_gemm" else "wgrad "
+        rs = [r for c, r in self.by_class().items() if c.startswith(pre)]
+        return sum(r["n"] for r in rs), sum(r["ms"] for r in rs), sum(r["flop"] for r in rs), sum(r["bytes_seq"] for r in rs)
+
+
+def roofline_by_kernel(timed, steps, arith_name):
+    """One entry per launch class of the step (instrumented pass: HIP events around every launch, all on one stream): launches per step,
+    average duration, algorithmic bytes per launch under both conventions (TimedBackend), and the fraction of the roof that bounds the
+    class -- HBM (8 TB/s) for everything but the weight gradients, whose bf16x6 arithmetic is matrix-pipe bound (2500 / 6 TFLOP/s-eq)."""
+    out = {}
+    tot_ms = sum(r["ms"] for r in timed.by_class().values())
+    for cls, r in sorted(timed.by_class().items(), key=lambda kv: -kv[1]["ms"]):
+        n, ms = r["n"], r["ms"]
+        e = {"launches_per_step": n / steps, "avg_us": 1e3 * ms / n, "ms_per_step": ms / steps, "share_of_kernel_time": ms / tot_ms}
+        if r["has_bytes"] and ms > 0:
+            e["algorithmic_MB_per_launch"] = r["bytes_seq"] / n / 1e6
+            e["GBps"] = r["bytes_seq"] / (ms * 1e-3) / 1e9
+            e["hbm_frac"] = e["GBps"] / (HBM_PEAK_TBS * 1e3)
+        if r["has_8d"] and ms > 0:
+            e["survey_8d_MB_per_launch"] = r["bytes_8d"] / n / 1e6
+            e["hbm_frac_8d"] = r["bytes_8d"] / (ms * 1e-3) / 1e9 / (HBM_PEAK_TBS * 1e3)
+        if r["flop"] > 0 and ms > 0:
+            ar = ("f32" if arith_name == "f32" else "bf16x6") if cls.startswith("wgrad") else arith_name
+            per, pipe = MFMA_PER_PRODUCT[ar]
+            e["tflops_equiv"] = r["flop"] / (ms * 1e-3) / 1e12
+            e["matrix_pipe_frac"] = e["tflops_equiv"] / (pipe / per)
+            e["bound"] = "mfma" if cls.startswith("wgrad") and ar != "f32" else "hbm"
+        elif r["has_bytes"]:
+            e["bound"] = "hbm"
+        else:
+            e["bound"] = "latency"
+        out[cls] = e
+    return out
 
 
 # ---- workload constants (SURVEY.md section 8d); restated here so that the timed path imports nothing from oracle/ -------
@@ -110,19 +205,92 @@ def bytes_per_frame(cfg):
     return 4 * (R * X * (2 * Bn + 4 * H + 2 * Sc) + (2 * N + Bn + 2 * ns * N + ns * S))
 
 
-def pmc_traffic(group):
-    """HBM bytes per launch of a kernel group ("gemm" / "wgrad") from the committed rocprofv3 PMC passes of THIS build's step
-    (profiles/hbm_traffic.json, written by tools/pmc_passes.sh + tools/pmc_traffic.py: separate --pmc FETCH_SIZE and --pmc
-    WRITE_SIZE runs, FETCH_SIZE x2 on gfx950 as MI355X_MICROARCH.md prescribes), launch-weighted over all launches of the group
-    in a step.  PMC counters cannot be read from inside the timed process: the value is the one measured on the profiled run of
-    this same command and is labelled so."""
+def kernel_source_hash():
+    """sha256 over the kernel sources and the ABI header: what a traffic table is valid for"""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "dnn-based_source_separation_amd", "csrc")
+    for fn in sorted(os.listdir(csrc)):
+        if fn.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(csrc, fn), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "sepkernels.h"), "rb").read())
+    h.update(open(os.path.join(ROOT, "dnn-based_source_separation_amd", "src", "sepkernels", "net.py"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measure_pmc_traffic(batch, timeout_s=300):
+    """HBM bytes per launch of every kernel of the step, measured NOW: this command's own step (2 + 1 steps, one stream) under
+    `rocprofv3 --pmc FETCH_SIZE` and again under `--pmc WRITE_SIZE` (separate passes, as MI355X_MICROARCH.md prescribes; counters only, no
+    tracing), outside the timed region.  FETCH_SIZE x 2: on gfx950 it tallies the 128-byte requests at 64 bytes -- re-checked on this
+    library's access patterns with known byte counts (tools/fetch_calib.hip, profiles/r03b_fetch_calib.txt: contiguous, 64-byte and
+    128-byte row segments, global_load and LDS-DMA all report exactly half; WRITE_SIZE reports exactly the bytes written).
+    Returns {kernel name: (launches, read bytes, written bytes per launch)} or None when rocprofv3 is not available / fails."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    res = {}
+    env = dict(os.environ, SEPK_SIDE_STREAM="0", TMPDIR="/tmp")
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="sepk_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", ctr, "-d", d, "--", sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--batch", str(batch),
+                   "--no-cpu-baseline", "--no-f32-pass", "--no-kernel-timing", "--no-pmc", "--no-stock"]
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            dbs = glob.glob(d + "/**/*.db", recursive=True)
+            if not dbs:
+                return None
+            con = sqlite3.connect(dbs[0])
+            for name, n, avg in con.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? group by kernel_name", (ctr,)):
+                short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+                e = res.setdefault(short, [0, 0.0, 0.0])
+                e[0] = max(e[0], n)
+                e[1 if ctr == "FETCH_SIZE" else 2] = avg * 1024.0 * (2.0 if ctr == "FETCH_SIZE" else 1.0)
+            con.close()
+        except (subprocess.SubprocessError, OSError, sqlite3.Error):
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return res
+
+
+def traffic_block(per_kernel, steps_in_capture=3.0):
+    """(per-group traffic for the roofline objects, per-kernel table, step total) from measure_pmc_traffic's result"""
+    import re
+    groups = {"gemm": [0, 0.0], "wgrad": [0, 0.0]}
+    table, total = {}, 0.0
+    for name, (n, rd, wr) in sorted(per_kernel.items()):
+        total += n * (rd + wr)
+        if rd + wr >= 1e6:
+            table[name] = {"launches_per_step": n / steps_in_capture, "read_MB": rd / 1e6, "write_MB": wr / 1e6}
+        g = "gemm" if re.match(r"pw_gemm_", name) else "wgrad" if re.match(r"pw_wgrad", name) else None
+        if g and rd + wr >= 1e6:          # rocprofv3 returns zeros for one kernel of a capture now and then: left out
+            groups[g][0] += n
+            groups[g][1] += n * (rd + wr)
+    return ({g: (v[1] / max(v[0], 1), v[0] / steps_in_capture) for g, v in groups.items()}, table, total / steps_in_capture)
+
+
+def pmc_traffic(group, live=None):
+    """roofline.traffic of a kernel group ("gemm" / "wgrad"): HBM bytes per launch, launch-weighted over the group's launches in a step.
+    `live` = this run's own measurement (measure_pmc_traffic); else the committed table profiles/hbm_traffic.json -- used ONLY if it was
+    measured on these very kernel sources (its `source_hash` stamp must equal kernel_source_hash(); round 2 once reported a stale copy)."""
+    if live is not None:
+        per_launch, launches = live[group]
+        return {"traffic": per_launch, "traffic_unit": "bytes/launch", "traffic_launches_per_step": launches, "traffic_live": True,
+                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this command, run by bench.py itself after the timed region (FETCH_SIZE x2 on gfx950)"}
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
+        if t.get("source_hash") != kernel_source_hash():
+            return {"traffic": None, "traffic_note": "profiles/hbm_traffic.json was measured on other kernel sources (stamp {} != {}): not reported".format(
+                t.get("source_hash"), kernel_source_hash())}
         g = t["groups"][group]
         return {"traffic": g["bytes_per_launch"], "traffic_unit": "bytes/launch", "traffic_launches_per_step": g["launches_per_step"],
-                "traffic_launches_per_step_without_counters": g.get("launches_per_step_without_counters", 0.0),
                 "traffic_live": False, "traffic_source": t["source"]}
     except (OSError, KeyError, ValueError):
         return {"traffic": None}
@@ -157,50 +325,126 @@ def kernel_roofline(timed, key, arith, steps, elapsed_instr, names):
     return out
 
 
+REFERENCE_SRC = "/root/reference/src"
+
+# Runs in a child process with the reference's src/ as the ONLY package root (its flat package names -- models, criterion, utils ... -- are
+# the ones this repository's drop-in uses too): the unmodified reference classes, timed exactly like the port below.
+_REFERENCE_TIMER = r"""
+import json, sys, time, torch
+sys.path.insert(0, sys.argv[1])
+from models.conv_tasnet import ConvTasNet
+from criterion.sdr import NegSISDR
+from criterion.pit import PIT1d
+cfg, T, timed_steps, do16 = json.loads(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+torch.manual_seed(111)
+model = ConvTasNet(**cfg)
+crit = PIT1d(NegSISDR(), n_sources=2)
+g = torch.Generator().manual_seed(111)
+def step(mixture, sources):
+    for q in model.parameters():
+        q.grad = None
+    loss, _ = crit(model(mixture), sources)
+    loss.backward()
+def run(B, cores, n):
+    sources = 0.1 * torch.randn(B, 2, T, generator=g)
+    mixture = sources.sum(1, keepdim=True)
+    torch.set_num_threads(cores)
+    step(mixture, sources)
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter(); step(mixture, sources); ts.append(time.perf_counter() - t0)
+    return sorted(ts)[len(ts) // 2]
+all_cores = torch.get_num_threads()
+best = min((run(2, c, 2), c) for c in sorted({all_cores, min(all_cores, 32)}, reverse=True))
+cores = best[1]
+out = {"cores": cores, "dt2": run(2, cores, timed_steps)}
+if do16:
+    out["dt16"] = run(16, cores, 1)
+print("REFJSON" + json.dumps(out))
+"""
+
+
+def _time_reference(timed_steps, do16):
+    """{cores, dt2[, dt16]} of the unmodified reference in a child process, or None where /root/reference is absent (the GPU boxes)"""
+    import subprocess
+    if not os.path.isdir(REFERENCE_SRC):
+        return None
+    try:
+        r = subprocess.run([sys.executable, "-c", _REFERENCE_TIMER, REFERENCE_SRC, json.dumps(PAPER), str(T_SAMPLES), str(timed_steps), str(int(do16))],
+                           capture_output=True, text=True, timeout=900, env={k: v for k, v in os.environ.items() if k != "PYTHONPATH"})
+        line = [q for q in r.stdout.splitlines() if q.startswith("REFJSON")]
+        return json.loads(line[-1][7:]) if line else None
+    except (subprocess.SubprocessError, OSError, ValueError):
+        return None
+
+
 def cpu_baseline(timed_steps=5):
-    """Reference-equivalent CPU path (oracle/fast_port.py) on the host cores, bounded sample: `timed_steps` fwd+PIT+bwd steps
-    of B=2 paper-best utterances (median), plus one step at the benchmark's own B=16 when the host has the memory."""
-    from oracle import fast_port as FP       # the ONLY oracle import of this file: the cpu_baseline leg
-    from models.conv_tasnet import ConvTasNet
-    torch.manual_seed(111)
-    model = ConvTasNet(**PAPER)
-    p = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    g = torch.Generator().manual_seed(111)
+    """The reference's CPU path on the host cores, bounded sample: `timed_steps` fwd+PIT+bwd steps of B=2 paper-best utterances (median),
+    plus one step at the benchmark's own B=16 when the host has the memory.  kind "reference": the unmodified reference classes
+    (/root/reference/src exists: the build container); kind "port": oracle/fast_port.py, the same path on torch.nn.functional (same ATen
+    CPU kernels), whose equality with the live reference at paper-best is tests/test_oracle_vs_reference_cpu.py."""
     F = num_frames(T_SAMPLES, 16, 8)
-
-    def run(B, cores, n):
-        sources = 0.1 * torch.randn(B, 2, T_SAMPLES, generator=g)
-        mixture = sources.sum(1, keepdim=True)
-        torch.set_num_threads(cores)
-        FP.train_step(p, PAPER, mixture, sources, dtype=torch.float32)      # oneDNN primitive caches / allocator warm-up
-        ts = []
-        for _ in range(n):
-            t0 = time.perf_counter()
-            FP.train_step(p, PAPER, mixture, sources, dtype=torch.float32)
-            ts.append(time.perf_counter() - t0)
-        return sorted(ts)[len(ts) // 2]
-
-    all_cores = torch.get_num_threads()
-    best = None
-    for cores in sorted({all_cores, min(all_cores, 32)}, reverse=True):   # oneDNN often peaks below the full core count
-        dt_c = run(2, cores, 2)
-        if best is None or dt_c < best[0]:
-            best = (dt_c, cores)
-    cores = best[1]
-    dt = run(2, cores, timed_steps)
-    out = {"value": 2 * F / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-           "sample": "median of {} timed fwd+PIT+bwd steps (after warm-up) of B=2 paper-best utterances, fp32, torch CPU (oracle/fast_port.py: "
-                     "same ATen conv/GroupNorm kernels as the reference modules; equality with the live reference is tested in "
-                     "tests/test_oracle_vs_reference_cpu.py), {:.2f} s/step".format(timed_steps, dt)}
     try:
         free_gb = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 2 ** 30
     except (ValueError, OSError):
         free_gb = 0.0
-    if free_gb > 48:                      # one B=16 step keeps ~14 GB of activations for autograd
-        dt16 = run(16, cores, 1)
+    do16 = free_gb > 48                   # one B=16 step keeps ~14 GB of activations for autograd
+    ref = _time_reference(timed_steps, do16)
+    if ref is not None:
+        kind, cores, dt, dt16 = "reference", ref["cores"], ref["dt2"], ref.get("dt16")
+        what = "the unmodified reference in a child process (/root/reference/src: models.conv_tasnet.ConvTasNet, criterion.pit.PIT1d(criterion.sdr.NegSISDR()))"
+    else:
+        from oracle import fast_port as FP       # the ONLY oracle import of this file: the cpu_baseline leg
+        from models.conv_tasnet import ConvTasNet
+        torch.manual_seed(111)
+        model = ConvTasNet(**PAPER)
+        p = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        g = torch.Generator().manual_seed(111)
+
+        def run(B, cores, n):
+            sources = 0.1 * torch.randn(B, 2, T_SAMPLES, generator=g)
+            mixture = sources.sum(1, keepdim=True)
+            torch.set_num_threads(cores)
+            FP.train_step(p, PAPER, mixture, sources, dtype=torch.float32)      # oneDNN primitive caches / allocator warm-up
+            ts = []
+            for _ in range(n):
+                t0 = time.perf_counter()
+                FP.train_step(p, PAPER, mixture, sources, dtype=torch.float32)
+                ts.append(time.perf_counter() - t0)
+            return sorted(ts)[len(ts) // 2]
+
+        all_cores = torch.get_num_threads()
+        best = min((run(2, c, 2), c) for c in sorted({all_cores, min(all_cores, 32)}, reverse=True))   # oneDNN often peaks below the full core count
+        cores = best[1]
+        dt = run(2, cores, timed_steps)
+        dt16 = run(16, cores, 1) if do16 else None
+        torch.set_num_threads(all_cores)
+        kind = "port"
+        what = ("oracle/fast_port.py (same ATen conv / GroupNorm kernels as the reference modules; equality with the live reference is tested in "
+                "tests/test_oracle_vs_reference_cpu.py; /root/reference is not present on this box)")
+    out = {"value": 2 * F / dt, "unit": "frames/s", "cores": cores, "kind": kind,
+           "sample": "median of {} timed fwd+PIT+bwd steps (after warm-up) of B=2 paper-best utterances, fp32, torch CPU: {}, {:.2f} s/step".format(timed_steps, what, dt)}
+    if dt16 is not None:
         out["batch16"] = {"value": 16 * F / dt16, "unit": "frames/s", "s_per_step": dt16, "sample": "one timed step (after one warm-up) at the benchmark's B=16"}
-    torch.set_num_threads(all_cores)
     return out
+
+
+def hipified_baseline(mixture, sources, steps=5):
+    """SURVEY.md section 8d's "hipified baseline": the same training step on stock PyTorch-ROCm ops (nn.Conv1d / nn.GroupNorm / nn.PReLU /
+    nn.ConvTranspose1d modules, autograd, torch.optim.Adam -> MIOpen / rocBLAS / ATen kernels; tools/stock_torch_convtasnet.py), same
+    batch, same device, timed after the headline region.  What the device gives without this library's kernels."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import stock_torch_convtasnet as stock
+    try:
+        dt, nparam = stock.time_train_step(PAPER, mixture, sources, steps=steps, warmup=2)
+    except RuntimeError as e:       # e.g. out of memory on a small device
+        return {"value": None, "error": str(e)[:200]}
+    finally:
+        torch.cuda.empty_cache()
+    B = mixture.shape[0]
+    F = num_frames(T_SAMPLES, PAPER["kernel_size"], PAPER["stride"])
+    return {"value": B * F / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt, "parameters": nparam,
+            "what": "stock torch.nn modules + autograd + torch.optim.Adam on the same device and batch (MIOpen / rocBLAS / ATen), fp32, {} timed steps after 2 warm-up".format(steps)}
 
 
 def _dual_path_workloads():
@@ -297,6 +541,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-f32-pass", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic (N = 1 only)")
+    ap.add_argument("--no-stock", action="store_true", help="skip the hipified_baseline leg (stock torch.nn modules on the same device)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured step (N = 1)")
     ap.add_argument("--config", default="convtasnet2", choices=["convtasnet2", "sinkpit4", "dprnn", "dptnet", "galrnet", "sepformer"],
                     help="convtasnet2 (default) = BASELINE.json configs[1]/[2], the headline; sinkpit4 = configs[4] (paper-best Conv-TasNet, "
@@ -398,9 +644,10 @@ def main():
     my_elapsed = elapsed
 
     arith_name = sepkernels.gemm_arith_name()
-    roof = roof_w = None
+    roof = roof_w = by_kernel = None
     if not args.no_kernel_timing:
         el_i = instrumented_pass(args.steps)
+        by_kernel = roofline_by_kernel(timed, args.steps, arith_name)
         roof = kernel_roofline(timed, "pw_gemm", arith_name, args.steps, el_i,
                                "sep_pw_gemm: pw_gemm_pc_kernel (K >= 512 or M >= 1024) / pw_gemm_coop_kernel")
         # the weight gradient keeps the exact three-way bf16 split in every non-f32 arithmetic
@@ -476,14 +723,30 @@ def main():
         }
         if f32_pass is not None:
             out["fp32_mfma_pass"] = f32_pass
+        live = None
+        if world == 1 and args.config == "convtasnet2" and not args.no_pmc and (roof is not None or roof_w is not None):
+            torch.cuda.empty_cache()                      # the counter passes run this command again in child processes (~10 GB each of the 288)
+            per_kernel = measure_pmc_traffic(args.batch)
+            if per_kernel:
+                live, table, step_total = traffic_block(per_kernel)
+                out["hbm_traffic"] = {"step_total_GB": step_total / 1e9, "over_algorithmic": step_total / (args.batch * F * by_frame), "per_kernel": table,
+                                      "source_hash": kernel_source_hash(),
+                                      "what": "HBM bytes of one step (forward + loss + backward + clip + Adam, one stream), rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
+                                              "separate passes of this command run by bench.py after the timed region; kernels above 1 MB per launch listed"}
         if roof is not None:
-            roof.update(pmc_traffic("gemm"))
+            roof.update(pmc_traffic("gemm", live))
             if roof.get("traffic"):
                 roof["traffic_over_algorithmic"] = roof["traffic"] / roof["algorithmic_bytes_per_launch"]
             out["roofline"] = roof
         if roof_w is not None:
-            roof_w.update(pmc_traffic("wgrad"))
+            roof_w.update(pmc_traffic("wgrad", live))
+            if roof_w.get("traffic"):
+                roof_w["traffic_over_algorithmic"] = roof_w["traffic"] / roof_w["algorithmic_bytes_per_launch"]
             out["roofline_wgrad"] = roof_w
+        if by_kernel is not None:
+            out["roofline_by_kernel"] = by_kernel
+        if world == 1 and args.config == "convtasnet2" and not args.no_stock:
+            out["hipified_baseline"] = hipified_baseline(mixture, sources)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

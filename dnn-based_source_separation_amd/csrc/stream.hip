@@ -419,8 +419,11 @@ __global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
     const float a1 = alpha1[0], a2 = alpha2[0];
     const float sc1 = gamma1[c] * r1, sh1 = beta1[c] - mu1 * sc1;
     const float g2 = gamma2[c];
-    float mg, mgx;
-    gln_bwd_means(bacc2 + (size_t)b * SEP_STATS_SLOTS * 2, stats2 + (size_t)b * SEP_STATS_SLOTS * 2, (double)C * T, eps, mg, mgx);
+    if (threadIdx.x == 0) {          // one thread forms the sample's two means (64 fp64 loads, fp64 divide / sqrt) while the others fetch the row
+        float a_, c_;
+        gln_bwd_means(bacc2 + (size_t)b * SEP_STATS_SLOTS * 2, stats2 + (size_t)b * SEP_STATS_SLOTS * 2, (double)C * T, eps, a_, c_);
+        part[3][0] = a_; part[3][1] = c_;
+    }
     const size_t rowoff = (size_t)row * ldt;
     const int nq4 = ldt / 4;
     float q_dal = 0.f;
@@ -436,6 +439,8 @@ __global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
             av[k] = ld4(a + rowoff + 4 * q);
         }
     }
+    __syncthreads();
+    const float mg = part[3][0], mgx = part[3][1];      // (part[] is written again only behind the next barrier)
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
         const int q = threadIdx.x + 256 * k;
@@ -621,15 +626,31 @@ __global__ __launch_bounds__(256) void gln_bwd_from_wgrad_kernel(const float* __
     __syncthreads();
     float r1 = 0.f, r2 = 0.f;
     if (live) {
+        // rows m = 4 j + wv of this wave, eight at a time with all their loads (8 x (sps + 1)) in flight: the first version walked the rows
+        // one by one -- 64 dependent round trips per wave, 87 us per launch for 42 MB (profiles/r03c_kernel_stats.md)
         const size_t slab = (size_t)M * N;
         const float* p0 = part + (size_t)b * sps * slab + n;
-        for (int m = wv; m < M; m += 4) {
-            float raw = 0.f;
-            for (int k = 0; k < sps; ++k) raw += p0[k * slab + (size_t)m * N];
-            const float w = W[(size_t)m * N + n], g = gs[m];
-            r1 = fmaf(w, g, r1);
-            r2 = fmaf(w, raw, r2);
-            dW_b[((size_t)b * M + m) * N + n] = fmaf(sc, raw, sh * g);
+        for (int m0 = wv; m0 < M; m0 += 32) {
+            float raw[8], w[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = m0 + 4 * i;
+                raw[i] = 0.f; w[i] = 0.f;
+                if (m < M) {
+                    w[i] = W[(size_t)m * N + n];
+                    for (int k = 0; k < sps; ++k) raw[i] += p0[k * slab + (size_t)m * N];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = m0 + 4 * i;
+                if (m < M) {
+                    const float g = gs[m];
+                    r1 = fmaf(w[i], g, r1);
+                    r2 = fmaf(w[i], raw[i], r2);
+                    dW_b[((size_t)b * M + m) * N + n] = fmaf(sc, raw[i], sh * g);
+                }
+            }
         }
     }
     red[(wv * 64 + lane) * 2] = r1;

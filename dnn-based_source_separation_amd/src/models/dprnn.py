@@ -82,6 +82,10 @@ class IntraChunkRNN(_PathRNN):
 
 class InterChunkRNN(_PathRNN):
     def __init__(self, num_features, hidden_channels, causal, norm=True, rnn_type="lstm", eps=EPS):
+        if rnn_type == "lstm":
+            # the reference builds this path's LSTM twice (dprnn.py:108-121: once unconditionally, then again by `causal`) and keeps the
+            # second: the first one's draws from the global generator are part of "same seed -> same initial weights"
+            choose_rnn(rnn_type, input_size=num_features, hidden_size=hidden_channels, batch_first=True, bidirectional=True)
         super().__init__(num_features, hidden_channels, not causal, "cLN" if causal else "gLN", norm, rnn_type, causal, eps)
 
     def forward(self, input):

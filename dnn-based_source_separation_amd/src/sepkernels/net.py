@@ -423,6 +423,19 @@ class _SideStream:
         if self.on:
             self.main.wait_stream(self.side)
 
+    def mark(self):
+        """an event behind what is queued on the side stream SO FAR"""
+        if not self.on:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self.side)
+        return ev
+
+    def wait(self, ev):
+        """main waits for a mark() (later side-stream work does not hold main up)"""
+        if self.on and ev is not None:
+            self.main.wait_event(ev)
+
 
 def backward(cfg, P, sv, d_est, G, on_ready=None):
     """See _backward; sets the per-pass weight bound of SEP_ARITH_F16X3 around it."""
@@ -480,6 +493,7 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
     # after the loop instead of ~100 tiny launches inside it (each costs a ~5 us dispatch bubble on the critical path).
     # Price: the slabs of all layers stay alive until the flush (~1.6 GB at B=16 paper-best; HBM is 288 GB).
     pending = []
+    deferred = []                  # leaves of the layer just differentiated, queued on the side stream behind the next layer's hand-off
     flushed_from = nl + 1          # dalpha entries [flushed_from, nl] are already converted (bucketed mode)
     dout = None
     for li in range(nl - 1, -1, -1):
@@ -510,15 +524,24 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
                 heads.append((dS, None, 0, Sc, Ws, [(sp + "skip_pointwise_conv1d.weight", 0, Sc)], [(sp + "skip_pointwise_conv1d.bias", 0, Sc)]))
         else:
             heads.append((dS, None, 0, Sc, Ws, [(sp + "skip_pointwise_conv1d.weight", 0, Sc)], [(sp + "skip_pointwise_conv1d.bias", 0, Sc)]))
+        # Side stream: [heads weight gradient -> gLN2 sums] run beside the input-gradient product below (both only need dout, dS, z); the
+        # depthwise backward waits for the sums through an event.  The PREVIOUS layer's conv1 weight gradient -- a leaf nobody waits for --
+        # is queued behind them, so that it never delays the hand-off.
         segs = []
-        for hi, (Gt, G2t, gsp, rows, Wmat, wnames, bnames) in enumerate(heads):
-            part, pb, ns = wgrad(rows, H, Gt, z, True, True, G2=G2t, g_split=gsp, **xkw)
-            dWb = torch.empty(B, rows, H, **f32)
-            K.gln_bwd_from_wgrad(part, pb, Wmat, st2, g2, b2, cnt, teps, dWb, pbeta2, pgamma2, bacc[2 + 2 * li], B, rows, H, ns // B,
-                                 accumulate=int(hi > 0))
-            segs += [(dWb, r0 * H, G[nm], nr * H, B, rows * H, 0, 1.0) for nm, r0, nr in wnames]
-            segs += [(pb, r0, G[nm], nr, ns, rows, 0, 1.0) for nm, r0, nr in bnames]
+        dWbs = [torch.empty(B, rows, H, **f32) for (_, _, _, rows, _, _, _) in heads]
+        side.keep(pbeta2, pgamma2, *dWbs)
+        with side:
+            for hi, (Gt, G2t, gsp, rows, Wmat, wnames, bnames) in enumerate(heads):
+                part, pb, ns = wgrad(rows, H, Gt, z, True, True, G2=G2t, g_split=gsp, **xkw)
+                K.gln_bwd_from_wgrad(part, pb, Wmat, st2, g2, b2, cnt, teps, dWbs[hi], pbeta2, pgamma2, bacc[2 + 2 * li], B, rows, H, ns // B,
+                                     accumulate=int(hi > 0))
+                segs += [(dWbs[hi], r0 * H, G[nm], nr * H, B, rows * H, 0, 1.0) for nm, r0, nr in wnames]
+                segs += [(pb, r0, G[nm], nr, ns, rows, 0, 1.0) for nm, r0, nr in bnames]
         pending += segs
+        ev_sums = side.mark()
+        for leaf in deferred:
+            leaf()
+        deferred = []
 
         # dv2 = Wo^T dout + Ws^T dS
         dv2 = torch.empty(B, H, ldt, **f32)
@@ -531,7 +554,8 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
         else:
             K.pw_gemm(B=B, M=H, K=Sc, T=F, ldt=ldt, trans_a=1, A=Ws, A_pk=PK.get("skip.{}^T".format(li)), X=dS, Y=dv2, eps=teps)
 
-        # depthwise^T and everything hanging off it
+        # depthwise^T and everything hanging off it (needs gLN2's sums from the side stream)
+        side.wait(ev_sums)
         dv1 = torch.empty(B, H, ldt, **f32)
         rp1 = torch.empty(B, H, nt1024, 8, **f32)
         K.dwconv_bwd(dv2, z, a, st1, g1, b1, al1, st2, g2, al2, bacc[2 + 2 * li], P[sp + "depthwise_conv1d.weight"], dv1, rp1,
@@ -561,21 +585,27 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
         # da and dx now exist: the side stream may go on (this layer's dW1, the next layer's head gradients)
         side.fork()
         side.keep(da, dx, rp1, pbeta1, pgamma1, pextra)
-        with side:
-            # second stage of gLN1's backward: parameter gradients only, nothing in the chain waits for it
-            K.gln_bwd_finalize(rp1, nt1024, 8, st1, g1, cnt, teps, None, pbeta1, pgamma1, pextra, B, H)
-            part, pb, ns = wgrad(H, Bn, da, x, True, True)
-            segs = [(part, 0, G[pre + "bottleneck_conv1d.weight"], H * Bn, ns, H * Bn, 0, 1.0),
-                    (pb, 0, G[pre + "bottleneck_conv1d.bias"], H, ns, H, 0, 1.0)]
-            if side.on:
-                K.reduce_slabs(segs)
-            else:
-                pending += segs
+
+        def conv1_leaves(da=da, x=x, rp1=rp1, st1=st1, g1=g1, pbeta1=pbeta1, pgamma1=pgamma1, pextra=pextra, pre=pre):
+            """this layer's leaves: second stage of gLN1's backward (parameter gradients only) and the conv1 weight gradient"""
+            with side:
+                K.gln_bwd_finalize(rp1, nt1024, 8, st1, g1, cnt, teps, None, pbeta1, pgamma1, pextra, B, H)
+                part, pb, ns = wgrad(H, Bn, da, x, True, True)
+                segs = [(part, 0, G[pre + "bottleneck_conv1d.weight"], H * Bn, ns, H * Bn, 0, 1.0),
+                        (pb, 0, G[pre + "bottleneck_conv1d.bias"], H, ns, H, 0, 1.0)]
+                if side.on:
+                    K.reduce_slabs(segs)
+                else:
+                    pending.extend(segs)
+        deferred.append(conv1_leaves)
         dout = dx
         X_layers = cfg["sep_num_layers"]
         if on_ready is not None and li % X_layers == 0 and li > 0:
             # a whole TCN block is done: flush its queued reductions (and its PReLU slopes) so that the caller can
             # start the all-reduce of this bucket while the earlier blocks are still being differentiated
+            for leaf in deferred:
+                leaf()
+            deferred = []
             side.join()
             blk = li // X_layers
             hi = nl + 1 if blk == cfg["sep_num_blocks"] - 1 else (blk + 1) * X_layers     # the last block also owns the mask PReLU slope
@@ -589,6 +619,8 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
             pending = []
             flushed_from = lo
             on_ready(blk)
+    for leaf in deferred:
+        leaf()
     side.join()
     # PReLU slope gradients were accumulated in fp64 (one scalar per layer + the mask PReLU): one conversion, then
     # scattered into the parameter gradients by the same flush

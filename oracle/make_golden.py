@@ -254,6 +254,45 @@ def dprnn_golden(NegSISDR, PIT1d):
     print("dprnn params", model.num_parameters, "loss", loss64.item(), "pattern", pattern.tolist())
 
 
+# BASELINE.json configs[3] at its REAL size (reference egs/wsj0-mix/dprnn-tasnet/train.sh:28-37), one utterance of 4 s @ 8 kHz
+DPRNN_FULL_CFG = dict(n_basis=64, kernel_size=2, stride=1, enc_basis="trainable", dec_basis="trainable", enc_nonlinear=None,
+                      sep_hidden_channels=128, sep_bottleneck_channels=64, sep_chunk_size=250, sep_hop_size=125, sep_num_blocks=6,
+                      sep_norm=True, mask_nonlinear="sigmoid", causal=False, rnn_type="lstm", n_sources=2)
+DPRNN_FULL_SEEDS = dict(model=111, perturb=11, data=333)
+
+
+def sample_index(n, k=64):
+    """the k positions of a flat tensor of n elements a fingerprint keeps (first, last and an even spread)"""
+    return sorted(set(int(round(q * (n - 1) / max(k - 1, 1))) for q in range(min(k, n))))
+
+
+def dprnn_full_golden(NegSISDR, PIT1d):
+    """The full-size DPRNN-TasNet of the REFERENCE on one seeded utterance, fp64: output, PIT loss, permutation and a fingerprint of every
+    parameter gradient (L2 norm, largest magnitude, 64 sampled elements).  The 2.6 M parameters are not stored: default initialisation under
+    the seed (the product's classes draw the same values, tests check the parameter fingerprints first) + perturb()."""
+    import copy
+    from models.dprnn_tasnet import DPRNNTasNet
+    torch.manual_seed(DPRNN_FULL_SEEDS["model"])
+    model = DPRNNTasNet(**DPRNN_FULL_CFG)
+    perturb(model, DPRNN_FULL_SEEDS["perturb"])
+    g = torch.Generator().manual_seed(DPRNN_FULL_SEEDS["data"])
+    sources = 0.1 * torch.randn(1, 2, 32000, generator=g)
+    mixture = sources.sum(dim=1, keepdim=True)
+    m64 = copy.deepcopy(model).double()
+    out64 = m64(mixture.double())
+    loss64, pattern = PIT1d(NegSISDR(), n_sources=2)(out64, sources.double())
+    loss64.backward()
+    blob = {"output_f64": out64.detach().numpy().astype(np.float32), "loss_f64": np.array(loss64.item()), "pattern": pattern.numpy(),
+            "num_parameters": np.array(model.num_parameters), "mixture_head": mixture.numpy()[0, 0, :16]}
+    for k, v in model.state_dict().items():
+        blob["pfp/" + k] = np.array([v.double().sum().item(), v.double().abs().sum().item()])
+    for k, p in m64.named_parameters():
+        gr = p.grad.reshape(-1)
+        blob["gfp/" + k] = np.concatenate([[gr.norm().item(), gr.abs().max().item()], gr[sample_index(gr.numel())].numpy()])
+    np.savez_compressed(os.path.join(OUT, "dprnn_tasnet_full.npz"), **blob)
+    print("dprnn full: params", model.num_parameters, "loss", loss64.item(), "pattern", pattern.tolist())
+
+
 # DPTNet / GALRNet / SepFormer (SURVEY.md section 8 row f4): small configurations, channel counts in multiples of 16 so that the
 # product runs them on its kernel path, plus one with odd widths (composition path).  403 samples -> 201 frames: both the
 # waveform padding and the chunk padding (1 frame left, 2 right) are exercised.
@@ -355,4 +394,6 @@ if __name__ == "__main__":
         pit_kat(NegSISDR, SISDR, PIT1d, SinkPIT)
         op_golden(NegSISDR)
         dprnn_golden(NegSISDR, PIT1d)
+    if not only or "dprnn_full" in only:
+        dprnn_full_golden(NegSISDR, PIT1d)
     print("golden vectors written to", OUT)

@@ -353,6 +353,52 @@ def test_dprnn_tasnet_golden(golden_dir):
     assert flat_rel <= 2e-3, "flat gradient rel-inf {:.3e}, worst tensor {}".format(flat_rel, worst)
 
 
+def _dprnn_full_model_and_data(g):
+    """the product's DPRNN-TasNet at BASELINE configs[3]'s real size under the seeds of oracle/make_golden.py::dprnn_full_golden; the 2.6 M
+    parameters are not in the fixture, so their fingerprints (sum, abs-sum per tensor) are checked against the reference's first"""
+    from oracle.make_golden import DPRNN_FULL_CFG, DPRNN_FULL_SEEDS, perturb
+    from models.dprnn_tasnet import DPRNNTasNet
+    torch.manual_seed(DPRNN_FULL_SEEDS["model"])
+    model = DPRNNTasNet(**DPRNN_FULL_CFG)
+    perturb(model, DPRNN_FULL_SEEDS["perturb"])
+    for k, v in model.state_dict().items():
+        fp = g["pfp/" + k]
+        assert abs(v.double().sum().item() - fp[0]) <= 1e-6 * (fp[1] + 1e-12) and abs(v.double().abs().sum().item() - fp[1]) <= 1e-6 * (fp[1] + 1e-12), k
+    gen = torch.Generator().manual_seed(DPRNN_FULL_SEEDS["data"])
+    sources = 0.1 * torch.randn(1, 2, 32000, generator=gen)
+    mixture = sources.sum(dim=1, keepdim=True)
+    assert np.array_equal(mixture.numpy()[0, 0, :16], g["mixture_head"])
+    return model, mixture, sources
+
+
+def test_dprnn_tasnet_full_size_golden(golden_dir):
+    """BASELINE.json configs[3] at its REAL size (N=64, L=2, F=64, H=128, K=250, P=125, 6 blocks; one utterance of 4 s @ 8 kHz = 31 999
+    frames, 255 chunks) against the unmodified reference's fp64 run (tests/golden/dprnn_tasnet_full.npz, written by
+    oracle/make_golden.py::dprnn_full_golden): output, PIT loss, permutation and every parameter gradient through its fingerprint (L2 norm
+    and 64 sampled elements per tensor)."""
+    from oracle.make_golden import sample_index
+    g = np.load(os.path.join(golden_dir, "dprnn_tasnet_full.npz"))
+    model, mixture, sources = _dprnn_full_model_and_data(g)
+    model.cuda()
+    est = model(mixture.cuda())
+    ref = torch.from_numpy(g["output_f64"])
+    assert _rel(est, ref) <= TOL
+    loss, pattern = PIT1d(NegSISDR(), n_sources=2)(est, sources.cuda())
+    assert abs(loss.item() - float(g["loss_f64"])) <= TOL * abs(float(g["loss_f64"]))
+    assert np.array_equal(pattern.cpu().numpy(), g["pattern"])
+    loss.backward()
+    gmax = max(float(g["gfp/" + k][1]) for k, _ in model.named_parameters())
+    worst = ("", 0.0)
+    for k, p in model.named_parameters():
+        fp = g["gfp/" + k]
+        gr = p.grad.detach().double().cpu().reshape(-1)
+        assert abs(gr.norm().item() - fp[0]) <= 2e-3 * fp[0] + 1e-6 * gmax, (k, gr.norm().item(), fp[0])
+        e = (gr[sample_index(gr.numel())] - torch.from_numpy(fp[2:]).double()).abs().max().item() / gmax
+        if e > worst[1]:
+            worst = (k, e)
+    assert worst[1] <= 2e-3, "sampled gradient elements: rel-inf {:.3e} (of the largest gradient magnitude) in {}".format(worst[1], worst[0])
+
+
 @pytest.mark.parametrize("name", ["dptnet", "dptnet_causal", "dptnet_odd", "galrnet", "galrnet_causal", "sepformer", "sepformer_causal",
                                   "dprnn_tasnet_causal", "dprnn_tasnet_odd", "dprnn_tasnet_softmax"])
 def test_sibling_separators_golden(golden_dir, name):
@@ -506,12 +552,15 @@ def test_paper_best_four_speakers_sinkpit_full_size():
     assert torch.equal(pat_s.cpu(), pat_h.cpu())
 
 
-def test_paper_best_four_speakers_sinkpit_against_oracle():
+@pytest.mark.parametrize("mask", ["softmax", "sigmoid"])
+def test_paper_best_four_speakers_sinkpit_against_oracle(mask):
     """BASELINE.json configs[4] at one utterance: forward, Sinkhorn-PIT (k = 200) loss and every parameter gradient against the
-    fp64 CPU port (oracle/fast_port.py forward + oracle/convtasnet_oracle.py sinkpit)."""
+    fp64 CPU port (oracle/fast_port.py forward + oracle/convtasnet_oracle.py sinkpit).  "softmax" is the configuration exactly as
+    bench.py --config sinkpit4 runs it (egs/tutorials/sinkpit_conv-tasnet/train.sh: mask_nonlinear softmax over all 4 x 512 channels of
+    a frame: sep_softmax_ch_fwd / bwd at C = 2048)."""
     from criterion.pit import SinkPIT
     from oracle import convtasnet_oracle as O
-    cfg = dict(PAPER, n_sources=4)
+    cfg = dict(PAPER, n_sources=4, mask_nonlinear=mask)
     torch.manual_seed(23)
     model = ConvTasNet(**cfg)
     p = {k: v.detach().clone() for k, v in model.state_dict().items()}
@@ -532,6 +581,29 @@ def test_paper_best_four_speakers_sinkpit_against_oracle():
     loss.backward()
     flat_rel, worst = _grad_report(model, ref_grads)
     assert flat_rel <= TOL, "flat gradient rel-inf {:.3e}, worst tensor {}".format(flat_rel, worst)
+
+
+@pytest.mark.parametrize("T", [80000, 64007, 8001])
+def test_validation_regime_paper_best_one_utterance_any_length(T):
+    """SURVEY.md section 8f rank 2 (reference egs/wsj0-mix/common/src/driver.py:166-206): validation runs ONE utterance of its natural
+    length (up to 10 s @ 8 kHz) through the paper-best model under torch.no_grad().  Forward and PIT loss against the fp64 CPU port at
+    10 s, at a length off every tile size (64007 -> 8000 frames + input padding) and at 1 s."""
+    torch.manual_seed(31)
+    model = ConvTasNet(**PAPER)
+    p = {k: v.detach().clone().double() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(T)
+    sources = 0.1 * torch.randn(1, 2, T, generator=g)
+    mixture = sources.sum(1, keepdim=True)
+    with torch.no_grad():
+        ref_out, _ = FP.conv_tasnet(mixture.double(), p, PAPER)
+        ref_loss, ref_pat = FP.neg_sisdr_pit(ref_out, sources.double())
+        model.cuda().eval()
+        est = model(mixture.cuda())
+        loss, pattern = PIT1d(NegSISDR(), n_sources=2)(est, sources.cuda())
+    assert est.shape == (1, 2, T)
+    assert _rel(est, ref_out) <= TOL
+    assert abs(loss.item() - ref_loss.item()) <= TOL * abs(ref_loss.item())
+    assert torch.equal(pattern.cpu(), ref_pat)
 
 
 def test_music_recipe_shapes_long_rows_and_generic_filterbank_paths():
