@@ -94,18 +94,28 @@ __device__ __forceinline__ void gln_mu_rstd(const double* st, double count, floa
     rstd = (float)r;
 }
 // gLN backward: the two per-sample means every input gradient needs,
-//     mg = mean_{c,t}(gamma_c g),   mgx = mean_{c,t}(gamma_c g xhat),   xhat = (u - mu) rstd,
-// from the RAW sums the kernel that produced g accumulated with fp64 atomics into SEP_STATS_SLOTS slots per sample, exactly like the
-// forward statistics:  acc[slot] = { sum_c gamma_c sum_t g , sum_c gamma_c sum_t g u }.  Both are linear in the row sums, so they need
-// neither mu nor rstd when they are accumulated, and no second-stage kernel sits between producer and consumer (round 2 had two
-// launches there, 98 per step on the critical path).  acc / st point at the sample's first slot.
-__device__ __forceinline__ void gln_bwd_means(const double* acc, const double* st, double count, float eps, float& mg, float& mgx) {
+//     mg = mean_{c,t}(gamma_c g),   mgx = mean_{c,t}(gamma_c g xhat),   xhat = (u - mu) rstd.
+// Round 2 formed them in two second-stage launches between the kernel that produces g and the kernel that consumes it (98 launches per
+// step on the critical path).  Now the PRODUCER finishes them: every workgroup adds its gamma-weighted row-sum totals
+//     acc[slot] += { sum_c gamma_c sum_t g , sum_c gamma_c sum_t g u }                  (fp64 atomics, SEP_STATS_SLOTS slots like the statistics)
+// and arrives at the sample's counter; the LAST of `expected` arrivals turns the slots into the two means and stores them where the
+// consumer's prologue reads two floats (as it always did).  ONE thread per workgroup calls this, behind a barrier that follows the
+// workgroup's atomics.  Both sums are linear in the row sums, so they need neither mu nor rstd while they are accumulated.
+// First form of this round: the CONSUMERS summed the slots -- 64 fp64 loads and an fp64 divide / sqrt in every workgroup of the
+// depthwise backward (+8 us per launch) and spilled registers in the GEMM kernels.
+__device__ __forceinline__ void gln_bwd_publish(const double* acc, const double* st, int* counter, float* means, int expected, double count, float eps) {
+    __threadfence();                                   // this workgroup's atomics are performed before its arrival is
+    if (atomicAdd(counter, 1) != expected - 1) return;
+    __threadfence();
     double s1 = 0.0, s2 = 0.0, m, r;
 #pragma unroll
-    for (int k = 0; k < SEP_STATS_SLOTS; ++k) { s1 += acc[2 * k]; s2 += acc[2 * k + 1]; }
+    for (int k = 0; k < SEP_STATS_SLOTS; ++k) {        // coherent loads: the slots were written by atomics of other compute units
+        s1 += __hip_atomic_load(acc + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s2 += __hip_atomic_load(acc + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     gln_mu_rstd_d(st, count, eps, m, r);
-    mg = (float)(s1 / count);
-    mgx = (float)(r * (s2 - m * s1) / count);
+    means[0] = (float)(s1 / count);
+    means[1] = (float)(r * (s2 - m * s1) / count);
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

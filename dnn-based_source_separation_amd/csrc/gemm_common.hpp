@@ -92,11 +92,6 @@ __device__ __forceinline__ void gemm_epilogue(const sep_gemm_desc& d, f32x16 (&a
     const int ef = EF >= 0 ? EF : d.epi_flags;
     const float alpha_e = (ef & (SEP_EPI_STATS_PRELU | SEP_EPI_PRELU_BWD | SEP_EPI_ROWSUMS_PRELU)) ? d.epi_alpha[0] : 0.f;
     float st_s = 0.f, st_ss = 0.f, dalpha_e = 0.f;
-    // ROWSUMS with epi_bacc: the tile's gamma-weighted totals for the consumer's gln_bwd_means (common.hpp).  Kept OUT of the registers of
-    // the pass loop (these kernels sit at their VGPR caps: two accumulators and a gain per pass made five instantiations spill, +4 us per
-    // launch): the row sums also go to the four unused pad columns of the wave's transposed tile, and once per 32-row block 32 lanes
-    // weigh them with the block's gains (one coalesced load issued before the block) and the wave adds two fp64 atomics.
-    const bool do_bacc = (ef & SEP_EPI_ROWSUMS) && d.epi_bacc != nullptr;       // block-uniform
     const int Mfirst = d.m_split ? d.m_split : d.M;
     const int wrow = m0 + wr * (32 * MI);                    // first output row of this wave
     const bool second = d.m_split && wrow >= d.m_split;      // wave-uniform: m_split is a multiple of 128, wrow of 32*MI
@@ -224,7 +219,6 @@ struct GrpOps { float4 ext[GRP], aux[GRP], old[GRP]; float bs[GRP], rs[GRP]; };
                     if (c4 == 0 && ok[j]) {
                         float* rp = d.epi_rowpart + (((size_t)b * d.M + wrow + mi * 32 + (g4 + j) * 4 + rsub) * (d.ldt / 64) + (t0 + wc * 64) / 64) * 2;
                         rp[0] = rs1; rp[1] = rs2;
-                        if (do_bacc) { float* pad = Tw + ((g4 + j) * 4 + rsub) * EPI_LD + 64; pad[0] = rs1; pad[1] = rs2; }
                     }
                 }
             }
@@ -252,12 +246,6 @@ struct GrpOps { float4 ext[GRP], aux[GRP], old[GRP]; float bs[GRP], rs[GRP]; };
         if (PIPE) issue_loads(0, 0, ops[0]);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-        float gm_blk = 0.f;
-        if (do_bacc && lane < 32) {
-            const int row = wrow + mi * 32 + lane;
-            gm_blk = (FULL || row < d.M) ? d.epi_gamma[row] : 0.f;
-            Tw[lane * EPI_LD + 64] = 0.f; Tw[lane * EPI_LD + 65] = 0.f;      // rows past M never write theirs
-        }
         // ---- transpose: registers -> LDS (C layout) --------------------------------------------
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -287,17 +275,6 @@ struct GrpOps { float4 ext[GRP], aux[GRP], old[GRP]; float bs[GRP], rs[GRP]; };
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (do_bacc) {
-            float a = 0.f, c = 0.f;
-            if (lane < 32) { a = gm_blk * Tw[lane * EPI_LD + 64]; c = gm_blk * Tw[lane * EPI_LD + 65]; }
-            a = row16_sum(a); c = row16_sum(c);                                  // lanes 0 and 16 hold the two halves
-            const float ta = __shfl(a, 0, 64) + __shfl(a, 16, 64), tc = __shfl(c, 0, 64) + __shfl(c, 16, 64);
-            if (lane == 0) {
-                double* ba = d.epi_bacc + ((size_t)b * SEP_STATS_SLOTS + ((blockIdx.x + wid) & (SEP_STATS_SLOTS - 1))) * 2;
-                atomicAdd(ba, (double)ta); atomicAdd(ba + 1, (double)tc);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
 #ifdef SEP_PROF
         PROF_STAMP(10 + 4 * mi);
 #endif

@@ -151,7 +151,7 @@ void pw_gemm_coop_kernel(const sep_gemm_desc d) {
             }
         }
     }
-    if (P_BWD) gln_bwd_means(d.pro_bacc + (size_t)b * SEP_STATS_SLOTS * 2, d.pro_stats + (size_t)b * SEP_STATS_SLOTS * 2, d.count, d.eps, mg, mgx);
+    if (P_BWD) { mg = d.pro_bsum[2 * b]; mgx = d.pro_bsum[2 * b + 1]; }
     float dalpha_pro = 0.f;
     // consume the loads NOW: the compiler does not count the asm LDS-DMAs below, so a wait it placed at a first use inside
     // the loop would be vmcnt(0) and drain the ring

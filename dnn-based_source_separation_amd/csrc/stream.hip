@@ -295,8 +295,9 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(
     const float* __restrict__ dv2, const float* __restrict__ z, const float* __restrict__ a,
     const double* __restrict__ stats1, const float* __restrict__ gamma1, const float* __restrict__ beta1,
     const float* __restrict__ alpha1, const double* __restrict__ stats2, const float* __restrict__ gamma2,
-    const float* __restrict__ alpha2, const double* __restrict__ bacc2, const float* __restrict__ wd,
-    float* __restrict__ dv1, float* __restrict__ rowpart, double* __restrict__ bacc1, int B, int C, int T, int ldt, int d, int dpad, float eps) {
+    const float* __restrict__ alpha2, const float* __restrict__ bsum2, const float* __restrict__ wd,
+    float* __restrict__ dv1, float* __restrict__ rowpart, double* __restrict__ bacc1, int* __restrict__ arrive1, float* __restrict__ bsum1,
+    int B, int C, int T, int ldt, int d, int dpad, float eps) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ntile = (ldt + DW_TT - 1) / DW_TT;
@@ -321,8 +322,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(
         const float a1 = alpha1[0], a2 = alpha2[0];
         sc1 = gamma1[c] * r1; sh1 = beta1[c] - mu1 * sc1;
         const float g2 = gamma2[c];
-        float mg, mgx;
-        gln_bwd_means(bacc2 + (size_t)b * SEP_STATS_SLOTS * 2, stats2 + (size_t)b * SEP_STATS_SLOTS * 2, (double)C * T, eps, mg, mgx);
+        const float mg = bsum2[2 * b], mgx = bsum2[2 * b + 1];
         const size_t rowoff = ((size_t)b * C + c) * ldt;
         for (int q = lane; q < wlen / 4; q += 64) {
             const int tp = t0 - dpad + 4 * q;
@@ -382,10 +382,12 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(
     if (active && lane == 0) {
         float* rp = rowpart + (((size_t)b * C + c) * ntile + tile) * 8;
         rp[0] = q0; rp[1] = q1; rp[2] = q2; rp[3] = q3; rp[4] = q4; rp[5] = q5; rp[6] = q_dal; rp[7] = 0.f;
-        if (bacc1) {        // gLN1's gamma-weighted totals for the consumer of dv1 (gln_bwd_means)
+        if (bacc1) {        // gLN1's gamma-weighted totals; the sample's last (channel, tile) publishes the two means (gln_bwd_publish)
             double* ba = bacc1 + ((size_t)b * SEP_STATS_SLOTS + (g & (SEP_STATS_SLOTS - 1))) * 2;
             const float g1 = gamma1[c];
             atomicAdd(ba, (double)(g1 * q0)); atomicAdd(ba + 1, (double)(g1 * q1));
+            gln_bwd_publish(bacc1 + (size_t)b * SEP_STATS_SLOTS * 2, stats1 + (size_t)b * SEP_STATS_SLOTS * 2, arrive1 + b, bsum1 + 2 * b, C * ntile,
+                            (double)C * T, eps);
         }
     }
 }
@@ -405,8 +407,9 @@ __global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
     const float* __restrict__ dv2, const float* __restrict__ z, const float* __restrict__ a,
     const double* __restrict__ stats1, const float* __restrict__ gamma1, const float* __restrict__ beta1,
     const float* __restrict__ alpha1, const double* __restrict__ stats2, const float* __restrict__ gamma2,
-    const float* __restrict__ alpha2, const double* __restrict__ bacc2, const float* __restrict__ wd,
-    float* __restrict__ dv1, float* __restrict__ rowpart, double* __restrict__ bacc1, int C, int T, int ldt, int d, float eps) {
+    const float* __restrict__ alpha2, const float* __restrict__ bsum2, const float* __restrict__ wd,
+    float* __restrict__ dv1, float* __restrict__ rowpart, double* __restrict__ bacc1, int* __restrict__ arrive1, float* __restrict__ bsum1,
+    int C, int T, int ldt, int d, float eps) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float part[4][8];
     float* dzs = lds;
@@ -419,11 +422,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
     const float a1 = alpha1[0], a2 = alpha2[0];
     const float sc1 = gamma1[c] * r1, sh1 = beta1[c] - mu1 * sc1;
     const float g2 = gamma2[c];
-    if (threadIdx.x == 0) {          // one thread forms the sample's two means (64 fp64 loads, fp64 divide / sqrt) while the others fetch the row
-        float a_, c_;
-        gln_bwd_means(bacc2 + (size_t)b * SEP_STATS_SLOTS * 2, stats2 + (size_t)b * SEP_STATS_SLOTS * 2, (double)C * T, eps, a_, c_);
-        part[3][0] = a_; part[3][1] = c_;
-    }
+    const float mg = bsum2[2 * b], mgx = bsum2[2 * b + 1];
     const size_t rowoff = (size_t)row * ldt;
     const int nq4 = ldt / 4;
     float q_dal = 0.f;
@@ -439,8 +438,6 @@ __global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
             av[k] = ld4(a + rowoff + 4 * q);
         }
     }
-    __syncthreads();
-    const float mg = part[3][0], mgx = part[3][1];      // (part[] is written again only behind the next barrier)
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
         const int q = threadIdx.x + 256 * k;
@@ -519,10 +516,12 @@ __global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
     float* rp = rowpart + (size_t)row * ntile * 8;
     for (int i = threadIdx.x; i < ntile * 8; i += 256)
         rp[i] = i < 8 ? (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]) : 0.f;
-    if (bacc1 && threadIdx.x < 2) {      // gLN1's gamma-weighted totals for the consumer of dv1 (gln_bwd_means)
-        const int i = threadIdx.x;
-        const float tot = (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]);
-        atomicAdd(bacc1 + ((size_t)b * SEP_STATS_SLOTS + (row & (SEP_STATS_SLOTS - 1))) * 2 + i, (double)(gamma1[c] * tot));
+    if (bacc1 && threadIdx.x == 0) {     // gLN1's gamma-weighted totals; the sample's last row publishes the two means (gln_bwd_publish)
+        const float g1c = gamma1[c];
+        double* ba = bacc1 + ((size_t)b * SEP_STATS_SLOTS + (row & (SEP_STATS_SLOTS - 1))) * 2;
+        atomicAdd(ba, (double)(g1c * ((part[0][0] + part[1][0]) + (part[2][0] + part[3][0]))));
+        atomicAdd(ba + 1, (double)(g1c * ((part[0][1] + part[1][1]) + (part[2][1] + part[3][1]))));
+        gln_bwd_publish(bacc1 + (size_t)b * SEP_STATS_SLOTS * 2, stats1 + (size_t)b * SEP_STATS_SLOTS * 2, arrive1 + b, bsum1 + 2 * b, C, (double)C * T, eps);
     }
 }
 
@@ -599,22 +598,26 @@ __global__ __launch_bounds__(256) void gln_bwd_finalize_sample_kernel(const floa
 // SAMPLE (sample-aligned slabs).  So the input-gradient product dv = W^T g needs no row-sum epilogue and does not read z at all (one
 // H-tensor less per layer and step), and no second-stage kernel runs for this gLN.  The gain / shift of the normalisation, which
 // the raw gradient skipped, is applied here on the small matrices:  dW_b[m][n] = sc_bn raw_b[m][n] + sh_bn gs_b[m].
-// grid (ceil(N / 64), B), 256 threads: lane = column n, wave w = rows w, w + 4, ...
+// grid (ceil(N / 32), B), 1024 threads: lane & 31 = column n, (wave, lane >> 5) = 32 row classes -- a thread's rows are m = cls + 32 i, all of
+// whose loads are in flight together (the first version walked 64 rows one by one in a 256-thread workgroup: 87 us per launch for 42 MB,
+// profiles/r03c_kernel_stats.md).  The sample's last workgroup publishes the two means the consumer of dv reads (gln_bwd_publish).
 // =====================================================================================
-__global__ __launch_bounds__(256) void gln_bwd_from_wgrad_kernel(const float* __restrict__ part, const float* __restrict__ part_bias,
-                                                                 const float* __restrict__ W, const double* __restrict__ stats,
-                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                 double count, float eps, float* __restrict__ dW_b,
-                                                                 float* __restrict__ pbeta, float* __restrict__ pgamma,
-                                                                 double* __restrict__ bacc, int M, int N, int sps, int accumulate) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];      // gs[M] | red[4][64][2]
+constexpr int GW_ROWS = 8;        // rows per thread and pass
+__global__ __launch_bounds__(1024) void gln_bwd_from_wgrad_kernel(const float* __restrict__ part, const float* __restrict__ part_bias,
+                                                                  const float* __restrict__ W, const double* __restrict__ stats,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  double count, float eps, float* __restrict__ dW_b,
+                                                                  float* __restrict__ pbeta, float* __restrict__ pgamma,
+                                                                  double* __restrict__ bacc, int* __restrict__ arrive, float* __restrict__ bsum,
+                                                                  int M, int N, int sps, int accumulate, int products) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // gs[M] | red[32 classes][32 columns][2]
     float* gs = lds;
     float* red = lds + M;
     const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int n = blockIdx.x * 64 + lane;
+    const int col = threadIdx.x & 31, cls = threadIdx.x >> 5;        // 32 row classes
+    const int n = blockIdx.x * 32 + col;
     const bool live = n < N;
-    for (int m = threadIdx.x; m < M; m += 256) {
+    for (int m = threadIdx.x; m < M; m += 1024) {
         float t = 0.f;
         for (int k = 0; k < sps; ++k) t += part_bias[(size_t)(b * sps + k) * M + m];
         gs[m] = t;
@@ -625,57 +628,67 @@ __global__ __launch_bounds__(256) void gln_bwd_from_wgrad_kernel(const float* __
     const float sc = gm * rstd, sh = live ? beta[n] - mu * sc : 0.f;
     __syncthreads();
     float r1 = 0.f, r2 = 0.f;
-    if (live) {
-        // rows m = 4 j + wv of this wave, eight at a time with all their loads (8 x (sps + 1)) in flight: the first version walked the rows
-        // one by one -- 64 dependent round trips per wave, 87 us per launch for 42 MB (profiles/r03c_kernel_stats.md)
-        const size_t slab = (size_t)M * N;
-        const float* p0 = part + (size_t)b * sps * slab + n;
-        for (int m0 = wv; m0 < M; m0 += 32) {
-            float raw[8], w[8];
+    const size_t slab = (size_t)M * N;
+    const int nc = live ? n : 0;
+    const float* p0 = part + (size_t)b * sps * slab + nc;
+    for (int m0 = cls; m0 < M; m0 += 32 * GW_ROWS) {
+        float raw[GW_ROWS], w[GW_ROWS];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int m = m0 + 4 * i;
-                raw[i] = 0.f; w[i] = 0.f;
-                if (m < M) {
-                    w[i] = W[(size_t)m * N + n];
-                    for (int k = 0; k < sps; ++k) raw[i] += p0[k * slab + (size_t)m * N];
-                }
+        for (int i = 0; i < GW_ROWS; ++i) {
+            const int m = m0 + 32 * i;
+            const int mc = m < M ? m : 0;                      // rows past M: a harmless in-bounds load, zero weight
+            w[i] = (m < M && live) ? W[(size_t)mc * N + nc] : 0.f;
+            raw[i] = p0[(size_t)mc * N];
+        }
+        for (int k = 1; k < sps; ++k)
+#pragma unroll
+            for (int i = 0; i < GW_ROWS; ++i) {
+                const int m = m0 + 32 * i;
+                raw[i] += p0[k * slab + (size_t)(m < M ? m : 0) * N];
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int m = m0 + 4 * i;
-                if (m < M) {
-                    const float g = gs[m];
-                    r1 = fmaf(w[i], g, r1);
-                    r2 = fmaf(w[i], raw[i], r2);
-                    dW_b[((size_t)b * M + m) * N + n] = fmaf(sc, raw[i], sh * g);
-                }
+        for (int i = 0; i < GW_ROWS; ++i) {
+            const int m = m0 + 32 * i;
+            if (m < M && live) {
+                const float g = gs[m];
+                r1 = fmaf(w[i], g, r1);
+                r2 = fmaf(w[i], raw[i], r2);
+                dW_b[((size_t)b * M + m) * N + n] = fmaf(sc, raw[i], sh * g);
             }
         }
     }
-    red[(wv * 64 + lane) * 2] = r1;
-    red[(wv * 64 + lane) * 2 + 1] = r2;
+    red[(cls * 32 + col) * 2] = r1;
+    red[(cls * 32 + col) * 2 + 1] = r2;
     __syncthreads();
-    if (wv == 0) {
-        const float R1 = (red[lane * 2] + red[(64 + lane) * 2]) + (red[(128 + lane) * 2] + red[(192 + lane) * 2]);
-        const float R2 = (red[lane * 2 + 1] + red[(64 + lane) * 2 + 1]) + (red[(128 + lane) * 2 + 1] + red[(192 + lane) * 2 + 1]);
-        if (live) {
+    if (threadIdx.x < 64) {                                // lanes 0-31: R1 of the block's columns, lanes 32-63: R2
+        const int q = threadIdx.x >> 5;
+        float R = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) R += red[(k * 32 + col) * 2 + q];
+        const float R1 = __shfl(R, col, 64), R2 = __shfl(R, 32 + col, 64);
+        if (live && q == 0) {
             const float pg = rstd * (R2 - mu * R1);
             if (accumulate) { pbeta[(size_t)b * N + n] += R1; pgamma[(size_t)b * N + n] += pg; }
             else { pbeta[(size_t)b * N + n] = R1; pgamma[(size_t)b * N + n] = pg; }
         }
-        const float a = wave_sum(gm * R1), c = wave_sum(gm * R2);
-        if (lane == 0) {
+        float a = gm * R;                                  // lanes 0-31: gamma R1 ; lanes 32-63: gamma R2
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);      // sums inside each 32-lane half
+        if (col == 0) {
             double* ba = bacc + ((size_t)b * SEP_STATS_SLOTS + (blockIdx.x & (SEP_STATS_SLOTS - 1))) * 2;
-            atomicAdd(ba, (double)a); atomicAdd(ba + 1, (double)c);
+            atomicAdd(ba + q, (double)a);
+            __threadfence();                               // performed before the barrier the publishing thread waits at
         }
     }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        gln_bwd_publish(bacc + (size_t)b * SEP_STATS_SLOTS * 2, stats + (size_t)b * SEP_STATS_SLOTS * 2, arrive + b, bsum + 2 * b, (int)gridDim.x * products, count, eps);
 }
 
 // dw = r0*(gamma*dvw - mg - xhat*mgx) + dwm  [* (w>0)]   in place on dvw
 __global__ __launch_bounds__(256) void head_bwd_kernel(float* __restrict__ dvw, const float* __restrict__ w,
                                                        const float* __restrict__ dwm, const double* __restrict__ stats0,
-                                                       const float* __restrict__ gamma0, const double* __restrict__ bacc0,
+                                                       const float* __restrict__ gamma0, const float* __restrict__ bsum0,
                                                        int C, int T, int ldt, double count, float eps, int relu) {
     const int row = blockIdx.y;            // b*C + c
     const int b = row / C, c = row % C;
@@ -683,9 +696,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(float* __restrict__ dvw, 
     if (t4 >= ldt) return;
     float mu, rstd;
     gln_mu_rstd(stats0 + (size_t)b * SEP_STATS_SLOTS * 2, count, eps, mu, rstd);
-    const float gc = gamma0[c];
-    float mg, mgx;
-    gln_bwd_means(bacc0 + (size_t)b * SEP_STATS_SLOTS * 2, stats0 + (size_t)b * SEP_STATS_SLOTS * 2, count, eps, mg, mgx);
+    const float gc = gamma0[c], mg = bsum0[2 * b], mgx = bsum0[2 * b + 1];
     const size_t off = (size_t)row * ldt + t4;
     const float4 g = ld4(dvw + off), ww = ld4(w + off), dm = ld4(dwm + off);
     const float g4[4] = {g.x, g.y, g.z, g.w}, w4[4] = {ww.x, ww.y, ww.z, ww.w}, m4[4] = {dm.x, dm.y, dm.z, dm.w};
@@ -1152,16 +1163,17 @@ extern "C" int sep_dwconv_fwd(const float* a, const double* stats1, const float*
 
 extern "C" int sep_dwconv_bwd(const float* dv2, const float* z, const float* a, const double* stats1, const float* gamma1,
                               const float* beta1, const float* alpha1, const double* stats2, const float* gamma2,
-                              const float* alpha2, const double* bacc2, const float* wd, float* dv1, float* rowpart,
-                              double* bacc1, int B, int C, int T, int ldt, int dilation, float eps, sep_stream_t stream) {
-    SEP_REQUIRE(dv2 && z && a && stats1 && gamma1 && beta1 && alpha1 && stats2 && gamma2 && alpha2 && bacc2 && wd && dv1 && rowpart, "sep_dwconv_bwd: null pointer");
+                              const float* alpha2, const float* bsum2, const float* wd, float* dv1, float* rowpart,
+                              double* bacc1, int* arrive1, float* bsum1, int B, int C, int T, int ldt, int dilation, float eps, sep_stream_t stream) {
+    SEP_REQUIRE(dv2 && z && a && stats1 && gamma1 && beta1 && alpha1 && stats2 && gamma2 && alpha2 && bsum2 && wd && dv1 && rowpart, "sep_dwconv_bwd: null pointer");
+    SEP_REQUIRE((bacc1 == nullptr) == (arrive1 == nullptr) && (bacc1 == nullptr) == (bsum1 == nullptr), "sep_dwconv_bwd: bacc1 / arrive1 / bsum1 come together");
     SEP_REQUIRE(B > 0 && C > 0 && T > 0 && ldt % 128 == 0 && ldt >= T, "sep_dwconv_bwd: bad sizes");
     SEP_REQUIRE(dilation >= 1 && dilation <= 2048, "sep_dwconv_bwd: dilation %d out of range [1, 2048]", dilation);
     static const bool force_tiles = getenv("SEPK_DWCONV_LDS") != nullptr;
     if (!force_tiles && ldt <= 8192 && (long)B * C <= 0x7fffffffL) {        // the row (ldt floats of LDS, ldt / 1024 float4 triples in registers)
         const size_t rsmem = (size_t)ldt * sizeof(float);
         const dim3 grid((unsigned)((long)B * C));
-#define SEP_DWB(AL, NIT) hipLaunchKernelGGL((dwconv_bwd_row_kernel<AL, NIT>), grid, dim3(256), rsmem, (hipStream_t)stream, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bacc2, wd, dv1, rowpart, bacc1, C, T, ldt, dilation, eps)
+#define SEP_DWB(AL, NIT) hipLaunchKernelGGL((dwconv_bwd_row_kernel<AL, NIT>), grid, dim3(256), rsmem, (hipStream_t)stream, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bsum2, wd, dv1, rowpart, bacc1, arrive1, bsum1, C, T, ldt, dilation, eps)
         if (dilation % 4 == 0) { if (ldt <= 4096) SEP_DWB(true, 4); else SEP_DWB(true, 8); }
         else { if (ldt <= 4096) SEP_DWB(false, 4); else SEP_DWB(false, 8); }
 #undef SEP_DWB
@@ -1171,7 +1183,7 @@ extern "C" int sep_dwconv_bwd(const float* dv2, const float* z, const float* a, 
     const int dpad = (dilation + 3) & ~3;
     const size_t smem = 4 * 2 * (size_t)(DW_TT + 2 * dpad) * sizeof(float);
     const long total = (long)B * C * ceil_div(ldt, DW_TT);
-    hipLaunchKernelGGL(dwconv_bwd_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), smem, (hipStream_t)stream, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bacc2, wd, dv1, rowpart, bacc1, B, C, T, ldt, dilation, dpad, eps);
+    hipLaunchKernelGGL(dwconv_bwd_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), smem, (hipStream_t)stream, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bsum2, wd, dv1, rowpart, bacc1, arrive1, bsum1, B, C, T, ldt, dilation, dpad, eps);
     SEP_CHECK_LAUNCH("sep_dwconv_bwd");
     return 0;
 }
@@ -1195,23 +1207,24 @@ extern "C" int sep_gln_bwd_finalize(const float* rowpart, int ntile, int nq, con
 
 extern "C" int sep_gln_bwd_from_wgrad(const float* part, const float* part_bias, const float* W, const double* stats, const float* gamma,
                                       const float* beta, double count, float eps, float* dW_b, float* pbeta, float* pgamma, double* bacc,
-                                      int B, int M, int N, int slabs_per_sample, int accumulate, sep_stream_t stream) {
-    SEP_REQUIRE(part && part_bias && W && stats && gamma && beta && dW_b && pbeta && pgamma && bacc, "sep_gln_bwd_from_wgrad: null pointer");
-    SEP_REQUIRE(B > 0 && B <= 65535 && M > 0 && M <= 8192 && N > 0 && slabs_per_sample > 0, "sep_gln_bwd_from_wgrad: bad sizes");
-    const size_t smem = ((size_t)M + 4 * 64 * 2) * sizeof(float);
-    hipLaunchKernelGGL(gln_bwd_from_wgrad_kernel, dim3(ceil_div(N, 64), B), dim3(256), smem, (hipStream_t)stream, part, part_bias, W, stats, gamma,
-                       beta, count, eps, dW_b, pbeta, pgamma, bacc, M, N, slabs_per_sample, accumulate);
+                                      int* arrive, float* bsum, int B, int M, int N, int slabs_per_sample, int accumulate, int products,
+                                      sep_stream_t stream) {
+    SEP_REQUIRE(part && part_bias && W && stats && gamma && beta && dW_b && pbeta && pgamma && bacc && arrive && bsum, "sep_gln_bwd_from_wgrad: null pointer");
+    SEP_REQUIRE(B > 0 && B <= 65535 && M > 0 && M <= 8192 && N > 0 && slabs_per_sample > 0 && products >= 1, "sep_gln_bwd_from_wgrad: bad sizes");
+    const size_t smem = ((size_t)M + 32 * 32 * 2) * sizeof(float);
+    hipLaunchKernelGGL(gln_bwd_from_wgrad_kernel, dim3(ceil_div(N, 32), B), dim3(1024), smem, (hipStream_t)stream, part, part_bias, W, stats, gamma,
+                       beta, count, eps, dW_b, pbeta, pgamma, bacc, arrive, bsum, M, N, slabs_per_sample, accumulate, products);
     SEP_CHECK_LAUNCH("sep_gln_bwd_from_wgrad");
     return 0;
 }
 
 extern "C" int sep_head_bwd(float* dvw, const float* w, const float* dwm, const double* stats0, const float* gamma0,
-                            const double* bacc0, int B, int C, int T, int ldt, double count, float eps, int relu,
+                            const float* bsum0, int B, int C, int T, int ldt, double count, float eps, int relu,
                             sep_stream_t stream) {
-    SEP_REQUIRE(dvw && w && dwm && stats0 && gamma0 && bacc0 && ldt % 4 == 0, "sep_head_bwd: bad arguments");
+    SEP_REQUIRE(dvw && w && dwm && stats0 && gamma0 && bsum0 && ldt % 4 == 0, "sep_head_bwd: bad arguments");
     SEP_REQUIRE((long)B * C <= 65535, "sep_head_bwd: B*C too large for grid.y");
     dim3 grid(ceil_div(ldt, 1024), B * C);
-    hipLaunchKernelGGL(head_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dvw, w, dwm, stats0, gamma0, bacc0, C, T, ldt, count, eps, relu);
+    hipLaunchKernelGGL(head_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dvw, w, dwm, stats0, gamma0, bsum0, C, T, ldt, count, eps, relu);
     SEP_CHECK_LAUNCH("sep_head_bwd");
     return 0;
 }

@@ -359,30 +359,37 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc_kernel(const sep_wgrad_des
             }
         }
     }
-    // ---- the consumers' tiles leave for the slab (C layout: a lane holds one column of 16 rows per accumulator)
+    // ---- the consumers' tiles leave for the slab.  The C layout gives a lane one column of 16 rows per accumulator, i.e. 4-byte stores
+    // (128 per lane and tile: store-issue bound, like the first GEMM epilogue).  Each wave transposes 32 rows at a time through a private
+    // piece of the (now idle) staging memory and stores float4: 256 contiguous bytes per 16 lanes, 4 rows per instruction.
+    __syncthreads();                                    // every wave is out of the rings: the staging area becomes the transpose buffer
     if (!producer) {
         int etid = tid, es = s, em0 = m0, en0 = n0;
         asm volatile("" : "+v"(etid), "+s"(es), "+s"(em0), "+s"(en0));
         const int ewid = __builtin_amdgcn_readfirstlane(etid >> 6);
-        const int ewr = ewid / WC, ewc = ewid % WC, elk = (etid >> 5) & 1, el31 = etid & 31;
-        auto put_tile = [&](auto atomic_c) {                // a plain store into slab s
-            constexpr bool AT = decltype(atomic_c)::value;
-            float* out = d.partial + (AT ? 0 : (size_t)es * d.M * d.N);
+        const int ewr = ewid / WC, ewc = ewid % WC, elk = (etid >> 5) & 1, el31 = etid & 31, elane = etid & 63;
+        static_assert(sizeof(Smem) >= 4 * EPI_WAVE_FLOATS * sizeof(float), "transpose buffer");
+        float* Tw = reinterpret_cast<float*>(&sm) + ewid * EPI_WAVE_FLOATS;
+        const int rsub = elane >> 4, c4 = elane & 15;
+        float* out = d.partial + (size_t)es * d.M * d.N + (size_t)(em0 + ewr * 64) * d.N + en0 + ewc * 128 + 4 * c4;
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = em0 + ewr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * elk;
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = (r & 3) + 8 * (r >> 2) + 4 * elk;
+                    Tw[rl * EPI_LD + el31] = acc[h][mi][0][r];
+                    Tw[rl * EPI_LD + 32 + el31] = acc[h][mi][1][r];
+                }
+                __builtin_amdgcn_wave_barrier();       // LDS is in-order per wave; this only pins the compiler's order
 #pragma unroll
-                        for (int n = 0; n < 2; ++n) {
-                            const int col = en0 + ewc * 128 + h * 64 + n * 32 + el31;
-                            wg_put<AT>(out + (size_t)row * d.N + col, nk > 0 ? acc[h][mi][n][r] : 0.f);
-                        }
-                    }
-        };
-        put_tile(std::false_type{});
+                for (int p8 = 0; p8 < 8; ++p8) {
+                    const int row = 4 * p8 + rsub;
+                    st4(out + (size_t)(mi * 32 + row) * d.N + h * 64, ld4(Tw + row * EPI_LD + 4 * c4));
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
     }
 }
 

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("SEPKERNELS_LIB", os.path.normpath(os.path.join(_HERE,
 # ---- constants mirrored from include/sepkernels.h -------------------------------------------------
 PRO_NONE, PRO_PRELU, PRO_GLN, PRO_GLN_PRELU, PRO_GLN_BWD = 0, 1, 2, 3, 4
 EPI_STATS_PRELU, EPI_RESIDUAL, EPI_SIGMOID, EPI_PRELU_BWD, EPI_ROWSUMS, EPI_ROWSUMS_PRELU = 1, 2, 4, 8, 16, 32
-ABI_VERSION = 13
+ABI_VERSION = 14
 STATS_SLOTS = 16   # SEP_STATS_SLOTS: gLN statistics are double[B][STATS_SLOTS][2]
 ARITH_F32, ARITH_BF16X6, ARITH_F16X3 = 0, 1, 2     # SEP_ARITH_*: how sep_pw_gemm forms its fp32 products (include/sepkernels.h)
 _ARITH_NAMES = {"f32": ARITH_F32, "bf16x6": ARITH_BF16X6, "f16x3": ARITH_F16X3}
@@ -70,8 +70,8 @@ class GemmDesc(ctypes.Structure):
     _fields_ = [(n, _i32) for n in ("B", "M", "K", "T", "ldt", "trans_a", "k_split", "m_split", "pro_mode", "epi_flags",
                                     "accumulate", "arith")] + [("eps", ctypes.c_float), ("count", ctypes.c_double)] + \
                [(n, _vp) for n in ("A", "A2", "X", "X2", "Y", "Y2", "bias", "pro_alpha", "pro_stats", "pro_gamma", "pro_beta",
-                                   "pro_aux", "pro_bacc", "pro_store", "pro_dalpha", "epi_alpha", "epi_stats", "epi_res",
-                                   "epi_aux", "epi_dalpha", "epi_rowpart", "epi_gamma", "epi_bacc", "a_amax", "A_pk", "a_rscale")]
+                                   "pro_aux", "pro_bsum", "pro_store", "pro_dalpha", "epi_alpha", "epi_stats", "epi_res",
+                                   "epi_aux", "epi_dalpha", "epi_rowpart", "a_amax", "A_pk", "a_rscale")]
 
 
 class WgradDesc(ctypes.Structure):
@@ -112,9 +112,9 @@ SIGNATURES = {
     "sep_encoder_fwd": [_vp, _vp, _vp, _vp] + [_I] * 10 + [_vp],
     "sep_unfold": [_vp, _vp] + [_I] * 8 + [_vp],
     "sep_dwconv_fwd": [_vp] * 10 + [_I] * 5 + [_F, _vp],
-    "sep_dwconv_bwd": [_vp] * 15 + [_I] * 5 + [_F, _vp],
+    "sep_dwconv_bwd": [_vp] * 17 + [_I] * 5 + [_F, _vp],
     "sep_gln_bwd_finalize": [_vp, _I, _I, _vp, _vp, _D, _F, _vp, _vp, _vp, _vp, _I, _I, _vp],
-    "sep_gln_bwd_from_wgrad": [_vp] * 6 + [_D, _F] + [_vp] * 4 + [_I] * 5 + [_vp],
+    "sep_gln_bwd_from_wgrad": [_vp] * 6 + [_D, _F] + [_vp] * 6 + [_I] * 6 + [_vp],
     "sep_head_bwd": [_vp] * 6 + [_I] * 4 + [_D, _F, _I, _vp],
     "sep_decoder_fwd": [_vp] * 5 + [_I] * 10 + [_vp],
     "sep_decoder_bwd": [_vp] * 6 + [_I] * 11 + [_vp],
@@ -206,9 +206,9 @@ class HipBackend:
 
     def pw_gemm(self, *, B, M, K, T, ldt, A, X, Y, trans_a=0, A2=None, X2=None, k_split=0, Y2=None, m_split=0,
                 pro_mode=PRO_NONE, epi_flags=0, accumulate=0, eps=1e-12, count=0.0, bias=None, pro_alpha=None,
-                pro_stats=None, pro_gamma=None, pro_beta=None, pro_aux=None, pro_bacc=None, pro_store=None,
+                pro_stats=None, pro_gamma=None, pro_beta=None, pro_aux=None, pro_bsum=None, pro_store=None,
                 pro_dalpha=None, epi_alpha=None, epi_stats=None, epi_res=None, epi_aux=None, epi_dalpha=None,
-                epi_rowpart=None, epi_gamma=None, epi_bacc=None, arith=None, a_amax=None, A_pk=None):
+                epi_rowpart=None, arith=None, a_amax=None, A_pk=None):
         arith = gemm_arith() if arith is None else arith
         if A_pk is not None and (A_pk.M != M or A_pk.K != K):
             raise SepKernelsError("packed weights are {}x{}, the product needs {}x{}".format(A_pk.M, A_pk.K, M, K))
@@ -222,9 +222,9 @@ class HipBackend:
                      A=_ptr(A, _f32), A2=_ptr(A2, _f32), X=_ptr(X, _f32), X2=_ptr(X2, _f32), Y=_ptr(Y, _f32), Y2=_ptr(Y2, _f32),
                      bias=_ptr(bias, _f32), pro_alpha=_ptr(pro_alpha, _f32), pro_stats=_ptr(pro_stats, _f64),
                      pro_gamma=_ptr(pro_gamma, _f32), pro_beta=_ptr(pro_beta, _f32), pro_aux=_ptr(pro_aux, _f32),
-                     pro_bacc=_ptr(pro_bacc, _f64), pro_store=_ptr(pro_store, _f32), pro_dalpha=_ptr(pro_dalpha, _f64),
+                     pro_bsum=_ptr(pro_bsum, _f32), pro_store=_ptr(pro_store, _f32), pro_dalpha=_ptr(pro_dalpha, _f64),
                      epi_alpha=_ptr(epi_alpha, _f32), epi_stats=_ptr(epi_stats, _f64), epi_res=_ptr(epi_res, _f32),
-                     epi_aux=_ptr(epi_aux, _f32), epi_dalpha=_ptr(epi_dalpha, _f64), epi_rowpart=_ptr(epi_rowpart, _f32), epi_gamma=_ptr(epi_gamma, _f32), epi_bacc=_ptr(epi_bacc, _f64),
+                     epi_aux=_ptr(epi_aux, _f32), epi_dalpha=_ptr(epi_dalpha, _f64), epi_rowpart=_ptr(epi_rowpart, _f32),
                      a_amax=_ptr(a_amax, _f32), A_pk=_ptr(A_pk.data, _f32) if A_pk is not None else None,
                      a_rscale=_ptr(A_pk.rscale, _f32) if A_pk is not None else None)
         _check(load().sep_pw_gemm(ctypes.byref(d), _stream()), "sep_pw_gemm")
@@ -291,11 +291,12 @@ class HipBackend:
                                      _ptr(wd, _f32), _ptr(bd, _f32), _ptr(alpha2, _f32), _ptr(z, _f32), _ptr(stats2, _f64),
                                      B, C, T, ldt, dilation, eps, _stream()), "sep_dwconv_fwd")
 
-    def dwconv_bwd(self, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bacc2, wd, dv1, rowpart, bacc1, B, C, T,
-                   ldt, dilation, eps):
+    def dwconv_bwd(self, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bsum2, wd, dv1, rowpart, bacc1, arrive1, bsum1,
+                   B, C, T, ldt, dilation, eps):
         _check(load().sep_dwconv_bwd(_ptr(dv2, _f32), _ptr(z, _f32), _ptr(a, _f32), _ptr(stats1, _f64), _ptr(gamma1, _f32),
                                      _ptr(beta1, _f32), _ptr(alpha1, _f32), _ptr(stats2, _f64), _ptr(gamma2, _f32),
-                                     _ptr(alpha2, _f32), _ptr(bacc2, _f64), _ptr(wd, _f32), _ptr(dv1, _f32), _ptr(rowpart, _f32), _ptr(bacc1, _f64),
+                                     _ptr(alpha2, _f32), _ptr(bsum2, _f32), _ptr(wd, _f32), _ptr(dv1, _f32), _ptr(rowpart, _f32), _ptr(bacc1, _f64),
+                                     _ptr(arrive1, torch.int32), _ptr(bsum1, _f32),
                                      B, C, T, ldt, dilation, eps, _stream()), "sep_dwconv_bwd")
 
     def gln_bwd_finalize(self, rowpart, ntile, nq, stats, gamma, count, eps, bsum, pbeta, pgamma, pextra, B, C):
@@ -303,15 +304,16 @@ class HipBackend:
                                            _ptr(bsum, _f32), _ptr(pbeta, _f32), _ptr(pgamma, _f32), _ptr(pextra, _f32), B, C,
                                            _stream()), "sep_gln_bwd_finalize")
 
-    def gln_bwd_from_wgrad(self, part, part_bias, W, stats, gamma, beta, count, eps, dW_b, pbeta, pgamma, bacc, B, M, N, slabs_per_sample,
-                           accumulate=0):
+    def gln_bwd_from_wgrad(self, part, part_bias, W, stats, gamma, beta, count, eps, dW_b, pbeta, pgamma, bacc, arrive, bsum, B, M, N,
+                           slabs_per_sample, accumulate=0, products=1):
         _check(load().sep_gln_bwd_from_wgrad(_ptr(part, _f32), _ptr(part_bias, _f32), _ptr(W, _f32), _ptr(stats, _f64), _ptr(gamma, _f32),
                                              _ptr(beta, _f32), float(count), eps, _ptr(dW_b, _f32), _ptr(pbeta, _f32), _ptr(pgamma, _f32),
-                                             _ptr(bacc, _f64), B, M, N, slabs_per_sample, int(accumulate), _stream()), "sep_gln_bwd_from_wgrad")
+                                             _ptr(bacc, _f64), _ptr(arrive, torch.int32), _ptr(bsum, _f32), B, M, N, slabs_per_sample, int(accumulate),
+                                             int(products), _stream()), "sep_gln_bwd_from_wgrad")
 
-    def head_bwd(self, dvw, w, dwm, stats0, gamma0, bacc0, B, C, T, ldt, count, eps, relu):
+    def head_bwd(self, dvw, w, dwm, stats0, gamma0, bsum0, B, C, T, ldt, count, eps, relu):
         _check(load().sep_head_bwd(_ptr(dvw, _f32), _ptr(w, _f32), _ptr(dwm, _f32), _ptr(stats0, _f64), _ptr(gamma0, _f32),
-                                   _ptr(bacc0, _f64), B, C, T, ldt, float(count), eps, int(relu), _stream()), "sep_head_bwd")
+                                   _ptr(bsum0, _f32), B, C, T, ldt, float(count), eps, int(relu), _stream()), "sep_head_bwd")
 
     def decoder_fwd(self, w, m, D, est, latent, B, n_src, N, Cout, L, S, F, ldt, Tout, pad_left):
         _check(load().sep_decoder_fwd(_ptr(w, _f32), _ptr(m, _f32), _ptr(D, _f32), _ptr(est, _f32), _ptr(latent, _f32), B, n_src,

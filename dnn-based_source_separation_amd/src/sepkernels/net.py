@@ -258,9 +258,8 @@ def tail_backward(cfg, P, geo, w, core, m, mixture_shape, d_est, G, dalpha_slot,
     return dcore, dwm
 
 
-def head_backward(cfg, P, geo, stats0, w, mixture, dx0, dwm, G, PK=None, bacc0=None):
-    """Backward of head_forward given dx0 = d(bottleneck output) and dwm = d(w) arriving through mask*w.
-    bacc0 (B, SLOTS, 2) fp64 zeros: receives the gamma-weighted row-sum totals of the first gLN's backward (see _backward)."""
+def head_backward(cfg, P, geo, stats0, w, mixture, dx0, dwm, G, PK=None):
+    """Backward of head_forward given dx0 = d(bottleneck output) and dwm = d(w) arriving through mask*w."""
     K = backend()
     B, Cin, T_in = mixture.shape
     N, L, S = cfg["n_basis"], cfg["kernel_size"], cfg["stride"]
@@ -276,14 +275,13 @@ def head_backward(cfg, P, geo, stats0, w, mixture, dx0, dwm, G, PK=None, bacc0=N
     part, pb, ns = _wgrad(K, B, F, ldt, eps, f32, Bn, N, dx0, w, True, x_mode=PRO_GLN, x_stats=stats0, x_gamma=g0, x_beta=b0, count=cnt0)
     dvw = torch.empty(B, N, ldt, **f32)
     rp0 = torch.empty(B, N, nt64, 2, **f32)
-    if bacc0 is None:
-        bacc0 = torch.zeros(B, STATS_SLOTS, 2, device=w.device, dtype=torch.float64)
     K.pw_gemm(B=B, M=N, K=Bn, T=F, ldt=ldt, trans_a=1, A=Wb, A_pk=(PK or {}).get("bottleneck^T"), X=dx0, Y=dvw, epi_flags=EPI_ROWSUMS, epi_aux=w,
-              epi_rowpart=rp0, epi_gamma=g0, epi_bacc=bacc0, eps=eps)
-    K.head_bwd(dvw, w, dwm, stats0, g0, bacc0, B, N, F, ldt, cnt0, eps, relu)
+              epi_rowpart=rp0, eps=eps)
+    bsum0 = torch.empty(B, 2, **f32)
     pbeta0 = torch.empty(B, N, **f32)
     pgamma0 = torch.empty(B, N, **f32)
-    K.gln_bwd_finalize(rp0, nt64, 2, stats0, g0, cnt0, eps, None, pbeta0, pgamma0, None, B, N)      # parameter gradients only
+    K.gln_bwd_finalize(rp0, nt64, 2, stats0, g0, cnt0, eps, bsum0, pbeta0, pgamma0, None, B, N)
+    K.head_bwd(dvw, w, dwm, stats0, g0, bsum0, B, N, F, ldt, cnt0, eps, relu)
     K.reduce_slabs([(part, 0, G["separator.bottleneck_conv1d.weight"], Bn * N, ns, Bn * N, 0, 1.0),
                     (pb, 0, G["separator.bottleneck_conv1d.bias"], Bn, ns, Bn, 0, 1.0),
                     (pbeta0, 0, G["separator.norm1d.norm.bias"], N, B, N, 0, 1.0),
@@ -471,13 +469,14 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
     chunks = B * (ldt // 32)
     nt64, nt1024 = ldt // 64, (ldt + 1023) // 1024
     dalpha = torch.zeros(nl + 1, device=dev, dtype=torch.float64)   # [layer alpha1 ..., mask prelu]
-    # gLN backward needs two per-sample means of the incoming gradient (mean(gamma g), mean(gamma g xhat)) before any element of the
-    # input gradient can be formed.  The kernel that PRODUCES g accumulates the raw gamma-weighted row-sum totals into these slots
-    # (fp64 atomics, laid out like `stats`: [0] first gLN, [1 + 2 li] / [2 + 2 li] gLN1 / gLN2 of layer li) and the kernel that consumes
-    # g forms the means itself (gln_bwd_means, csrc/common.hpp): no second-stage launch between them.  sep_gln_bwd_finalize still turns
-    # the row partials into the parameter gradients, as a leaf on the side stream.
+    # gLN backward needs two per-sample means of the incoming gradient g -- mean(gamma g), mean(gamma g xhat) -- before any element of the
+    # input gradient can be formed.  Inside the TCN layers the kernel that PRODUCES g's sums finishes them: its workgroups add their
+    # gamma-weighted totals to fp64 slots (bacc, laid out like `stats`: [1 + 2 li] / [2 + 2 li] = gLN1 / gLN2 of layer li), count their
+    # arrivals (arrive), and the sample's last one stores the two means (bsum) the consumer's prologue reads -- no second-stage launch in
+    # between (gln_bwd_publish, csrc/common.hpp).  sep_gln_bwd_finalize still turns gLN1's row partials into parameter gradients, as a leaf.
     bacc = torch.zeros(2 * nl + 1, B, STATS_SLOTS, 2, device=dev, dtype=torch.float64)
-
+    arrive = torch.zeros(2 * nl + 1, B, device=dev, dtype=torch.int32)
+    bsum = torch.empty(2 * nl + 1, B, 2, **f32)
     def wgrad(M, Nn, Gt, Xt, dW, dbias=None, Bq=B, weps=None, **kw):
         return _wgrad(K, B, F, ldt, eps, f32, M, Nn, Gt, Xt, dbias is not None, Bq=Bq, weps=weps, **kw)
 
@@ -533,8 +532,8 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
         with side:
             for hi, (Gt, G2t, gsp, rows, Wmat, wnames, bnames) in enumerate(heads):
                 part, pb, ns = wgrad(rows, H, Gt, z, True, True, G2=G2t, g_split=gsp, **xkw)
-                K.gln_bwd_from_wgrad(part, pb, Wmat, st2, g2, b2, cnt, teps, dWbs[hi], pbeta2, pgamma2, bacc[2 + 2 * li], B, rows, H, ns // B,
-                                     accumulate=int(hi > 0))
+                K.gln_bwd_from_wgrad(part, pb, Wmat, st2, g2, b2, cnt, teps, dWbs[hi], pbeta2, pgamma2, bacc[2 + 2 * li], arrive[2 + 2 * li],
+                                     bsum[2 + 2 * li], B, rows, H, ns // B, accumulate=int(hi > 0), products=len(heads))
                 segs += [(dWbs[hi], r0 * H, G[nm], nr * H, B, rows * H, 0, 1.0) for nm, r0, nr in wnames]
                 segs += [(pb, r0, G[nm], nr, ns, rows, 0, 1.0) for nm, r0, nr in bnames]
         pending += segs
@@ -558,8 +557,8 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
         side.wait(ev_sums)
         dv1 = torch.empty(B, H, ldt, **f32)
         rp1 = torch.empty(B, H, nt1024, 8, **f32)
-        K.dwconv_bwd(dv2, z, a, st1, g1, b1, al1, st2, g2, al2, bacc[2 + 2 * li], P[sp + "depthwise_conv1d.weight"], dv1, rp1,
-                     bacc[1 + 2 * li], B, H, F, ldt, dil, teps)
+        K.dwconv_bwd(dv2, z, a, st1, g1, b1, al1, st2, g2, al2, bsum[2 + 2 * li], P[sp + "depthwise_conv1d.weight"], dv1, rp1,
+                     bacc[1 + 2 * li], arrive[1 + 2 * li], bsum[1 + 2 * li], B, H, F, ldt, dil, teps)
         pbeta1 = torch.empty(B, H, **f32)
         pgamma1 = torch.empty(B, H, **f32)
         pextra = torch.empty(B * 4 * H + B + B * H, **f32)
@@ -579,7 +578,7 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
         # with several row tiles the other tiles still need the untouched dv1, so da goes to its own buffer
         da = dv1 if Bn <= 128 else torch.empty_like(dv1)
         K.pw_gemm(B=B, M=Bn, K=H, T=F, ldt=ldt, trans_a=1, A=P[pre + "bottleneck_conv1d.weight"], A_pk=PK.get("conv1.{}^T".format(li)),
-                  X=dv1, Y=dx, pro_mode=PRO_GLN_BWD, pro_stats=st1, pro_gamma=g1, pro_alpha=al1, pro_aux=a, pro_bacc=bacc[1 + 2 * li],
+                  X=dv1, Y=dx, pro_mode=PRO_GLN_BWD, pro_stats=st1, pro_gamma=g1, pro_alpha=al1, pro_aux=a, pro_bsum=bsum[1 + 2 * li],
                   pro_store=da, pro_dalpha=dalpha[li:li + 1], count=cnt, eps=teps,
                   epi_flags=(EPI_RESIDUAL if dout is not None else 0), epi_res=dout)
         # da and dx now exist: the side stream may go on (this layer's dW1, the next layer's head gradients)
@@ -633,4 +632,4 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
     K.reduce_slabs(pending)
 
     # ---- head: bottleneck conv, first gLN, encoder ------------------------------------------------------
-    head_backward(cfg, P, geo, stats[0], w, mixture, dout, dwm, G, PK, bacc[0])
+    head_backward(cfg, P, geo, stats[0], w, mixture, dout, dwm, G, PK)

@@ -33,7 +33,7 @@ extern "C" {
 
 typedef void* sep_stream_t; /* hipStream_t */
 
-#define SEP_ABI_VERSION 13
+#define SEP_ABI_VERSION 14
 #define SEP_STATS_SLOTS 16
 
 int sep_version(void);
@@ -105,9 +105,8 @@ typedef struct sep_gemm_desc {
     const float* pro_gamma;
     const float* pro_beta;
     const float* pro_aux;
-    const double* pro_bacc; /* GLN_BWD: [B][SEP_STATS_SLOTS][2], raw sums {sum_c gamma_c sum_t g, sum_c gamma_c sum_t g*u} of the gLN being
-                               back-propagated, as accumulated by the kernel that produced g (epi_bacc of sep_pw_gemm, bacc1 of
-                               sep_dwconv_bwd); the prologue forms mean(gamma g) and mean(gamma g xhat) from them and pro_stats */
+    const float* pro_bsum; /* GLN_BWD: [B][2] = mean(gamma g), mean(gamma g xhat) of the gLN being back-propagated (bsum1 of sep_dwconv_bwd,
+                              bsum of sep_gln_bwd_from_wgrad / sep_gln_bwd_finalize) */
     float* pro_store;
     double* pro_dalpha;
     const float* epi_alpha;
@@ -116,9 +115,6 @@ typedef struct sep_gemm_desc {
     const float* epi_aux;
     double* epi_dalpha;
     float* epi_rowpart;
-    const float* epi_gamma; /* with epi_bacc: [M], the gain of the gLN whose backward the ROWSUMS feed */
-    double* epi_bacc;       /* ROWSUMS, optional: [B][SEP_STATS_SLOTS][2] zeroed by the caller; every workgroup adds (fp64 atomics, slot =
-                               blockIdx & 15) sum_rows gamma_m * {rowsum1, rowsum2} of its tile */
     const float* a_amax; /* SEP_ARITH_F16X3: device scalar >= max|A| (and |A2|); any upper bound, e.g. over all parameters */
     const void* A_pk;       /* SEP_ARITH_F16X3: A ([M][K], already in the orientation of the product: the transpose and the
                                [A|A2] concatenation of a k_split call are done by the packer) as written by sep_pack_weights,
@@ -210,24 +206,25 @@ int sep_dwconv_fwd(const float* a, const double* stats1, const float* gamma1, co
 
 /* Backward of [gLN2 o PReLU2 o depthwise] given dv2 = d(gLN2 output):
  *   du2 = r2*(gamma2*dv2 - mg2 - xhat2*mgx2) ; dz = du2*PReLU'(z) ; dv1 = depthwise^T(dz)
- * mg2 / mgx2 = mean(gamma2 dv2), mean(gamma2 dv2 xhat2) are formed from bacc2 [B][SEP_STATS_SLOTS][2], the raw sums the producer of dv2
- * accumulated (sep_gemm_desc.epi_bacc), and stats2; bacc1 (same shape, zeroed by the caller, may be NULL) receives the same sums for
- * gLN1: {sum_c gamma1_c sum_t dv1, sum_c gamma1_c sum_t dv1*u1}, fp64 atomics, slot = workgroup & 15 -- so that neither side waits for
- * a second-stage kernel (round 2 had sep_gln_bwd_finalize between them, 98 launches per step on the critical path).
+ * bsum2 [B][2] = {mg2, mgx2} = mean(gamma2 dv2), mean(gamma2 dv2 xhat2), written by the producer of dv2's sums (sep_gln_bwd_from_wgrad).
+ * For gLN1 this kernel is the producer: bacc1 [B][SEP_STATS_SLOTS][2] (fp64, zeroed by the caller) receives its workgroups'
+ * {sum_c gamma1_c sum_t dv1, sum_c gamma1_c sum_t dv1*u1}, arrive1 [B] (int, zeroed) counts them, and the sample's LAST workgroup stores
+ * bsum1 [B][2] = {mean(gamma1 dv1), mean(gamma1 dv1 xhat1)} for the consumer's prologue (sep_gemm_desc.pro_bsum) -- no second-stage launch
+ * between the two (round 2: sep_gln_bwd_finalize, 98 launches per step on the critical path).  All three may be NULL together.
  * Writes dv1 and, per (b, c, 1024-frame tile), 8 partial row sums into rowpart[b][c][ntile][8]:
  *   {sum dv1, sum dv1*u1, sum dz, sum dz*v1[t-d], sum dz*v1[t], sum dz*v1[t+d], sum du2*z*[z<=0], 0}
  * (u1 = PReLU(a), v1 = gLN1(u1) inside [0,T) and 0 outside; ntile = ceil(ldt/1024)). */
 int sep_dwconv_bwd(const float* dv2, const float* z, const float* a, const double* stats1, const float* gamma1,
                    const float* beta1, const float* alpha1, const double* stats2, const float* gamma2,
-                   const float* alpha2, const double* bacc2, const float* wd, float* dv1, float* rowpart, double* bacc1,
-                   int B, int C, int T, int ldt, int dilation, float eps, sep_stream_t stream);
+                   const float* alpha2, const float* bsum2, const float* wd, float* dv1, float* rowpart, double* bacc1,
+                   int* arrive1, float* bsum1, int B, int C, int T, int ldt, int dilation, float eps, sep_stream_t stream);
 
 /* Second stage of every gLN backward (Appendix A of SURVEY.md).  rowpart is [B][C][ntile][nq], nq in {2, 8}:
  *   R1 = sum_tiles rowpart[..][0], R2 = sum_tiles rowpart[..][1]
  *   pbeta[b][c] = R1 ; pgamma[b][c] = r_b*(R2 - mu_b*R1)
- *   bsum[b] = { sum_c gamma_c*R1 / count , sum_c gamma_c*pgamma[b][c] / count }     (bsum may be NULL: the fused Conv-TasNet path takes
- *             these means from the producers' epi_bacc / bacc1 sums instead and runs this kernel only for the parameter gradients,
- *             off the critical path; the stand-alone GlobalLayerNorm backward -- sep_gln_bwd_apply -- uses bsum)
+ *   bsum[b] = { sum_c gamma_c*R1 / count , sum_c gamma_c*pgamma[b][c] / count }     (bsum may be NULL: inside the TCN layers of the fused
+ *             Conv-TasNet path the producers publish these means themselves -- sep_dwconv_bwd's bsum1, sep_gln_bwd_from_wgrad's bsum -- and
+ *             this kernel only forms the parameter gradients, off the critical path)
  *   nq == 8 additionally (pextra holds B*C*4 + B + B*C floats; the last B*C are scratch):
  *     pextra[b*4C + c]           = sum_tiles rowpart[..][2]      (depthwise bias gradient, per sample)
  *     pextra[b*4C + C + 3c + k]  = sum_tiles rowpart[..][3+k]    (depthwise weight gradient [C][3], per sample)
@@ -245,17 +242,21 @@ int sep_gln_bwd_finalize(const float* rowpart, int ntile, int nq, const double* 
  * and does not read z (reference tdcn.py:173-175 backward + modules/norm.py:18,27 backward).  Outputs:
  *     dW_b[b][m][n] = sc_bn raw_b[m][n] + sh_bn gs_b[m]      (the true per-sample weight gradient; sum over b with sep_reduce_slabs)
  *     pbeta[b][n] (+)= R1,  pgamma[b][n] (+)= rstd_b (R2 - mu_b R1)      (accumulate = 1 adds: a second product feeding the same gLN)
- *     bacc[b][slot] += { sum_n gamma_n R1, sum_n gamma_n R2 }           (what the consumer's prologue turns into the two means)
+ *     bacc[b][slot] += { sum_n gamma_n R1, sum_n gamma_n R2 }   (fp64, zeroed by the caller; `products` calls feed one gLN -- e.g. the
+ *                          output and the skip product when their weights are not adjacent -- each adding its share)
+ *     bsum[b] = { mean(gamma dv), mean(gamma dv xhat) }         stored by the LAST workgroup of the last call (arrive [B], int, zeroed by the
+ *                          caller, counts the arrivals): what the consumer of dv reads (sep_dwconv_bwd's bsum2)
  * W is [M][N] row-major (rows of adjacent matrices may be handed over as one, e.g. [Wo; Ws]). */
 int sep_gln_bwd_from_wgrad(const float* part, const float* part_bias, const float* W, const double* stats, const float* gamma,
                            const float* beta, double count, float eps, float* dW_b, float* pbeta, float* pgamma, double* bacc,
-                           int B, int M, int N, int slabs_per_sample, int accumulate, sep_stream_t stream);
+                           int* arrive, float* bsum, int B, int M, int N, int slabs_per_sample, int accumulate, int products,
+                           sep_stream_t stream);
 
 /* Backward tail of the separator head: dw = r0*(gamma0*dvw - mg - xhat*mgx) + dwm, times [w>0] if the encoder has ReLU
- * (mg, mgx from bacc0 [B][SEP_STATS_SLOTS][2] = the epi_bacc sums of the bottleneck^T product, and stats0).
+ * (bsum0 [B][2] = {mg, mgx} from sep_gln_bwd_finalize).
  * In place on dvw. (conv_tasnet.py:370 gLN backward + conv_tasnet.py:159-160 product rule + filterbank.py:227) */
 int sep_head_bwd(float* dvw, const float* w, const float* dwm, const double* stats0, const float* gamma0,
-                 const double* bacc0, int B, int C, int T, int ldt, double count, float eps, int relu,
+                 const float* bsum0, int B, int C, int T, int ldt, double count, float eps, int relu,
                  sep_stream_t stream);
 
 /* mask * w, Decoder.forward = basis synthesis + overlap-add, and the crop (conv_tasnet.py:159-169, filterbank.py:245-247):

@@ -48,14 +48,20 @@ def _mu_rstd(stats, count, eps, dtype):
     return m.to(dtype).view(-1, 1, 1), (1.0 / torch.sqrt(var + eps)).to(dtype).view(-1, 1, 1)
 
 
-def _bwd_means(bacc, stats, count, eps, dtype):
-    """gln_bwd_means of csrc/common.hpp: mean(gamma g), mean(gamma g xhat) per sample from the producers' raw slotted sums
-    {sum_c gamma_c sum_t g, sum_c gamma_c sum_t g u} and the gLN's statistics, in fp64"""
+def _publish(bacc, stats, arrive, bsum, arrivals, expected, count, eps):
+    """gln_bwd_publish of csrc/common.hpp: the producers' arrivals are counted per sample; the call that completes `expected` turns the
+    slotted sums {sum_c gamma_c sum_t g, sum_c gamma_c sum_t g u} and the gLN's statistics into the two means (fp64 arithmetic)"""
+    arrive += arrivals
+    if int(arrive.reshape(-1)[0]) < expected:
+        return
+    assert int(arrive.max()) == expected and int(arrive.min()) == expected, "arrival counters out of step"
     st, ba = _tot(stats), _tot(bacc)
     m = st[:, 0] / count
     var = (st[:, 1] / count - m * m).clamp_min(0.0)
     r = 1.0 / torch.sqrt(var + eps)
-    return (ba[:, 0] / count).to(dtype).view(-1, 1, 1), (r * (ba[:, 1] - m * ba[:, 0]) / count).to(dtype).view(-1, 1, 1)
+    bs = bsum.reshape(-1, 2)
+    bs[:, 0] = (ba[:, 0] / count).to(bs.dtype)
+    bs[:, 1] = (r * (ba[:, 1] - m * ba[:, 0]) / count).to(bs.dtype)
 
 
 class EmuBackend:
@@ -73,9 +79,9 @@ class EmuBackend:
 
     def pw_gemm(self, *, B, M, K, T, ldt, A, X, Y, trans_a=0, A2=None, X2=None, k_split=0, Y2=None, m_split=0,
                 pro_mode=PRO_NONE, epi_flags=0, accumulate=0, eps=1e-12, count=0.0, bias=None, pro_alpha=None,
-                pro_stats=None, pro_gamma=None, pro_beta=None, pro_aux=None, pro_bacc=None, pro_store=None,
+                pro_stats=None, pro_gamma=None, pro_beta=None, pro_aux=None, pro_bsum=None, pro_store=None,
                 pro_dalpha=None, epi_alpha=None, epi_stats=None, epi_res=None, epi_aux=None, epi_dalpha=None,
-                epi_rowpart=None, epi_gamma=None, epi_bacc=None, arith=None, a_amax=None, A_pk=None):
+                epi_rowpart=None, arith=None, a_amax=None, A_pk=None):
         dt = X.dtype
         k1 = k_split if k_split else K
         if trans_a:
@@ -112,7 +118,7 @@ class EmuBackend:
             a = pro_aux.reshape(B, K, ldt)
             u = _prelu(a, pro_alpha)
             xh = (u - mu) * rstd
-            mg, mgx = _bwd_means(pro_bacc, pro_stats, count, eps, dt)
+            mg, mgx = pro_bsum[:, 0].view(B, 1, 1), pro_bsum[:, 1].view(B, 1, 1)
             du = rstd * (pro_gamma.view(1, K, 1) * Xf - mg - xh * mgx)
             da = torch.where(valid, du * _prelu_grad(a, pro_alpha), torch.zeros_like(du))
             pro_dalpha += torch.where(valid & (a <= 0), du * a, torch.zeros_like(du)).sum().double()
@@ -143,9 +149,6 @@ class EmuBackend:
             rp = epi_rowpart.reshape(B, M, ldt // 64, 2)
             rp[..., 0] = yv.reshape(B, M, ldt // 64, 64).sum(-1)
             rp[..., 1] = (yv * u).reshape(B, M, ldt // 64, 64).sum(-1)
-            if epi_bacc is not None:
-                gm = epi_gamma.reshape(1, M, 1).to(dt)
-                _acc(epi_bacc, (gm * yv).sum((1, 2)), (gm * yv * u).sum((1, 2)))
         y = torch.where(valid, y, torch.zeros_like(y))
         if m_split:
             Y.reshape(B, Mf, ldt).copy_(y[:, :Mf])
@@ -286,8 +289,8 @@ class EmuBackend:
         u = _prelu(zz, alpha2)
         _acc(stats2, u.sum((1, 2)), (u * u).sum((1, 2)))
 
-    def dwconv_bwd(self, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bacc2, wd, dv1, rowpart, bacc1, B, C, T,
-                   ldt, dilation, eps):
+    def dwconv_bwd(self, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bsum2, wd, dv1, rowpart, bacc1, arrive1, bsum1,
+                   B, C, T, ldt, dilation, eps):
         dt = a.dtype
         d = dilation
         cnt = float(C * T)
@@ -298,8 +301,7 @@ class EmuBackend:
         g = dv2.reshape(B, C, ldt)[:, :, :T]
         u2 = _prelu(zz, alpha2)
         xh = (u2 - mu2) * r2
-        mg2, mgx2 = _bwd_means(bacc2, stats2, cnt, eps, dt)
-        du2 = r2 * (gamma2.view(1, C, 1) * g - mg2 - xh * mgx2)
+        du2 = r2 * (gamma2.view(1, C, 1) * g - bsum2[:, 0].view(B, 1, 1) - xh * bsum2[:, 1].view(B, 1, 1))
         dz = du2 * _prelu_grad(zz, alpha2)
         dal = torch.where(zz <= 0, du2 * zz, torch.zeros_like(zz)).sum(2)
         u1 = _prelu(aa, alpha1)
@@ -328,6 +330,7 @@ class EmuBackend:
         if bacc1 is not None:
             g1 = gamma1.view(1, C, 1).to(dt)
             _acc(bacc1, (g1 * dv).sum((1, 2)), (g1 * dv * u1).sum((1, 2)))
+            _publish(bacc1, stats1, arrive1, bsum1, 1, 1, cnt, eps)
 
     def gln_bwd_finalize(self, rowpart, ntile, nq, stats, gamma, count, eps, bsum, pbeta, pgamma, pextra, B, C):
         dt = rowpart.dtype
@@ -348,8 +351,8 @@ class EmuBackend:
             pe[B * 4 * C:B * 4 * C + B] = rp[..., 6].sum(1)
             pe[B * 4 * C + B:B * 4 * C + B + B * C] = rp[..., 6].reshape(-1)      # per-row scratch of the two-kernel finalize
 
-    def gln_bwd_from_wgrad(self, part, part_bias, W, stats, gamma, beta, count, eps, dW_b, pbeta, pgamma, bacc, B, M, N, slabs_per_sample,
-                           accumulate=0):
+    def gln_bwd_from_wgrad(self, part, part_bias, W, stats, gamma, beta, count, eps, dW_b, pbeta, pgamma, bacc, arrive, bsum, B, M, N,
+                           slabs_per_sample, accumulate=0, products=1):
         dt = part.dtype
         raw = part.reshape(B, slabs_per_sample, M, N).sum(1)
         gs = part_bias.reshape(B, slabs_per_sample, M).sum(1)
@@ -369,15 +372,15 @@ class EmuBackend:
             pb.copy_(R1)
             pg.copy_(rstd * (R2 - mu * R1))
         _acc(bacc, (gamma.view(1, N) * R1).sum(1), (gamma.view(1, N) * R2).sum(1))
+        _publish(bacc, stats, arrive, bsum, 1, products, count, eps)
 
-    def head_bwd(self, dvw, w, dwm, stats0, gamma0, bacc0, B, C, T, ldt, count, eps, relu):
+    def head_bwd(self, dvw, w, dwm, stats0, gamma0, bsum0, B, C, T, ldt, count, eps, relu):
         dt = w.dtype
         mu, rstd = _mu_rstd(stats0, count, eps, dt)
         g = dvw.reshape(B, C, ldt)
         wv = w.reshape(B, C, ldt)
         xh = (wv - mu) * rstd
-        mg, mgx = _bwd_means(bacc0, stats0, count, eps, dt)
-        v = rstd * (gamma0.view(1, C, 1) * g - mg - xh * mgx) + dwm.reshape(B, C, ldt)
+        v = rstd * (gamma0.view(1, C, 1) * g - bsum0[:, 0].view(B, 1, 1) - xh * bsum0[:, 1].view(B, 1, 1)) + dwm.reshape(B, C, ldt)
         if relu:
             v = torch.where(wv > 0, v, torch.zeros_like(v))
         v[:, :, T:] = 0

@@ -75,15 +75,6 @@ def stats_of(x, T):
     return (tot.unsqueeze(1) * w.view(1, SLOTS, 1)).contiguous()
 
 
-def bacc_rand(B, count, scale=0.01):
-    """slotted gLN-backward accumulators (sep_gemm_desc.pro_bacc / epi_bacc): random raw sums {sum gamma g, sum gamma g u} of the size
-    `scale * count`, spread unevenly over the slots"""
-    tot = (torch.randn(B, 2, generator=G) * scale * count).double()
-    w = torch.rand(SLOTS, generator=G).double()
-    w = w / w.sum()
-    return (tot.unsqueeze(1) * w.view(1, SLOTS, 1)).contiguous()
-
-
 def to_device(t):
     """where the second copy of every buffer lives (tests/test_kernel_source_on_host_cpu.py swaps HIP, to_device and device_sync to run
     these same cases on the host simulation of the kernel sources)"""
@@ -237,9 +228,7 @@ def test_gemm_dgrad_two_sources_rowsums(arith):
     dout, dS, z = padded(B, Bn, T, ldt), padded(B, Sc, T, ldt), padded(B, H, T, ldt)
     kw = dict(B=B, M=H, K=Bn + Sc, T=T, ldt=ldt, trans_a=1, A=Wo, A2=Ws, X=dout, X2=dS, k_split=Bn, Y=nan(B, H, ldt),
               epi_flags=EPI_ROWSUMS | EPI_ROWSUMS_PRELU, epi_aux=z, epi_alpha=torch.tensor([0.15]),
-              epi_rowpart=nan(B, H, ldt // 64, 2), epi_gamma=rnd(H) + 1, epi_bacc=zstats(B))
-    both("pw_gemm", [], kw)
-    kw.update(Y=nan(B, H, ldt), epi_rowpart=nan(B, H, ldt // 64, 2), epi_gamma=None, epi_bacc=None)      # the stand-alone form: row partials only
+              epi_rowpart=nan(B, H, ldt // 64, 2))
     both("pw_gemm", [], kw)
 
 
@@ -262,7 +251,7 @@ def test_gemm_gln_bwd_prologue(residual, arith):
     st = stats_of(u, T)
     dv = padded(B, K, T, ldt)
     kw = dict(B=B, M=M, K=K, T=T, ldt=ldt, trans_a=1, A=W1, X=dv, Y=nan(B, M, ldt), pro_mode=PRO_GLN_BWD, pro_stats=st,
-              pro_gamma=rnd(K) + 1, pro_alpha=torch.tensor([0.2]), pro_aux=a, pro_bacc=bacc_rand(B, K * T), pro_store=dv,
+              pro_gamma=rnd(K) + 1, pro_alpha=torch.tensor([0.2]), pro_aux=a, pro_bsum=rnd(B, 2, scale=0.01), pro_store=dv,
               pro_dalpha=torch.zeros(1, dtype=torch.float64), count=K * T, eps=1e-12)
     if residual:
         kw.update(epi_flags=EPI_RESIDUAL, epi_res=padded(B, M, T, ldt))
@@ -278,7 +267,7 @@ def test_gemm_gln_bwd_prologue_several_row_tiles(M, K, arith):
     dv = padded(B, K, T, ldt)
     kw = dict(B=B, M=M, K=K, T=T, ldt=ldt, trans_a=1, A=rnd(K, M, scale=0.1), X=dv, Y=nan(B, M, ldt), pro_mode=PRO_GLN_BWD,
               pro_stats=stats_of(torch.where(a > 0, a, 0.2 * a), T), pro_gamma=rnd(K) + 1, pro_alpha=torch.tensor([0.2]), pro_aux=a,
-              pro_bacc=bacc_rand(B, K * T), pro_store=nan(B, K, ldt), pro_dalpha=torch.full((1,), 100.0, dtype=torch.float64), count=K * T, eps=1e-12,
+              pro_bsum=rnd(B, 2, scale=0.01), pro_store=nan(B, K, ldt), pro_dalpha=torch.full((1,), 100.0, dtype=torch.float64), count=K * T, eps=1e-12,
               epi_flags=EPI_RESIDUAL, epi_res=padded(B, M, T, ldt))
     both("pw_gemm", [], kw)
     kw["pro_store"] = kw["X"]
@@ -311,7 +300,7 @@ def test_gemm_prelu_prologues_any_slope(alpha):
         dv = padded(B, K, T, ldt)
         both("pw_gemm", [], dict(B=B, M=M, K=K, T=T, ldt=ldt, trans_a=1, A=rnd(K, M, scale=0.1), X=dv, Y=nan(B, M, ldt), pro_mode=PRO_GLN_BWD,
                                  pro_stats=stats_of(torch.where(a > 0, a, alpha * a), T), pro_gamma=rnd(K) + 1, pro_alpha=al, pro_aux=a,
-                                 pro_bacc=bacc_rand(B, K * T), pro_store=dv, pro_dalpha=torch.zeros(1, dtype=torch.float64), count=K * T, eps=1e-12,
+                                 pro_bsum=rnd(B, 2, scale=0.01), pro_store=dv, pro_dalpha=torch.zeros(1, dtype=torch.float64), count=K * T, eps=1e-12,
                                  epi_flags=EPI_RESIDUAL, epi_res=padded(B, M, T, ldt)))
     finally:
         PACKED[0] = False
@@ -488,8 +477,10 @@ def test_wgrad_sample_aligned_slabs_and_gln_sums_from_them(B, M, N, T, k, arith)
     kw = dict(B=B, M=M, N=N, T=T, ldt=ldt, G=g, X=z, x_mode=PRO_PRELU, x_alpha=al, partial=part, partial_bias=pb, nsplit=ns)
     _wgrad_both(kw)
     W, gamma, beta, st = rnd(M, N, scale=N ** -0.5), rnd(N) + 1, rnd(N), stats_of(u, T)
-    args = [part, pb, W, st, gamma, beta, N * float(T), 1e-12, nan(B, M, N), nan(B, N), nan(B, N), zstats(B), B, M, N, k, 0]
-    both("gln_bwd_from_wgrad", args, tol=3e-4)       # `part` / `pb` now hold the emulator's slabs on both sides
+    arrive_c, arrive_g = torch.zeros(B, dtype=torch.int32), to_device(torch.zeros(B, dtype=torch.int32))
+    args = [part, pb, W, st, gamma, beta, N * float(T), 1e-12, nan(B, M, N), nan(B, N), nan(B, N), zstats(B), None, nan(B, 2), B, M, N, k, 0, 2]
+    _sums_both(args, arrive_c, arrive_g)             # `part` / `pb` now hold the emulator's slabs on both sides; first of two products:
+    assert not torch.isfinite(args[13]).any()        # ... nothing published yet
     dv = torch.einsum("mn,bmt->bnt", W.double(), g.double())
     R1, R2 = dv.sum(2), (dv * u.double()).sum(2)
     assert (args[9].double() - R1).abs().max() <= 1e-4 * R1.abs().max()
@@ -497,8 +488,35 @@ def test_wgrad_sample_aligned_slabs_and_gln_sums_from_them(B, M, N, T, k, arith)
     assert torch.allclose(tot[:, 0], (gamma.double() * R1).sum(1), rtol=1e-3, atol=1e-4 * R1.abs().max().item() * N ** 0.5)
     assert torch.allclose(tot[:, 1], (gamma.double() * R2).sum(1), rtol=1e-3, atol=1e-4 * R2.abs().max().item() * N ** 0.5)
     args2 = list(args)
-    args2[-1] = 1                                      # accumulate: a second product feeding the same gLN adds its sums
-    both("gln_bwd_from_wgrad", args2, tol=3e-4)
+    args2[-2] = 1                                      # accumulate: the second product feeding the same gLN adds its sums and publishes the means
+    _sums_both(args2, arrive_c, arrive_g)
+    mu = (u[..., :T].double().sum((1, 2)) / (N * T)).view(B, 1)
+    rstd = 1.0 / torch.sqrt(((u[..., :T].double() - mu.view(B, 1, 1)) ** 2).sum((1, 2)) / (N * T) + 1e-12).view(B, 1)
+    mg = 2 * (gamma.double() * R1).sum(1) / (N * T)
+    mgx = 2 * (rstd.view(B) * ((gamma.double() * R2).sum(1) - mu.view(B) * (gamma.double() * R1).sum(1))) / (N * T)
+    assert torch.allclose(args2[13][:, 0].double(), mg, rtol=2e-3, atol=1e-6 * mg.abs().max().item() + 1e-12)
+    assert torch.allclose(args2[13][:, 1].double(), mgx, rtol=2e-3, atol=2e-3 * mgx.abs().max().item() + 1e-12)
+
+
+def _sums_both(args, arrive_c, arrive_g):
+    """sep_gln_bwd_from_wgrad on both sides with persistent arrival counters (argument 12), everything else compared by `both`"""
+    memo_args = list(args)
+    memo_args[12] = arrive_c
+    gargs = [to_device(v) if torch.is_tensor(v) else v for v in memo_args]
+    gargs[12] = arrive_g
+    EMU.gln_bwd_from_wgrad(*memo_args)
+    HIP.gln_bwd_from_wgrad(*gargs)
+    device_sync()
+    assert torch.equal(arrive_c * 0 + int(arrive_c[0]), arrive_c)
+    for i in (8, 9, 10, 13):
+        c, g = memo_args[i], gargs[i].cpu()
+        assert torch.isfinite(g).all() == torch.isfinite(c).all(), i
+        if torch.isfinite(c).all():
+            assert (c.double() - g.double()).abs().max() <= 3e-4 * c.double().abs().max() + 1e-30, i
+    tc, tg = memo_args[11].sum(1), gargs[11].cpu().sum(1)
+    assert (tc - tg).abs().max() <= 3e-4 * tc.abs().max()
+    for i in (8, 9, 10, 11, 13):                       # the next call continues from the EMULATOR's state on both sides
+        args[i] = memo_args[i]
 
 
 def test_wgrad_two_sources_gln_prelu(arith):
@@ -555,7 +573,8 @@ def test_dwconv_fwd_bwd(T, d):
     # backward on the emulator's z / stats2 (identical inputs for both)
     dv2 = padded(B, C, T, ldt)
     ntile = (ldt + 1023) // 1024
-    args = [dv2, z, a, st1, g1, b1, a1, st2, rnd(C) + 1, a2, bacc_rand(B, C * T), wd, nan(B, C, ldt), nan(B, C, ntile, 8), zstats(B), B, C, T, ldt, d, 1e-12]
+    args = [dv2, z, a, st1, g1, b1, a1, st2, rnd(C) + 1, a2, rnd(B, 2, scale=0.01), wd, nan(B, C, ldt), nan(B, C, ntile, 8), zstats(B),
+            torch.zeros(B, dtype=torch.int32), nan(B, 2), B, C, T, ldt, d, 1e-12]
     gargs = [to_device(v) if torch.is_tensor(v) else v for v in args]
     EMU.dwconv_bwd(*args)
     HIP.dwconv_bwd(*gargs)
@@ -567,6 +586,15 @@ def test_dwconv_fwd_bwd(T, d):
     bc, bg = args[14].sum(1), gargs[14].cpu().sum(1)                              # gLN1's gamma-weighted totals (slots -> totals)
     assert (bc - bg).abs().max() <= 3e-4 * bc.abs().max()
     assert torch.allclose(bc[:, 0], (g1.view(1, C).double() * rc[..., 0]).sum(1), rtol=1e-5, atol=1e-6 * bc.abs().max().item())
+    # the sample's last workgroup published the two means (and every workgroup arrived exactly once)
+    assert torch.equal(args[15], gargs[15].cpu() * 0 + 1) and int(gargs[15].cpu().min()) >= C
+    assert (args[16] - gargs[16].cpu()).abs().max() <= 3e-4 * args[16].abs().max()
+    # without the gLN1 outputs (stand-alone use)
+    args2 = list(args)
+    args2[14:17] = [None, None, None]
+    args2[12], args2[13] = nan(B, C, ldt), nan(B, C, ntile, 8)
+    HIP.dwconv_bwd(*[to_device(v) if torch.is_tensor(v) else v for v in args2])
+    device_sync()
 
 
 @pytest.mark.parametrize("Kw,stride,pad,dil,Tin", [(3, 1, 1, 1, 300), (5, 2, 4, 2, 257), (4, 4, 0, 1, 64), (3, 1, 8, 8, 1000), (16, 8, 0, 1, 403)])
@@ -597,7 +625,7 @@ def test_gln_bwd_finalize(nq, ntile):
 def test_head_bwd(relu):
     B, C, T, ldt = 2, 64, 300, 384
     w = padded(B, C, T, ldt)
-    both("head_bwd", [padded(B, C, T, ldt), w, padded(B, C, T, ldt), stats_of(w, T), rnd(C) + 1, bacc_rand(B, C * T), B, C, T, ldt, C * float(T), 1e-12, relu])
+    both("head_bwd", [padded(B, C, T, ldt), w, padded(B, C, T, ldt), stats_of(w, T), rnd(C) + 1, rnd(B, 2, scale=0.01), B, C, T, ldt, C * float(T), 1e-12, relu])
 
 
 # ------------------------------------------------------------------------------------------- decoder

@@ -7,6 +7,7 @@
 //   read_rows64       a wave reads 16 rows x 64 B per instruction (lane >> 2 = row, lane & 3 = 16-byte piece), walking along the
 //                     rows 64 B at a time: the weight-gradient kernels' operand fetch (global_load_dwordx4 form)
 //   read_rows64_dma   the same addresses through global_load_lds_dwordx4 (what pw_wgrad_pc_kernel issues)
+//   read_rows64_dma_spaced   the same with ~1 us between the two 64-byte halves of a line (the weight-gradient kernel's real timing)
 //   read_rows128_dma  a wave reads 8 rows x 128 B per instruction through the LDS DMA: pw_gemm_pc_kernel's operand fetch
 //   write_contig16    a wave writes 1 KiB contiguous per instruction (the transposed GEMM epilogue, the streaming kernels)
 //   write_rows4       a lane writes 4 B, 32 lanes = 128 B of one row, two rows per instruction: the gLN-backward store-back
@@ -50,6 +51,24 @@ __global__ __launch_bounds__(256) void read_rows64_dma(const float* __restrict__
     }
     if (s == 12345.678f) out[0] = s;
 }
+// read_rows64_dma with the two 64-byte halves of every 128-byte line requested ~a microsecond apart (a dependent ALU chain between the
+// chunks), as in pw_wgrad_pc_kernel where the second half belongs to the NEXT chunk: do the halves still merge into one 128-byte request?
+__global__ __launch_bounds__(256) void read_rows64_dma_spaced(const float* __restrict__ x, float* out) {
+    __shared__ __attribute__((aligned(16))) float buf[4][256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int row = blockIdx.x * 64 + wv * 16 + (lane >> 2);
+    const float* p = x + (size_t)row * LDT + blockIdx.y * 4096 + 4 * (lane & 3);
+    float s = 0.f;
+    for (int c = 0; c < 4096 / 16; ++c) {
+        glds16(p + 16 * c, &buf[wv][0]);
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        float t = buf[wv][lane];
+#pragma unroll 1
+        for (int k = 0; k < 400; ++k) t = t * 1.0001f + 0.5f;        // ~400 dependent VALU ~ 1 us
+        s += t;
+    }
+    if (s == 12345.678f) out[0] = s;
+}
 // a wave reads 8 rows x 128 B per instruction; workgroup = 4 waves = 32 rows... walking 128 B at a time
 __global__ __launch_bounds__(256) void read_rows128_dma(const float* __restrict__ x, float* out) {
     __shared__ __attribute__((aligned(16))) float buf[4][4][256];
@@ -88,6 +107,7 @@ int main() {
         hipLaunchKernelGGL(read_rows64, dim3(ROWS / 64, LDT / 4096), dim3(256), 0, 0, x, out);
         hipLaunchKernelGGL(read_rows64_dma, dim3(ROWS / 64, LDT / 4096), dim3(256), 0, 0, x, out);
         hipLaunchKernelGGL(read_rows128_dma, dim3(ROWS / 32, LDT / 4096), dim3(256), 0, 0, x, out);
+        hipLaunchKernelGGL(read_rows64_dma_spaced, dim3(ROWS / 64, LDT / 4096), dim3(256), 0, 0, x, out);
         hipLaunchKernelGGL(write_contig16, dim3(8192), dim3(256), 0, 0, (float4*)y, N / 4);
         hipLaunchKernelGGL(write_rows4, dim3(ROWS / 64, LDT / 4096), dim3(256), 0, 0, y);
     }

@@ -100,8 +100,6 @@ def case_gemm_forms(R):
                   k_split=Bn, Y=GK.nan(B, H, ldt), epi_flags=EPI_ROWSUMS | EPI_ROWSUMS_PRELU, epi_aux=GK.padded(B, H, T, ldt), epi_alpha=al, epi_rowpart=GK.nan(B, H, ldt // 64, 2))
         if R.random() < 0.3:
             kw.update(epi_flags=EPI_ROWSUMS)
-        if R.random() < 0.6:       # with the sample's gamma-weighted totals for the consumer (what the model's step uses)
-            kw.update(epi_gamma=GK.rnd(H) + 1, epi_bacc=GK.zstats(B))
     elif form == 3:        # mask^T: PReLU-derivative epilogue with the slope gradient
         M, K = unit * R.randint(1, 6), 16 * R.randint(1, 12)
         kw = dict(B=B, M=M, K=K, T=T, ldt=ldt, trans_a=1, A=GK.rnd(K, M, scale=0.1), X=GK.padded(B, K, T, ldt), Y=GK.nan(B, M, ldt), epi_flags=EPI_PRELU_BWD,
@@ -111,7 +109,7 @@ def case_gemm_forms(R):
         a = GK.padded(B, K, T, ldt)
         dv = GK.padded(B, K, T, ldt)
         kw = dict(B=B, M=M, K=K, T=T, ldt=ldt, trans_a=1, A=GK.rnd(K, M, scale=0.1), X=dv, Y=GK.nan(B, M, ldt), pro_mode=PRO_GLN_BWD,
-                  pro_stats=GK.stats_of(torch.where(a > 0, a, al * a), T), pro_gamma=GK.rnd(K) + 1, pro_alpha=al, pro_aux=a, pro_bacc=GK.bacc_rand(B, K * T), pro_store=dv if M <= 128 else GK.nan(B, K, ldt),     # in place only with one row tile (sepkernels.h)
+                  pro_stats=GK.stats_of(torch.where(a > 0, a, al * a), T), pro_gamma=GK.rnd(K) + 1, pro_alpha=al, pro_aux=a, pro_bsum=GK.rnd(B, 2, scale=0.01), pro_store=dv if M <= 128 else GK.nan(B, K, ldt),     # in place only with one row tile (sepkernels.h)
                   pro_dalpha=walk(B * K * T), count=K * T, eps=1e-12)
         if R.random() < 0.5:
             kw.update(epi_flags=EPI_RESIDUAL, epi_res=GK.padded(B, M, T, ldt))

@@ -19,7 +19,7 @@ g1, b1, g2 = f(C), f(C), f(C)
 a1, a2 = torch.tensor([0.25], device=dev), torch.tensor([0.1], device=dev)
 wd, bd = f(C, 1, 3), f(C)
 st1, st2 = st(), st()
-bacc2, bacc1 = st() * 1e-3, st()
+bsum2, bacc1, arrive1, bsum1 = f(B, 2) * 0.01, st(), torch.zeros(B, device=dev, dtype=torch.int32), f(B, 2)
 rp = torch.empty(B, C, (ldt + 1023) // 1024, 8, device=dev)
 
 
@@ -40,7 +40,7 @@ H = B * C * ldt * 4 / 1e6   # MB per H-tensor
 tf = tb = 0.0
 for d in (1, 2, 4, 8, 16, 32, 64, 128):
     ms_f = timeit(lambda: K.dwconv_fwd(a, st1, g1, b1, a1, wd, bd, a2, z, st2, B, C, T, ldt, d, 1e-12))
-    ms_b = timeit(lambda: K.dwconv_bwd(dv2, z, a, st1, g1, b1, a1, st2, g2, a2, bacc2, wd, dv1, rp, bacc1, B, C, T, ldt, d, 1e-12))
+    ms_b = timeit(lambda: K.dwconv_bwd(dv2, z, a, st1, g1, b1, a1, st2, g2, a2, bsum2, wd, dv1, rp, bacc1, arrive1, bsum1, B, C, T, ldt, d, 1e-12))
     tf += ms_f
     tb += ms_b
     print("d={:4d}  fwd {:7.1f} us ({:5.2f} TB/s)   bwd {:7.1f} us ({:5.2f} TB/s)".format(d, 1e3 * ms_f, 2 * H / ms_f / 1e3, 1e3 * ms_b, 4 * H / ms_b / 1e3))
