@@ -107,7 +107,7 @@ class TimedBackend:
             B, C, T = a[10], a[11], a[12]
             return "depthwise fwd", None, 2.0 * C * 4 * B * T, 2.0 * C * 4 * B * T
         if name == "dwconv_bwd":
-            B, C, T = a[15], a[16], a[17]
+            B, C, T = a[17], a[18], a[19]
             return "depthwise bwd", None, 4.0 * C * 4 * B * T, 4.0 * C * 4 * B * T
         if name == "encoder_fwd":
             B, Tin, N, F = a[4], a[6], a[7], a[10]
@@ -124,7 +124,7 @@ class TimedBackend:
         if name == "reduce_slabs":
             return "reduce_slabs", None, 4.0 * sum(sg[3] * (sg[4] + 1) for sg in a[0]), None
         if name == "gln_bwd_from_wgrad":
-            B, M, N, sps = a[12], a[13], a[14], a[15]
+            B, M, N, sps = a[14], a[15], a[16], a[17]
             return "gln sums from wgrad", None, 4.0 * B * M * N * (sps + 1), None
         if name in ("gln_bwd_finalize", "f64_to_f32", "pack_weights", "unfold", "sqnorm", "adam_step", "adam_step_dev", "softmax_ch_fwd", "softmax_ch_bwd"):
             return name, None, None, None

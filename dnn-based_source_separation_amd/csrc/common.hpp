@@ -98,14 +98,21 @@ __device__ __forceinline__ void gln_mu_rstd(const double* st, double count, floa
 // Round 2 formed them in two second-stage launches between the kernel that produces g and the kernel that consumes it (98 launches per
 // step on the critical path).  Now the PRODUCER finishes them: every workgroup adds its gamma-weighted row-sum totals
 //     acc[slot] += { sum_c gamma_c sum_t g , sum_c gamma_c sum_t g u }                  (fp64 atomics, SEP_STATS_SLOTS slots like the statistics)
-// and arrives at the sample's counter; the LAST of `expected` arrivals turns the slots into the two means and stores them where the
-// consumer's prologue reads two floats (as it always did).  ONE thread per workgroup calls this, behind a barrier that follows the
-// workgroup's atomics.  Both sums are linear in the row sums, so they need neither mu nor rstd while they are accumulated.
+// and arrives at the sample's counters; the LAST arrival turns the slots into the two means and stores them where the consumer's
+// prologue reads two floats (as it always did).  ONE thread per workgroup calls this, behind a barrier that follows the workgroup's
+// atomics.  Both sums are linear in the row sums, so they need neither mu nor rstd while they are accumulated.
 // First form of this round: the CONSUMERS summed the slots -- 64 fp64 loads and an fp64 divide / sqrt in every workgroup of the
 // depthwise backward (+8 us per launch) and spilled registers in the GEMM kernels.
-__device__ __forceinline__ void gln_bwd_publish(const double* acc, const double* st, int* counter, float* means, int expected, double count, float eps) {
+// Arrival counters: SEP_STATS_SLOTS + 1 ints per sample.  A workgroup arrives at ITS SLOT's counter; the last of that slot's
+// `expected_in_slot` arrivals arrives at the sample's counter [SEP_STATS_SLOTS]; the last of those `nslots` is the sample's last workgroup.
+// Two levels because a returning atomic on ONE address costs about a microsecond and they serialise: 512 workgroups per sample on one
+// counter made the depthwise backward take 504 us instead of 95 (profiles/r03e_kernel_stats.md); 32 per address disappear in its run time.
+static_assert(SEP_ARRIVE_INTS == SEP_STATS_SLOTS + 1, "arrival counters");
+__device__ __forceinline__ void gln_bwd_publish(const double* acc, const double* st, int* counters, float* means, int slot, int expected_in_slot,
+                                                int nslots, double count, float eps) {
     __threadfence();                                   // this workgroup's atomics are performed before its arrival is
-    if (atomicAdd(counter, 1) != expected - 1) return;
+    if (atomicAdd(counters + slot, 1) != expected_in_slot - 1) return;
+    if (atomicAdd(counters + SEP_STATS_SLOTS, 1) != nslots - 1) return;
     __threadfence();
     double s1 = 0.0, s2 = 0.0, m, r;
 #pragma unroll
@@ -117,6 +124,9 @@ __device__ __forceinline__ void gln_bwd_publish(const double* acc, const double*
     means[0] = (float)(s1 / count);
     means[1] = (float)(r * (s2 - m * s1) / count);
 }
+// arrivals a slot sees when `n` workgroups numbered 0 .. n-1 arrive at slot (number & (SEP_STATS_SLOTS - 1)), and how many slots see any
+__device__ __forceinline__ int arrivals_in_slot(int n, int slot) { return (n - slot + SEP_STATS_SLOTS - 1) / SEP_STATS_SLOTS; }
+__device__ __forceinline__ int slots_in_use(int n) { return n < SEP_STATS_SLOTS ? n : SEP_STATS_SLOTS; }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 

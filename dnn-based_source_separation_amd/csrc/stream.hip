@@ -386,8 +386,18 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(
             double* ba = bacc1 + ((size_t)b * SEP_STATS_SLOTS + (g & (SEP_STATS_SLOTS - 1))) * 2;
             const float g1 = gamma1[c];
             atomicAdd(ba, (double)(g1 * q0)); atomicAdd(ba + 1, (double)(g1 * q1));
-            gln_bwd_publish(bacc1 + (size_t)b * SEP_STATS_SLOTS * 2, stats1 + (size_t)b * SEP_STATS_SLOTS * 2, arrive1 + b, bsum1 + 2 * b, C * ntile,
-                            (double)C * T, eps);
+            const int slot = (int)(g & (SEP_STATS_SLOTS - 1));
+            // slots are taken by the global unit number g; a sample's units are C * ntile consecutive numbers starting at b * C * ntile
+            const long first = (long)b * C * ntile, nun = (long)C * ntile;
+            int in_slot = 0, used = 0;
+            for (int q = 0; q < SEP_STATS_SLOTS; ++q) {
+                const long f0 = first + ((q - first) & (SEP_STATS_SLOTS - 1));      // first unit of the sample landing in slot q
+                const int cnt_q = f0 < first + nun ? (int)((first + nun - f0 + SEP_STATS_SLOTS - 1) / SEP_STATS_SLOTS) : 0;
+                used += cnt_q > 0;
+                if (q == slot) in_slot = cnt_q;
+            }
+            gln_bwd_publish(bacc1 + (size_t)b * SEP_STATS_SLOTS * 2, stats1 + (size_t)b * SEP_STATS_SLOTS * 2, arrive1 + (size_t)b * SEP_ARRIVE_INTS,
+                            bsum1 + 2 * b, slot, in_slot, used, (double)C * T, eps);
         }
     }
 }
@@ -521,7 +531,17 @@ __global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
         double* ba = bacc1 + ((size_t)b * SEP_STATS_SLOTS + (row & (SEP_STATS_SLOTS - 1))) * 2;
         atomicAdd(ba, (double)(g1c * ((part[0][0] + part[1][0]) + (part[2][0] + part[3][0]))));
         atomicAdd(ba + 1, (double)(g1c * ((part[0][1] + part[1][1]) + (part[2][1] + part[3][1]))));
-        gln_bwd_publish(bacc1 + (size_t)b * SEP_STATS_SLOTS * 2, stats1 + (size_t)b * SEP_STATS_SLOTS * 2, arrive1 + b, bsum1 + 2 * b, C, (double)C * T, eps);
+        // slots are taken by the global row number; a sample's rows are C consecutive numbers starting at b * C
+        const int slot = row & (SEP_STATS_SLOTS - 1), first = b * C;
+        int in_slot = 0, used = 0;
+        for (int q = 0; q < SEP_STATS_SLOTS; ++q) {
+            const int f0 = first + ((q - first) & (SEP_STATS_SLOTS - 1));
+            const int cnt_q = f0 < first + C ? (first + C - f0 + SEP_STATS_SLOTS - 1) / SEP_STATS_SLOTS : 0;
+            used += cnt_q > 0;
+            if (q == slot) in_slot = cnt_q;
+        }
+        gln_bwd_publish(bacc1 + (size_t)b * SEP_STATS_SLOTS * 2, stats1 + (size_t)b * SEP_STATS_SLOTS * 2, arrive1 + (size_t)b * SEP_ARRIVE_INTS, bsum1 + 2 * b,
+                        slot, in_slot, used, (double)C * T, eps);
     }
 }
 
@@ -681,8 +701,11 @@ __global__ __launch_bounds__(1024) void gln_bwd_from_wgrad_kernel(const float* _
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0)
-        gln_bwd_publish(bacc + (size_t)b * SEP_STATS_SLOTS * 2, stats + (size_t)b * SEP_STATS_SLOTS * 2, arrive + b, bsum + 2 * b, (int)gridDim.x * products, count, eps);
+    if (threadIdx.x == 0) {      // gridDim.x workgroups per sample and product, numbered blockIdx.x: slot blockIdx.x & 15
+        const int slot = blockIdx.x & (SEP_STATS_SLOTS - 1);
+        gln_bwd_publish(bacc + (size_t)b * SEP_STATS_SLOTS * 2, stats + (size_t)b * SEP_STATS_SLOTS * 2, arrive + (size_t)b * SEP_ARRIVE_INTS, bsum + 2 * b,
+                        slot, arrivals_in_slot((int)gridDim.x, slot) * products, slots_in_use((int)gridDim.x), count, eps);
+    }
 }
 
 // dw = r0*(gamma*dvw - mg - xhat*mgx) + dwm  [* (w>0)]   in place on dvw

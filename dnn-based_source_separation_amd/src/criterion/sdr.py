@@ -14,6 +14,10 @@ import sepkernels
 EPS = 1e-12
 
 
+_MAX_ROWS = 65535      # sep_sisdr_dots / sep_sisdr_bwd put the batch on a 16-bit grid dimension: larger batches (sisdr() flattens every
+                       # leading axis into it: 4-D inputs, long evaluation lists) go through in slices
+
+
 class _SISDRPairsFn(torch.autograd.Function):
     """est, tgt (B, n, T) -> sisdr (B, n, n): entry [b, i, j] = SI-SDR(est_i, tgt_j); only the diagonal is computed
     (others 0) when all_pairs is False."""
@@ -29,9 +33,11 @@ class _SISDRPairsFn(torch.autograd.Function):
         dots = torch.zeros(B, n, n, device=dev, dtype=torch.float64)
         tt = torch.zeros(B, n, device=dev, dtype=torch.float64)
         xx = torch.zeros(B, n, device=dev, dtype=torch.float64)
-        K.sisdr_dots(est, tgt, dots, tt, xx, B, n, T, all_pairs)
         out = torch.empty(B, n, n, device=dev, dtype=est.dtype)
-        K.sisdr_from_dots(dots, tt, xx, out, B, n, all_pairs, eps)
+        for b0 in range(0, B, _MAX_ROWS):
+            b1 = min(B, b0 + _MAX_ROWS)
+            K.sisdr_dots(est[b0:b1], tgt[b0:b1], dots[b0:b1], tt[b0:b1], xx[b0:b1], b1 - b0, n, T, all_pairs)
+            K.sisdr_from_dots(dots[b0:b1], tt[b0:b1], xx[b0:b1], out[b0:b1], b1 - b0, n, all_pairs, eps)
         ctx.save_for_backward(est, tgt, dots, tt, xx)
         ctx.meta = (all_pairs, eps)
         return out
@@ -43,7 +49,10 @@ class _SISDRPairsFn(torch.autograd.Function):
         all_pairs, eps = ctx.meta
         B, n, T = est.shape
         d_est = torch.empty_like(est)
-        K.sisdr_bwd(est, tgt, dots, tt, xx, gout.contiguous().to(est.dtype), d_est, B, n, T, all_pairs, eps)
+        gout = gout.contiguous().to(est.dtype)
+        for b0 in range(0, B, _MAX_ROWS):
+            b1 = min(B, b0 + _MAX_ROWS)
+            K.sisdr_bwd(est[b0:b1], tgt[b0:b1], dots[b0:b1], tt[b0:b1], xx[b0:b1], gout[b0:b1], d_est[b0:b1], b1 - b0, n, T, all_pairs, eps)
         return d_est, None, None, None
 
 

@@ -18,6 +18,7 @@ import torch.nn.functional as F
 from utils.filterbank import choose_filterbank
 from utils.tasnet import choose_layer_norm
 from models.tdcn import TimeDilatedConvNet
+from utils.checkpoint import load_checkpoint
 from sepkernels import net as _net
 
 SAMPLE_RATE_MUSDB18 = 44100
@@ -323,7 +324,7 @@ class ConvTasNet(nn.Module):
 
     @classmethod
     def build_model(cls, model_path, load_state_dict=False):
-        config = torch.load(model_path, map_location=lambda storage, loc: storage, weights_only=False)
+        config = load_checkpoint(model_path)
         return cls._from_config(config, load_state_dict)
 
     @classmethod
@@ -381,7 +382,7 @@ class ConvTasNet(nn.Module):
         if not os.path.exists(model_path):
             from utils.utils import download_pretrained_model_from_google_drive   # reference helper (gdown), reused as-is
             download_pretrained_model_from_google_drive(model_id, download_dir, quiet=quiet)
-        config = torch.load(model_path, map_location=lambda storage, loc: storage, weights_only=False)
+        config = load_checkpoint(model_path)
         model = cls._from_config(config, load_state_dict=load_state_dict)
         if task == "musdb18":
             extra.update({"sources": config["sources"], "n_sources": len(config["sources"])})

@@ -15,6 +15,7 @@ from utils.tasnet import choose_layer_norm
 from models.dprnn import DPRNN
 from models.masking import MaskingTasNet
 from models.transform import Segment1d, OverlapAdd1d
+from utils.checkpoint import load_checkpoint
 from sepkernels import net as _net
 from sepkernels.functional import HeadFn, TailFn, SegmentFn, OverlapAddFn, HEAD_KEYS, TAIL_KEYS, segment_geometry
 
@@ -77,7 +78,7 @@ class DPRNNTasNet(MaskingTasNet):
 
     @classmethod
     def build_model(cls, model_path, load_state_dict=False):
-        config = torch.load(model_path, map_location=lambda storage, loc: storage, weights_only=False)
+        config = load_checkpoint(model_path)
         model = cls(config.get("n_bases") or config["n_basis"], in_channels=config.get("in_channels") or 1,
                     kernel_size=config["kernel_size"], stride=config["stride"],
                     enc_basis=config.get("enc_bases") or config["enc_basis"], dec_basis=config.get("dec_bases") or config["dec_basis"],

@@ -40,6 +40,9 @@ class GALRBlock(nn.Module):
         return self.inter_chunk_block(self.intra_chunk_block(input))
 
 
+_POSITION_CODES = {}       # id(block) -> {(S, Q, C, device, dtype): code}, see GloballyAttentiveBlockBase._position_code
+
+
 class GloballyAttentiveBlockBase(nn.Module):
     def positional_encoding(self, length, dimension, base=10000):
         """(length, dimension): [sin(p / base^(i/dimension)) for i < dimension/2 | the cosines]  (halves, not interleaved)"""
@@ -52,12 +55,15 @@ class GloballyAttentiveBlockBase(nn.Module):
     def _position_code(self, S, Q, C, like):
         """(C, S, Q) code on the device / in the dtype of `like`, built once per shape: forming it on the host and copying it
         over in every forward would stall the launch queue once per block"""
-        cache = self.__dict__.setdefault("_codes", {})
+        cache = _POSITION_CODES.setdefault(id(self), {})      # not an attribute: deepcopy / state_dict must not carry device tensors along
         key = (S, Q, C, like.device, like.dtype)
-        if key not in cache:
-            cache.clear()                                    # one shape at a time (training: fixed length; evaluation: one utterance)
-            cache[key] = self.positional_encoding(length=S * Q, dimension=C).t().reshape(C, S, Q).to(device=like.device, dtype=like.dtype)
-        return cache[key]
+        code = cache.pop(key, None)
+        if code is None:
+            if len(cache) >= 8:                              # a few shapes stay resident (training length, validation utterances): least recently used goes
+                cache.pop(next(iter(cache)))
+            code = self.positional_encoding(length=S * Q, dimension=C).t().reshape(C, S, Q).to(device=like.device, dtype=like.dtype)
+        cache[key] = code                                    # (re-)inserted last = most recently used
+        return code
 
     def _attend(self, x):
         """x (batch_size, num_features, S, Q): [channel norm ->] + position code -> attention over S -> [dropout] + its input

@@ -25,6 +25,7 @@ from sepkernels import net as _net
 from sepkernels.functional import EncodeFn, MaskDecodeFn, PaddedPointwiseFn, segment_geometry, takes as _takes
 from utils.filterbank import choose_filterbank
 from utils.model import choose_nonlinear
+from utils.checkpoint import load_checkpoint
 from models.filterbank import Decoder, Encoder
 from models.gtu import GTU1d       # noqa: F401  (the separators build theirs through this module)
 
@@ -39,6 +40,7 @@ def make_mask_nonlinear(name):
     if name == "softmax":
         return choose_nonlinear(name, dim=1)
     raise ValueError("Cannot support {}".format(name))
+
 
 
 class GatedMaskSeparator(nn.Module):
@@ -138,7 +140,9 @@ class MaskingTasNet(nn.Module):
             mixture = input.view(batch_size, n_mics, T)
         else:
             raise ValueError("Not support {} dimension input".format(n_dims))
-        if _takes(mixture) and not self.kernel_path_problems():
+        # the kernel path's EncodeFn / HeadFn do not differentiate with respect to the mixture itself: such calls take the composition
+        wants_input_grad = torch.is_grad_enabled() and mixture.requires_grad
+        if _takes(mixture) and not wants_input_grad and not self.kernel_path_problems():
             est, latent = self._run_kernels(mixture.contiguous())
         else:
             est, latent = self._run_composed(mixture)
@@ -185,8 +189,8 @@ class MaskingTasNet(nn.Module):
         return self.get_config()
 
     @classmethod
-    def build_model(cls, model_path, load_state_dict=False):
-        config = torch.load(model_path, map_location=lambda storage, loc: storage, weights_only=False)
+    def build_model(cls, model_path, load_state_dict=False, trust_pickle=None):
+        config = load_checkpoint(model_path, trust_pickle)
         legacy = {"n_basis": "n_bases", "enc_basis": "enc_bases", "dec_basis": "dec_bases"}       # keys of older checkpoints
         args = {}
         for k in ("n_basis", "kernel_size", "stride", "enc_basis", "dec_basis", "enc_nonlinear", "window_fn") + tuple(cls.SEP_KEYS) + \

@@ -18,6 +18,8 @@ import os
 import time
 
 import torch
+
+from utils.checkpoint import load_checkpoint
 import torch.distributed as dist
 
 from sepkernels.train import FusedTrainStep
@@ -67,7 +69,7 @@ class Trainer:
         self.train_loss = torch.empty(self.epochs)
         self.valid_loss = torch.empty(self.epochs)
         if getattr(args, "continue_from", None):
-            ck = torch.load(args.continue_from, map_location="cpu", weights_only=False)
+            ck = load_checkpoint(args.continue_from)
             self.start_epoch = ck["epoch"]
             self.train_loss[:self.start_epoch] = ck["train_loss"][:self.start_epoch]
             self.valid_loss[:self.start_epoch] = ck["valid_loss"][:self.start_epoch]
@@ -193,7 +195,7 @@ class Tester:
             os.makedirs(self.out_dir, exist_ok=True)
         self.device = next(model.parameters()).device
         if getattr(args, "model_path", None):
-            ck = torch.load(args.model_path, map_location="cpu", weights_only=False)
+            ck = load_checkpoint(args.model_path)
             model.load_state_dict(ck["state_dict"])
 
     def run(self):

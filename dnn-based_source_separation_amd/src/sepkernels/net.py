@@ -21,7 +21,7 @@ import torch
 
 import sepkernels
 
-from . import (STATS_SLOTS, EPI_PRELU_BWD, EPI_RESIDUAL, EPI_ROWSUMS, EPI_ROWSUMS_PRELU, EPI_SIGMOID, EPI_STATS_PRELU, PRO_GLN,
+from . import (ARRIVE_INTS, STATS_SLOTS, EPI_PRELU_BWD, EPI_RESIDUAL, EPI_ROWSUMS, EPI_ROWSUMS_PRELU, EPI_SIGMOID, EPI_STATS_PRELU, PRO_GLN,
                PRO_GLN_BWD, PRO_GLN_PRELU, PRO_PRELU, backend)
 
 
@@ -475,7 +475,7 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
     # arrivals (arrive), and the sample's last one stores the two means (bsum) the consumer's prologue reads -- no second-stage launch in
     # between (gln_bwd_publish, csrc/common.hpp).  sep_gln_bwd_finalize still turns gLN1's row partials into parameter gradients, as a leaf.
     bacc = torch.zeros(2 * nl + 1, B, STATS_SLOTS, 2, device=dev, dtype=torch.float64)
-    arrive = torch.zeros(2 * nl + 1, B, device=dev, dtype=torch.int32)
+    arrive = torch.zeros(2 * nl + 1, B, ARRIVE_INTS, device=dev, dtype=torch.int32)
     bsum = torch.empty(2 * nl + 1, B, 2, **f32)
     def wgrad(M, Nn, Gt, Xt, dW, dbias=None, Bq=B, weps=None, **kw):
         return _wgrad(K, B, F, ldt, eps, f32, M, Nn, Gt, Xt, dbias is not None, Bq=Bq, weps=weps, **kw)

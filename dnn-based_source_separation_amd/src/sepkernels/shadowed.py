@@ -6,6 +6,9 @@ MMDenseLSTM family, `criterion.pit.ProbPIT`, ...), which other reference modules
 PEP 562 `__getattr__` that finds the hidden file further down `sys.path`, loads it under a private name and serves the missing
 attribute from it, so `from modules.conv import MultiDilatedConv2d` keeps working in a merged tree.  Without the reference on the
 path (the GPU box, a stand-alone install) the attribute is simply missing, as it would be anyway.
+The hidden copy RE-DEFINES the classes this tree defines too (SISDR, GlobalLayerNorm ...): objects built from names served here are
+the reference's own classes, not this tree's -- isinstance checks against this tree's classes do not see them, and such objects take the
+generic (composed) paths.  Only names this tree does not define are ever served, so product code never receives such a twin by accident.
 """
 import importlib.util
 import os
@@ -20,8 +23,14 @@ def _hidden_module(module_name, own_file):
     rel = os.path.join(*module_name.split(".")) + ".py"
     own = os.path.realpath(own_file)
     found = None
-    for entry in sys.path:
-        cand = os.path.join(entry or ".", rel)
+    # Where the hidden file may live: SEPK_REFERENCE_SRC (the reference's src/, when set: nowhere else), otherwise the entries of sys.path
+    # that were put there explicitly -- never '' / '.' / the working directory: a same-named file lying around where the process happens
+    # to run (./criterion/pit.py ...) must not be executed.
+    root = os.environ.get("SEPK_REFERENCE_SRC")
+    cwd = os.path.realpath(os.getcwd())
+    entries = [root] if root else [e for e in sys.path if e not in ("", ".") and os.path.realpath(e) != cwd]
+    for entry in entries:
+        cand = os.path.join(entry, rel)
         if os.path.isfile(cand) and os.path.realpath(cand) != own:
             spec = importlib.util.spec_from_file_location("_shadowed_." + module_name, cand)
             found = importlib.util.module_from_spec(spec)

@@ -50,6 +50,21 @@ class FusedTrainStep:
         self._step_dev = None
         self._lr_dev = None
 
+    def _trainable_mask(self):
+        """None when every parameter trains (the usual case: nothing extra runs), else a 0 / 1 vector over the flat buffer, rebuilt when the
+        set of frozen parameters changes.  Frozen parameters (requires_grad = False) get a zero gradient before the norm is taken, and their
+        values / moments are put back after the fused Adam (which would otherwise apply weight decay to them); alignment gaps hold zeros."""
+        key = tuple(p.requires_grad for p in self.model.parameters())
+        if all(key):
+            return None
+        if getattr(self, "_mask_key", None) != key or self._mask.device != self.flat.device:
+            mask = torch.zeros_like(self.flat)
+            for (off, n, _), p in zip(self._spans(), self.model.parameters()):
+                if p.requires_grad:
+                    mask[off:off + n] = 1.0
+            self._mask, self._mask_key = mask, key
+        return self._mask
+
     def zero_grad(self):
         for p in self.model.parameters():
             p.grad = None
@@ -65,6 +80,7 @@ class FusedTrainStep:
         self.flat = flat
         self.gflat, self.m, self.v = (t.to(flat.device) for t in (self.gflat, self.m, self.v))
         self.sqnorm = self.sqnorm.to(flat.device)
+        self._graph = None          # a captured step writes through the OLD buffers' addresses: it has to be recorded again
 
     # ---- hipGraph of the whole step -----------------------------------------------------------------------------------
     def capture(self, mixture, sources, warmup=3):
@@ -90,10 +106,14 @@ class FusedTrainStep:
             self._static_loss = self._eager(*self._static, graph=True)
         self._graph = g
         self._graph_shapes = (tuple(mixture.shape), tuple(sources.shape))
+        self._graph_hyper = (tuple(self.betas), self.eps, self.weight_decay)
         # capture only records: run the step it recorded once, so that the caller sees warmup + 1 steps done
         return self._replay()
 
     def _replay(self):
+        if self.model.flat_parameters() is not self.flat:      # model.to() / .float() since the capture: the graph is stale
+            self._graph = None
+            return self._eager(*self._static)
         self._lr_dev.fill_(self.lr)
         self._graph.replay()
         self.step_count += 1
@@ -135,6 +155,11 @@ class FusedTrainStep:
             else:
                 dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM, group=self.group)
         n = self.gflat.numel()
+        mask = self._trainable_mask()
+        frozen = None
+        if mask is not None:
+            self.gflat.mul_(mask)         # frozen parameters (requires_grad = False) take no part in the norm and are not moved by Adam
+            frozen = self.flat * (1.0 - mask)
         self.sqnorm.zero_()
         if self.max_norm and self.max_norm > 0:
             K.sqnorm(self.gflat, self.sqnorm, n)
@@ -147,6 +172,10 @@ class FusedTrainStep:
                 self._step_dev.fill_(self.step_count)          # an eager step between replays (other shapes) keeps the device count in step
             K.adam_step(self.flat, self.gflat, self.m, self.v, self.sqnorm, n, self.lr, self.betas[0], self.betas[1], self.eps,
                         self.weight_decay, float(self.max_norm or 0.0), 1.0 / self.world, self.step_count)
+        if frozen is not None:
+            self.flat.mul_(mask).add_(frozen)
+            self.m.mul_(mask)
+            self.v.mul_(mask)
         return loss.detach()
 
     # ---- optimizer state in torch.optim.Adam's state_dict layout (checkpoint interchange with the reference's
@@ -194,4 +223,10 @@ class FusedTrainStep:
             if len(set(steps)) != 1:
                 raise ValueError("per-parameter Adam step counts differ; the fused step keeps one")
             self.step_count = steps[0]
+        # a captured step carries betas / eps / weight_decay as launch constants and the step count in device memory: refresh the count,
+        # and drop the graph if any of the constants moved (capture() records it again)
+        if self._step_dev is not None:
+            self._step_dev.fill_(self.step_count)
+        if self._graph is not None and getattr(self, "_graph_hyper", None) != (tuple(self.betas), self.eps, self.weight_decay):
+            self._graph = None
 

@@ -35,6 +35,7 @@ typedef void* sep_stream_t; /* hipStream_t */
 
 #define SEP_ABI_VERSION 14
 #define SEP_STATS_SLOTS 16
+#define SEP_ARRIVE_INTS 17 /* arrival counters per sample: one per slot + one for the slots (csrc/common.hpp, gln_bwd_publish) */
 
 int sep_version(void);
 const char* sep_last_error(void);
@@ -208,7 +209,7 @@ int sep_dwconv_fwd(const float* a, const double* stats1, const float* gamma1, co
  *   du2 = r2*(gamma2*dv2 - mg2 - xhat2*mgx2) ; dz = du2*PReLU'(z) ; dv1 = depthwise^T(dz)
  * bsum2 [B][2] = {mg2, mgx2} = mean(gamma2 dv2), mean(gamma2 dv2 xhat2), written by the producer of dv2's sums (sep_gln_bwd_from_wgrad).
  * For gLN1 this kernel is the producer: bacc1 [B][SEP_STATS_SLOTS][2] (fp64, zeroed by the caller) receives its workgroups'
- * {sum_c gamma1_c sum_t dv1, sum_c gamma1_c sum_t dv1*u1}, arrive1 [B] (int, zeroed) counts them, and the sample's LAST workgroup stores
+ * {sum_c gamma1_c sum_t dv1, sum_c gamma1_c sum_t dv1*u1}, arrive1 [B][SEP_ARRIVE_INTS] (int, zeroed) counts them, and the sample's LAST workgroup stores
  * bsum1 [B][2] = {mean(gamma1 dv1), mean(gamma1 dv1 xhat1)} for the consumer's prologue (sep_gemm_desc.pro_bsum) -- no second-stage launch
  * between the two (round 2: sep_gln_bwd_finalize, 98 launches per step on the critical path).  All three may be NULL together.
  * Writes dv1 and, per (b, c, 1024-frame tile), 8 partial row sums into rowpart[b][c][ntile][8]:
@@ -244,8 +245,8 @@ int sep_gln_bwd_finalize(const float* rowpart, int ntile, int nq, const double* 
  *     pbeta[b][n] (+)= R1,  pgamma[b][n] (+)= rstd_b (R2 - mu_b R1)      (accumulate = 1 adds: a second product feeding the same gLN)
  *     bacc[b][slot] += { sum_n gamma_n R1, sum_n gamma_n R2 }   (fp64, zeroed by the caller; `products` calls feed one gLN -- e.g. the
  *                          output and the skip product when their weights are not adjacent -- each adding its share)
- *     bsum[b] = { mean(gamma dv), mean(gamma dv xhat) }         stored by the LAST workgroup of the last call (arrive [B], int, zeroed by the
- *                          caller, counts the arrivals): what the consumer of dv reads (sep_dwconv_bwd's bsum2)
+ *     bsum[b] = { mean(gamma dv), mean(gamma dv xhat) }         stored by the LAST workgroup of the last call (arrive [B][SEP_ARRIVE_INTS], int,
+ *                          zeroed by the caller, counts the arrivals): what the consumer of dv reads (sep_dwconv_bwd's bsum2)
  * W is [M][N] row-major (rows of adjacent matrices may be handed over as one, e.g. [Wo; Ws]). */
 int sep_gln_bwd_from_wgrad(const float* part, const float* part_bias, const float* W, const double* stats, const float* gamma,
                            const float* beta, double count, float eps, float* dW_b, float* pbeta, float* pgamma, double* bacc,

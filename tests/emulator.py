@@ -51,10 +51,11 @@ def _mu_rstd(stats, count, eps, dtype):
 def _publish(bacc, stats, arrive, bsum, arrivals, expected, count, eps):
     """gln_bwd_publish of csrc/common.hpp: the producers' arrivals are counted per sample; the call that completes `expected` turns the
     slotted sums {sum_c gamma_c sum_t g, sum_c gamma_c sum_t g u} and the gLN's statistics into the two means (fp64 arithmetic)"""
-    arrive += arrivals
-    if int(arrive.reshape(-1)[0]) < expected:
+    top = arrive.reshape(-1, 17)[:, 16]          # the emulator only keeps the samples' top-level counters (one arrival per call)
+    top += arrivals
+    if int(top[0]) < expected:
         return
-    assert int(arrive.max()) == expected and int(arrive.min()) == expected, "arrival counters out of step"
+    assert int(top.max()) == expected and int(top.min()) == expected, "arrival counters out of step"
     st, ba = _tot(stats), _tot(bacc)
     m = st[:, 0] / count
     var = (st[:, 1] / count - m * m).clamp_min(0.0)

@@ -266,3 +266,80 @@ def test_widths_in_odd_multiples_of_16(emu, widths):
     loss.backward()
     for k, p in model.named_parameters():
         assert (p.grad - ref_grads[k]).abs().max() <= 1e-8 * max(ref_grads[k].abs().max().item(), 1e-9), k
+
+
+def test_sisdr_batches_beyond_one_launch(emu, monkeypatch):
+    """criterion/sdr.py cuts batches above the kernels' 65 535-row limit into slices (the limit is lowered here so that the CPU tier sees it)"""
+    import criterion.sdr as S
+    monkeypatch.setattr(S, "_MAX_ROWS", 3)
+    g = torch.Generator().manual_seed(2)
+    est = torch.randn(8, 2, 50, generator=g, dtype=torch.float64, requires_grad=True)
+    tgt = torch.randn(8, 2, 50, generator=g, dtype=torch.float64)
+    out = S.sisdr(est, tgt)
+    a = (est * tgt).sum(-1, keepdim=True) / ((tgt ** 2).sum(-1, keepdim=True) + S.EPS)
+    ref = 10 * torch.log10((((a * tgt) ** 2).sum(-1) + S.EPS) / (((a * tgt - est) ** 2).sum(-1) + S.EPS))
+    assert torch.allclose(out, ref.detach(), rtol=1e-10)
+    gout = torch.randn(8, 2, generator=g, dtype=torch.float64)
+    (g1,) = torch.autograd.grad((out * gout).sum(), est)
+    (g2,) = torch.autograd.grad((ref * gout).sum(), est)
+    assert torch.allclose(g1, g2, rtol=1e-8, atol=1e-12)
+
+
+def test_frozen_parameters_are_left_alone_by_the_fused_step(golden_dir, emu):
+    """FusedTrainStep with requires_grad = False on some parameters: they take no part in the gradient norm and neither Adam nor its
+    weight decay moves them; everything else steps exactly as with all parameters trainable and the frozen gradients forced to zero."""
+    from sepkernels.train import FusedTrainStep
+    name = "tiny"
+    g = np.load(os.path.join(golden_dir, "convtasnet_{}.npz".format(name)))
+    mixture, sources = torch.from_numpy(g["mixture"]).double(), torch.from_numpy(g["sources"]).double()
+
+    def make():
+        m = ConvTasNet(**CONFIGS[name])
+        m.load_state_dict({k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param/")})
+        return m.double()
+    frozen = ("encoder.conv1d.weight", "separator.norm1d.norm.bias")
+    model = make()
+    for k, p in model.named_parameters():
+        if k in frozen:
+            p.requires_grad_(False)
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
+    step = FusedTrainStep(model, PIT1d(NegSISDR(), n_sources=2), lr=1e-2, weight_decay=0.1, max_norm=5.0, distributed=False)
+    step(mixture, sources)
+    step(mixture, sources)
+    moved = {k: (p.detach() - before[k]).abs().max().item() for k, p in model.named_parameters()}
+    assert all(moved[k] == 0.0 for k in frozen), moved
+    assert all(v > 0 for k, v in moved.items() if k not in frozen)
+    # the trainable ones: same as an all-trainable model whose frozen gradients never count (torch.optim.Adam on the reference flow)
+    ref = make()
+    params = [p for k, p in ref.named_parameters() if k not in frozen]
+    opt = torch.optim.Adam(params, lr=1e-2, weight_decay=0.1)
+    for _ in range(2):
+        opt.zero_grad()
+        loss, _ = PIT1d(NegSISDR(), n_sources=2)(ref(mixture), sources)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 5.0)
+        opt.step()
+    for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        if k not in frozen:
+            assert (p - q).abs().max() <= 1e-9 * max(q.abs().max().item(), 1e-6), k
+
+
+def test_checkpoints_load_through_the_safe_unpickler(tmp_path):
+    """utils/checkpoint.py: a package in the reference's format loads with weights_only=True; a file that needs arbitrary objects is refused
+    unless the caller vouches for it"""
+    from utils.checkpoint import load_checkpoint
+    m = ConvTasNet(**CONFIGS["tiny"])
+    pkg = m.get_config()
+    pkg["state_dict"] = m.state_dict()
+    pkg["train_loss"] = torch.zeros(3)
+    path = str(tmp_path / "ok.pth")
+    torch.save(pkg, path)
+    m2 = ConvTasNet.build_model(path, load_state_dict=True)
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+
+    import fractions
+    bad = str(tmp_path / "odd.pth")
+    torch.save({"thing": fractions.Fraction(1, 3)}, bad)          # an object outside the safe unpickler's allow-list
+    with pytest.raises(RuntimeError):
+        load_checkpoint(bad)
+    assert load_checkpoint(bad, trust_pickle=True)["thing"] == fractions.Fraction(1, 3)

@@ -188,3 +188,17 @@ def test_layer_norms_split_batches_beyond_one_launch(emu, monkeypatch):
     whole = cln(xf)
     monkeypatch.setattr(norm, "GRID_ROWS", 4)
     assert torch.equal(whole, cln(xf))
+
+
+@pytest.mark.parametrize("name", ["dptnet", "sepformer", "galrnet"])
+def test_gradient_with_respect_to_the_mixture(golden_dir, emu, name):
+    """A mixture that itself requires a gradient (the reference supports it): the kernel path's encoder does not differentiate with respect
+    to its input, so such calls take the composition -- and give the same estimate and the input gradient of the composed model."""
+    g, _, model = _build(golden_dir, name)
+    mixture = torch.from_numpy(g["mixture"]).double().requires_grad_(True)
+    est = model(mixture)
+    est.square().sum().backward()
+    assert mixture.grad is not None and torch.isfinite(mixture.grad).all() and mixture.grad.abs().max() > 0
+    with torch.no_grad():
+        est_k = model(mixture.detach())              # the kernel path (through the emulator) on the same input
+    assert (est_k - est.detach()).abs().max() <= 1e-9 * est.detach().abs().max()

@@ -19,7 +19,7 @@ g1, b1, g2 = f(C), f(C), f(C)
 a1, a2 = torch.tensor([0.25], device=dev), torch.tensor([0.1], device=dev)
 wd, bd = f(C, 1, 3), f(C)
 st1, st2 = st(), st()
-bsum2, bacc1, arrive1, bsum1 = f(B, 2) * 0.01, st(), torch.zeros(B, device=dev, dtype=torch.int32), f(B, 2)
+bsum2, bacc1, arrive1, bsum1 = f(B, 2) * 0.01, st(), torch.zeros(B, 17, device=dev, dtype=torch.int32), f(B, 2)
 rp = torch.empty(B, C, (ldt + 1023) // 1024, 8, device=dev)
 
 
