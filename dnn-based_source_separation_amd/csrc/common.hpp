@@ -99,8 +99,7 @@ __device__ __forceinline__ void gln_mu_rstd(const double* st, double count, floa
 // step on the critical path).  Now the PRODUCER finishes them: every workgroup adds its gamma-weighted row-sum totals
 //     acc[slot] += { sum_c gamma_c sum_t g , sum_c gamma_c sum_t g u }                  (fp64 atomics, SEP_STATS_SLOTS slots like the statistics)
 // and arrives at the sample's counters; the LAST arrival turns the slots into the two means and stores them where the consumer's
-// prologue reads two floats (as it always did).  ONE thread per workgroup calls this, behind a barrier that follows the workgroup's
-// atomics.  Both sums are linear in the row sums, so they need neither mu nor rstd while they are accumulated.
+// prologue reads two floats (as it always did).  ONE thread per workgroup calls this with the workgroup's two totals.  Both sums are linear in the row sums, so they need neither mu nor rstd while they are accumulated.
 // First form of this round: the CONSUMERS summed the slots -- 64 fp64 loads and an fp64 divide / sqrt in every workgroup of the
 // depthwise backward (+8 us per launch) and spilled registers in the GEMM kernels.
 // Arrival counters: SEP_STATS_SLOTS + 1 ints per sample.  A workgroup arrives at ITS SLOT's counter; the last of that slot's
@@ -108,12 +107,16 @@ __device__ __forceinline__ void gln_mu_rstd(const double* st, double count, floa
 // Two levels because a returning atomic on ONE address costs about a microsecond and they serialise: 512 workgroups per sample on one
 // counter made the depthwise backward take 504 us instead of 95 (profiles/r03e_kernel_stats.md); 32 per address disappear in its run time.
 static_assert(SEP_ARRIVE_INTS == SEP_STATS_SLOTS + 1, "arrival counters");
-__device__ __forceinline__ void gln_bwd_publish(const double* acc, const double* st, int* counters, float* means, int slot, int expected_in_slot,
-                                                int nslots, double count, float eps) {
-    __threadfence();                                   // this workgroup's atomics are performed before its arrival is
+// No fences: every access that has to be seen by another compute unit here is an agent-scope ATOMIC (performed at the level the XCDs
+// share), and the thread waits for the values its own adds return before it arrives, so its sums are in place when its arrival is counted.
+// A __threadfence() instead writes back / invalidates the whole L2 of the XCD on this part -- in a kernel streaming 134 MB through that
+// L2 it took the depthwise backward from 95 to 504 us (profiles/r03e_kernel_stats.md, r03f_kernel_stats.md).
+__device__ __forceinline__ void gln_bwd_publish(double* acc, const double* st, int* counters, float* means, int slot, int expected_in_slot,
+                                                int nslots, double a1, double a2, double count, float eps) {
+    const double o1 = atomicAdd(acc + 2 * slot, a1), o2 = atomicAdd(acc + 2 * slot + 1, a2);      // returning forms: waited for below
+    asm volatile("" :: "v"(o1), "v"(o2));
     if (atomicAdd(counters + slot, 1) != expected_in_slot - 1) return;
     if (atomicAdd(counters + SEP_STATS_SLOTS, 1) != nslots - 1) return;
-    __threadfence();
     double s1 = 0.0, s2 = 0.0, m, r;
 #pragma unroll
     for (int k = 0; k < SEP_STATS_SLOTS; ++k) {        // coherent loads: the slots were written by atomics of other compute units

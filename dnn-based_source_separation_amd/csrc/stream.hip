@@ -383,9 +383,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(
         float* rp = rowpart + (((size_t)b * C + c) * ntile + tile) * 8;
         rp[0] = q0; rp[1] = q1; rp[2] = q2; rp[3] = q3; rp[4] = q4; rp[5] = q5; rp[6] = q_dal; rp[7] = 0.f;
         if (bacc1) {        // gLN1's gamma-weighted totals; the sample's last (channel, tile) publishes the two means (gln_bwd_publish)
-            double* ba = bacc1 + ((size_t)b * SEP_STATS_SLOTS + (g & (SEP_STATS_SLOTS - 1))) * 2;
             const float g1 = gamma1[c];
-            atomicAdd(ba, (double)(g1 * q0)); atomicAdd(ba + 1, (double)(g1 * q1));
             const int slot = (int)(g & (SEP_STATS_SLOTS - 1));
             // slots are taken by the global unit number g; a sample's units are C * ntile consecutive numbers starting at b * C * ntile
             const long first = (long)b * C * ntile, nun = (long)C * ntile;
@@ -397,7 +395,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(
                 if (q == slot) in_slot = cnt_q;
             }
             gln_bwd_publish(bacc1 + (size_t)b * SEP_STATS_SLOTS * 2, stats1 + (size_t)b * SEP_STATS_SLOTS * 2, arrive1 + (size_t)b * SEP_ARRIVE_INTS,
-                            bsum1 + 2 * b, slot, in_slot, used, (double)C * T, eps);
+                            bsum1 + 2 * b, slot, in_slot, used, (double)(g1 * q0), (double)(g1 * q1), (double)C * T, eps);
         }
     }
 }
@@ -528,9 +526,6 @@ __global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
         rp[i] = i < 8 ? (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]) : 0.f;
     if (bacc1 && threadIdx.x == 0) {     // gLN1's gamma-weighted totals; the sample's last row publishes the two means (gln_bwd_publish)
         const float g1c = gamma1[c];
-        double* ba = bacc1 + ((size_t)b * SEP_STATS_SLOTS + (row & (SEP_STATS_SLOTS - 1))) * 2;
-        atomicAdd(ba, (double)(g1c * ((part[0][0] + part[1][0]) + (part[2][0] + part[3][0]))));
-        atomicAdd(ba + 1, (double)(g1c * ((part[0][1] + part[1][1]) + (part[2][1] + part[3][1]))));
         // slots are taken by the global row number; a sample's rows are C consecutive numbers starting at b * C
         const int slot = row & (SEP_STATS_SLOTS - 1), first = b * C;
         int in_slot = 0, used = 0;
@@ -541,7 +536,8 @@ __global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
             if (q == slot) in_slot = cnt_q;
         }
         gln_bwd_publish(bacc1 + (size_t)b * SEP_STATS_SLOTS * 2, stats1 + (size_t)b * SEP_STATS_SLOTS * 2, arrive1 + (size_t)b * SEP_ARRIVE_INTS, bsum1 + 2 * b,
-                        slot, in_slot, used, (double)C * T, eps);
+                        slot, in_slot, used, (double)(g1c * ((part[0][0] + part[1][0]) + (part[2][0] + part[3][0]))),
+                        (double)(g1c * ((part[0][1] + part[1][1]) + (part[2][1] + part[3][1]))), (double)C * T, eps);
     }
 }
 
@@ -694,17 +690,12 @@ __global__ __launch_bounds__(1024) void gln_bwd_from_wgrad_kernel(const float* _
         float a = gm * R;                                  // lanes 0-31: gamma R1 ; lanes 32-63: gamma R2
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);      // sums inside each 32-lane half
-        if (col == 0) {
-            double* ba = bacc + ((size_t)b * SEP_STATS_SLOTS + (blockIdx.x & (SEP_STATS_SLOTS - 1))) * 2;
-            atomicAdd(ba + q, (double)a);
-            __threadfence();                               // performed before the barrier the publishing thread waits at
+        const float a2 = __shfl(a, 32, 64);
+        if (threadIdx.x == 0) {      // gridDim.x workgroups per sample and product, numbered blockIdx.x: slot blockIdx.x & 15
+            const int slot = blockIdx.x & (SEP_STATS_SLOTS - 1);
+            gln_bwd_publish(bacc + (size_t)b * SEP_STATS_SLOTS * 2, stats + (size_t)b * SEP_STATS_SLOTS * 2, arrive + (size_t)b * SEP_ARRIVE_INTS, bsum + 2 * b,
+                            slot, arrivals_in_slot((int)gridDim.x, slot) * products, slots_in_use((int)gridDim.x), (double)a, (double)a2, count, eps);
         }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {      // gridDim.x workgroups per sample and product, numbered blockIdx.x: slot blockIdx.x & 15
-        const int slot = blockIdx.x & (SEP_STATS_SLOTS - 1);
-        gln_bwd_publish(bacc + (size_t)b * SEP_STATS_SLOTS * 2, stats + (size_t)b * SEP_STATS_SLOTS * 2, arrive + (size_t)b * SEP_ARRIVE_INTS, bsum + 2 * b,
-                        slot, arrivals_in_slot((int)gridDim.x, slot) * products, slots_in_use((int)gridDim.x), count, eps);
     }
 }
 

@@ -84,6 +84,7 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc_kernel(const sep_wgrad_des
     constexpr int PG = TM / 64, PX = TN / 64;             // DMA pieces (16 rows x 64 B) per producer wave and chunk
     constexpr int G = PG + PX;
     constexpr int KEEP = (NS - 2) * G;
+    constexpr bool PAIRS = NS == 4;                       // raw ring of four chunks, refilled two at a time (see the producer loop)
     static_assert(sizeof(Smem) <= 160 * 1024, "LDS");
     __shared__ Smem sm;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -224,10 +225,25 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc_kernel(const sep_wgrad_des
             WSTAMP(1, 2);
 #endif
             // raw chunk j+1 has landed -- mine: all but the newer chunks; everyone's: the barrier -- and the operands of chunk j are written
-            if (KEEP > 0 && j + NS <= nk) wp_wait_barrier<KEEP>();
-            else wp_wait_barrier<0>();                                           // B_j
-            WSTAMP(1, 3);
-            if (ci < nk) issue();                                                // chunk j+NS into the stage B_j freed
+            if (PAIRS) {
+                // Chunks are fetched in PAIRS (behind the odd barriers: chunks j+3, j+4 into the stages of j-1, j): the two 64-byte pieces a
+                // chunk pair takes of every 128-byte line are then requested back to back and the L2 fetches the line ONCE.  Issued one chunk
+                // (~1 us) apart, the second piece found its line evicted again -- rows of the (B, C, ldt = 4096) activations are 16 KiB apart,
+                // a few L2 sets for a tile's 384 rows: measured 1.9x the algorithmic bytes (331 MB for 173, rocprofv3 TCC_EA0_RDREQ; with a row
+                // stride of 4224 floats the same kernel read 178; profiles/r03f_wgrad_fetch.txt).
+                if (j & 1) { if (j + 3 <= nk) wp_wait_barrier<G>(); else wp_wait_barrier<0>(); }          // newer: chunk j+2
+                else { if (j + 4 <= nk) wp_wait_barrier<2 * G>(); else wp_wait_barrier<0>(); }            // newer: chunks j+2, j+3
+                WSTAMP(1, 3);
+                if (j & 1) {
+                    if (ci < nk) issue();
+                    if (ci < nk) issue();
+                }
+            } else {
+                if (KEEP > 0 && j + NS <= nk) wp_wait_barrier<KEEP>();
+                else wp_wait_barrier<0>();                                       // B_j
+                WSTAMP(1, 3);
+                if (ci < nk) issue();                                            // chunk j+NS into the stage B_j freed
+            }
             WSTAMP(1, 4);
             stage = stage + 1 == NS ? 0 : stage + 1;
         }
@@ -397,8 +413,9 @@ template <int WR, int WC, int XMODE>
 void launch_wpc(const sep_wgrad_desc& d, hipStream_t stream) {
     const int ntiles = (d.M / (64 * WR)) * (d.N / (128 * WC));
     const int grid = 8 * ntiles * ceil_div(d.nsplit, 8);
-    // raw-ring depth NS: a DMA has NS - 1 chunk periods to land (SEPK_WPC_NS = 2 | 3 | 4 for A/B runs)
-    static const int ns = getenv("SEPK_WPC_NS") ? atoi(getenv("SEPK_WPC_NS")) : 2;
+    // raw-ring depth NS (SEPK_WPC_NS = 2 | 3 | 4 for A/B runs): 4 = chunks fetched in pairs (one HBM fetch per 128-byte line), 2 / 3 = one
+    // chunk per barrier, a DMA has NS - 1 chunk periods to land
+    static const int ns = getenv("SEPK_WPC_NS") ? atoi(getenv("SEPK_WPC_NS")) : 4;
     if (ns == 4) hipLaunchKernelGGL((pw_wgrad_pc_kernel<WR, WC, XMODE, 4>), dim3(grid), dim3(512), 0, stream, d);
     else if (ns == 3) hipLaunchKernelGGL((pw_wgrad_pc_kernel<WR, WC, XMODE, 3>), dim3(grid), dim3(512), 0, stream, d);
     else hipLaunchKernelGGL((pw_wgrad_pc_kernel<WR, WC, XMODE, 2>), dim3(grid), dim3(512), 0, stream, d);

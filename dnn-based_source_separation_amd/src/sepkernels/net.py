@@ -357,7 +357,8 @@ def _forward(cfg, P, mixture, want_latent, save):
             xo = None
             K.pw_gemm(B=B, M=Sc, K=H, T=F, ldt=ldt, A=Ws, A_pk=PK.get("skip.{}".format(li)), X=z, Y=skip, bias=bs,
                       accumulate=int(li > 0), **pro)
-        acts.append((x, a, z))
+        if save:
+            acts.append((x, a, z))          # inference (torch.no_grad()): nothing is kept, a / z go back to the allocator layer by layer
         x = xo
 
     est, latent, m = tail_forward(cfg, P, geo, w, skip, mixture.shape, want_latent, PK)

@@ -26,7 +26,7 @@ import sepkernels
 
 class FusedTrainStep:
     def __init__(self, model, criterion, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=5.0,
-                 process_group=None, distributed=None):
+                 process_group=None, distributed=None, uneven_batches=False, time_collectives=False):
         self.model, self.criterion = model, criterion
         self.lr, self.betas, self.eps, self.weight_decay, self.max_norm = lr, betas, eps, weight_decay, max_norm
         self.group = process_group
@@ -44,6 +44,15 @@ class FusedTrainStep:
         self.sqnorm = torch.zeros(1, device=flat.device, dtype=torch.float64)
         self.step_count = 0
         self.bucketed = os.environ.get("SEPK_DDP_BUCKETS", "1") != "0"
+        # uneven_batches: ranks may hold DIFFERENT numbers of utterances in a step (a last batch that does not divide; the reference's
+        # nn.DataParallel scatters such a batch unevenly and still takes the mean over all of it).  Each rank then back-propagates the SUM
+        # over its utterances, the utterance counts are summed across ranks by a 1-element all-reduce hidden under the forward pass, and
+        # the reduced gradient is divided by the global count.  Off by default: the recipes shard equally and drop the tail.
+        self.uneven = bool(uneven_batches)
+        # time_collectives: HIP events around the waits on the gradient all-reduces -> last_comm (bench.py's `ranks` block)
+        self.time_collectives = bool(time_collectives)
+        self.last_comm = None
+        self.last_bucket_bytes = []
         # graph state (see capture())
         self._graph = None
         self._static = None
@@ -64,6 +73,13 @@ class FusedTrainStep:
                     mask[off:off + n] = 1.0
             self._mask, self._mask_key = mask, key
         return self._mask
+
+    def exposed_comm_ms(self):
+        """milliseconds the compute stream waited for the last step's gradient exchange (time_collectives=True; synchronises)"""
+        if self.last_comm is None:
+            return None
+        self.last_comm[1].synchronize()
+        return self.last_comm[0].elapsed_time(self.last_comm[1])
 
     def zero_grad(self):
         for p in self.model.parameters():
@@ -134,26 +150,44 @@ class FusedTrainStep:
         self.zero_grad()
         model._grad_sink = self.gflat                 # backward writes every gradient straight into the flat buffer
         works = []
+        self.last_bucket_bytes = []
+        count_work = None
+        if self.world > 1 and self.uneven:
+            count = torch.tensor([float(mixture.shape[0])], device=self.gflat.device, dtype=torch.float32)
+            count_work = (dist.all_reduce(count, op=dist.ReduceOp.SUM, group=self.group, async_op=True), count)
         if self.world > 1 and self.bucketed:
             # one asynchronous RCCL all-reduce per TCN block, issued as soon as the block's gradients are final, so the
             # exchange of the late layers travels under the differentiation of the early ones (3 buckets at paper-best)
             def bucket_ready(lo, hi):
+                self.last_bucket_bytes.append(4 * (hi - lo))
                 works.append(dist.all_reduce(self.gflat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             model._grad_bucket_hook = bucket_ready
         try:
             est = model(mixture)
             loss, _ = self.criterion(est, sources)
-            loss.backward()
+            (loss * float(mixture.shape[0]) if count_work is not None else loss).backward()
         finally:
             model._grad_sink = None
             model._grad_bucket_hook = None
         self.last_buckets = len(works)
+        grad_scale = 1.0 / self.world
         if self.world > 1:
+            timed = self.time_collectives and self.gflat.is_cuda
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             if works:
                 for w in works:
                     w.wait()
             else:
+                self.last_bucket_bytes = [4 * self.gflat.numel()]
                 dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM, group=self.group)
+            if timed:
+                e1.record()
+                self.last_comm = (e0, e1)         # elapsed = what the compute stream had to wait for the exchange (nothing else lies between)
+            if count_work is not None:
+                count_work[0].wait()
+                grad_scale = 1.0 / float(count_work[1].item())
         n = self.gflat.numel()
         mask = self._trainable_mask()
         frozen = None
@@ -165,13 +199,13 @@ class FusedTrainStep:
             K.sqnorm(self.gflat, self.sqnorm, n)
         if graph:
             K.adam_step_dev(self.flat, self.gflat, self.m, self.v, self.sqnorm, n, self._lr_dev, self._step_dev, self.betas[0], self.betas[1],
-                            self.eps, self.weight_decay, float(self.max_norm or 0.0), 1.0 / self.world)
+                            self.eps, self.weight_decay, float(self.max_norm or 0.0), grad_scale)
         else:
             self.step_count += 1
             if self._step_dev is not None:
                 self._step_dev.fill_(self.step_count)          # an eager step between replays (other shapes) keeps the device count in step
             K.adam_step(self.flat, self.gflat, self.m, self.v, self.sqnorm, n, self.lr, self.betas[0], self.betas[1], self.eps,
-                        self.weight_decay, float(self.max_norm or 0.0), 1.0 / self.world, self.step_count)
+                        self.weight_decay, float(self.max_norm or 0.0), grad_scale, self.step_count)
         if frozen is not None:
             self.flat.mul_(mask).add_(frozen)
             self.m.mul_(mask)

@@ -150,3 +150,90 @@ def test_dual_path_separator_under_distributed_data_parallel(tmp_path):
     assert torch.allclose(flat, r0["flat"], rtol=0, atol=1e-9), (flat - r0["flat"]).abs().max()
     for k in range(2):                                              # global mean loss == mean of the two rank means
         assert abs(0.5 * (r0["losses"][k] + r1["losses"][k]) - losses[k]) < 1e-9
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Uneven shards: the last batch of an epoch need not divide by the world size (the reference's nn.DataParallel scatters it unevenly
+# and still averages over all of it).  FusedTrainStep(uneven_batches=True) weighs every rank by its utterance count.
+def _uneven_worker(rank, world, port, out_dir):
+    _setup_paths()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    import sepkernels
+    from emulator import EmuBackend
+    from sepkernels.train import FusedTrainStep
+    from models.conv_tasnet import ConvTasNet
+    from criterion.sdr import NegSISDR
+    from criterion.pit import PIT1d
+    sepkernels._set_backend_for_tests(EmuBackend())
+    mixture, sources = _data()
+    sl = slice(0, 3) if rank == 0 else slice(3, 4)                 # 3 utterances here, 1 there
+    torch.manual_seed(111)
+    model = ConvTasNet(**CFG)
+    step = FusedTrainStep(model, PIT1d(NegSISDR(), n_sources=2), lr=1e-3, max_norm=5.0, distributed=True, uneven_batches=True)
+    for _ in range(2):
+        step(mixture[sl], sources[sl])
+    torch.save({"flat": model.flat_parameters().clone(), "bucket_bytes": list(step.last_bucket_bytes)}, os.path.join(out_dir, "un_rank{}.pt".format(rank)))
+    dist.destroy_process_group()
+
+
+def test_uneven_shards_equal_the_global_batch(tmp_path):
+    _setup_paths()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_uneven_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "un_rank0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "un_rank1.pt"))
+    assert torch.equal(r0["flat"], r1["flat"])
+    assert len(r0["bucket_bytes"]) == 3 and sum(r0["bucket_bytes"]) == 4 * r0["flat"].numel()      # three buckets, every gradient once
+    import sepkernels
+    old = sepkernels.backend()
+    try:
+        mixture, sources = _data()
+        flat, _ = _run_steps(mixture, sources, 2, False)           # single process, all four utterances: the true global mean
+    finally:
+        sepkernels._set_backend_for_tests(old)
+    assert (r0["flat"] - flat).abs().max() <= 2e-5 * flat.abs().max()
+
+
+# A rank that raises in the middle of a step must bring the job DOWN, not leave its peers waiting in an all-reduce: the failing process
+# exits non-zero without touching another collective, and the launcher (torch.multiprocessing.spawn here, torchrun in the recipes) ends
+# the others.  What is checked: the job fails within seconds instead of hanging until the collective's time-out.
+def _failing_worker(rank, world, port):
+    _setup_paths()
+    import datetime
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+    torch.set_num_threads(2)
+    import sepkernels
+    from emulator import EmuBackend
+    from sepkernels.train import FusedTrainStep
+    from models.conv_tasnet import ConvTasNet
+    from criterion.sdr import NegSISDR
+    from criterion.pit import PIT1d
+    sepkernels._set_backend_for_tests(EmuBackend())
+    mixture, sources = _data()
+    torch.manual_seed(111)
+    model = ConvTasNet(**CFG)
+    step = FusedTrainStep(model, PIT1d(NegSISDR(), n_sources=2), lr=1e-3, max_norm=5.0, distributed=True)
+    sl = slice(2 * rank, 2 * rank + 2)
+    step(mixture[sl], sources[sl])
+    if rank == 1:
+        raise RuntimeError("rank 1 fails in its second step (e.g. a corrupt utterance)")
+    step(mixture[sl], sources[sl])                                  # rank 0 is inside the gradient exchange when its peer dies
+
+
+def test_a_failing_rank_ends_the_job_instead_of_hanging_it():
+    import time
+    import pytest
+    _setup_paths()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    t0 = time.time()
+    with pytest.raises(Exception) as err:
+        mp.spawn(_failing_worker, args=(2, port), nprocs=2, join=True)
+    assert "rank 1 fails" in str(err.value)
+    assert time.time() - t0 < 300, "the surviving rank was left waiting in its all-reduce"

@@ -369,3 +369,70 @@ def test_reference_recipe_test_py_runs_end_to_end(tmp_path, recipe_name):
     rows = [l for l in r.stdout.splitlines() if l.startswith("utt0")]
     assert len(rows) == 2 and all(len(l.split(", ")) == 7 for l in rows)          # ID, loss, improvement, SDRi, SIRi, SAR, PESQ per utterance
     assert os.path.exists(os.path.join(out, "test", "utt00.wav")) and os.path.exists(os.path.join(out, "test", "utt00_1-estimated.wav"))
+
+
+_REFERENCE_CHECKPOINT_WRITER = r"""
+import sys, types, torch
+sys.modules.setdefault("torchaudio", types.ModuleType("torchaudio"))
+sys.path.insert(0, sys.argv[1])
+from models.conv_tasnet import ConvTasNet
+torch.manual_seed(3)
+model = ConvTasNet(512, 16, stride=8, enc_basis="trainable", dec_basis="trainable", enc_nonlinear=None, sep_hidden_channels=512,
+                   sep_bottleneck_channels=128, sep_skip_channels=128, sep_kernel_size=3, sep_num_blocks=3, sep_num_layers=8, dilated=True,
+                   separable=True, causal=False, sep_nonlinear="prelu", sep_norm=True, mask_nonlinear="sigmoid", n_sources=2)
+with torch.no_grad():
+    for p in model.parameters():                      # away from the default initialisation: gains, shifts and slopes matter
+        p.add_(0.02 * torch.randn_like(p))
+opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+x = 0.1 * torch.randn(1, 1, 4003)
+model(x).square().mean().backward()
+opt.step()
+# what driver.TrainerBase.save_model writes (egs/wsj0-mix/common/src/driver.py:208-226), field by field
+config = model.get_config()
+config["state_dict"] = model.state_dict()
+config["optim_dict"] = opt.state_dict()
+config["best_loss"] = float("infinity")
+config["no_improvement"] = 0
+config["train_loss"] = torch.zeros(5)
+config["valid_loss"] = torch.zeros(5)
+config["epoch"] = 1
+torch.save(config, sys.argv[2])
+with torch.no_grad():
+    torch.save({"x": x, "y": model(x)}, sys.argv[3])
+"""
+
+
+def test_a_paper_best_checkpoint_written_by_the_reference_loads_and_separates_the_same(tmp_path):
+    """a model package written by the UNMODIFIED reference (its ConvTasNet at the paper-best configuration, its
+    optimizer, the fields of driver.save_model) is rebuilt by this tree's ConvTasNet.build_model -- through the safe unpickler -- and gives
+    the reference's own estimates on the same input (CPU tier: the C ABI behind the model is the emulator)."""
+    import torch
+    for q in (os.path.join(ROOT, "dnn-based_source_separation_amd", "src"), os.path.join(ROOT, "tests")):
+        if q not in sys.path:
+            sys.path.insert(0, q)
+    import sepkernels
+    from emulator import EmuBackend
+    ck, io = str(tmp_path / "best.pth"), str(tmp_path / "io.pth")
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    r = subprocess.run([sys.executable, "-c", _REFERENCE_CHECKPOINT_WRITER, os.path.join(REF, "src"), ck, io], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    from models.conv_tasnet import ConvTasNet
+    model = ConvTasNet.build_model(ck, load_state_dict=True)
+    assert model.fused and model.num_parameters == 4984881
+    ref = torch.load(io)
+    old = sepkernels._set_backend_for_tests(EmuBackend())
+    try:
+        with torch.no_grad():
+            y = model(ref["x"])
+    finally:
+        sepkernels._set_backend_for_tests(old)
+    assert y.shape == ref["y"].shape
+    assert (y - ref["y"]).abs().max() <= 1e-4 * ref["y"].abs().max()
+    # the optimizer state of the package resumes in the fused step (Adam moments keyed like torch.optim.Adam's state_dict)
+    from sepkernels.train import FusedTrainStep
+    from utils.checkpoint import load_checkpoint
+    from criterion.sdr import NegSISDR
+    from criterion.pit import PIT1d
+    step = FusedTrainStep(model, PIT1d(NegSISDR(), n_sources=2), distributed=False)
+    step.load_optim_state_dict(load_checkpoint(ck)["optim_dict"])
+    assert step.step_count == 1 and float(step.v.abs().sum()) > 0

@@ -37,6 +37,7 @@ cases = {
     "F4 mask        M1024 K128 PReLU-pro sigmoid": dict(M=ns * N, K=Sc, A=f(ns * N, Sc), X=xS, Y=z(B, ns * N, ldt), bias=f(ns * N), pro_mode=PRO_PRELU, pro_alpha=al, epi_flags=EPI_SIGMOID),
     "G4 mask dgrad  M128 K1024 T PReLU-bwd": dict(M=Sc, K=ns * N, trans_a=1, A=f(ns * N, Sc), X=xM, Y=z(B, Sc, ldt), epi_flags=EPI_PRELU_BWD, epi_aux=xS, epi_alpha=al, epi_dalpha=d64()),
     "G3 heads dgrad M512 K256 T rowsums": dict(M=H, K=Bn + Sc, trans_a=1, A=f(Bn, H), A2=f(Sc, H), X=xB, X2=xS, k_split=Bn, Y=z(B, H, ldt), epi_flags=EPI_ROWSUMS | EPI_ROWSUMS_PRELU, epi_aux=xH, epi_alpha=al, epi_rowpart=z(B, H, ldt // 64, 2)),
+    "G3p heads dgrad M512 K256 T plain": dict(M=H, K=Bn + Sc, trans_a=1, A=f(Bn, H), A2=f(Sc, H), X=xB, X2=xS, k_split=Bn, Y=z(B, H, ldt)),
     "G2 conv1 dgrad M128 K512 T gLN-bwd-pro res": dict(M=Bn, K=H, trans_a=1, A=f(H, Bn), X=f(B, H, ldt), Y=z(B, Bn, ldt), pro_mode=PRO_GLN_BWD, pro_stats=st(), pro_gamma=f(H), pro_alpha=al, pro_aux=xH, pro_bsum=f(B, 2) * 0.01, pro_store=z(B, H, ldt), pro_dalpha=d64(), count=H * T, epi_flags=EPI_RESIDUAL, epi_res=xB),
     "G1 bneck dgrad M512 K128 T rowsums": dict(M=N, K=Bn, trans_a=1, A=f(Bn, N), X=xB, Y=z(B, N, ldt), epi_flags=EPI_ROWSUMS, epi_aux=xN, epi_rowpart=z(B, N, ldt // 64, 2)),
     "P0 plain       M512 K512": dict(M=H, K=H, A=f(H, H), X=xH, Y=z(B, H, ldt)),
