@@ -127,6 +127,17 @@ __device__ __forceinline__ void gln_bwd_publish(double* acc, const double* st, i
     means[0] = (float)(s1 / count);
     means[1] = (float)(r * (s2 - m * s1) / count);
 }
+// Consumer-side form of the same means: from slots a producer only ADDED to (non-returning atomics, no arrival protocol).  For producers
+// with thousands of short workgroups -- the depthwise backward: 8192 per launch -- the two waited-for round trips of gln_bwd_publish at
+// the end of every workgroup cost more (+10 us per launch) than one thread of each consuming workgroup summing the 16 slots (+~1 us).
+__device__ __forceinline__ void gln_bwd_means(const double* acc, const double* st, double count, float eps, float& mg, float& mgx) {
+    double s1 = 0.0, s2 = 0.0, m, r;
+#pragma unroll
+    for (int k = 0; k < SEP_STATS_SLOTS; ++k) { s1 += acc[2 * k]; s2 += acc[2 * k + 1]; }
+    gln_mu_rstd_d(st, count, eps, m, r);
+    mg = (float)(s1 / count);
+    mgx = (float)(r * (s2 - m * s1) / count);
+}
 // arrivals a slot sees when `n` workgroups numbered 0 .. n-1 arrive at slot (number & (SEP_STATS_SLOTS - 1)), and how many slots see any
 __device__ __forceinline__ int arrivals_in_slot(int n, int slot) { return (n - slot + SEP_STATS_SLOTS - 1) / SEP_STATS_SLOTS; }
 __device__ __forceinline__ int slots_in_use(int n) { return n < SEP_STATS_SLOTS ? n : SEP_STATS_SLOTS; }

@@ -130,7 +130,10 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const sep_gemm_desc d) 
     const int pro = d.pro_mode;
     if (pro == SEP_PRO_GLN || pro == SEP_PRO_GLN_PRELU || pro == SEP_PRO_GLN_BWD) gln_mu_rstd(d.pro_stats + (size_t)b * SEP_STATS_SLOTS * 2, d.count, d.eps, mu, rstd);
     if (pro == SEP_PRO_PRELU || pro == SEP_PRO_GLN_PRELU || pro == SEP_PRO_GLN_BWD) alpha_p = d.pro_alpha[0];
-    if (pro == SEP_PRO_GLN_BWD) { mg = d.pro_bsum[2 * b]; mgx = d.pro_bsum[2 * b + 1]; }
+    if (pro == SEP_PRO_GLN_BWD) {
+        if (d.pro_bacc) gln_bwd_means(d.pro_bacc + (size_t)b * SEP_STATS_SLOTS * 2, d.pro_stats + (size_t)b * SEP_STATS_SLOTS * 2, d.count, d.eps, mg, mgx);
+        else { mg = d.pro_bsum[2 * b]; mgx = d.pro_bsum[2 * b + 1]; }
+    }
     float dalpha_pro = 0.f;
 
     // ---- thread -> staging coordinates -------------------------------------------------
@@ -396,7 +399,10 @@ __global__ __launch_bounds__(256, (AR >= 1 ? 3 : PRO == SEP_PRO_GLN_BWD ? 3 : PR
             }
         }
     }
-    if (P_BWD) { mg = d.pro_bsum[2 * b]; mgx = d.pro_bsum[2 * b + 1]; }
+    if (P_BWD) {
+        if (d.pro_bacc) gln_bwd_means(d.pro_bacc + (size_t)b * SEP_STATS_SLOTS * 2, d.pro_stats + (size_t)b * SEP_STATS_SLOTS * 2, d.count, d.eps, mg, mgx);
+        else { mg = d.pro_bsum[2 * b]; mgx = d.pro_bsum[2 * b + 1]; }
+    }
     float dalpha_pro = 0.f;
     const bool writer = P_BWD && wr == 0 && rt == 0;           // the waves that own the store-back / slope gradient
 
@@ -1555,7 +1561,7 @@ extern "C" int sep_pw_gemm(const sep_gemm_desc* d, sep_stream_t stream) {
     if (d->pro_mode >= SEP_PRO_GLN)
         SEP_REQUIRE(d->pro_stats && d->pro_gamma && (d->pro_mode == SEP_PRO_GLN_BWD || d->pro_beta) && d->count > 0, "sep_pw_gemm: gLN prologue needs stats/gamma/beta/count");
     if (d->pro_mode == SEP_PRO_GLN_BWD)
-        SEP_REQUIRE(d->pro_aux && d->pro_bsum && d->pro_store && d->pro_dalpha && !d->k_split, "sep_pw_gemm: GLN_BWD prologue needs aux/bsum/store/dalpha");
+        SEP_REQUIRE(d->pro_aux && (d->pro_bsum || d->pro_bacc) && d->pro_store && d->pro_dalpha && !d->k_split, "sep_pw_gemm: GLN_BWD prologue needs aux/bsum/store/dalpha");
     if (d->pro_mode == SEP_PRO_GLN_BWD)      // row tile 0 stores da while the other row tiles still read X: in place only with one row tile
         SEP_REQUIRE(d->pro_store != d->X || d->M <= BM, "sep_pw_gemm: pro_store may alias X only when M <= %d (one row tile)", BM);
     if (d->epi_flags & SEP_EPI_STATS_PRELU) SEP_REQUIRE(d->epi_stats && d->epi_alpha, "sep_pw_gemm: STATS_PRELU needs epi_stats/epi_alpha");

@@ -61,7 +61,7 @@ constexpr int coop_occupancy() {
     // registers, not LDS, bound the residency now: 64 accumulators + two operand sets (64) + the splitter's values need ~160 VGPRs
     // with two 32-row blocks per wave (3 waves per SIMD), ~120 with one (4)
     constexpr int by_lds = (int)((160 * 1024) / ((sizeof(CoopSmem<MI, NS, BWD>) + 511) / 512 * 512));
-    constexpr int by_regs = MI == 2 ? 3 : 4;
+    constexpr int by_regs = MI == 4 ? 2 : MI == 2 ? 3 : 4;
     return by_lds < by_regs ? by_lds : by_regs;
 }
 
@@ -151,7 +151,10 @@ void pw_gemm_coop_kernel(const sep_gemm_desc d) {
             }
         }
     }
-    if (P_BWD) { mg = d.pro_bsum[2 * b]; mgx = d.pro_bsum[2 * b + 1]; }
+    if (P_BWD) {
+        if (d.pro_bacc) gln_bwd_means(d.pro_bacc + (size_t)b * SEP_STATS_SLOTS * 2, d.pro_stats + (size_t)b * SEP_STATS_SLOTS * 2, d.count, d.eps, mg, mgx);
+        else { mg = d.pro_bsum[2 * b]; mgx = d.pro_bsum[2 * b + 1]; }
+    }
     float dalpha_pro = 0.f;
     // consume the loads NOW: the compiler does not count the asm LDS-DMAs below, so a wait it placed at a first use inside
     // the loop would be vmcnt(0) and drain the ring
@@ -486,6 +489,11 @@ int sep_pw_gemm_packed(const sep_gemm_desc* d, hipStream_t stream) {
     const bool sp = d->k_split != 0;
     const int mi = (force_mi == 1 || d->M % 256 != 0) ? 1 : 2;
     const int ns = env_ns == 2 || env_ns == 3 ? env_ns : 2;
+    // 128-row waves (a 512 x 64 workgroup tile: every value of X is split ONCE for 512 outputs instead of once per 256): the write-heavy
+    // short-contraction shapes with M % 512 == 0 -- TCN conv1, heads^T, skip^T (SEPK_COOP_MI=4 while it is being measured)
+    if (force_mi == 4 && d->M % 512 == 0 && !sp && pm == SEP_PRO_NONE && ef == SEP_EPI_STATS_PRELU) { launch_coop<4, SEP_PRO_NONE, false, SEP_EPI_STATS_PRELU>(*d, ns, stream); return 1; }
+    if (force_mi == 4 && d->M % 512 == 0 && sp && pm == SEP_PRO_NONE && ef == 0) { launch_coop<4, SEP_PRO_NONE, true, 0>(*d, ns, stream); return 1; }
+    if (force_mi == 4 && d->M % 512 == 0 && !sp && pm == SEP_PRO_NONE && ef == 0) { launch_coop<4, SEP_PRO_NONE, false, 0>(*d, ns, stream); return 1; }
 #define SEP_LC(P, S, E)                                              \
     do {                                                             \
         if (mi == 2) launch_coop<2, P, S, E>(*d, ns, stream);        \

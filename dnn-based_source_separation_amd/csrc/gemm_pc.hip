@@ -154,11 +154,25 @@ __global__ __launch_bounds__(512, 2) void pw_gemm_pc_kernel(const sep_gemm_desc 
             }
         }
     }
-    if (P_BWD) { mg = d.pro_bsum[2 * b]; mgx = d.pro_bsum[2 * b + 1]; }
+    // the two means of the gLN being back-propagated: published floats (pro_bsum), or formed here from the producer's slots (pro_bacc) by
+    // ONE thread and handed over through LDS -- in every thread that code cost the main loop spilled registers (the kernel sits at 256 VGPRs)
+    const bool from_slots = P_BWD && d.pro_bacc != nullptr;
+    if (P_BWD && !from_slots) { mg = d.pro_bsum[2 * b]; mgx = d.pro_bsum[2 * b + 1]; }
+    if (from_slots && tid == 64) {
+        float a, c;
+        gln_bwd_means(d.pro_bacc + (size_t)b * SEP_STATS_SLOTS * 2, d.pro_stats + (size_t)b * SEP_STATS_SLOTS * 2, d.count, d.eps, a, c);
+        float* hand = reinterpret_cast<float*>(sm.red);
+        hand[0] = a; hand[1] = c;
+    }
     if (tid < 4) { sm.ready[tid] = 0; sm.freed[tid] = 0; }
     float dalpha_pro = 0.f;
     asm volatile("" :: "v"(alpha_p), "v"(mu), "v"(rstd), "v"(mg), "v"(mgx));      // loads consumed before the first asm DMA
-    __syncthreads();                                     // tables and counters visible; no DMA in flight yet
+    __syncthreads();                                     // tables, counters and the two means visible; no DMA in flight yet
+    if (from_slots) {
+        const float* hand = reinterpret_cast<const float*>(sm.red);
+        mg = hand[0]; mgx = hand[1];
+        asm volatile("" :: "v"(mg), "v"(mgx));
+    }
 
     f32x16 acc[2][2][2];                                 // [column half][mi][ni]: the consumer's 64 x 128 tile (producers: unused)
 

@@ -394,8 +394,13 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(
                 used += cnt_q > 0;
                 if (q == slot) in_slot = cnt_q;
             }
-            gln_bwd_publish(bacc1 + (size_t)b * SEP_STATS_SLOTS * 2, stats1 + (size_t)b * SEP_STATS_SLOTS * 2, arrive1 + (size_t)b * SEP_ARRIVE_INTS,
-                            bsum1 + 2 * b, slot, in_slot, used, (double)(g1 * q0), (double)(g1 * q1), (double)C * T, eps);
+            if (arrive1)
+                gln_bwd_publish(bacc1 + (size_t)b * SEP_STATS_SLOTS * 2, stats1 + (size_t)b * SEP_STATS_SLOTS * 2, arrive1 + (size_t)b * SEP_ARRIVE_INTS,
+                                bsum1 + 2 * b, slot, in_slot, used, (double)(g1 * q0), (double)(g1 * q1), (double)C * T, eps);
+            else {      // sums only: the consumer forms the means (sep_gemm_desc.pro_bacc)
+                double* ba = bacc1 + ((size_t)b * SEP_STATS_SLOTS + slot) * 2;
+                atomicAdd(ba, (double)(g1 * q0)); atomicAdd(ba + 1, (double)(g1 * q1));
+            }
         }
     }
 }
@@ -535,9 +540,15 @@ __global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
             used += cnt_q > 0;
             if (q == slot) in_slot = cnt_q;
         }
-        gln_bwd_publish(bacc1 + (size_t)b * SEP_STATS_SLOTS * 2, stats1 + (size_t)b * SEP_STATS_SLOTS * 2, arrive1 + (size_t)b * SEP_ARRIVE_INTS, bsum1 + 2 * b,
-                        slot, in_slot, used, (double)(g1c * ((part[0][0] + part[1][0]) + (part[2][0] + part[3][0]))),
-                        (double)(g1c * ((part[0][1] + part[1][1]) + (part[2][1] + part[3][1]))), (double)C * T, eps);
+        const double t0_ = (double)(g1c * ((part[0][0] + part[1][0]) + (part[2][0] + part[3][0])));
+        const double t1_ = (double)(g1c * ((part[0][1] + part[1][1]) + (part[2][1] + part[3][1])));
+        if (arrive1)
+            gln_bwd_publish(bacc1 + (size_t)b * SEP_STATS_SLOTS * 2, stats1 + (size_t)b * SEP_STATS_SLOTS * 2, arrive1 + (size_t)b * SEP_ARRIVE_INTS, bsum1 + 2 * b,
+                            slot, in_slot, used, t0_, t1_, (double)C * T, eps);
+        else {          // sums only: the consumer forms the means (sep_gemm_desc.pro_bacc)
+            double* ba = bacc1 + ((size_t)b * SEP_STATS_SLOTS + slot) * 2;
+            atomicAdd(ba, t0_); atomicAdd(ba + 1, t1_);
+        }
     }
 }
 
@@ -1180,7 +1191,7 @@ extern "C" int sep_dwconv_bwd(const float* dv2, const float* z, const float* a, 
                               const float* alpha2, const float* bsum2, const float* wd, float* dv1, float* rowpart,
                               double* bacc1, int* arrive1, float* bsum1, int B, int C, int T, int ldt, int dilation, float eps, sep_stream_t stream) {
     SEP_REQUIRE(dv2 && z && a && stats1 && gamma1 && beta1 && alpha1 && stats2 && gamma2 && alpha2 && bsum2 && wd && dv1 && rowpart, "sep_dwconv_bwd: null pointer");
-    SEP_REQUIRE((bacc1 == nullptr) == (arrive1 == nullptr) && (bacc1 == nullptr) == (bsum1 == nullptr), "sep_dwconv_bwd: bacc1 / arrive1 / bsum1 come together");
+    SEP_REQUIRE((arrive1 == nullptr) == (bsum1 == nullptr) && (bacc1 != nullptr || arrive1 == nullptr), "sep_dwconv_bwd: arrive1 and bsum1 come together and need bacc1");
     SEP_REQUIRE(B > 0 && C > 0 && T > 0 && ldt % 128 == 0 && ldt >= T, "sep_dwconv_bwd: bad sizes");
     SEP_REQUIRE(dilation >= 1 && dilation <= 2048, "sep_dwconv_bwd: dilation %d out of range [1, 2048]", dilation);
     static const bool force_tiles = getenv("SEPK_DWCONV_LDS") != nullptr;

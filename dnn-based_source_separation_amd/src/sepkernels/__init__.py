@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("SEPKERNELS_LIB", os.path.normpath(os.path.join(_HERE,
 # ---- constants mirrored from include/sepkernels.h -------------------------------------------------
 PRO_NONE, PRO_PRELU, PRO_GLN, PRO_GLN_PRELU, PRO_GLN_BWD = 0, 1, 2, 3, 4
 EPI_STATS_PRELU, EPI_RESIDUAL, EPI_SIGMOID, EPI_PRELU_BWD, EPI_ROWSUMS, EPI_ROWSUMS_PRELU = 1, 2, 4, 8, 16, 32
-ABI_VERSION = 14
+ABI_VERSION = 15
 STATS_SLOTS = 16   # SEP_STATS_SLOTS: gLN statistics are double[B][STATS_SLOTS][2]
 ARRIVE_INTS = 17   # SEP_ARRIVE_INTS: arrival counters of the gLN-backward publishers, int[B][ARRIVE_INTS]
 ARITH_F32, ARITH_BF16X6, ARITH_F16X3 = 0, 1, 2     # SEP_ARITH_*: how sep_pw_gemm forms its fp32 products (include/sepkernels.h)
@@ -71,7 +71,7 @@ class GemmDesc(ctypes.Structure):
     _fields_ = [(n, _i32) for n in ("B", "M", "K", "T", "ldt", "trans_a", "k_split", "m_split", "pro_mode", "epi_flags",
                                     "accumulate", "arith")] + [("eps", ctypes.c_float), ("count", ctypes.c_double)] + \
                [(n, _vp) for n in ("A", "A2", "X", "X2", "Y", "Y2", "bias", "pro_alpha", "pro_stats", "pro_gamma", "pro_beta",
-                                   "pro_aux", "pro_bsum", "pro_store", "pro_dalpha", "epi_alpha", "epi_stats", "epi_res",
+                                   "pro_aux", "pro_bsum", "pro_bacc", "pro_store", "pro_dalpha", "epi_alpha", "epi_stats", "epi_res",
                                    "epi_aux", "epi_dalpha", "epi_rowpart", "a_amax", "A_pk", "a_rscale")]
 
 
@@ -207,7 +207,7 @@ class HipBackend:
 
     def pw_gemm(self, *, B, M, K, T, ldt, A, X, Y, trans_a=0, A2=None, X2=None, k_split=0, Y2=None, m_split=0,
                 pro_mode=PRO_NONE, epi_flags=0, accumulate=0, eps=1e-12, count=0.0, bias=None, pro_alpha=None,
-                pro_stats=None, pro_gamma=None, pro_beta=None, pro_aux=None, pro_bsum=None, pro_store=None,
+                pro_stats=None, pro_gamma=None, pro_beta=None, pro_aux=None, pro_bsum=None, pro_bacc=None, pro_store=None,
                 pro_dalpha=None, epi_alpha=None, epi_stats=None, epi_res=None, epi_aux=None, epi_dalpha=None,
                 epi_rowpart=None, arith=None, a_amax=None, A_pk=None):
         arith = gemm_arith() if arith is None else arith
@@ -223,7 +223,7 @@ class HipBackend:
                      A=_ptr(A, _f32), A2=_ptr(A2, _f32), X=_ptr(X, _f32), X2=_ptr(X2, _f32), Y=_ptr(Y, _f32), Y2=_ptr(Y2, _f32),
                      bias=_ptr(bias, _f32), pro_alpha=_ptr(pro_alpha, _f32), pro_stats=_ptr(pro_stats, _f64),
                      pro_gamma=_ptr(pro_gamma, _f32), pro_beta=_ptr(pro_beta, _f32), pro_aux=_ptr(pro_aux, _f32),
-                     pro_bsum=_ptr(pro_bsum, _f32), pro_store=_ptr(pro_store, _f32), pro_dalpha=_ptr(pro_dalpha, _f64),
+                     pro_bsum=_ptr(pro_bsum, _f32), pro_bacc=_ptr(pro_bacc, _f64), pro_store=_ptr(pro_store, _f32), pro_dalpha=_ptr(pro_dalpha, _f64),
                      epi_alpha=_ptr(epi_alpha, _f32), epi_stats=_ptr(epi_stats, _f64), epi_res=_ptr(epi_res, _f32),
                      epi_aux=_ptr(epi_aux, _f32), epi_dalpha=_ptr(epi_dalpha, _f64), epi_rowpart=_ptr(epi_rowpart, _f32),
                      a_amax=_ptr(a_amax, _f32), A_pk=_ptr(A_pk.data, _f32) if A_pk is not None else None,

@@ -474,7 +474,10 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
     # input gradient can be formed.  Inside the TCN layers the kernel that PRODUCES g's sums finishes them: its workgroups add their
     # gamma-weighted totals to fp64 slots (bacc, laid out like `stats`: [1 + 2 li] / [2 + 2 li] = gLN1 / gLN2 of layer li), count their
     # arrivals (arrive), and the sample's last one stores the two means (bsum) the consumer's prologue reads -- no second-stage launch in
-    # between (gln_bwd_publish, csrc/common.hpp).  sep_gln_bwd_finalize still turns gLN1's row partials into parameter gradients, as a leaf.
+    # between (gln_bwd_publish, csrc/common.hpp).  That is gLN2 (16 workgroups per sample in the sums kernel); for gLN1 the depthwise backward --
+    # thousands of short workgroups -- only adds to the slots and one thread per workgroup of the conv1^T product forms the means
+    # (pro_bacc): the arrival protocol cost that kernel +10 us per launch.  sep_gln_bwd_finalize still turns gLN1's row partials into
+    # parameter gradients, as a leaf.
     bacc = torch.zeros(2 * nl + 1, B, STATS_SLOTS, 2, device=dev, dtype=torch.float64)
     arrive = torch.zeros(2 * nl + 1, B, ARRIVE_INTS, device=dev, dtype=torch.int32)
     bsum = torch.empty(2 * nl + 1, B, 2, **f32)
@@ -559,7 +562,7 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
         dv1 = torch.empty(B, H, ldt, **f32)
         rp1 = torch.empty(B, H, nt1024, 8, **f32)
         K.dwconv_bwd(dv2, z, a, st1, g1, b1, al1, st2, g2, al2, bsum[2 + 2 * li], P[sp + "depthwise_conv1d.weight"], dv1, rp1,
-                     bacc[1 + 2 * li], arrive[1 + 2 * li], bsum[1 + 2 * li], B, H, F, ldt, dil, teps)
+                     bacc[1 + 2 * li], None, None, B, H, F, ldt, dil, teps)
         pbeta1 = torch.empty(B, H, **f32)
         pgamma1 = torch.empty(B, H, **f32)
         pextra = torch.empty(B * 4 * H + B + B * H, **f32)
@@ -579,7 +582,7 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
         # with several row tiles the other tiles still need the untouched dv1, so da goes to its own buffer
         da = dv1 if Bn <= 128 else torch.empty_like(dv1)
         K.pw_gemm(B=B, M=Bn, K=H, T=F, ldt=ldt, trans_a=1, A=P[pre + "bottleneck_conv1d.weight"], A_pk=PK.get("conv1.{}^T".format(li)),
-                  X=dv1, Y=dx, pro_mode=PRO_GLN_BWD, pro_stats=st1, pro_gamma=g1, pro_alpha=al1, pro_aux=a, pro_bsum=bsum[1 + 2 * li],
+                  X=dv1, Y=dx, pro_mode=PRO_GLN_BWD, pro_stats=st1, pro_gamma=g1, pro_alpha=al1, pro_aux=a, pro_bacc=bacc[1 + 2 * li],
                   pro_store=da, pro_dalpha=dalpha[li:li + 1], count=cnt, eps=teps,
                   epi_flags=(EPI_RESIDUAL if dout is not None else 0), epi_res=dout)
         # da and dx now exist: the side stream may go on (this layer's dW1, the next layer's head gradients)

@@ -33,7 +33,7 @@ extern "C" {
 
 typedef void* sep_stream_t; /* hipStream_t */
 
-#define SEP_ABI_VERSION 14
+#define SEP_ABI_VERSION 15
 #define SEP_STATS_SLOTS 16
 #define SEP_ARRIVE_INTS 17 /* arrival counters per sample: one per slot + one for the slots (csrc/common.hpp, gln_bwd_publish) */
 
@@ -108,6 +108,8 @@ typedef struct sep_gemm_desc {
     const float* pro_aux;
     const float* pro_bsum; /* GLN_BWD: [B][2] = mean(gamma g), mean(gamma g xhat) of the gLN being back-propagated (bsum1 of sep_dwconv_bwd,
                               bsum of sep_gln_bwd_from_wgrad / sep_gln_bwd_finalize) */
+    const double* pro_bacc; /* GLN_BWD, instead of pro_bsum: [B][SEP_STATS_SLOTS][2], the raw sums {sum_c gamma_c sum_t g, sum_c gamma_c sum_t g*u} a
+                               producer only added up (sep_dwconv_bwd's bacc1 without arrive1 / bsum1); the kernel forms the two means itself */
     float* pro_store;
     double* pro_dalpha;
     const float* epi_alpha;
@@ -211,7 +213,9 @@ int sep_dwconv_fwd(const float* a, const double* stats1, const float* gamma1, co
  * For gLN1 this kernel is the producer: bacc1 [B][SEP_STATS_SLOTS][2] (fp64, zeroed by the caller) receives its workgroups'
  * {sum_c gamma1_c sum_t dv1, sum_c gamma1_c sum_t dv1*u1}, arrive1 [B][SEP_ARRIVE_INTS] (int, zeroed) counts them, and the sample's LAST workgroup stores
  * bsum1 [B][2] = {mean(gamma1 dv1), mean(gamma1 dv1 xhat1)} for the consumer's prologue (sep_gemm_desc.pro_bsum) -- no second-stage launch
- * between the two (round 2: sep_gln_bwd_finalize, 98 launches per step on the critical path).  All three may be NULL together.
+ * between the two (round 2: sep_gln_bwd_finalize, 98 launches per step on the critical path).  arrive1 = bsum1 = NULL: the sums only (the
+ * consumer forms the means from them: sep_gemm_desc.pro_bacc -- what the Conv-TasNet step uses, this kernel has thousands of short
+ * workgroups and the arrival protocol's two waited-for round trips cost it 10 us per launch); all three NULL: none of it.
  * Writes dv1 and, per (b, c, 1024-frame tile), 8 partial row sums into rowpart[b][c][ntile][8]:
  *   {sum dv1, sum dv1*u1, sum dz, sum dz*v1[t-d], sum dz*v1[t], sum dz*v1[t+d], sum du2*z*[z<=0], 0}
  * (u1 = PReLU(a), v1 = gLN1(u1) inside [0,T) and 0 outside; ntile = ceil(ldt/1024)). */

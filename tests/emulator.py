@@ -80,7 +80,7 @@ class EmuBackend:
 
     def pw_gemm(self, *, B, M, K, T, ldt, A, X, Y, trans_a=0, A2=None, X2=None, k_split=0, Y2=None, m_split=0,
                 pro_mode=PRO_NONE, epi_flags=0, accumulate=0, eps=1e-12, count=0.0, bias=None, pro_alpha=None,
-                pro_stats=None, pro_gamma=None, pro_beta=None, pro_aux=None, pro_bsum=None, pro_store=None,
+                pro_stats=None, pro_gamma=None, pro_beta=None, pro_aux=None, pro_bsum=None, pro_bacc=None, pro_store=None,
                 pro_dalpha=None, epi_alpha=None, epi_stats=None, epi_res=None, epi_aux=None, epi_dalpha=None,
                 epi_rowpart=None, arith=None, a_amax=None, A_pk=None):
         dt = X.dtype
@@ -119,7 +119,13 @@ class EmuBackend:
             a = pro_aux.reshape(B, K, ldt)
             u = _prelu(a, pro_alpha)
             xh = (u - mu) * rstd
-            mg, mgx = pro_bsum[:, 0].view(B, 1, 1), pro_bsum[:, 1].view(B, 1, 1)
+            if pro_bacc is not None:        # gln_bwd_means: the kernel forms the two means from the producer's slots
+                st, ba = _tot(pro_stats), _tot(pro_bacc)
+                m64 = st[:, 0] / count
+                r64 = 1.0 / torch.sqrt((st[:, 1] / count - m64 * m64).clamp_min(0.0) + eps)
+                mg, mgx = (ba[:, 0] / count).to(dt).view(B, 1, 1), (r64 * (ba[:, 1] - m64 * ba[:, 0]) / count).to(dt).view(B, 1, 1)
+            else:
+                mg, mgx = pro_bsum[:, 0].view(B, 1, 1), pro_bsum[:, 1].view(B, 1, 1)
             du = rstd * (pro_gamma.view(1, K, 1) * Xf - mg - xh * mgx)
             da = torch.where(valid, du * _prelu_grad(a, pro_alpha), torch.zeros_like(du))
             pro_dalpha += torch.where(valid & (a <= 0), du * a, torch.zeros_like(du)).sum().double()
@@ -331,7 +337,8 @@ class EmuBackend:
         if bacc1 is not None:
             g1 = gamma1.view(1, C, 1).to(dt)
             _acc(bacc1, (g1 * dv).sum((1, 2)), (g1 * dv * u1).sum((1, 2)))
-            _publish(bacc1, stats1, arrive1, bsum1, 1, 1, cnt, eps)
+            if arrive1 is not None:
+                _publish(bacc1, stats1, arrive1, bsum1, 1, 1, cnt, eps)
 
     def gln_bwd_finalize(self, rowpart, ntile, nq, stats, gamma, count, eps, bsum, pbeta, pgamma, pextra, B, C):
         dt = rowpart.dtype

@@ -30,9 +30,9 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(lib, n), "{} declared in sepkernels.h but not exported".format(n)
         assert n in sepkernels.SIGNATURES, "{} has no ctypes signature".format(n)
     assert sorted(sepkernels.SIGNATURES) == names
-    assert lib.sep_version() == sepkernels.ABI_VERSION == 14
+    assert lib.sep_version() == sepkernels.ABI_VERSION == 15
     header = open(HEADER).read()
-    assert "#define SEP_ABI_VERSION 14" in header and "#define SEP_STATS_SLOTS 16" in header
+    assert "#define SEP_ABI_VERSION 15" in header and "#define SEP_STATS_SLOTS 16" in header
     assert sepkernels.STATS_SLOTS == 16
 
 
@@ -40,8 +40,8 @@ def test_descriptor_layouts_match_the_header():
     # both: 12 int32 + float (+4 pad), double at offset 56, then pointers: the layouts the header's field order implies on LP64
     assert sepkernels.GemmDesc.arith.offset == 44 and sepkernels.GemmDesc.eps.offset == 48
     assert sepkernels.GemmDesc.count.offset == 56 and sepkernels.GemmDesc.A.offset == 64
-    assert ctypes.sizeof(sepkernels.GemmDesc) == 64 + 24 * 8
-    assert sepkernels.GemmDesc.A_pk.offset == 64 + 22 * 8 and ctypes.sizeof(sepkernels.PackSeg) == 40
+    assert ctypes.sizeof(sepkernels.GemmDesc) == 64 + 25 * 8
+    assert sepkernels.GemmDesc.A_pk.offset == 64 + 23 * 8 and ctypes.sizeof(sepkernels.PackSeg) == 40
     assert sepkernels.WgradDesc.arith.offset == 44 and sepkernels.WgradDesc.count.offset == 56 and sepkernels.WgradDesc.G.offset == 64
     assert ctypes.sizeof(sepkernels.WgradDesc) == 64 + 10 * 8
     assert ctypes.sizeof(sepkernels.ReduceSeg) == 40

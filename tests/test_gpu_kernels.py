@@ -75,6 +75,15 @@ def stats_of(x, T):
     return (tot.unsqueeze(1) * w.view(1, SLOTS, 1)).contiguous()
 
 
+def bacc_rand(B, count, scale=0.01):
+    """slotted gLN-backward sums (sep_gemm_desc.pro_bacc): random raw totals {sum gamma g, sum gamma g u} of the size `scale * count`,
+    spread unevenly over the slots"""
+    tot = (torch.randn(B, 2, generator=G) * scale * count).double()
+    w = torch.rand(SLOTS, generator=G).double()
+    w = w / w.sum()
+    return (tot.unsqueeze(1) * w.view(1, SLOTS, 1)).contiguous()
+
+
 def to_device(t):
     """where the second copy of every buffer lives (tests/test_kernel_source_on_host_cpu.py swaps HIP, to_device and device_sync to run
     these same cases on the host simulation of the kernel sources)"""
@@ -232,6 +241,17 @@ def test_gemm_dgrad_two_sources_rowsums(arith):
     both("pw_gemm", [], kw)
 
 
+@pytest.mark.parametrize("H,T", [(512, 700), (256, 130)])
+def test_gemm_dgrad_two_sources_plain(H, T, arith):
+    """dv2 = Wo^T dout + Ws^T dS with a plain epilogue: the heads^T product of the step since its gLN sums come from the weight gradient
+    (H = 512: the 128-row-per-wave form of the cooperative kernel when SEPK_COOP_MI=4)"""
+    B, Bn, Sc = 2, 128, 128
+    ldt = (T + 127) // 128 * 128
+    Wo, Ws = rnd(Bn, H, scale=0.1), rnd(Sc, H, scale=0.1)
+    kw = dict(B=B, M=H, K=Bn + Sc, T=T, ldt=ldt, trans_a=1, A=Wo, A2=Ws, X=padded(B, Bn, T, ldt), X2=padded(B, Sc, T, ldt), k_split=Bn, Y=nan(B, H, ldt))
+    both("pw_gemm", [], kw)
+
+
 def test_gemm_dgrad_prelu_bwd(arith):
     B, M, K, T = 2, 64, 384, 333
     ldt = 384
@@ -253,8 +273,8 @@ def test_gemm_gln_bwd_prologue(residual, arith):
     kw = dict(B=B, M=M, K=K, T=T, ldt=ldt, trans_a=1, A=W1, X=dv, Y=nan(B, M, ldt), pro_mode=PRO_GLN_BWD, pro_stats=st,
               pro_gamma=rnd(K) + 1, pro_alpha=torch.tensor([0.2]), pro_aux=a, pro_bsum=rnd(B, 2, scale=0.01), pro_store=dv,
               pro_dalpha=torch.zeros(1, dtype=torch.float64), count=K * T, eps=1e-12)
-    if residual:
-        kw.update(epi_flags=EPI_RESIDUAL, epi_res=padded(B, M, T, ldt))
+    if residual:      # ... and the means formed by the kernel from a producer's slots (pro_bacc) instead of published floats
+        kw.update(epi_flags=EPI_RESIDUAL, epi_res=padded(B, M, T, ldt), pro_bsum=None, pro_bacc=bacc_rand(B, K * T))
     both("pw_gemm", [], kw)
 
 
@@ -591,6 +611,13 @@ def test_dwconv_fwd_bwd(T, d):
     assert bool((units == units[0]).all()) and int(units[0]) >= C
     assert bool((arrived[:, 16] == min(16, int(units[0]))).all())
     assert (args[16] - gargs[16].cpu()).abs().max() <= 3e-4 * args[16].abs().max()
+    # sums only (the consumer forms the means: what the Conv-TasNet step uses)
+    args3 = list(args)
+    args3[12], args3[13], args3[14], args3[15], args3[16] = nan(B, C, ldt), nan(B, C, ntile, 8), zstats(B), None, None
+    g3 = [to_device(v) if torch.is_tensor(v) else v for v in args3]
+    HIP.dwconv_bwd(*g3)
+    device_sync()
+    assert (g3[14].cpu().sum(1) - bc).abs().max() <= 3e-4 * bc.abs().max()
     # without the gLN1 outputs (stand-alone use)
     args2 = list(args)
     args2[14:17] = [None, None, None]

@@ -55,6 +55,7 @@ GEMM_CASES = [
     ("f16x3-packed", "test_gemm_gln_prologue_and_stats_epilogue", ()),
     ("f16x3-packed", "test_gemm_dgrad_two_sources_rowsums", ()),
     ("f16x3-packed", "test_gemm_dgrad_prelu_bwd", ()),
+    ("f16x3-packed", "test_gemm_dgrad_two_sources_plain", (512, 700)),
     ("f16x3-packed", "test_gemm_packed_heads_residual_accumulate", ()),
     ("f32", "test_gemm_gln_bwd_prologue", (0,)),
     ("bf16x6", "test_wgrad_two_sources_gln_prelu", ()),
