@@ -1664,6 +1664,10 @@ extern "C" int sep_pw_wgrad(const sep_wgrad_desc* d, sep_stream_t stream) {
     const bool direct_ok = !force_staged && !d->g_mul && (d->x_mode < SEP_PRO_GLN || d->B / d->x_div <= WMAXB) &&
                            (long)d->nsplit <= (long)d->B * (d->ldt / DK);
     SEP_REQUIRE(d->arith >= SEP_ARITH_F32 && d->arith <= SEP_ARITH_F16X3, "sep_pw_wgrad: bad arith %d", d->arith);
+    if (direct_ok && d->arith == SEP_ARITH_F16X3 && sep_pw_wgrad_pc16(d, (hipStream_t)stream)) {   // scaled two-part fp16 split (wgrad_pc16.hip)
+        SEP_CHECK_LAUNCH("sep_pw_wgrad (pc16)");
+        return 0;
+    }
     if (direct_ok && d->arith != SEP_ARITH_F32 && sep_pw_wgrad_pc(d, (hipStream_t)stream)) {      // producer / consumer form (wgrad_pc.hip)
         SEP_CHECK_LAUNCH("sep_pw_wgrad (pc)");
         return 0;

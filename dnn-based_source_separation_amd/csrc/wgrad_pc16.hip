@@ -1,0 +1,413 @@
+// Weight gradient of the 1x1 convolutions in the SCALED TWO-PART fp16 arithmetic (SEP_ARITH_F16X3), producer / consumer workgroup:
+//
+//   partial[s][m][n] = sum over the (sample, frame) columns of slab s of  G[b][m][t] * pro(X[b][n][t]),   partial_bias[s][m] = sum G
+//
+// Replaces autograd's conv weight / bias gradient of nn.Conv1d(kernel_size=1) at reference src/models/tdcn.py:86,173,175 and
+// src/models/conv_tasnet.py:335,341, like pw_wgrad_pc_kernel (wgrad_pc.hip), whose workgroup structure, slab / tile mapping, DMA rings
+// (chunk pairs, NS = 4) and barrier protocol it keeps.  What changes is the arithmetic of the products: wgrad_pc.hip splits both operands
+// EXACTLY into three bf16 parts and issues six of the nine part products (6 x 32 matrix-pipe cycles per 32x32x16 block); here
+//     x 2^s = hi + lo,  hi = fp16(x 2^s) toward zero, lo = fp16(x 2^s - hi)         (11 + 11 significand bits)
+//     x y = hi_x lo_y + lo_x hi_y + hi_x hi_y                                          (3 x 32 cycles)
+// as in the forward / input-gradient kernels (gemm_pc.hip).  Both operands are activations, so BOTH carry run-time scales, exact powers
+// of two that only ever fall:
+//   * one exponent per ROW of X, kept by the producer thread(s) that own the row, handed over with every chunk (xe[]); an X row is an
+//     accumulator COLUMN, owned by a lane: the lane rescales its accumulators when the exponent drops (as gemm_pc.hip does);
+//   * one exponent per ROW of G, kept by the consumer lanes that load the row; a G row is an accumulator ROW, i.e. a REGISTER of every
+//     lane of the wave: when it drops, the registers of that row are rescaled in all lanes (the deltas travel by ds_bpermute).
+// A new maximum re-centres the row at 2^9 with head room to 2^14 (fp16 overflows at 2^16), so after the first chunks of a slab the
+// rescale branches are not taken.  Values ~2^-25 below their row's running maximum lose low bits: the error is relative to |G||X| per
+// output, as for fp32 accumulation, not elementwise (same model as the forward kernels; tests/test_gpu_kernels.py).
+#include "gemm_common.hpp"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+constexpr int W16MAXB = 256;      // samples whose gLN constants fit the LDS table
+constexpr int W16UNSET = 10000;   // exponent of a row that has only seen zeros: any first maximum "outgrows" it, ldexp(0, anything) = 0
+
+template <int WR, int WC, int NS>
+struct __attribute__((aligned(16))) W16Smem {
+    static constexpr int TM = 64 * WR, TN = 128 * WC;
+    float Gr[NS + 1][TM * DK];      // raw G chunk [row][16 frames], 16-byte granules XOR-swizzled by ((row >> 2) & 3)
+    float Xr[NS][TN * DK];          // raw X chunk, same layout
+    float Xp[2][4][TN * 4];         // split X chunk: plane (frame half lk, part hi / lo) -> [row][16 B = 8 fp16]
+    int xe[2][TN];                  // the rows' scale exponents, per operand buffer
+    float mu[W16MAXB];
+    float rstd[W16MAXB];
+};
+
+__device__ __forceinline__ f32x16 w16_mfma(const u32x4_t a, const u32x4_t b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void w16_wait_barrier() {      // vmcnt(N) lgkmcnt(0), then the workgroup barrier
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0070 | (N & 15) | ((N >> 4) << 14));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void w16_lgkm0_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ float w16_amax8(const float (&v)[8]) {
+    return fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7]))));
+}
+// running scale exponent of a row given the maximum of its next 16 frames: unchanged while the scaled maximum stays below 2^14 (and for a
+// chunk of zeros), else re-centred so that this maximum lands in [2^8, 2^9)
+__device__ __forceinline__ int w16_next_exp(const float m, const int cur) {
+    const int ex = __builtin_amdgcn_frexp_expf(m);                       // m = f 2^ex, f in [0.5, 1)
+    const int ex2 = __builtin_bit_cast(int, m) == 0 ? -3 * W16UNSET : ex;
+    return ex2 + cur > 14 ? 9 - ex : cur;
+}
+
+template <int WR, int WC, int XMODE>
+__global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_desc d) {
+    constexpr int NS = 4;
+    constexpr bool X_GLN = XMODE == SEP_PRO_GLN || XMODE == SEP_PRO_GLN_PRELU;
+    constexpr bool X_PRELU = XMODE == SEP_PRO_PRELU || XMODE == SEP_PRO_GLN_PRELU;
+    using Smem = W16Smem<WR, WC, NS>;
+    constexpr int TM = Smem::TM, TN = Smem::TN;
+    constexpr int PG = TM / 64, PX = TN / 64;             // DMA pieces (16 rows x 64 B) per producer wave and chunk
+    constexpr int G = PG + PX;
+    static_assert(sizeof(Smem) <= 160 * 1024, "LDS");
+    static_assert(sizeof(Smem) >= 4 * EPI_WAVE_FLOATS * sizeof(float), "transpose buffer");
+    __shared__ Smem sm;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wid >= 4;
+    const int lk = lane >> 5, l31 = lane & 31;
+
+    const int ntm = d.M / TM, ntn = d.N / TN;
+    const int ntiles = ntm * ntn;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, jj = bid >> 3;
+    const int tile = jj % ntiles;
+    const int s = (jj / ntiles) * 8 + xcd;
+    if (s >= d.nsplit) return;
+    const int m0 = (tile / ntn) * TM, n0 = (tile % ntn) * TN;
+
+    const int cps_t = d.ldt / DK;                  // chunks per sample
+    const long chunks_total = (long)d.B * cps_t;
+    const long cper = (chunks_total + d.nsplit - 1) / d.nsplit;
+    const long c_begin = (long)s * cper;
+    long c_end = c_begin + cper;
+    if (c_end > chunks_total) c_end = chunks_total;
+    const int nk = (int)(c_end > c_begin ? c_end - c_begin : 0);
+
+    if (X_GLN) {
+        for (int bx = tid; bx < d.B; bx += 512) {
+            float mu, rstd;
+            gln_mu_rstd(d.x_stats + (size_t)bx * SEP_STATS_SLOTS * 2, d.count, d.eps, mu, rstd);
+            sm.mu[bx] = mu; sm.rstd[bx] = rstd;
+        }
+    }
+    const float alpha_x = X_PRELU ? d.x_alpha[0] : 0.f;
+    const bool do_bias = d.partial_bias != nullptr && (tile % ntn) == 0;
+
+    f32x16 acc[2][2][2];                                 // [column half][mi][n]: the consumer's 64 x 128 tile (producers: unused)
+
+    if (producer) {
+        // =================================================================================== producer waves
+        const int pw = wid - 4;
+        const int ptid = tid - 256;
+        const int Mg1 = d.g_split ? d.g_split : d.M;
+        const int r16 = lane >> 2, cch = (lane & 3) ^ ((r16 >> 2) & 3);
+        unsigned voffG[PG], voffX[PX];
+        const float* srcG[PG];
+        int MgOf[PG];
+#pragma unroll
+        for (int q = 0; q < PG; ++q) {
+            const int row = m0 + 16 * (pw + 4 * q) + r16;
+            const bool second = d.g_split && (m0 + 16 * (pw + 4 * q)) >= d.g_split;   // wave-uniform
+            srcG[q] = second ? d.G2 : d.G;
+            MgOf[q] = second ? d.M - d.g_split : Mg1;
+            voffG[q] = 4u * (unsigned)((row - (second ? d.g_split : 0)) * d.ldt + 4 * cch);
+        }
+#pragma unroll
+        for (int q = 0; q < PX; ++q) voffX[q] = 4u * (unsigned)((n0 + 16 * (pw + 4 * q) + r16) * d.ldt + 4 * cch);
+        int ib = (int)(c_begin / cps_t), it = (int)(c_begin % cps_t);
+        int ci = 0, cst = 0, gst = 0;
+        auto issue = [&]() {
+#pragma unroll
+            for (int q = 0; q < PG; ++q)
+                glds16_asm(srcG[q] + (size_t)ib * MgOf[q] * d.ldt + it * DK, voffG[q], lds_addr(&sm.Gr[gst][16 * (pw + 4 * q) * DK]));
+#pragma unroll
+            for (int q = 0; q < PX; ++q)
+                glds16_asm(d.X + (size_t)ib * d.N * d.ldt + it * DK, voffX[q], lds_addr(&sm.Xr[cst][16 * (pw + 4 * q) * DK]));
+            if (++it >= cps_t) { it = 0; ++ib; }
+            ++ci;
+            cst = cst + 1 == NS ? 0 : cst + 1;
+            gst = gst + 1 == NS + 1 ? 0 : gst + 1;
+        };
+
+        // an operand with 256 rows gives every producer thread one whole row (16 frames), one with 128 rows half a row (8 frames): the
+        // row's two halves then sit in neighbouring lanes
+        constexpr bool X_FULL = TN == 256;
+        const int x_row = X_FULL ? ptid : ptid >> 1, x_half = X_FULL ? 0 : ptid & 1;
+        float xg = 0.f, xb = 0.f;
+        if (X_GLN) { xg = d.x_gamma[n0 + x_row]; xb = d.x_beta[n0 + x_row]; }
+        asm volatile("" :: "v"(xg), "v"(xb), "v"(alpha_x));
+        int cb = (int)(c_begin / cps_t), ct = (int)(c_begin % cps_t);
+        int xexp = W16UNSET;                                                     // this row's running scale exponent
+
+        auto read8 = [&](const float* raw, const int row, const int half, float (&v)[8]) {
+            const int f = (row >> 2) & 3;
+            const float4 a = ld4(raw + row * DK + 4 * ((2 * half) ^ f));
+            const float4 b = ld4(raw + row * DK + 4 * ((2 * half + 1) ^ f));
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        };
+        auto put8 = [&](float* planes, const int row, const int half, const float (&v)[8]) {
+            unsigned hi[4], lo[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) split2_pair(v[2 * q], v[2 * q + 1], hi[q], lo[q]);
+            float* base = planes + (size_t)(2 * half) * TN * 4 + row * 4;
+            *reinterpret_cast<u32x4_t*>(base) = u32x4_t{hi[0], hi[1], hi[2], hi[3]};
+            *reinterpret_cast<u32x4_t*>(base + TN * 4) = u32x4_t{lo[0], lo[1], lo[2], lo[3]};
+        };
+
+        __syncthreads();                                                         // mu / rstd table visible; no DMA in flight yet
+#pragma unroll
+        for (int g = 0; g < NS; ++g)
+            if (ci < nk) issue();
+        if (nk >= NS) w16_wait_barrier<(NS - 1) * G>();                          // B_-1: raw chunk 0 landed
+        else w16_wait_barrier<0>();
+
+        int stage = 0;
+        for (int j = 0; j < nk; ++j) {
+            const float* Xb = sm.Xr[stage];
+            float* Xp = &sm.Xp[j & 1][0][0];
+            float sc = 1.f, sh = 0.f;
+            if (X_GLN) {
+                const float rstd = sm.rstd[cb], mu = sm.mu[cb];
+                sc = xg * rstd;
+                sh = xb - mu * sc;
+            }
+            float v[X_FULL ? 2 : 1][8];
+            float m = 0.f;
+#pragma unroll
+            for (int h = 0; h < (X_FULL ? 2 : 1); ++h) {
+                read8(Xb, x_row, X_FULL ? h : x_half, v[h]);
+                if (XMODE != SEP_PRO_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float x = v[h][e];
+                        if (X_PRELU) x = prelu_f(x, alpha_x);
+                        v[h][e] = X_GLN ? x * sc + sh : x;
+                    }
+                }
+                m = fmaxf(m, w16_amax8(v[h]));
+            }
+            if (!X_FULL) m = fmaxf(m, __shfl_xor(m, 1, 64));                     // the row's other eight frames sit in the neighbouring lane
+            xexp = w16_next_exp(m, xexp);
+#pragma unroll
+            for (int h = 0; h < (X_FULL ? 2 : 1); ++h) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[h][e] = __builtin_ldexpf(v[h][e], xexp);
+                put8(Xp, x_row, X_FULL ? h : x_half, v[h]);
+            }
+            sm.xe[j & 1][x_row] = xexp;                                          // (both halves of a row store the same word)
+            if (++ct >= cps_t) { ct = 0; ++cb; }
+            // raw chunk j+1 has landed -- mine: all but the newer chunks; everyone's: the barrier -- and the operands of chunk j are written.
+            // Chunks are fetched in PAIRS behind the odd barriers (wgrad_pc.hip: one HBM fetch per 128-byte line).
+            if (j & 1) { if (j + 3 <= nk) w16_wait_barrier<G>(); else w16_wait_barrier<0>(); }
+            else { if (j + 4 <= nk) w16_wait_barrier<2 * G>(); else w16_wait_barrier<0>(); }
+            if (j & 1) {
+                if (ci < nk) issue();
+                if (ci < nk) issue();
+            }
+            stage = stage + 1 == NS ? 0 : stage + 1;
+        }
+    } else {
+        // =================================================================================== consumer waves
+        const int wr = wid / WC, wcc = wid % WC;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[h][mi][n][r] = 0.f;
+        u32x4_t sa[2][2], sb[2][2];                                              // A: [mi][hi, lo]; B of the column half in work: [n][hi, lo]
+        float ra[2][8];                                                          // raw G: [mi][frame 8*lk + e] of row 64*wr + 32*mi + l31
+        float bias_acc[2] = {0.f, 0.f};
+        int gexp[2] = {W16UNSET, W16UNSET};                                      // running scale exponents of this lane's two G rows
+        int bcur[2][2] = {{W16UNSET, W16UNSET}, {W16UNSET, W16UNSET}};           // scale the accumulators of column block (h, n) are in
+        const int g_f = (l31 >> 2) & 3;
+        const int g_off = (64 * wr + l31) * DK;
+        const int b_off = (128 * wcc + l31) * 4 + lk * 2 * TN * 4;               // + (64 * h + 32 * n) * 4 + part * TN * 4
+        auto read_raw_a = [&](const int gstage) {
+            const float* Gb = sm.Gr[gstage] + g_off;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const float4 x = ld4(Gb + mi * 32 * DK + 4 * ((2 * lk) ^ g_f));
+                const float4 y = ld4(Gb + mi * 32 * DK + 4 * ((2 * lk + 1) ^ g_f));
+                ra[mi][0] = x.x; ra[mi][1] = x.y; ra[mi][2] = x.z; ra[mi][3] = x.w; ra[mi][4] = y.x; ra[mi][5] = y.y; ra[mi][6] = y.z; ra[mi][7] = y.w;
+            }
+        };
+        // scale, split and (when a row's maximum outgrew its scale) the accumulator rows follow: a G row is register r of EVERY lane
+        auto split_a = [&]() {
+            int delta[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                if (do_bias) bias_acc[mi] += ((ra[mi][0] + ra[mi][1]) + (ra[mi][2] + ra[mi][3])) + ((ra[mi][4] + ra[mi][5]) + (ra[mi][6] + ra[mi][7]));
+                float m = w16_amax8(ra[mi]);
+                m = fmaxf(m, __shfl_xor(m, 32, 64));                             // the row's other eight frames: lane + 32
+                const int nexp = w16_next_exp(m, gexp[mi]);
+                delta[mi] = nexp - gexp[mi];
+                gexp[mi] = nexp;
+            }
+            if (__builtin_amdgcn_ballot_w64((delta[0] | delta[1]) != 0) != 0) {  // rare after the first chunks of a slab
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dr = __shfl(delta[mi], (r & 3) + 8 * (r >> 2) + 4 * lk, 64);      // row of register r (C layout), kept by lane = row
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int n = 0; n < 2; ++n) acc[h][mi][n][r] = __builtin_ldexpf(acc[h][mi][n][r], dr);
+                    }
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                float w[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w[e] = __builtin_ldexpf(ra[mi][e], gexp[mi]);
+                unsigned hi[4], lo[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) split2_pair(w[2 * q], w[2 * q + 1], hi[q], lo[q]);
+                sa[mi][0] = u32x4_t{hi[0], hi[1], hi[2], hi[3]};
+                sa[mi][1] = u32x4_t{lo[0], lo[1], lo[2], lo[3]};
+            }
+        };
+        // the operands of column half h in buffer buf, and the accumulator columns follow their X rows' scales (a column is a lane's own)
+        auto load_b = [&](const int h, const int buf) {
+            const float* p = &sm.Xp[buf][0][0] + b_off + 64 * h * 4;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                sb[n][0] = *reinterpret_cast<const u32x4_t*>(p + n * 32 * 4);
+                sb[n][1] = *reinterpret_cast<const u32x4_t*>(p + n * 32 * 4 + TN * 4);
+                const int en = sm.xe[buf][128 * wcc + 64 * h + 32 * n + l31];
+                const int dl = en - bcur[h][n];
+                if (__builtin_amdgcn_ballot_w64(dl != 0) != 0) {
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[h][mi][n][r] = __builtin_ldexpf(acc[h][mi][n][r], dl);
+                }
+                bcur[h][n] = en;
+            }
+        };
+        auto mfmas = [&](const int h) {
+            // x*y = hi*lo + lo*hi + hi*hi (the dropped lo*lo is <= 2^-22 |xy|)
+#pragma unroll
+            for (int part = 0; part < 3; ++part)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[h][mi][n] = w16_mfma(sa[mi][part == 1 ? 1 : 0], sb[n][part == 0 ? 1 : 0], acc[h][mi][n]);
+        };
+        __syncthreads();                                                         // (the producers' table barrier)
+        w16_lgkm0_barrier();                                                     // B_-1: raw chunk 0 has landed
+        int gstage = 0;
+        if (nk > 0) read_raw_a(0);
+        for (int j = 0; j < nk; ++j) {
+            w16_lgkm0_barrier();                                                 // B_j: the X operands of chunk j are there, raw G of chunk j+1 too
+            const int buf = j & 1;
+            split_a();
+            load_b(0, buf);
+            mfmas(0);
+            load_b(1, buf);
+            gstage = gstage + 1 == NS + 1 ? 0 : gstage + 1;
+            read_raw_a(gstage);                                                  // raw G of chunk j+1 (unused after the last chunk)
+            mfmas(1);
+        }
+        // undo the scales: accumulator (row, column) is in units of 2^(gexp[row] + bcur[column])
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gr = __shfl(gexp[mi], (r & 3) + 8 * (r >> 2) + 4 * lk, 64);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) acc[h][mi][n][r] = __builtin_ldexpf(acc[h][mi][n][r], -(gr + bcur[h][n]));
+            }
+        if (do_bias && wcc == 0) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const float tot = bias_acc[mi] + __shfl_xor(bias_acc[mi], 32, 64);     // the two lane halves own different frames
+                if (lk == 0) d.partial_bias[(size_t)s * d.M + m0 + 64 * wr + 32 * mi + l31] = tot;
+            }
+        }
+    }
+    // ---- the consumers' tiles leave for the slab: transposed through LDS, float4 stores (see wgrad_pc.hip)
+    __syncthreads();
+    if (!producer) {
+        int etid = tid, es = s, em0 = m0, en0 = n0;
+        asm volatile("" : "+v"(etid), "+s"(es), "+s"(em0), "+s"(en0));
+        const int ewid = __builtin_amdgcn_readfirstlane(etid >> 6);
+        const int ewr = ewid / WC, ewc = ewid % WC, elk = (etid >> 5) & 1, el31 = etid & 31, elane = etid & 63;
+        float* Tw = reinterpret_cast<float*>(&sm) + ewid * EPI_WAVE_FLOATS;
+        const int rsub = elane >> 4, c4 = elane & 15;
+        float* out = d.partial + (size_t)es * d.M * d.N + (size_t)(em0 + ewr * 64) * d.N + en0 + ewc * 128 + 4 * c4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = (r & 3) + 8 * (r >> 2) + 4 * elk;
+                    Tw[rl * EPI_LD + el31] = acc[h][mi][0][r];
+                    Tw[rl * EPI_LD + 32 + el31] = acc[h][mi][1][r];
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int p8 = 0; p8 < 8; ++p8) {
+                    const int row = 4 * p8 + rsub;
+                    st4(out + (size_t)(mi * 32 + row) * d.N + h * 64, ld4(Tw + row * EPI_LD + 4 * c4));
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+    }
+}
+
+template <int WR, int WC, int XMODE>
+void launch_w16(const sep_wgrad_desc& d, hipStream_t stream) {
+    const int ntiles = (d.M / (64 * WR)) * (d.N / (128 * WC));
+    const int grid = 8 * ntiles * ceil_div(d.nsplit, 8);
+    hipLaunchKernelGGL((pw_wgrad_pc16_kernel<WR, WC, XMODE>), dim3(grid), dim3(512), 0, stream, d);
+}
+
+}  // namespace
+
+// Called by sep_pw_wgrad (gemm.hip) for SEP_ARITH_F16X3.  Returns 1 when the call was launched here (same shapes as sep_pw_wgrad_pc).
+int sep_pw_wgrad_pc16(const sep_wgrad_desc* d, hipStream_t stream) {
+    static const bool off = getenv("SEPK_WGRAD_F16") != nullptr && atoi(getenv("SEPK_WGRAD_F16")) == 0;
+    if (off || d->arith != SEP_ARITH_F16X3 || d->g_mul || d->x_div != 1 || d->B > W16MAXB || d->g_split % 128 != 0) return 0;
+    const bool tall = d->M % 256 == 0 && d->N % 128 == 0;
+    const bool wide = d->M % 128 == 0 && d->N % 256 == 0;
+    if (!tall && !wide) return 0;
+    if ((size_t)d->M * d->ldt * 4 >= (1ull << 32) || (size_t)d->N * d->ldt * 4 >= (1ull << 32)) return 0;      // 32-bit DMA offsets
+    if ((long)d->nsplit > (long)d->B * (d->ldt / DK)) return 0;
+#define SEP_LW(XM)                                           \
+    do {                                                     \
+        if (tall) launch_w16<4, 1, XM>(*d, stream);          \
+        else launch_w16<2, 2, XM>(*d, stream);               \
+        return 1;                                            \
+    } while (0)
+    switch (d->x_mode) {
+        case SEP_PRO_NONE: SEP_LW(SEP_PRO_NONE);
+        case SEP_PRO_PRELU: SEP_LW(SEP_PRO_PRELU);
+        case SEP_PRO_GLN: SEP_LW(SEP_PRO_GLN);
+        default: SEP_LW(SEP_PRO_GLN_PRELU);
+    }
+#undef SEP_LW
+    return 0;
+}

@@ -398,6 +398,51 @@ def test_gemm_packed_adversarial_operands(case):
     assert err["packed"] <= max(3 * err["f32"], 2e-6), err
 
 
+@pytest.mark.parametrize("case", ["row_scales_1e12", "late_jumps", "zero_rows_then_signal", "subnormal", "one_slab_many_samples"])
+def test_wgrad_f16_adversarial_operands(case):
+    """sep_pw_wgrad in SEP_ARITH_F16X3 (wgrad_pc16.hip: both operands scaled per row at run time) where fixed scales would fail: rows of G
+    and of X 24 decades apart; rows whose magnitude jumps by 1e6 late in a slab (the accumulator-row and accumulator-column rescale
+    paths, both at once); rows that are all zero for the first half of the slab; operands in fp32's subnormal range; one slab running
+    over several samples.  Error of the summed slabs relative to sum_t |G||X| per output, beside the exact bf16x6 kernel on the same operands."""
+    B, M, N, T, ns = 3, 256, 128, 1900, (1 if case == "one_slab_many_samples" else 5)
+    ldt = 1920
+    Gm, X = padded(B, M, T, ldt), padded(B, N, T, ldt)
+    if case == "row_scales_1e12":
+        Gm[:, ::2] *= 1e12
+        Gm[:, 1::2] *= 1e-12
+        X[:, ::3] *= 1e9
+        X[:, 1::3] *= 1e-9
+    elif case == "late_jumps":
+        Gm[:, 3::7, 1500:] *= 1e6
+        X[:, 5::11, 1700:] *= 1e6
+        Gm[1, 40, 1899] = 3e4
+    elif case == "zero_rows_then_signal":
+        Gm[:, ::4, :1000] = 0
+        X[:, ::5, :1200] = 0
+        Gm[:, 9] = 0
+        X[:, 17] = 0
+    elif case == "subnormal":
+        Gm, X = Gm * 1e-20, X * 1e-19                        # products ~1e-39: fp32 subnormals in the accumulators
+    Gm[..., T:] = 0
+    X[..., T:] = 0
+    ref = torch.einsum("bmt,bnt->mn", Gm.double(), X.double())
+    scale = torch.einsum("bmt,bnt->mn", Gm.double().abs(), X.double().abs())
+    err = {}
+    for name, arith in (("bf16x6", sepkernels.ARITH_BF16X6), ("f16x3", sepkernels.ARITH_F16X3)):
+        part = torch.full((ns, M, N), float("nan"), device=device_name())
+        pb = torch.full((ns, M), float("nan"), device=device_name())
+        HIP.pw_wgrad(B=B, M=M, N=N, T=T, ldt=ldt, G=to_device(Gm), X=to_device(X), partial=part, partial_bias=pb, nsplit=ns, arith=arith)
+        device_sync()
+        assert torch.isfinite(part).all() and torch.isfinite(pb).all()
+        got = part.cpu().double().sum(0)
+        err[name] = ((got - ref).abs() / (scale + 1e-300 + 1.4e-45 * T)).max().item()
+        assert (pb.cpu().double().sum(0) - Gm.double().sum((0, 2))).abs().max() <= 1e-5 * Gm.double().abs().sum((0, 2)).max()
+        if case == "zero_rows_then_signal":
+            assert (got[9] == 0).all() and (got[:, 17] == 0).all()
+    assert err["bf16x6"] <= 2e-6, err
+    assert err["f16x3"] <= max(4 * err["bf16x6"], 2e-6), err
+
+
 def test_pack_weights_reproduces_the_weights():
     """hi + lo of every packed group, times the row's inverse scale, is the weight to 2^-22 relative to the row maximum."""
     W = rnd(96, 64) * torch.exp(5 * rnd(96, 1))

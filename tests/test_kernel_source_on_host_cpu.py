@@ -75,6 +75,10 @@ GEMM_CASES = [
     (None, "test_gemm_packed_weights_model_shapes", (1024, 128, 130)),       # producer / consumer kernel, 4 x 1 consumer waves
     (None, "test_gemm_packed_adversarial_operands", ("late_jump_k1024",)),
     (None, "test_gemm_prelu_prologues_any_slope", (-0.3,)),
+    (None, "test_wgrad_f16_adversarial_operands", ("late_jumps",)),
+    (None, "test_wgrad_f16_adversarial_operands", ("zero_rows_then_signal",)),
+    ("f16x3", "test_wgrad_plain", (2, 512, 128, 999, 7)),                      # the scaled two-part fp16 weight-gradient kernel
+    ("f16x3", "test_wgrad_two_sources_gln_prelu", ()),
     (None, "test_pack_weights_reproduces_the_weights", ()),
     (None, "test_reduce_slabs_and_f64", ()),
 ]
