@@ -53,6 +53,25 @@ __device__ __forceinline__ void w16_lgkm0_barrier() {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
+// Single-instruction forms (see gemm_pc.hip): the maximum with the lane 32 away as one v_permlane32_swap (no LDS round trip in the middle
+// of the MFMA stream), with the neighbouring lane as one v_max_f32_dpp, and lo = x - float(hi half) as one mixed-precision FMA.
+__device__ __forceinline__ float w16_max_halves(const float m) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
+    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+__device__ __forceinline__ float w16_max_neighbour(const float m) {      // max(m, m of lane ^ 1)
+    float r;
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=&v"(r) : "v"(m));
+    return r;
+}
+__device__ __forceinline__ void w16_split2_pair(const float x0, const float x1, unsigned& hi, unsigned& lo) {
+    const fp16x2_t h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+    hi = __builtin_bit_cast(unsigned, h);
+    float l0, l1;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(x0), "v"(hi));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(x1), "v"(hi));
+    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l0, l1));
+}
 __device__ __forceinline__ float w16_amax8(const float (&v)[8]) {
     return fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7]))));
 }
@@ -163,7 +182,7 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
         auto put8 = [&](float* planes, const int row, const int half, const float (&v)[8]) {
             unsigned hi[4], lo[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) split2_pair(v[2 * q], v[2 * q + 1], hi[q], lo[q]);
+            for (int q = 0; q < 4; ++q) w16_split2_pair(v[2 * q], v[2 * q + 1], hi[q], lo[q]);
             float* base = planes + (size_t)(2 * half) * TN * 4 + row * 4;
             *reinterpret_cast<u32x4_t*>(base) = u32x4_t{hi[0], hi[1], hi[2], hi[3]};
             *reinterpret_cast<u32x4_t*>(base + TN * 4) = u32x4_t{lo[0], lo[1], lo[2], lo[3]};
@@ -201,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
                 }
                 m = fmaxf(m, w16_amax8(v[h]));
             }
-            if (!X_FULL) m = fmaxf(m, __shfl_xor(m, 1, 64));                     // the row's other eight frames sit in the neighbouring lane
+            if (!X_FULL) m = w16_max_neighbour(m);                     // the row's other eight frames sit in the neighbouring lane
             xexp = w16_next_exp(m, xexp);
 #pragma unroll
             for (int h = 0; h < (X_FULL ? 2 : 1); ++h) {
@@ -232,15 +251,23 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
                 for (int n = 0; n < 2; ++n)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[h][mi][n][r] = 0.f;
-        u32x4_t sa[2][2], sb[2][2];                                              // A: [mi][hi, lo]; B of the column half in work: [n][hi, lo]
+        // Operand registers: A (= G) of the chunk being multiplied and of the NEXT chunk (sa[parity]: the next chunk is scaled and split in
+        // the shadow of this chunk's MFMAs, one micro-step behind every second MFMA, each pinned with sched_barrier -- left to itself hipcc
+        // emits the ~110 VALU of the split as one block in front of the MFMAs and the matrix pipe idles through it); B (= X) of both column
+        // halves (sb[h]: all reads of a chunk are issued right behind its barrier).
+        u32x4_t sa[2][2][2], sb[2][2][2];                                        // sa[parity][mi][hi, lo]; sb[h][n][hi, lo]
         float ra[2][8];                                                          // raw G: [mi][frame 8*lk + e] of row 64*wr + 32*mi + l31
         float bias_acc[2] = {0.f, 0.f};
         int gexp[2] = {W16UNSET, W16UNSET};                                      // running scale exponents of this lane's two G rows
+        int gdelta[2] = {0, 0};                                                  // their change with the chunk split last: applied to the accumulators
+                                                                                 // before that chunk's first MFMA
         int bcur[2][2] = {{W16UNSET, W16UNSET}, {W16UNSET, W16UNSET}};           // scale the accumulators of column block (h, n) are in
+        int en[2][2];
         const int g_f = (l31 >> 2) & 3;
         const int g_off = (64 * wr + l31) * DK;
         const int b_off = (128 * wcc + l31) * 4 + lk * 2 * TN * 4;               // + (64 * h + 32 * n) * 4 + part * TN * 4
-        auto read_raw_a = [&](const int gstage) {
+#define W16_SB() __builtin_amdgcn_sched_barrier(0)
+        auto read_raw_a = [&](const int gstage) __attribute__((always_inline)) {
             const float* Gb = sm.Gr[gstage] + g_off;
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
@@ -249,85 +276,138 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
                 ra[mi][0] = x.x; ra[mi][1] = x.y; ra[mi][2] = x.z; ra[mi][3] = x.w; ra[mi][4] = y.x; ra[mi][5] = y.y; ra[mi][6] = y.z; ra[mi][7] = y.w;
             }
         };
-        // scale, split and (when a row's maximum outgrew its scale) the accumulator rows follow: a G row is register r of EVERY lane
-        auto split_a = [&]() {
-            int delta[2];
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                if (do_bias) bias_acc[mi] += ((ra[mi][0] + ra[mi][1]) + (ra[mi][2] + ra[mi][3])) + ((ra[mi][4] + ra[mi][5]) + (ra[mi][6] + ra[mi][7]));
-                float m = w16_amax8(ra[mi]);
-                m = fmaxf(m, __shfl_xor(m, 32, 64));                             // the row's other eight frames: lane + 32
-                const int nexp = w16_next_exp(m, gexp[mi]);
-                delta[mi] = nexp - gexp[mi];
-                gexp[mi] = nexp;
-            }
-            if (__builtin_amdgcn_ballot_w64((delta[0] | delta[1]) != 0) != 0) {  // rare after the first chunks of a slab
+        // micro-steps of the split of row block mi: (A) the row's new scale exponent; (B q) values 2q, 2q+1 scaled and split
+        auto split_exp = [&](auto mic, const bool live) __attribute__((always_inline)) {
+            constexpr int mi = decltype(mic)::value;
+            const float rsum = ((ra[mi][0] + ra[mi][1]) + (ra[mi][2] + ra[mi][3])) + ((ra[mi][4] + ra[mi][5]) + (ra[mi][6] + ra[mi][7]));
+            bias_acc[mi] += (do_bias && live) ? rsum : 0.f;
+            float m = w16_amax8(ra[mi]);
+            m = w16_max_halves(m);                                               // the row's other eight frames: lane + 32
+            const int nexp = live ? w16_next_exp(m, gexp[mi]) : gexp[mi];
+            gdelta[mi] = nexp - gexp[mi];
+            gexp[mi] = nexp;
+            asm volatile("" : "+v"(gdelta[mi]), "+v"(gexp[mi]));                 // materialise HERE (pure arithmetic is otherwise sunk past the MFMAs)
+            W16_SB();
+        };
+        auto split_pair = [&](auto parc, auto mic, auto qc) __attribute__((always_inline)) {      // straight into the operand registers of set `par`
+            constexpr int par = decltype(parc)::value, mi = decltype(mic)::value, q = decltype(qc)::value;
+            unsigned hi, lo;
+            w16_split2_pair(__builtin_ldexpf(ra[mi][2 * q], gexp[mi]), __builtin_ldexpf(ra[mi][2 * q + 1], gexp[mi]), hi, lo);
+            sa[par][mi][0][q] = hi;
+            sa[par][mi][1][q] = lo;
+            asm volatile("" : "+v"(sa[par][mi][0]), "+v"(sa[par][mi][1]));
+            W16_SB();
+        };
+        // when a G row's maximum outgrew its scale the accumulator ROWS follow: a G row is register r of EVERY lane (rare after the first chunks)
+        auto follow_rows = [&]() __attribute__((always_inline)) {
+            if (__builtin_amdgcn_ballot_w64((gdelta[0] | gdelta[1]) != 0) != 0) {
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int dr = __shfl(delta[mi], (r & 3) + 8 * (r >> 2) + 4 * lk, 64);      // row of register r (C layout), kept by lane = row
+                        const int dr = __shfl(gdelta[mi], (r & 3) + 8 * (r >> 2) + 4 * lk, 64);      // row of register r (C layout), kept by lane = row
 #pragma unroll
                         for (int h = 0; h < 2; ++h)
 #pragma unroll
                             for (int n = 0; n < 2; ++n) acc[h][mi][n][r] = __builtin_ldexpf(acc[h][mi][n][r], dr);
+                        W16_SB();                                                // one row at a time: 32 permutes hoisted to the top would spill
                     }
             }
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                float w[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) w[e] = __builtin_ldexpf(ra[mi][e], gexp[mi]);
-                unsigned hi[4], lo[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) split2_pair(w[2 * q], w[2 * q + 1], hi[q], lo[q]);
-                sa[mi][0] = u32x4_t{hi[0], hi[1], hi[2], hi[3]};
-                sa[mi][1] = u32x4_t{lo[0], lo[1], lo[2], lo[3]};
-            }
+            W16_SB();
         };
-        // the operands of column half h in buffer buf, and the accumulator columns follow their X rows' scales (a column is a lane's own)
-        auto load_b = [&](const int h, const int buf) {
-            const float* p = &sm.Xp[buf][0][0] + b_off + 64 * h * 4;
+        // the operands of both column halves in buffer buf (issued together, right behind the barrier)
+        auto load_b = [&](const int buf) __attribute__((always_inline)) {
+            const float* p = &sm.Xp[buf][0][0] + b_off;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    sb[h][n][0] = *reinterpret_cast<const u32x4_t*>(p + (64 * h + 32 * n) * 4);
+                    sb[h][n][1] = *reinterpret_cast<const u32x4_t*>(p + (64 * h + 32 * n) * 4 + TN * 4);
+                    en[h][n] = sm.xe[buf][128 * wcc + 64 * h + 32 * n + l31];
+                }
+            W16_SB();
+        };
+        // ... and the accumulator COLUMNS follow their X rows' scales (a column is a lane's own)
+        auto follow_cols = [&](auto hc) __attribute__((always_inline)) {
+            constexpr int h = decltype(hc)::value;
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                sb[n][0] = *reinterpret_cast<const u32x4_t*>(p + n * 32 * 4);
-                sb[n][1] = *reinterpret_cast<const u32x4_t*>(p + n * 32 * 4 + TN * 4);
-                const int en = sm.xe[buf][128 * wcc + 64 * h + 32 * n + l31];
-                const int dl = en - bcur[h][n];
+                const int dl = en[h][n] - bcur[h][n];
                 if (__builtin_amdgcn_ballot_w64(dl != 0) != 0) {
 #pragma unroll
                     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[h][mi][n][r] = __builtin_ldexpf(acc[h][mi][n][r], dl);
                 }
-                bcur[h][n] = en;
+                bcur[h][n] = en[h][n];
             }
+            W16_SB();
         };
-        auto mfmas = [&](const int h) {
-            // x*y = hi*lo + lo*hi + hi*hi (the dropped lo*lo is <= 2^-22 |xy|)
-#pragma unroll
-            for (int part = 0; part < 3; ++part)
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        acc[h][mi][n] = w16_mfma(sa[mi][part == 1 ? 1 : 0], sb[n][part == 0 ? 1 : 0], acc[h][mi][n]);
+        // MFMA k of column half h: parts hi*lo, lo*hi, hi*hi over the 2 x 2 blocks (the dropped lo*lo is <= 2^-22 |xy|)
+        auto M = [&](auto parc, auto hc, auto kc) __attribute__((always_inline)) {
+            constexpr int par = decltype(parc)::value, h = decltype(hc)::value, k = decltype(kc)::value;
+            constexpr int part = k >> 2, mi = (k >> 1) & 1, n = k & 1;
+            acc[h][mi][n] = w16_mfma(sa[par][mi][part == 1 ? 1 : 0], sb[h][n][part == 0 ? 1 : 0], acc[h][mi][n]);
+            W16_SB();
+        };
+#define W16_I(k) std::integral_constant<int, (k)>{}
+        // one chunk: its 24 MFMAs with the split of the NEXT chunk's G rows woven in (more = there is a next chunk)
+        // `more` = there is a next chunk.  It only feeds selects: behind the last chunk the split runs on the stage's stale contents (in-bounds,
+        // never multiplied) and the rows' exponents / bias sums are left alone -- ten `last chunk?` branches per chunk in the MFMA stream, or
+        // separate code paths for the tail (tried: the allocator then spills 870 registers at the joins), cost more.
+        auto step = [&](auto parc, const bool more, const int buf, const int gstage_next) __attribute__((always_inline)) {
+            constexpr int P = decltype(parc)::value;
+            load_b(buf);
+            read_raw_a(gstage_next);                                             // raw G of the next chunk (landed before this step's barrier)
+            W16_SB();
+            follow_rows();                                                       // (scales chosen while the previous chunk was multiplied)
+            follow_cols(W16_I(0));
+            M(W16_I(P), W16_I(0), W16_I(0)); M(W16_I(P), W16_I(0), W16_I(1));
+            split_exp(W16_I(0), more);
+            M(W16_I(P), W16_I(0), W16_I(2)); M(W16_I(P), W16_I(0), W16_I(3));
+            split_pair(W16_I(P ^ 1), W16_I(0), W16_I(0));
+            M(W16_I(P), W16_I(0), W16_I(4)); M(W16_I(P), W16_I(0), W16_I(5));
+            split_pair(W16_I(P ^ 1), W16_I(0), W16_I(1));
+            M(W16_I(P), W16_I(0), W16_I(6)); M(W16_I(P), W16_I(0), W16_I(7));
+            split_pair(W16_I(P ^ 1), W16_I(0), W16_I(2));
+            M(W16_I(P), W16_I(0), W16_I(8)); M(W16_I(P), W16_I(0), W16_I(9));
+            split_pair(W16_I(P ^ 1), W16_I(0), W16_I(3));
+            M(W16_I(P), W16_I(0), W16_I(10)); M(W16_I(P), W16_I(0), W16_I(11));
+            follow_cols(W16_I(1));
+            M(W16_I(P), W16_I(1), W16_I(0)); M(W16_I(P), W16_I(1), W16_I(1));
+            split_exp(W16_I(1), more);
+            M(W16_I(P), W16_I(1), W16_I(2)); M(W16_I(P), W16_I(1), W16_I(3));
+            split_pair(W16_I(P ^ 1), W16_I(1), W16_I(0));
+            M(W16_I(P), W16_I(1), W16_I(4)); M(W16_I(P), W16_I(1), W16_I(5));
+            split_pair(W16_I(P ^ 1), W16_I(1), W16_I(1));
+            M(W16_I(P), W16_I(1), W16_I(6)); M(W16_I(P), W16_I(1), W16_I(7));
+            split_pair(W16_I(P ^ 1), W16_I(1), W16_I(2));
+            M(W16_I(P), W16_I(1), W16_I(8)); M(W16_I(P), W16_I(1), W16_I(9));
+            split_pair(W16_I(P ^ 1), W16_I(1), W16_I(3));
+            M(W16_I(P), W16_I(1), W16_I(10)); M(W16_I(P), W16_I(1), W16_I(11));
+            W16_SB();
         };
         __syncthreads();                                                         // (the producers' table barrier)
         w16_lgkm0_barrier();                                                     // B_-1: raw chunk 0 has landed
         int gstage = 0;
-        if (nk > 0) read_raw_a(0);
-        for (int j = 0; j < nk; ++j) {
-            w16_lgkm0_barrier();                                                 // B_j: the X operands of chunk j are there, raw G of chunk j+1 too
-            const int buf = j & 1;
-            split_a();
-            load_b(0, buf);
-            mfmas(0);
-            load_b(1, buf);
-            gstage = gstage + 1 == NS + 1 ? 0 : gstage + 1;
-            read_raw_a(gstage);                                                  // raw G of chunk j+1 (unused after the last chunk)
-            mfmas(1);
+        if (nk > 0) {                                                            // chunk 0 is scaled and split up front
+            read_raw_a(0);
+            split_exp(W16_I(0), true); split_exp(W16_I(1), true);
+            split_pair(W16_I(0), W16_I(0), W16_I(0)); split_pair(W16_I(0), W16_I(0), W16_I(1)); split_pair(W16_I(0), W16_I(0), W16_I(2)); split_pair(W16_I(0), W16_I(0), W16_I(3));
+            split_pair(W16_I(0), W16_I(1), W16_I(0)); split_pair(W16_I(0), W16_I(1), W16_I(1)); split_pair(W16_I(0), W16_I(1), W16_I(2)); split_pair(W16_I(0), W16_I(1), W16_I(3));
         }
+        for (int j = 0; j < nk; j += 2) {
+            w16_lgkm0_barrier();                                                 // B_j: the X operands of chunk j are there, raw G of chunk j+1 too
+            gstage = gstage + 1 == NS + 1 ? 0 : gstage + 1;
+            step(W16_I(0), j + 1 < nk, 0, gstage);
+            if (j + 1 < nk) {
+                w16_lgkm0_barrier();                                             // B_{j+1}
+                gstage = gstage + 1 == NS + 1 ? 0 : gstage + 1;
+                step(W16_I(1), j + 2 < nk, 1, gstage);
+            }
+        }
+        follow_rows();                                                           // (a change decided with the last split has nothing to follow: no-op)
         // undo the scales: accumulator (row, column) is in units of 2^(gexp[row] + bcur[column])
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
@@ -338,6 +418,7 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int n = 0; n < 2; ++n) acc[h][mi][n][r] = __builtin_ldexpf(acc[h][mi][n][r], -(gr + bcur[h][n]));
+                __builtin_amdgcn_sched_barrier(0);
             }
         if (do_bias && wcc == 0) {
 #pragma unroll

@@ -41,6 +41,10 @@ _HELPERS = {
         ("pcd_vmax", "static inline float pcd_vmax(const float a, const float b) { return a > b ? a : b; }\n"),
         ("pcd_max_quad_neighbour", "static inline float pcd_max_quad_neighbour(const float m) { const float o = sim_read_lane(m, (threadIdx.x & 63) ^ 1); return m > o ? m : o; }\n"),
         ("pcd_split2_pair", _SPLIT2.format(n="pcd_split2_pair"))],
+    "wgrad_pc16.hip": [
+        ("w16_max_halves", "static inline float w16_max_halves(const float m) { const float o = sim_read_lane(m, (threadIdx.x & 63) ^ 32); return m > o ? m : o; }\n"),
+        ("w16_max_neighbour", "static inline float w16_max_neighbour(const float m) { const float o = sim_read_lane(m, (threadIdx.x & 63) ^ 1); return m > o ? m : o; }\n"),
+        ("w16_split2_pair", _SPLIT2.format(n="w16_split2_pair"))],
     "gemm_coop.hip": [
         ("co_vmax", "static inline float co_vmax(const float a, const float b) { return a > b ? a : b; }\n"),
         ("co_quad_max", "static inline float co_quad_max(const float m) { float o = sim_read_lane(m, (threadIdx.x & 63) ^ 1); const float t = m > o ? m : o; "
