@@ -142,16 +142,32 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc_kernel(const sep_wgrad_des
         }
 #pragma unroll
         for (int q = 0; q < PX; ++q) voffX[q] = 4u * (unsigned)((n0 + 16 * (pw + 4 * q) + r16) * d.ldt + 4 * cch);
-        int ib = (int)(c_begin / cps_t), it = (int)(c_begin % cps_t);            // (sample, frame chunk) of the next chunk to issue
+        // Source pointers of the NEXT chunk to fetch, one per DMA piece, advanced by 16 frames per chunk (or to the next sample's rows): formed
+        // afresh from (sample, chunk) for every piece, the 64-bit scalar multiplies made the twelve DMA instructions of a chunk pair cost
+        // 1300 - 2300 cycles of one producer wave, with the consumers waiting at the barrier behind it (s_memtime stamps, tools/wpc16_prof.py)
+        int it = (int)(c_begin % cps_t);
         int ci = 0, cst = 0, gst = 0;
+        const float* pG[PG];
+        long wrapG[PG];
+#pragma unroll
+        for (int q = 0; q < PG; ++q) {
+            pG[q] = srcG[q] + (size_t)(c_begin / cps_t) * MgOf[q] * d.ldt + it * DK;
+            wrapG[q] = (long)MgOf[q] * d.ldt - (long)(cps_t - 1) * DK;
+        }
+        const float* pX = d.X + (size_t)(c_begin / cps_t) * d.N * d.ldt + it * DK;
+        const long wrapX = (long)d.N * d.ldt - (long)(cps_t - 1) * DK;
         auto issue = [&]() {
 #pragma unroll
             for (int q = 0; q < PG; ++q)
-                glds16_asm(srcG[q] + (size_t)ib * MgOf[q] * d.ldt + it * DK, voffG[q], lds_addr(&sm.Gr[gst][16 * (pw + 4 * q) * DK]));
+                glds16_asm(pG[q], voffG[q], lds_addr(&sm.Gr[gst][16 * (pw + 4 * q) * DK]));
 #pragma unroll
             for (int q = 0; q < PX; ++q)
-                glds16_asm(d.X + (size_t)ib * d.N * d.ldt + it * DK, voffX[q], lds_addr(&sm.Xr[cst][16 * (pw + 4 * q) * DK]));
-            if (++it >= cps_t) { it = 0; ++ib; }
+                glds16_asm(pX, voffX[q], lds_addr(&sm.Xr[cst][16 * (pw + 4 * q) * DK]));
+            const bool wrap = ++it >= cps_t;                                     // the next chunk is the first of the next sample
+            if (wrap) it = 0;
+#pragma unroll
+            for (int q = 0; q < PG; ++q) pG[q] += wrap ? wrapG[q] : (long)DK;
+            pX += wrap ? wrapX : (long)DK;
             ++ci;
             cst = cst + 1 == NS ? 0 : cst + 1;
             gst = gst + 1 == NS + 1 ? 0 : gst + 1;

@@ -21,6 +21,14 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifdef WPC16_PROF
+__device__ long long g_wpc_step[2][64][8];
+#define W16STAMP(role, s) do { if (bid == 100 && (wid & 3) == 1 && lane == 0 && j < 64) g_wpc_step[role][j][s] = clock64(); } while (0)
+extern "C" int sep_debug_wpc_step(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wpc_step), sizeof(long long) * 2 * 64 * 8) == hipSuccess ? 0 : -1; }
+#else
+#define W16STAMP(role, s) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int W16MAXB = 256;      // samples whose gLN constants fit the LDS table
@@ -56,8 +64,11 @@ __device__ __forceinline__ void w16_lgkm0_barrier() {
 // Single-instruction forms (see gemm_pc.hip): the maximum with the lane 32 away as one v_permlane32_swap (no LDS round trip in the middle
 // of the MFMA stream), with the neighbouring lane as one v_max_f32_dpp, and lo = x - float(hi half) as one mixed-precision FMA.
 __device__ __forceinline__ float w16_max_halves(const float m) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, m), false, false);
-    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+    // v_permlane32_swap exchanges lanes 32-63 of its first operand with lanes 0-31 of its second: the operands must be two REGISTERS (the
+    // builtin, handed the same value twice, was given one register by hipcc and returned garbage: tools/w16_probe.hip), hence the copy in asm
+    unsigned a = __builtin_bit_cast(unsigned, m), b;
+    asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "=&v"(b));
+    return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
 }
 __device__ __forceinline__ float w16_max_neighbour(const float m) {      // max(m, m of lane ^ 1)
     float r;
@@ -148,16 +159,32 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
         }
 #pragma unroll
         for (int q = 0; q < PX; ++q) voffX[q] = 4u * (unsigned)((n0 + 16 * (pw + 4 * q) + r16) * d.ldt + 4 * cch);
-        int ib = (int)(c_begin / cps_t), it = (int)(c_begin % cps_t);
+        // Source pointers of the NEXT chunk to fetch, one per DMA piece, advanced by 16 frames per chunk (or to the next sample's rows): formed
+        // afresh from (sample, chunk) for every piece, the 64-bit scalar multiplies made the twelve DMA instructions of a chunk pair cost
+        // 1300 - 2300 cycles of one producer wave, with the consumers waiting at the barrier behind it (s_memtime stamps, tools/wpc16_prof.py)
+        int it = (int)(c_begin % cps_t);
         int ci = 0, cst = 0, gst = 0;
+        const float* pG[PG];
+        long wrapG[PG];
+#pragma unroll
+        for (int q = 0; q < PG; ++q) {
+            pG[q] = srcG[q] + (size_t)(c_begin / cps_t) * MgOf[q] * d.ldt + it * DK;
+            wrapG[q] = (long)MgOf[q] * d.ldt - (long)(cps_t - 1) * DK;
+        }
+        const float* pX = d.X + (size_t)(c_begin / cps_t) * d.N * d.ldt + it * DK;
+        const long wrapX = (long)d.N * d.ldt - (long)(cps_t - 1) * DK;
         auto issue = [&]() {
 #pragma unroll
             for (int q = 0; q < PG; ++q)
-                glds16_asm(srcG[q] + (size_t)ib * MgOf[q] * d.ldt + it * DK, voffG[q], lds_addr(&sm.Gr[gst][16 * (pw + 4 * q) * DK]));
+                glds16_asm(pG[q], voffG[q], lds_addr(&sm.Gr[gst][16 * (pw + 4 * q) * DK]));
 #pragma unroll
             for (int q = 0; q < PX; ++q)
-                glds16_asm(d.X + (size_t)ib * d.N * d.ldt + it * DK, voffX[q], lds_addr(&sm.Xr[cst][16 * (pw + 4 * q) * DK]));
-            if (++it >= cps_t) { it = 0; ++ib; }
+                glds16_asm(pX, voffX[q], lds_addr(&sm.Xr[cst][16 * (pw + 4 * q) * DK]));
+            const bool wrap = ++it >= cps_t;                                     // the next chunk is the first of the next sample
+            if (wrap) it = 0;
+#pragma unroll
+            for (int q = 0; q < PG; ++q) pG[q] += wrap ? wrapG[q] : (long)DK;
+            pX += wrap ? wrapX : (long)DK;
             ++ci;
             cst = cst + 1 == NS ? 0 : cst + 1;
             gst = gst + 1 == NS + 1 ? 0 : gst + 1;
@@ -197,6 +224,7 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
 
         int stage = 0;
         for (int j = 0; j < nk; ++j) {
+            W16STAMP(1, 0);
             const float* Xb = sm.Xr[stage];
             float* Xp = &sm.Xp[j & 1][0][0];
             float sc = 1.f, sh = 0.f;
@@ -230,14 +258,21 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
             }
             sm.xe[j & 1][x_row] = xexp;                                          // (both halves of a row store the same word)
             if (++ct >= cps_t) { ct = 0; ++cb; }
+            W16STAMP(1, 1);
+#ifdef WPC16_PROF
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            W16STAMP(1, 2);
+#endif
             // raw chunk j+1 has landed -- mine: all but the newer chunks; everyone's: the barrier -- and the operands of chunk j are written.
             // Chunks are fetched in PAIRS behind the odd barriers (wgrad_pc.hip: one HBM fetch per 128-byte line).
             if (j & 1) { if (j + 3 <= nk) w16_wait_barrier<G>(); else w16_wait_barrier<0>(); }
             else { if (j + 4 <= nk) w16_wait_barrier<2 * G>(); else w16_wait_barrier<0>(); }
+            W16STAMP(1, 3);
             if (j & 1) {
                 if (ci < nk) issue();
                 if (ci < nk) issue();
             }
+            W16STAMP(1, 4);
             stage = stage + 1 == NS ? 0 : stage + 1;
         }
     } else {
@@ -398,13 +433,18 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
             split_pair(W16_I(0), W16_I(1), W16_I(0)); split_pair(W16_I(0), W16_I(1), W16_I(1)); split_pair(W16_I(0), W16_I(1), W16_I(2)); split_pair(W16_I(0), W16_I(1), W16_I(3));
         }
         for (int j = 0; j < nk; j += 2) {
+            W16STAMP(0, 0);
             w16_lgkm0_barrier();                                                 // B_j: the X operands of chunk j are there, raw G of chunk j+1 too
+            W16STAMP(0, 1);
             gstage = gstage + 1 == NS + 1 ? 0 : gstage + 1;
             step(W16_I(0), j + 1 < nk, 0, gstage);
+            W16STAMP(0, 2);
             if (j + 1 < nk) {
                 w16_lgkm0_barrier();                                             // B_{j+1}
+                W16STAMP(0, 3);
                 gstage = gstage + 1 == NS + 1 ? 0 : gstage + 1;
                 step(W16_I(1), j + 2 < nk, 1, gstage);
+                W16STAMP(0, 4);
             }
         }
         follow_rows();                                                           // (a change decided with the last split has nothing to follow: no-op)
