@@ -523,13 +523,36 @@ def bench_dual_path(args):
     src = (0.1 * torch.randn(B, 2, T_SAMPLES, generator=torch.Generator().manual_seed(111))).to(dev)
     mix = src.sum(1, keepdim=True).contiguous()
 
+    use_graph = os.environ.get("SEPK_GRAPH", "0") == "1" and not args.no_graph
+    if use_graph:
+        opt = torch.optim.Adam(model.parameters(), capturable=True, **adam)
+
     def step():
-        opt.zero_grad(set_to_none=True)
+        opt.zero_grad(set_to_none=not use_graph)
         loss, _ = crit(model(mix), src)
         loss.backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
         opt.step()
         return loss.detach()
+    launch = "eager (one launch per kernel)"
+    if use_graph:
+        # The dual-path steps are launch-bound (hundreds of short kernels around the LSTM sweeps): the whole step -- forward, PIT, backward,
+        # clip, Adam -- recorded once into a hipGraph and replayed (SEPK_GRAPH=1; shapes are fixed, nothing in the step reads back to the host)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_loss = step()
+        eager_step = step
+
+        def step():
+            graph.replay()
+            return static_loss
+        launch = "hipGraph replay of the captured step"
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -542,7 +565,7 @@ def bench_dual_path(args):
     F = (T_SAMPLES + (S - (T_SAMPLES - L) % S) % S - L) // S + 1
     config = {"workload": "{}, 2 spk, 4 s @ 8 kHz synthetic mixtures, batch {} (recipe default), fwd + PIT(NegSI-SDR) + bwd + clip(5) + Adam".format(label, B),
               "global_batch": B, "frames_per_utterance": F, "parallelism": "dp1", "utt_per_s": B * args.steps / el, "final_loss": float(loss),
-              "parameters": model.num_parameters}
+              "parameters": model.num_parameters, "launch": launch}
     note = "no roofline: the step is a sequence of library GEMM / attention calls between this library's kernels, none of which dominates"
     if gflop is not None:
         config["algorithmic_gflop_per_utterance_fwd_bwd"] = gflop

@@ -615,6 +615,68 @@ __global__ __launch_bounds__(256) void gln_bwd_finalize_sample_kernel(const floa
     }
 }
 
+// The same two stages for up to 64 gLNs in ONE launch each (the Conv-TasNet step queues the second stages of all its layers -- leaves of
+// the backward pass -- and flushes them together: 2 launches instead of 2 per layer).
+constexpr int FMAXSEG = 64;
+struct FinalizeArgs {
+    sep_finalize_seg seg[FMAXSEG];
+    int blk_start[FMAXSEG + 1];
+    int nseg;
+};
+__global__ __launch_bounds__(256) void gln_bwd_finalize_rows_batch_kernel(const FinalizeArgs a) {
+    int sgi = 0;
+    while (sgi + 1 < a.nseg && (int)blockIdx.x >= a.blk_start[sgi + 1]) ++sgi;
+    const sep_finalize_seg sg = a.seg[sgi];
+    const int lane = threadIdx.x & 63;
+    const long row = (long)((int)blockIdx.x - a.blk_start[sgi]) * 4 + (threadIdx.x >> 6);      // b*C + c
+    if (row >= (long)sg.B * sg.C) return;
+    const int b = (int)(row / sg.C), c = (int)(row % sg.C);
+    float mu, rstd;
+    gln_mu_rstd(sg.stats + (size_t)b * SEP_STATS_SLOTS * 2, sg.count, sg.eps, mu, rstd);
+    const int rowlen = sg.ntile * sg.nq;
+    const float* rp = sg.rowpart + (size_t)row * rowlen;
+    float acc = 0.f;
+    for (int i = lane; i < rowlen; i += 64) acc += rp[i];            // i % nq == lane % nq (nq divides 64)
+    for (int o = sg.nq; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    const float R1 = __shfl(acc, 0, 64), R2 = __shfl(acc, 1, 64);
+    if (lane == 0) {
+        sg.pbeta[row] = R1;
+        sg.pgamma[row] = rstd * (R2 - mu * R1);
+    }
+    if (sg.nq == 8) {
+        float* scratch = sg.pextra + (size_t)sg.B * sg.C * 4 + sg.B;
+        if (lane == 2) sg.pextra[(size_t)b * 4 * sg.C + c] = acc;
+        if (lane >= 3 && lane < 6) sg.pextra[(size_t)b * 4 * sg.C + sg.C + (size_t)c * 3 + (lane - 3)] = acc;
+        if (lane == 6) scratch[row] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void gln_bwd_finalize_sample_batch_kernel(const FinalizeArgs a) {
+    __shared__ double red[4];
+    int sgi = 0;
+    while (sgi + 1 < a.nseg && (int)blockIdx.x >= a.blk_start[sgi + 1]) ++sgi;      // (blk_start counts samples here)
+    const sep_finalize_seg sg = a.seg[sgi];
+    const int b = (int)blockIdx.x - a.blk_start[sgi];
+    const bool slopes = sg.nq == 8;
+    const float* scratch = slopes ? sg.pextra + (size_t)sg.B * sg.C * 4 + sg.B : nullptr;
+    double sg1 = 0.0, sgx = 0.0, sal = 0.0;
+    for (int c = threadIdx.x; c < sg.C; c += 256) {
+        const float gc = sg.gamma[c];
+        sg1 += (double)(gc * sg.pbeta[(size_t)b * sg.C + c]);
+        sgx += (double)(gc * sg.pgamma[(size_t)b * sg.C + c]);
+        if (slopes) sal += (double)scratch[(size_t)b * sg.C + c];
+    }
+    const double tg = block_sum_256<double>(sg1, red);
+    const double tgx = block_sum_256<double>(sgx, red);
+    const double tal = block_sum_256<double>(sal, red);
+    if (threadIdx.x == 0) {
+        if (sg.bsum) {
+            sg.bsum[2 * b] = (float)(tg / sg.count);
+            sg.bsum[2 * b + 1] = (float)(tgx / sg.count);
+        }
+        if (slopes) sg.pextra[(size_t)sg.B * sg.C * 4 + b] = (float)tal;
+    }
+}
+
 // =====================================================================================
 // gLN backward statistics FROM the weight gradient.  For a product y = W v (1x1 convolution) behind v = gLN(u), u = PReLU(z), the
 // gradient arriving at v is dv = W^T g, and the two row sums the gLN backward needs are contractions the weight gradient has
@@ -1227,6 +1289,29 @@ extern "C" int sep_gln_bwd_finalize(const float* rowpart, int ntile, int nq, con
     if (bsum || palpha)      // the per-sample stage: the means (stand-alone gLN backward) and / or the PReLU slope partials
         hipLaunchKernelGGL(gln_bwd_finalize_sample_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pbeta, pgamma, gamma, scratch, count, bsum, palpha, C);
     SEP_CHECK_LAUNCH("sep_gln_bwd_finalize");
+    return 0;
+}
+
+extern "C" int sep_gln_bwd_finalize_batch(const sep_finalize_seg* segs, int nseg, sep_stream_t stream) {
+    SEP_REQUIRE(segs && nseg >= 1 && nseg <= FMAXSEG, "sep_gln_bwd_finalize_batch: 1..64 segments per launch (got %d)", nseg);
+    FinalizeArgs rows, samples;
+    int rb = 0, sb = 0;
+    bool any_sample = false;
+    for (int i = 0; i < nseg; ++i) {
+        const sep_finalize_seg& g = segs[i];
+        SEP_REQUIRE(g.rowpart && g.stats && g.gamma && g.pbeta && g.pgamma && (g.nq == 2 || (g.nq == 8 && g.pextra)) && g.B > 0 && g.C > 0 && g.ntile > 0,
+                    "sep_gln_bwd_finalize_batch: bad segment %d", i);
+        rows.seg[i] = g; samples.seg[i] = g;
+        rows.blk_start[i] = rb; samples.blk_start[i] = sb;
+        rb += (int)(((long)g.B * g.C + 3) / 4);
+        sb += (g.bsum || g.nq == 8) ? g.B : 0;           // segments that need no per-sample stage take no blocks of it
+        any_sample |= (g.bsum || g.nq == 8);
+    }
+    rows.blk_start[nseg] = rb; samples.blk_start[nseg] = sb;
+    rows.nseg = samples.nseg = nseg;
+    hipLaunchKernelGGL(gln_bwd_finalize_rows_batch_kernel, dim3(rb), dim3(256), 0, (hipStream_t)stream, rows);
+    if (any_sample) hipLaunchKernelGGL(gln_bwd_finalize_sample_batch_kernel, dim3(sb), dim3(256), 0, (hipStream_t)stream, samples);
+    SEP_CHECK_LAUNCH("sep_gln_bwd_finalize_batch");
     return 0;
 }
 

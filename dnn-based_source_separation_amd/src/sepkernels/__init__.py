@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("SEPKERNELS_LIB", os.path.normpath(os.path.join(_HERE,
 # ---- constants mirrored from include/sepkernels.h -------------------------------------------------
 PRO_NONE, PRO_PRELU, PRO_GLN, PRO_GLN_PRELU, PRO_GLN_BWD = 0, 1, 2, 3, 4
 EPI_STATS_PRELU, EPI_RESIDUAL, EPI_SIGMOID, EPI_PRELU_BWD, EPI_ROWSUMS, EPI_ROWSUMS_PRELU = 1, 2, 4, 8, 16, 32
-ABI_VERSION = 15
+ABI_VERSION = 16
 STATS_SLOTS = 16   # SEP_STATS_SLOTS: gLN statistics are double[B][STATS_SLOTS][2]
 ARRIVE_INTS = 17   # SEP_ARRIVE_INTS: arrival counters of the gLN-backward publishers, int[B][ARRIVE_INTS]
 ARITH_F32, ARITH_BF16X6, ARITH_F16X3 = 0, 1, 2     # SEP_ARITH_*: how sep_pw_gemm forms its fp32 products (include/sepkernels.h)
@@ -95,6 +95,11 @@ class PackedA:
         self.data, self.rscale, self.M, self.K, self.src = data, rscale, M, K, src
 
 
+class FinalizeSeg(ctypes.Structure):
+    _fields_ = [(n, _vp) for n in ("rowpart", "stats", "gamma", "bsum", "pbeta", "pgamma", "pextra")] + [("count", ctypes.c_double), ("eps", ctypes.c_float)] + \
+               [(n, _i32) for n in ("ntile", "nq", "B", "C")]
+
+
 class ReduceSeg(ctypes.Structure):
     _fields_ = [("src", _vp), ("dst", _vp), ("n", _i32), ("nslab", _i32), ("stride", ctypes.c_int64),
                 ("accumulate", _i32), ("scale", ctypes.c_float)]
@@ -115,6 +120,7 @@ SIGNATURES = {
     "sep_dwconv_fwd": [_vp] * 10 + [_I] * 5 + [_F, _vp],
     "sep_dwconv_bwd": [_vp] * 17 + [_I] * 5 + [_F, _vp],
     "sep_gln_bwd_finalize": [_vp, _I, _I, _vp, _vp, _D, _F, _vp, _vp, _vp, _vp, _I, _I, _vp],
+    "sep_gln_bwd_finalize_batch": [ctypes.POINTER(FinalizeSeg), _I, _vp],
     "sep_gln_bwd_from_wgrad": [_vp] * 6 + [_D, _F] + [_vp] * 6 + [_I] * 6 + [_vp],
     "sep_head_bwd": [_vp] * 6 + [_I] * 4 + [_D, _F, _I, _vp],
     "sep_decoder_fwd": [_vp] * 5 + [_I] * 10 + [_vp],
@@ -304,6 +310,18 @@ class HipBackend:
         _check(load().sep_gln_bwd_finalize(_ptr(rowpart, _f32), ntile, nq, _ptr(stats, _f64), _ptr(gamma, _f32), float(count), eps,
                                            _ptr(bsum, _f32), _ptr(pbeta, _f32), _ptr(pgamma, _f32), _ptr(pextra, _f32), B, C,
                                            _stream()), "sep_gln_bwd_finalize")
+
+    def gln_bwd_finalize_batch(self, segs):
+        """segs: list of (rowpart, ntile, nq, stats, gamma, count, eps, bsum, pbeta, pgamma, pextra, B, C) -- sep_gln_bwd_finalize's arguments"""
+        lib = load()
+        for i in range(0, len(segs), 64):
+            chunk = segs[i:i + 64]
+            arr = (FinalizeSeg * len(chunk))()
+            for k, (rowpart, ntile, nq, stats, gamma, count, eps, bsum, pbeta, pgamma, pextra, B, C) in enumerate(chunk):
+                arr[k] = FinalizeSeg(rowpart=_ptr(rowpart, _f32), stats=_ptr(stats, _f64), gamma=_ptr(gamma, _f32), bsum=_ptr(bsum, _f32),
+                                     pbeta=_ptr(pbeta, _f32), pgamma=_ptr(pgamma, _f32), pextra=_ptr(pextra, _f32), count=float(count), eps=eps,
+                                     ntile=ntile, nq=nq, B=B, C=C)
+            _check(lib.sep_gln_bwd_finalize_batch(arr, len(chunk), _stream()), "sep_gln_bwd_finalize_batch")
 
     def gln_bwd_from_wgrad(self, part, part_bias, W, stats, gamma, beta, count, eps, dW_b, pbeta, pgamma, bacc, arrive, bsum, B, M, N,
                            slabs_per_sample, accumulate=0, products=1):

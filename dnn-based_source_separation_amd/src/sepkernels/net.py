@@ -497,6 +497,7 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
     # Price: the slabs of all layers stay alive until the flush (~1.6 GB at B=16 paper-best; HBM is 288 GB).
     pending = []
     deferred = []                  # leaves of the layer just differentiated, queued on the side stream behind the next layer's hand-off
+    finals = []                    # queued sep_gln_bwd_finalize calls (flushed with `pending`, in front of it)
     flushed_from = nl + 1          # dalpha entries [flushed_from, nl] are already converted (bucketed mode)
     dout = None
     for li in range(nl - 1, -1, -1):
@@ -589,10 +590,12 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
         side.fork()
         side.keep(da, dx, rp1, pbeta1, pgamma1, pextra)
 
-        def conv1_leaves(da=da, x=x, rp1=rp1, st1=st1, g1=g1, pbeta1=pbeta1, pgamma1=pgamma1, pextra=pextra, pre=pre):
-            """this layer's leaves: second stage of gLN1's backward (parameter gradients only) and the conv1 weight gradient"""
+        # second stage of gLN1's backward (parameter gradients only: a leaf): queued, all layers of a flush go out in one launch per stage
+        finals.append((rp1, nt1024, 8, st1, g1, cnt, teps, None, pbeta1, pgamma1, pextra, B, H))
+
+        def conv1_leaves(da=da, x=x, pre=pre):
+            """this layer's leaf on the side stream: the conv1 weight gradient"""
             with side:
-                K.gln_bwd_finalize(rp1, nt1024, 8, st1, g1, cnt, teps, None, pbeta1, pgamma1, pextra, B, H)
                 part, pb, ns = wgrad(H, Bn, da, x, True, True)
                 segs = [(part, 0, G[pre + "bottleneck_conv1d.weight"], H * Bn, ns, H * Bn, 0, 1.0),
                         (pb, 0, G[pre + "bottleneck_conv1d.bias"], H, ns, H, 0, 1.0)]
@@ -618,6 +621,8 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
             pending += [(d32, q - lo, G[layers[q][0] + "nonlinear1d.weight"], 1, 1, 1, 0, 1.0) for q in range(lo, min(hi, nl))]
             if hi == nl + 1:
                 pending.append((d32, nl - lo, G["separator.prelu.weight"], 1, 1, 1, 0, 1.0))
+            K.gln_bwd_finalize_batch(finals)
+            finals = []
             K.reduce_slabs(pending)
             pending = []
             flushed_from = lo
@@ -633,6 +638,8 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
     pending += [(dal32, li, G[layers[li][0] + "nonlinear1d.weight"], 1, 1, 1, 0, 1.0) for li in range(min(rest, nl))]
     if rest == nl + 1:
         pending.append((dal32, nl, G["separator.prelu.weight"], 1, 1, 1, 0, 1.0))
+    if finals:
+        K.gln_bwd_finalize_batch(finals)
     K.reduce_slabs(pending)
 
     # ---- head: bottleneck conv, first gLN, encoder ------------------------------------------------------

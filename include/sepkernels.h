@@ -33,7 +33,7 @@ extern "C" {
 
 typedef void* sep_stream_t; /* hipStream_t */
 
-#define SEP_ABI_VERSION 15
+#define SEP_ABI_VERSION 16
 #define SEP_STATS_SLOTS 16
 #define SEP_ARRIVE_INTS 17 /* arrival counters per sample: one per slot + one for the slots (csrc/common.hpp, gln_bwd_publish) */
 
@@ -237,6 +237,21 @@ int sep_dwconv_bwd(const float* dv2, const float* z, const float* a, const doubl
 int sep_gln_bwd_finalize(const float* rowpart, int ntile, int nq, const double* stats, const float* gamma, double count,
                          float eps, float* bsum, float* pbeta, float* pgamma, float* pextra, int B, int C,
                          sep_stream_t stream);
+
+/* sep_gln_bwd_finalize for up to 64 gLNs in one launch per stage (same outputs; bsum may be NULL per segment). */
+typedef struct sep_finalize_seg {
+    const float* rowpart;
+    const double* stats;
+    const float* gamma;
+    float* bsum;
+    float* pbeta;
+    float* pgamma;
+    float* pextra;
+    double count;
+    float eps;
+    int32_t ntile, nq, B, C;
+} sep_finalize_seg;
+int sep_gln_bwd_finalize_batch(const sep_finalize_seg* segs_host, int nseg, sep_stream_t stream);
 
 /* gLN backward statistics FROM the weight gradient (round 3).  For y = W v with v = gLN(u), u = PReLU(z): the gradient at v is
  * dv = W^T g, and the row sums its gLN backward needs are contractions the weight gradient has already done,

@@ -359,6 +359,10 @@ class EmuBackend:
             pe[B * 4 * C:B * 4 * C + B] = rp[..., 6].sum(1)
             pe[B * 4 * C + B:B * 4 * C + B + B * C] = rp[..., 6].reshape(-1)      # per-row scratch of the two-kernel finalize
 
+    def gln_bwd_finalize_batch(self, segs):
+        for sg in segs:
+            self.gln_bwd_finalize(*sg)
+
     def gln_bwd_from_wgrad(self, part, part_bias, W, stats, gamma, beta, count, eps, dW_b, pbeta, pgamma, bacc, arrive, bsum, B, M, N,
                            slabs_per_sample, accumulate=0, products=1):
         dt = part.dtype

@@ -695,6 +695,30 @@ def test_gln_bwd_finalize(nq, ntile):
     both("gln_bwd_finalize", [rp, ntile, nq, st, rnd(C) + 1, C * 50.0, 1e-12, None, nan(B, C), nan(B, C), pextra, B, C])      # without the means
 
 
+def test_gln_bwd_finalize_batch():
+    """several gLNs' second stages in one launch per stage (what the Conv-TasNet step flushes at the end of its backward pass): mixed nq,
+    sizes, with and without the means"""
+    def seg(B, C, ntile, nq, with_bsum):
+        x = rnd(B, C, 50)
+        return [rnd(B, C, ntile, nq), ntile, nq, stats_of(x, 50), rnd(C) + 1, C * 50.0, 1e-12, nan(B, 2) if with_bsum else None, nan(B, C), nan(B, C),
+                nan(B * 4 * C + B + B * C) if nq == 8 else None, B, C]
+    segs = [seg(3, 96, 4, 8, False), seg(2, 40, 8, 2, True), seg(1, 130, 1, 8, True), seg(4, 16, 64, 2, False)]
+    gsegs = [[to_device(v) if torch.is_tensor(v) else v for v in sg] for sg in segs]
+    EMU.gln_bwd_finalize_batch([tuple(sg) for sg in segs])
+    HIP.gln_bwd_finalize_batch([tuple(sg) for sg in gsegs])
+    device_sync()
+    for sg, gg in zip(segs, gsegs):
+        for i in (7, 8, 9, 10):
+            if sg[i] is None:
+                continue
+            c, g = sg[i], gg[i].cpu()
+            if i == 10:                      # the trailing B*C floats are scratch of the two-stage form
+                n = sg[11] * 4 * sg[12] + sg[11]
+                c, g = c[:n], g[:n]
+            assert torch.isfinite(g).all(), i
+            assert (c.double() - g.double()).abs().max() <= 2e-4 * c.double().abs().max() + 1e-30, i
+
+
 @pytest.mark.parametrize("relu", [0, 1])
 def test_head_bwd(relu):
     B, C, T, ldt = 2, 64, 300, 384

@@ -28,6 +28,7 @@ CASES = [
     ("test_dwconv_fwd_bwd", [(300, 8), (1030, 64), (2100, 256)]),
     ("test_depthwise_generic", [(5, 2, 4, 2, 130), (4, 4, 0, 1, 64)]),
     ("test_gln_bwd_finalize", [(2, 8), (8, 1)]),
+    ("test_gln_bwd_finalize_batch", [()]),
     ("test_head_bwd", [(0,), (1,)]),
     ("test_decoder_fwd_bwd", [(2, 1, 16, 8, 0, True), (3, 1, 16, 8, 3, False), (5, 1, 16, 8, 0, False), (4, 1, 16, 8, 5, True), (2, 2, 20, 10, 4, True),
                               (2, 1, 2, 1, 0, False), (1, 1, 64, 16, 0, False)]),
