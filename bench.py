@@ -523,36 +523,16 @@ def bench_dual_path(args):
     src = (0.1 * torch.randn(B, 2, T_SAMPLES, generator=torch.Generator().manual_seed(111))).to(dev)
     mix = src.sum(1, keepdim=True).contiguous()
 
-    use_graph = os.environ.get("SEPK_GRAPH", "0") == "1" and not args.no_graph
-    if use_graph:
-        opt = torch.optim.Adam(model.parameters(), capturable=True, **adam)
-
+    # (Recording the whole step into a hipGraph was measured in round 3 -- DPRNN-TasNet 57.9 vs 56.5 ms eager, DPTNet 58.4 vs 56.3, GALRNet 16.8 vs
+    # 15.9 and a NaN loss from the dropout generator under capture: these steps are no longer launch-bound, and the option is gone.)
     def step():
-        opt.zero_grad(set_to_none=not use_graph)
+        opt.zero_grad(set_to_none=True)
         loss, _ = crit(model(mix), src)
         loss.backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
         opt.step()
         return loss.detach()
     launch = "eager (one launch per kernel)"
-    if use_graph:
-        # The dual-path steps are launch-bound (hundreds of short kernels around the LSTM sweeps): the whole step -- forward, PIT, backward,
-        # clip, Adam -- recorded once into a hipGraph and replayed (SEPK_GRAPH=1; shapes are fixed, nothing in the step reads back to the host)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                step()
-        torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static_loss = step()
-        eager_step = step
-
-        def step():
-            graph.replay()
-            return static_loss
-        launch = "hipGraph replay of the captured step"
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -567,15 +547,22 @@ def bench_dual_path(args):
               "global_batch": B, "frames_per_utterance": F, "parallelism": "dp1", "utt_per_s": B * args.steps / el, "final_loss": float(loss),
               "parameters": model.num_parameters, "launch": launch}
     note = "no roofline: the step is a sequence of library GEMM / attention calls between this library's kernels, none of which dominates"
+    roofline = None
     if gflop is not None:
         config["algorithmic_gflop_per_utterance_fwd_bwd"] = gflop
-        note = "{:.0f} GFLOP per utterance (SURVEY.md 8d): {:.1f} TFLOP/s achieved; 57 % of it in this library's LSTM recurrence kernel " \
-               "(fp32 MFMA), the rest in rocBLAS GEMMs".format(gflop, gflop * 1e9 * B * args.steps / el / 1e12)
+        tf = gflop * 1e9 * B * args.steps / el / 1e12
+        # the step's arithmetic is fp32 throughout (the LSTM recurrences on v_mfma_f32_16x16x4 / 4x4x1, projections on rocBLAS fp32): matrix-pipe roof
+        roofline = {"kernel": "whole step (sep_lstm_fwd / sep_lstm_bwd sweeps ~80 % of it)", "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "what": "algorithmic fp32 FLOP of forward + backward (SURVEY.md 8d: {:.0f} GFLOP per utterance) / step time against the dense fp32 MFMA "
+                            "peak; the recurrences are latency-bound chains (one workgroup per 4 or 16 sequences, a barrier per time step), not "
+                            "throughput-bound".format(gflop)}
+        note = "{:.0f} GFLOP per utterance (SURVEY.md 8d): {:.1f} TFLOP/s achieved".format(gflop, tf)
     print(json.dumps({
         "metric": "separated audio frames/sec (fwd+bwd), {} 2-spk 4s@8kHz".format("DPRNN-TasNet" if args.config == "dprnn" else cls.__name__) +
                   (" (BASELINE configs[3])" if args.config == "dprnn" else ""), "value": B * F * args.steps / el, "unit": "frames/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": config, "roofline": None, "roofline_note": note}))
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": config, "roofline": roofline, "roofline_note": note}))
 
 
 def main():
