@@ -107,8 +107,9 @@ class TimedBackend:
             B, C, T = a[10], a[11], a[12]
             return "depthwise fwd", None, 2.0 * C * 4 * B * T, 2.0 * C * 4 * B * T
         if name == "dwconv_bwd":
-            B, C, T = a[17], a[18], a[19]
-            return "depthwise bwd", None, 4.0 * C * 4 * B * T, 4.0 * C * 4 * B * T
+            B, C, T = a[18], a[19], a[20]
+            # z is formed again from `a` (sep_dwconv_bwd with bd): dv2 and a in, dv1 out; SURVEY 8d counts the z read as well
+            return "depthwise bwd", None, 3.0 * C * 4 * B * T, 4.0 * C * 4 * B * T
         if name == "encoder_fwd":
             B, Tin, N, F = a[4], a[6], a[7], a[10]
             return "encoder fwd", None, 4.0 * B * (N * F + Tin), 4.0 * B * N * F

@@ -336,6 +336,17 @@ __device__ __forceinline__ void glds16_asm(const float* base, unsigned voff, uns
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
 }
+// the same for data a kernel reads exactly once (the activation stream of the forward / input-gradient products): with -DSEPK_DMA_NT the
+// request carries the non-temporal hint, so the stream does not push the packed weights every workgroup re-reads out of the XCD's L2
+__device__ __forceinline__ void glds16_asm_once(const float* base, unsigned voff, unsigned lds_dst) {
+#ifdef SEPK_DMA_NT
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+#else
+    glds16_asm(base, voff, lds_dst);
+#endif
+}
 // same, with a full 64-bit per-lane source address
 __device__ __forceinline__ void glds16_asm_v(const float* gsrc, unsigned lds_dst) {
     unsigned keep;

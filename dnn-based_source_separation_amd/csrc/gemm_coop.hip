@@ -172,8 +172,8 @@ void pw_gemm_coop_kernel(const sep_gemm_desc d) {
     int xi = 0, xst = 0;                       // next chunk to issue and its ring stage
     auto issue_x = [&]() {
         if (SPLIT && xi == split_chunk) baseX = d.X2 + ((size_t)b * (d.K - d.k_split) + 4 * wid) * d.ldt + t0;
-        glds16_asm(baseX, offX, lds_addr(&sm.Bs[xst][wid * RBI]));
-        if (P_BWD) glds16_asm(baseC, offX, lds_addr(&sm.Cs[P_BWD ? xst : 0][wid * RBI]));
+        glds16_asm_once(baseX, offX, lds_addr(&sm.Bs[xst][wid * RBI]));
+        if (P_BWD) glds16_asm_once(baseC, offX, lds_addr(&sm.Cs[P_BWD ? xst : 0][wid * RBI]));
         baseX += stepX;
         if (P_BWD) baseC += stepX;
         ++xi;

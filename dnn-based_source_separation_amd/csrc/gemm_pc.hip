@@ -202,8 +202,8 @@ __global__ __launch_bounds__(512, 2) void pw_gemm_pc_kernel(const sep_gemm_desc 
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const size_t go = (size_t)(8 * hh) * d.ldt + 128 * cc;
-                    glds16_asm(baseX + go, offX, xr_lds + 4u * (unsigned)(st * Smem::WSTG + (2 * cc + hh) * PIECE));
-                    if (P_BWD) glds16_asm(baseC + go, offX, cr_lds + 4u * (unsigned)(st * Smem::WSTG + (2 * cc + hh) * PIECE));
+                    glds16_asm_once(baseX + go, offX, xr_lds + 4u * (unsigned)(st * Smem::WSTG + (2 * cc + hh) * PIECE));
+                    if (P_BWD) glds16_asm_once(baseC + go, offX, cr_lds + 4u * (unsigned)(st * Smem::WSTG + (2 * cc + hh) * PIECE));
                 }
             baseX += stepX;
             if (P_BWD) baseC += stepX;

@@ -415,9 +415,9 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(
 // neighbours); NIT >= ldt / 1024.  Writes the row totals into tile 0 of rowpart and zeros into the other tiles (the
 // finalize kernel sums over tiles).
 // =====================================================================================
-template <bool ALIGNED, int NIT>
+template <bool ALIGNED, int NIT, bool RECOMP>
 __global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
-    const float* __restrict__ dv2, const float* __restrict__ z, const float* __restrict__ a,
+    const float* __restrict__ dv2, const float* __restrict__ z, const float* __restrict__ bd, const float* __restrict__ a,
     const double* __restrict__ stats1, const float* __restrict__ gamma1, const float* __restrict__ beta1,
     const float* __restrict__ alpha1, const double* __restrict__ stats2, const float* __restrict__ gamma2,
     const float* __restrict__ alpha2, const float* __restrict__ bsum2, const float* __restrict__ wd,
@@ -441,14 +441,65 @@ __global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
     float q_dal = 0.f;
     float4 gv[NIT], zv[NIT], av[NIT];
     float uv[NIT][4];
-    // all global reads of the row first: 3 * NIT float4 in flight per thread
+    const float w0 = wd[c * 3 + 0], w1 = wd[c * 3 + 1], w2 = wd[c * 3 + 2];
+    // all global reads of the row first: 3 (RECOMP: 2) * NIT float4 in flight per thread
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
         const int q = threadIdx.x + 256 * k;
         if (q < nq4) {
             gv[k] = ld4(dv2 + rowoff + 4 * q);
-            zv[k] = ld4(z + rowoff + 4 * q);
+            if (!RECOMP) zv[k] = ld4(z + rowoff + 4 * q);
             av[k] = ld4(a + rowoff + 4 * q);
+        }
+    }
+    if (RECOMP) {
+        // z is not read: the row of v1 = gLN1(PReLU1(a)) goes to a second LDS row and z = bd + the three taps is formed again exactly as
+        // dwconv_fwd_direct_kernel formed it (same expression, zero outside [0, T)) -- a quarter of the kernel's HBM bytes for 8 B of LDS
+        // traffic per frame
+        float* v1s = lds + ldt;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int q = threadIdx.x + 256 * k;
+            if (q < nq4) {
+                const int tp = 4 * q;
+                const float a4[4] = {av[k].x, av[k].y, av[k].z, av[k].w};
+                float v4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    uv[k][e] = tp + e < T ? prelu_f(a4[e], a1) : 0.f;
+                    v4[e] = tp + e < T ? fmaf(uv[k][e], sc1, sh1) : 0.f;
+                }
+                st4(v1s + tp, make_float4(v4[0], v4[1], v4[2], v4[3]));
+            }
+        }
+        __syncthreads();
+        const float bb = bd[c];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int q = threadIdx.x + 256 * k;
+            if (q < nq4) {
+                const int t = 4 * q;
+                float lft[4], rgt[4], o[4];
+                if (ALIGNED) {
+                    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 m1 = t - d >= 0 ? ld4(v1s + t - d) : zero4, p1 = t + d < ldt ? ld4(v1s + t + d) : zero4;
+                    lft[0] = m1.x; lft[1] = m1.y; lft[2] = m1.z; lft[3] = m1.w;
+                    rgt[0] = p1.x; rgt[1] = p1.y; rgt[2] = p1.z; rgt[3] = p1.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int tm = t + e - d, tq = t + e + d;
+                        lft[e] = tm >= 0 ? v1s[tm] : 0.f;
+                        rgt[e] = tq < ldt ? v1s[tq] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float ce = t + e < T ? fmaf(uv[k][e], sc1, sh1) : 0.f;
+                    o[e] = t + e < T ? bb + w0 * lft[e] + w1 * ce + w2 * rgt[e] : 0.f;
+                }
+                zv[k] = make_float4(o[0], o[1], o[2], o[3]);
+            }
         }
     }
 #pragma unroll
@@ -462,13 +513,14 @@ __global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
             float dzv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                dzv[e] = 0.f; uv[k][e] = 0.f;
+                dzv[e] = 0.f;
+                if (!RECOMP) uv[k][e] = 0.f;
                 if (tp + e < T) {
                     const float u2 = prelu_f(z4[e], a2);
                     const float xh = (u2 - mu2) * r2;
                     const float du2 = r2 * (g2 * g4[e] - mg - xh * mgx);
                     dzv[e] = du2 * prelu_grad(z4[e], a2);
-                    uv[k][e] = prelu_f(a4[e], a1);
+                    if (!RECOMP) uv[k][e] = prelu_f(a4[e], a1);
                     if (z4[e] <= 0.f) q_dal = fmaf(du2, z4[e], q_dal);
                 }
             }
@@ -476,7 +528,6 @@ __global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
         }
     }
     __syncthreads();
-    const float w0 = wd[c * 3 + 0], w1 = wd[c * 3 + 1], w2 = wd[c * 3 + 2];
     float* orow = dv1 + rowoff;
     float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f, q4 = 0.f, q5 = 0.f;
 #pragma unroll
@@ -1250,19 +1301,24 @@ extern "C" int sep_dwconv_fwd(const float* a, const double* stats1, const float*
 
 extern "C" int sep_dwconv_bwd(const float* dv2, const float* z, const float* a, const double* stats1, const float* gamma1,
                               const float* beta1, const float* alpha1, const double* stats2, const float* gamma2,
-                              const float* alpha2, const float* bsum2, const float* wd, float* dv1, float* rowpart,
+                              const float* alpha2, const float* bsum2, const float* wd, const float* bd, float* dv1, float* rowpart,
                               double* bacc1, int* arrive1, float* bsum1, int B, int C, int T, int ldt, int dilation, float eps, sep_stream_t stream) {
     SEP_REQUIRE(dv2 && z && a && stats1 && gamma1 && beta1 && alpha1 && stats2 && gamma2 && alpha2 && bsum2 && wd && dv1 && rowpart, "sep_dwconv_bwd: null pointer");
     SEP_REQUIRE((arrive1 == nullptr) == (bsum1 == nullptr) && (bacc1 != nullptr || arrive1 == nullptr), "sep_dwconv_bwd: arrive1 and bsum1 come together and need bacc1");
     SEP_REQUIRE(B > 0 && C > 0 && T > 0 && ldt % 128 == 0 && ldt >= T, "sep_dwconv_bwd: bad sizes");
     SEP_REQUIRE(dilation >= 1 && dilation <= 2048, "sep_dwconv_bwd: dilation %d out of range [1, 2048]", dilation);
     static const bool force_tiles = getenv("SEPK_DWCONV_LDS") != nullptr;
+    static const bool no_recompute = getenv("SEPK_DWB_RECOMPUTE") != nullptr && atoi(getenv("SEPK_DWB_RECOMPUTE")) == 0;
     if (!force_tiles && ldt <= 8192 && (long)B * C <= 0x7fffffffL) {        // the row (ldt floats of LDS, ldt / 1024 float4 triples in registers)
-        const size_t rsmem = (size_t)ldt * sizeof(float);
+        // with the depthwise bias at hand z is formed again from `a` instead of being read (two LDS rows): 3 streams of HBM instead of 4
+        const bool recomp = bd != nullptr && !no_recompute;
+        const size_t rsmem = (size_t)ldt * sizeof(float) * (recomp ? 2 : 1);
         const dim3 grid((unsigned)((long)B * C));
-#define SEP_DWB(AL, NIT) hipLaunchKernelGGL((dwconv_bwd_row_kernel<AL, NIT>), grid, dim3(256), rsmem, (hipStream_t)stream, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bsum2, wd, dv1, rowpart, bacc1, arrive1, bsum1, C, T, ldt, dilation, eps)
-        if (dilation % 4 == 0) { if (ldt <= 4096) SEP_DWB(true, 4); else SEP_DWB(true, 8); }
-        else { if (ldt <= 4096) SEP_DWB(false, 4); else SEP_DWB(false, 8); }
+#define SEP_DWB(AL, NIT, RC) hipLaunchKernelGGL((dwconv_bwd_row_kernel<AL, NIT, RC>), grid, dim3(256), rsmem, (hipStream_t)stream, dv2, z, bd, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bsum2, wd, dv1, rowpart, bacc1, arrive1, bsum1, C, T, ldt, dilation, eps)
+#define SEP_DWB2(AL, NIT) do { if (recomp) SEP_DWB(AL, NIT, true); else SEP_DWB(AL, NIT, false); } while (0)
+        if (dilation % 4 == 0) { if (ldt <= 4096) SEP_DWB2(true, 4); else SEP_DWB2(true, 8); }
+        else { if (ldt <= 4096) SEP_DWB2(false, 4); else SEP_DWB2(false, 8); }
+#undef SEP_DWB2
 #undef SEP_DWB
         SEP_CHECK_LAUNCH("sep_dwconv_bwd");
         return 0;

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("SEPKERNELS_LIB", os.path.normpath(os.path.join(_HERE,
 # ---- constants mirrored from include/sepkernels.h -------------------------------------------------
 PRO_NONE, PRO_PRELU, PRO_GLN, PRO_GLN_PRELU, PRO_GLN_BWD = 0, 1, 2, 3, 4
 EPI_STATS_PRELU, EPI_RESIDUAL, EPI_SIGMOID, EPI_PRELU_BWD, EPI_ROWSUMS, EPI_ROWSUMS_PRELU = 1, 2, 4, 8, 16, 32
-ABI_VERSION = 16
+ABI_VERSION = 17
 STATS_SLOTS = 16   # SEP_STATS_SLOTS: gLN statistics are double[B][STATS_SLOTS][2]
 ARRIVE_INTS = 17   # SEP_ARRIVE_INTS: arrival counters of the gLN-backward publishers, int[B][ARRIVE_INTS]
 ARITH_F32, ARITH_BF16X6, ARITH_F16X3 = 0, 1, 2     # SEP_ARITH_*: how sep_pw_gemm forms its fp32 products (include/sepkernels.h)
@@ -118,7 +118,7 @@ SIGNATURES = {
     "sep_encoder_fwd": [_vp, _vp, _vp, _vp] + [_I] * 10 + [_vp],
     "sep_unfold": [_vp, _vp] + [_I] * 8 + [_vp],
     "sep_dwconv_fwd": [_vp] * 10 + [_I] * 5 + [_F, _vp],
-    "sep_dwconv_bwd": [_vp] * 17 + [_I] * 5 + [_F, _vp],
+    "sep_dwconv_bwd": [_vp] * 18 + [_I] * 5 + [_F, _vp],
     "sep_gln_bwd_finalize": [_vp, _I, _I, _vp, _vp, _D, _F, _vp, _vp, _vp, _vp, _I, _I, _vp],
     "sep_gln_bwd_finalize_batch": [ctypes.POINTER(FinalizeSeg), _I, _vp],
     "sep_gln_bwd_from_wgrad": [_vp] * 6 + [_D, _F] + [_vp] * 6 + [_I] * 6 + [_vp],
@@ -298,11 +298,11 @@ class HipBackend:
                                      _ptr(wd, _f32), _ptr(bd, _f32), _ptr(alpha2, _f32), _ptr(z, _f32), _ptr(stats2, _f64),
                                      B, C, T, ldt, dilation, eps, _stream()), "sep_dwconv_fwd")
 
-    def dwconv_bwd(self, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bsum2, wd, dv1, rowpart, bacc1, arrive1, bsum1,
+    def dwconv_bwd(self, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bsum2, wd, bd, dv1, rowpart, bacc1, arrive1, bsum1,
                    B, C, T, ldt, dilation, eps):
         _check(load().sep_dwconv_bwd(_ptr(dv2, _f32), _ptr(z, _f32), _ptr(a, _f32), _ptr(stats1, _f64), _ptr(gamma1, _f32),
                                      _ptr(beta1, _f32), _ptr(alpha1, _f32), _ptr(stats2, _f64), _ptr(gamma2, _f32),
-                                     _ptr(alpha2, _f32), _ptr(bsum2, _f32), _ptr(wd, _f32), _ptr(dv1, _f32), _ptr(rowpart, _f32), _ptr(bacc1, _f64),
+                                     _ptr(alpha2, _f32), _ptr(bsum2, _f32), _ptr(wd, _f32), _ptr(bd, _f32), _ptr(dv1, _f32), _ptr(rowpart, _f32), _ptr(bacc1, _f64),
                                      _ptr(arrive1, torch.int32), _ptr(bsum1, _f32),
                                      B, C, T, ldt, dilation, eps, _stream()), "sep_dwconv_bwd")
 

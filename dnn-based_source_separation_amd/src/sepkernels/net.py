@@ -562,7 +562,7 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
         side.wait(ev_sums)
         dv1 = torch.empty(B, H, ldt, **f32)
         rp1 = torch.empty(B, H, nt1024, 8, **f32)
-        K.dwconv_bwd(dv2, z, a, st1, g1, b1, al1, st2, g2, al2, bsum[2 + 2 * li], P[sp + "depthwise_conv1d.weight"], dv1, rp1,
+        K.dwconv_bwd(dv2, z, a, st1, g1, b1, al1, st2, g2, al2, bsum[2 + 2 * li], P[sp + "depthwise_conv1d.weight"], P[sp + "depthwise_conv1d.bias"], dv1, rp1,
                      bacc[1 + 2 * li], None, None, B, H, F, ldt, dil, teps)
         pbeta1 = torch.empty(B, H, **f32)
         pgamma1 = torch.empty(B, H, **f32)

@@ -33,7 +33,7 @@ extern "C" {
 
 typedef void* sep_stream_t; /* hipStream_t */
 
-#define SEP_ABI_VERSION 16
+#define SEP_ABI_VERSION 17
 #define SEP_STATS_SLOTS 16
 #define SEP_ARRIVE_INTS 17 /* arrival counters per sample: one per slot + one for the slots (csrc/common.hpp, gln_bwd_publish) */
 
@@ -218,11 +218,13 @@ int sep_dwconv_fwd(const float* a, const double* stats1, const float* gamma1, co
  * workgroups and the arrival protocol's two waited-for round trips cost it 10 us per launch); all three NULL: none of it.
  * Writes dv1 and, per (b, c, 1024-frame tile), 8 partial row sums into rowpart[b][c][ntile][8]:
  *   {sum dv1, sum dv1*u1, sum dz, sum dz*v1[t-d], sum dz*v1[t], sum dz*v1[t+d], sum du2*z*[z<=0], 0}
- * (u1 = PReLU(a), v1 = gLN1(u1) inside [0,T) and 0 outside; ntile = ceil(ldt/1024)). */
+ * (u1 = PReLU(a), v1 = gLN1(u1) inside [0,T) and 0 outside; ntile = ceil(ldt/1024)).
+ * bd (the depthwise bias, may be NULL): with it the kernel forms z = bd + depthwise(v1) again from `a`, which it reads anyway, instead of
+ * reading z -- three streams of HBM instead of four (rows of up to 8192 frames; longer rows and bd = NULL read z). */
 int sep_dwconv_bwd(const float* dv2, const float* z, const float* a, const double* stats1, const float* gamma1,
                    const float* beta1, const float* alpha1, const double* stats2, const float* gamma2,
-                   const float* alpha2, const float* bsum2, const float* wd, float* dv1, float* rowpart, double* bacc1,
-                   int* arrive1, float* bsum1, int B, int C, int T, int ldt, int dilation, float eps, sep_stream_t stream);
+                   const float* alpha2, const float* bsum2, const float* wd, const float* bd, float* dv1, float* rowpart,
+                   double* bacc1, int* arrive1, float* bsum1, int B, int C, int T, int ldt, int dilation, float eps, sep_stream_t stream);
 
 /* Second stage of every gLN backward (Appendix A of SURVEY.md).  rowpart is [B][C][ntile][nq], nq in {2, 8}:
  *   R1 = sum_tiles rowpart[..][0], R2 = sum_tiles rowpart[..][1]

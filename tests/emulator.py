@@ -296,7 +296,7 @@ class EmuBackend:
         u = _prelu(zz, alpha2)
         _acc(stats2, u.sum((1, 2)), (u * u).sum((1, 2)))
 
-    def dwconv_bwd(self, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bsum2, wd, dv1, rowpart, bacc1, arrive1, bsum1,
+    def dwconv_bwd(self, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bsum2, wd, bd, dv1, rowpart, bacc1, arrive1, bsum1,
                    B, C, T, ldt, dilation, eps):
         dt = a.dtype
         d = dilation

@@ -637,38 +637,50 @@ def test_dwconv_fwd_bwd(T, d):
     # backward on the emulator's z / stats2 (identical inputs for both)
     dv2 = padded(B, C, T, ldt)
     ntile = (ldt + 1023) // 1024
-    args = [dv2, z, a, st1, g1, b1, a1, st2, rnd(C) + 1, a2, rnd(B, 2, scale=0.01), wd, nan(B, C, ldt), nan(B, C, ntile, 8), zstats(B),
+    DV1, RP, BACC, ARR, BSUM = 13, 14, 15, 16, 17
+    args = [dv2, z, a, st1, g1, b1, a1, st2, rnd(C) + 1, a2, rnd(B, 2, scale=0.01), wd, bd, nan(B, C, ldt), nan(B, C, ntile, 8), zstats(B),
             torch.zeros(B, 17, dtype=torch.int32), nan(B, 2), B, C, T, ldt, d, 1e-12]
-    gargs = [to_device(v) if torch.is_tensor(v) else v for v in args]
     EMU.dwconv_bwd(*args)
-    HIP.dwconv_bwd(*gargs)
-    device_sync()
-    assert torch.isfinite(gargs[12]).all() and torch.isfinite(gargs[13]).all()
-    assert (args[12] - gargs[12].cpu()).abs().max() <= 2e-4 * args[12].abs().max()
-    rc, rg = args[13].double().sum(2), gargs[13].cpu().double().sum(2)          # per-tile partials -> per-row totals
-    assert (rc - rg).abs().max() <= 3e-4 * rc.abs().max()
-    bc, bg = args[14].sum(1), gargs[14].cpu().sum(1)                              # gLN1's gamma-weighted totals (slots -> totals)
-    assert (bc - bg).abs().max() <= 3e-4 * bc.abs().max()
+    bc = args[BACC].sum(1)                                                              # gLN1's gamma-weighted totals (slots -> totals)
+    rc = args[RP].double().sum(2)                                                       # per-tile partials -> per-row totals
     assert torch.allclose(bc[:, 0], (g1.view(1, C).double() * rc[..., 0]).sum(1), rtol=1e-5, atol=1e-6 * bc.abs().max().item())
-    # the sample's last workgroup published the two means (and every workgroup arrived exactly once)
-    arrived = gargs[15].cpu()
-    units = arrived[:, :16].sum(1)                     # workgroups (rows, or (channel, tile) units) of every sample: each arrived exactly once
-    assert bool((units == units[0]).all()) and int(units[0]) >= C
-    assert bool((arrived[:, 16] == min(16, int(units[0]))).all())
-    assert (args[16] - gargs[16].cpu()).abs().max() <= 3e-4 * args[16].abs().max()
-    # sums only (the consumer forms the means: what the Conv-TasNet step uses)
-    args3 = list(args)
-    args3[12], args3[13], args3[14], args3[15], args3[16] = nan(B, C, ldt), nan(B, C, ntile, 8), zstats(B), None, None
-    g3 = [to_device(v) if torch.is_tensor(v) else v for v in args3]
-    HIP.dwconv_bwd(*g3)
-    device_sync()
-    assert (g3[14].cpu().sum(1) - bc).abs().max() <= 3e-4 * bc.abs().max()
-    # without the gLN1 outputs (stand-alone use)
-    args2 = list(args)
-    args2[14:17] = [None, None, None]
-    args2[12], args2[13] = nan(B, C, ldt), nan(B, C, ntile, 8)
-    HIP.dwconv_bwd(*[to_device(v) if torch.is_tensor(v) else v for v in args2])
-    device_sync()
+
+    def fresh(bias, mode):
+        out = list(args)
+        out[12] = bias
+        out[DV1], out[RP] = nan(B, C, ldt), nan(B, C, ntile, 8)
+        out[BACC], out[ARR], out[BSUM] = {"publish": (zstats(B), torch.zeros(B, 17, dtype=torch.int32), nan(B, 2)), "sums": (zstats(B), None, None),
+                                          "none": (None, None, None)}[mode]
+        return [to_device(v) if torch.is_tensor(v) else v for v in out]
+
+    # with the bias z is formed again from `a` (what the Conv-TasNet step does), without it z is read
+    for bias in (bd, None):
+        gargs = fresh(bias, "publish")
+        HIP.dwconv_bwd(*gargs)
+        device_sync()
+        assert torch.isfinite(gargs[DV1]).all() and torch.isfinite(gargs[RP]).all()
+        assert (args[DV1] - gargs[DV1].cpu()).abs().max() <= 2e-4 * args[DV1].abs().max()
+        rg = gargs[RP].cpu().double().sum(2)
+        assert (rc - rg).abs().max() <= 3e-4 * rc.abs().max()
+        bg = gargs[BACC].cpu().sum(1)
+        assert (bc - bg).abs().max() <= 3e-4 * bc.abs().max()
+        # the sample's last workgroup published the two means (and every workgroup arrived exactly once)
+        arrived = gargs[ARR].cpu()
+        units = arrived[:, :16].sum(1)                     # workgroups (rows, or (channel, tile) units) of every sample: each arrived exactly once
+        assert bool((units == units[0]).all()) and int(units[0]) >= C
+        assert bool((arrived[:, 16] == min(16, int(units[0]))).all())
+        assert (args[BSUM] - gargs[BSUM].cpu()).abs().max() <= 3e-4 * args[BSUM].abs().max()
+        # sums only (the consumer forms the means: what the Conv-TasNet step uses)
+        g3 = fresh(bias, "sums")
+        HIP.dwconv_bwd(*g3)
+        device_sync()
+        assert (g3[BACC].cpu().sum(1) - bc).abs().max() <= 3e-4 * bc.abs().max()
+        assert (args[DV1] - g3[DV1].cpu()).abs().max() <= 2e-4 * args[DV1].abs().max()
+        # without the gLN1 outputs (stand-alone use)
+        g2_ = fresh(bias, "none")
+        HIP.dwconv_bwd(*g2_)
+        device_sync()
+        assert (args[DV1] - g2_[DV1].cpu()).abs().max() <= 2e-4 * args[DV1].abs().max()
 
 
 @pytest.mark.parametrize("Kw,stride,pad,dil,Tin", [(3, 1, 1, 1, 300), (5, 2, 4, 2, 257), (4, 4, 0, 1, 64), (3, 1, 8, 8, 1000), (16, 8, 0, 1, 403)])

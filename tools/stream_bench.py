@@ -42,7 +42,7 @@ for d in (1, 2, 4, 8, 16, 32, 64, 128):
     ms_f = timeit(lambda: K.dwconv_fwd(a, st1, g1, b1, a1, wd, bd, a2, z, st2, B, C, T, ldt, d, 1e-12))
     mode = os.environ.get("DWB_MODE", "sums")      # none | sums (what the step uses) | publish
     extra = {"none": (None, None, None), "sums": (bacc1, None, None), "publish": (bacc1, arrive1, bsum1)}[mode]
-    ms_b = timeit(lambda: K.dwconv_bwd(dv2, z, a, st1, g1, b1, a1, st2, g2, a2, bsum2, wd, dv1, rp, *extra, B, C, T, ldt, d, 1e-12))
+    ms_b = timeit(lambda: K.dwconv_bwd(dv2, z, a, st1, g1, b1, a1, st2, g2, a2, bsum2, wd, (None if os.environ.get("DWB_READ_Z") else bd), dv1, rp, *extra, B, C, T, ldt, d, 1e-12))
     tf += ms_f
     tb += ms_b
     print("d={:4d}  fwd {:7.1f} us ({:5.2f} TB/s)   bwd {:7.1f} us ({:5.2f} TB/s)".format(d, 1e3 * ms_f, 2 * H / ms_f / 1e3, 1e3 * ms_b, 4 * H / ms_b / 1e3))
