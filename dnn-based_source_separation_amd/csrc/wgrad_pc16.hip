@@ -3,8 +3,11 @@
 //   partial[s][m][n] = sum over the (sample, frame) columns of slab s of  G[b][m][t] * pro(X[b][n][t]),   partial_bias[s][m] = sum G
 //
 // Replaces autograd's conv weight / bias gradient of nn.Conv1d(kernel_size=1) at reference src/models/tdcn.py:86,173,175 and
-// src/models/conv_tasnet.py:335,341, like pw_wgrad_pc_kernel (wgrad_pc.hip), whose workgroup structure, slab / tile mapping, DMA rings
-// (chunk pairs, NS = 4) and barrier protocol it keeps.  What changes is the arithmetic of the products: wgrad_pc.hip splits both operands
+// src/models/conv_tasnet.py:335,341, like pw_wgrad_pc_kernel (wgrad_pc.hip), whose workgroup structure, slab / tile mapping and barrier
+// protocol it keeps.  The operands arrive in WHOLE 128-byte lines: a DMA instruction fetches 8 rows x 32 frames -- the two 16-frame chunks
+// of a PAIR -- where wgrad_pc.hip asks for 16 rows x 64 bytes per chunk; with the rows 16 KiB apart the two half-line requests of that
+// form each cost an HBM fetch of the line (rocprofv3 FETCH_SIZE: 336 MB per conv1 launch for 168 MB of operands, 186 MB in this form;
+// profiles/r03q_wgrad_line.txt).  What else changes is the arithmetic of the products: wgrad_pc.hip splits both operands
 // EXACTLY into three bf16 parts and issues six of the nine part products (6 x 32 matrix-pipe cycles per 32x32x16 block); here
 //     x 2^s = hi + lo,  hi = fp16(x 2^s) toward zero, lo = fp16(x 2^s - hi)         (11 + 11 significand bits)
 //     x y = hi_x lo_y + lo_x hi_y + hi_x hi_y                                          (3 x 32 cycles)
@@ -34,17 +37,23 @@ namespace {
 constexpr int W16MAXB = 256;      // samples whose gLN constants fit the LDS table
 constexpr int W16UNSET = 10000;   // exponent of a row that has only seen zeros: any first maximum "outgrows" it, ldexp(0, anything) = 0
 
-template <int WR, int WC, int NS>
+constexpr int W16NGP = 3, W16NXP = 2;      // raw ring depths in chunk PAIRS: G is fetched two pairs ahead of its use, X one
+template <int WR, int WC>
 struct __attribute__((aligned(16))) W16Smem {
     static constexpr int TM = 64 * WR, TN = 128 * WC;
-    float Gr[NS + 1][TM * DK];      // raw G chunk [row][16 frames], 16-byte granules XOR-swizzled by ((row >> 2) & 3)
-    float Xr[NS][TN * DK];          // raw X chunk, same layout
+    float Gr[W16NGP][TM * 2 * DK];  // raw G chunk pair [row][32 frames = 8 granules of 16 B]; granule q of a row sits in slot q ^ w16_f8(row)
+    float Xr[W16NXP][TN * 2 * DK];  // raw X chunk pair, same layout
     float Xp[2][4][TN * 4];         // split X chunk: plane (frame half lk, part hi / lo) -> [row][16 B = 8 fp16]
     int xe[2][TN];                  // the rows' scale exponents, per operand buffer
     float mu[W16MAXB];
     float rstd[W16MAXB];
 };
 
+// Slot permutation of a raw row's eight granules.  ds_read_b128 is served 16 lanes at a time from a 256-byte window of banks and the rows
+// are 128 bytes apart, so rows (2i, 2i+1) need f8 to be a bijection of i = 0..7 for readers of 16 consecutive rows (the consumers' G rows,
+// the producers' X rows at 256 columns), and readers of 8 consecutive rows x both chunk halves (X at 128 columns: the half toggles bit 1
+// of the granule index) need bits 0 and 2 of f8 to tell i = 0..3 apart: bit 0 <- row bit 1, bit 2 <- row bit 2, bit 1 <- row bit 3.
+__device__ __forceinline__ int w16_f8(const int row) { return ((row >> 1) & 1) | (((row >> 2) & 1) << 2) | (((row >> 3) & 1) << 1); }
 __device__ __forceinline__ f32x16 w16_mfma(const u32x4_t a, const u32x4_t b, const f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
 }
@@ -96,13 +105,12 @@ __device__ __forceinline__ int w16_next_exp(const float m, const int cur) {
 
 template <int WR, int WC, int XMODE>
 __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_desc d) {
-    constexpr int NS = 4;
     constexpr bool X_GLN = XMODE == SEP_PRO_GLN || XMODE == SEP_PRO_GLN_PRELU;
     constexpr bool X_PRELU = XMODE == SEP_PRO_PRELU || XMODE == SEP_PRO_GLN_PRELU;
-    using Smem = W16Smem<WR, WC, NS>;
+    using Smem = W16Smem<WR, WC>;
     constexpr int TM = Smem::TM, TN = Smem::TN;
-    constexpr int PG = TM / 64, PX = TN / 64;             // DMA pieces (16 rows x 64 B) per producer wave and chunk
-    constexpr int G = PG + PX;
+    constexpr int PG = TM / 32, PX = TN / 32;             // DMA pieces (8 rows x 128 B) per producer wave and chunk PAIR
+    constexpr int RL = 2 * DK;                            // floats per raw row
     static_assert(sizeof(Smem) <= 160 * 1024, "LDS");
     static_assert(sizeof(Smem) >= 4 * EPI_WAVE_FLOATS * sizeof(float), "transpose buffer");
     __shared__ Smem sm;
@@ -122,11 +130,13 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
 
     const int cps_t = d.ldt / DK;                  // chunks per sample
     const long chunks_total = (long)d.B * cps_t;
-    const long cper = (chunks_total + d.nsplit - 1) / d.nsplit;
+    long cper = (chunks_total + d.nsplit - 1) / d.nsplit;
+    cper += cper & 1;                              // whole pairs (slab boundaries on 32-frame marks, as in wgrad_pc.hip; ldt % 32 == 0)
     const long c_begin = (long)s * cper;
     long c_end = c_begin + cper;
     if (c_end > chunks_total) c_end = chunks_total;
-    const int nk = (int)(c_end > c_begin ? c_end - c_begin : 0);
+    const int nk = (int)(c_end > c_begin ? c_end - c_begin : 0);      // even
+    const int np = nk >> 1;
 
     if (X_GLN) {
         for (int bx = tid; bx < d.B; bx += 512) {
@@ -145,49 +155,59 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
         const int pw = wid - 4;
         const int ptid = tid - 256;
         const int Mg1 = d.g_split ? d.g_split : d.M;
-        const int r16 = lane >> 2, cch = (lane & 3) ^ ((r16 >> 2) & 3);
+        const int r8 = lane >> 3, slot = lane & 7;       // a DMA instruction: 8 rows x 8 granules, lane-linear in LDS = [row][32 frames]
         unsigned voffG[PG], voffX[PX];
         const float* srcG[PG];
         int MgOf[PG];
 #pragma unroll
         for (int q = 0; q < PG; ++q) {
-            const int row = m0 + 16 * (pw + 4 * q) + r16;
-            const bool second = d.g_split && (m0 + 16 * (pw + 4 * q)) >= d.g_split;   // wave-uniform
+            const int rowt = 8 * (pw + 4 * q) + r8;                                     // row of the tile
+            const bool second = d.g_split && (m0 + 8 * (pw + 4 * q)) >= d.g_split;     // wave-uniform
             srcG[q] = second ? d.G2 : d.G;
             MgOf[q] = second ? d.M - d.g_split : Mg1;
-            voffG[q] = 4u * (unsigned)((row - (second ? d.g_split : 0)) * d.ldt + 4 * cch);
+            voffG[q] = 4u * (unsigned)((m0 + rowt - (second ? d.g_split : 0)) * d.ldt + 4 * (slot ^ w16_f8(rowt)));
         }
 #pragma unroll
-        for (int q = 0; q < PX; ++q) voffX[q] = 4u * (unsigned)((n0 + 16 * (pw + 4 * q) + r16) * d.ldt + 4 * cch);
-        // Source pointers of the NEXT chunk to fetch, one per DMA piece, advanced by 16 frames per chunk (or to the next sample's rows): formed
-        // afresh from (sample, chunk) for every piece, the 64-bit scalar multiplies made the twelve DMA instructions of a chunk pair cost
-        // 1300 - 2300 cycles of one producer wave, with the consumers waiting at the barrier behind it (s_memtime stamps, tools/wpc16_prof.py)
-        int it = (int)(c_begin % cps_t);
-        int ci = 0, cst = 0, gst = 0;
+        for (int q = 0; q < PX; ++q) {
+            const int rowt = 8 * (pw + 4 * q) + r8;
+            voffX[q] = 4u * (unsigned)((n0 + rowt) * d.ldt + 4 * (slot ^ w16_f8(rowt)));
+        }
+        // Source pointers of the NEXT pair to fetch, one per DMA piece, advanced by 32 frames per pair (or to the next sample's rows): formed
+        // afresh from (sample, chunk) for every piece, the 64-bit scalar multiplies made the DMA instructions of a pair cost 1300 - 2300
+        // cycles of one producer wave, with the consumers waiting at the barrier behind it (s_memtime stamps, tools/wpc16_prof.py).
+        // G runs one pair ahead of X (three raw G stages, two raw X stages).
+        const int pps = cps_t / 2;                                               // pairs per sample
+        int itG = (int)(c_begin % cps_t) / 2, itX = itG;
+        int ciG = 0, ciX = 0, gst = 0, xst = 0;
         const float* pG[PG];
         long wrapG[PG];
 #pragma unroll
         for (int q = 0; q < PG; ++q) {
-            pG[q] = srcG[q] + (size_t)(c_begin / cps_t) * MgOf[q] * d.ldt + it * DK;
-            wrapG[q] = (long)MgOf[q] * d.ldt - (long)(cps_t - 1) * DK;
+            pG[q] = srcG[q] + (size_t)(c_begin / cps_t) * MgOf[q] * d.ldt + itG * RL;
+            wrapG[q] = (long)MgOf[q] * d.ldt - (long)(pps - 1) * RL;
         }
-        const float* pX = d.X + (size_t)(c_begin / cps_t) * d.N * d.ldt + it * DK;
-        const long wrapX = (long)d.N * d.ldt - (long)(cps_t - 1) * DK;
-        auto issue = [&]() {
+        const float* pX = d.X + (size_t)(c_begin / cps_t) * d.N * d.ldt + itX * RL;
+        const long wrapX = (long)d.N * d.ldt - (long)(pps - 1) * RL;
+        auto issueG = [&]() {
 #pragma unroll
             for (int q = 0; q < PG; ++q)
-                glds16_asm(pG[q], voffG[q], lds_addr(&sm.Gr[gst][16 * (pw + 4 * q) * DK]));
+                glds16_asm(pG[q], voffG[q], lds_addr(&sm.Gr[gst][8 * (pw + 4 * q) * RL]));
+            const bool wrap = ++itG >= pps;                                      // the next pair is the first of the next sample
+            if (wrap) itG = 0;
+#pragma unroll
+            for (int q = 0; q < PG; ++q) pG[q] += wrap ? wrapG[q] : (long)RL;
+            ++ciG;
+            gst = gst + 1 == W16NGP ? 0 : gst + 1;
+        };
+        auto issueX = [&]() {
 #pragma unroll
             for (int q = 0; q < PX; ++q)
-                glds16_asm(pX, voffX[q], lds_addr(&sm.Xr[cst][16 * (pw + 4 * q) * DK]));
-            const bool wrap = ++it >= cps_t;                                     // the next chunk is the first of the next sample
-            if (wrap) it = 0;
-#pragma unroll
-            for (int q = 0; q < PG; ++q) pG[q] += wrap ? wrapG[q] : (long)DK;
-            pX += wrap ? wrapX : (long)DK;
-            ++ci;
-            cst = cst + 1 == NS ? 0 : cst + 1;
-            gst = gst + 1 == NS + 1 ? 0 : gst + 1;
+                glds16_asm(pX, voffX[q], lds_addr(&sm.Xr[xst][8 * (pw + 4 * q) * RL]));
+            const bool wrap = ++itX >= pps;
+            if (wrap) itX = 0;
+            pX += wrap ? wrapX : (long)RL;
+            ++ciX;
+            xst = xst + 1 == W16NXP ? 0 : xst + 1;
         };
 
         // an operand with 256 rows gives every producer thread one whole row (16 frames), one with 128 rows half a row (8 frames): the
@@ -200,10 +220,10 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
         int cb = (int)(c_begin / cps_t), ct = (int)(c_begin % cps_t);
         int xexp = W16UNSET;                                                     // this row's running scale exponent
 
-        auto read8 = [&](const float* raw, const int row, const int half, float (&v)[8]) {
-            const int f = (row >> 2) & 3;
-            const float4 a = ld4(raw + row * DK + 4 * ((2 * half) ^ f));
-            const float4 b = ld4(raw + row * DK + 4 * ((2 * half + 1) ^ f));
+        auto read8 = [&](const float* raw, const int par, const int row, const int half, float (&v)[8]) {      // chunk `par` of the pair
+            const int f = w16_f8(row);
+            const float4 a = ld4(raw + row * RL + 4 * ((4 * par + 2 * half) ^ f));
+            const float4 b = ld4(raw + row * RL + 4 * ((4 * par + 2 * half + 1) ^ f));
             v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
         };
         auto put8 = [&](float* planes, const int row, const int half, const float (&v)[8]) {
@@ -216,16 +236,16 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
         };
 
         __syncthreads();                                                         // mu / rstd table visible; no DMA in flight yet
-#pragma unroll
-        for (int g = 0; g < NS; ++g)
-            if (ci < nk) issue();
-        if (nk >= NS) w16_wait_barrier<(NS - 1) * G>();                          // B_-1: raw chunk 0 landed
+        if (np > 0) { issueG(); issueX(); }
+        if (np > 1) { issueG(); issueX(); }
+        if (np > 2) issueG();
+        if (np > 2) w16_wait_barrier<2 * PG + PX>();                             // B_-1: raw pair 0 landed (behind it: G1 X1 G2)
         else w16_wait_barrier<0>();
 
-        int stage = 0;
         for (int j = 0; j < nk; ++j) {
+            const int P = j >> 1, par = j & 1;
             W16STAMP(1, 0);
-            const float* Xb = sm.Xr[stage];
+            const float* Xb = sm.Xr[P & 1];
             float* Xp = &sm.Xp[j & 1][0][0];
             float sc = 1.f, sh = 0.f;
             if (X_GLN) {
@@ -237,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
             float m = 0.f;
 #pragma unroll
             for (int h = 0; h < (X_FULL ? 2 : 1); ++h) {
-                read8(Xb, x_row, X_FULL ? h : x_half, v[h]);
+                read8(Xb, par, x_row, X_FULL ? h : x_half, v[h]);
                 if (XMODE != SEP_PRO_NONE) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
@@ -263,17 +283,19 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
             __builtin_amdgcn_s_waitcnt(0xc07f);
             W16STAMP(1, 2);
 #endif
-            // raw chunk j+1 has landed -- mine: all but the newer chunks; everyone's: the barrier -- and the operands of chunk j are written.
-            // Chunks are fetched in PAIRS behind the odd barriers (wgrad_pc.hip: one HBM fetch per 128-byte line).
-            if (j & 1) { if (j + 3 <= nk) w16_wait_barrier<G>(); else w16_wait_barrier<0>(); }
-            else { if (j + 4 <= nk) w16_wait_barrier<2 * G>(); else w16_wait_barrier<0>(); }
-            W16STAMP(1, 3);
-            if (j & 1) {
-                if (ci < nk) issue();
-                if (ci < nk) issue();
+            // The operands of chunk j are written; behind an odd chunk the next chunk opens a new pair, which must have landed -- mine: all
+            // but the G pair fetched after it; everyone's: the barrier.  Then the stage just read takes X of the pair after next and the
+            // oldest G stage the pair after that.
+            if (par) {
+                if (P + 2 < np) w16_wait_barrier<PG>(); else w16_wait_barrier<0>();
+                W16STAMP(1, 3);
+                if (P + 2 < np) issueX();
+                if (P + 3 < np) issueG();
+            } else {
+                w16_lgkm0_barrier();
+                W16STAMP(1, 3);
             }
             W16STAMP(1, 4);
-            stage = stage + 1 == NS ? 0 : stage + 1;
         }
     } else {
         // =================================================================================== consumer waves
@@ -298,16 +320,17 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
                                                                                  // before that chunk's first MFMA
         int bcur[2][2] = {{W16UNSET, W16UNSET}, {W16UNSET, W16UNSET}};           // scale the accumulators of column block (h, n) are in
         int en[2][2];
-        const int g_f = (l31 >> 2) & 3;
-        const int g_off = (64 * wr + l31) * DK;
+        const int g_f = w16_f8(l31);
+        const int g_off = (64 * wr + l31) * RL;
         const int b_off = (128 * wcc + l31) * 4 + lk * 2 * TN * 4;               // + (64 * h + 32 * n) * 4 + part * TN * 4
 #define W16_SB() __builtin_amdgcn_sched_barrier(0)
-        auto read_raw_a = [&](const int gstage) __attribute__((always_inline)) {
+        auto read_raw_a = [&](const int gstage, auto parc) __attribute__((always_inline)) {      // chunk `par` of the pair in stage gstage
+            constexpr int par = decltype(parc)::value;
             const float* Gb = sm.Gr[gstage] + g_off;
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
-                const float4 x = ld4(Gb + mi * 32 * DK + 4 * ((2 * lk) ^ g_f));
-                const float4 y = ld4(Gb + mi * 32 * DK + 4 * ((2 * lk + 1) ^ g_f));
+                const float4 x = ld4(Gb + mi * 32 * RL + 4 * ((4 * par + 2 * lk) ^ g_f));
+                const float4 y = ld4(Gb + mi * 32 * RL + 4 * ((4 * par + 2 * lk + 1) ^ g_f));
                 ra[mi][0] = x.x; ra[mi][1] = x.y; ra[mi][2] = x.z; ra[mi][3] = x.w; ra[mi][4] = y.x; ra[mi][5] = y.y; ra[mi][6] = y.z; ra[mi][7] = y.w;
             }
         };
@@ -394,7 +417,7 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
         auto step = [&](auto parc, const bool more, const int buf, const int gstage_next) __attribute__((always_inline)) {
             constexpr int P = decltype(parc)::value;
             load_b(buf);
-            read_raw_a(gstage_next);                                             // raw G of the next chunk (landed before this step's barrier)
+            read_raw_a(gstage_next, W16_I(P ^ 1));                               // raw G of the next chunk (landed before this step's barrier)
             W16_SB();
             follow_rows();                                                       // (scales chosen while the previous chunk was multiplied)
             follow_cols(W16_I(0));
@@ -427,7 +450,7 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
         w16_lgkm0_barrier();                                                     // B_-1: raw chunk 0 has landed
         int gstage = 0;
         if (nk > 0) {                                                            // chunk 0 is scaled and split up front
-            read_raw_a(0);
+            read_raw_a(0, W16_I(0));
             split_exp(W16_I(0), true); split_exp(W16_I(1), true);
             split_pair(W16_I(0), W16_I(0), W16_I(0)); split_pair(W16_I(0), W16_I(0), W16_I(1)); split_pair(W16_I(0), W16_I(0), W16_I(2)); split_pair(W16_I(0), W16_I(0), W16_I(3));
             split_pair(W16_I(0), W16_I(1), W16_I(0)); split_pair(W16_I(0), W16_I(1), W16_I(1)); split_pair(W16_I(0), W16_I(1), W16_I(2)); split_pair(W16_I(0), W16_I(1), W16_I(3));
@@ -436,13 +459,12 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
             W16STAMP(0, 0);
             w16_lgkm0_barrier();                                                 // B_j: the X operands of chunk j are there, raw G of chunk j+1 too
             W16STAMP(0, 1);
-            gstage = gstage + 1 == NS + 1 ? 0 : gstage + 1;
-            step(W16_I(0), j + 1 < nk, 0, gstage);
+            step(W16_I(0), j + 1 < nk, 0, gstage);                               // (the next chunk is the second of this pair)
             W16STAMP(0, 2);
             if (j + 1 < nk) {
                 w16_lgkm0_barrier();                                             // B_{j+1}
                 W16STAMP(0, 3);
-                gstage = gstage + 1 == NS + 1 ? 0 : gstage + 1;
+                gstage = gstage + 1 == W16NGP ? 0 : gstage + 1;
                 step(W16_I(1), j + 2 < nk, 1, gstage);
                 W16STAMP(0, 4);
             }

@@ -11,7 +11,7 @@ from sepkernels import STATS_SLOTS  # noqa: E402
 
 K = sepkernels.HipBackend()
 dev = "cuda"
-B, C, T, ldt = 16, 512, 3999, 4096
+B, C, T, ldt = 16, 512, 3999, int(os.environ.get("LDT", "4096"))
 f = lambda *s: torch.randn(*s, device=dev)
 st = lambda: torch.rand(B, STATS_SLOTS, 2, device=dev, dtype=torch.float64) * 1e3 + torch.tensor([0.0, 1e6], device=dev, dtype=torch.float64)
 a, z, dv2, dv1 = f(B, C, ldt), f(B, C, ldt), f(B, C, ldt), f(B, C, ldt)
