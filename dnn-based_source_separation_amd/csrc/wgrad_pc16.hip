@@ -38,13 +38,14 @@ constexpr int W16MAXB = 256;      // samples whose gLN constants fit the LDS tab
 constexpr int W16UNSET = 10000;   // exponent of a row that has only seen zeros: any first maximum "outgrows" it, ldexp(0, anything) = 0
 
 constexpr int W16NGP = 3, W16NXP = 2;      // raw ring depths in chunk PAIRS: G is fetched two pairs ahead of its use, X one
+constexpr int W16NXB = 3;                  // operand buffers: the producers run ONE CHUNK AHEAD of the chunk being multiplied (see the kernel)
 template <int WR, int WC>
 struct __attribute__((aligned(16))) W16Smem {
     static constexpr int TM = 64 * WR, TN = 128 * WC;
     float Gr[W16NGP][TM * 2 * DK];  // raw G chunk pair [row][32 frames = 8 granules of 16 B]; granule q of a row sits in slot q ^ w16_f8(row)
     float Xr[W16NXP][TN * 2 * DK];  // raw X chunk pair, same layout
-    float Xp[2][4][TN * 4];         // split X chunk: plane (frame half lk, part hi / lo) -> [row][16 B = 8 fp16]
-    int xe[2][TN];                  // the rows' scale exponents, per operand buffer
+    float Xp[W16NXB][4][TN * 4];    // split X chunk: plane (frame half lk, part hi / lo) -> [row][16 B = 8 fp16]
+    int xe[W16NXB][TN];             // the rows' scale exponents, per operand buffer
     float mu[W16MAXB];
     float rstd[W16MAXB];
 };
@@ -235,18 +236,14 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
             *reinterpret_cast<u32x4_t*>(base + TN * 4) = u32x4_t{lo[0], lo[1], lo[2], lo[3]};
         };
 
-        __syncthreads();                                                         // mu / rstd table visible; no DMA in flight yet
-        if (np > 0) { issueG(); issueX(); }
-        if (np > 1) { issueG(); issueX(); }
-        if (np > 2) issueG();
-        if (np > 2) w16_wait_barrier<2 * PG + PX>();                             // B_-1: raw pair 0 landed (behind it: G1 X1 G2)
-        else w16_wait_barrier<0>();
-
-        for (int j = 0; j < nk; ++j) {
-            const int P = j >> 1, par = j & 1;
+        // operands of chunk i: this thread's row (half row) of X scaled, split and written to buffer i % 3
+        auto process = [&](const int i) {
+            const int j = i;                                                     // (the stamps' chunk index)
+            const int P = i >> 1, par = i & 1;
             W16STAMP(1, 0);
             const float* Xb = sm.Xr[P & 1];
-            float* Xp = &sm.Xp[j & 1][0][0];
+            const int xb3 = i % W16NXB;
+            float* Xp = &sm.Xp[xb3][0][0];
             float sc = 1.f, sh = 0.f;
             if (X_GLN) {
                 const float rstd = sm.rstd[cb], mu = sm.mu[cb];
@@ -276,24 +273,42 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
                 for (int e = 0; e < 8; ++e) v[h][e] = __builtin_ldexpf(v[h][e], xexp);
                 put8(Xp, x_row, X_FULL ? h : x_half, v[h]);
             }
-            sm.xe[j & 1][x_row] = xexp;                                          // (both halves of a row store the same word)
+            if (X_FULL || x_half == 0) sm.xe[xb3][x_row] = xexp;                 // (both halves of a row hold the same exponent)
             if (++ct >= cps_t) { ct = 0; ++cb; }
             W16STAMP(1, 1);
 #ifdef WPC16_PROF
             __builtin_amdgcn_s_waitcnt(0xc07f);
             W16STAMP(1, 2);
 #endif
-            // The operands of chunk j are written; behind an odd chunk the next chunk opens a new pair, which must have landed -- mine: all
-            // but the G pair fetched after it; everyone's: the barrier.  Then the stage just read takes X of the pair after next and the
-            // oldest G stage the pair after that.
-            if (par) {
+        };
+
+        // The producers stay ONE CHUNK AHEAD: barrier B_j finds the operands of chunk j + 1 written (three operand buffers), so a consumer
+        // fetches the first half of its next chunk's operands under the second half of this chunk's MFMAs and starts behind the barrier
+        // without an LDS round trip in front of its first MFMA (stamps with operands of chunk j published AT B_j: 1530 ticks per consumer
+        // step for 768 of MFMAs, 370 waiting at the barrier; profiles/r03s_wpc16_stamps.txt).  B_j also finds the raw pairs holding the
+        // chunks up to j + 2 landed: the consumers read raw G of chunk j + 1 in step j, the producers raw X of chunk j + 2 behind B_j.
+        __syncthreads();                                                         // mu / rstd table visible; no DMA in flight yet
+        if (np > 0) { issueG(); issueX(); }
+        if (np > 1) { issueG(); issueX(); }
+        if (np > 2) issueG();
+        if (np > 2) w16_wait_barrier<2 * PG + PX>();                             // B_-2: raw pair 0 landed (behind it: G1 X1 G2)
+        else w16_wait_barrier<0>();
+        if (nk > 0) process(0);
+        w16_lgkm0_barrier();                                                     // B_-1: the operands of chunk 0
+
+        for (int j = 0; j < nk; ++j) {
+            const int P = j >> 1;
+            if (j + 1 < nk) process(j + 1);
+            if (!(j & 1)) {
+                // chunk j + 2 opens pair P + 1: landed -- mine: all but the G pair fetched after it; everyone's: the barrier.  The X stage
+                // of pair P has been read for the last time (chunk j + 1, just now) and takes the pair after next.
                 if (P + 2 < np) w16_wait_barrier<PG>(); else w16_wait_barrier<0>();
                 W16STAMP(1, 3);
                 if (P + 2 < np) issueX();
-                if (P + 3 < np) issueG();
             } else {
                 w16_lgkm0_barrier();
                 W16STAMP(1, 3);
+                if (P + 3 < np) issueG();                                       // (raw G of pair P was read for the last time in step j - 1)
             }
             W16STAMP(1, 4);
         }
@@ -373,17 +388,16 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
             }
             W16_SB();
         };
-        // the operands of both column halves in buffer buf (issued together, right behind the barrier)
-        auto load_b = [&](const int buf) __attribute__((always_inline)) {
+        // the operands of column half h in buffer buf
+        auto load_b = [&](const int buf, auto hc) __attribute__((always_inline)) {
+            constexpr int h = decltype(hc)::value;
             const float* p = &sm.Xp[buf][0][0] + b_off;
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    sb[h][n][0] = *reinterpret_cast<const u32x4_t*>(p + (64 * h + 32 * n) * 4);
-                    sb[h][n][1] = *reinterpret_cast<const u32x4_t*>(p + (64 * h + 32 * n) * 4 + TN * 4);
-                    en[h][n] = sm.xe[buf][128 * wcc + 64 * h + 32 * n + l31];
-                }
+            for (int n = 0; n < 2; ++n) {
+                sb[h][n][0] = *reinterpret_cast<const u32x4_t*>(p + (64 * h + 32 * n) * 4);
+                sb[h][n][1] = *reinterpret_cast<const u32x4_t*>(p + (64 * h + 32 * n) * 4 + TN * 4);
+                en[h][n] = sm.xe[buf][128 * wcc + 64 * h + 32 * n + l31];
+            }
             W16_SB();
         };
         // ... and the accumulator COLUMNS follow their X rows' scales (a column is a lane's own)
@@ -414,9 +428,11 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
         // `more` = there is a next chunk.  It only feeds selects: behind the last chunk the split runs on the stage's stale contents (in-bounds,
         // never multiplied) and the rows' exponents / bias sums are left alone -- ten `last chunk?` branches per chunk in the MFMA stream, or
         // separate code paths for the tail (tried: the allocator then spills 870 registers at the joins), cost more.
-        auto step = [&](auto parc, const bool more, const int buf, const int gstage_next) __attribute__((always_inline)) {
+        // The first column half's operands were fetched under the previous step (buffer buf), the next chunk's (buffer buf_next) are
+        // fetched here as soon as this chunk's first half is multiplied.
+        auto step = [&](auto parc, const bool more, const int buf, const int buf_next, const int gstage_next) __attribute__((always_inline)) {
             constexpr int P = decltype(parc)::value;
-            load_b(buf);
+            load_b(buf, W16_I(1));
             read_raw_a(gstage_next, W16_I(P ^ 1));                               // raw G of the next chunk (landed before this step's barrier)
             W16_SB();
             follow_rows();                                                       // (scales chosen while the previous chunk was multiplied)
@@ -432,6 +448,7 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
             M(W16_I(P), W16_I(0), W16_I(8)); M(W16_I(P), W16_I(0), W16_I(9));
             split_pair(W16_I(P ^ 1), W16_I(0), W16_I(3));
             M(W16_I(P), W16_I(0), W16_I(10)); M(W16_I(P), W16_I(0), W16_I(11));
+            load_b(buf_next, W16_I(0));                                          // (behind the last chunk: a stale buffer, never multiplied)
             follow_cols(W16_I(1));
             M(W16_I(P), W16_I(1), W16_I(0)); M(W16_I(P), W16_I(1), W16_I(1));
             split_exp(W16_I(1), more);
@@ -447,7 +464,7 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
             W16_SB();
         };
         __syncthreads();                                                         // (the producers' table barrier)
-        w16_lgkm0_barrier();                                                     // B_-1: raw chunk 0 has landed
+        w16_lgkm0_barrier();                                                     // B_-2: raw pair 0 has landed
         int gstage = 0;
         if (nk > 0) {                                                            // chunk 0 is scaled and split up front
             read_raw_a(0, W16_I(0));
@@ -455,17 +472,24 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
             split_pair(W16_I(0), W16_I(0), W16_I(0)); split_pair(W16_I(0), W16_I(0), W16_I(1)); split_pair(W16_I(0), W16_I(0), W16_I(2)); split_pair(W16_I(0), W16_I(0), W16_I(3));
             split_pair(W16_I(0), W16_I(1), W16_I(0)); split_pair(W16_I(0), W16_I(1), W16_I(1)); split_pair(W16_I(0), W16_I(1), W16_I(2)); split_pair(W16_I(0), W16_I(1), W16_I(3));
         }
+        w16_lgkm0_barrier();                                                     // B_-1: the X operands of chunk 0 are there
+        load_b(0, W16_I(0));
+        int buf = 0;
         for (int j = 0; j < nk; j += 2) {
             W16STAMP(0, 0);
-            w16_lgkm0_barrier();                                                 // B_j: the X operands of chunk j are there, raw G of chunk j+1 too
+            w16_lgkm0_barrier();                                                 // B_j: the X operands of chunk j+1 are there, raw G of chunk j+1 too
             W16STAMP(0, 1);
-            step(W16_I(0), j + 1 < nk, 0, gstage);                               // (the next chunk is the second of this pair)
+            int nb = buf + 1 == W16NXB ? 0 : buf + 1;
+            step(W16_I(0), j + 1 < nk, buf, nb, gstage);                         // (the next chunk is the second of this pair)
+            buf = nb;
             W16STAMP(0, 2);
             if (j + 1 < nk) {
                 w16_lgkm0_barrier();                                             // B_{j+1}
                 W16STAMP(0, 3);
                 gstage = gstage + 1 == W16NGP ? 0 : gstage + 1;
-                step(W16_I(1), j + 2 < nk, 1, gstage);
+                nb = buf + 1 == W16NXB ? 0 : buf + 1;
+                step(W16_I(1), j + 2 < nk, buf, nb, gstage);
+                buf = nb;
                 W16STAMP(0, 4);
             }
         }
@@ -534,15 +558,14 @@ void launch_w16(const sep_wgrad_desc& d, hipStream_t stream) {
 int sep_pw_wgrad_pc16(const sep_wgrad_desc* d, hipStream_t stream) {
     static const bool off = getenv("SEPK_WGRAD_F16") != nullptr && atoi(getenv("SEPK_WGRAD_F16")) == 0;
     if (off || d->arith != SEP_ARITH_F16X3 || d->g_mul || d->x_div != 1 || d->B > W16MAXB || d->g_split % 128 != 0) return 0;
-    const bool tall = d->M % 256 == 0 && d->N % 128 == 0;
-    const bool wide = d->M % 128 == 0 && d->N % 256 == 0;
-    if (!tall && !wide) return 0;
+    // 256 x 128 workgroup tiles only: with three operand buffers the 128 x 256 form does not fit the LDS; such shapes (one launch of the
+    // Conv-TasNet step: the bottleneck's 128 x 512) go to the exact bf16 kernel (wgrad_pc.hip)
+    if (d->M % 256 != 0 || d->N % 128 != 0) return 0;
     if ((size_t)d->M * d->ldt * 4 >= (1ull << 32) || (size_t)d->N * d->ldt * 4 >= (1ull << 32)) return 0;      // 32-bit DMA offsets
     if ((long)d->nsplit > (long)d->B * (d->ldt / DK)) return 0;
 #define SEP_LW(XM)                                           \
     do {                                                     \
-        if (tall) launch_w16<4, 1, XM>(*d, stream);          \
-        else launch_w16<2, 2, XM>(*d, stream);               \
+        launch_w16<4, 1, XM>(*d, stream);                    \
         return 1;                                            \
     } while (0)
     switch (d->x_mode) {

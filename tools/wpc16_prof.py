@@ -16,12 +16,21 @@ for name, kw, ns, M, N in (("heads 256x512 PReLU", dict(M=Bn + Sc, N=H, G=f(B, B
     for _ in range(3):
         K.pw_wgrad(B=B, T=T, ldt=ldt, eps=1e-12, partial=part, partial_bias=pb, nsplit=ns, **kw)
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        K.pw_wgrad(B=B, T=T, ldt=ldt, eps=1e-12, partial=part, partial_bias=pb, nsplit=ns, **kw)
+    e1.record()
+    torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / 10
     sb = (ctypes.c_longlong * (2 * 64 * 8))()
     assert lib.sep_debug_wpc_step(sb) == 0
     s = np.array(sb[:]).reshape(2, 64, 8).astype(np.float64)
     nkk = 4096 * 16 // 16 // ns
     pr = s[1, 4:min(60, nkk - 2), :5]
-    print(name, "chunks per slab", nkk)
+    nst = min(64, nkk)
+    span = s[0, nst - 2 if nst % 2 == 0 else nst - 1, 0] - s[0, 0, 0]
+    print(name, "chunks per slab", nkk, " kernel {:.1f} us;  consumer stamps chunk 0 -> {}: {:.0f} ticks ({:.0f} per chunk)".format(us, nst - 2, span, span / max(1, nst - 2)))
     print("  producer cycles: read+split+write {:.0f} | lgkm drain {:.0f} | vm wait + barrier {:.0f} | DMA issue {:.0f} (every other chunk) | step {:.0f}".format(
         (pr[:, 1] - pr[:, 0]).mean(), (pr[:, 2] - pr[:, 1]).mean(), (pr[:, 3] - pr[:, 2]).mean(), (pr[:, 4] - pr[:, 3]).mean(), np.diff(pr[:, 0]).mean()))
     co = s[0, 4:min(60, nkk - 2):2, :5]
