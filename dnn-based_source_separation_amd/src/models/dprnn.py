@@ -10,7 +10,7 @@ gLN; layout changes are torch views/permutes.
 """
 import torch.nn as nn
 
-from sepkernels.functional import lstm_apply
+from sepkernels.functional import linear_apply, lstm_apply
 
 from utils.model import choose_rnn
 from utils.tasnet import choose_layer_norm
@@ -61,7 +61,7 @@ class _PathRNN(nn.Module):
         else:
             x = input.permute(0, 3, 2, 1).reshape(B * K, S, F)
         x = lstm_apply(x, self.rnn)              # the sweep kernels for 16 / 32 / 64 / 128 units, torch's LSTM otherwise
-        x = self.fc(x)                                           # (B*S, K, F) or (B*K, S, F)
+        x = linear_apply(x, self.fc)                             # (B*S, K, F) or (B*K, S, F): csrc/linear.hip for feature counts % 64 == 0
         x = x.reshape(B, S * K, F).permute(0, 2, 1).contiguous()  # (B, F, S*K) [or (B, F, K*S)]
         if self.norm:
             x = self.norm1d(x)                                   # statistics over all of (F, S*K): order-free

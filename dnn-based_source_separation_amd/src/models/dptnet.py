@@ -7,7 +7,7 @@ recurrence of the feed-forward sub-block: the LSTM sweep kernels; layer norms: t
 import torch.nn as nn
 import torch.nn.functional as F
 
-from sepkernels.functional import OverlapAddFn, PaddedPointwiseFn, SegmentFn, lstm_apply
+from sepkernels.functional import OverlapAddFn, PaddedPointwiseFn, SegmentFn, linear_apply, lstm_apply
 from utils.model import choose_nonlinear, choose_rnn
 from utils.tasnet import choose_layer_norm
 from models.gtu import GTU1d
@@ -195,7 +195,7 @@ class FeedForwardBlock(nn.Module):
     def forward(self, input):
         """(T, batch_size, num_features) -> same shape: LSTM -> activation -> Linear, + input [-> norm]"""
         h = lstm_apply(input.transpose(0, 1), self.rnn).transpose(0, 1)          # the sweep kernels run sequence-major per batch row
-        x = self.fc(self.nonlinear1d(h)) + input
+        x = linear_apply(self.nonlinear1d(h), self.fc) + input
         return _norm_time_first(self.norm1d, x) if self.norm else x
 
 

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("SEPKERNELS_LIB", os.path.normpath(os.path.join(_HERE,
 # ---- constants mirrored from include/sepkernels.h -------------------------------------------------
 PRO_NONE, PRO_PRELU, PRO_GLN, PRO_GLN_PRELU, PRO_GLN_BWD = 0, 1, 2, 3, 4
 EPI_STATS_PRELU, EPI_RESIDUAL, EPI_SIGMOID, EPI_PRELU_BWD, EPI_ROWSUMS, EPI_ROWSUMS_PRELU = 1, 2, 4, 8, 16, 32
-ABI_VERSION = 17
+ABI_VERSION = 18
 STATS_SLOTS = 16   # SEP_STATS_SLOTS: gLN statistics are double[B][STATS_SLOTS][2]
 ARRIVE_INTS = 17   # SEP_ARRIVE_INTS: arrival counters of the gLN-backward publishers, int[B][ARRIVE_INTS]
 ARITH_F32, ARITH_BF16X6, ARITH_F16X3 = 0, 1, 2     # SEP_ARITH_*: how sep_pw_gemm forms its fp32 products (include/sepkernels.h)
@@ -152,6 +152,9 @@ SIGNATURES = {
     "sep_adam_step_dev": [_vp] * 5 + [_L, _vp, _vp] + [_F] * 6 + [_vp],
     "sep_lstm_fwd": [_vp] * 5 + [_I] * 4 + [_vp],
     "sep_lstm_bwd": [_vp] * 5 + [_I] * 4 + [_vp],
+    "sep_linear_fwd": [_vp] * 5 + [_L, _I, _I, _vp],
+    "sep_linear_bwd_input": [_vp] * 3 + [_L, _I, _I, _I, _vp],
+    "sep_linear_bwd_weight": [_vp] * 4 + [_L] + [_I] * 5 + [_vp],
 }
 
 _lib = None
@@ -434,6 +437,16 @@ class HipBackend:
     def lstm_bwd(self, dh_out, gates, cstate, w_hh, dxg, nseq, L, H, reverse):
         _check(load().sep_lstm_bwd(_ptr(dh_out, _f32), _ptr(gates, _f32), _ptr(cstate, _f32), _ptr(w_hh, _f32), _ptr(dxg, _f32),
                                    nseq, L, H, int(reverse), _stream()), "sep_lstm_bwd")
+
+    def linear_fwd(self, x, w, bias, bias2, y, ntok, K, N):
+        _check(load().sep_linear_fwd(_ptr(x, _f32), _ptr(w, _f32), _ptr(bias, _f32), _ptr(bias2, _f32), _ptr(y, _f32), ntok, K, N, _stream()), "sep_linear_fwd")
+
+    def linear_bwd_input(self, dy, w, dx, ntok, K, N, accumulate):
+        _check(load().sep_linear_bwd_input(_ptr(dy, _f32), _ptr(w, _f32), _ptr(dx, _f32), ntok, K, N, int(accumulate), _stream()), "sep_linear_bwd_input")
+
+    def linear_bwd_weight(self, dy, x, partial, partial_bias, ntok, K, N, L, shift, nslab):
+        _check(load().sep_linear_bwd_weight(_ptr(dy, _f32), _ptr(x, _f32), _ptr(partial, _f32), _ptr(partial_bias, _f32), ntok, K, N, L, shift, nslab,
+                                            _stream()), "sep_linear_bwd_weight")
 
     def adam_step(self, p, g, m, v, sqnorm, n, lr, beta1, beta2, eps, weight_decay, max_norm, grad_scale, step):
         _check(load().sep_adam_step(_ptr(p, _f32), _ptr(g, _f32), _ptr(m, _f32), _ptr(v, _f32), _ptr(sqnorm, _f64), n, lr, beta1,

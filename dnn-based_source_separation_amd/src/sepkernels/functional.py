@@ -343,12 +343,107 @@ class DepthwiseConv1dFn(torch.autograd.Function):
         return dx, dwb[:, :Kw].reshape(C, 1, Kw).contiguous(), (dwb[:, Kw].contiguous() if has_bias else None), None, None, None
 
 
+def _dense_ok(K_in, N_out):
+    """shapes csrc/linear.hip takes (everything the dual-path separators of the reference's recipes use); others go to torch's BLAS"""
+    return K_in % 64 == 0 and N_out % 64 == 0
+
+
+def _wgrad_slabs(ntok, N, K):
+    """number of partial sums of sep_linear_bwd_weight: ~512 workgroups, at least 32 tokens per slab"""
+    tiles = max(1, (N // (128 if N % 128 == 0 else 64)) * (K // (128 if K % 128 == 0 else 64)))
+    return int(max(1, min(512 // tiles, (ntok + 255) // 256)))
+
+
+def dense_forward(x2, w, bias=None, bias2=None):
+    """x2 (ntok, K) @ w (N, K).t() + bias + bias2 -> (ntok, N)"""
+    ntok, Kin = x2.shape
+    N = w.shape[0]
+    if not (_dense_ok(Kin, N) and takes(x2)):
+        out = x2 @ w.t()
+        for b in (bias, bias2):
+            if b is not None:
+                out = out + b
+        return out
+    y = torch.empty(ntok, N, device=x2.device, dtype=x2.dtype)
+    backend().linear_fwd(x2.contiguous(), w.contiguous(), bias, bias2, y, ntok, Kin, N)
+    return y
+
+
+def dense_backward_input(dy2, w, out=None):
+    """dy2 (ntok, N) @ w (N, K) -> (ntok, K); `out`: added to it in place"""
+    ntok, N = dy2.shape
+    Kin = w.shape[1]
+    if not (_dense_ok(Kin, N) and takes(dy2)):
+        r = dy2 @ w
+        return r if out is None else out.add_(r)
+    dx = out if out is not None else torch.empty(ntok, Kin, device=dy2.device, dtype=dy2.dtype)
+    backend().linear_bwd_input(dy2.contiguous(), w.contiguous(), dx, ntok, Kin, N, out is not None)
+    return dx
+
+
+def dense_backward_weight(dy2, x2, want_bias=False, L=1, shift=0):
+    """dy2 (ntok, N).t() @ shifted(x2) (ntok, K) -> (N, K) [, dy2.sum(0)]; shift = -1 / +1: x2 is read one step earlier / later inside
+    sequences of L steps (zero beyond the sequence's ends) -- the h_{t-1} operand of an LSTM's recurrent weight gradient"""
+    ntok, N = dy2.shape
+    Kin = x2.shape[1]
+    if not (_dense_ok(Kin, N) and takes(dy2)):
+        xs = x2
+        if shift:
+            xv = x2.reshape(ntok // L, L, Kin)
+            xs = torch.zeros_like(xv)
+            if shift < 0:
+                xs[:, 1:] = xv[:, :-1]
+            else:
+                xs[:, :-1] = xv[:, 1:]
+            xs = xs.reshape(ntok, Kin)
+        return dy2.t() @ xs, (dy2.sum(dim=0) if want_bias else None)
+    K_ = backend()
+    ns = _wgrad_slabs(ntok, N, Kin)
+    part = torch.empty(ns, N, Kin, device=dy2.device, dtype=dy2.dtype)
+    pb = torch.empty(ns, N, device=dy2.device, dtype=dy2.dtype) if want_bias else None
+    K_.linear_bwd_weight(dy2.contiguous(), x2.contiguous(), part, pb, ntok, Kin, N, L, shift, ns)
+    dw = torch.empty(N, Kin, device=dy2.device, dtype=dy2.dtype)
+    segs = [(part, 0, dw, N * Kin, ns, N * Kin, 0, 1.0)]
+    db = None
+    if want_bias:
+        db = torch.empty(N, device=dy2.device, dtype=dy2.dtype)
+        segs.append((pb, 0, db, N, ns, N, 0, 1.0))
+    K_.reduce_slabs(segs)
+    return dw, db
+
+
+class DenseFn(torch.autograd.Function):
+    """nn.Linear on [..., K] activations through csrc/linear.hip (reference src/models/dprnn.py:96-99,143-146: the fc layers)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x2 = x.reshape(-1, x.shape[-1])
+        ctx.save_for_backward(x2, weight)
+        ctx.xshape, ctx.has_bias = x.shape, bias is not None
+        return dense_forward(x2, weight, bias).reshape(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        d2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+        dx = dense_backward_input(d2, weight).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dw, db = dense_backward_weight(d2, x2, want_bias=ctx.has_bias)
+        return dx, dw, db
+
+
+def linear_apply(x, fc):
+    """x (..., K) through an nn.Linear parameter container"""
+    if isinstance(fc, torch.nn.Linear) and _dense_ok(fc.in_features, fc.out_features) and takes(x):
+        return DenseFn.apply(x, fc.weight, fc.bias)
+    return fc(x)
+
+
 class LSTMDirectionFn(torch.autograd.Function):
     """One direction of nn.LSTM(batch_first=True) with zero initial state: x (nseq, L, F) -> h (nseq, L, H).
 
     The recurrence is libsepkernels (`sep_lstm_fwd` / `sep_lstm_bwd`: W_hh register-resident, persistent over the L
-    steps); the input projection and the three weight-gradient products are plain GEMMs and go to the BLAS library
-    through torch (addmm / mm), as a library GEMM is exactly what they are.
+    steps); the input projection and the three weight-gradient products are token-major dense layers (csrc/linear.hip where
+    the feature counts are multiples of 64, torch's BLAS otherwise).
     reference: src/models/dprnn.py:65-148 (nn.LSTM inside IntraChunkRNN / InterChunkRNN)."""
 
     @staticmethod
@@ -357,7 +452,7 @@ class LSTMDirectionFn(torch.autograd.Function):
         nseq, L, F = x.shape
         H = w_hh.shape[1]
         x2 = x.reshape(nseq * L, F)
-        xg = torch.addmm(b_ih + b_hh, x2, w_ih.t())                      # (nseq*L, 4H)
+        xg = dense_forward(x2, w_ih, b_ih, b_hh)                          # (nseq*L, 4H)
         h = torch.empty(nseq, L, H, device=x.device, dtype=x.dtype)
         gates = torch.empty(nseq, L, 4 * H, device=x.device, dtype=x.dtype)
         cst = torch.empty(nseq, L, H, device=x.device, dtype=x.dtype)
@@ -374,15 +469,10 @@ class LSTMDirectionFn(torch.autograd.Function):
         dxg = torch.empty(nseq, L, 4 * H, device=dh.device, dtype=dh.dtype)
         K.lstm_bwd(dh.contiguous(), gates, cst, w_hh.contiguous(), dxg, nseq, L, H, ctx.reverse)
         d2 = dxg.reshape(nseq * L, 4 * H)
-        hprev = torch.zeros_like(h)                                       # h_{t-1} of every step (zero initial state)
-        if ctx.reverse:
-            hprev[:, :-1] = h[:, 1:]
-        else:
-            hprev[:, 1:] = h[:, :-1]
-        dw_ih = d2.t() @ x2
-        dw_hh = d2.t() @ hprev.reshape(nseq * L, H)
-        db = d2.sum(dim=0)
-        dx = (d2 @ w_ih).reshape(nseq, L, F)
+        dw_ih, db = dense_backward_weight(d2, x2, want_bias=True)
+        # h_{t-1} of every step (zero initial state): h read one step earlier (later, for the reversed direction)
+        dw_hh, _ = dense_backward_weight(d2, h.reshape(nseq * L, H), L=L, shift=(1 if ctx.reverse else -1))
+        dx = dense_backward_input(d2, w_ih).reshape(nseq, L, F)
         return dx, dw_ih, dw_hh, db, db, None
 
 
@@ -397,9 +487,14 @@ class LSTMBidirectionalFn(torch.autograd.Function):
         nseq, L, F = x.shape
         H = w_hh_f.shape[1]
         x2 = x.reshape(nseq * L, F)
-        xg = torch.empty(2, nseq * L, 4 * H, device=x.device, dtype=x.dtype)
-        torch.addmm(b_ih_f + b_hh_f, x2, w_ih_f.t(), out=xg[0])
-        torch.addmm(b_ih_r + b_hh_r, x2, w_ih_r.t(), out=xg[1])
+        if _dense_ok(F, 4 * H) and takes(x2):
+            xg = torch.empty(2, nseq * L, 4 * H, device=x.device, dtype=x.dtype)
+            K.linear_fwd(x2.contiguous(), w_ih_f.contiguous(), b_ih_f, b_hh_f, xg[0], nseq * L, F, 4 * H)
+            K.linear_fwd(x2.contiguous(), w_ih_r.contiguous(), b_ih_r, b_hh_r, xg[1], nseq * L, F, 4 * H)
+        else:
+            xg = torch.empty(2, nseq * L, 4 * H, device=x.device, dtype=x.dtype)
+            torch.addmm(b_ih_f + b_hh_f, x2, w_ih_f.t(), out=xg[0])
+            torch.addmm(b_ih_r + b_hh_r, x2, w_ih_r.t(), out=xg[1])
         w_hh = torch.stack([w_hh_f, w_hh_r]).contiguous()
         h = torch.empty(2, nseq, L, H, device=x.device, dtype=x.dtype)
         gates = torch.empty(2, nseq, L, 4 * H, device=x.device, dtype=x.dtype)
@@ -418,13 +513,15 @@ class LSTMBidirectionalFn(torch.autograd.Function):
         dxg = torch.empty(2, nseq, L, 4 * H, device=dy.device, dtype=dy.dtype)
         K.lstm_bwd(dh, gates, cst, w_hh, dxg, nseq, L, H, 2)
         d2 = dxg.reshape(2, nseq * L, 4 * H)
-        hprev = torch.zeros_like(h)                                        # h_{t-1} as each direction saw it
-        hprev[0, :, 1:] = h[0, :, :-1]
-        hprev[1, :, :-1] = h[1, :, 1:]
-        hp2 = hprev.reshape(2, nseq * L, H)
-        dx = (d2[0] @ w_ih_f + d2[1] @ w_ih_r).reshape(nseq, L, F)
-        db_f, db_r = d2[0].sum(dim=0), d2[1].sum(dim=0)
-        return (dx, d2[0].t() @ x2, d2[0].t() @ hp2[0], db_f, db_f, d2[1].t() @ x2, d2[1].t() @ hp2[1], db_r, db_r)
+        h2 = h.reshape(2, nseq * L, H)
+        dx = dense_backward_input(d2[0], w_ih_f)
+        dx = dense_backward_input(d2[1], w_ih_r, out=dx).reshape(nseq, L, F)
+        dw_ih_f, db_f = dense_backward_weight(d2[0], x2, want_bias=True)
+        dw_ih_r, db_r = dense_backward_weight(d2[1], x2, want_bias=True)
+        # h_{t-1} as each direction saw it: h one step earlier (forward) / later (reversed), zero at the sequence's end
+        dw_hh_f, _ = dense_backward_weight(d2[0], h2[0], L=L, shift=-1)
+        dw_hh_r, _ = dense_backward_weight(d2[1], h2[1], L=L, shift=1)
+        return (dx, dw_ih_f, dw_hh_f, db_f, db_f, dw_ih_r, dw_hh_r, db_r, db_r)
 
 
 def lstm_bidirectional(x, rnn):

@@ -33,7 +33,7 @@ extern "C" {
 
 typedef void* sep_stream_t; /* hipStream_t */
 
-#define SEP_ABI_VERSION 17
+#define SEP_ABI_VERSION 18
 #define SEP_STATS_SLOTS 16
 #define SEP_ARRIVE_INTS 17 /* arrival counters per sample: one per slot + one for the slots (csrc/common.hpp, gln_bwd_publish) */
 
@@ -411,6 +411,22 @@ int sep_lstm_fwd(const float* xg, const float* w_hh, float* h_out, float* gates,
                  int reverse, sep_stream_t stream);
 int sep_lstm_bwd(const float* dh_out, const float* gates, const float* cstate, const float* w_hh, float* dxg, int nseq,
                  int L, int H, int reverse, sep_stream_t stream);
+
+/* Token-major dense layers of the dual-path separators (fp32 on the matrix pipe): the LSTMs' input projections and the nn.Linear behind
+ * them at reference src/models/dprnn.py:65-148, with their gradients -- torch.addmm / `@` on [tokens][features] activations (features
+ * contiguous) and torch's [N out][K in] weights.  K and N: multiples of 64 (sep_linear_fwd: K of 32; sep_linear_bwd_input: N of 32).
+ *   sep_linear_fwd         y[t][n] = sum_k x[t][k] w[n][k] + bias[n] + bias2[n]          (bias, bias2 may be NULL)
+ *   sep_linear_bwd_input   dx[t][k] = sum_n dy[t][n] w[n][k]                             (accumulate != 0: added to dx)
+ *   sep_linear_bwd_weight  partial[s][n][k] = sum over the tokens of slab s of dy[t][n] x[t + shift][k],  s < nslab (the caller adds the
+ *                          slabs: sep_reduce_slabs), partial_bias[s][n] = sum of dy[t][n] over the same tokens (may be NULL).
+ *                          shift in {-1, 0, +1} and L: with shift != 0 the tokens are sequences of L steps (ntok % L == 0) and x[t + shift]
+ *                          is the previous / next step's row of the SAME sequence, zero at its first / last step: the h_{t-1} operand of
+ *                          the recurrent weights' gradient (dW_hh = sum_t dgates_t h_{t-1}^T) taken from h itself. */
+int sep_linear_fwd(const float* x, const float* w, const float* bias, const float* bias2, float* y, long ntok, int K, int N,
+                   sep_stream_t stream);
+int sep_linear_bwd_input(const float* dy, const float* w, float* dx, long ntok, int K, int N, int accumulate, sep_stream_t stream);
+int sep_linear_bwd_weight(const float* dy, const float* x, float* partial, float* partial_bias, long ntok, int K, int N, int L,
+                          int shift, int nslab, sep_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -642,6 +642,40 @@ class EmuBackend:
             dc = dcc * f
             dhr = da @ w_hh
 
+    # ---- token-major dense layers (csrc/linear.hip)
+    def linear_fwd(self, x, w, bias, bias2, y, ntok, K, N):
+        out = x.reshape(ntok, K) @ w.reshape(N, K).t()
+        if bias is not None:
+            out = out + bias
+        if bias2 is not None:
+            out = out + bias2
+        y.reshape(ntok, N)[:] = out
+
+    def linear_bwd_input(self, dy, w, dx, ntok, K, N, accumulate):
+        out = dy.reshape(ntok, N) @ w.reshape(N, K)
+        if accumulate:
+            dx.reshape(ntok, K)[:] += out
+        else:
+            dx.reshape(ntok, K)[:] = out
+
+    def linear_bwd_weight(self, dy, x, partial, partial_bias, ntok, K, N, L, shift, nslab):
+        d2, x2 = dy.reshape(ntok, N), x.reshape(ntok, K)
+        if shift:
+            xs = torch.zeros_like(x2).reshape(ntok // L, L, K)
+            xv = x2.reshape(ntok // L, L, K)
+            if shift < 0:
+                xs[:, 1:] = xv[:, :-1]
+            else:
+                xs[:, :-1] = xv[:, 1:]
+            x2 = xs.reshape(ntok, K)
+        chunks = (ntok + 31) // 32
+        per = (chunks + nslab - 1) // nslab * 32
+        for s_ in range(nslab):
+            lo, hi = min(ntok, s_ * per), min(ntok, (s_ + 1) * per)
+            partial.reshape(nslab, N, K)[s_] = d2[lo:hi].t() @ x2[lo:hi]
+            if partial_bias is not None:
+                partial_bias.reshape(nslab, N)[s_] = d2[lo:hi].sum(0)
+
     def adam_step_dev(self, p, g, m, v, sqnorm, n, lr_dev, step_dev, beta1, beta2, eps, weight_decay, max_norm, grad_scale):
         step_dev += 1
         self.adam_step(p, g, m, v, sqnorm, n, float(lr_dev[0]), beta1, beta2, eps, weight_decay, max_norm, grad_scale, int(step_dev[0]))

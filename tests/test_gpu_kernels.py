@@ -902,6 +902,49 @@ def test_segment_overlap_add(T, chunk, hop):
 LSTM_KERNELS = {"sixteen": 0x100, "four": 0x200}      # SEP_LSTM_FORCE16 / SEP_LSTM_FORCE4: every case runs on both sweep kernels
 
 
+# ------------------------------------------------------------------------------------------- token-major dense layers
+@pytest.mark.parametrize("ntok,K,N", [(1000, 64, 512), (777, 256, 64), (130, 128, 128), (64, 64, 64), (3001, 128, 512)])
+def test_linear_forward_and_input_gradient(ntok, K, N):
+    """sep_linear_fwd / sep_linear_bwd_input against x @ w.t() + b and dy @ w (ragged last 128-token tile; both column tile widths)."""
+    x, w, b1, b2 = rnd(ntok, K), rnd(N, K, scale=K ** -0.5), rnd(N), rnd(N)
+    both("linear_fwd", [x, w, b1, b2, nan(ntok, N), ntok, K, N])
+    both("linear_fwd", [x, w, None, None, nan(ntok, N), ntok, K, N])
+    dy = rnd(ntok, N)
+    both("linear_bwd_input", [dy, w, nan(ntok, K), ntok, K, N, 0], tol=2e-4 * (N / 64) ** 0.5)
+    both("linear_bwd_input", [dy, w, rnd(ntok, K), ntok, K, N, 1], tol=2e-4 * (N / 64) ** 0.5)
+
+
+@pytest.mark.parametrize("nseq,L,K,N,shift,nslab", [(32, 20, 64, 512, 0, 7), (9, 31, 128, 512, -1, 3), (9, 31, 128, 512, 1, 5), (5, 250, 256, 64, 0, 40),
+                                                    (3, 7, 64, 64, -1, 1), (40, 50, 128, 128, 1, 64)])
+def test_linear_weight_gradient(nseq, L, K, N, shift, nslab):
+    """sep_linear_bwd_weight: dy.t() @ x in nslab partial sums (slabs beyond the last token are zero), the bias sums, and the x operand
+    read one step earlier / later inside sequences of L steps (the h_{t-1} of an LSTM's recurrent weight gradient)."""
+    ntok = nseq * L
+    dy, x = rnd(ntok, N), rnd(ntok, K)
+    part_c, pb_c = nan(nslab, N, K), nan(nslab, N)
+    part_g, pb_g = to_device(part_c), to_device(pb_c)
+    EMU.linear_bwd_weight(dy, x, part_c, pb_c, ntok, K, N, L, shift, nslab)
+    HIP.linear_bwd_weight(to_device(dy), to_device(x), part_g, pb_g, ntok, K, N, L, shift, nslab)
+    device_sync()
+    ref = part_c.sum(0)
+    assert torch.isfinite(part_g).all() and torch.isfinite(pb_g).all()
+    assert (part_g.cpu() - part_c).abs().max() <= 2e-4 * ref.abs().max()                 # slab by slab: the partition is part of the contract
+    assert (pb_g.cpu() - pb_c).abs().max() <= 2e-4 * max(1.0, pb_c.sum(0).abs().max().item())
+    # ... and against the plain formula
+    xs = x.reshape(nseq, L, K)
+    if shift:
+        z = torch.zeros_like(xs)
+        if shift < 0:
+            z[:, 1:] = xs[:, :-1]
+        else:
+            z[:, :-1] = xs[:, 1:]
+        xs = z
+    want = dy.double().t() @ xs.reshape(ntok, K).double()
+    assert (part_g.cpu().double().sum(0) - want).abs().max() <= 2e-4 * want.abs().max()
+    HIP.linear_bwd_weight(to_device(dy), to_device(x), part_g, None, ntok, K, N, L, shift, nslab)      # without the bias sums
+    device_sync()
+
+
 @pytest.mark.parametrize("kernel", sorted(LSTM_KERNELS))
 @pytest.mark.parametrize("H,nseq,L,reverse", [(16, 5, 7, 0), (32, 37, 23, 1), (64, 16, 40, 0), (128, 50, 31, 1), (128, 33, 250, 0)])
 def test_lstm_sweeps(H, nseq, L, reverse, kernel):
