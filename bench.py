@@ -505,9 +505,9 @@ def bench_dual_path(args):
     """The dual-path separators at the sizes of the reference's own recipes, 2 speakers, 4 s @ 8 kHz, the recipe's batch size, one
     GPU: forward + PIT(NegSI-SDR) + backward + clip(5) + Adam (torch.optim.Adam: these models' parameters are ordinary tensors).
     A frame is one encoder frame.  Analysis / synthesis bases, every 1x1 convolution of the separator's two ends, chunking /
-    overlap-add, gLN and the LSTM time recurrences are this library's kernels; attention, the transformer feed-forward layers, the
-    LSTM input projections, the Linear layers and their weight gradients are library GEMMs (torch -> rocBLAS / SDPA), as DESIGN.md
-    states."""
+    overlap-add, gLN, the LSTM time recurrences, the LSTMs' input projections and the Linear layers behind them (with their input / weight
+    gradients: csrc/linear.hip, fp32 on the matrix pipe) are this library's kernels; attention and the transformer feed-forward layers
+    are library calls (torch -> hipBLASLt / SDPA), as DESIGN.md states."""
     import sepkernels
     from criterion.sdr import NegSISDR
     from criterion.pit import PIT1d
@@ -553,11 +553,12 @@ def bench_dual_path(args):
         config["algorithmic_gflop_per_utterance_fwd_bwd"] = gflop
         tf = gflop * 1e9 * B * args.steps / el / 1e12
         # the step's arithmetic is fp32 throughout (the LSTM recurrences on v_mfma_f32_16x16x4 / 4x4x1, projections on rocBLAS fp32): matrix-pipe roof
-        roofline = {"kernel": "whole step (sep_lstm_fwd / sep_lstm_bwd sweeps ~80 % of it)", "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS,
+        roofline = {"kernel": "whole step (rocprofv3, profiles/r03v_dprnn_kernel_stats.md: sep_lstm_fwd / sep_lstm_bwd sweeps 34 % of the kernel time, the dense "
+                              "layers of csrc/linear.hip 37 %, layout copies 18 %; the GPU idles a third of the step behind the Python launches)", "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
                     "what": "algorithmic fp32 FLOP of forward + backward (SURVEY.md 8d: {:.0f} GFLOP per utterance) / step time against the dense fp32 MFMA "
-                            "peak; the recurrences are latency-bound chains (one workgroup per 4 or 16 sequences, a barrier per time step), not "
-                            "throughput-bound".format(gflop)}
+                            "peak; the recurrences are latency-bound chains (one workgroup per 4 or 16 sequences, a barrier per time step), the "
+                            "dense layers run at 50 - 70 TFLOP/s".format(gflop)}
         note = "{:.0f} GFLOP per utterance (SURVEY.md 8d): {:.1f} TFLOP/s achieved".format(gflop, tf)
     print(json.dumps({
         "metric": "separated audio frames/sec (fwd+bwd), {} 2-spk 4s@8kHz".format("DPRNN-TasNet" if args.config == "dprnn" else cls.__name__) +

@@ -81,46 +81,41 @@ __global__ __launch_bounds__(256) void linear_kernel(const lin_args p) {
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
     float bsum = 0.f;                                     // BWD_WEIGHT: this thread's share of a row sum of dy (thread = (row, half))
 
-    for (long r0 = r_begin; r0 < r_end; r0 += LIN_RC) {
-        // ---- gather the A tile [TI][32] and the B tile [TJ][32] (contiguous along the contraction)
+    // A tile [TI][32] and B tile [TJ][32], both contiguous along the contraction: a straight copy of 128-byte row pieces where the operand
+    // is stored that way, float4s along the OTHER index scattered into four rows where it is not.  Granule g (4 steps) of row `row` sits
+    // at granule g ^ ((row >> 4) & 3): the scattered writes of 32 lanes then fall on 16 banks instead of 4 (rows 4 apart are 16 banks
+    // apart at this pitch), and the operand reads -- 16 consecutive rows per quarter wave, one swizzle value -- stay conflict-free.
+    // The global loads of chunk c + 1 are issued before the MFMAs of chunk c and land in registers (fa / fb) behind them.
+    constexpr int QA = TI / 32, QB = TJ / 32;
+    float4 fa[QA], fb[QB];
+    auto fetch = [&](const long r0) {
         if (MODE == LIN_FWD || MODE == LIN_BWD_INPUT) {
-            // A(i, r) = a[i0 + i][r0 + r]: rows of 128 bytes, float4 per thread
-            const int lda = MODE == LIN_FWD ? p.K : p.N;
+            const int lda = MODE == LIN_FWD ? p.K : p.N;          // A(i, r) = a[i0 + i][r0 + r]
 #pragma unroll
-            for (int q = 0; q < TI / 32; ++q) {
-                const int row = (tid >> 3) + 32 * q, c4 = tid & 7;
-                const long gi = i0 + row;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gi < p.ntok) v = *reinterpret_cast<const float4*>(p.a + gi * lda + r0 + 4 * c4);
-                *reinterpret_cast<float4*>(&As[row * LIN_LD + 4 * c4]) = v;
+            for (int q = 0; q < QA; ++q) {
+                const long gi = i0 + (tid >> 3) + 32 * q;
+                fa[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gi < p.ntok) fa[q] = *reinterpret_cast<const float4*>(p.a + gi * lda + r0 + 4 * (tid & 7));
             }
-        } else {
-            // A(i, r) = dy[r0 + r][i0 + i]: float4 along i, transposed on the way in
+        } else {                                                  // A(i, r) = dy[r0 + r][i0 + i]: float4 along i
 #pragma unroll
-            for (int q = 0; q < TI / 32; ++q) {
-                const int rr = (tid / (TI / 4)) + (256 / (TI / 4)) * q, iq = tid % (TI / 4);
-                const long gt = r0 + rr;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gt < r_end) v = *reinterpret_cast<const float4*>(p.a + gt * p.N + i0 + 4 * iq);
-                As[(4 * iq + 0) * LIN_LD + rr] = v.x; As[(4 * iq + 1) * LIN_LD + rr] = v.y;
-                As[(4 * iq + 2) * LIN_LD + rr] = v.z; As[(4 * iq + 3) * LIN_LD + rr] = v.w;
+            for (int q = 0; q < QA; ++q) {
+                const long gt = r0 + (tid / (TI / 4)) + (256 / (TI / 4)) * q;
+                fa[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gt < r_end) fa[q] = *reinterpret_cast<const float4*>(p.a + gt * p.N + i0 + 4 * (tid % (TI / 4)));
             }
         }
-        if (MODE == LIN_FWD) {
-            // B(r, j) = w[j0 + j][r0 + r]
+        if (MODE == LIN_FWD) {                                    // B(r, j) = w[j0 + j][r0 + r]
 #pragma unroll
-            for (int q = 0; q < TJ / 32; ++q) {
-                const int row = (tid >> 3) + 32 * q, c4 = tid & 7;
-                *reinterpret_cast<float4*>(&Bs[row * LIN_LD + 4 * c4]) = *reinterpret_cast<const float4*>(p.b + (size_t)(j0 + row) * p.K + r0 + 4 * c4);
-            }
-        } else {
-            // B(r, j) = b[row(r0 + r)][j0 + j] with b = w (BWD_INPUT) or the (shifted) x (BWD_WEIGHT): float4 along j, transposed
+            for (int q = 0; q < QB; ++q)
+                fb[q] = *reinterpret_cast<const float4*>(p.b + (size_t)(j0 + (tid >> 3) + 32 * q) * p.K + r0 + 4 * (tid & 7));
+        } else {                                                  // B(r, j) = w[r0 + r][j0 + j] or the (shifted) x[r0 + r][j0 + j]: float4 along j
 #pragma unroll
-            for (int q = 0; q < TJ / 32; ++q) {
+            for (int q = 0; q < QB; ++q) {
                 const int rr = (tid / (TJ / 4)) + (256 / (TJ / 4)) * q, jq = tid % (TJ / 4);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                fb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (MODE == LIN_BWD_INPUT) {
-                    v = *reinterpret_cast<const float4*>(p.b + (size_t)(r0 + rr) * p.K + j0 + 4 * jq);
+                    fb[q] = *reinterpret_cast<const float4*>(p.b + (size_t)(r0 + rr) * p.K + j0 + 4 * jq);
                 } else {
                     const long gt = r0 + rr;
                     bool ok = gt < r_end;
@@ -130,14 +125,38 @@ __global__ __launch_bounds__(256) void linear_kernel(const lin_args p) {
                         ok = ok && step >= 0 && step < p.L;
                         src = gt + p.shift;
                     }
-                    if (ok) v = *reinterpret_cast<const float4*>(p.b + src * p.K + j0 + 4 * jq);
+                    if (ok) fb[q] = *reinterpret_cast<const float4*>(p.b + src * p.K + j0 + 4 * jq);
                 }
-                Bs[(4 * jq + 0) * LIN_LD + rr] = v.x; Bs[(4 * jq + 1) * LIN_LD + rr] = v.y;
-                Bs[(4 * jq + 2) * LIN_LD + rr] = v.z; Bs[(4 * jq + 3) * LIN_LD + rr] = v.w;
             }
         }
+    };
+    auto put_row = [&](float* tile, const int row, const int c4, const float4 v) {           // 4 steps of one row
+        *reinterpret_cast<float4*>(&tile[row * LIN_LD + 4 * (c4 ^ ((row >> 4) & 3))]) = v;
+    };
+    auto put_col = [&](float* tile, const int row4, const int rr, const float4 v) {          // step rr of rows row4 .. row4 + 3
+        const int c = 4 * ((rr >> 2) ^ ((row4 >> 4) & 3)) + (rr & 3);
+        tile[(row4 + 0) * LIN_LD + c] = v.x; tile[(row4 + 1) * LIN_LD + c] = v.y;
+        tile[(row4 + 2) * LIN_LD + c] = v.z; tile[(row4 + 3) * LIN_LD + c] = v.w;
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int q = 0; q < QA; ++q) {
+            if (MODE == LIN_FWD || MODE == LIN_BWD_INPUT) put_row(As, (tid >> 3) + 32 * q, tid & 7, fa[q]);
+            else put_col(As, 4 * (tid % (TI / 4)), (tid / (TI / 4)) + (256 / (TI / 4)) * q, fa[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < QB; ++q) {
+            if (MODE == LIN_FWD) put_row(Bs, (tid >> 3) + 32 * q, tid & 7, fb[q]);
+            else put_col(Bs, 4 * (tid % (TJ / 4)), (tid / (TJ / 4)) + (256 / (TJ / 4)) * q, fb[q]);
+        }
+    };
+
+    if (r_begin < r_end) fetch(r_begin);
+    for (long r0 = r_begin; r0 < r_end; r0 += LIN_RC) {
+        commit();
         __syncthreads();
-        if (MODE == LIN_BWD_WEIGHT && p.cbias != nullptr && j0 == 0 && tid < 2 * TI) {      // row sums of dy: thread = (row, 16-step half)
+        if (r0 + LIN_RC < r_end) fetch(r0 + LIN_RC);
+        if (MODE == LIN_BWD_WEIGHT && p.cbias != nullptr && j0 == 0 && tid < 2 * TI) {      // row sums of dy: thread = (row, 16-step half; the swizzle stays inside a half)
             const float* rp = &As[(tid >> 1) * LIN_LD + 16 * (tid & 1)];
             float s = 0.f;
 #pragma unroll
@@ -146,14 +165,18 @@ __global__ __launch_bounds__(256) void linear_kernel(const lin_args p) {
         }
         // ---- 16 k-steps of 2: a lane's float4 holds the contraction steps {4g + 16 lk .. + 3} of its row -- the pairing of steps into
         // the instruction's two k slots is free as long as A and B agree on it
+        const int swa = ((32 * wr + l31) >> 4) & 3;              // the swizzle of this lane's rows
         const float* ap = &As[(32 * wr + l31) * LIN_LD + 16 * lk];
         const float* bp = &Bs[(32 * NB * wc + l31) * LIN_LD + 16 * lk];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 a4 = *reinterpret_cast<const float4*>(ap + 4 * g);
+            const float4 a4 = *reinterpret_cast<const float4*>(ap + 4 * (g ^ swa));
             float4 b4[NB];
 #pragma unroll
-            for (int n = 0; n < NB; ++n) b4[n] = *reinterpret_cast<const float4*>(bp + 32 * n * LIN_LD + 4 * g);
+            for (int n = 0; n < NB; ++n) {
+                const int swb = ((32 * (NB * wc + n) + l31) >> 4) & 3;
+                b4[n] = *reinterpret_cast<const float4*>(bp + 32 * n * LIN_LD + 4 * (g ^ swb));
+            }
 #pragma unroll
             for (int n = 0; n < NB; ++n) {
                 acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4[n].x, acc[n], 0, 0, 0);

@@ -381,35 +381,46 @@ def dense_backward_input(dy2, w, out=None):
     return dx
 
 
+def dense_backward_weights(jobs):
+    """jobs: [(dy2 (ntok, N), x2 (ntok, K), want_bias, L, shift)] -> [(dy2.t() @ shifted(x2) (N, K), dy2.sum(0) or None)], the partial sums of
+    ALL jobs added in one sep_reduce_slabs launch.  shift = -1 / +1: x2 is read one step earlier / later inside sequences of L steps (zero
+    beyond the sequence's ends) -- the h_{t-1} operand of an LSTM's recurrent weight gradient, without materialising it."""
+    out, segs = [None] * len(jobs), []
+    K_ = None
+    for n_, (dy2, x2, want_bias, L, shift) in enumerate(jobs):
+        ntok, N = dy2.shape
+        Kin = x2.shape[1]
+        if not (_dense_ok(Kin, N) and takes(dy2)):
+            xs = x2
+            if shift:
+                xv = x2.reshape(ntok // L, L, Kin)
+                xs = torch.zeros_like(xv)
+                if shift < 0:
+                    xs[:, 1:] = xv[:, :-1]
+                else:
+                    xs[:, :-1] = xv[:, 1:]
+                xs = xs.reshape(ntok, Kin)
+            out[n_] = (dy2.t() @ xs, (dy2.sum(dim=0) if want_bias else None))
+            continue
+        K_ = K_ or backend()
+        ns = _wgrad_slabs(ntok, N, Kin)
+        part = torch.empty(ns, N, Kin, device=dy2.device, dtype=dy2.dtype)
+        pb = torch.empty(ns, N, device=dy2.device, dtype=dy2.dtype) if want_bias else None
+        K_.linear_bwd_weight(dy2.contiguous(), x2.contiguous(), part, pb, ntok, Kin, N, L, shift, ns)
+        dw = torch.empty(N, Kin, device=dy2.device, dtype=dy2.dtype)
+        segs.append((part, 0, dw, N * Kin, ns, N * Kin, 0, 1.0))
+        db = None
+        if want_bias:
+            db = torch.empty(N, device=dy2.device, dtype=dy2.dtype)
+            segs.append((pb, 0, db, N, ns, N, 0, 1.0))
+        out[n_] = (dw, db)
+    if segs:
+        K_.reduce_slabs(segs)
+    return out
+
+
 def dense_backward_weight(dy2, x2, want_bias=False, L=1, shift=0):
-    """dy2 (ntok, N).t() @ shifted(x2) (ntok, K) -> (N, K) [, dy2.sum(0)]; shift = -1 / +1: x2 is read one step earlier / later inside
-    sequences of L steps (zero beyond the sequence's ends) -- the h_{t-1} operand of an LSTM's recurrent weight gradient"""
-    ntok, N = dy2.shape
-    Kin = x2.shape[1]
-    if not (_dense_ok(Kin, N) and takes(dy2)):
-        xs = x2
-        if shift:
-            xv = x2.reshape(ntok // L, L, Kin)
-            xs = torch.zeros_like(xv)
-            if shift < 0:
-                xs[:, 1:] = xv[:, :-1]
-            else:
-                xs[:, :-1] = xv[:, 1:]
-            xs = xs.reshape(ntok, Kin)
-        return dy2.t() @ xs, (dy2.sum(dim=0) if want_bias else None)
-    K_ = backend()
-    ns = _wgrad_slabs(ntok, N, Kin)
-    part = torch.empty(ns, N, Kin, device=dy2.device, dtype=dy2.dtype)
-    pb = torch.empty(ns, N, device=dy2.device, dtype=dy2.dtype) if want_bias else None
-    K_.linear_bwd_weight(dy2.contiguous(), x2.contiguous(), part, pb, ntok, Kin, N, L, shift, ns)
-    dw = torch.empty(N, Kin, device=dy2.device, dtype=dy2.dtype)
-    segs = [(part, 0, dw, N * Kin, ns, N * Kin, 0, 1.0)]
-    db = None
-    if want_bias:
-        db = torch.empty(N, device=dy2.device, dtype=dy2.dtype)
-        segs.append((pb, 0, db, N, ns, N, 0, 1.0))
-    K_.reduce_slabs(segs)
-    return dw, db
+    return dense_backward_weights([(dy2, x2, want_bias, L, shift)])[0]
 
 
 class DenseFn(torch.autograd.Function):
@@ -469,9 +480,8 @@ class LSTMDirectionFn(torch.autograd.Function):
         dxg = torch.empty(nseq, L, 4 * H, device=dh.device, dtype=dh.dtype)
         K.lstm_bwd(dh.contiguous(), gates, cst, w_hh.contiguous(), dxg, nseq, L, H, ctx.reverse)
         d2 = dxg.reshape(nseq * L, 4 * H)
-        dw_ih, db = dense_backward_weight(d2, x2, want_bias=True)
         # h_{t-1} of every step (zero initial state): h read one step earlier (later, for the reversed direction)
-        dw_hh, _ = dense_backward_weight(d2, h.reshape(nseq * L, H), L=L, shift=(1 if ctx.reverse else -1))
+        (dw_ih, db), (dw_hh, _) = dense_backward_weights([(d2, x2, True, 1, 0), (d2, h.reshape(nseq * L, H), False, L, 1 if ctx.reverse else -1)])
         dx = dense_backward_input(d2, w_ih).reshape(nseq, L, F)
         return dx, dw_ih, dw_hh, db, db, None
 
@@ -516,11 +526,9 @@ class LSTMBidirectionalFn(torch.autograd.Function):
         h2 = h.reshape(2, nseq * L, H)
         dx = dense_backward_input(d2[0], w_ih_f)
         dx = dense_backward_input(d2[1], w_ih_r, out=dx).reshape(nseq, L, F)
-        dw_ih_f, db_f = dense_backward_weight(d2[0], x2, want_bias=True)
-        dw_ih_r, db_r = dense_backward_weight(d2[1], x2, want_bias=True)
         # h_{t-1} as each direction saw it: h one step earlier (forward) / later (reversed), zero at the sequence's end
-        dw_hh_f, _ = dense_backward_weight(d2[0], h2[0], L=L, shift=-1)
-        dw_hh_r, _ = dense_backward_weight(d2[1], h2[1], L=L, shift=1)
+        (dw_ih_f, db_f), (dw_ih_r, db_r), (dw_hh_f, _), (dw_hh_r, _) = dense_backward_weights(
+            [(d2[0], x2, True, 1, 0), (d2[1], x2, True, 1, 0), (d2[0], h2[0], False, L, -1), (d2[1], h2[1], False, L, 1)])
         return (dx, dw_ih_f, dw_hh_f, db_f, db_f, dw_ih_r, dw_hh_r, db_r, db_r)
 
 

@@ -521,6 +521,28 @@ def test_dprnn_tasnet_config4_full_size():
     ours = lstm_bidirectional(x, blk.rnn)
     ref, _ = blk.rnn(x)
     assert _rel(ours.detach(), ref.detach().cpu()) <= 1e-5
+    # ... and its gradients (input, the four weight matrices, the biases: sep_lstm_bwd + csrc/linear.hip, the recurrent weights' gradient
+    # reading h one step off) against autograd through MIOpen; then the Linear behind it against F.linear
+    go = torch.randn(510, 250, 256, device="cuda")
+    grads = []
+    for fn in (lambda t: lstm_bidirectional(t, blk.rnn), lambda t: blk.rnn(t)[0]):
+        xr = x.clone().requires_grad_(True)
+        blk.rnn.zero_grad()
+        fn(xr).backward(go)
+        grads.append([xr.grad.clone()] + [p.grad.clone() for p in blk.rnn.parameters()])
+    for a, b in zip(*grads):
+        assert _rel(a, b.cpu()) <= 2e-4
+    from sepkernels.functional import linear_apply
+    hcat = torch.randn(510 * 250, 256, device="cuda")
+    grads = []
+    for fn in (lambda t: linear_apply(t, blk.fc), lambda t: blk.fc(t)):
+        hr = hcat.clone().requires_grad_(True)
+        blk.fc.zero_grad()
+        y = fn(hr)
+        y.backward(torch.ones_like(y) * 0.5 + y.detach())
+        grads.append([y.detach().clone(), hr.grad.clone(), blk.fc.weight.grad.clone(), blk.fc.bias.grad.clone()])
+    for a, b in zip(*grads):
+        assert _rel(a, b.cpu()) <= 2e-4
 
 
 def test_paper_best_four_speakers_sinkpit_full_size():
