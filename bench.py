@@ -155,7 +155,8 @@ class TimedBackend:
 def roofline_by_kernel(timed, steps, arith_name):
     """One entry per launch class of the step (instrumented pass: HIP events around every launch, all on one stream): launches per step,
     average duration, algorithmic bytes per launch under both conventions (TimedBackend), and the fraction of the roof that bounds the
-    class -- HBM (8 TB/s) for everything but the weight gradients, whose bf16x6 arithmetic is matrix-pipe bound (2500 / 6 TFLOP/s-eq)."""
+    class -- min(HBM at 8 TB/s, matrix pipe of the arithmetic the class issues: roof_of()); the weight gradients run the arithmetic
+    wgrad_arith() names."""
     out = {}
     tot_ms = sum(r["ms"] for r in timed.by_class().values())
     for cls, r in sorted(timed.by_class().items(), key=lambda kv: -kv[1]["ms"]):
@@ -169,11 +170,11 @@ def roofline_by_kernel(timed, steps, arith_name):
             e["survey_8d_MB_per_launch"] = r["bytes_8d"] / n / 1e6
             e["hbm_frac_8d"] = r["bytes_8d"] / (ms * 1e-3) / 1e9 / (HBM_PEAK_TBS * 1e3)
         if r["flop"] > 0 and ms > 0:
-            ar = ("f32" if arith_name == "f32" else "bf16x6") if cls.startswith("wgrad") else arith_name
+            ar = wgrad_arith(arith_name) if cls.startswith("wgrad") else arith_name
             per, pipe = MFMA_PER_PRODUCT[ar]
             e["tflops_equiv"] = r["flop"] / (ms * 1e-3) / 1e12
             e["matrix_pipe_frac"] = e["tflops_equiv"] / (pipe / per)
-            e["bound"] = "mfma" if cls.startswith("wgrad") and ar != "f32" else "hbm"
+            e["bound"] = roof_of(ar, r["flop"], r["bytes_seq"])[0] if r["has_bytes"] else "mfma"
         elif r["has_bytes"]:
             e["bound"] = "hbm"
         else:
@@ -295,6 +296,14 @@ def pmc_traffic(group, live=None):
                 "traffic_live": False, "traffic_source": t["source"]}
     except (OSError, KeyError, ValueError):
         return {"traffic": None}
+
+
+def wgrad_arith(arith_name):
+    """arithmetic of the weight-gradient products: the forward arithmetic, except that SEPK_WGRAD_F16=0 keeps the exact three-way bf16
+    split (wgrad_pc.hip) under f16x3"""
+    if arith_name == "f16x3" and os.environ.get("SEPK_WGRAD_F16", "1") == "0":
+        return "bf16x6"
+    return arith_name
 
 
 def roof_of(arith, flop, nbytes):
@@ -685,9 +694,9 @@ def main():
         by_kernel = roofline_by_kernel(timed, args.steps, arith_name)
         roof = kernel_roofline(timed, "pw_gemm", arith_name, args.steps, el_i,
                                "sep_pw_gemm: pw_gemm_pc_kernel (K >= 512 or M >= 1024) / pw_gemm_coop_kernel")
-        # the weight gradient keeps the exact three-way bf16 split in every non-f32 arithmetic
-        roof_w = kernel_roofline(timed, "pw_wgrad", "f32" if arith_name == "f32" else "bf16x6", args.steps, el_i,
-                                 "sep_pw_wgrad: pw_wgrad_pc_kernel" if arith_name != "f32" else "sep_pw_wgrad: pw_wgrad_direct_kernel")
+        roof_w = kernel_roofline(timed, "pw_wgrad", wgrad_arith(arith_name), args.steps, el_i,
+                                 {"f16x3": "sep_pw_wgrad: pw_wgrad_pc16_kernel (256 x 128 tiles; other shapes pw_wgrad_pc_kernel, bf16x6)",
+                                  "bf16x6": "sep_pw_wgrad: pw_wgrad_pc_kernel", "f32": "sep_pw_wgrad: pw_wgrad_direct_kernel"}[wgrad_arith(arith_name)])
     # N = 1 only: the same K steps with sep_pw_gemm / sep_pw_wgrad on the fp32 MFMA instruction (v_mfma_f32_32x32x2_f32), i.e. the
     # reference's own arithmetic, reported beside the headline with its own roofline (peak 157.3 TFLOP/s)
     f32_pass = None
