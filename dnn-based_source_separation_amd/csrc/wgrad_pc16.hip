@@ -339,15 +339,14 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
         const int g_off = (64 * wr + l31) * RL;
         const int b_off = (128 * wcc + l31) * 4 + lk * 2 * TN * 4;               // + (64 * h + 32 * n) * 4 + part * TN * 4
 #define W16_SB() __builtin_amdgcn_sched_barrier(0)
-        auto read_raw_a = [&](const int gstage, auto parc) __attribute__((always_inline)) {      // chunk `par` of the pair in stage gstage
-            constexpr int par = decltype(parc)::value;
-            const float* Gb = sm.Gr[gstage] + g_off;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                const float4 x = ld4(Gb + mi * 32 * RL + 4 * ((4 * par + 2 * lk) ^ g_f));
-                const float4 y = ld4(Gb + mi * 32 * RL + 4 * ((4 * par + 2 * lk + 1) ^ g_f));
-                ra[mi][0] = x.x; ra[mi][1] = x.y; ra[mi][2] = x.z; ra[mi][3] = x.w; ra[mi][4] = y.x; ra[mi][5] = y.y; ra[mi][6] = y.z; ra[mi][7] = y.w;
-            }
+        // raw G rows of block mi of chunk `par` of the pair in stage gstage
+        auto read_raw_mi = [&](const int gstage, auto parc, auto mic) __attribute__((always_inline)) {
+            constexpr int par = decltype(parc)::value, mi = decltype(mic)::value;
+            const float* Gb = sm.Gr[gstage] + g_off + mi * 32 * RL;
+            const float4 x = ld4(Gb + 4 * ((4 * par + 2 * lk) ^ g_f));
+            const float4 y = ld4(Gb + 4 * ((4 * par + 2 * lk + 1) ^ g_f));
+            ra[mi][0] = x.x; ra[mi][1] = x.y; ra[mi][2] = x.z; ra[mi][3] = x.w; ra[mi][4] = y.x; ra[mi][5] = y.y; ra[mi][6] = y.z; ra[mi][7] = y.w;
+            W16_SB();
         };
         // micro-steps of the split of row block mi: (A) the row's new scale exponent; (B q) values 2q, 2q+1 scaled and split
         auto split_exp = [&](auto mic, const bool live) __attribute__((always_inline)) {
@@ -429,11 +428,12 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
         // never multiplied) and the rows' exponents / bias sums are left alone -- ten `last chunk?` branches per chunk in the MFMA stream, or
         // separate code paths for the tail (tried: the allocator then spills 870 registers at the joins), cost more.
         // The first column half's operands were fetched under the previous step (buffer buf), the next chunk's (buffer buf_next) are
-        // fetched here as soon as this chunk's first half is multiplied.
-        auto step = [&](auto parc, const bool more, const int buf, const int buf_next, const int gstage_next) __attribute__((always_inline)) {
+        // fetched here as soon as this chunk's first half is multiplied.  Likewise the raw G rows: the registers hold the NEXT chunk's rows
+        // when the step starts (they are split during it) and are refilled with the rows of the chunk after next (same parity, stage
+        // gstage2) as soon as each row block's split is done -- no LDS round trip in front of the first split either.
+        auto step = [&](auto parc, const bool more, const int buf, const int buf_next, const int gstage2) __attribute__((always_inline)) {
             constexpr int P = decltype(parc)::value;
             load_b(buf, W16_I(1));
-            read_raw_a(gstage_next, W16_I(P ^ 1));                               // raw G of the next chunk (landed before this step's barrier)
             W16_SB();
             follow_rows();                                                       // (scales chosen while the previous chunk was multiplied)
             follow_cols(W16_I(0));
@@ -447,6 +447,7 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
             split_pair(W16_I(P ^ 1), W16_I(0), W16_I(2));
             M(W16_I(P), W16_I(0), W16_I(8)); M(W16_I(P), W16_I(0), W16_I(9));
             split_pair(W16_I(P ^ 1), W16_I(0), W16_I(3));
+            read_raw_mi(gstage2, W16_I(P), W16_I(0));
             M(W16_I(P), W16_I(0), W16_I(10)); M(W16_I(P), W16_I(0), W16_I(11));
             load_b(buf_next, W16_I(0));                                          // (behind the last chunk: a stale buffer, never multiplied)
             follow_cols(W16_I(1));
@@ -460,6 +461,7 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
             split_pair(W16_I(P ^ 1), W16_I(1), W16_I(2));
             M(W16_I(P), W16_I(1), W16_I(8)); M(W16_I(P), W16_I(1), W16_I(9));
             split_pair(W16_I(P ^ 1), W16_I(1), W16_I(3));
+            read_raw_mi(gstage2, W16_I(P), W16_I(1));
             M(W16_I(P), W16_I(1), W16_I(10)); M(W16_I(P), W16_I(1), W16_I(11));
             W16_SB();
         };
@@ -467,31 +469,33 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
         w16_lgkm0_barrier();                                                     // B_-2: raw pair 0 has landed
         int gstage = 0;
         if (nk > 0) {                                                            // chunk 0 is scaled and split up front
-            read_raw_a(0, W16_I(0));
+            read_raw_mi(0, W16_I(0), W16_I(0)); read_raw_mi(0, W16_I(0), W16_I(1));
             split_exp(W16_I(0), true); split_exp(W16_I(1), true);
             split_pair(W16_I(0), W16_I(0), W16_I(0)); split_pair(W16_I(0), W16_I(0), W16_I(1)); split_pair(W16_I(0), W16_I(0), W16_I(2)); split_pair(W16_I(0), W16_I(0), W16_I(3));
             split_pair(W16_I(0), W16_I(1), W16_I(0)); split_pair(W16_I(0), W16_I(1), W16_I(1)); split_pair(W16_I(0), W16_I(1), W16_I(2)); split_pair(W16_I(0), W16_I(1), W16_I(3));
+            read_raw_mi(0, W16_I(1), W16_I(0)); read_raw_mi(0, W16_I(1), W16_I(1));      // chunk 1 (same pair): split during step 0
         }
         w16_lgkm0_barrier();                                                     // B_-1: the X operands of chunk 0 are there
         load_b(0, W16_I(0));
         int buf = 0;
         for (int j = 0; j < nk; j += 2) {
             W16STAMP(0, 0);
-            w16_lgkm0_barrier();                                                 // B_j: the X operands of chunk j+1 are there, raw G of chunk j+1 too
+            w16_lgkm0_barrier();                                                 // B_j: the X operands of chunk j+1 are there, the raw pair of chunk j+2 too
             W16STAMP(0, 1);
+            const int gnext = gstage + 1 == W16NGP ? 0 : gstage + 1;            // stage of the NEXT pair: chunks j+2 and j+3
             int nb = buf + 1 == W16NXB ? 0 : buf + 1;
-            step(W16_I(0), j + 1 < nk, buf, nb, gstage);                         // (the next chunk is the second of this pair)
+            step(W16_I(0), j + 1 < nk, buf, nb, gnext);
             buf = nb;
             W16STAMP(0, 2);
             if (j + 1 < nk) {
                 w16_lgkm0_barrier();                                             // B_{j+1}
                 W16STAMP(0, 3);
-                gstage = gstage + 1 == W16NGP ? 0 : gstage + 1;
                 nb = buf + 1 == W16NXB ? 0 : buf + 1;
-                step(W16_I(1), j + 2 < nk, buf, nb, gstage);
+                step(W16_I(1), j + 2 < nk, buf, nb, gnext);
                 buf = nb;
                 W16STAMP(0, 4);
             }
+            gstage = gnext;
         }
         follow_rows();                                                           // (a change decided with the last split has nothing to follow: no-op)
         // undo the scales: accumulator (row, column) is in units of 2^(gexp[row] + bcur[column])
