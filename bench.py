@@ -553,6 +553,31 @@ def bench_dual_path(args):
     el = time.perf_counter() - t0
     L, S = cfg["kernel_size"], cfg["stride"]
     F = (T_SAMPLES + (S - (T_SAMPLES - L) % S) % S - L) // S + 1
+    # Optional second leg (SEPK_GRAPH=1): the same step recorded into a hipGraph and replayed (sepkernels.train.GraphedStep).  Measured
+    # (profiles/r04d_dual.txt): replay = eager within 1 % for DPRNN-TasNet and DPTNet (36.9 vs 36.9, 45.2 vs 43.3 ms) -- these steps are
+    # bound by their kernels, not by the Python launches -- and the models with dropout (GALRNet, SepFormer) diverge under replay on this
+    # stack (loss inf), so the leg is off by default and flags itself invalid there.
+    graph_leg = None
+    if os.environ.get("SEPK_GRAPH", "0") == "1" and not args.no_graph:
+        try:
+            from sepkernels.train import GraphedStep
+            gopt = torch.optim.Adam(model.parameters(), capturable=True, **adam)
+            gstep = GraphedStep(model, crit, gopt, max_norm=5.0)
+            gstep.capture(mix, src)
+            for _ in range(args.warmup):
+                gstep(mix, src)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                gl = gstep(mix, src)
+            torch.cuda.synchronize()
+            gel = time.perf_counter() - t0
+            gl = float(gl)
+            graph_leg = {"ms_per_step": 1e3 * gel / args.steps, "value": B * F * args.steps / gel, "unit": "frames/s", "final_loss": gl,
+                         "valid": gl == gl and abs(gl) != float("inf"),
+                         "what": "the same step (fresh Adam state, parameters where the eager leg left them) as ONE hipGraph launch per step"}
+        except Exception as e:                                   # noqa: BLE001 -- a leg that cannot be recorded is reported, not fatal
+            graph_leg = {"error": "{}: {}".format(type(e).__name__, e)}
     config = {"workload": "{}, 2 spk, 4 s @ 8 kHz synthetic mixtures, batch {} (recipe default), fwd + PIT(NegSI-SDR) + bwd + clip(5) + Adam".format(label, B),
               "global_batch": B, "frames_per_utterance": F, "parallelism": "dp1", "utt_per_s": B * args.steps / el, "final_loss": float(loss),
               "parameters": model.num_parameters, "launch": launch}
@@ -563,7 +588,7 @@ def bench_dual_path(args):
         tf = gflop * 1e9 * B * args.steps / el / 1e12
         # the step's arithmetic is fp32 throughout (the LSTM recurrences on v_mfma_f32_16x16x4 / 4x4x1, projections on rocBLAS fp32): matrix-pipe roof
         roofline = {"kernel": "whole step (rocprofv3, profiles/r03v_dprnn_kernel_stats.md: sep_lstm_fwd / sep_lstm_bwd sweeps 34 % of the kernel time, the dense "
-                              "layers of csrc/linear.hip 37 %, layout copies 18 %; the GPU idles a third of the step behind the Python launches)", "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS,
+                              "layers of csrc/linear.hip 37 %, layout copies 18 %)", "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
                     "what": "algorithmic fp32 FLOP of forward + backward (SURVEY.md 8d: {:.0f} GFLOP per utterance) / step time against the dense fp32 MFMA "
                             "peak; the recurrences are latency-bound chains (one workgroup per 4 or 16 sequences, a barrier per time step), the "
@@ -573,7 +598,8 @@ def bench_dual_path(args):
         "metric": "separated audio frames/sec (fwd+bwd), {} 2-spk 4s@8kHz".format("DPRNN-TasNet" if args.config == "dprnn" else cls.__name__) +
                   (" (BASELINE configs[3])" if args.config == "dprnn" else ""), "value": B * F * args.steps / el, "unit": "frames/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": config, "roofline": roofline, "roofline_note": note}))
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": config, "roofline": roofline, "roofline_note": note,
+        "graph_replay": graph_leg}))
 
 
 def main():

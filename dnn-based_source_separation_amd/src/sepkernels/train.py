@@ -264,3 +264,75 @@ class FusedTrainStep:
         if self._graph is not None and getattr(self, "_graph_hyper", None) != (tuple(self.betas), self.eps, self.weight_decay):
             self._graph = None
 
+
+
+class GraphedStep:
+    """forward + criterion + backward [+ clip] + optimizer step of ANY separator of this tree, recorded once into a hipGraph and replayed.
+
+    For separators whose parameters are ordinary tensors (DPRNN-TasNet, DPTNet ...; ConvTasNet has FusedTrainStep.capture): shapes are
+    fixed and nothing in these steps reads back to the host, so the whole step can be one graph launch.  `optimizer` must keep its state
+    on the device and step without a host sync (torch.optim.Adam(..., capturable=True)).  Measured on MI355X (profiles/r04d_dual.txt):
+    replay equals the eager step to 1e-4 (tests/test_gpu_model.py) and takes the SAME time at the recipes' sizes (DPRNN-TasNet 36.9 ms
+    either way: the step is bound by its kernels) -- it pays where the launches are the bottleneck (small batches, short utterances).
+    Models with dropout diverged under replay on this stack (GALRNet, SepFormer: loss inf): use it for dropout-free configurations.
+
+        step = GraphedStep(model, criterion, optimizer, max_norm=5.0)
+        loss = step(mixture, sources)          # first call: three eager steps on a side stream (allocator warm-up), capture, then replay
+
+    The warm-up and the recording run real optimizer steps; `restore=True` (default) puts parameters, gradients-free, and the Adam
+    moments / step counts back IN PLACE afterwards (the graph holds their addresses), so that the first replay is the first step.
+    Batches of another shape need another GraphedStep.  reference: egs/wsj0-mix/common/src/driver.py:132-164 (the eager step)."""
+
+    def __init__(self, model, criterion, optimizer, max_norm=None, warmup=3, restore=True):
+        for g in optimizer.param_groups:
+            if not g.get("capturable", False):
+                raise ValueError("GraphedStep needs an optimizer that steps on the device: torch.optim.Adam(..., capturable=True)")
+        self.model, self.criterion, self.optimizer = model, criterion, optimizer
+        self.max_norm, self.warmup, self.restore = max_norm, int(warmup), bool(restore)
+        self._graph = self._static = self._loss = None
+
+    def _eager(self, mixture, sources):
+        self.optimizer.zero_grad(set_to_none=False)
+        out = self.criterion(self.model(mixture), sources)
+        loss = out[0] if isinstance(out, (tuple, list)) else out
+        loss.backward()
+        if self.max_norm is not None:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_norm)
+        self.optimizer.step()
+        return loss.detach()
+
+    def capture(self, mixture, sources):
+        params = [p for p in self.model.parameters()]
+        saved = [p.detach().clone() for p in params] if self.restore else None
+        self._static = (mixture.clone(), sources.clone())
+        for p in params:                                   # gradients must exist (and keep their addresses) before the recording
+            if p.grad is None and p.requires_grad:
+                p.grad = torch.zeros_like(p)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(self.warmup):
+                self._eager(*self._static)
+        torch.cuda.current_stream().wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._loss = self._eager(*self._static)
+        if self.restore:
+            with torch.no_grad():
+                for p, s in zip(params, saved):
+                    p.copy_(s)
+                for st in self.optimizer.state.values():   # Adam-family state starts at zero
+                    for v in st.values():
+                        if torch.is_tensor(v):
+                            v.zero_()
+        return self
+
+    def __call__(self, mixture, sources):
+        if self._graph is None:
+            self.capture(mixture, sources)
+        elif mixture.shape != self._static[0].shape or sources.shape != self._static[1].shape:
+            raise ValueError("GraphedStep was recorded for batches of shape {} / {}".format(tuple(self._static[0].shape), tuple(self._static[1].shape)))
+        self._static[0].copy_(mixture)
+        self._static[1].copy_(sources)
+        self._graph.replay()
+        return self._loss

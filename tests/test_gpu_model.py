@@ -697,3 +697,40 @@ def test_distance_and_sdr_criteria_on_gpu():
         got.backward()
         assert abs(got.item() - want.item()) <= 1e-5 * abs(want.item()), name
         assert _rel(xg.grad, xd.grad) <= 1e-5, name
+
+
+def test_graphed_step_replays_the_eager_step():
+    """sepkernels.train.GraphedStep: forward + PIT + backward + clip + Adam of a DPRNN-TasNet recorded into a hipGraph; three replayed
+    steps leave the same losses and parameters as three eager steps from the same start (the recording's own warm-up steps are undone)."""
+    from models.dprnn_tasnet import DPRNNTasNet
+    from sepkernels.train import GraphedStep
+    cfg = dict(n_basis=64, kernel_size=2, stride=1, enc_basis="trainable", dec_basis="trainable", enc_nonlinear=None, sep_hidden_channels=64,
+               sep_bottleneck_channels=64, sep_chunk_size=50, sep_hop_size=25, sep_num_blocks=2, sep_norm=True, mask_nonlinear="sigmoid",
+               causal=False, rnn_type="lstm", n_sources=2)
+    g = torch.Generator().manual_seed(3)
+    batches = [(0.1 * torch.randn(2, 2, 4000, generator=g)).cuda() for _ in range(3)]
+    runs = []
+    for graphed in (False, True):
+        torch.manual_seed(21)
+        model = DPRNNTasNet(**cfg).cuda()
+        crit = PIT1d(NegSISDR(), n_sources=2)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=graphed)
+        losses = []
+        if graphed:
+            step = GraphedStep(model, crit, opt, max_norm=5.0)
+            for src in batches:
+                losses.append(float(step(src.sum(1, keepdim=True).contiguous(), src)))
+        else:
+            for src in batches:
+                opt.zero_grad()
+                loss, _ = crit(model(src.sum(1, keepdim=True).contiguous()), src)
+                loss.backward()
+                torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+                opt.step()
+                losses.append(float(loss))
+        runs.append((losses, [p.detach().clone() for p in model.parameters()]))
+    (le, pe), (lg, pg) = runs
+    assert all(abs(a - b) <= 1e-4 * max(1.0, abs(a)) for a, b in zip(le, lg)), (le, lg)
+    assert le[0] != le[2]                                             # (the steps did train)
+    for a, b in zip(pe, pg):
+        assert _rel(b, a.cpu()) <= 1e-3
