@@ -4,7 +4,7 @@
 //
 //   sep_linear_fwd          y[t][n]  = sum_k x[t][k] w[n][k] + bias[n] (+ bias2[n])                  torch.addmm(b, x, w.t())
 //   sep_linear_bwd_input    dx[t][k] (+)= sum_n dy[t][n] w[n][k]                                       dy @ w
-//   sep_linear_bwd_weight   partial[s][n][k] = sum over the tokens of slab s of dy[t][n] x[t + shift][k]   dy.t() @ x, in `nslab` partial sums
+//   sep_linear_bwd_weight   partial[s][n][k] = sum over the tokens of slab s of dy[t][n] x[t + shift][k]   dy.t() @ x, in `nslab` partial sums (x rows ldx apart)
 //                           partial_bias[s][n] = sum over the same tokens of dy[t][n]                     dy.sum(0)
 //     (shift = -1 / +1 with sequences of L steps: x is the PREVIOUS / NEXT step's row of the same sequence, zero at the sequence's first /
 //      last step -- the h_{t-1} operand of the recurrent weights' gradient without materialising it)
@@ -36,6 +36,7 @@ struct lin_args {
     int L, shift;          // BWD_WEIGHT: sequence length and row shift of x
     int nslab;
     int accumulate;
+    long ldb;              // BWD_WEIGHT: row stride of x
 };
 
 template <int MODE, int TI, int TJ>
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const lin_args p) {
                         ok = ok && step >= 0 && step < p.L;
                         src = gt + p.shift;
                     }
-                    if (ok) fb[q] = *reinterpret_cast<const float4*>(p.b + src * p.K + j0 + 4 * jq);
+                    if (ok) fb[q] = *reinterpret_cast<const float4*>(p.b + src * p.ldb + j0 + 4 * jq);
                 }
             }
         }
@@ -217,6 +218,47 @@ __global__ __launch_bounds__(256) void linear_kernel(const lin_args p) {
     }
 }
 
+
+// (B, F, S, K) chunked features <-> token-major rows [B][tokens][F] for the dual-path recurrences (reference src/models/dprnn.py:73-76,
+// 123-126: `input.permute(0, 2, 3, 1).reshape(B*S, K, F)` for the intra-chunk path, `input.permute(0, 3, 2, 1).reshape(B*K, S, F)` for the
+// inter-chunk path, and their inverses behind the Linear): 32 x 32 tiles through LDS, 128-byte rows on both sides -- torch's strided
+// copies ran at ~1 TB/s here (61 - 93 us for 2 x 33 MB, 66 launches per DPRNN-TasNet step).
+template <bool TO_TOKENS>
+__global__ __launch_bounds__(256) void chunk_tokens_kernel(const float* __restrict__ src, float* __restrict__ dst, int F, int S, int K, int inter) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int k0 = blockIdx.x * 32, s = blockIdx.y;
+    const int nft = (F + 31) / 32;
+    const int b = blockIdx.z / nft, f0 = (blockIdx.z % nft) * 32;
+    const size_t tokbase = (size_t)b * S * K;
+    auto tok = [&](int k) { return inter ? (size_t)k * S + s : (size_t)s * K + k; };
+    if (TO_TOKENS) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = f0 + ty + 8 * r, k = k0 + tx;
+            tile[ty + 8 * r][tx] = (f < F && k < K) ? src[(((size_t)b * F + f) * S + s) * K + k] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = k0 + ty + 8 * r, f = f0 + tx;
+            if (k < K && f < F) dst[(tokbase + tok(k)) * F + f] = tile[tx][ty + 8 * r];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = k0 + ty + 8 * r, f = f0 + tx;
+            tile[ty + 8 * r][tx] = (k < K && f < F) ? src[(tokbase + tok(k)) * F + f] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = f0 + ty + 8 * r, k = k0 + tx;
+            if (f < F && k < K) dst[(((size_t)b * F + f) * S + s) * K + k] = tile[tx][ty + 8 * r];
+        }
+    }
+}
+
 template <int MODE>
 int lin_launch(const lin_args& p, int ti, int tj, unsigned grid, hipStream_t stream) {
 #define SEP_LIN(TI, TJ) hipLaunchKernelGGL((linear_kernel<MODE, TI, TJ>), dim3(grid), dim3(256), 0, stream, p)
@@ -234,7 +276,7 @@ extern "C" int sep_linear_fwd(const float* x, const float* w, const float* bias,
                               sep_stream_t stream) {
     SEP_REQUIRE(x && w && y, "sep_linear_fwd: null pointer");
     SEP_REQUIRE(ntok > 0 && K > 0 && N > 0 && K % 32 == 0 && N % 64 == 0, "sep_linear_fwd: K=%d must be a multiple of 32 and N=%d of 64", K, N);
-    lin_args p = {x, w, bias, bias2, y, nullptr, ntok, K, N, 1, 0, 1, 0};
+    lin_args p = {x, w, bias, bias2, y, nullptr, ntok, K, N, 1, 0, 1, 0, K};
     const int tj = N % 128 == 0 ? 128 : 64;
     const long tiles = ((ntok + 127) / 128) * (N / tj);
     SEP_REQUIRE(tiles <= 0x7fffffffL, "sep_linear_fwd: too many tiles");
@@ -246,7 +288,7 @@ extern "C" int sep_linear_fwd(const float* x, const float* w, const float* bias,
 extern "C" int sep_linear_bwd_input(const float* dy, const float* w, float* dx, long ntok, int K, int N, int accumulate, sep_stream_t stream) {
     SEP_REQUIRE(dy && w && dx, "sep_linear_bwd_input: null pointer");
     SEP_REQUIRE(ntok > 0 && K > 0 && N > 0 && N % 32 == 0 && K % 64 == 0, "sep_linear_bwd_input: N=%d must be a multiple of 32 and K=%d of 64", N, K);
-    lin_args p = {dy, w, nullptr, nullptr, dx, nullptr, ntok, K, N, 1, 0, 1, accumulate};
+    lin_args p = {dy, w, nullptr, nullptr, dx, nullptr, ntok, K, N, 1, 0, 1, accumulate, K};
     const int tj = K % 128 == 0 ? 128 : 64;
     const long tiles = ((ntok + 127) / 128) * (K / tj);
     SEP_REQUIRE(tiles <= 0x7fffffffL, "sep_linear_bwd_input: too many tiles");
@@ -255,17 +297,40 @@ extern "C" int sep_linear_bwd_input(const float* dy, const float* w, float* dx, 
     return 0;
 }
 
-extern "C" int sep_linear_bwd_weight(const float* dy, const float* x, float* partial, float* partial_bias, long ntok, int K, int N, int L,
+extern "C" int sep_linear_bwd_weight(const float* dy, const float* x, long ldx, float* partial, float* partial_bias, long ntok, int K, int N, int L,
                                      int shift, int nslab, sep_stream_t stream) {
     SEP_REQUIRE(dy && x && partial, "sep_linear_bwd_weight: null pointer");
     SEP_REQUIRE(ntok > 0 && K > 0 && N > 0 && N % 64 == 0 && K % 64 == 0, "sep_linear_bwd_weight: N=%d and K=%d must be multiples of 64", N, K);
     SEP_REQUIRE(nslab >= 1 && shift >= -1 && shift <= 1 && L >= 1 && (shift == 0 || ntok % L == 0),
                 "sep_linear_bwd_weight: nslab >= 1, shift in {-1, 0, 1}, and whole sequences of L steps for a shifted x");
-    lin_args p = {dy, x, nullptr, nullptr, partial, partial_bias, ntok, K, N, L, shift, nslab, 0};
+    SEP_REQUIRE(ldx >= K && ldx % 4 == 0, "sep_linear_bwd_weight: ldx=%ld must be a multiple of 4 and >= K=%d", ldx, K);
+    lin_args p = {dy, x, nullptr, nullptr, partial, partial_bias, ntok, K, N, L, shift, nslab, 0, ldx};
     const int ti = N % 128 == 0 ? 128 : 64, tj = K % 128 == 0 ? 128 : 64;
     const long grid = (long)(N / ti) * (K / tj) * nslab;
     SEP_REQUIRE(grid <= 0x7fffffffL, "sep_linear_bwd_weight: too many workgroups");
     lin_launch<LIN_BWD_WEIGHT>(p, ti, tj, (unsigned)grid, (hipStream_t)stream);
     SEP_CHECK_LAUNCH("sep_linear_bwd_weight");
+    return 0;
+}
+
+static int chunk_tokens(const float* src, float* dst, int B, int F, int S, int K, int inter, bool to_tokens, const char* name, hipStream_t stream) {
+    SEP_REQUIRE(src && dst && B > 0 && F > 0 && S > 0 && K > 0, "%s: bad arguments", name);
+    const long gz = (long)B * ((F + 31) / 32);
+    SEP_REQUIRE(S <= 65535 && gz <= 65535, "%s: S = %d chunks and B x ceil(F / 32) = %ld must fit a grid dimension (65535)", name, S, gz);
+    const dim3 grid((K + 31) / 32, S, (unsigned)gz);
+    if (to_tokens) hipLaunchKernelGGL((chunk_tokens_kernel<true>), grid, dim3(256), 0, stream, src, dst, F, S, K, inter);
+    else hipLaunchKernelGGL((chunk_tokens_kernel<false>), grid, dim3(256), 0, stream, src, dst, F, S, K, inter);
+    return 0;
+}
+
+extern "C" int sep_chunk_to_tokens(const float* x, float* y, int B, int F, int S, int K, int inter, sep_stream_t stream) {
+    if (chunk_tokens(x, y, B, F, S, K, inter, true, "sep_chunk_to_tokens", (hipStream_t)stream)) return -1;
+    SEP_CHECK_LAUNCH("sep_chunk_to_tokens");
+    return 0;
+}
+
+extern "C" int sep_tokens_to_chunk(const float* y, float* x, int B, int F, int S, int K, int inter, sep_stream_t stream) {
+    if (chunk_tokens(y, x, B, F, S, K, inter, false, "sep_tokens_to_chunk", (hipStream_t)stream)) return -1;
+    SEP_CHECK_LAUNCH("sep_tokens_to_chunk");
     return 0;
 }

@@ -31,14 +31,14 @@ constexpr int LSTM_NS = 16;     // sequences per workgroup = N of the 16x16x4 MF
 template <int H>
 __global__ __launch_bounds__(H * 4) void lstm_fwd_kernel(const float* __restrict__ xg, const float* __restrict__ whh,
                                                          float* __restrict__ hout, float* __restrict__ gates,
-                                                         float* __restrict__ cstate, int nseq, int L, int dirs) {
+                                                         float* __restrict__ cstate, int nseq, int L, int dirs, int hrow) {
     constexpr int KS = H / 4;                  // MFMA k-steps per gate block
     // dirs: 0 forward in time, 1 backward in time, 2 both -- blockIdx.y picks the direction and its slab of every buffer
     const int dir = dirs == 2 ? (int)blockIdx.y : 0;
     const int reverse = dirs == 2 ? dir : dirs;
     {
         const size_t rows = (size_t)nseq * L;
-        xg += dir * rows * 4 * H; whh += (size_t)dir * 4 * H * H; hout += dir * rows * H;
+        xg += dir * rows * 4 * H; whh += (size_t)dir * 4 * H * H; hout += hrow == H ? dir * rows * H : dir * H;
         if (gates) gates += dir * rows * 4 * H;
         if (cstate) cstate += dir * rows * H;
     }
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(H * 4) void lstm_fwd_kernel(const float* __restrict
         }
         if (live) {
             const size_t o = seq_base + t;
-            st4g(hout + o * H + u0, make_float4(hn[0], hn[1], hn[2], hn[3]));
+            st4g(hout + o * hrow + u0, make_float4(hn[0], hn[1], hn[2], hn[3]));
             if (gates) {
                 float* gp = gates + o * 4 * H + u0;
                 st4g(gp, make_float4(gi[0], gi[1], gi[2], gi[3]));
@@ -119,13 +119,13 @@ __global__ __launch_bounds__(H * 4) void lstm_fwd_kernel(const float* __restrict
 template <int H>
 __global__ __launch_bounds__(H * 4) void lstm_bwd_kernel(const float* __restrict__ dhout, const float* __restrict__ gates,
                                                          const float* __restrict__ cstate, const float* __restrict__ whh,
-                                                         float* __restrict__ dxg, int nseq, int L, int dirs) {
+                                                         float* __restrict__ dxg, int nseq, int L, int dirs, int hrow) {
     constexpr int KS = 4 * H / 4;              // k-steps over the 4H gate rows
     const int dir = dirs == 2 ? (int)blockIdx.y : 0;
     const int reverse = dirs == 2 ? dir : dirs;
     {
         const size_t rows = (size_t)nseq * L;
-        dhout += dir * rows * H; gates += dir * rows * 4 * H; cstate += dir * rows * H; whh += (size_t)dir * 4 * H * H;
+        dhout += hrow == H ? dir * rows * H : dir * H; gates += dir * rows * 4 * H; cstate += dir * rows * H; whh += (size_t)dir * 4 * H * H;
         dxg += dir * rows * 4 * H;
     }
     __shared__ float das[4 * H * LSTM_NS];     // d(pre-activation) of the current step as [gate row][sequence]
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(H * 4) void lstm_bwd_kernel(const float* __restrict
         const int tprev = reverse ? t + 1 : t - 1;                 // the step that fed c_{t-1}
         const bool has_prev = tprev >= 0 && tprev < L;
         const size_t o = seq_base + t;
-        const float4 dho = ld4g(dhout + o * H + u0);
+        const float4 dho = ld4g(dhout + o * hrow + u0);
         const float* gp = gates + o * 4 * H + u0;
         const float4 vi = ld4g(gp), vf = ld4g(gp + H), vg = ld4g(gp + 2 * H), vo = ld4g(gp + 3 * H);
         const float4 vc = ld4g(cstate + o * H + u0);
@@ -215,13 +215,13 @@ __device__ __forceinline__ f32x4 mfma4(const float a, const float b, const f32x4
 template <int H>
 __global__ __launch_bounds__(H * 4) void lstm_fwd4_kernel(const float* __restrict__ xg, const float* __restrict__ whh,
                                                           float* __restrict__ hout, float* __restrict__ gates,
-                                                          float* __restrict__ cstate, int nseq, int L, int dirs) {
+                                                          float* __restrict__ cstate, int nseq, int L, int dirs, int hrow) {
     constexpr int HS = H + 4;                  // row stride of the h panel: rows 16-byte aligned and on different bank groups
     const int dir = dirs == 2 ? (int)blockIdx.y : 0;
     const int reverse = dirs == 2 ? dir : dirs;
     {
         const size_t rows = (size_t)nseq * L;
-        xg += dir * rows * 4 * H; whh += (size_t)dir * 4 * H * H; hout += dir * rows * H;
+        xg += dir * rows * 4 * H; whh += (size_t)dir * 4 * H * H; hout += hrow == H ? dir * rows * H : dir * H;
         if (gates) gates += dir * rows * 4 * H;
         if (cstate) cstate += dir * rows * H;
     }
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(H * 4) void lstm_fwd4_kernel(const float* __restric
         const float hn = go * tanh_f(c);
         hs[cur ^ 1][hi * HS + u] = hn;
         if (live) {
-            hout[(crow + t) * H + u] = hn;
+            hout[(crow + t) * hrow + u] = hn;
             if (cstate) cstate[(crow + t) * H + u] = c;
         }
 #pragma unroll
@@ -315,14 +315,14 @@ __global__ __launch_bounds__(H * 4) void lstm_fwd4_kernel(const float* __restric
 template <int H>
 __global__ __launch_bounds__(H * 4) void lstm_bwd4_kernel(const float* __restrict__ dhout, const float* __restrict__ gates,
                                                           const float* __restrict__ cstate, const float* __restrict__ whh,
-                                                          float* __restrict__ dxg, int nseq, int L, int dirs) {
+                                                          float* __restrict__ dxg, int nseq, int L, int dirs, int hrow) {
     constexpr int HG = H + 16;                 // gate stride of the d(pre-activation) panel
     constexpr int DS = 4 * HG + 4;             // its sequence stride
     const int dir = dirs == 2 ? (int)blockIdx.y : 0;
     const int reverse = dirs == 2 ? dir : dirs;
     {
         const size_t rows = (size_t)nseq * L;
-        dhout += dir * rows * H; gates += dir * rows * 4 * H; cstate += dir * rows * H; whh += (size_t)dir * 4 * H * H;
+        dhout += hrow == H ? dir * rows * H : dir * H; gates += dir * rows * 4 * H; cstate += dir * rows * H; whh += (size_t)dir * 4 * H * H;
         dxg += dir * rows * 4 * H;
     }
     __shared__ __attribute__((aligned(16))) float das[NS4 * DS];         // d(pre-activation) of the current step as [sequence][gate][unit]
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(H * 4) void lstm_bwd4_kernel(const float* __restric
     auto load_step = [&](int t, StepIn& d) {
         const int tprev = reverse ? t + 1 : t - 1;
         const size_t o = crow + t;
-        d.dh = dhout[o * H + u];
+        d.dh = dhout[o * hrow + u];
         const float* gp = gates + o * 4 * H + u;
         d.i = gp[0]; d.f = gp[H]; d.g = gp[2 * H]; d.o = gp[3 * H];
         d.cp = (tprev >= 0 && tprev < L) ? cstate[(crow + tprev) * H + u] : 0.f;
@@ -410,21 +410,21 @@ bool few_sequences(int nseq, int reverse, int force) {
 }
 
 template <int H>
-int launch_fwd(const float* xg, const float* whh, float* hout, float* gates, float* cstate, int nseq, int L, int reverse, int force, hipStream_t st) {
+int launch_fwd(const float* xg, const float* whh, float* hout, float* gates, float* cstate, int nseq, int L, int reverse, int force, int hs, hipStream_t st) {
     if (few_sequences(nseq, reverse, force)) {
-        hipLaunchKernelGGL((lstm_fwd4_kernel<H>), dim3((nseq + NS4 - 1) / NS4, reverse == 2 ? 2 : 1), dim3(H * 4), 0, st, xg, whh, hout, gates, cstate, nseq, L, reverse);
+        hipLaunchKernelGGL((lstm_fwd4_kernel<H>), dim3((nseq + NS4 - 1) / NS4, reverse == 2 ? 2 : 1), dim3(H * 4), 0, st, xg, whh, hout, gates, cstate, nseq, L, reverse, hs);
         return 0;
     }
-    hipLaunchKernelGGL((lstm_fwd_kernel<H>), dim3((nseq + LSTM_NS - 1) / LSTM_NS, reverse == 2 ? 2 : 1), dim3(H * 4), 0, st, xg, whh, hout, gates, cstate, nseq, L, reverse);
+    hipLaunchKernelGGL((lstm_fwd_kernel<H>), dim3((nseq + LSTM_NS - 1) / LSTM_NS, reverse == 2 ? 2 : 1), dim3(H * 4), 0, st, xg, whh, hout, gates, cstate, nseq, L, reverse, hs);
     return 0;
 }
 template <int H>
-int launch_bwd(const float* dhout, const float* gates, const float* cstate, const float* whh, float* dxg, int nseq, int L, int reverse, int force, hipStream_t st) {
+int launch_bwd(const float* dhout, const float* gates, const float* cstate, const float* whh, float* dxg, int nseq, int L, int reverse, int force, int hs, hipStream_t st) {
     if (few_sequences(nseq, reverse, force)) {
-        hipLaunchKernelGGL((lstm_bwd4_kernel<H>), dim3((nseq + NS4 - 1) / NS4, reverse == 2 ? 2 : 1), dim3(H * 4), 0, st, dhout, gates, cstate, whh, dxg, nseq, L, reverse);
+        hipLaunchKernelGGL((lstm_bwd4_kernel<H>), dim3((nseq + NS4 - 1) / NS4, reverse == 2 ? 2 : 1), dim3(H * 4), 0, st, dhout, gates, cstate, whh, dxg, nseq, L, reverse, hs);
         return 0;
     }
-    hipLaunchKernelGGL((lstm_bwd_kernel<H>), dim3((nseq + LSTM_NS - 1) / LSTM_NS, reverse == 2 ? 2 : 1), dim3(H * 4), 0, st, dhout, gates, cstate, whh, dxg, nseq, L, reverse);
+    hipLaunchKernelGGL((lstm_bwd_kernel<H>), dim3((nseq + LSTM_NS - 1) / LSTM_NS, reverse == 2 ? 2 : 1), dim3(H * 4), 0, st, dhout, gates, cstate, whh, dxg, nseq, L, reverse, hs);
     return 0;
 }
 
@@ -434,14 +434,17 @@ extern "C" int sep_lstm_fwd(const float* xg, const float* w_hh, float* h_out, fl
                             int H, int reverse, sep_stream_t stream) {
     SEP_REQUIRE(xg && w_hh && h_out, "sep_lstm_fwd: null pointer");
     const int force = (reverse >> 8) & 3;
+    const bool interleaved = (reverse & SEP_LSTM_INTERLEAVED) != 0;
     reverse &= 0xff;
     SEP_REQUIRE(nseq > 0 && L > 0 && reverse >= 0 && reverse <= 2 && force <= 2, "sep_lstm_fwd: bad sizes / direction");
+    SEP_REQUIRE(!interleaved || reverse == 2, "sep_lstm_fwd: SEP_LSTM_INTERLEAVED goes with both directions in one call (reverse = 2)");
+    const int hs = interleaved ? 2 * H : H;
     hipStream_t st = (hipStream_t)stream;
     switch (H) {
-        case 16: launch_fwd<16>(xg, w_hh, h_out, gates, cstate, nseq, L, reverse, force, st); break;
-        case 32: launch_fwd<32>(xg, w_hh, h_out, gates, cstate, nseq, L, reverse, force, st); break;
-        case 64: launch_fwd<64>(xg, w_hh, h_out, gates, cstate, nseq, L, reverse, force, st); break;
-        case 128: launch_fwd<128>(xg, w_hh, h_out, gates, cstate, nseq, L, reverse, force, st); break;
+        case 16: launch_fwd<16>(xg, w_hh, h_out, gates, cstate, nseq, L, reverse, force, hs, st); break;
+        case 32: launch_fwd<32>(xg, w_hh, h_out, gates, cstate, nseq, L, reverse, force, hs, st); break;
+        case 64: launch_fwd<64>(xg, w_hh, h_out, gates, cstate, nseq, L, reverse, force, hs, st); break;
+        case 128: launch_fwd<128>(xg, w_hh, h_out, gates, cstate, nseq, L, reverse, force, hs, st); break;
         default: SEP_REQUIRE(false, "sep_lstm_fwd: hidden size %d not supported (16, 32, 64, 128)", H);
     }
     SEP_CHECK_LAUNCH("sep_lstm_fwd");
@@ -452,14 +455,17 @@ extern "C" int sep_lstm_bwd(const float* dh_out, const float* gates, const float
                             int nseq, int L, int H, int reverse, sep_stream_t stream) {
     SEP_REQUIRE(dh_out && gates && cstate && w_hh && dxg, "sep_lstm_bwd: null pointer");
     const int force = (reverse >> 8) & 3;
+    const bool interleaved = (reverse & SEP_LSTM_INTERLEAVED) != 0;
     reverse &= 0xff;
     SEP_REQUIRE(nseq > 0 && L > 0 && reverse >= 0 && reverse <= 2 && force <= 2, "sep_lstm_bwd: bad sizes / direction");
+    SEP_REQUIRE(!interleaved || reverse == 2, "sep_lstm_bwd: SEP_LSTM_INTERLEAVED goes with both directions in one call (reverse = 2)");
+    const int hs = interleaved ? 2 * H : H;
     hipStream_t st = (hipStream_t)stream;
     switch (H) {
-        case 16: launch_bwd<16>(dh_out, gates, cstate, w_hh, dxg, nseq, L, reverse, force, st); break;
-        case 32: launch_bwd<32>(dh_out, gates, cstate, w_hh, dxg, nseq, L, reverse, force, st); break;
-        case 64: launch_bwd<64>(dh_out, gates, cstate, w_hh, dxg, nseq, L, reverse, force, st); break;
-        case 128: launch_bwd<128>(dh_out, gates, cstate, w_hh, dxg, nseq, L, reverse, force, st); break;
+        case 16: launch_bwd<16>(dh_out, gates, cstate, w_hh, dxg, nseq, L, reverse, force, hs, st); break;
+        case 32: launch_bwd<32>(dh_out, gates, cstate, w_hh, dxg, nseq, L, reverse, force, hs, st); break;
+        case 64: launch_bwd<64>(dh_out, gates, cstate, w_hh, dxg, nseq, L, reverse, force, hs, st); break;
+        case 128: launch_bwd<128>(dh_out, gates, cstate, w_hh, dxg, nseq, L, reverse, force, hs, st); break;
         default: SEP_REQUIRE(false, "sep_lstm_bwd: hidden size %d not supported (16, 32, 64, 128)", H);
     }
     SEP_CHECK_LAUNCH("sep_lstm_bwd");

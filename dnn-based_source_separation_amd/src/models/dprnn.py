@@ -10,8 +10,9 @@ gLN; layout changes are torch views/permutes.
 """
 import torch.nn as nn
 
-from sepkernels.functional import linear_apply, lstm_apply
+from sepkernels.functional import ChunkToTokensFn, TokensToChunkFn, linear_apply, lstm_apply, takes
 
+from modules.norm import CumulativeLayerNorm1d
 from utils.model import choose_rnn
 from utils.tasnet import choose_layer_norm
 
@@ -56,12 +57,25 @@ class _PathRNN(nn.Module):
     def _run(self, input, seq_axis):
         """input (B, F, S, K); seq_axis 3 -> recur over K for every (b, s); 2 -> over S for every (b, k)."""
         B, F, S, K = input.shape
+        inter = seq_axis == 2
+        # gLN's statistics run over all of (F, S*K) and its gain / bias are per feature, so the frame ORDER behind the Linear does not
+        # matter to it: the rows go straight back to (B, F, S, K) and the inter-chunk path needs no second permutation.  cLN (the causal
+        # inter-chunk path) accumulates along the sequence axis and keeps the reference's order below.
+        order_free = not self.norm or not isinstance(self.norm1d, CumulativeLayerNorm1d)
+        if order_free and S <= 65535 and takes(input):
+            x = ChunkToTokensFn.apply(input, inter)                  # tiled transposes (csrc/linear.hip) instead of strided copies
+            x = lstm_apply(x, self.rnn)          # the sweep kernels for 16 / 32 / 64 / 128 units, torch's LSTM otherwise
+            x = linear_apply(x, self.fc)                             # csrc/linear.hip for feature counts % 64 == 0
+            x = TokensToChunkFn.apply(x, (B, F, S, K), inter)
+            if self.norm:
+                x = self.norm1d(x.view(B, F, S * K)).view(B, F, S, K)
+            return x + input
         if seq_axis == 3:
             x = input.permute(0, 2, 3, 1).reshape(B * S, K, F)
         else:
             x = input.permute(0, 3, 2, 1).reshape(B * K, S, F)
-        x = lstm_apply(x, self.rnn)              # the sweep kernels for 16 / 32 / 64 / 128 units, torch's LSTM otherwise
-        x = linear_apply(x, self.fc)                             # (B*S, K, F) or (B*K, S, F): csrc/linear.hip for feature counts % 64 == 0
+        x = lstm_apply(x, self.rnn)
+        x = linear_apply(x, self.fc)                             # (B*S, K, F) or (B*K, S, F)
         x = x.reshape(B, S * K, F).permute(0, 2, 1).contiguous()  # (B, F, S*K) [or (B, F, K*S)]
         if self.norm:
             x = self.norm1d(x)                                   # statistics over all of (F, S*K): order-free

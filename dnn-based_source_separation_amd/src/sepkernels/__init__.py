@@ -17,7 +17,8 @@ LIB_PATH = os.environ.get("SEPKERNELS_LIB", os.path.normpath(os.path.join(_HERE,
 # ---- constants mirrored from include/sepkernels.h -------------------------------------------------
 PRO_NONE, PRO_PRELU, PRO_GLN, PRO_GLN_PRELU, PRO_GLN_BWD = 0, 1, 2, 3, 4
 EPI_STATS_PRELU, EPI_RESIDUAL, EPI_SIGMOID, EPI_PRELU_BWD, EPI_ROWSUMS, EPI_ROWSUMS_PRELU = 1, 2, 4, 8, 16, 32
-ABI_VERSION = 18
+ABI_VERSION = 19
+LSTM_INTERLEAVED = 0x400       # sep_lstm_fwd / sep_lstm_bwd with reverse = 2: h_out / dh_out as one (nseq, L, 2H) buffer
 STATS_SLOTS = 16   # SEP_STATS_SLOTS: gLN statistics are double[B][STATS_SLOTS][2]
 ARRIVE_INTS = 17   # SEP_ARRIVE_INTS: arrival counters of the gLN-backward publishers, int[B][ARRIVE_INTS]
 ARITH_F32, ARITH_BF16X6, ARITH_F16X3 = 0, 1, 2     # SEP_ARITH_*: how sep_pw_gemm forms its fp32 products (include/sepkernels.h)
@@ -154,7 +155,9 @@ SIGNATURES = {
     "sep_lstm_bwd": [_vp] * 5 + [_I] * 4 + [_vp],
     "sep_linear_fwd": [_vp] * 5 + [_L, _I, _I, _vp],
     "sep_linear_bwd_input": [_vp] * 3 + [_L, _I, _I, _I, _vp],
-    "sep_linear_bwd_weight": [_vp] * 4 + [_L] + [_I] * 5 + [_vp],
+    "sep_linear_bwd_weight": [_vp, _vp, _L, _vp, _vp, _L] + [_I] * 5 + [_vp],
+    "sep_chunk_to_tokens": [_vp, _vp] + [_I] * 5 + [_vp],
+    "sep_tokens_to_chunk": [_vp, _vp] + [_I] * 5 + [_vp],
 }
 
 _lib = None
@@ -438,15 +441,25 @@ class HipBackend:
         _check(load().sep_lstm_bwd(_ptr(dh_out, _f32), _ptr(gates, _f32), _ptr(cstate, _f32), _ptr(w_hh, _f32), _ptr(dxg, _f32),
                                    nseq, L, H, int(reverse), _stream()), "sep_lstm_bwd")
 
+    def chunk_to_tokens(self, x, y, B, F, S, K, inter):
+        _check(load().sep_chunk_to_tokens(_ptr(x, _f32), _ptr(y, _f32), B, F, S, K, int(inter), _stream()), "sep_chunk_to_tokens")
+
+    def tokens_to_chunk(self, y, x, B, F, S, K, inter):
+        _check(load().sep_tokens_to_chunk(_ptr(y, _f32), _ptr(x, _f32), B, F, S, K, int(inter), _stream()), "sep_tokens_to_chunk")
+
     def linear_fwd(self, x, w, bias, bias2, y, ntok, K, N):
         _check(load().sep_linear_fwd(_ptr(x, _f32), _ptr(w, _f32), _ptr(bias, _f32), _ptr(bias2, _f32), _ptr(y, _f32), ntok, K, N, _stream()), "sep_linear_fwd")
 
     def linear_bwd_input(self, dy, w, dx, ntok, K, N, accumulate):
         _check(load().sep_linear_bwd_input(_ptr(dy, _f32), _ptr(w, _f32), _ptr(dx, _f32), ntok, K, N, int(accumulate), _stream()), "sep_linear_bwd_input")
 
-    def linear_bwd_weight(self, dy, x, partial, partial_bias, ntok, K, N, L, shift, nslab):
-        _check(load().sep_linear_bwd_weight(_ptr(dy, _f32), _ptr(x, _f32), _ptr(partial, _f32), _ptr(partial_bias, _f32), ntok, K, N, L, shift, nslab,
-                                            _stream()), "sep_linear_bwd_weight")
+    def linear_bwd_weight(self, dy, x, ldx, partial, partial_bias, ntok, K, N, L, shift, nslab):
+        # x may be a column slice of a wider row-major matrix (rows ldx floats apart): one direction's half of an interleaved bi-LSTM output
+        if not (x.dim() == 2 and x.stride(1) == 1 and x.stride(0) == ldx):
+            raise SepKernelsError("linear_bwd_weight: x must be a matrix with unit column stride and row stride ldx")
+        _ptr(x[:1], _f32)                                     # device / dtype checks on a (contiguous) row of it
+        _check(load().sep_linear_bwd_weight(_ptr(dy, _f32), x.data_ptr(), ldx, _ptr(partial, _f32), _ptr(partial_bias, _f32), ntok, K, N, L, shift,
+                                            nslab, _stream()), "sep_linear_bwd_weight")
 
     def adam_step(self, p, g, m, v, sqnorm, n, lr, beta1, beta2, eps, weight_decay, max_norm, grad_scale, step):
         _check(load().sep_adam_step(_ptr(p, _f32), _ptr(g, _f32), _ptr(m, _f32), _ptr(v, _f32), _ptr(sqnorm, _f64), n, lr, beta1,

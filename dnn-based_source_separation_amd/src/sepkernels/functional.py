@@ -9,7 +9,7 @@ also exposed one operation at a time: EncodeFn, PaddedPointwiseFn, MaskDecodeFn.
 """
 import torch
 
-from . import backend, STATS_SLOTS
+from . import backend, LSTM_INTERLEAVED, STATS_SLOTS
 from . import net as _net
 
 HEAD_KEYS = ("encoder.conv1d.weight", "separator.norm1d.norm.weight", "separator.norm1d.norm.bias",
@@ -343,6 +343,46 @@ class DepthwiseConv1dFn(torch.autograd.Function):
         return dx, dwb[:, :Kw].reshape(C, 1, Kw).contiguous(), (dwb[:, Kw].contiguous() if has_bias else None), None, None, None
 
 
+class ChunkToTokensFn(torch.autograd.Function):
+    """(B, F, S, K) -> (B*S, K, F) [inter = False: a sequence per (b, s)] or (B*K, S, F) [inter = True: a sequence per (b, k)] -- the
+    permute + reshape in front of the dual-path recurrences (reference dprnn.py:73-76,123-126) as one tiled transpose; backward = the
+    inverse kernel."""
+
+    @staticmethod
+    def forward(ctx, x, inter):
+        B, F, S, K = x.shape
+        ctx.dims, ctx.inter = (B, F, S, K), bool(inter)
+        y = torch.empty((B * K, S, F) if inter else (B * S, K, F), device=x.device, dtype=x.dtype)
+        backend().chunk_to_tokens(x.contiguous(), y, B, F, S, K, inter)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, F, S, K = ctx.dims
+        dx = torch.empty(B, F, S, K, device=dy.device, dtype=dy.dtype)
+        backend().tokens_to_chunk(dy.contiguous(), dx, B, F, S, K, ctx.inter)
+        return dx, None
+
+
+class TokensToChunkFn(torch.autograd.Function):
+    """the inverse: token-major rows back to (B, F, S, K), contiguous"""
+
+    @staticmethod
+    def forward(ctx, y, dims, inter):
+        B, F, S, K = dims
+        ctx.dims, ctx.inter = tuple(dims), bool(inter)
+        x = torch.empty(B, F, S, K, device=y.device, dtype=y.dtype)
+        backend().tokens_to_chunk(y.contiguous(), x, B, F, S, K, inter)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        B, F, S, K = ctx.dims
+        dy = torch.empty((B * K, S, F) if ctx.inter else (B * S, K, F), device=dx.device, dtype=dx.dtype)
+        backend().chunk_to_tokens(dx.contiguous(), dy, B, F, S, K, ctx.inter)
+        return dy, None, None
+
+
 def _dense_ok(K_in, N_out):
     """shapes csrc/linear.hip takes (everything the dual-path separators of the reference's recipes use); others go to torch's BLAS"""
     return K_in % 64 == 0 and N_out % 64 == 0
@@ -406,7 +446,9 @@ def dense_backward_weights(jobs):
         ns = _wgrad_slabs(ntok, N, Kin)
         part = torch.empty(ns, N, Kin, device=dy2.device, dtype=dy2.dtype)
         pb = torch.empty(ns, N, device=dy2.device, dtype=dy2.dtype) if want_bias else None
-        K_.linear_bwd_weight(dy2.contiguous(), x2.contiguous(), part, pb, ntok, Kin, N, L, shift, ns)
+        if x2.stride(1) != 1 or x2.stride(0) % 4 != 0 or x2.data_ptr() % 16 != 0:
+            x2 = x2.contiguous()
+        K_.linear_bwd_weight(dy2.contiguous(), x2, x2.stride(0), part, pb, ntok, Kin, N, L, shift, ns)
         dw = torch.empty(N, Kin, device=dy2.device, dtype=dy2.dtype)
         segs.append((part, 0, dw, N * Kin, ns, N * Kin, 0, 1.0))
         db = None
@@ -506,29 +548,30 @@ class LSTMBidirectionalFn(torch.autograd.Function):
             torch.addmm(b_ih_f + b_hh_f, x2, w_ih_f.t(), out=xg[0])
             torch.addmm(b_ih_r + b_hh_r, x2, w_ih_r.t(), out=xg[1])
         w_hh = torch.stack([w_hh_f, w_hh_r]).contiguous()
-        h = torch.empty(2, nseq, L, H, device=x.device, dtype=x.dtype)
+        # h of both directions as ONE (nseq, L, 2H) tensor, the layout nn.LSTM(bidirectional=True) returns (SEP_LSTM_INTERLEAVED): no
+        # torch.cat behind the sweeps, no torch.stack of the incoming gradient in front of the reverse sweeps
+        h = torch.empty(nseq, L, 2 * H, device=x.device, dtype=x.dtype)
         gates = torch.empty(2, nseq, L, 4 * H, device=x.device, dtype=x.dtype)
         cst = torch.empty(2, nseq, L, H, device=x.device, dtype=x.dtype)
-        K.lstm_fwd(xg, w_hh, h, gates, cst, nseq, L, H, 2)
+        K.lstm_fwd(xg, w_hh, h, gates, cst, nseq, L, H, 2 | LSTM_INTERLEAVED)
         ctx.save_for_backward(x2, w_ih_f, w_ih_r, w_hh, h, gates, cst)
         ctx.shape = (nseq, L, F, H)
-        return torch.cat([h[0], h[1]], dim=2)
+        return h
 
     @staticmethod
     def backward(ctx, dy):
         K = backend()
         x2, w_ih_f, w_ih_r, w_hh, h, gates, cst = ctx.saved_tensors
         nseq, L, F, H = ctx.shape
-        dh = torch.stack([dy[..., :H], dy[..., H:]]).contiguous()          # (2, nseq, L, H)
         dxg = torch.empty(2, nseq, L, 4 * H, device=dy.device, dtype=dy.dtype)
-        K.lstm_bwd(dh, gates, cst, w_hh, dxg, nseq, L, H, 2)
+        K.lstm_bwd(dy.contiguous(), gates, cst, w_hh, dxg, nseq, L, H, 2 | LSTM_INTERLEAVED)
         d2 = dxg.reshape(2, nseq * L, 4 * H)
-        h2 = h.reshape(2, nseq * L, H)
+        h2 = h.reshape(nseq * L, 2 * H)
         dx = dense_backward_input(d2[0], w_ih_f)
         dx = dense_backward_input(d2[1], w_ih_r, out=dx).reshape(nseq, L, F)
-        # h_{t-1} as each direction saw it: h one step earlier (forward) / later (reversed), zero at the sequence's end
+        # h_{t-1} as each direction saw it: its half of h one step earlier (forward) / later (reversed), zero at the sequence's end
         (dw_ih_f, db_f), (dw_ih_r, db_r), (dw_hh_f, _), (dw_hh_r, _) = dense_backward_weights(
-            [(d2[0], x2, True, 1, 0), (d2[1], x2, True, 1, 0), (d2[0], h2[0], False, L, -1), (d2[1], h2[1], False, L, 1)])
+            [(d2[0], x2, True, 1, 0), (d2[1], x2, True, 1, 0), (d2[0], h2[:, :H], False, L, -1), (d2[1], h2[:, H:], False, L, 1)])
         return (dx, dw_ih_f, dw_hh_f, db_f, db_f, dw_ih_r, dw_hh_r, db_r, db_r)
 
 

@@ -33,7 +33,7 @@ extern "C" {
 
 typedef void* sep_stream_t; /* hipStream_t */
 
-#define SEP_ABI_VERSION 18
+#define SEP_ABI_VERSION 19
 #define SEP_STATS_SLOTS 16
 #define SEP_ARRIVE_INTS 17 /* arrival counters per sample: one per slot + one for the slots (csrc/common.hpp, gln_bwd_publish) */
 
@@ -407,6 +407,10 @@ int sep_adam_step_dev(float* p, float* g, float* m, float* v, const double* sqno
  * `reverse` forces one of them for the call (tests). */
 #define SEP_LSTM_FORCE16 0x100
 #define SEP_LSTM_FORCE4 0x200
+/* with reverse = 2: h_out (sep_lstm_fwd) and dh_out (sep_lstm_bwd) are ONE (nseq, L, 2H) buffer, forward direction in columns [0, H),
+ * reversed in [H, 2H) -- the layout nn.LSTM(bidirectional=True) returns -- instead of two (nseq, L, H) slabs: no torch.cat / torch.stack
+ * around the sweeps.  gates, cstate, xg and dxg keep one slab per direction. */
+#define SEP_LSTM_INTERLEAVED 0x400
 int sep_lstm_fwd(const float* xg, const float* w_hh, float* h_out, float* gates, float* cstate, int nseq, int L, int H,
                  int reverse, sep_stream_t stream);
 int sep_lstm_bwd(const float* dh_out, const float* gates, const float* cstate, const float* w_hh, float* dxg, int nseq,
@@ -421,12 +425,21 @@ int sep_lstm_bwd(const float* dh_out, const float* gates, const float* cstate, c
  *                          slabs: sep_reduce_slabs), partial_bias[s][n] = sum of dy[t][n] over the same tokens (may be NULL).
  *                          shift in {-1, 0, +1} and L: with shift != 0 the tokens are sequences of L steps (ntok % L == 0) and x[t + shift]
  *                          is the previous / next step's row of the SAME sequence, zero at its first / last step: the h_{t-1} operand of
- *                          the recurrent weights' gradient (dW_hh = sum_t dgates_t h_{t-1}^T) taken from h itself. */
+ *                          the recurrent weights' gradient (dW_hh = sum_t dgates_t h_{t-1}^T) taken from h itself.  ldx: row stride of x in
+ *                          floats (>= K, multiple of 4; x 16-byte aligned): one direction's half of an interleaved bi-LSTM output. */
 int sep_linear_fwd(const float* x, const float* w, const float* bias, const float* bias2, float* y, long ntok, int K, int N,
                    sep_stream_t stream);
 int sep_linear_bwd_input(const float* dy, const float* w, float* dx, long ntok, int K, int N, int accumulate, sep_stream_t stream);
-int sep_linear_bwd_weight(const float* dy, const float* x, float* partial, float* partial_bias, long ntok, int K, int N, int L,
+int sep_linear_bwd_weight(const float* dy, const float* x, long ldx, float* partial, float* partial_bias, long ntok, int K, int N, int L,
                           int shift, int nslab, sep_stream_t stream);
+
+/* The layout change in front of and behind those layers (reference src/models/dprnn.py:73-76,123-126, the permute / reshape pairs around
+ * the intra- and inter-chunk recurrences), each the other's inverse and backward:
+ *   sep_chunk_to_tokens   y[b][s][k][f] = x[b][f][s][k]   (inter = 0: sequences over k for every (b, s): y is (B*S, K, F))
+ *                         y[b][k][s][f] = x[b][f][s][k]   (inter = 1: sequences over s for every (b, k): y is (B*K, S, F))
+ *   sep_tokens_to_chunk   the reverse, x (B, F, S, K) contiguous. */
+int sep_chunk_to_tokens(const float* x, float* y, int B, int F, int S, int K, int inter, sep_stream_t stream);
+int sep_tokens_to_chunk(const float* y, float* x, int B, int F, int S, int K, int inter, sep_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -593,7 +593,13 @@ class EmuBackend:
         out += (g.reshape(-1)[:n].double() ** 2).sum()
 
     def lstm_fwd(self, xg, w_hh, h_out, gates, cstate, nseq, L, H, reverse):
+        interleaved = bool(int(reverse) & 0x400)
         reverse = int(reverse) & 0xff        # bits 8-9 choose between the device's two sweep kernels: same arithmetic
+        if interleaved:                # h_out is ONE (nseq, L, 2H) buffer: forward direction in columns [0, H), reversed in [H, 2H)
+            slabs = torch.empty(2, nseq, L, H, dtype=h_out.dtype)
+            self.lstm_fwd(xg, w_hh, slabs, gates, cstate, nseq, L, H, 2)
+            h_out.reshape(nseq, L, 2 * H)[:] = torch.cat([slabs[0], slabs[1]], dim=2)
+            return
         if int(reverse) == 2:          # both directions: two slabs per buffer
             for d in range(2):
                 self.lstm_fwd(xg.reshape(2, -1)[d], w_hh.reshape(2, 4 * H, H)[d], h_out.reshape(2, -1)[d],
@@ -617,7 +623,12 @@ class EmuBackend:
                 cstate.reshape(nseq, L, H)[:, t] = c
 
     def lstm_bwd(self, dh_out, gates, cstate, w_hh, dxg, nseq, L, H, reverse):
+        interleaved = bool(int(reverse) & 0x400)
         reverse = int(reverse) & 0xff
+        if interleaved:                # dh_out is ONE (nseq, L, 2H) buffer
+            d3 = dh_out.reshape(nseq, L, 2 * H)
+            self.lstm_bwd(torch.stack([d3[..., :H], d3[..., H:]]).contiguous(), gates, cstate, w_hh, dxg, nseq, L, H, 2)
+            return
         if int(reverse) == 2:
             for d in range(2):
                 self.lstm_bwd(dh_out.reshape(2, -1)[d], gates.reshape(2, -1)[d], cstate.reshape(2, -1)[d], w_hh.reshape(2, 4 * H, H)[d],
@@ -642,6 +653,14 @@ class EmuBackend:
             dc = dcc * f
             dhr = da @ w_hh
 
+    def chunk_to_tokens(self, x, y, B, F, S, K, inter):
+        v = x.reshape(B, F, S, K)
+        y.reshape(-1)[:] = (v.permute(0, 3, 2, 1) if inter else v.permute(0, 2, 3, 1)).reshape(-1)
+
+    def tokens_to_chunk(self, y, x, B, F, S, K, inter):
+        v = y.reshape(B, K, S, F).permute(0, 3, 2, 1) if inter else y.reshape(B, S, K, F).permute(0, 3, 1, 2)
+        x.reshape(-1)[:] = v.reshape(-1)
+
     # ---- token-major dense layers (csrc/linear.hip)
     def linear_fwd(self, x, w, bias, bias2, y, ntok, K, N):
         out = x.reshape(ntok, K) @ w.reshape(N, K).t()
@@ -658,7 +677,8 @@ class EmuBackend:
         else:
             dx.reshape(ntok, K)[:] = out
 
-    def linear_bwd_weight(self, dy, x, partial, partial_bias, ntok, K, N, L, shift, nslab):
+    def linear_bwd_weight(self, dy, x, ldx, partial, partial_bias, ntok, K, N, L, shift, nslab):
+        assert x.dim() == 2 and x.stride(0) == ldx and x.stride(1) == 1
         d2, x2 = dy.reshape(ntok, N), x.reshape(ntok, K)
         if shift:
             xs = torch.zeros_like(x2).reshape(ntok // L, L, K)

@@ -902,6 +902,21 @@ def test_segment_overlap_add(T, chunk, hop):
 LSTM_KERNELS = {"sixteen": 0x100, "four": 0x200}      # SEP_LSTM_FORCE16 / SEP_LSTM_FORCE4: every case runs on both sweep kernels
 
 
+# ------------------------------------------------------------------------------------------- chunked features <-> token-major rows
+@pytest.mark.parametrize("B,F,S,K", [(2, 64, 5, 250), (1, 48, 3, 33), (3, 7, 2, 1), (2, 64, 257, 50)])
+def test_chunk_tokens_layout_pair(B, F, S, K):
+    """sep_chunk_to_tokens / sep_tokens_to_chunk against permute + reshape, both sequence axes, ragged 32 x 32 tiles, and as inverses."""
+    x = rnd(B, F, S, K)
+    for inter in (0, 1):
+        y = nan(B * K, S, F) if inter else nan(B * S, K, F)
+        both("chunk_to_tokens", [x, y, B, F, S, K, inter], tol=0)
+        want = x.permute(0, 3, 2, 1).reshape(B * K, S, F) if inter else x.permute(0, 2, 3, 1).reshape(B * S, K, F)
+        assert torch.equal(y, want)
+        back = nan(B, F, S, K)
+        both("tokens_to_chunk", [y, back, B, F, S, K, inter], tol=0)
+        assert torch.equal(back, x)
+
+
 # ------------------------------------------------------------------------------------------- token-major dense layers
 @pytest.mark.parametrize("ntok,K,N", [(1000, 64, 512), (777, 256, 64), (130, 128, 128), (64, 64, 64), (3001, 128, 512)])
 def test_linear_forward_and_input_gradient(ntok, K, N):
@@ -923,8 +938,8 @@ def test_linear_weight_gradient(nseq, L, K, N, shift, nslab):
     dy, x = rnd(ntok, N), rnd(ntok, K)
     part_c, pb_c = nan(nslab, N, K), nan(nslab, N)
     part_g, pb_g = to_device(part_c), to_device(pb_c)
-    EMU.linear_bwd_weight(dy, x, part_c, pb_c, ntok, K, N, L, shift, nslab)
-    HIP.linear_bwd_weight(to_device(dy), to_device(x), part_g, pb_g, ntok, K, N, L, shift, nslab)
+    EMU.linear_bwd_weight(dy, x, K, part_c, pb_c, ntok, K, N, L, shift, nslab)
+    HIP.linear_bwd_weight(to_device(dy), to_device(x), K, part_g, pb_g, ntok, K, N, L, shift, nslab)
     device_sync()
     ref = part_c.sum(0)
     assert torch.isfinite(part_g).all() and torch.isfinite(pb_g).all()
@@ -941,8 +956,16 @@ def test_linear_weight_gradient(nseq, L, K, N, shift, nslab):
         xs = z
     want = dy.double().t() @ xs.reshape(ntok, K).double()
     assert (part_g.cpu().double().sum(0) - want).abs().max() <= 2e-4 * want.abs().max()
-    HIP.linear_bwd_weight(to_device(dy), to_device(x), part_g, None, ntok, K, N, L, shift, nslab)      # without the bias sums
+    HIP.linear_bwd_weight(to_device(dy), to_device(x), K, part_g, None, ntok, K, N, L, shift, nslab)      # without the bias sums
     device_sync()
+    # x as the right half of a wider row-major matrix (rows 2K + 4 floats apart): one direction of an interleaved bi-LSTM output
+    wide = rnd(ntok, 2 * K + 4)
+    wide[:, K + 4:] = x
+    wide_g = to_device(wide)
+    part2 = to_device(nan(nslab, N, K))
+    HIP.linear_bwd_weight(to_device(dy), wide_g[:, K + 4:], 2 * K + 4, part2, None, ntok, K, N, L, shift, nslab)
+    device_sync()
+    assert (part2.cpu() - part_c).abs().max() <= 2e-4 * ref.abs().max()
 
 
 @pytest.mark.parametrize("kernel", sorted(LSTM_KERNELS))
@@ -957,6 +980,22 @@ def test_lstm_sweeps(H, nseq, L, reverse, kernel):
     both("lstm_fwd", [xg, w_hh, h, gates, cst, nseq, L, H, reverse], tol=tol)
     # backward on the emulator's saved gates / cell states (identical inputs for both sides)
     both("lstm_bwd", [rnd(nseq, L, H), gates, cst, w_hh, nan(nseq, L, 4 * H), nseq, L, H, reverse], tol=tol)
+
+
+@pytest.mark.parametrize("kernel", sorted(LSTM_KERNELS))
+def test_lstm_sweeps_interleaved_output(kernel):
+    """reverse = 2 | SEP_LSTM_INTERLEAVED: h_out and dh_out are one (nseq, L, 2H) buffer, the layout nn.LSTM(bidirectional=True) returns."""
+    H, nseq, L = 64, 9, 17
+    mode = 2 | 0x400 | LSTM_KERNELS[kernel]
+    xg = rnd(2, nseq, L, 4 * H)
+    w_hh = rnd(2, 4 * H, H, scale=H ** -0.5)
+    h, gates, cst = nan(nseq, L, 2 * H), nan(2, nseq, L, 4 * H), nan(2, nseq, L, H)
+    both("lstm_fwd", [xg, w_hh, h, gates, cst, nseq, L, H, mode])
+    slabs = nan(2, nseq, L, H)
+    EMU.lstm_fwd(xg, w_hh, slabs, None, None, nseq, L, H, 2)
+    assert torch.equal(h, torch.cat([slabs[0], slabs[1]], dim=2))
+    dh = rnd(nseq, L, 2 * H)
+    both("lstm_bwd", [dh, gates, cst, w_hh, nan(2, nseq, L, 4 * H), nseq, L, H, mode])
 
 
 @pytest.mark.parametrize("kernel", sorted(LSTM_KERNELS))

@@ -1,7 +1,7 @@
 """CPU: the HIP kernel files' OWN SOURCE executed on the host.  tools/hostsim.py compiles every file of csrc/ as plain C++ against a
 stand-in for the pieces of the HIP programming model they use (one host thread per lane, pthread barriers for workgroup and wave;
 shuffles, DPP, ballots and the MFMA instructions as collective operations of a wave; LDS-DMA as a wave-wide copy; the GEMM files' few
-inline-assembly helpers get a C++ body in the compiled copy) into a library with the same C ABI -- all 47 entry points -- and the kernel
+inline-assembly helpers get a C++ body in the compiled copy) into a library with the same C ABI -- all 49 entry points -- and the kernel
 cases of tests/test_gpu_kernels.py -- the very functions that run on the MI355X -- are run against it here: encoder / unfold, depthwise forward / backward, gLN statistics / apply / backward pieces, head backward,
 decoder forward / backward, channel softmax, cLN, SI-SDR, PIT search, Sinkhorn, row distances, squared norm + Adam, chunking /
 overlap-add, the LSTM sweeps (both kernels: sixteen and four sequences per workgroup, forced per call),
@@ -44,6 +44,8 @@ CASES = [
     ("test_lstm_sweeps", [(16, 5, 7, 0, "sixteen"), (32, 37, 23, 1, "sixteen"), (64, 16, 40, 0, "sixteen"), (128, 50, 31, 1, "sixteen"),
                           (16, 5, 7, 0, "four"), (32, 37, 23, 1, "four"), (64, 16, 40, 0, "four"), (128, 50, 31, 1, "four")]),
     ("test_lstm_sweeps_both_directions_one_launch", [("sixteen",), ("four",)]),
+    ("test_lstm_sweeps_interleaved_output", [("sixteen",), ("four",)]),
+    ("test_chunk_tokens_layout_pair", [(2, 64, 5, 250), (1, 48, 3, 33), (3, 7, 2, 1)]),
     ("test_linear_forward_and_input_gradient", [(1000, 64, 512), (777, 256, 64), (130, 128, 128)]),
     ("test_linear_weight_gradient", [(32, 20, 64, 512, 0, 7), (9, 31, 128, 512, -1, 3), (9, 31, 128, 512, 1, 5), (3, 7, 64, 64, -1, 1), (5, 250, 256, 64, 0, 40)]),
 ]
