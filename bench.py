@@ -587,8 +587,8 @@ def bench_dual_path(args):
         config["algorithmic_gflop_per_utterance_fwd_bwd"] = gflop
         tf = gflop * 1e9 * B * args.steps / el / 1e12
         # the step's arithmetic is fp32 throughout (the LSTM recurrences on v_mfma_f32_16x16x4 / 4x4x1, projections on rocBLAS fp32): matrix-pipe roof
-        roofline = {"kernel": "whole step (rocprofv3, profiles/r03v_dprnn_kernel_stats.md: sep_lstm_fwd / sep_lstm_bwd sweeps 34 % of the kernel time, the dense "
-                              "layers of csrc/linear.hip 37 %, layout copies 18 %)", "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS,
+        roofline = {"kernel": "whole step (rocprofv3, profiles/r04e_dprnn_kernel_stats.md: sep_lstm_fwd / sep_lstm_bwd sweeps 40 % of the kernel time, the dense "
+                              "layers of csrc/linear.hip 43 %)", "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
                     "what": "algorithmic fp32 FLOP of forward + backward (SURVEY.md 8d: {:.0f} GFLOP per utterance) / step time against the dense fp32 MFMA "
                             "peak; the recurrences are latency-bound chains (one workgroup per 4 or 16 sequences, a barrier per time step), the "
