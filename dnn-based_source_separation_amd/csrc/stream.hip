@@ -411,11 +411,39 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(
 // a float4.  u1 never goes to LDS: the three correlation sums are re-indexed onto the thread's own frame,
 //   sum_t dz[t] v1[t-d] = sum_s v1[s] dz[s+d],   sum_t dz[t] v1[t+d] = sum_s v1[s] dz[s-d]      (dz = 0 outside [0, T)),
 // so a thread keeps the PReLU1 outputs of its NIT float4 in registers across the barrier: 16 KiB of LDS per workgroup at
-// ldt = 4096 instead of 32 (8 workgroups per CU instead of 4) and half the LDS traffic.  ALIGNED: d % 4 == 0 (ds_read_b128
+// ldt = 4096 instead of 32 (8 workgroups per CU instead of 4) and half the LDS traffic.  DM: see dw_row_neighbours (d % 4 == 0: ds_read_b128
 // neighbours); NIT >= ldt / 1024.  Writes the row totals into tile 0 of rowpart and zeros into the other tiles (the
 // finalize kernel sums over tiles).
 // =====================================================================================
-template <bool ALIGNED, int NIT, bool RECOMP>
+// the neighbours at distance d of the four frames t .. t + 3 of an LDS row: DM 0: d % 4 == 0 (two aligned float4 reads), 1 / 2: d = 1 / 2 (the
+// two neighbouring float4s and register selects, as dwconv_fwd_direct_kernel does with global loads), 3: any d (eight scalar reads)
+template <int DM>
+__device__ __forceinline__ void dw_row_neighbours(const float* row, const float4 c, const int t, const int d, const int ldt, float (&lft)[4], float (&rgt)[4]) {
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (DM == 0) {
+        const float4 m1 = t - d >= 0 ? ld4(row + t - d) : zero4, p1 = t + d < ldt ? ld4(row + t + d) : zero4;
+        lft[0] = m1.x; lft[1] = m1.y; lft[2] = m1.z; lft[3] = m1.w;
+        rgt[0] = p1.x; rgt[1] = p1.y; rgt[2] = p1.z; rgt[3] = p1.w;
+    } else if (DM == 1 || DM == 2) {
+        const float4 l4 = t >= 4 ? ld4(row + t - 4) : zero4, r4 = t + 4 < ldt ? ld4(row + t + 4) : zero4;
+        if (DM == 1) {
+            lft[0] = l4.w; lft[1] = c.x; lft[2] = c.y; lft[3] = c.z;
+            rgt[0] = c.y; rgt[1] = c.z; rgt[2] = c.w; rgt[3] = r4.x;
+        } else {
+            lft[0] = l4.z; lft[1] = l4.w; lft[2] = c.x; lft[3] = c.y;
+            rgt[0] = c.z; rgt[1] = c.w; rgt[2] = r4.x; rgt[3] = r4.y;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int tm = t + e - d, tq = t + e + d;
+            lft[e] = tm >= 0 ? row[tm] : 0.f;
+            rgt[e] = tq < ldt ? row[tq] : 0.f;
+        }
+    }
+}
+
+template <int DM, int NIT, bool RECOMP>
 __global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
     const float* __restrict__ dv2, const float* __restrict__ z, const float* __restrict__ bd, const float* __restrict__ a,
     const double* __restrict__ stats1, const float* __restrict__ gamma1, const float* __restrict__ beta1,
@@ -480,19 +508,10 @@ __global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
             if (q < nq4) {
                 const int t = 4 * q;
                 float lft[4], rgt[4], o[4];
-                if (ALIGNED) {
-                    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                    const float4 m1 = t - d >= 0 ? ld4(v1s + t - d) : zero4, p1 = t + d < ldt ? ld4(v1s + t + d) : zero4;
-                    lft[0] = m1.x; lft[1] = m1.y; lft[2] = m1.z; lft[3] = m1.w;
-                    rgt[0] = p1.x; rgt[1] = p1.y; rgt[2] = p1.z; rgt[3] = p1.w;
-                } else {
+                float c4[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int tm = t + e - d, tq = t + e + d;
-                        lft[e] = tm >= 0 ? v1s[tm] : 0.f;
-                        rgt[e] = tq < ldt ? v1s[tq] : 0.f;
-                    }
-                }
+                for (int e = 0; e < 4; ++e) c4[e] = t + e < T ? fmaf(uv[k][e], sc1, sh1) : 0.f;      // this thread's own v1 (what it wrote)
+                dw_row_neighbours<DM>(v1s, make_float4(c4[0], c4[1], c4[2], c4[3]), t, d, ldt, lft, rgt);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float ce = t + e < T ? fmaf(uv[k][e], sc1, sh1) : 0.f;
@@ -537,19 +556,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
             const int t = 4 * q;
             const float4 dzc4 = ld4(dzs + t);
             float dzm[4], dzp[4];
-            if (ALIGNED) {
-                const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 m1 = t - d >= 0 ? ld4(dzs + t - d) : zero4, p1 = t + d < ldt ? ld4(dzs + t + d) : zero4;
-                dzm[0] = m1.x; dzm[1] = m1.y; dzm[2] = m1.z; dzm[3] = m1.w;
-                dzp[0] = p1.x; dzp[1] = p1.y; dzp[2] = p1.z; dzp[3] = p1.w;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int tm = t + e - d, tq = t + e + d;
-                    dzm[e] = tm >= 0 ? dzs[tm] : 0.f;
-                    dzp[e] = tq < ldt ? dzs[tq] : 0.f;
-                }
-            }
+            dw_row_neighbours<DM>(dzs, dzc4, t, d, ldt, dzm, dzp);
             const float dzc[4] = {dzc4.x, dzc4.y, dzc4.z, dzc4.w};
             float o[4];
 #pragma unroll
@@ -1316,8 +1323,11 @@ extern "C" int sep_dwconv_bwd(const float* dv2, const float* z, const float* a, 
         const dim3 grid((unsigned)((long)B * C));
 #define SEP_DWB(AL, NIT, RC) hipLaunchKernelGGL((dwconv_bwd_row_kernel<AL, NIT, RC>), grid, dim3(256), rsmem, (hipStream_t)stream, dv2, z, bd, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bsum2, wd, dv1, rowpart, bacc1, arrive1, bsum1, C, T, ldt, dilation, eps)
 #define SEP_DWB2(AL, NIT) do { if (recomp) SEP_DWB(AL, NIT, true); else SEP_DWB(AL, NIT, false); } while (0)
-        if (dilation % 4 == 0) { if (ldt <= 4096) SEP_DWB2(true, 4); else SEP_DWB2(true, 8); }
-        else { if (ldt <= 4096) SEP_DWB2(false, 4); else SEP_DWB2(false, 8); }
+        const int dm = dilation % 4 == 0 ? 0 : dilation <= 2 ? dilation : 3;
+        if (dm == 0) { if (ldt <= 4096) SEP_DWB2(0, 4); else SEP_DWB2(0, 8); }
+        else if (dm == 1) { if (ldt <= 4096) SEP_DWB2(1, 4); else SEP_DWB2(1, 8); }
+        else if (dm == 2) { if (ldt <= 4096) SEP_DWB2(2, 4); else SEP_DWB2(2, 8); }
+        else { if (ldt <= 4096) SEP_DWB2(3, 4); else SEP_DWB2(3, 8); }
 #undef SEP_DWB2
 #undef SEP_DWB
         SEP_CHECK_LAUNCH("sep_dwconv_bwd");
