@@ -681,31 +681,62 @@ struct FinalizeArgs {
     int blk_start[FMAXSEG + 1];
     int nseg;
 };
+// lanes that share one row of partials: rowlen / 4 (a float4 each) when that is a power of two <= 64 -- 8 for the depthwise kernel's
+// 4 tiles x 8 sums, so a wave reduces EIGHT rows -- else the whole wave walks the row by scalars (the stand-alone kernel's form).  One wave
+// per 128-byte row made this launch 133 us for 49 segments (100,000 workgroups of a few instructions each).
+__host__ __device__ inline int fin_lanes_per_row(int rowlen, int nq) {
+    const int l = rowlen / 4;
+    const bool pow2 = rowlen % 4 == 0 && l >= 1 && l <= 64 && (l & (l - 1)) == 0;
+    return pow2 && (nq == 2 || l >= 2) ? l : 64;
+}
 __global__ __launch_bounds__(256) void gln_bwd_finalize_rows_batch_kernel(const FinalizeArgs a) {
     int sgi = 0;
     while (sgi + 1 < a.nseg && (int)blockIdx.x >= a.blk_start[sgi + 1]) ++sgi;
     const sep_finalize_seg sg = a.seg[sgi];
     const int lane = threadIdx.x & 63;
-    const long row = (long)((int)blockIdx.x - a.blk_start[sgi]) * 4 + (threadIdx.x >> 6);      // b*C + c
-    if (row >= (long)sg.B * sg.C) return;
+    const int rowlen = sg.ntile * sg.nq;
+    const int lpr = fin_lanes_per_row(rowlen, sg.nq), rpw = 64 / lpr;
+    const bool packed = lpr != 64 || rowlen == 256;
+    const long nrows = (long)sg.B * sg.C;
+    const long row = ((long)((int)blockIdx.x - a.blk_start[sgi]) * 4 + (threadIdx.x >> 6)) * rpw + lane / lpr;      // b*C + c
+    const int p = lane % lpr;
+    const bool live = row < nrows;
+    const float* rp = sg.rowpart + (size_t)(live ? row : 0) * rowlen;
+    float q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // the row's totals of quantity 0 .. nq-1, valid in the row's lane p == 0
+    if (packed) {
+        float4 v = live ? ld4(rp + 4 * p) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sg.nq == 8) {                                        // float4 p holds quantities 4 (p & 1) .. + 3
+            for (int o = 2; o < lpr; o <<= 1) {
+                v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64); v.z += __shfl_xor(v.z, o, 64); v.w += __shfl_xor(v.w, o, 64);
+            }
+            q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+            q[4] = __shfl_xor(v.x, 1, 64); q[5] = __shfl_xor(v.y, 1, 64); q[6] = __shfl_xor(v.z, 1, 64); q[7] = __shfl_xor(v.w, 1, 64);
+        } else {                                                 // nq == 2: elements alternate between the two quantities
+            float s0 = v.x + v.z, s1 = v.y + v.w;
+            for (int o = 1; o < lpr; o <<= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
+            q[0] = s0; q[1] = s1;
+        }
+    } else {
+        float acc = 0.f;
+        if (live)
+            for (int i = lane; i < rowlen; i += 64) acc += rp[i];    // i % nq == lane % nq (nq divides 64)
+        for (int o = sg.nq; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) q[k] = __shfl(acc, k, 64);
+    }
+    if (!live || p != 0) return;
     const int b = (int)(row / sg.C), c = (int)(row % sg.C);
     float mu, rstd;
     gln_mu_rstd(sg.stats + (size_t)b * SEP_STATS_SLOTS * 2, sg.count, sg.eps, mu, rstd);
-    const int rowlen = sg.ntile * sg.nq;
-    const float* rp = sg.rowpart + (size_t)row * rowlen;
-    float acc = 0.f;
-    for (int i = lane; i < rowlen; i += 64) acc += rp[i];            // i % nq == lane % nq (nq divides 64)
-    for (int o = sg.nq; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
-    const float R1 = __shfl(acc, 0, 64), R2 = __shfl(acc, 1, 64);
-    if (lane == 0) {
-        sg.pbeta[row] = R1;
-        sg.pgamma[row] = rstd * (R2 - mu * R1);
-    }
+    sg.pbeta[row] = q[0];
+    sg.pgamma[row] = rstd * (q[1] - mu * q[0]);
     if (sg.nq == 8) {
         float* scratch = sg.pextra + (size_t)sg.B * sg.C * 4 + sg.B;
-        if (lane == 2) sg.pextra[(size_t)b * 4 * sg.C + c] = acc;
-        if (lane >= 3 && lane < 6) sg.pextra[(size_t)b * 4 * sg.C + sg.C + (size_t)c * 3 + (lane - 3)] = acc;
-        if (lane == 6) scratch[row] = acc;
+        sg.pextra[(size_t)b * 4 * sg.C + c] = q[2];
+        sg.pextra[(size_t)b * 4 * sg.C + sg.C + (size_t)c * 3 + 0] = q[3];
+        sg.pextra[(size_t)b * 4 * sg.C + sg.C + (size_t)c * 3 + 1] = q[4];
+        sg.pextra[(size_t)b * 4 * sg.C + sg.C + (size_t)c * 3 + 2] = q[5];
+        scratch[row] = q[6];
     }
 }
 __global__ __launch_bounds__(256) void gln_bwd_finalize_sample_batch_kernel(const FinalizeArgs a) {
@@ -1369,7 +1400,8 @@ extern "C" int sep_gln_bwd_finalize_batch(const sep_finalize_seg* segs, int nseg
                     "sep_gln_bwd_finalize_batch: bad segment %d", i);
         rows.seg[i] = g; samples.seg[i] = g;
         rows.blk_start[i] = rb; samples.blk_start[i] = sb;
-        rb += (int)(((long)g.B * g.C + 3) / 4);
+        const int rows_per_block = 4 * (64 / fin_lanes_per_row(g.ntile * g.nq, g.nq));
+        rb += (int)(((long)g.B * g.C + rows_per_block - 1) / rows_per_block);
         sb += (g.bsum || g.nq == 8) ? g.B : 0;           // segments that need no per-sample stage take no blocks of it
         any_sample |= (g.bsum || g.nq == 8);
     }

@@ -714,7 +714,8 @@ def test_gln_bwd_finalize_batch():
         x = rnd(B, C, 50)
         return [rnd(B, C, ntile, nq), ntile, nq, stats_of(x, 50), rnd(C) + 1, C * 50.0, 1e-12, nan(B, 2) if with_bsum else None, nan(B, C), nan(B, C),
                 nan(B * 4 * C + B + B * C) if nq == 8 else None, B, C]
-    segs = [seg(3, 96, 4, 8, False), seg(2, 40, 8, 2, True), seg(1, 130, 1, 8, True), seg(4, 16, 64, 2, False)]
+    # rows of 32, 16, 8, 128 floats (several rows per wave), 24 (not a power of two of float4s: a wave per row) and 256 (a whole wave of float4s)
+    segs = [seg(3, 96, 4, 8, False), seg(2, 40, 8, 2, True), seg(1, 130, 1, 8, True), seg(4, 16, 64, 2, False), seg(2, 33, 3, 8, True), seg(1, 9, 32, 8, False)]
     gsegs = [[to_device(v) if torch.is_tensor(v) else v for v in sg] for sg in segs]
     EMU.gln_bwd_finalize_batch([tuple(sg) for sg in segs])
     HIP.gln_bwd_finalize_batch([tuple(sg) for sg in gsegs])
