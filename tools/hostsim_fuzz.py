@@ -208,6 +208,28 @@ def case_lstm(R):
     return "lstm H={} nseq={} L={} reverse={} kernel={}".format(H, nseq, L, rev, kernel)
 
 
+def case_dense(R):
+    """token-major dense layers and the chunk <-> token layout pair (csrc/linear.hip) at random sizes: ragged token tiles, both tile widths,
+    slab counts beyond the token count, x as a column slice of a wider matrix, both shifts"""
+    pick = R.randint(0, 3)
+    if pick == 0:
+        ntok, K, N = R.randint(1, 700), 64 * R.randint(1, 4), 64 * R.randint(1, 8)
+        GK.test_linear_forward_and_input_gradient(ntok, K, N)
+        return "linear fwd / dx ntok={} K={} N={}".format(ntok, K, N)
+    if pick == 1:
+        nseq, L, K, N = R.randint(1, 12), R.randint(1, 40), 64 * R.randint(1, 4), 64 * R.randint(1, 8)
+        shift, nslab = R.choice([-1, 0, 1]), R.randint(1, 30)
+        GK.test_linear_weight_gradient(nseq, L, K, N, shift, nslab)
+        return "linear dW nseq={} L={} K={} N={} shift={} nslab={}".format(nseq, L, K, N, shift, nslab)
+    if pick == 2:
+        B, F, S, K = R.randint(1, 3), R.randint(1, 70), R.randint(1, 9), R.randint(1, 80)
+        GK.test_chunk_tokens_layout_pair(B, F, S, K)
+        return "chunk <-> tokens B={} F={} S={} K={}".format(B, F, S, K)
+    kernel = R.choice(["sixteen", "four"])
+    GK.test_lstm_sweeps_interleaved_output(kernel)
+    return "lstm interleaved " + kernel
+
+
 def case_test_functions(R):
     """the parametrised kernel tests of tests/test_gpu_kernels.py at random parameters"""
     pick = R.randint(0, 6)
@@ -242,7 +264,8 @@ def case_test_functions(R):
     return "cln fwd+bwd {} {} {}".format(B, C, T)
 
 
-CASES = [case_gemm, case_gemm, case_gemm_forms, case_gemm_forms, case_wgrad, case_wgrad, case_codec, case_norms, case_chunks, case_lstm, case_test_functions, case_test_functions]
+CASES = [case_gemm, case_gemm, case_gemm_forms, case_gemm_forms, case_wgrad, case_wgrad, case_codec, case_norms, case_chunks, case_lstm, case_dense, case_dense,
+         case_test_functions, case_test_functions]
 
 
 def run_cases(seed, seconds=None, max_cases=None):
