@@ -237,3 +237,33 @@ def test_a_failing_rank_ends_the_job_instead_of_hanging_it():
         mp.spawn(_failing_worker, args=(2, port), nprocs=2, join=True)
     assert "rank 1 fails" in str(err.value)
     assert time.time() - t0 < 300, "the surviving rank was left waiting in its all-reduce"
+
+
+def test_bench_gpus_flag_starts_the_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the driver's command shape) must itself start two ranks: on this GPU-less box
+    with SEPK_BENCH_BACKEND=gloo it is the launcher dry run (tests' emulator, flagged `dry_run`), and the LAST stdout line is one compact
+    JSON object with n_gpus == 2 that fits the driver's 8 KB stdout window with room to spare."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["SEPK_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = r.stdout.strip().splitlines()[-1]
+    assert len(line) < 3072
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["config"]["global_batch"] == 4
+    assert out["dry_run"] and out["value"] > 0 and out["ms_per_step"] > 0
+    for k in ("metric", "unit", "steps", "warmup", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert k in out
+
+
+def test_bench_without_gpu_fails_loudly():
+    """no GPU, no dry-run switch: the bench refuses instead of measuring a fallback"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SEPK_BENCH_BACKEND")}
+    if torch.cuda.is_available():
+        return
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "no GPU visible" in r.stderr
