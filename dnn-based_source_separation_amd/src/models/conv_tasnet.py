@@ -323,8 +323,9 @@ class ConvTasNet(nn.Module):
         return self.get_config()
 
     @classmethod
-    def build_model(cls, model_path, load_state_dict=False):
-        config = load_checkpoint(model_path)
+    def build_model(cls, model_path, load_state_dict=False, trust_pickle=None):
+        """trust_pickle: see utils.checkpoint.load_checkpoint (None = the SEPK_TRUST_CHECKPOINTS switch)"""
+        config = load_checkpoint(model_path, trust_pickle)
         return cls._from_config(config, load_state_dict)
 
     @classmethod
@@ -350,6 +351,7 @@ class ConvTasNet(nn.Module):
         """Same task table and directory convention as the reference (conv_tasnet.py:238-310).  The download itself
         needs the reference's gdown helper (utils.utils); an already-downloaded checkpoint is loaded directly."""
         task = kwargs.get("task")
+        trust_pickle = kwargs.get("trust_pickle")          # utils.checkpoint.load_checkpoint; downloads are NOT trusted by default
         if task not in cls.pretrained_model_ids:
             raise KeyError("Invalid task ({}) is specified.".format(task))
         ids = cls.pretrained_model_ids[task]
@@ -382,7 +384,7 @@ class ConvTasNet(nn.Module):
         if not os.path.exists(model_path):
             from utils.utils import download_pretrained_model_from_google_drive   # reference helper (gdown), reused as-is
             download_pretrained_model_from_google_drive(model_id, download_dir, quiet=quiet)
-        config = load_checkpoint(model_path)
+        config = load_checkpoint(model_path, trust_pickle)
         model = cls._from_config(config, load_state_dict=load_state_dict)
         if task == "musdb18":
             extra.update({"sources": config["sources"], "n_sources": len(config["sources"])})

@@ -62,7 +62,7 @@ class _PathRNN(nn.Module):
         # matter to it: the rows go straight back to (B, F, S, K) and the inter-chunk path needs no second permutation.  cLN (the causal
         # inter-chunk path) accumulates along the sequence axis and keeps the reference's order below.
         order_free = not self.norm or not isinstance(self.norm1d, CumulativeLayerNorm1d)
-        if order_free and S <= 65535 and takes(input):
+        if order_free and S <= 65535 and B * ((F + 31) // 32) <= 65535 and takes(input):     # grid limits of sep_chunk_to_tokens / sep_tokens_to_chunk
             x = ChunkToTokensFn.apply(input, inter)                  # tiled transposes (csrc/linear.hip) instead of strided copies
             x = lstm_apply(x, self.rnn)          # the sweep kernels for 16 / 32 / 64 / 128 units, torch's LSTM otherwise
             x = linear_apply(x, self.fc)                             # csrc/linear.hip for feature counts % 64 == 0

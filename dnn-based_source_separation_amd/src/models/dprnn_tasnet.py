@@ -77,8 +77,8 @@ class DPRNNTasNet(MaskingTasNet):
                                        "sep_hop_size", "sep_num_blocks", "causal", "sep_norm", "mask_nonlinear", "rnn_type", "n_sources", "eps")}
 
     @classmethod
-    def build_model(cls, model_path, load_state_dict=False):
-        config = load_checkpoint(model_path)
+    def build_model(cls, model_path, load_state_dict=False, trust_pickle=None):
+        config = load_checkpoint(model_path, trust_pickle)
         model = cls(config.get("n_bases") or config["n_basis"], in_channels=config.get("in_channels") or 1,
                     kernel_size=config["kernel_size"], stride=config["stride"],
                     enc_basis=config.get("enc_bases") or config["enc_basis"], dec_basis=config.get("dec_bases") or config["dec_basis"],

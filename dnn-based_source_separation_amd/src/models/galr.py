@@ -40,7 +40,8 @@ class GALRBlock(nn.Module):
         return self.inter_chunk_block(self.intra_chunk_block(input))
 
 
-_POSITION_CODES = {}       # id(block) -> {(S, Q, C, device, dtype): code}, see GloballyAttentiveBlockBase._position_code
+_POSITION_CODES = {}       # (S, Q, C, device, dtype) -> code, ONE bounded LRU for all blocks, see GloballyAttentiveBlockBase._position_code
+_POSITION_CODES_MAX = 16
 
 
 class GloballyAttentiveBlockBase(nn.Module):
@@ -55,11 +56,14 @@ class GloballyAttentiveBlockBase(nn.Module):
     def _position_code(self, S, Q, C, like):
         """(C, S, Q) code on the device / in the dtype of `like`, built once per shape: forming it on the host and copying it
         over in every forward would stall the launch queue once per block"""
-        cache = _POSITION_CODES.setdefault(id(self), {})      # not an attribute: deepcopy / state_dict must not carry device tensors along
+        # The code depends on the shape only, not on the block: one module-level LRU (not an attribute: deepcopy / state_dict must not
+        # carry device tensors along; not keyed by id(self): nn.DataParallel replicas are fresh objects every forward and destroyed
+        # models would leave their entries behind).
+        cache = _POSITION_CODES
         key = (S, Q, C, like.device, like.dtype)
         code = cache.pop(key, None)
         if code is None:
-            if len(cache) >= 8:                              # a few shapes stay resident (training length, validation utterances): least recently used goes
+            if len(cache) >= _POSITION_CODES_MAX:            # a few shapes stay resident (training length, validation utterances): least recently used goes
                 cache.pop(next(iter(cache)))
             code = self.positional_encoding(length=S * Q, dimension=C).t().reshape(C, S, Q).to(device=like.device, dtype=like.dtype)
         cache[key] = code                                    # (re-)inserted last = most recently used

@@ -69,7 +69,7 @@ class Trainer:
         self.train_loss = torch.empty(self.epochs)
         self.valid_loss = torch.empty(self.epochs)
         if getattr(args, "continue_from", None):
-            ck = load_checkpoint(args.continue_from)
+            ck = load_checkpoint(args.continue_from, getattr(args, "trust_pickle", None))
             self.start_epoch = ck["epoch"]
             self.train_loss[:self.start_epoch] = ck["train_loss"][:self.start_epoch]
             self.valid_loss[:self.start_epoch] = ck["valid_loss"][:self.start_epoch]
@@ -195,7 +195,7 @@ class Tester:
             os.makedirs(self.out_dir, exist_ok=True)
         self.device = next(model.parameters()).device
         if getattr(args, "model_path", None):
-            ck = load_checkpoint(args.model_path)
+            ck = load_checkpoint(args.model_path, getattr(args, "trust_pickle", None))
             model.load_state_dict(ck["state_dict"])
 
     def run(self):

@@ -407,6 +407,15 @@ class _SideStream:
                 if t is not None:
                     t.record_stream(self.side)
 
+    def lend(self, *tensors):
+        """the other direction of keep(): tensors ALLOCATED inside `with side:` (side-stream pool) that the main stream reads later
+        (queued reduce_slabs segments).  Without the mark the block returns to the side pool when its last reference drops and the next
+        side-stream allocation may write it while main's read is still in flight."""
+        if self.on:
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(self.main)
+
     def __enter__(self):
         if self.on:
             self._ctx = torch.cuda.stream(self.side)
@@ -537,6 +546,7 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
         with side:
             for hi, (Gt, G2t, gsp, rows, Wmat, wnames, bnames) in enumerate(heads):
                 part, pb, ns = wgrad(rows, H, Gt, z, True, True, G2=G2t, g_split=gsp, **xkw)
+                side.lend(pb)           # reduced on the MAIN stream by the flush of `pending`
                 K.gln_bwd_from_wgrad(part, pb, Wmat, st2, g2, b2, cnt, teps, dWbs[hi], pbeta2, pgamma2, bacc[2 + 2 * li], arrive[2 + 2 * li],
                                      bsum[2 + 2 * li], B, rows, H, ns // B, accumulate=int(hi > 0), products=len(heads))
                 segs += [(dWbs[hi], r0 * H, G[nm], nr * H, B, rows * H, 0, 1.0) for nm, r0, nr in wnames]
@@ -602,7 +612,7 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
                 if side.on:
                     K.reduce_slabs(segs)
                 else:
-                    pending.extend(segs)
+                    pending.extend(segs)        # (side off: one stream, one pool -- nothing to lend)
         deferred.append(conv1_leaves)
         dout = dx
         X_layers = cfg["sep_num_layers"]

@@ -302,8 +302,21 @@ class GraphedStep:
         return loss.detach()
 
     def capture(self, mixture, sources):
+        # Recorded dropout diverges on this stack (GALRNet / SepFormer at their recipe sizes: loss inf after the first replays,
+        # profiles/r04d_dual.txt -- the philox offset of the captured native_dropout does not advance as the eager one does): refuse
+        # rather than train on it.
+        live = [n for n, m in self.model.named_modules() if isinstance(m, torch.nn.modules.dropout._DropoutNd) and m.training and m.p > 0]
+        if live:
+            raise RuntimeError("GraphedStep: active dropout ({}{}) is not supported under hipGraph replay on this stack -- use the eager "
+                               "step, model.eval(), or dropout 0".format(", ".join(live[:3]), " ..." if len(live) > 3 else ""))
         params = [p for p in self.model.parameters()]
         saved = [p.detach().clone() for p in params] if self.restore else None
+        # optimizer state that exists ALREADY (continue_from / load_state_dict / earlier eager steps) is put back after the recording;
+        # only state born during the warm-up starts from zero
+        saved_state = {}
+        if self.restore:
+            for p, st in self.optimizer.state.items():
+                saved_state[p] = {k: v.detach().clone() for k, v in st.items() if torch.is_tensor(v)}
         self._static = (mixture.clone(), sources.clone())
         for p in params:                                   # gradients must exist (and keep their addresses) before the recording
             if p.grad is None and p.requires_grad:
@@ -321,10 +334,14 @@ class GraphedStep:
             with torch.no_grad():
                 for p, s in zip(params, saved):
                     p.copy_(s)
-                for st in self.optimizer.state.values():   # Adam-family state starts at zero
-                    for v in st.values():
+                for p, st in self.optimizer.state.items():
+                    old = saved_state.get(p, {})
+                    for k, v in st.items():
                         if torch.is_tensor(v):
-                            v.zero_()
+                            if k in old:
+                                v.copy_(old[k])            # in place: the graph holds the addresses
+                            else:
+                                v.zero_()                  # Adam-family state born in the warm-up starts at zero
         return self
 
     def __call__(self, mixture, sources):

@@ -4,6 +4,19 @@ import os
 
 import torch
 
+def _numpy_scalar_globals():
+    """what a reference-written package may hold besides tensors: numpy scalars (`best_loss` as np.float64 ...) -- data, not code"""
+    try:
+        import numpy as np
+        out = [np.dtype, np.float64, np.float32, np.int64, np.int32, np.bool_]
+        core = getattr(np, "_core", None) or getattr(np, "core")
+        out.append(core.multiarray.scalar)
+        out += [type(np.dtype(t)) for t in ("float64", "float32", "int64", "int32", "bool")]
+        return out
+    except Exception:                            # noqa: BLE001 -- numpy layout differences only cost the convenience
+        return []
+
+
 def load_checkpoint(path, trust_pickle=None):
     """torch.load of a package written by the reference's driver.save_model (config values + `state_dict` [+ optimizer / history]):
     plain containers, numbers, strings and tensors, which the safe unpickler (weights_only=True) reads.  Only a file that needs arbitrary
@@ -11,8 +24,13 @@ def load_checkpoint(path, trust_pickle=None):
     SEPK_TRUST_CHECKPOINTS=1 (checkpoints fetched from the network should not be given that)."""
     import pickle
     try:
-        return torch.load(path, map_location="cpu", weights_only=True)
+        with torch.serialization.safe_globals(_numpy_scalar_globals()):
+            return torch.load(path, map_location="cpu", weights_only=True)
+    except (EOFError, OSError):
+        raise                                   # truncated / unreadable file: that is what it is, not a trust question
     except (pickle.UnpicklingError, RuntimeError) as e:
+        if "PytorchStreamReader" in str(e) or "failed finding central directory" in str(e):
+            raise RuntimeError("{}: corrupt or truncated checkpoint ({})".format(path, str(e).splitlines()[0])) from e
         if trust_pickle is None:
             trust_pickle = os.environ.get("SEPK_TRUST_CHECKPOINTS", "0") == "1"
         if not trust_pickle:

@@ -55,7 +55,10 @@ def conv_tasnet(x, p, cfg):
     for r in range(R):
         for l in range(X):
             last = r == R - 1 and l == X - 1
-            h, skip = _layer(h, p, "separator.tdcn.net.{}.net.{}.".format(r, l), 2 ** l, not last, EPS)
+            # NOT cfg["eps"]: the reference's Separator builds its TimeDilatedConvNet without handing `eps` down (conv_tasnet.py:336-339), so
+            # every gLN inside the TCN runs with tdcn.py's own default EPS whatever ConvTasNet(eps=...) says; "tcn_eps" is the key
+            # sepkernels/net.py uses for the same fact
+            h, skip = _layer(h, p, "separator.tdcn.net.{}.net.{}.".format(r, l), 2 ** l, not last, cfg.get("tcn_eps", EPS))
             skip_sum = skip_sum + skip
     h = F.prelu(skip_sum, p["separator.prelu.weight"])
     mask = F.conv1d(h, p["separator.mask_conv1d.weight"], p["separator.mask_conv1d.bias"])

@@ -67,3 +67,15 @@ def test_missing_library_is_a_hard_error():
     env = dict(os.environ, SEPKERNELS_LIB="/nonexistent/libsepkernels.so")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert "LOUD True" in out.stdout, out.stdout + out.stderr
+
+
+def test_integration_md_struct_stub_matches_the_binding():
+    """INTEGRATION.md route B shows the ctypes struct a maintainer would copy: its field list must be the package's GemmDesc (a missing
+    pointer shifts every field behind it)."""
+    import re
+    import sepkernels
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = text[text.index("class GemmDesc(ctypes.Structure)"):]
+    block = block[:block.index("_lib.sep_pw_gemm.argtypes")]
+    names = re.findall(r'"([A-Za-z_0-9]+)"', block)
+    assert names == [n for n, _ in sepkernels.GemmDesc._fields_]
