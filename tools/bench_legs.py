@@ -77,7 +77,8 @@ class TimedBackend:
                 cls = {0: "conv1", 1: "mask", 2: "bottleneck", 3: "heads"}.get(pro, "gemm")
                 r8 = K + M + (M - msp if kw.get("accumulate") else 0)          # 8d: in + out (+ the skip sum read back)
             else:
-                cls = ("conv1^T" if ef & 2 else "conv1^T (layer 0: no residual gradient)") if pro == 4 else "mask^T" if ef & 8 else "heads^T" if kw.get("k_split") or (ef == 0 and M > K) else \
+                conv1t = pro == 4 or (pro == 0 and M < K and not (ef & 24) and not kw.get("k_split"))     # GLN_BWD prologue, or the plain product on da (direct)
+                cls = ("conv1^T" if ef & 2 else "conv1^T (layer 0: no residual gradient)") if conv1t else "mask^T" if ef & 8 else "heads^T" if kw.get("k_split") or (ef == 0 and M > K) else \
                     "bottleneck^T" if ef & 16 else "gemm^T"
                 r8 = K + M                                                       # 8d: the forward counterpart's in + out
                 r8 += (K - kw["k_split"]) if kw.get("k_split") else 0            # heads: + the skip sum read back
