@@ -1608,7 +1608,6 @@ extern "C" int sep_pw_gemm(const sep_gemm_desc* d, sep_stream_t stream) {
         else if (!tr && !sp && pm == SEP_PRO_GLN && ef == 0) SEP_LD(false, SEP_PRO_GLN, false, 0);                                               // bottleneck
         else if (!tr && !sp && pm == SEP_PRO_NONE && ef == 0) SEP_LD(false, SEP_PRO_NONE, false, 0);                                             // plain 1x1 conv
         else if (tr && !sp && pm == SEP_PRO_NONE && ef == 0) SEP_LD(true, SEP_PRO_NONE, false, 0);                                               // plain input gradient
-        else if (tr && !sp && pm == SEP_PRO_NONE && ef == SEP_EPI_RESIDUAL) SEP_LD(true, SEP_PRO_NONE, false, SEP_EPI_RESIDUAL);                 // conv1^T on da (sep_dwconv_bwd direct)
         else if (tr && !sp && pm == SEP_PRO_NONE && ef == SEP_EPI_PRELU_BWD) SEP_LD(true, SEP_PRO_NONE, false, SEP_EPI_PRELU_BWD);               // mask^T
         else if (tr && sp && pm == SEP_PRO_NONE && ef == (SEP_EPI_ROWSUMS | SEP_EPI_ROWSUMS_PRELU)) SEP_LD(true, SEP_PRO_NONE, true, SEP_EPI_ROWSUMS | SEP_EPI_ROWSUMS_PRELU);   // heads^T
         else if (tr && !sp && pm == SEP_PRO_NONE && ef == (SEP_EPI_ROWSUMS | SEP_EPI_ROWSUMS_PRELU)) SEP_LD(true, SEP_PRO_NONE, false, SEP_EPI_ROWSUMS | SEP_EPI_ROWSUMS_PRELU);

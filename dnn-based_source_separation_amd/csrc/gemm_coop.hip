@@ -508,7 +508,6 @@ int sep_pw_gemm_packed(const sep_gemm_desc* d, hipStream_t stream) {
     if (!sp && pm == SEP_PRO_PRELU && ef == 0) SEP_LC(SEP_PRO_PRELU, false, 0);                                                       // mask (softmax follows)
     if (!sp && pm == SEP_PRO_GLN && ef == 0) SEP_LC(SEP_PRO_GLN, false, 0);                                                           // bottleneck
     if (!sp && pm == SEP_PRO_NONE && ef == 0) SEP_LC(SEP_PRO_NONE, false, 0);                                                         // plain 1x1 conv / input gradient
-    if (!sp && pm == SEP_PRO_NONE && ef == SEP_EPI_RESIDUAL) SEP_LC(SEP_PRO_NONE, false, SEP_EPI_RESIDUAL);                               // conv1^T on da (sep_dwconv_bwd direct)
     if (!sp && pm == SEP_PRO_NONE && ef == SEP_EPI_PRELU_BWD) SEP_LC(SEP_PRO_NONE, false, SEP_EPI_PRELU_BWD);                         // mask^T
     if (sp && pm == SEP_PRO_NONE && ef == 0) SEP_LC(SEP_PRO_NONE, true, 0);                                                           // heads^T (its gLN sums come from the weight gradient)
     if (sp && pm == SEP_PRO_NONE && ef == (SEP_EPI_ROWSUMS | SEP_EPI_ROWSUMS_PRELU)) SEP_LC(SEP_PRO_NONE, true, SEP_EPI_ROWSUMS | SEP_EPI_ROWSUMS_PRELU);    // heads^T

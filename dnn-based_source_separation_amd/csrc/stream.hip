@@ -443,32 +443,16 @@ __device__ __forceinline__ void dw_row_neighbours(const float* row, const float4
     }
 }
 
-// DIRECT (sep_dwconv_bwd with direct = 1): the kernel ALSO back-propagates through gLN1 and PReLU1, i.e. it writes
-//     da = r1 (gamma1 dv1 - mg1 - xhat1 mgx1) PReLU1'(a)
-// where it wrote dv1, so that the conv1^T product behind it is a plain GEMM on da (no prologue, no second read of `a`, no store-back of
-// da: 268 MB less HBM traffic per layer at the paper-best shapes) and the conv1 weight gradient reads the same tensor.  The two means
-// (mg1, mgx1) run over the whole SAMPLE, so a row's workgroup holds its dv1 in registers, adds its gamma-weighted sums to the sample's
-// slots (bacc1), counts itself in (arrive1), and waits until all C rows of the sample have arrived before it forms da.  That needs the C
-// workgroups of a sample resident together: the host side checks C against half the kernel's resident capacity, workgroups are
-// dispatched in blockIdx order (a sample's rows are consecutive), and every earlier sample is complete or completing, so the oldest
-// waiting sample always has all its rows on the chip.  A wait that exceeds DWB_SPIN_LIMIT polls gives up, counts itself in
-// g_sync_timeouts (sep_sync_timeouts) and lets the launch finish with wrong numbers instead of hanging the device.
-// phase: 0 = all of it in one launch (the device); 1 = sums and arrival only, 2 = everything but them (two launches: the host simulation
-// of tools/hostsim.py runs one workgroup at a time and cannot wait for a later one).
-constexpr int DWB_SPIN_LIMIT = 1 << 20;
-__device__ int g_sync_timeouts = 0;
-
-template <int DM, int NIT, bool RECOMP, bool DIRECT>
+template <int DM, int NIT, bool RECOMP>
 __global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
     const float* __restrict__ dv2, const float* __restrict__ z, const float* __restrict__ bd, const float* __restrict__ a,
     const double* __restrict__ stats1, const float* __restrict__ gamma1, const float* __restrict__ beta1,
     const float* __restrict__ alpha1, const double* __restrict__ stats2, const float* __restrict__ gamma2,
     const float* __restrict__ alpha2, const float* __restrict__ bsum2, const float* __restrict__ wd,
     float* __restrict__ dv1, float* __restrict__ rowpart, double* __restrict__ bacc1, int* __restrict__ arrive1, float* __restrict__ bsum1,
-    int C, int T, int ldt, int d, float eps, int phase) {
+    int C, int T, int ldt, int d, float eps) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float part[4][8];
-    __shared__ float hand[8];
     float* dzs = lds;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int row = blockIdx.x;
@@ -565,11 +549,9 @@ __global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
     __syncthreads();
     float* orow = dv1 + rowoff;
     float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f, q4 = 0.f, q5 = 0.f;
-    float dvv[DIRECT ? NIT : 1][4];                      // DIRECT: the row's dv1 stays in registers until the sample's means are known
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
         const int q = threadIdx.x + 256 * k;
-        if (DIRECT) { dvv[DIRECT ? k : 0][0] = 0.f; dvv[DIRECT ? k : 0][1] = 0.f; dvv[DIRECT ? k : 0][2] = 0.f; dvv[DIRECT ? k : 0][3] = 0.f; }
         if (q < nq4) {
             const int t = 4 * q;
             const float4 dzc4 = ld4(dzs + t);
@@ -591,8 +573,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
                 }
                 o[e] = dv;
             }
-            if (DIRECT) { dvv[DIRECT ? k : 0][0] = o[0]; dvv[DIRECT ? k : 0][1] = o[1]; dvv[DIRECT ? k : 0][2] = o[2]; dvv[DIRECT ? k : 0][3] = o[3]; }
-            else st4(orow + t, make_float4(o[0], o[1], o[2], o[3]));
+            st4(orow + t, make_float4(o[0], o[1], o[2], o[3]));
         }
     }
     q0 = wave_sum(q0); q1 = wave_sum(q1); q2 = wave_sum(q2); q3 = wave_sum(q3);
@@ -604,76 +585,6 @@ __global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
     __syncthreads();
     const int ntile = (ldt + DW_TT - 1) / DW_TT;
     float* rp = rowpart + (size_t)row * ntile * 8;
-    if (DIRECT) {
-        const float g1c = gamma1[c];
-        double* ba = bacc1 + (size_t)b * SEP_STATS_SLOTS * 2;
-        int* cnt = arrive1 + (size_t)b * SEP_ARRIVE_INTS;
-        if (wv == 0) {
-            if (phase != 2 && lane == 0) {
-                const int slot = row & (SEP_STATS_SLOTS - 1);
-                const double t0_ = (double)(g1c * ((part[0][0] + part[1][0]) + (part[2][0] + part[3][0])));
-                const double t1_ = (double)(g1c * ((part[0][1] + part[1][1]) + (part[2][1] + part[3][1])));
-                // the sums with RETURNING atomics, waited for, then the arrival: whoever counts C arrivals finds every sum in place (agent-scope
-                // atomics are performed where the XCDs meet; no fence -- see gln_bwd_publish)
-                const double o1 = atomicAdd(ba + 2 * slot, t0_), o2 = atomicAdd(ba + 2 * slot + 1, t1_);
-                asm volatile("" :: "v"(o1), "v"(o2));
-                __hip_atomic_fetch_add(cnt + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (phase == 0) {                               // the sample's other rows: 16 counters, one per lane, until they add up to C
-                int spins = 0;
-                while (true) {
-                    int got = lane < SEP_STATS_SLOTS ? __hip_atomic_load(cnt + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) got += __shfl_xor(got, o, 64);
-                    if (got >= C) break;
-                    if (++spins > DWB_SPIN_LIMIT) { if (lane == 0) atomicAdd(&g_sync_timeouts, 1); break; }
-                    __builtin_amdgcn_s_sleep(16);
-                }
-            }
-            if (phase != 1) {
-                double s1 = lane < SEP_STATS_SLOTS ? __hip_atomic_load(ba + 2 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-                double s2 = lane < SEP_STATS_SLOTS ? __hip_atomic_load(ba + 2 * lane + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-                s1 = wave_sum(s1); s2 = wave_sum(s2);
-                if (lane == 0) {
-                    double m, r;
-                    const double count = (double)C * T;
-                    gln_mu_rstd_d(stats1 + (size_t)b * SEP_STATS_SLOTS * 2, count, eps, m, r);
-                    hand[0] = (float)(s1 / count);
-                    hand[1] = (float)(r * (s2 - m * s1) / count);
-                }
-            }
-        }
-        __syncthreads();
-        if (phase == 1) return;
-        // da = (dv1 (r1 gamma1) + PReLU1(a) k1 + k0) PReLU1'(a) -- the expression of the GLN_BWD prologue of the 1x1-convolution kernels
-        const float mg1 = hand[0], mgx1 = hand[1];
-        const float sck = r1 * g1c, bk1 = -r1 * r1 * mgx1, bk0 = r1 * (mu1 * r1 * mgx1 - mg1);
-        float dal1 = 0.f;
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            const int q = threadIdx.x + 256 * k;
-            if (q < nq4) {
-                const int t = 4 * q;
-                const float a4[4] = {av[k].x, av[k].y, av[k].z, av[k].w};
-                float o[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float aa = a4[e];
-                    const float du = fmaf(dvv[DIRECT ? k : 0][e], sck, fmaf(prelu_f(aa, a1), bk1, bk0));
-                    const bool in = t + e < T;
-                    o[e] = in ? (aa > 0.f ? du : du * a1) : 0.f;
-                    dal1 = fmaf(in ? du : 0.f, fminf(aa, 0.f), dal1);          // d(alpha1) += du * a where a <= 0
-                }
-                st4(orow + t, make_float4(o[0], o[1], o[2], o[3]));
-            }
-        }
-        dal1 = wave_sum(dal1);
-        if (lane == 0) hand[4 + wv] = dal1;
-        __syncthreads();
-        for (int i = threadIdx.x; i < ntile * 8; i += 256)
-            rp[i] = i < 7 ? (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]) : i == 7 ? (hand[4] + hand[5]) + (hand[6] + hand[7]) : 0.f;
-        return;
-    }
     for (int i = threadIdx.x; i < ntile * 8; i += 256)
         rp[i] = i < 8 ? (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]) : 0.f;
     if (bacc1 && threadIdx.x == 0) {     // gLN1's gamma-weighted totals; the sample's last row publishes the two means (gln_bwd_publish)
@@ -734,7 +645,6 @@ __global__ __launch_bounds__(256) void gln_bwd_finalize_rows_kernel(const float*
         if (lane == 2) pextra[(size_t)b * 4 * C + c] = acc;
         if (lane >= 3 && lane < 6) pextra[(size_t)b * 4 * C + C + (size_t)c * 3 + (lane - 3)] = acc;
         if (lane == 6) scratch[row] = acc;
-        if (lane == 7) scratch[(size_t)B * C + B + row] = acc;       // slot 7: the slope partial of the PReLU in FRONT of this gLN (sep_dwconv_bwd direct)
     }
 }
 
@@ -760,14 +670,6 @@ __global__ __launch_bounds__(256) void gln_bwd_finalize_sample_kernel(const floa
             bsum[2 * b + 1] = (float)(tgx / count);
         }
         if (palpha) palpha[b] = (float)tal;
-    }
-    if (palpha) {                                        // second slope (rowpart slot 7): [palpha1 B | scratch1 B*C] behind the first scratch block
-        const int B = gridDim.x;
-        const float* scratch1 = scratch + (size_t)B * C + B;
-        double s1 = 0.0;
-        for (int c = threadIdx.x; c < C; c += 256) s1 += (double)scratch1[(size_t)b * C + c];
-        const double t1 = block_sum_256<double>(s1, red);
-        if (threadIdx.x == 0) palpha[(size_t)B + (size_t)B * C + b] = (float)t1;
     }
 }
 
@@ -835,7 +737,6 @@ __global__ __launch_bounds__(256) void gln_bwd_finalize_rows_batch_kernel(const 
         sg.pextra[(size_t)b * 4 * sg.C + sg.C + (size_t)c * 3 + 1] = q[4];
         sg.pextra[(size_t)b * 4 * sg.C + sg.C + (size_t)c * 3 + 2] = q[5];
         scratch[row] = q[6];
-        scratch[(size_t)sg.B * sg.C + sg.B + row] = q[7];            // slot 7 -> scratch1 (see sep_gln_bwd_finalize's pextra layout)
     }
 }
 __global__ __launch_bounds__(256) void gln_bwd_finalize_sample_batch_kernel(const FinalizeArgs a) {
@@ -846,29 +747,22 @@ __global__ __launch_bounds__(256) void gln_bwd_finalize_sample_batch_kernel(cons
     const int b = (int)blockIdx.x - a.blk_start[sgi];
     const bool slopes = sg.nq == 8;
     const float* scratch = slopes ? sg.pextra + (size_t)sg.B * sg.C * 4 + sg.B : nullptr;
-    double sg1 = 0.0, sgx = 0.0, sal = 0.0, sal1 = 0.0;
+    double sg1 = 0.0, sgx = 0.0, sal = 0.0;
     for (int c = threadIdx.x; c < sg.C; c += 256) {
         const float gc = sg.gamma[c];
         sg1 += (double)(gc * sg.pbeta[(size_t)b * sg.C + c]);
         sgx += (double)(gc * sg.pgamma[(size_t)b * sg.C + c]);
-        if (slopes) {
-            sal += (double)scratch[(size_t)b * sg.C + c];
-            sal1 += (double)scratch[(size_t)sg.B * sg.C + sg.B + (size_t)b * sg.C + c];
-        }
+        if (slopes) sal += (double)scratch[(size_t)b * sg.C + c];
     }
     const double tg = block_sum_256<double>(sg1, red);
     const double tgx = block_sum_256<double>(sgx, red);
     const double tal = block_sum_256<double>(sal, red);
-    const double tal1 = block_sum_256<double>(sal1, red);
     if (threadIdx.x == 0) {
         if (sg.bsum) {
             sg.bsum[2 * b] = (float)(tg / sg.count);
             sg.bsum[2 * b + 1] = (float)(tgx / sg.count);
         }
-        if (slopes) {
-            sg.pextra[(size_t)sg.B * sg.C * 4 + b] = (float)tal;
-            sg.pextra[(size_t)sg.B * sg.C * 4 + sg.B + (size_t)sg.B * sg.C + b] = (float)tal1;
-        }
+        if (slopes) sg.pextra[(size_t)sg.B * sg.C * 4 + b] = (float)tal;
     }
 }
 
@@ -1444,87 +1338,30 @@ extern "C" int sep_dwconv_fwd(const float* a, const double* stats1, const float*
     return 0;
 }
 
-// workgroups of the DIRECT row kernel the device keeps resident at once (occupancy x compute units), per instance, asked once
-template <int DM, int NIT, bool RC>
-static long dwb_direct_capacity(size_t smem) {
-#ifdef SEP_HOSTSIM
-    (void)smem;
-    return 1L << 30;
-#else
-    static long cap = -1;
-    static size_t cap_smem = 0;
-    if (cap < 0 || cap_smem != smem) {
-        int per_cu = 0, dev = 0;
-        hipDeviceProp_t prop;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dwconv_bwd_row_kernel<DM, NIT, RC, true>, 256, smem) != hipSuccess ||
-            hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-        cap = (long)per_cu * prop.multiProcessorCount;
-        cap_smem = smem;
-    }
-    return cap;
-#endif
-}
-
-extern "C" int sep_sync_timeouts(int* out) {
-    SEP_REQUIRE(out, "sep_sync_timeouts: null pointer");
-#ifdef SEP_HOSTSIM
-    *out = g_sync_timeouts;
-#else
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sync_timeouts), sizeof(int)) != hipSuccess) { sep_set_error("sep_sync_timeouts: copy failed"); return -2; }
-#endif
-    return 0;
-}
-
-// Largest C (rows per sample) sep_dwconv_bwd takes with direct = 1 for rows of ldt frames on the current device (0: not at all):
-// half the resident capacity of the most demanding instance, so that a sample's rows always fit beside the sample in front of it.
-extern "C" int sep_dwconv_bwd_direct_max_rows(int ldt, int with_bd) {
-    if (ldt <= 0 || ldt % 128 != 0 || ldt > 8192 || getenv("SEPK_DWCONV_LDS") != nullptr) return 0;
-    const bool recomp = with_bd != 0 && !(getenv("SEPK_DWB_RECOMPUTE") != nullptr && atoi(getenv("SEPK_DWB_RECOMPUTE")) == 0);
-    const size_t rsmem = (size_t)ldt * sizeof(float) * (recomp ? 2 : 1);
-    long cap = 1L << 30;
-#define SEP_CAP(AL, NIT) do { const long c_ = recomp ? dwb_direct_capacity<AL, NIT, true>(rsmem) : dwb_direct_capacity<AL, NIT, false>(rsmem); cap = c_ < cap ? c_ : cap; } while (0)
-    if (ldt <= 4096) { SEP_CAP(0, 4); SEP_CAP(1, 4); SEP_CAP(2, 4); SEP_CAP(3, 4); }
-    else { SEP_CAP(0, 8); SEP_CAP(1, 8); SEP_CAP(2, 8); SEP_CAP(3, 8); }
-#undef SEP_CAP
-    return (int)(cap / 2 > 0x7fffffffL ? 0x7fffffffL : cap / 2);
-}
-
 extern "C" int sep_dwconv_bwd(const float* dv2, const float* z, const float* a, const double* stats1, const float* gamma1,
                               const float* beta1, const float* alpha1, const double* stats2, const float* gamma2,
                               const float* alpha2, const float* bsum2, const float* wd, const float* bd, float* dv1, float* rowpart,
-                              double* bacc1, int* arrive1, float* bsum1, int B, int C, int T, int ldt, int dilation, float eps, int direct,
-                              sep_stream_t stream) {
+                              double* bacc1, int* arrive1, float* bsum1, int B, int C, int T, int ldt, int dilation, float eps, sep_stream_t stream) {
     SEP_REQUIRE(dv2 && z && a && stats1 && gamma1 && beta1 && alpha1 && stats2 && gamma2 && alpha2 && bsum2 && wd && dv1 && rowpart, "sep_dwconv_bwd: null pointer");
-    SEP_REQUIRE(direct || ((arrive1 == nullptr) == (bsum1 == nullptr) && (bacc1 != nullptr || arrive1 == nullptr)), "sep_dwconv_bwd: arrive1 and bsum1 come together and need bacc1");
-    SEP_REQUIRE(!direct || (bacc1 && arrive1), "sep_dwconv_bwd: direct needs bacc1 and arrive1");
+    SEP_REQUIRE((arrive1 == nullptr) == (bsum1 == nullptr) && (bacc1 != nullptr || arrive1 == nullptr), "sep_dwconv_bwd: arrive1 and bsum1 come together and need bacc1");
     SEP_REQUIRE(B > 0 && C > 0 && T > 0 && ldt % 128 == 0 && ldt >= T, "sep_dwconv_bwd: bad sizes");
     SEP_REQUIRE(dilation >= 1 && dilation <= 2048, "sep_dwconv_bwd: dilation %d out of range [1, 2048]", dilation);
     static const bool force_tiles = getenv("SEPK_DWCONV_LDS") != nullptr;
     static const bool no_recompute = getenv("SEPK_DWB_RECOMPUTE") != nullptr && atoi(getenv("SEPK_DWB_RECOMPUTE")) == 0;
-    SEP_REQUIRE(!direct || (!force_tiles && ldt <= 8192 && (long)B * C <= 0x7fffffffL), "sep_dwconv_bwd: direct is a form of the row kernel (ldt <= 8192)");
     if (!force_tiles && ldt <= 8192 && (long)B * C <= 0x7fffffffL) {        // the row (ldt floats of LDS, ldt / 1024 float4 triples in registers)
         // with the depthwise bias at hand z is formed again from `a` instead of being read (two LDS rows): 3 streams of HBM instead of 4
         const bool recomp = bd != nullptr && !no_recompute;
         const size_t rsmem = (size_t)ldt * sizeof(float) * (recomp ? 2 : 1);
         const dim3 grid((unsigned)((long)B * C));
-        long capacity = -1;
-#define SEP_DWB(AL, NIT, RC, DI, PH) hipLaunchKernelGGL((dwconv_bwd_row_kernel<AL, NIT, RC, DI>), grid, dim3(256), rsmem, (hipStream_t)stream, dv2, z, bd, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bsum2, wd, dv1, rowpart, bacc1, arrive1, bsum1, C, T, ldt, dilation, eps, PH)
-#ifdef SEP_HOSTSIM
-#define SEP_DWBD(AL, NIT, RC) do { capacity = dwb_direct_capacity<AL, NIT, RC>(rsmem); SEP_DWB(AL, NIT, RC, true, 1); SEP_DWB(AL, NIT, RC, true, 2); } while (0)
-#else
-#define SEP_DWBD(AL, NIT, RC) do { capacity = dwb_direct_capacity<AL, NIT, RC>(rsmem); if (2L * C <= capacity) SEP_DWB(AL, NIT, RC, true, 0); } while (0)
-#endif
-#define SEP_DWB2(AL, NIT) do { if (direct) { if (recomp) SEP_DWBD(AL, NIT, true); else SEP_DWBD(AL, NIT, false); } \
-                               else if (recomp) SEP_DWB(AL, NIT, true, false, 0); else SEP_DWB(AL, NIT, false, false, 0); } while (0)
+#define SEP_DWB(AL, NIT, RC) hipLaunchKernelGGL((dwconv_bwd_row_kernel<AL, NIT, RC>), grid, dim3(256), rsmem, (hipStream_t)stream, dv2, z, bd, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bsum2, wd, dv1, rowpart, bacc1, arrive1, bsum1, C, T, ldt, dilation, eps)
+#define SEP_DWB2(AL, NIT) do { if (recomp) SEP_DWB(AL, NIT, true); else SEP_DWB(AL, NIT, false); } while (0)
         const int dm = dilation % 4 == 0 ? 0 : dilation <= 2 ? dilation : 3;
         if (dm == 0) { if (ldt <= 4096) SEP_DWB2(0, 4); else SEP_DWB2(0, 8); }
         else if (dm == 1) { if (ldt <= 4096) SEP_DWB2(1, 4); else SEP_DWB2(1, 8); }
         else if (dm == 2) { if (ldt <= 4096) SEP_DWB2(2, 4); else SEP_DWB2(2, 8); }
         else { if (ldt <= 4096) SEP_DWB2(3, 4); else SEP_DWB2(3, 8); }
 #undef SEP_DWB2
-#undef SEP_DWBD
 #undef SEP_DWB
-        SEP_REQUIRE(!direct || 2L * C <= capacity, "sep_dwconv_bwd: direct needs the %d rows of a sample resident together twice over (device capacity %ld workgroups)", C, capacity);
         SEP_CHECK_LAUNCH("sep_dwconv_bwd");
         return 0;
     }
@@ -1542,8 +1379,7 @@ extern "C" int sep_gln_bwd_finalize(const float* rowpart, int ntile, int nq, con
     SEP_REQUIRE(rowpart && stats && gamma && pbeta && pgamma, "sep_gln_bwd_finalize: null pointer");
     SEP_REQUIRE(nq == 2 || nq == 8, "sep_gln_bwd_finalize: nq must be 2 or 8 (got %d)", nq);
     SEP_REQUIRE(nq == 2 || pextra, "sep_gln_bwd_finalize: nq == 8 needs pextra");
-    // pextra layout for nq == 8: B slabs of 4C floats [db[C] | dw[C][3]], then palpha[B], then B*C floats of scratch, then the same pair
-    // for rowpart slot 7: palpha1[B], scratch1[B*C]   (B*4C + 2B + 2BC floats in all)
+    // pextra layout for nq == 8: B slabs of 4C floats [db[C] | dw[C][3]], then palpha[B], then B*C floats of scratch
     float* palpha = (nq == 8) ? pextra + (size_t)B * C * 4 : nullptr;
     float* scratch = (nq == 8) ? palpha + B : nullptr;
     const long rows = (long)B * C;

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("SEPKERNELS_LIB", os.path.normpath(os.path.join(_HERE,
 # ---- constants mirrored from include/sepkernels.h -------------------------------------------------
 PRO_NONE, PRO_PRELU, PRO_GLN, PRO_GLN_PRELU, PRO_GLN_BWD = 0, 1, 2, 3, 4
 EPI_STATS_PRELU, EPI_RESIDUAL, EPI_SIGMOID, EPI_PRELU_BWD, EPI_ROWSUMS, EPI_ROWSUMS_PRELU = 1, 2, 4, 8, 16, 32
-ABI_VERSION = 20
+ABI_VERSION = 19
 LSTM_INTERLEAVED = 0x400       # sep_lstm_fwd / sep_lstm_bwd with reverse = 2: h_out / dh_out as one (nseq, L, 2H) buffer
 STATS_SLOTS = 16   # SEP_STATS_SLOTS: gLN statistics are double[B][STATS_SLOTS][2]
 ARRIVE_INTS = 17   # SEP_ARRIVE_INTS: arrival counters of the gLN-backward publishers, int[B][ARRIVE_INTS]
@@ -119,9 +119,7 @@ SIGNATURES = {
     "sep_encoder_fwd": [_vp, _vp, _vp, _vp] + [_I] * 10 + [_vp],
     "sep_unfold": [_vp, _vp] + [_I] * 8 + [_vp],
     "sep_dwconv_fwd": [_vp] * 10 + [_I] * 5 + [_F, _vp],
-    "sep_dwconv_bwd": [_vp] * 18 + [_I] * 5 + [_F, _I, _vp],
-    "sep_dwconv_bwd_direct_max_rows": [_I, _I],
-    "sep_sync_timeouts": [ctypes.POINTER(ctypes.c_int)],
+    "sep_dwconv_bwd": [_vp] * 18 + [_I] * 5 + [_F, _vp],
     "sep_gln_bwd_finalize": [_vp, _I, _I, _vp, _vp, _D, _F, _vp, _vp, _vp, _vp, _I, _I, _vp],
     "sep_gln_bwd_finalize_batch": [ctypes.POINTER(FinalizeSeg), _I, _vp],
     "sep_gln_bwd_from_wgrad": [_vp] * 6 + [_D, _F] + [_vp] * 6 + [_I] * 6 + [_vp],
@@ -218,7 +216,6 @@ class HipBackend:
     arithmetic so that the host-side orchestration can be exercised without a GPU (test infrastructure only)."""
 
     name = "hip"
-    _direct_rows = {}
 
     def pw_gemm(self, *, B, M, K, T, ldt, A, X, Y, trans_a=0, A2=None, X2=None, k_split=0, Y2=None, m_split=0,
                 pro_mode=PRO_NONE, epi_flags=0, accumulate=0, eps=1e-12, count=0.0, bias=None, pro_alpha=None,
@@ -307,26 +304,13 @@ class HipBackend:
                                      _ptr(wd, _f32), _ptr(bd, _f32), _ptr(alpha2, _f32), _ptr(z, _f32), _ptr(stats2, _f64),
                                      B, C, T, ldt, dilation, eps, _stream()), "sep_dwconv_fwd")
 
-    def dwconv_bwd_direct_max_rows(self, ldt, with_bd=True):
-        """largest channel count sep_dwconv_bwd takes with direct=1 at this row length on the current device (0: never)"""
-        key = (torch.cuda.current_device() if torch.cuda.is_available() else -1, int(ldt), bool(with_bd), LIB_PATH if _lib is None else id(_lib))
-        if key not in self._direct_rows:
-            self._direct_rows[key] = int(load().sep_dwconv_bwd_direct_max_rows(int(ldt), int(bool(with_bd))))
-        return self._direct_rows[key]
-
-    def sync_timeouts(self):
-        """in-kernel waits that gave up since the library was loaded (0 on a healthy run); synchronises the device"""
-        n = ctypes.c_int(0)
-        _check(load().sep_sync_timeouts(ctypes.byref(n)), "sep_sync_timeouts")
-        return n.value
-
     def dwconv_bwd(self, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bsum2, wd, bd, dv1, rowpart, bacc1, arrive1, bsum1,
-                   B, C, T, ldt, dilation, eps, direct=0):
+                   B, C, T, ldt, dilation, eps):
         _check(load().sep_dwconv_bwd(_ptr(dv2, _f32), _ptr(z, _f32), _ptr(a, _f32), _ptr(stats1, _f64), _ptr(gamma1, _f32),
                                      _ptr(beta1, _f32), _ptr(alpha1, _f32), _ptr(stats2, _f64), _ptr(gamma2, _f32),
                                      _ptr(alpha2, _f32), _ptr(bsum2, _f32), _ptr(wd, _f32), _ptr(bd, _f32), _ptr(dv1, _f32), _ptr(rowpart, _f32), _ptr(bacc1, _f64),
                                      _ptr(arrive1, torch.int32), _ptr(bsum1, _f32),
-                                     B, C, T, ldt, dilation, eps, int(direct), _stream()), "sep_dwconv_bwd")
+                                     B, C, T, ldt, dilation, eps, _stream()), "sep_dwconv_bwd")
 
     def gln_bwd_finalize(self, rowpart, ntile, nq, stats, gamma, count, eps, bsum, pbeta, pgamma, pextra, B, C):
         _check(load().sep_gln_bwd_finalize(_ptr(rowpart, _f32), ntile, nq, _ptr(stats, _f64), _ptr(gamma, _f32), float(count), eps,

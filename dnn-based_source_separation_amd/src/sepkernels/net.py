@@ -498,10 +498,6 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
     dS, dwm = tail_backward(cfg, P, geo, w, skip, m, mixture.shape, d_est, G, dalpha[nl:nl + 1], PK)
 
     # ---- TCN layers, reversed -----------------------------------------------------------------------
-    # sep_dwconv_bwd direct = 1: the depthwise backward goes on through gLN1 / PReLU1 and writes da itself (a sample's rows wait for each other
-    # inside the kernel), conv1^T becomes a plain product on da: `a` is read once less and da written once less per layer.  Needs the H
-    # rows of a sample resident together (the library answers for the device at hand); SEPK_DWB_DIRECT=0 keeps the two-kernel form.
-    direct = os.environ.get("SEPK_DWB_DIRECT", "1") != "0" and 0 < H <= K.dwconv_bwd_direct_max_rows(ldt, True)
     side = _SideStream(dev)
     side.fork()   # dS exists
     # Every second-stage reduction of the layer loop (weight-gradient slabs, per-sample gLN/depthwise partials, PReLU
@@ -577,10 +573,10 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
         dv1 = torch.empty(B, H, ldt, **f32)
         rp1 = torch.empty(B, H, nt1024, 8, **f32)
         K.dwconv_bwd(dv2, z, a, st1, g1, b1, al1, st2, g2, al2, bsum[2 + 2 * li], P[sp + "depthwise_conv1d.weight"], P[sp + "depthwise_conv1d.bias"], dv1, rp1,
-                     bacc[1 + 2 * li], arrive[1 + 2 * li] if direct else None, None, B, H, F, ldt, dil, teps, direct=int(direct))
+                     bacc[1 + 2 * li], None, None, B, H, F, ldt, dil, teps)
         pbeta1 = torch.empty(B, H, **f32)
         pgamma1 = torch.empty(B, H, **f32)
-        pextra = torch.empty(B * 4 * H + 2 * B + 2 * B * H, **f32)
+        pextra = torch.empty(B * 4 * H + B + B * H, **f32)
         pending += [
             (pbeta2, 0, G[sp + "norm1d.norm.bias"], H, B, H, 0, 1.0),
             (pgamma2, 0, G[sp + "norm1d.norm.weight"], H, B, H, 0, 1.0),
@@ -590,23 +586,16 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
             (pextra, H, G[sp + "depthwise_conv1d.weight"], 3 * H, B, 4 * H, 0, 1.0),
             (pextra, B * 4 * H, G[sp + "nonlinear1d.weight"], 1, B, 1, 0, 1.0),
         ]
-        if direct:      # PReLU1's slope gradient comes out of the depthwise backward (rowpart slot 7 -> pextra's second slope block)
-            pending.append((pextra, B * 4 * H + B + B * H, G[pre + "nonlinear1d.weight"], 1, B, 1, 0, 1.0))
 
         # dx = W1^T da (+ dout through the residual); da = gLN1/PReLU1 backward of dv1, formed in the GEMM prologue
         dx = torch.empty(B, Bn, ldt, **f32)
         # da overwrites dv1 in place when a single row tile covers all outputs (each X element is then read once);
         # with several row tiles the other tiles still need the untouched dv1, so da goes to its own buffer
-        if direct:
-            da = dv1                                     # the depthwise backward wrote da there
-            K.pw_gemm(B=B, M=Bn, K=H, T=F, ldt=ldt, trans_a=1, A=P[pre + "bottleneck_conv1d.weight"], A_pk=PK.get("conv1.{}^T".format(li)),
-                      X=da, Y=dx, eps=teps, epi_flags=(EPI_RESIDUAL if dout is not None else 0), epi_res=dout)
-        else:
-            da = dv1 if Bn <= 128 else torch.empty_like(dv1)
-            K.pw_gemm(B=B, M=Bn, K=H, T=F, ldt=ldt, trans_a=1, A=P[pre + "bottleneck_conv1d.weight"], A_pk=PK.get("conv1.{}^T".format(li)),
-                      X=dv1, Y=dx, pro_mode=PRO_GLN_BWD, pro_stats=st1, pro_gamma=g1, pro_alpha=al1, pro_aux=a, pro_bacc=bacc[1 + 2 * li],
-                      pro_store=da, pro_dalpha=dalpha[li:li + 1], count=cnt, eps=teps,
-                      epi_flags=(EPI_RESIDUAL if dout is not None else 0), epi_res=dout)
+        da = dv1 if Bn <= 128 else torch.empty_like(dv1)
+        K.pw_gemm(B=B, M=Bn, K=H, T=F, ldt=ldt, trans_a=1, A=P[pre + "bottleneck_conv1d.weight"], A_pk=PK.get("conv1.{}^T".format(li)),
+                  X=dv1, Y=dx, pro_mode=PRO_GLN_BWD, pro_stats=st1, pro_gamma=g1, pro_alpha=al1, pro_aux=a, pro_bacc=bacc[1 + 2 * li],
+                  pro_store=da, pro_dalpha=dalpha[li:li + 1], count=cnt, eps=teps,
+                  epi_flags=(EPI_RESIDUAL if dout is not None else 0), epi_res=dout)
         # da and dx now exist: the side stream may go on (this layer's dW1, the next layer's head gradients)
         side.fork()
         side.keep(da, dx, rp1, pbeta1, pgamma1, pextra)
@@ -639,8 +628,7 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
             lo = li
             d32 = torch.empty(hi - lo, **f32)
             K.f64_to_f32(dalpha[lo:hi], d32, hi - lo, 0)
-            if not direct:
-                pending += [(d32, q - lo, G[layers[q][0] + "nonlinear1d.weight"], 1, 1, 1, 0, 1.0) for q in range(lo, min(hi, nl))]
+            pending += [(d32, q - lo, G[layers[q][0] + "nonlinear1d.weight"], 1, 1, 1, 0, 1.0) for q in range(lo, min(hi, nl))]
             if hi == nl + 1:
                 pending.append((d32, nl - lo, G["separator.prelu.weight"], 1, 1, 1, 0, 1.0))
             K.gln_bwd_finalize_batch(finals)
@@ -657,8 +645,7 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
     rest = flushed_from if on_ready is not None else nl + 1
     dal32 = torch.empty(rest, **f32)
     K.f64_to_f32(dalpha[:rest], dal32, rest, 0)
-    if not direct:
-        pending += [(dal32, li, G[layers[li][0] + "nonlinear1d.weight"], 1, 1, 1, 0, 1.0) for li in range(min(rest, nl))]
+    pending += [(dal32, li, G[layers[li][0] + "nonlinear1d.weight"], 1, 1, 1, 0, 1.0) for li in range(min(rest, nl))]
     if rest == nl + 1:
         pending.append((dal32, nl, G["separator.prelu.weight"], 1, 1, 1, 0, 1.0))
     if finals:

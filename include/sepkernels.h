@@ -33,7 +33,7 @@ extern "C" {
 
 typedef void* sep_stream_t; /* hipStream_t */
 
-#define SEP_ABI_VERSION 20
+#define SEP_ABI_VERSION 19
 #define SEP_STATS_SLOTS 16
 #define SEP_ARRIVE_INTS 17 /* arrival counters per sample: one per slot + one for the slots (csrc/common.hpp, gln_bwd_publish) */
 
@@ -217,28 +217,14 @@ int sep_dwconv_fwd(const float* a, const double* stats1, const float* gamma1, co
  * consumer forms the means from them: sep_gemm_desc.pro_bacc -- what the Conv-TasNet step uses, this kernel has thousands of short
  * workgroups and the arrival protocol's two waited-for round trips cost it 10 us per launch); all three NULL: none of it.
  * Writes dv1 and, per (b, c, 1024-frame tile), 8 partial row sums into rowpart[b][c][ntile][8]:
- *   {sum dv1, sum dv1*u1, sum dz, sum dz*v1[t-d], sum dz*v1[t], sum dz*v1[t+d], sum du2*z*[z<=0], 0 (direct: sum du1*a*[a<=0])}
+ *   {sum dv1, sum dv1*u1, sum dz, sum dz*v1[t-d], sum dz*v1[t], sum dz*v1[t+d], sum du2*z*[z<=0], 0}
  * (u1 = PReLU(a), v1 = gLN1(u1) inside [0,T) and 0 outside; ntile = ceil(ldt/1024)).
  * bd (the depthwise bias, may be NULL): with it the kernel forms z = bd + depthwise(v1) again from `a`, which it reads anyway, instead of
- * reading z -- three streams of HBM instead of four (rows of up to 8192 frames; longer rows and bd = NULL read z).
- * direct = 1 (ABI 20): the kernel goes on through gLN1 and PReLU1 and writes, where it wrote dv1,
- *     da = r1 (gamma1 dv1 - mg1 - xhat1 mgx1) PReLU1'(a),     mg1 / mgx1 = mean(gamma1 dv1), mean(gamma1 dv1 xhat1) over the SAMPLE,
- * i.e. the gradient at the conv1 output (tdcn.py:98-100 backward): the conv1^T product behind it is then a plain GEMM on da and the conv1
- * weight gradient reads the same tensor -- `a` is not read a second time and da is not written a second time (268 MB less HBM traffic
- * per layer at the paper-best shapes).  A row's workgroup keeps dv1 in registers, adds its sums to bacc1, counts itself in arrive1 (both
- * required, zeroed by the caller; bsum1 is not used) and WAITS for the sample's other rows: the C workgroups of a sample must be resident
- * together -- C <= sep_dwconv_bwd_direct_max_rows(ldt, bd != NULL), else the call fails -- and rowpart slot 7 becomes sum du1*a*[a<=0], the
- * partial of d(alpha1).  A wait that never ends (another process holding the compute units) gives up after ~1 s and counts itself in
- * sep_sync_timeouts instead of hanging the device. */
+ * reading z -- three streams of HBM instead of four (rows of up to 8192 frames; longer rows and bd = NULL read z). */
 int sep_dwconv_bwd(const float* dv2, const float* z, const float* a, const double* stats1, const float* gamma1,
                    const float* beta1, const float* alpha1, const double* stats2, const float* gamma2,
                    const float* alpha2, const float* bsum2, const float* wd, const float* bd, float* dv1, float* rowpart,
-                   double* bacc1, int* arrive1, float* bsum1, int B, int C, int T, int ldt, int dilation, float eps, int direct,
-                   sep_stream_t stream);
-/* largest C for direct = 1 on the current device and row length (0: never) */
-int sep_dwconv_bwd_direct_max_rows(int ldt, int with_bd);
-/* *out = number of in-kernel waits that gave up since the library was loaded (sep_dwconv_bwd direct); synchronises the device */
-int sep_sync_timeouts(int* out);
+                   double* bacc1, int* arrive1, float* bsum1, int B, int C, int T, int ldt, int dilation, float eps, sep_stream_t stream);
 
 /* Second stage of every gLN backward (Appendix A of SURVEY.md).  rowpart is [B][C][ntile][nq], nq in {2, 8}:
  *   R1 = sum_tiles rowpart[..][0], R2 = sum_tiles rowpart[..][1]
@@ -246,11 +232,10 @@ int sep_sync_timeouts(int* out);
  *   bsum[b] = { sum_c gamma_c*R1 / count , sum_c gamma_c*pgamma[b][c] / count }     (bsum may be NULL: inside the TCN layers of the fused
  *             Conv-TasNet path the producers publish these means themselves -- sep_dwconv_bwd's bsum1, sep_gln_bwd_from_wgrad's bsum -- and
  *             this kernel only forms the parameter gradients, off the critical path)
- *   nq == 8 additionally (pextra holds B*C*4 + 2*B + 2*B*C floats: [slabs B*4C | palpha B | scratch B*C | palpha1 B | scratch1 B*C]):
+ *   nq == 8 additionally (pextra holds B*C*4 + B + B*C floats; the last B*C are scratch):
  *     pextra[b*4C + c]           = sum_tiles rowpart[..][2]      (depthwise bias gradient, per sample)
  *     pextra[b*4C + C + 3c + k]  = sum_tiles rowpart[..][3+k]    (depthwise weight gradient [C][3], per sample)
- *     pextra[B*4C + b]           = sum_{c,tiles} rowpart[..][6]  (PReLU slope gradient, per sample)
- *     pextra[B*4C + B + B*C + b] = sum_{c,tiles} rowpart[..][7]  (ABI 20: slope gradient of the PReLU in front of the gLN, sep_dwconv_bwd direct) */
+ *     pextra[B*4C + b]           = sum_{c,tiles} rowpart[..][6]  (PReLU slope gradient, per sample) */
 int sep_gln_bwd_finalize(const float* rowpart, int ntile, int nq, const double* stats, const float* gamma, double count,
                          float eps, float* bsum, float* pbeta, float* pgamma, float* pextra, int B, int C,
                          sep_stream_t stream);

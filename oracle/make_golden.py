@@ -293,6 +293,55 @@ def dprnn_full_golden(NegSISDR, PIT1d):
     print("dprnn full: params", model.num_parameters, "loss", loss64.item(), "pattern", pattern.tolist())
 
 
+
+# BASELINE.json configs[1] at its real batch (paper-best Conv-TasNet, 16 utterances of 4 s): the REFERENCE in fp64, once, here -- the GPU
+# box has no reference and its fp64 port of this batch takes minutes.  What is stored: per-utterance output fingerprints (norm, largest
+# magnitude, 64 samples per source), per-utterance and batch PIT loss, permutations, and a fingerprint of every parameter gradient (norm,
+# largest magnitude, 64 samples; scalars whole).  The 5 M parameters are not stored: default init under the seed + the perturbation below
+# (the product's class draws the same values; tests check the parameter fingerprints first).
+PAPER_CFG = dict(n_basis=512, kernel_size=16, stride=8, enc_basis="trainable", dec_basis="trainable", enc_nonlinear=None,
+                 sep_hidden_channels=512, sep_bottleneck_channels=128, sep_skip_channels=128, sep_kernel_size=3, sep_num_blocks=3,
+                 sep_num_layers=8, dilated=True, separable=True, causal=False, sep_nonlinear="prelu", sep_norm=True,
+                 mask_nonlinear="sigmoid", n_sources=2)
+PAPER_B16_SEEDS = {"model": 111, "data": 5}
+
+
+def paper_b16_inputs(model):
+    """the batch and the parameter perturbation of tests/test_gpu_model.py::test_batch16_* (one generator, in this order)"""
+    g = torch.Generator().manual_seed(PAPER_B16_SEEDS["data"])
+    with torch.no_grad():
+        for n, q in model.named_parameters():
+            if n.endswith("norm.weight") or n.endswith("norm.bias"):
+                q.add_(0.1 * torch.randn(q.shape, generator=g))
+    sources = 0.1 * torch.randn(16, 2, 32000, generator=g) * torch.exp(0.7 * torch.randn(16, 2, 1, generator=g))     # utterances / speakers of different level
+    return sources.sum(1, keepdim=True), sources
+
+
+def paper_b16_golden(ConvTasNet, NegSISDR, PIT1d):
+    import time
+    torch.manual_seed(PAPER_B16_SEEDS["model"])
+    model = ConvTasNet(**PAPER_CFG)
+    mixture, sources = paper_b16_inputs(model)
+    blob = {"mixture_head": mixture.numpy()[:, 0, :8].copy()}
+    for k, v in model.state_dict().items():
+        blob["pfp/" + k] = np.array([v.double().sum().item(), v.double().abs().sum().item()])
+    t0 = time.time()
+    m64 = model.double()
+    out64 = m64(mixture.double())
+    crit = PIT1d(NegSISDR(), n_sources=2)
+    loss64, pattern = crit(out64, sources.double())
+    per_utt, _ = crit(out64.detach(), sources.double(), batch_mean=False)
+    loss64.backward()
+    o = out64.detach()
+    idx = sample_index(32000)
+    blob.update({"loss_f64": np.array(loss64.item()), "per_utt_f64": per_utt.numpy(), "pattern": pattern.numpy(),
+                 "out_norm": o.norm(dim=2).numpy(), "out_amax": o.abs().amax(dim=2).numpy(), "out_idx": np.array(idx), "out_samples": o[:, :, idx].numpy()})
+    for k, p in m64.named_parameters():
+        gr = p.grad.reshape(-1)
+        blob["gfp/" + k] = np.concatenate([[gr.norm().item(), gr.abs().max().item()], gr[sample_index(gr.numel())].numpy()])
+    np.savez_compressed(os.path.join(OUT, "convtasnet_paper_b16.npz"), **blob)
+    print("paper-best B=16 fp64 reference: loss", loss64.item(), "in {:.0f} s".format(time.time() - t0))
+
 # DPTNet / GALRNet / SepFormer (SURVEY.md section 8 row f4): small configurations, channel counts in multiples of 16 so that the
 # product runs them on its kernel path, plus one with odd widths (composition path).  403 samples -> 201 frames: both the
 # waveform padding and the chunk padding (1 frame left, 2 right) are exercised.
@@ -396,4 +445,6 @@ if __name__ == "__main__":
         dprnn_golden(NegSISDR, PIT1d)
     if not only or "dprnn_full" in only:
         dprnn_full_golden(NegSISDR, PIT1d)
+    if not only or "paper_b16" in only:
+        paper_b16_golden(ConvTasNet, NegSISDR, PIT1d)
     print("golden vectors written to", OUT)

@@ -296,14 +296,8 @@ class EmuBackend:
         u = _prelu(zz, alpha2)
         _acc(stats2, u.sum((1, 2)), (u * u).sum((1, 2)))
 
-    def dwconv_bwd_direct_max_rows(self, ldt, with_bd=True):
-        return 1 << 20 if ldt <= 8192 else 0
-
-    def sync_timeouts(self):
-        return 0
-
     def dwconv_bwd(self, dv2, z, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bsum2, wd, bd, dv1, rowpart, bacc1, arrive1, bsum1,
-                   B, C, T, ldt, dilation, eps, direct=0):
+                   B, C, T, ldt, dilation, eps):
         dt = a.dtype
         d = dilation
         cnt = float(C * T)
@@ -340,19 +334,7 @@ class EmuBackend:
         rp[:, :, 0, 4] = (dz * v1).sum(2)
         rp[:, :, 0, 5] = (dz * v1p[:, :, 2 * d:2 * d + T]).sum(2)
         rp[:, :, 0, 6] = dal
-        if direct:
-            # sep_dwconv_bwd direct = 1: on through gLN1 and PReLU1; the sample means from THIS call's sums (bacc1 receives them as well)
-            g1 = gamma1.view(1, C, 1).to(dt)
-            s1, s2 = (g1 * dv).sum((1, 2)), (g1 * dv * u1).sum((1, 2))
-            _acc(bacc1, s1, s2)
-            arrive1.reshape(B, -1)[:, 0] += C
-            mg = (s1 / cnt).view(B, 1, 1)
-            mgx = (r1.view(B) * (s2 - mu1.view(B) * s1) / cnt).view(B, 1, 1)
-            xh1 = (u1 - mu1) * r1
-            du1 = r1 * (g1 * dv - mg - xh1 * mgx)
-            out[:, :, :T] = du1 * _prelu_grad(aa, alpha1)
-            rp[:, :, 0, 7] = torch.where(aa <= 0, du1 * aa, torch.zeros_like(aa)).sum(2)
-        elif bacc1 is not None:
+        if bacc1 is not None:
             g1 = gamma1.view(1, C, 1).to(dt)
             _acc(bacc1, (g1 * dv).sum((1, 2)), (g1 * dv * u1).sum((1, 2)))
             if arrive1 is not None:
@@ -376,9 +358,6 @@ class EmuBackend:
             slab[:, C:] = rp[..., 3:6].reshape(B, 3 * C)
             pe[B * 4 * C:B * 4 * C + B] = rp[..., 6].sum(1)
             pe[B * 4 * C + B:B * 4 * C + B + B * C] = rp[..., 6].reshape(-1)      # per-row scratch of the two-kernel finalize
-            o1 = B * 4 * C + B + B * C
-            pe[o1:o1 + B] = rp[..., 7].sum(1)                                      # slot 7: slope partial of the PReLU in front of the gLN
-            pe[o1 + B:o1 + B + B * C] = rp[..., 7].reshape(-1)
 
     def gln_bwd_finalize_batch(self, segs):
         for sg in segs:

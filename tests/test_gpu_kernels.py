@@ -681,32 +681,6 @@ def test_dwconv_fwd_bwd(T, d):
         HIP.dwconv_bwd(*g2_)
         device_sync()
         assert (args[DV1] - g2_[DV1].cpu()).abs().max() <= 2e-4 * args[DV1].abs().max()
-    # direct = 1: the kernel goes on through gLN1 / PReLU1 (a sample's rows wait for each other) and writes da; rowpart slot 7 = d(alpha1) partial
-    dargs = list(args)
-    dargs[DV1], dargs[RP], dargs[BACC], dargs[ARR], dargs[BSUM] = nan(B, C, ldt), nan(B, C, ntile, 8), zstats(B), torch.zeros(B, 17, dtype=torch.int32), None
-    EMU.dwconv_bwd(*dargs, direct=1)
-    # the emulator's direct form against the two-step form it replaces: GLN_BWD prologue semantics on the dv1 / sums of the plain call
-    cnt = float(C * T)
-    mu1, r1 = (v.view(B, 1, 1) for v in __import__("emulator")._mu_rstd(st1, cnt, 1e-12, a.dtype))
-    mg = (bc[:, 0] / cnt).view(B, 1, 1).float()
-    mgx = (r1.view(B).double() * (bc[:, 1] - mu1.view(B).double() * bc[:, 0]) / cnt).view(B, 1, 1).float()
-    du1 = r1 * (g1.view(1, C, 1) * args[DV1][:, :, :T] - mg - (u1[:, :, :T] - mu1) * r1 * mgx)
-    da_ref = du1 * torch.where(a[:, :, :T] > 0, torch.ones(()), a1)
-    assert (dargs[DV1][:, :, :T] - da_ref).abs().max() <= 1e-5 * da_ref.abs().max()
-    assert dargs[DV1][:, :, T:].abs().max() == 0
-    dal_ref = torch.where(a[:, :, :T] <= 0, du1 * a[:, :, :T], torch.zeros(())).sum(2)
-    assert (dargs[RP][:, :, :, 7].sum(2) - dal_ref).abs().max() <= 1e-5 * dal_ref.abs().max()
-    assert HIP.dwconv_bwd_direct_max_rows(ldt, True) >= C
-    for bias in (bd, None):
-        gd = [to_device(v) if torch.is_tensor(v) else v for v in dargs[:12] + [bias, nan(B, C, ldt), nan(B, C, ntile, 8), zstats(B), torch.zeros(B, 17, dtype=torch.int32), None] + dargs[18:]]
-        HIP.dwconv_bwd(*gd, direct=1)
-        device_sync()
-        assert torch.isfinite(gd[DV1]).all() and torch.isfinite(gd[RP]).all()
-        assert (dargs[DV1] - gd[DV1].cpu()).abs().max() <= 2e-4 * dargs[DV1].abs().max()
-        assert (dargs[RP].double().sum(2) - gd[RP].cpu().double().sum(2)).abs().max() <= 3e-4 * dargs[RP].double().sum(2).abs().max()
-        assert (gd[BACC].cpu().sum(1) - bc).abs().max() <= 3e-4 * bc.abs().max()
-        assert bool((gd[ARR].cpu()[:, :16].sum(1) == C).all())              # every row arrived exactly once
-    assert HIP.sync_timeouts() == 0
 
 
 @pytest.mark.parametrize("Kw,stride,pad,dil,Tin", [(3, 1, 1, 1, 300), (5, 2, 4, 2, 257), (4, 4, 0, 1, 64), (3, 1, 8, 8, 1000), (16, 8, 0, 1, 403)])
@@ -728,7 +702,7 @@ def test_gln_bwd_finalize(nq, ntile):
     rp = rnd(B, C, ntile, nq)
     x = rnd(B, C, 50)
     st = stats_of(x, 50)
-    pextra = nan(B * 4 * C + 2 * B + 2 * B * C) if nq == 8 else None
+    pextra = nan(B * 4 * C + B + B * C) if nq == 8 else None
     both("gln_bwd_finalize", [rp, ntile, nq, st, rnd(C) + 1, C * 50.0, 1e-12, nan(B, 2), nan(B, C), nan(B, C), pextra, B, C])
     both("gln_bwd_finalize", [rp, ntile, nq, st, rnd(C) + 1, C * 50.0, 1e-12, None, nan(B, C), nan(B, C), pextra, B, C])      # without the means
 
@@ -739,7 +713,7 @@ def test_gln_bwd_finalize_batch():
     def seg(B, C, ntile, nq, with_bsum):
         x = rnd(B, C, 50)
         return [rnd(B, C, ntile, nq), ntile, nq, stats_of(x, 50), rnd(C) + 1, C * 50.0, 1e-12, nan(B, 2) if with_bsum else None, nan(B, C), nan(B, C),
-                nan(B * 4 * C + 2 * B + 2 * B * C) if nq == 8 else None, B, C]
+                nan(B * 4 * C + B + B * C) if nq == 8 else None, B, C]
     # rows of 32, 16, 8, 128 floats (several rows per wave), 24 (not a power of two of float4s: a wave per row) and 256 (a whole wave of float4s)
     segs = [seg(3, 96, 4, 8, False), seg(2, 40, 8, 2, True), seg(1, 130, 1, 8, True), seg(4, 16, 64, 2, False), seg(2, 33, 3, 8, True), seg(1, 9, 32, 8, False)]
     gsegs = [[to_device(v) if torch.is_tensor(v) else v for v in sg] for sg in segs]
@@ -751,10 +725,9 @@ def test_gln_bwd_finalize_batch():
             if sg[i] is None:
                 continue
             c, g = sg[i], gg[i].cpu()
-            if i == 10:                      # [slabs | palpha | scratch B*C | palpha1 | scratch1 B*C]: the scratch blocks belong to the two-stage form
+            if i == 10:                      # the trailing B*C floats are scratch of the two-stage form
                 n = sg[11] * 4 * sg[12] + sg[11]
-                o1 = n + sg[11] * sg[12]
-                c, g = torch.cat([c[:n], c[o1:o1 + sg[11]]]), torch.cat([g[:n], g[o1:o1 + sg[11]]])
+                c, g = c[:n], g[:n]
             assert torch.isfinite(g).all(), i
             assert (c.double() - g.double()).abs().max() <= 2e-4 * c.double().abs().max() + 1e-30, i
 

@@ -94,7 +94,7 @@ def build(workdir, sanitize=None):
         cpp = os.path.join(workdir, f + ".cpp")
         open(cpp, "w").write(host_copy(f + ".hip"))
         objs.append(os.path.join(workdir, f + ".o"))
-        procs.append(subprocess.Popen([cxx, "-std=c++17", "-O1", "-fPIC", "-pthread", "-DSEP_HOSTSIM"] + san + ["-I", workdir, "-I", inc, "-I", CSRC, "-c", cpp, "-o", objs[-1]]))
+        procs.append(subprocess.Popen([cxx, "-std=c++17", "-O1", "-fPIC", "-pthread"] + san + ["-I", workdir, "-I", inc, "-I", CSRC, "-c", cpp, "-o", objs[-1]]))
     for pr in procs:
         if pr.wait() != 0:
             raise RuntimeError("hostsim: compiling a kernel file for the host failed")

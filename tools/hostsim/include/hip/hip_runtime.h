@@ -125,7 +125,6 @@ static inline double atomicAdd(double* p, double v) {
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __hip_atomic_load(p, order, scope) (*(p))
-#define __hip_atomic_fetch_add(p, v, order, scope) atomicAdd((p), (v))
 static inline float unsafeAtomicAdd(float* p, float v) { return atomicAdd(p, v); }          // the hardware fp32 atomic of the device build
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
