@@ -113,3 +113,21 @@ def test_fast_port_matches_reference_and_algebra_oracle(golden_dir, name):
     for k, gr in grads.items():
         r = torch.from_numpy(g["grad/" + k]).double()
         assert (gr - r).abs().max() <= 2e-6 * r.abs().max() + 1e-12, k
+
+
+def test_paper_b16_fixture_parameters_are_reproducible_here():
+    """tests/golden/convtasnet_paper_b16.npz stores no parameters: the GPU test rebuilds them from the seeds with the PRODUCT's class.  Here
+    (no GPU): that construction reproduces the reference's parameter fingerprints and input head, i.e. the fixture can be used at all."""
+    import numpy as np
+    from oracle.make_golden import PAPER_CFG, PAPER_B16_SEEDS, paper_b16_inputs
+    from models.conv_tasnet import ConvTasNet
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "convtasnet_paper_b16.npz"))
+    torch.manual_seed(PAPER_B16_SEEDS["model"])
+    model = ConvTasNet(**PAPER_CFG)
+    mixture, sources = paper_b16_inputs(model)
+    assert np.array_equal(mixture.numpy()[:, 0, :8], fx["mixture_head"])
+    for k, v in model.state_dict().items():
+        got = np.array([v.double().sum().item(), v.double().abs().sum().item()])
+        assert np.allclose(got, fx["pfp/" + k], rtol=1e-9, atol=1e-12), k
+    assert fx["pattern"].shape == (16, 2) and fx["per_utt_f64"].shape == (16,)
+    assert len([k for k in fx.files if k.startswith("gfp/")]) == len(list(model.parameters()))
