@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="utterances per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default: 16 for the Conv-TasNet configs, the recipe's batch size for the dual-path ones)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-f32-pass", action="store_true")
@@ -132,6 +132,8 @@ def main():
     args = ap.parse_args()
     if args.config in ("dprnn", "dptnet", "galrnet", "sepformer"):
         return legs.bench_dual_path(args)
+    if args.batch is None:
+        args.batch = PER_GPU_BATCH
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus))

@@ -17,15 +17,19 @@ namespace {
 constexpr int CLN_TCOLS = 64;        // frames per column-sum block (one lane each), 4 waves share the channels
 
 // ws[b][0][t], ws[b][1][t] <- the two column sums of frame t
+// alpha (may be NULL): the single slope of a PReLU in front of the norm -- the kernels then normalise u = PReLU(x; alpha) and read / write
+// x itself (reference tdcn.py:113-116, 182-186: nonlinear1d then norm1d), one H-tensor round trip less than a stand-alone activation
 template <bool BWD>
 __global__ __launch_bounds__(256) void cln_colsums_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ gamma,
-                                                          const float* __restrict__ mean, double* __restrict__ ws, int C, int T, int ldt) {
+                                                          const float* __restrict__ mean, const float* __restrict__ alpha, double* __restrict__ ws, int C, int T, int ldt) {
     __shared__ float red[2][4][CLN_TCOLS];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int b = blockIdx.y, t = blockIdx.x * CLN_TCOLS + lane;
     const bool live = t < T;
     const size_t base = (size_t)b * C * ldt + (live ? t : 0);
     const float m = BWD && live ? mean[(size_t)b * T + t] : 0.f;
+    const bool act = alpha != nullptr;
+    const float al = act ? alpha[0] : 1.f;
     float s0 = 0.f, s1 = 0.f;
     for (int c = w; c < C; c += 16) {                   // four rows per trip and wave: independent loads in flight
         float xv[4], gv[4];
@@ -33,6 +37,7 @@ __global__ __launch_bounds__(256) void cln_colsums_kernel(const float* __restric
         for (int q = 0; q < 4; ++q) {
             const int cc = c + 4 * q;
             xv[q] = cc < C ? x[base + (size_t)cc * ldt] : 0.f;
+            if (act) xv[q] = prelu_f(xv[q], al);
             gv[q] = BWD && cc < C ? g[base + (size_t)cc * ldt] * gamma[cc] : 0.f;
         }
 #pragma unroll
@@ -133,11 +138,14 @@ __global__ __launch_bounds__(1024) void cln_scan_bwd_kernel(double* __restrict__
 
 // one wave per row (b, c): 256 frames per trip
 __global__ __launch_bounds__(256) void cln_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y, int C, int T, int ldt) {
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ alpha,
+                                                            float* __restrict__ y, int C, int T, int ldt) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 4 + w, b = blockIdx.y;
     if (c >= C) return;
     const float ga = gamma[c], be = beta[c];
+    const bool act = alpha != nullptr;
+    const float al = act ? alpha[0] : 1.f;
     const size_t row = ((size_t)b * C + c) * ldt;
     for (int t = 4 * lane; t < ldt; t += 256) {
         const float4 xv = *reinterpret_cast<const float4*>(x + row + t);
@@ -146,25 +154,28 @@ __global__ __launch_bounds__(256) void cln_apply_fwd_kernel(const float* __restr
         for (int e = 0; e < 4; ++e) {
             const bool live = t + e < T;
             const float m = live ? mean[(size_t)b * T + t + e] : 0.f, r = live ? rstd[(size_t)b * T + t + e] : 0.f;
-            o[e] = live ? (xs[e] - m) * r * ga + be : 0.f;
+            const float u = act ? prelu_f(xs[e], al) : xs[e];
+            o[e] = live ? (u - m) * r * ga + be : 0.f;
         }
         *reinterpret_cast<float4*>(y + row + t) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 
 __global__ __launch_bounds__(256) void cln_apply_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            const double* __restrict__ ws, const float* __restrict__ gamma, float* __restrict__ dx,
-                                                            float* __restrict__ dgamma_part, float* __restrict__ dbeta_part, int C, int T, int ldt) {
+                                                            const double* __restrict__ ws, const float* __restrict__ gamma, const float* __restrict__ alpha, float* __restrict__ dx,
+                                                            float* __restrict__ dgamma_part, float* __restrict__ dbeta_part, float* __restrict__ dalpha_part, int C, int T, int ldt) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 4 + w, b = blockIdx.y;
     if (c >= C) return;
     const float ga = gamma[c];
+    const bool act = alpha != nullptr;
+    const float al = act ? alpha[0] : 1.f;
     const size_t row = ((size_t)b * C + c) * ldt;
-    double sg = 0.0, sb = 0.0;
+    double sg = 0.0, sb = 0.0, sa = 0.0;
     for (int t = 4 * lane; t < ldt; t += 256) {
         const float4 xv = *reinterpret_cast<const float4*>(x + row + t), gv = *reinterpret_cast<const float4*>(g + row + t);
         float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w}, o[4];
-        float pg = 0.f, pb = 0.f;
+        float pg = 0.f, pb = 0.f, pa = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const bool live = t + e < T;
@@ -172,43 +183,51 @@ __global__ __launch_bounds__(256) void cln_apply_bwd_kernel(const float* __restr
             const float m = live ? mean[k] : 0.f, r = live ? rstd[k] : 0.f;
             const float P = live ? (float)ws[((size_t)b * 2 + 0) * T + t + e] : 0.f, Q = live ? (float)ws[((size_t)b * 2 + 1) * T + t + e] : 0.f;
             const float gl = live ? gs[e] : 0.f;
-            o[e] = live ? gl * ga * r + P + 2.f * xs[e] * Q : 0.f;
-            pg += gl * (xs[e] - m) * r;
+            const float u = act ? prelu_f(xs[e], al) : xs[e];
+            const float du = live ? gl * ga * r + P + 2.f * u * Q : 0.f;
+            o[e] = act ? du * prelu_grad(xs[e], al) : du;
+            if (act && xs[e] <= 0.f) pa = fmaf(du, xs[e], pa);
+            pg += gl * (u - m) * r;
             pb += gl;
         }
         sg += (double)pg;
         sb += (double)pb;
+        sa += (double)pa;
         *reinterpret_cast<float4*>(dx + row + t) = make_float4(o[0], o[1], o[2], o[3]);
     }
     sg = wave_sum(sg);
     sb = wave_sum(sb);
+    if (act) sa = wave_sum(sa);
     if (lane == 0) {
         dgamma_part[(size_t)b * C + c] = (float)sg;
         dbeta_part[(size_t)b * C + c] = (float)sb;
+        if (act) dalpha_part[(size_t)b * C + c] = (float)sa;
     }
 }
 
 }  // namespace
 
 extern "C" int sep_cln_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, double* ws,
-                           int B, int C, int T, int ldt, float eps, sep_stream_t stream_) {
+                           int B, int C, int T, int ldt, float eps, const float* alpha, sep_stream_t stream_) {
     SEP_REQUIRE(x && gamma && beta && y && mean && rstd && ws && B > 0 && B <= 65535 && C > 0 && T > 0 && ldt >= T && ldt % 4 == 0, "sep_cln_fwd: bad arguments");
     hipStream_t stream = (hipStream_t)stream_;
-    hipLaunchKernelGGL((cln_colsums_kernel<false>), dim3(ceil_div(T, CLN_TCOLS), B), dim3(256), 0, stream, x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, ws, C, T, ldt);
+    hipLaunchKernelGGL((cln_colsums_kernel<false>), dim3(ceil_div(T, CLN_TCOLS), B), dim3(256), 0, stream, x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, alpha, ws, C, T, ldt);
     hipLaunchKernelGGL(cln_scan_fwd_kernel, dim3(B), dim3(1024), 0, stream, (const double*)ws, mean, rstd, C, T, eps);
-    hipLaunchKernelGGL(cln_apply_fwd_kernel, dim3(ceil_div(C, 4), B), dim3(256), 0, stream, x, (const float*)mean, (const float*)rstd, gamma, beta, y, C, T, ldt);
+    hipLaunchKernelGGL(cln_apply_fwd_kernel, dim3(ceil_div(C, 4), B), dim3(256), 0, stream, x, (const float*)mean, (const float*)rstd, gamma, beta, alpha, y, C, T, ldt);
     SEP_CHECK_LAUNCH("sep_cln_fwd");
     return 0;
 }
 
 extern "C" int sep_cln_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
-                           float* dgamma_part, float* dbeta_part, double* ws, int B, int C, int T, int ldt, float eps, sep_stream_t stream_) {
+                           float* dgamma_part, float* dbeta_part, double* ws, int B, int C, int T, int ldt, float eps, const float* alpha,
+                           float* dalpha_part, sep_stream_t stream_) {
     SEP_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma_part && dbeta_part && ws && B > 0 && B <= 65535 && C > 0 && T > 0 && ldt >= T && ldt % 4 == 0,
                 "sep_cln_bwd: bad arguments");
+    SEP_REQUIRE((alpha == nullptr) == (dalpha_part == nullptr), "sep_cln_bwd: alpha and dalpha_part come together");
     hipStream_t stream = (hipStream_t)stream_;
-    hipLaunchKernelGGL((cln_colsums_kernel<true>), dim3(ceil_div(T, CLN_TCOLS), B), dim3(256), 0, stream, x, dy, gamma, mean, ws, C, T, ldt);
+    hipLaunchKernelGGL((cln_colsums_kernel<true>), dim3(ceil_div(T, CLN_TCOLS), B), dim3(256), 0, stream, x, dy, gamma, mean, alpha, ws, C, T, ldt);
     hipLaunchKernelGGL(cln_scan_bwd_kernel, dim3(B), dim3(1024), 0, stream, ws, mean, rstd, C, T, eps);
-    hipLaunchKernelGGL(cln_apply_bwd_kernel, dim3(ceil_div(C, 4), B), dim3(256), 0, stream, dy, x, mean, rstd, (const double*)ws, gamma, dx, dgamma_part, dbeta_part, C, T, ldt);
+    hipLaunchKernelGGL(cln_apply_bwd_kernel, dim3(ceil_div(C, 4), B), dim3(256), 0, stream, dy, x, mean, rstd, (const double*)ws, gamma, alpha, dx, dgamma_part, dbeta_part, dalpha_part, C, T, ldt);
     SEP_CHECK_LAUNCH("sep_cln_bwd");
     return 0;
 }

@@ -172,6 +172,11 @@ class ConvTasNet(nn.Module):
             self.fused, self.fused_reason = True, None
         except NotImplementedError as e:
             self.fused, self.fused_reason = False, str(e)
+        # ... and between the two: the CAUSAL family (the reference constructor's default: cLN everywhere, all padding on the left,
+        # tdcn.py:98,125-127,169) runs layer by layer on this library's kernels -- `staged`: every 1x1 convolution on the MFMA GEMM,
+        # PReLU + cLN in sep_cln_*, the dilated depthwise taps in sep_depthwise_*, encoder / mask / decoder as in the fused path -- on
+        # (B, C, ldt) workspace rows throughout.  Not one fused sequence (each norm is a pass of its own), no torch convolution either.
+        self.staged, self.staged_reason = self._staged_supported()
         self._flatten_parameters()
 
     # ------------------------------------------------------------------ parameter storage
@@ -241,6 +246,11 @@ class ConvTasNet(nn.Module):
         cfg = self.get_config()
         if mixture.size(1) != self.in_channels:
             raise ValueError("input has {} channels, the model was built with in_channels={}".format(mixture.size(1), self.in_channels))
+        if not self.fused and self.staged and ((mixture.is_cuda and mixture.dtype == torch.float32) or _net.backend().name != "hip"):
+            est, latent = self._run_staged(mixture.contiguous(), want_latent)
+            if n_dims == 3:
+                est = est.view(batch_size, self.n_sources, T)
+            return est, latent
         if not self.fused:
             est, latent = self._run_composed(mixture.contiguous(), want_latent)
             if n_dims == 3:
@@ -285,6 +295,65 @@ class ConvTasNet(nn.Module):
             raise RuntimeError("ConvTasNet has no parameters to run with (a module replica without `_former_parameters`?); for "
                                "multi-GPU training use one process per GPU with sepkernels.train.FusedTrainStep")
         return out
+
+    def _staged_supported(self):
+        cfg = self.get_config()
+        problems = []
+        if self.fused:
+            return False, "the fused sequence takes this configuration"
+        if not cfg.get("causal"):
+            problems.append("causal=False outside the fused family")
+        if cfg.get("enc_basis") != "trainable" or cfg.get("dec_basis") != "trainable":
+            problems.append("enc_basis/dec_basis must be 'trainable'")
+        if cfg.get("enc_nonlinear") not in (None, "", "relu"):
+            problems.append("enc_nonlinear must be None or 'relu'")
+        if not cfg.get("separable", True) or not cfg.get("dilated", True):
+            problems.append("separable=True and dilated=True are required")
+        if cfg.get("sep_nonlinear") != "prelu" or not cfg.get("sep_norm", True):
+            problems.append("sep_nonlinear='prelu' and sep_norm=True are required")
+        for k in ("n_basis", "sep_hidden_channels", "sep_bottleneck_channels", "sep_skip_channels"):
+            if cfg[k] % 16:
+                problems.append("{} must be a multiple of 16".format(k))
+        if cfg["kernel_size"] % cfg["stride"]:
+            problems.append("kernel_size must be divisible by stride")
+        return (not problems), ("; ".join(problems) or None)
+
+    def _run_staged(self, mixture, want_latent):
+        """The causal Conv-TasNet of the reference (conv_tasnet.py:121-171 with tdcn.py:107-147, 177-196 and norm.py:58-101) as a sequence of
+        this library's kernels on (B, C, ldt) rows, autograd through sepkernels.functional:
+            encoder (+ReLU)                  EncodeFn                         sep_encoder_fwd
+            cLN, 1x1 bottleneck              PaddedCLNFn, PaddedPointwiseFn   sep_cln_*, sep_pw_gemm
+            per layer  1x1 -> PReLU+cLN -> depthwise (left padding (P-1) d) -> PReLU+cLN -> 1x1 output (+ residual) / 1x1 skip
+                                             PaddedPointwiseFn, PaddedCLNFn, PaddedDepthwiseFn
+            PReLU + 1x1 mask, sigmoid | softmax, mask * w -> decoder -> crop     PaddedPointwiseFn, torch elementwise, MaskDecodeFn"""
+        from sepkernels.functional import EncodeFn, PaddedPointwiseFn, PaddedCLNFn, PaddedDepthwiseFn, MaskDecodeFn
+        B, Cin, T = mixture.shape
+        sep = self.separator
+        geo = _net.Geometry(T, self.kernel_size, self.stride)
+        F_ = geo.F
+        w = EncodeFn.apply(mixture, self.encoder.conv1d.weight, self.stride, self.enc_nonlinear == "relu")
+        x = PaddedCLNFn.apply(w, F_, None, sep.norm1d.gamma, sep.norm1d.beta, sep.norm1d.eps)
+        x = PaddedPointwiseFn.apply(x, F_, sep.bottleneck_conv1d.weight, sep.bottleneck_conv1d.bias, None)
+        total = None
+        for block in sep.tdcn.net:
+            for layer in block.net:
+                dw = layer.separable_conv1d
+                d, P = layer.dilation, layer.kernel_size
+                a = PaddedPointwiseFn.apply(x, F_, layer.bottleneck_conv1d.weight, layer.bottleneck_conv1d.bias, None)
+                v1 = PaddedCLNFn.apply(a, F_, layer.nonlinear1d.weight, layer.norm1d.gamma, layer.norm1d.beta, layer.norm1d.eps)
+                z = PaddedDepthwiseFn.apply(v1, F_, dw.depthwise_conv1d.weight, dw.depthwise_conv1d.bias, d, (P - 1) * d)
+                v2 = PaddedCLNFn.apply(z, F_, dw.nonlinear1d.weight, dw.norm1d.gamma, dw.norm1d.beta, dw.norm1d.eps)
+                skip = PaddedPointwiseFn.apply(v2, F_, dw.skip_pointwise_conv1d.weight, dw.skip_pointwise_conv1d.bias, None)
+                total = skip if total is None else total + skip
+                if dw.dual_head:
+                    x = PaddedPointwiseFn.apply(v2, F_, dw.output_pointwise_conv1d.weight, dw.output_pointwise_conv1d.bias, None) + x
+        m = PaddedPointwiseFn.apply(total, F_, sep.mask_conv1d.weight, sep.mask_conv1d.bias, sep.prelu.weight)
+        m = torch.sigmoid(m) if self.mask_nonlinear == "sigmoid" else torch.softmax(m, dim=1)
+        out = MaskDecodeFn.apply(w, m, self.decoder.conv_transpose1d.weight, self.stride, T, want_latent)
+        if want_latent:
+            est, latent = out
+            return est, latent[..., :F_]
+        return out, None
 
     def _run_composed(self, mixture, want_latent):
         """The reference's own sequence (conv_tasnet.py:121-171) on this repository's modules, for configurations outside

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("SEPKERNELS_LIB", os.path.normpath(os.path.join(_HERE,
 # ---- constants mirrored from include/sepkernels.h -------------------------------------------------
 PRO_NONE, PRO_PRELU, PRO_GLN, PRO_GLN_PRELU, PRO_GLN_BWD = 0, 1, 2, 3, 4
 EPI_STATS_PRELU, EPI_RESIDUAL, EPI_SIGMOID, EPI_PRELU_BWD, EPI_ROWSUMS, EPI_ROWSUMS_PRELU = 1, 2, 4, 8, 16, 32
-ABI_VERSION = 19
+ABI_VERSION = 20
 LSTM_INTERLEAVED = 0x400       # sep_lstm_fwd / sep_lstm_bwd with reverse = 2: h_out / dh_out as one (nseq, L, 2H) buffer
 STATS_SLOTS = 16   # SEP_STATS_SLOTS: gLN statistics are double[B][STATS_SLOTS][2]
 ARRIVE_INTS = 17   # SEP_ARRIVE_INTS: arrival counters of the gLN-backward publishers, int[B][ARRIVE_INTS]
@@ -128,8 +128,8 @@ SIGNATURES = {
     "sep_decoder_bwd": [_vp] * 6 + [_I] * 11 + [_vp],
     "sep_softmax_ch_fwd": [_vp] + [_I] * 4 + [_vp],
     "sep_softmax_ch_bwd": [_vp, _vp] + [_I] * 4 + [_vp],
-    "sep_cln_fwd": [_vp] * 7 + [_I] * 4 + [_F, _vp],
-    "sep_cln_bwd": [_vp] * 9 + [_I] * 4 + [_F, _vp],
+    "sep_cln_fwd": [_vp] * 7 + [_I] * 4 + [_F, _vp, _vp],
+    "sep_cln_bwd": [_vp] * 9 + [_I] * 4 + [_F, _vp, _vp, _vp],
     "sep_gln_stats": [_vp, _vp, _I, _I, _I, _I, _vp],
     "sep_gln_apply": [_vp] * 5 + [_I] * 4 + [_D, _F, _vp],
     "sep_gln_bwd_rowsums": [_vp, _vp, _vp, _I, _I, _I, _I, _vp],
@@ -355,13 +355,14 @@ class HipBackend:
     def softmax_ch_bwd(self, y, g, B, C, T, ldt):
         _check(load().sep_softmax_ch_bwd(_ptr(y, _f32), _ptr(g, _f32), B, C, T, ldt, _stream()), "sep_softmax_ch_bwd")
 
-    def cln_fwd(self, x, gamma, beta, y, mean, rstd, ws, B, C, T, ldt, eps):
+    def cln_fwd(self, x, gamma, beta, y, mean, rstd, ws, B, C, T, ldt, eps, alpha=None):
         _check(load().sep_cln_fwd(_ptr(x, _f32), _ptr(gamma, _f32), _ptr(beta, _f32), _ptr(y, _f32), _ptr(mean, _f32), _ptr(rstd, _f32),
-                                  _ptr(ws, _f64), B, C, T, ldt, eps, _stream()), "sep_cln_fwd")
+                                  _ptr(ws, _f64), B, C, T, ldt, eps, _ptr(alpha, _f32), _stream()), "sep_cln_fwd")
 
-    def cln_bwd(self, dy, x, gamma, mean, rstd, dx, dgamma_part, dbeta_part, ws, B, C, T, ldt, eps):
+    def cln_bwd(self, dy, x, gamma, mean, rstd, dx, dgamma_part, dbeta_part, ws, B, C, T, ldt, eps, alpha=None, dalpha_part=None):
         _check(load().sep_cln_bwd(_ptr(dy, _f32), _ptr(x, _f32), _ptr(gamma, _f32), _ptr(mean, _f32), _ptr(rstd, _f32), _ptr(dx, _f32),
-                                  _ptr(dgamma_part, _f32), _ptr(dbeta_part, _f32), _ptr(ws, _f64), B, C, T, ldt, eps, _stream()), "sep_cln_bwd")
+                                  _ptr(dgamma_part, _f32), _ptr(dbeta_part, _f32), _ptr(ws, _f64), B, C, T, ldt, eps, _ptr(alpha, _f32),
+                                  _ptr(dalpha_part, _f32), _stream()), "sep_cln_bwd")
 
     def gln_stats(self, x, stats, B, C, T, ldt):
         _check(load().sep_gln_stats(_ptr(x, _f32), _ptr(stats, _f64), B, C, T, ldt, _stream()), "sep_gln_stats")

@@ -202,6 +202,80 @@ class MaskDecodeFn(torch.autograd.Function):
         return dw, dmask, dD, None, None, None
 
 
+class PaddedCLNFn(torch.autograd.Function):
+    """[PReLU ->] CumulativeLayerNorm1d on rows that already carry the workspace stride: x (B, C, ldt) with n_frames valid frames -> the
+    same shape, frames beyond zero (reference src/modules/norm.py:58-101, behind nonlinear1d of tdcn.py:113-116 / 182-186 when `alpha` -- the
+    single PReLU slope -- is given).  sep_cln_fwd / sep_cln_bwd (csrc/cln.hip): column sums over the channels, fp64 prefix / suffix sums per
+    sample, one apply pass; the activation costs no pass of its own."""
+
+    @staticmethod
+    def forward(ctx, x, n_frames, alpha, gamma, beta, eps):
+        K = backend()
+        x = x.contiguous()
+        B, C, ldt = x.shape
+        f32 = dict(device=x.device, dtype=x.dtype)
+        g1, b1 = gamma.reshape(-1).contiguous(), beta.reshape(-1).contiguous()
+        y = torch.empty(B, C, ldt, **f32)
+        mean, rstd = torch.empty(B, n_frames, **f32), torch.empty(B, n_frames, **f32)
+        ws = torch.empty(B, 2, n_frames, device=x.device, dtype=torch.float64)
+        K.cln_fwd(x, g1, b1, y, mean, rstd, ws, B, C, n_frames, ldt, eps, alpha=alpha)
+        ctx.save_for_backward(x, g1, mean, rstd, alpha)
+        ctx.meta = (B, C, n_frames, ldt, eps, gamma.shape, beta.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        K = backend()
+        x, g1, mean, rstd, alpha = ctx.saved_tensors
+        B, C, F, ldt, eps, gshape, bshape = ctx.meta
+        f32 = dict(device=x.device, dtype=x.dtype)
+        dx = torch.empty(B, C, ldt, **f32)
+        pg, pb = torch.empty(B, C, **f32), torch.empty(B, C, **f32)
+        pa = torch.empty(B, C, **f32) if alpha is not None else None
+        ws = torch.empty(B, 2, F, device=x.device, dtype=torch.float64)
+        K.cln_bwd(dy.contiguous(), x, g1, mean, rstd, dx, pg, pb, ws, B, C, F, ldt, eps, alpha=alpha, dalpha_part=pa)
+        dgamma, dbeta = torch.empty(C, **f32), torch.empty(C, **f32)
+        segs = [(pg, 0, dgamma, C, B, C, 0, 1.0), (pb, 0, dbeta, C, B, C, 0, 1.0)]
+        K.reduce_slabs(segs)
+        dalpha = pa.double().sum().to(x.dtype).view(alpha.shape) if alpha is not None else None      # B*C row partials -> the one slope
+        return dx, None, dalpha, dgamma.view(gshape), dbeta.view(bshape), None
+
+
+class PaddedDepthwiseFn(torch.autograd.Function):
+    """nn.Conv1d(C, C, k, dilation=d, groups=C) of a TCN layer on rows that carry the workspace stride, with the layer's zero padding folded
+    in: `left` zeros in front (causal: (k - 1) d, all of it; else the smaller half -- reference tdcn.py:118-129), the output has the input's
+    n_frames.  x (B, C, ldt) with frames >= n_frames zero -> (B, C, ldt); sep_depthwise_* (csrc/stream.hip) on rows of ldt frames -- what
+    the kernel writes beyond n_frames is whatever the taps reach there and is ignored by every consumer (they all take n_frames)."""
+
+    @staticmethod
+    def forward(ctx, x, n_frames, weight, bias, dilation, left):
+        K = backend()
+        x = x.contiguous()
+        B, C, ldt = x.shape
+        Kw = weight.shape[-1]
+        y = torch.empty(B, C, ldt, device=x.device, dtype=x.dtype)
+        K.depthwise_fwd(x, weight, bias, y, B, C, ldt, ldt, Kw, 1, left, dilation)
+        ctx.save_for_backward(x, weight)
+        ctx.meta = (B, C, ldt, Kw, dilation, left, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        K = backend()
+        x, weight = ctx.saved_tensors
+        B, C, ldt, Kw, dilation, left, has_bias = ctx.meta
+        dy = dy.contiguous()                                     # zero beyond n_frames: it comes out of a kernel that writes the pad frames
+        f32 = dict(device=x.device, dtype=x.dtype)
+        dx = torch.empty(B, C, ldt, **f32)
+        K.depthwise_bwd_input(dy, weight, dx, B, C, ldt, ldt, Kw, 1, left, dilation)
+        part = torch.empty(B, C, Kw + 1, **f32)
+        K.depthwise_bwd_weight(dy, x, part, B, C, ldt, ldt, Kw, 1, left, dilation)
+        dwb = torch.empty(C * (Kw + 1), **f32)
+        K.reduce_slabs([(part, 0, dwb, C * (Kw + 1), B, C * (Kw + 1), 0, 1.0)])
+        dwb = dwb.view(C, Kw + 1)
+        return dx, None, dwb[:, :Kw].reshape(C, 1, Kw).contiguous(), (dwb[:, Kw].contiguous() if has_bias else None), None, None
+
+
 def segment_geometry(T, chunk_size, hop_size):
     padding = (hop_size - (T - chunk_size) % hop_size) % hop_size
     pad_left = padding // 2

@@ -33,7 +33,7 @@ extern "C" {
 
 typedef void* sep_stream_t; /* hipStream_t */
 
-#define SEP_ABI_VERSION 19
+#define SEP_ABI_VERSION 20
 #define SEP_STATS_SLOTS 16
 #define SEP_ARRIVE_INTS 17 /* arrival counters per sample: one per slot + one for the slots (csrc/common.hpp, gln_bwd_publish) */
 
@@ -302,11 +302,14 @@ int sep_softmax_ch_bwd(const float* y, float* g, int B, int C, int T, int ldt, s
  *   y = (x - m_t) / (sqrt(v_t) + eps) * gamma_c + beta_c with the mean / biased variance of all channels and frames <= t.
  * x, y, dy, dx: (B, C, ldt) fp32, frames contiguous, ldt % 4 == 0, frames >= T written as zeros; mean, rstd: (B, T) fp32, written
  * by the forward and read by the backward; ws: (B, 2, T) fp64 scratch (column sums, then their prefix / suffix sums);
- * dgamma_part, dbeta_part: (B, C) per-sample sums, to be added over the samples (sep_reduce_slabs). */
+ * dgamma_part, dbeta_part: (B, C) per-sample sums, to be added over the samples (sep_reduce_slabs).
+ * alpha (ABI 20; may be NULL): the single slope of a PReLU in FRONT of the norm (tdcn.py:113-116, 182-186: nonlinear1d then norm1d): the
+ * kernels normalise u = PReLU(x; alpha), dx is the gradient at x, and dalpha_part (B, C) receives sum_t du * x * [x <= 0] per row. */
 int sep_cln_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, double* ws, int B, int C,
-                int T, int ldt, float eps, sep_stream_t stream);
+                int T, int ldt, float eps, const float* alpha, sep_stream_t stream);
 int sep_cln_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
-                float* dgamma_part, float* dbeta_part, double* ws, int B, int C, int T, int ldt, float eps, sep_stream_t stream);
+                float* dgamma_part, float* dbeta_part, double* ws, int B, int C, int T, int ldt, float eps, const float* alpha,
+                float* dalpha_part, sep_stream_t stream);
 
 /* Stand-alone gLN (modules/norm.py:11-35) for callers outside the fused network. */
 int sep_gln_stats(const float* x, double* stats, int B, int C, int T, int ldt, sep_stream_t stream);

@@ -399,22 +399,25 @@ class EmuBackend:
         g.copy_(v)
 
     # ------------------------------------------------------------------ cumulative layer norm
-    def cln_fwd(self, x, gamma, beta, y, mean, rstd, ws, B, C, T, ldt, eps):
+    def cln_fwd(self, x, gamma, beta, y, mean, rstd, ws, B, C, T, ldt, eps, alpha=None):
+        if alpha is not None:
+            x = _prelu(x, alpha)
         v = x.reshape(B, C, ldt)[:, :, :T].double()
         n = torch.arange(1, T + 1, dtype=torch.float64) * C
         m = v.sum(1).cumsum(1) / n
         var = ((v * v).sum(1).cumsum(1) / n - m * m).clamp_min(0)
         r = 1.0 / (var.sqrt() + eps)
-        mean.reshape(B, T).copy_(m.float())
-        rstd.reshape(B, T).copy_(r.float())
+        mean.reshape(B, T).copy_(m.to(mean.dtype))           # fp32 on the device; the fp64 emulator runs of the CPU tests keep fp64
+        rstd.reshape(B, T).copy_(r.to(rstd.dtype))
         out = torch.zeros(B, C, ldt, dtype=x.dtype)
         mf, rf = mean.reshape(B, 1, T), rstd.reshape(B, 1, T)
         out[:, :, :T] = (x.reshape(B, C, ldt)[:, :, :T] - mf) * rf * gamma.view(1, C, 1) + beta.view(1, C, 1)
         y.reshape(B, C, ldt).copy_(out)
 
-    def cln_bwd(self, dy, x, gamma, mean, rstd, dx, dgamma_part, dbeta_part, ws, B, C, T, ldt, eps):
+    def cln_bwd(self, dy, x, gamma, mean, rstd, dx, dgamma_part, dbeta_part, ws, B, C, T, ldt, eps, alpha=None, dalpha_part=None):
         g = dy.reshape(B, C, ldt)[:, :, :T].double()
-        v = x.reshape(B, C, ldt)[:, :, :T].double()
+        x_pre = x.reshape(B, C, ldt)[:, :, :T].double()
+        v = _prelu(x_pre, alpha) if alpha is not None else x_pre
         m, r = mean.reshape(B, 1, T).double(), rstd.reshape(B, 1, T).double()
         gh = g * gamma.view(1, C, 1).double()
         A, Bq = gh.sum(1), (gh * (v - m)).sum(1)
@@ -425,10 +428,14 @@ class EmuBackend:
         P = (Dm / n).flip(1).cumsum(1).flip(1).unsqueeze(1)
         Q = (Dq / n).flip(1).cumsum(1).flip(1).unsqueeze(1)
         out = torch.zeros(B, C, ldt, dtype=x.dtype)
-        out[:, :, :T] = (gh * r + P + 2 * v * Q).float()
+        du = gh * r + P + 2 * v * Q
+        if alpha is not None:
+            dalpha_part.reshape(B, C).copy_(torch.where(x_pre <= 0, du * x_pre, torch.zeros_like(du)).sum(2).to(dalpha_part.dtype))
+            du = du * _prelu_grad(x_pre, alpha)
+        out[:, :, :T] = du.to(x.dtype)
         dx.reshape(B, C, ldt).copy_(out)
-        dgamma_part.reshape(B, C).copy_((g * (v - m) * r).sum(2).float())
-        dbeta_part.reshape(B, C).copy_(g.sum(2).float())
+        dgamma_part.reshape(B, C).copy_((g * (v - m) * r).sum(2).to(dgamma_part.dtype))
+        dbeta_part.reshape(B, C).copy_(g.sum(2).to(dbeta_part.dtype))
 
     # ------------------------------------------------------------------ stand-alone gLN
     def gln_stats(self, x, stats, B, C, T, ldt):
@@ -462,15 +469,23 @@ class EmuBackend:
         d.zero_()
         d[:, :T] = src.reshape(rows, ld_src)[:, :T]
 
+    @staticmethod
+    def _depthwise(x3, w, bias, C, Tin, Tout, Kw, stride, pad, dil):
+        """y[to] = bias + sum_k w[k] xpad[to*stride + k*dil - pad] for to < Tout, x zero outside [0, Tin) -- the kernel's contract: ANY Tout
+        (the TCN layers ask for Tout = Tin with pad = (Kw-1) dil: all of the padding on the left)"""
+        need = (Tout - 1) * stride + (Kw - 1) * dil + 1              # padded input frames the Tout outputs reach
+        right = max(0, need - pad - Tin)
+        xp = torch.nn.functional.pad(x3, (pad, right))
+        r = torch.nn.functional.conv1d(xp, w.reshape(C, 1, Kw), None if bias is None else bias.reshape(C), stride=stride, dilation=dil, groups=C)
+        return r[:, :, :Tout]
+
     def depthwise_fwd(self, x, w, bias, y, B, C, Tin, Tout, Kw, stride, pad, dil):
-        r = torch.nn.functional.conv1d(x.reshape(B, C, Tin), w.reshape(C, 1, Kw), None if bias is None else bias.reshape(C),
-                                       stride=stride, padding=pad, dilation=dil, groups=C)
-        y.reshape(B, C, Tout).copy_(r)
+        y.reshape(B, C, Tout).copy_(self._depthwise(x.reshape(B, C, Tin), w, bias, C, Tin, Tout, Kw, stride, pad, dil))
 
     def depthwise_bwd_input(self, dy, w, dx, B, C, Tin, Tout, Kw, stride, pad, dil):
         with torch.enable_grad():
             x0 = torch.zeros(B, C, Tin, dtype=dy.dtype, requires_grad=True)
-            r = torch.nn.functional.conv1d(x0, w.detach().reshape(C, 1, Kw), None, stride=stride, padding=pad, dilation=dil, groups=C)
+            r = self._depthwise(x0, w.detach(), None, C, Tin, Tout, Kw, stride, pad, dil)
             gx = torch.autograd.grad(r, x0, dy.detach().reshape(B, C, Tout))[0]
         dx.reshape(B, C, Tin).copy_(gx)
 

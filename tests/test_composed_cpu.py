@@ -12,7 +12,7 @@ import torch
 
 import sepkernels
 from emulator import EmuBackend
-from oracle.make_golden import CONFIGS, COMPOSED
+from oracle.make_golden import CONFIGS, COMPOSED, STAGED
 from models.conv_tasnet import ConvTasNet
 from models.tdcn import TimeDilatedConvNet, ResidualBlock1d
 from modules.norm import CumulativeLayerNorm1d
@@ -60,6 +60,34 @@ def test_composed_path_matches_the_reference(golden_dir, name, emu):
         assert (p.grad - gr).abs().max() <= 2e-6 * max(gr.abs().max().item(), 1e-6), k          # the fixture stores fp64 gradients as fp32
         seen += 1
     assert seen == sum(1 for f in g.files if f.startswith("grad/"))
+
+
+@pytest.mark.parametrize("name", STAGED)
+def test_staged_causal_path_matches_the_reference(golden_dir, name, emu):
+    """The causal family (the reference constructor's default) on channel counts the kernels take: runs layer by layer on the C ABI
+    (models/conv_tasnet.py::_run_staged -- 1x1 convolutions on sep_pw_gemm, PReLU + cLN in sep_cln_*, the left-padded dilated taps in
+    sep_depthwise_*), here through the CPU emulator in fp64, against golden vectors of the unmodified reference."""
+    g, model = _load(golden_dir, name)
+    assert not model.fused and model.staged and model.staged_reason is None
+    mixture, sources = torch.from_numpy(g["mixture"]).double(), torch.from_numpy(g["sources"]).double()
+    calls = []
+    backend = sepkernels.backend()
+    for fn in ("cln_fwd", "depthwise_fwd", "pw_gemm"):
+        orig = getattr(backend, fn)
+        setattr(backend, fn, (lambda o, n: (lambda *a, **k: (calls.append(n), o(*a, **k))[1]))(orig, fn))
+    est, latent = model.extract_latent(mixture)
+    nl = CONFIGS[name]["sep_num_blocks"] * CONFIGS[name]["sep_num_layers"]
+    assert calls.count("cln_fwd") == 2 * nl + 1 and calls.count("depthwise_fwd") == nl          # the staged path ran, not the torch composition
+    ref = torch.from_numpy(g["output_f64"])
+    assert (est - ref).abs().max() <= 1e-9 * ref.abs().max()
+    assert abs(latent.sum().item() - float(g["latent_f64_sum"])) <= 1e-8 * float(g["latent_f64_abs_sum"])
+    loss, pattern = PIT1d(NegSISDR(), n_sources=CONFIGS[name]["n_sources"])(est, sources)
+    assert abs(loss.item() - float(g["loss_f64"])) <= 1e-9 * abs(float(g["loss_f64"]))
+    assert np.array_equal(pattern.numpy(), g["pattern"])
+    loss.backward()
+    for k, p in model.named_parameters():
+        gr = torch.from_numpy(g["grad/" + k]).double()
+        assert (p.grad - gr).abs().max() <= 2e-6 * max(gr.abs().max().item(), 1e-6), k          # the fixture stores fp64 gradients as fp32
 
 
 def test_cumulative_layer_norm_formula():

@@ -832,6 +832,48 @@ def test_cln_fwd_bwd(B, C, T):
     assert (dxe - dx).abs().max() <= 5e-5 * dxe.abs().max() and (pge - pg.cpu()).abs().max() <= 5e-5 * pge.abs().max()
 
 
+@pytest.mark.parametrize("B,C,T,a", [(2, 24, 203, 0.25), (2, 96, 3999, -0.3), (1, 48, 1030, 0.0)])
+def test_prelu_cln_fwd_bwd(B, C, T, a):
+    """sep_cln_fwd / sep_cln_bwd with the PReLU in front of the norm folded in (alpha != NULL): nonlinear1d -> norm1d of the causal TCN
+    layers (reference tdcn.py:113-116, 182-186) against torch's float64 autograd, gradients at x, gamma, beta and the slope."""
+    ldt = (T + 127) // 128 * 128
+    torch.manual_seed(B * 1000 + C)
+    x = torch.zeros(B, C, ldt)
+    x[..., :T] = torch.randn(B, C, T) * torch.linspace(0.3, 2.5, T) + 0.1
+    gamma, beta, dy = torch.randn(C) + 1, torch.randn(C), torch.zeros(B, C, ldt)
+    dy[..., :T] = torch.randn(B, C, T)
+    alpha = torch.tensor([a])
+    eps = 1e-12
+    x64 = x[..., :T].double().requires_grad_(True)
+    g64, b64, a64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True), alpha.double().requires_grad_(True)
+    u64 = torch.where(x64 > 0, x64, a64 * x64)
+    n = torch.arange(1, T + 1, dtype=torch.float64) * C
+    m = u64.sum(1).cumsum(1) / n
+    v = (u64 * u64).sum(1).cumsum(1) / n - m * m
+    y64 = (u64 - m.unsqueeze(1)) / (v.sqrt().unsqueeze(1) + eps) * g64.view(1, C, 1) + b64.view(1, C, 1)
+    (y64 * dy[..., :T].double()).sum().backward()
+    f32 = dict(device=device_name(), dtype=torch.float32)
+    y, mean, rstd = torch.full((B, C, ldt), float("nan"), **f32), torch.empty(B, T, **f32), torch.empty(B, T, **f32)
+    ws = torch.empty(B, 2, T, device=device_name(), dtype=torch.float64)
+    HIP.cln_fwd(to_device(x), to_device(gamma), to_device(beta), y, mean, rstd, ws, B, C, T, ldt, eps, alpha=to_device(alpha))
+    dx, pg, pb, pa = torch.full((B, C, ldt), float("nan"), **f32), torch.empty(B, C, **f32), torch.empty(B, C, **f32), torch.empty(B, C, **f32)
+    HIP.cln_bwd(to_device(dy), to_device(x), to_device(gamma), mean, rstd, dx, pg, pb, ws, B, C, T, ldt, eps, alpha=to_device(alpha), dalpha_part=pa)
+    device_sync()
+    y, dx = y.cpu(), dx.cpu()
+    assert (y[..., T:] == 0).all() and (dx[..., T:] == 0).all()
+    assert (y[..., :T].double() - y64.detach()).abs().max() <= 2e-5 * y64.detach().abs().max()
+    assert (dx[..., :T].double() - x64.grad).abs().max() <= 5e-5 * x64.grad.abs().max()
+    assert (pg.cpu().double().sum(0) - g64.grad).abs().max() <= 5e-5 * g64.grad.abs().max()
+    assert (pb.cpu().double().sum(0) - b64.grad).abs().max() <= 5e-5 * b64.grad.abs().max()
+    assert abs(pa.cpu().double().sum().item() - a64.grad.item()) <= 2e-4 * (x64.grad.abs() * x64.detach().abs()).sum().item() / max(1, B * C) ** 0.5 + 1e-6
+    ye, me, re_ = torch.empty(B, C, ldt), torch.empty(B, T), torch.empty(B, T)
+    EMU.cln_fwd(x, gamma, beta, ye, me, re_, None, B, C, T, ldt, eps, alpha=alpha)
+    assert (ye - y).abs().max() <= 2e-5 * ye.abs().max()
+    dxe, pge, pbe, pae = torch.empty(B, C, ldt), torch.empty(B, C), torch.empty(B, C), torch.empty(B, C)
+    EMU.cln_bwd(dy, x, gamma, me, re_, dxe, pge, pbe, None, B, C, T, ldt, eps, alpha=alpha, dalpha_part=pae)
+    assert (dxe - dx).abs().max() <= 5e-5 * dxe.abs().max() and (pae - pa.cpu()).abs().max() <= 2e-4 * pae.abs().max() + 1e-5
+
+
 # ------------------------------------------------------------------------------------------- losses / optimiser
 @pytest.mark.parametrize("n,all_pairs", [(1, 0), (2, 1), (4, 1), (3, 0)])
 def test_sisdr_kernels(n, all_pairs):

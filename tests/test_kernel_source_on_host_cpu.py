@@ -35,6 +35,7 @@ CASES = [
     ("test_softmax_over_channels", [(2, 128, 300), (3, 50, 64), (2, 7, 1)]),
     ("test_gln_standalone_and_repack", [()]),
     ("test_cln_fwd_bwd", [(2, 24, 203), (3, 128, 3999)]),
+    ("test_prelu_cln_fwd_bwd", [(2, 24, 203, 0.25), (1, 48, 1030, 0.0)]),
     ("test_sisdr_kernels", [(1, 0), (2, 1), (3, 0)]),
     ("test_pit_search", [(2, 0, 1), (3, 1, 1), (4, 0, 0)]),
     ("test_sinkhorn", [(3, 10, 1.0), (5, 200, 1.0), (10, 5, 0.5)]),

@@ -591,7 +591,7 @@ def bench_dual_path(args):
     assert not problems, problems
     crit = PIT1d(NegSISDR(), n_sources=2)
     opt = torch.optim.Adam(model.parameters(), **adam)
-    B = recipe_batch if args.batch == PER_GPU_BATCH else args.batch
+    B = recipe_batch if args.batch is None else args.batch
     src = (0.1 * torch.randn(B, 2, T_SAMPLES, generator=torch.Generator().manual_seed(111))).to(dev)
     mix = src.sum(1, keepdim=True).contiguous()
 
@@ -640,25 +640,24 @@ def bench_dual_path(args):
                          "what": "the same step (fresh Adam state, parameters where the eager leg left them) as ONE hipGraph launch per step"}
         except Exception as e:                                   # noqa: BLE001 -- a leg that cannot be recorded is reported, not fatal
             graph_leg = {"error": "{}: {}".format(type(e).__name__, e)}
-    config = {"workload": "{}, 2 spk, 4 s @ 8 kHz synthetic mixtures, batch {} (recipe default), fwd + PIT(NegSI-SDR) + bwd + clip(5) + Adam".format(label, B),
+    config = {"workload": "{}, 2 spk, 4 s @ 8 kHz synthetic mixtures, batch {}{}, fwd + PIT(NegSI-SDR) + bwd + clip(5) + Adam".format(
+                  label, B, " (recipe default)" if B == recipe_batch else " (recipe default: {})".format(recipe_batch)),
               "global_batch": B, "frames_per_utterance": F, "parallelism": "dp1", "utt_per_s": B * args.steps / el, "final_loss": float(loss),
               "parameters": model.num_parameters, "launch": launch}
-    note = "no roofline: the step is a sequence of library GEMM / attention calls between this library's kernels, none of which dominates"
+    note = "no roofline: library GEMM / attention calls between this library's kernels, none of which dominates"
     roofline = None
     if gflop is not None:
         config["algorithmic_gflop_per_utterance_fwd_bwd"] = gflop
         tf = gflop * 1e9 * B * args.steps / el / 1e12
         # the step's arithmetic is fp32 throughout (the LSTM recurrences on v_mfma_f32_16x16x4 / 4x4x1, projections on rocBLAS fp32): matrix-pipe roof
-        roofline = {"kernel": "whole step (rocprofv3, profiles/r04e_dprnn_kernel_stats.md: sep_lstm_fwd / sep_lstm_bwd sweeps 40 % of the kernel time, the dense "
-                              "layers of csrc/linear.hip 43 %)", "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS,
+        roofline = {"kernel": "whole step (sep_lstm_fwd / sep_lstm_bwd sweeps + the dense layers of csrc/linear.hip; per-kernel: profiles/r04e_dprnn_kernel_stats.md)",
+                    "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                    "what": "algorithmic fp32 FLOP of forward + backward (SURVEY.md 8d: {:.0f} GFLOP per utterance) / step time against the dense fp32 MFMA "
-                            "peak; the recurrences are latency-bound chains (one workgroup per 4 or 16 sequences, a barrier per time step), the "
-                            "dense layers run at 50 - 70 TFLOP/s".format(gflop)}
+                    "what": "algorithmic fp32 FLOP of fwd + bwd ({:.0f} GFLOP per utterance, SURVEY.md 8d) / step time vs the dense fp32 MFMA peak".format(gflop)}
         note = "{:.0f} GFLOP per utterance (SURVEY.md 8d): {:.1f} TFLOP/s achieved".format(gflop, tf)
     print(json.dumps({
         "metric": "separated audio frames/sec (fwd+bwd), {} 2-spk 4s@8kHz".format("DPRNN-TasNet" if args.config == "dprnn" else cls.__name__) +
                   (" (BASELINE configs[3])" if args.config == "dprnn" else ""), "value": B * F * args.steps / el, "unit": "frames/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": config, "roofline": roofline, "roofline_note": note,
-        "graph_replay": graph_leg}))
+        "peak_memory_GB": torch.cuda.max_memory_allocated() / 2 ** 30, "graph_replay": graph_leg}), flush=True)
