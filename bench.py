@@ -124,13 +124,13 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic (N = 1 only)")
     ap.add_argument("--no-stock", action="store_true", help="skip the hipified_baseline leg (stock torch.nn modules on the same device)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured step (N = 1)")
-    ap.add_argument("--config", default="convtasnet2", choices=["convtasnet2", "sinkpit4", "dprnn", "dptnet", "galrnet", "sepformer"],
+    ap.add_argument("--config", default="convtasnet2", choices=["convtasnet2", "sinkpit4", "causal", "dprnn", "dptnet", "galrnet", "sepformer"],
                     help="convtasnet2 (default) = BASELINE.json configs[1]/[2], the headline; sinkpit4 = configs[4] (paper-best Conv-TasNet, "
                          "4 speakers, SinkPIT(NegSI-SDR, coldness 1, 200 iterations)); dprnn = configs[3] (DPRNN-TasNet N64 L2 F64 H128 K250 P125 B6, batch 2); dptnet / galrnet / sepformer = the reference recipes' "
                          "own sizes of those separators (SURVEY.md section 8 row f4)")
     ap.add_argument("--sink-iters", type=int, default=200, help="sinkpit4: Sinkhorn iterations (the tutorial recipe uses 200; the paper's ablation 10)")
     args = ap.parse_args()
-    if args.config in ("dprnn", "dptnet", "galrnet", "sepformer"):
+    if args.config in ("causal", "dprnn", "dptnet", "galrnet", "sepformer"):
         return legs.bench_dual_path(args)
     if args.batch is None:
         args.batch = PER_GPU_BATCH

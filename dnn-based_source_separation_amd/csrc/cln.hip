@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void cln_colsums_kernel(const float* __restric
     const int b = blockIdx.y, t = blockIdx.x * CLN_TCOLS + lane;
     const bool live = t < T;
     const size_t base = (size_t)b * C * ldt + (live ? t : 0);
-    const float m = BWD && live ? mean[(size_t)b * T + t] : 0.f;
+    const float m = BWD && live ? mean[(size_t)b * ldt + t] : 0.f;
     const bool act = alpha != nullptr;
     const float al = act ? alpha[0] : 1.f;
     float s0 = 0.f, s1 = 0.f;
@@ -52,8 +52,8 @@ __global__ __launch_bounds__(256) void cln_colsums_kernel(const float* __restric
     if (w == 0 && live) {
         const double a0 = (double)red[0][0][lane] + (double)red[0][1][lane] + (double)red[0][2][lane] + (double)red[0][3][lane];
         const double a1 = (double)red[1][0][lane] + (double)red[1][1][lane] + (double)red[1][2][lane] + (double)red[1][3][lane];
-        ws[((size_t)b * 2 + 0) * T + t] = a0;
-        ws[((size_t)b * 2 + 1) * T + t] = a1;
+        ws[((size_t)b * 2 + 0) * ldt + t] = a0;
+        ws[((size_t)b * 2 + 1) * ldt + t] = a1;
     }
 }
 
@@ -82,13 +82,13 @@ __device__ __forceinline__ void block_scan2(double& a, double& b, double (*sm)[1
 }
 
 // forward: prefix sums -> mean, rstd.   one block per sample
-__global__ __launch_bounds__(1024) void cln_scan_fwd_kernel(const double* __restrict__ ws, float* __restrict__ mean, float* __restrict__ rstd, int C, int T, float eps) {
+__global__ __launch_bounds__(1024) void cln_scan_fwd_kernel(const double* __restrict__ ws, float* __restrict__ mean, float* __restrict__ rstd, int C, int T, int ldt, float eps) {
     __shared__ double sm[2][16];
     const int b = blockIdx.x;
     double ca = 0.0, cb = 0.0;
     for (int t0 = 0; t0 < T; t0 += 1024) {
         const int t = t0 + threadIdx.x;
-        double a = t < T ? ws[((size_t)b * 2 + 0) * T + t] : 0.0, q = t < T ? ws[((size_t)b * 2 + 1) * T + t] : 0.0, ta, tb;
+        double a = t < T ? ws[((size_t)b * 2 + 0) * ldt + t] : 0.0, q = t < T ? ws[((size_t)b * 2 + 1) * ldt + t] : 0.0, ta, tb;
         block_scan2(a, q, sm, ta, tb);
         a += ca;
         q += cb;
@@ -99,14 +99,14 @@ __global__ __launch_bounds__(1024) void cln_scan_fwd_kernel(const double* __rest
             const double m = a / n;
             double var = q / n - m * m;
             if (var < 0.0) var = 0.0;
-            mean[(size_t)b * T + t] = (float)m;
-            rstd[(size_t)b * T + t] = (float)(1.0 / (sqrt(var) + (double)eps));
+            mean[(size_t)b * ldt + t] = (float)m;
+            rstd[(size_t)b * ldt + t] = (float)(1.0 / (sqrt(var) + (double)eps));
         }
     }
 }
 
 // backward: ws holds A_t, Bq_t; leaves P_t, Q_t (suffix sums) in their place.   one block per sample, frames visited from the end
-__global__ __launch_bounds__(1024) void cln_scan_bwd_kernel(double* __restrict__ ws, const float* __restrict__ mean, const float* __restrict__ rstd, int C, int T, float eps) {
+__global__ __launch_bounds__(1024) void cln_scan_bwd_kernel(double* __restrict__ ws, const float* __restrict__ mean, const float* __restrict__ rstd, int C, int T, int ldt, float eps) {
     __shared__ double sm[2][16];
     const int b = blockIdx.x;
     double ca = 0.0, cb = 0.0;
@@ -114,8 +114,8 @@ __global__ __launch_bounds__(1024) void cln_scan_bwd_kernel(double* __restrict__
         const int t = T - 1 - (r0 + (int)threadIdx.x);                 // reversed: thread order = descending frames
         double dm = 0.0, dq = 0.0;
         if (t >= 0) {
-            const double A = ws[((size_t)b * 2 + 0) * T + t], Bq = ws[((size_t)b * 2 + 1) * T + t];
-            const double r = (double)rstd[(size_t)b * T + t], m = (double)mean[(size_t)b * T + t];
+            const double A = ws[((size_t)b * 2 + 0) * ldt + t], Bq = ws[((size_t)b * 2 + 1) * ldt + t];
+            const double r = (double)rstd[(size_t)b * ldt + t], m = (double)mean[(size_t)b * ldt + t];
             const double sigma = 1.0 / r - (double)eps;
             const double n = (double)C * (double)(t + 1);
             const double Dq = sigma > 0.0 ? -Bq * r * r / (2.0 * sigma) : 0.0;      // d r / d v = -r^2 / (2 sigma); a constant prefix (sigma = 0) has no slope here
@@ -130,8 +130,8 @@ __global__ __launch_bounds__(1024) void cln_scan_bwd_kernel(double* __restrict__
         ca += ta;
         cb += tb;
         if (t >= 0) {
-            ws[((size_t)b * 2 + 0) * T + t] = dm;
-            ws[((size_t)b * 2 + 1) * T + t] = dq;
+            ws[((size_t)b * 2 + 0) * ldt + t] = dm;
+            ws[((size_t)b * 2 + 1) * ldt + t] = dq;
         }
     }
 }
@@ -150,10 +150,14 @@ __global__ __launch_bounds__(256) void cln_apply_fwd_kernel(const float* __restr
     for (int t = 4 * lane; t < ldt; t += 256) {
         const float4 xv = *reinterpret_cast<const float4*>(x + row + t);
         float xs[4] = {xv.x, xv.y, xv.z, xv.w}, o[4];
+        // the frames' statistics: rows of ldt floats, so a lane's four frames are ONE 16-byte load (one scalar load per frame made these
+        // kernels issue-bound: 175 us per backward apply at the paper-best sizes, profiles/r05o_causal_kernel_stats.md)
+        const float4 m4 = *reinterpret_cast<const float4*>(mean + (size_t)b * ldt + t), r4 = *reinterpret_cast<const float4*>(rstd + (size_t)b * ldt + t);
+        const float ms[4] = {m4.x, m4.y, m4.z, m4.w}, rs[4] = {r4.x, r4.y, r4.z, r4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const bool live = t + e < T;
-            const float m = live ? mean[(size_t)b * T + t + e] : 0.f, r = live ? rstd[(size_t)b * T + t + e] : 0.f;
+            const float m = live ? ms[e] : 0.f, r = live ? rs[e] : 0.f;
             const float u = act ? prelu_f(xs[e], al) : xs[e];
             o[e] = live ? (u - m) * r * ga + be : 0.f;
         }
@@ -176,12 +180,16 @@ __global__ __launch_bounds__(256) void cln_apply_bwd_kernel(const float* __restr
         const float4 xv = *reinterpret_cast<const float4*>(x + row + t), gv = *reinterpret_cast<const float4*>(g + row + t);
         float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w}, o[4];
         float pg = 0.f, pb = 0.f, pa = 0.f;
+        const float4 m4 = *reinterpret_cast<const float4*>(mean + (size_t)b * ldt + t), r4 = *reinterpret_cast<const float4*>(rstd + (size_t)b * ldt + t);
+        const double2 p01 = *reinterpret_cast<const double2*>(ws + ((size_t)b * 2 + 0) * ldt + t), p23 = *reinterpret_cast<const double2*>(ws + ((size_t)b * 2 + 0) * ldt + t + 2);
+        const double2 q01 = *reinterpret_cast<const double2*>(ws + ((size_t)b * 2 + 1) * ldt + t), q23 = *reinterpret_cast<const double2*>(ws + ((size_t)b * 2 + 1) * ldt + t + 2);
+        const float ms[4] = {m4.x, m4.y, m4.z, m4.w}, rs[4] = {r4.x, r4.y, r4.z, r4.w};
+        const float Ps[4] = {(float)p01.x, (float)p01.y, (float)p23.x, (float)p23.y}, Qs[4] = {(float)q01.x, (float)q01.y, (float)q23.x, (float)q23.y};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const bool live = t + e < T;
-            const size_t k = (size_t)b * T + t + e;
-            const float m = live ? mean[k] : 0.f, r = live ? rstd[k] : 0.f;
-            const float P = live ? (float)ws[((size_t)b * 2 + 0) * T + t + e] : 0.f, Q = live ? (float)ws[((size_t)b * 2 + 1) * T + t + e] : 0.f;
+            const float m = live ? ms[e] : 0.f, r = live ? rs[e] : 0.f;
+            const float P = live ? Ps[e] : 0.f, Q = live ? Qs[e] : 0.f;
             const float gl = live ? gs[e] : 0.f;
             const float u = act ? prelu_f(xs[e], al) : xs[e];
             const float du = live ? gl * ga * r + P + 2.f * u * Q : 0.f;
@@ -212,7 +220,7 @@ extern "C" int sep_cln_fwd(const float* x, const float* gamma, const float* beta
     SEP_REQUIRE(x && gamma && beta && y && mean && rstd && ws && B > 0 && B <= 65535 && C > 0 && T > 0 && ldt >= T && ldt % 4 == 0, "sep_cln_fwd: bad arguments");
     hipStream_t stream = (hipStream_t)stream_;
     hipLaunchKernelGGL((cln_colsums_kernel<false>), dim3(ceil_div(T, CLN_TCOLS), B), dim3(256), 0, stream, x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, alpha, ws, C, T, ldt);
-    hipLaunchKernelGGL(cln_scan_fwd_kernel, dim3(B), dim3(1024), 0, stream, (const double*)ws, mean, rstd, C, T, eps);
+    hipLaunchKernelGGL(cln_scan_fwd_kernel, dim3(B), dim3(1024), 0, stream, (const double*)ws, mean, rstd, C, T, ldt, eps);
     hipLaunchKernelGGL(cln_apply_fwd_kernel, dim3(ceil_div(C, 4), B), dim3(256), 0, stream, x, (const float*)mean, (const float*)rstd, gamma, beta, alpha, y, C, T, ldt);
     SEP_CHECK_LAUNCH("sep_cln_fwd");
     return 0;
@@ -226,7 +234,7 @@ extern "C" int sep_cln_bwd(const float* dy, const float* x, const float* gamma, 
     SEP_REQUIRE((alpha == nullptr) == (dalpha_part == nullptr), "sep_cln_bwd: alpha and dalpha_part come together");
     hipStream_t stream = (hipStream_t)stream_;
     hipLaunchKernelGGL((cln_colsums_kernel<true>), dim3(ceil_div(T, CLN_TCOLS), B), dim3(256), 0, stream, x, dy, gamma, mean, alpha, ws, C, T, ldt);
-    hipLaunchKernelGGL(cln_scan_bwd_kernel, dim3(B), dim3(1024), 0, stream, ws, mean, rstd, C, T, eps);
+    hipLaunchKernelGGL(cln_scan_bwd_kernel, dim3(B), dim3(1024), 0, stream, ws, mean, rstd, C, T, ldt, eps);
     hipLaunchKernelGGL(cln_apply_bwd_kernel, dim3(ceil_div(C, 4), B), dim3(256), 0, stream, dy, x, mean, rstd, (const double*)ws, gamma, alpha, dx, dgamma_part, dbeta_part, dalpha_part, C, T, ldt);
     SEP_CHECK_LAUNCH("sep_cln_bwd");
     return 0;

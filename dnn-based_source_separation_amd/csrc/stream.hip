@@ -1273,6 +1273,88 @@ __global__ __launch_bounds__(256) void depthwise_bwd_weight_kernel(const float* 
     }
 }
 
+// ---- the TCN layers' own depthwise geometry (stride 1, three taps, Tin = Tout = the workspace stride, `pad` zeros in front: (P - 1) d when
+// causal), one (b, c) row per workgroup, a float4 of frames per thread and trip.  Tap k sits at t + k d - pad.  For shifts that are multiples
+// of 4 the taps are aligned float4 loads; for the others (d = 1, 2: the first two layers of a block) the row goes through LDS once.
+// The generic kernels above take one frame per thread: 130 - 144 us per call at the paper-best sizes (profiles/r05o_causal_kernel_stats.md).
+template <int MODE>      // 0: forward  y = b + sum_k w_k x[t + k d - pad];  1: input gradient  dx[t] = sum_k w_k dy[t - k d + pad]
+__global__ __launch_bounds__(256) void depthwise3_row_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                             float* __restrict__ y, int C, int ldt, int dil, int pad) {
+    extern __shared__ __attribute__((aligned(16))) float rowbuf[];
+    const int row = blockIdx.x, c = row % C;
+    const float* xr = x + (size_t)row * ldt;
+    float* yr = y + (size_t)row * ldt;
+    const float w0 = w[c * 3 + 0], w1 = w[c * 3 + 1], w2 = w[c * 3 + 2];
+    const float bb = (MODE == 0 && bias) ? bias[c] : 0.f;
+    // shifts of the three taps relative to the output frame
+    const int s0 = MODE == 0 ? -pad : pad, s1 = MODE == 0 ? dil - pad : pad - dil, s2 = MODE == 0 ? 2 * dil - pad : pad - 2 * dil;
+    const bool aligned = ((s0 | s1 | s2) & 3) == 0;
+    if (!aligned) {
+        for (int t = 4 * threadIdx.x; t < ldt; t += 1024) st4(rowbuf + t, ld4(xr + t));
+        __syncthreads();
+    }
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 4 * threadIdx.x; t < ldt; t += 1024) {
+        float a0[4], a1[4], a2[4];
+        if (aligned) {
+            const float4 v0 = (t + s0 >= 0 && t + s0 < ldt) ? ld4(xr + t + s0) : zero4;
+            const float4 v1 = (t + s1 >= 0 && t + s1 < ldt) ? ld4(xr + t + s1) : zero4;
+            const float4 v2 = (t + s2 >= 0 && t + s2 < ldt) ? ld4(xr + t + s2) : zero4;
+            a0[0] = v0.x; a0[1] = v0.y; a0[2] = v0.z; a0[3] = v0.w;
+            a1[0] = v1.x; a1[1] = v1.y; a1[2] = v1.z; a1[3] = v1.w;
+            a2[0] = v2.x; a2[1] = v2.y; a2[2] = v2.z; a2[3] = v2.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i0 = t + e + s0, i1 = t + e + s1, i2 = t + e + s2;
+                a0[e] = (i0 >= 0 && i0 < ldt) ? rowbuf[i0] : 0.f;
+                a1[e] = (i1 >= 0 && i1 < ldt) ? rowbuf[i1] : 0.f;
+                a2[e] = (i2 >= 0 && i2 < ldt) ? rowbuf[i2] : 0.f;
+            }
+        }
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaf(w2, a2[e], fmaf(w1, a1[e], fmaf(w0, a0[e], bb)));
+        st4(yr + t, make_float4(o[0], o[1], o[2], o[3]));
+    }
+}
+
+// partial[b][c][k] = sum_t dy[t] x[t + k d - pad] (k < 3), partial[b][c][3] = sum_t dy[t]: one row per workgroup, the x row through LDS
+__global__ __launch_bounds__(256) void depthwise3_wgrad_row_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ partial,
+                                                                   int ldt, int dil, int pad) {
+    extern __shared__ __attribute__((aligned(16))) float rowbuf[];
+    __shared__ float red[4][4];
+    const int row = blockIdx.x;
+    const float* xr = x + (size_t)row * ldt;
+    const float* gr = dy + (size_t)row * ldt;
+    for (int t = 4 * threadIdx.x; t < ldt; t += 1024) st4(rowbuf + t, ld4(xr + t));
+    __syncthreads();
+    float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+    for (int t = 4 * threadIdx.x; t < ldt; t += 1024) {
+        const float4 g4 = ld4(gr + t);
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i0 = t + e - pad, i1 = i0 + dil, i2 = i1 + dil;
+            q0 = fmaf(g[e], (i0 >= 0 && i0 < ldt) ? rowbuf[i0] : 0.f, q0);
+            q1 = fmaf(g[e], (i1 >= 0 && i1 < ldt) ? rowbuf[i1] : 0.f, q1);
+            q2 = fmaf(g[e], (i2 >= 0 && i2 < ldt) ? rowbuf[i2] : 0.f, q2);
+            q3 += g[e];
+        }
+    }
+    q0 = wave_sum(q0); q1 = wave_sum(q1); q2 = wave_sum(q2); q3 = wave_sum(q3);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { red[wv][0] = q0; red[wv][1] = q1; red[wv][2] = q2; red[wv][3] = q3; }
+    __syncthreads();
+    if (threadIdx.x < 4) partial[(size_t)row * 4 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// the row kernels take the TCN layers' geometry: stride 1, three taps, rows of a multiple of 4 frames that fit the LDS
+static inline bool depthwise3_rows(int Tin, int Tout, int Kw, int stride) {
+    static const bool off = getenv("SEPK_DEPTHWISE_ROWS") != nullptr && atoi(getenv("SEPK_DEPTHWISE_ROWS")) == 0;
+    return !off && Kw == 3 && stride == 1 && Tin == Tout && Tin % 4 == 0 && Tin <= 32768;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------
@@ -1655,6 +1737,11 @@ extern "C" int sep_overlap_add(const float* y, float* out, int rows, int T, int 
 extern "C" int sep_depthwise_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C, int Tin, int Tout,
                                  int Kw, int stride, int pad, int dil, sep_stream_t stream) {
     SEP_REQUIRE(x && w && y && B > 0 && C > 0 && Tin > 0 && Tout > 0 && Kw > 0 && stride > 0 && dil > 0 && pad >= 0, "sep_depthwise_fwd: bad arguments");
+    if (depthwise3_rows(Tin, Tout, Kw, stride)) {
+        hipLaunchKernelGGL((depthwise3_row_kernel<0>), dim3((unsigned)((long)B * C)), dim3(256), (size_t)Tin * sizeof(float), (hipStream_t)stream, x, w, bias, y, C, Tin, dil, pad);
+        SEP_CHECK_LAUNCH("sep_depthwise_fwd");
+        return 0;
+    }
     SEP_REQUIRE((long)B * C <= 65535, "sep_depthwise_fwd: B*C too large");
     hipLaunchKernelGGL(depthwise_fwd_kernel, dim3(ceil_div(Tout, 256), B * C), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, C, Tin, Tout, Kw, stride, pad, dil);
     SEP_CHECK_LAUNCH("sep_depthwise_fwd");
@@ -1663,7 +1750,13 @@ extern "C" int sep_depthwise_fwd(const float* x, const float* w, const float* bi
 
 extern "C" int sep_depthwise_bwd_input(const float* dy, const float* w, float* dx, int B, int C, int Tin, int Tout, int Kw,
                                        int stride, int pad, int dil, sep_stream_t stream) {
-    SEP_REQUIRE(dy && w && dx && (long)B * C <= 65535 && stride > 0, "sep_depthwise_bwd_input: bad arguments");
+    SEP_REQUIRE(dy && w && dx && B > 0 && C > 0 && stride > 0, "sep_depthwise_bwd_input: bad arguments");
+    if (depthwise3_rows(Tin, Tout, Kw, stride)) {
+        hipLaunchKernelGGL((depthwise3_row_kernel<1>), dim3((unsigned)((long)B * C)), dim3(256), (size_t)Tin * sizeof(float), (hipStream_t)stream, dy, w, (const float*)nullptr, dx, C, Tin, dil, pad);
+        SEP_CHECK_LAUNCH("sep_depthwise_bwd_input");
+        return 0;
+    }
+    SEP_REQUIRE((long)B * C <= 65535, "sep_depthwise_bwd_input: B*C too large");
     hipLaunchKernelGGL(depthwise_bwd_input_kernel, dim3(ceil_div(Tin, 256), B * C), dim3(256), 0, (hipStream_t)stream, dy, w, dx, C, Tin, Tout, Kw, stride, pad, dil);
     SEP_CHECK_LAUNCH("sep_depthwise_bwd_input");
     return 0;
@@ -1672,6 +1765,11 @@ extern "C" int sep_depthwise_bwd_input(const float* dy, const float* w, float* d
 extern "C" int sep_depthwise_bwd_weight(const float* dy, const float* x, float* partial, int B, int C, int Tin, int Tout, int Kw,
                                         int stride, int pad, int dil, sep_stream_t stream) {
     SEP_REQUIRE(dy && x && partial && B > 0 && C > 0, "sep_depthwise_bwd_weight: bad arguments");
+    if (depthwise3_rows(Tin, Tout, Kw, stride)) {
+        hipLaunchKernelGGL(depthwise3_wgrad_row_kernel, dim3((unsigned)((long)B * C)), dim3(256), (size_t)Tin * sizeof(float), (hipStream_t)stream, dy, x, partial, Tin, dil, pad);
+        SEP_CHECK_LAUNCH("sep_depthwise_bwd_weight");
+        return 0;
+    }
     hipLaunchKernelGGL(depthwise_bwd_weight_kernel, dim3(B * C), dim3(256), 0, (hipStream_t)stream, dy, x, partial, C, Tin, Tout, Kw, stride, pad, dil);
     SEP_CHECK_LAUNCH("sep_depthwise_bwd_weight");
     return 0;

@@ -331,23 +331,24 @@ class ConvTasNet(nn.Module):
         sep = self.separator
         geo = _net.Geometry(T, self.kernel_size, self.stride)
         F_ = geo.F
+        wa = _net._weights_amax(dict(self.named_parameters()))      # ONE operand bound for the ~100 products of the pass (None off the f16x3 arithmetic)
         w = EncodeFn.apply(mixture, self.encoder.conv1d.weight, self.stride, self.enc_nonlinear == "relu")
         x = PaddedCLNFn.apply(w, F_, None, sep.norm1d.gamma, sep.norm1d.beta, sep.norm1d.eps)
-        x = PaddedPointwiseFn.apply(x, F_, sep.bottleneck_conv1d.weight, sep.bottleneck_conv1d.bias, None)
+        x = PaddedPointwiseFn.apply(x, F_, sep.bottleneck_conv1d.weight, sep.bottleneck_conv1d.bias, None, wa)
         total = None
         for block in sep.tdcn.net:
             for layer in block.net:
                 dw = layer.separable_conv1d
                 d, P = layer.dilation, layer.kernel_size
-                a = PaddedPointwiseFn.apply(x, F_, layer.bottleneck_conv1d.weight, layer.bottleneck_conv1d.bias, None)
+                a = PaddedPointwiseFn.apply(x, F_, layer.bottleneck_conv1d.weight, layer.bottleneck_conv1d.bias, None, wa)
                 v1 = PaddedCLNFn.apply(a, F_, layer.nonlinear1d.weight, layer.norm1d.gamma, layer.norm1d.beta, layer.norm1d.eps)
                 z = PaddedDepthwiseFn.apply(v1, F_, dw.depthwise_conv1d.weight, dw.depthwise_conv1d.bias, d, (P - 1) * d)
                 v2 = PaddedCLNFn.apply(z, F_, dw.nonlinear1d.weight, dw.norm1d.gamma, dw.norm1d.beta, dw.norm1d.eps)
-                skip = PaddedPointwiseFn.apply(v2, F_, dw.skip_pointwise_conv1d.weight, dw.skip_pointwise_conv1d.bias, None)
+                skip = PaddedPointwiseFn.apply(v2, F_, dw.skip_pointwise_conv1d.weight, dw.skip_pointwise_conv1d.bias, None, wa)
                 total = skip if total is None else total + skip
                 if dw.dual_head:
-                    x = PaddedPointwiseFn.apply(v2, F_, dw.output_pointwise_conv1d.weight, dw.output_pointwise_conv1d.bias, None) + x
-        m = PaddedPointwiseFn.apply(total, F_, sep.mask_conv1d.weight, sep.mask_conv1d.bias, sep.prelu.weight)
+                    x = PaddedPointwiseFn.apply(v2, F_, dw.output_pointwise_conv1d.weight, dw.output_pointwise_conv1d.bias, None, wa) + x
+        m = PaddedPointwiseFn.apply(total, F_, sep.mask_conv1d.weight, sep.mask_conv1d.bias, sep.prelu.weight, wa)
         m = torch.sigmoid(m) if self.mask_nonlinear == "sigmoid" else torch.softmax(m, dim=1)
         out = MaskDecodeFn.apply(w, m, self.decoder.conv_transpose1d.weight, self.stride, T, want_latent)
         if want_latent:

@@ -109,8 +109,8 @@ class _CumulativeLayerNormFn(torch.autograd.Function):
         else:
             xp = x3
         yp = torch.empty_like(xp)
-        mean, rstd = torch.empty(B, T, **f32), torch.empty(B, T, **f32)
-        ws = torch.empty(B, 2, T, device=x.device, dtype=torch.float64)
+        mean, rstd = torch.empty(B, ldt, **f32), torch.empty(B, ldt, **f32)      # rows of ldt (ABI 20)
+        ws = torch.empty(B, 2, ldt, device=x.device, dtype=torch.float64)
         g1, b1 = gamma.reshape(C).contiguous(), beta.reshape(C).contiguous()
         K.cln_fwd(xp, g1, b1, yp, mean, rstd, ws, B, C, T, ldt, eps)
         if ldt != T:
@@ -136,7 +136,7 @@ class _CumulativeLayerNormFn(torch.autograd.Function):
             dyp = dy3
         dxp = torch.empty_like(xp)
         pg, pb = torch.empty(B, C, **f32), torch.empty(B, C, **f32)
-        ws = torch.empty(B, 2, T, device=xp.device, dtype=torch.float64)
+        ws = torch.empty(B, 2, ldt, device=xp.device, dtype=torch.float64)
         K.cln_bwd(dyp, xp, g1, mean, rstd, dxp, pg, pb, ws, B, C, T, ldt, eps)
         dgamma, dbeta = torch.empty(C, **f32), torch.empty(C, **f32)
         K.reduce_slabs([(pg, 0, dgamma, C, B, C, 0, 1.0), (pb, 0, dbeta, C, B, C, 0, 1.0)])

@@ -119,7 +119,9 @@ class PaddedPointwiseFn(torch.autograd.Function):
     sigmoid (sepkernels/net.py tail_forward / tail_backward)."""
 
     @staticmethod
-    def forward(ctx, x, n_frames, weight, bias, alpha):
+    def forward(ctx, x, n_frames, weight, bias, alpha, a_amax=None):
+        """a_amax: (1,) device tensor >= max|w| over the weights of this and the backward product (SEP_ARITH_F16X3's operand bound), or None:
+        the binding then forms it per call (two small reductions); a model that makes dozens of these calls per pass hands over ONE bound"""
         K = backend()
         x = x.contiguous()
         B, Cin, ldt = x.shape
@@ -128,33 +130,33 @@ class PaddedPointwiseFn(torch.autograd.Function):
             raise NotImplementedError("PaddedPointwiseFn: channel counts must be multiples of 16 (got {} -> {})".format(Cin, Cout))
         y = torch.empty(B, Cout, ldt, device=x.device, dtype=x.dtype)
         pro = dict(pro_mode=_net.PRO_PRELU, pro_alpha=alpha) if alpha is not None else {}
-        K.pw_gemm(B=B, M=Cout, K=Cin, T=n_frames, ldt=ldt, A=weight, X=x, Y=y, bias=bias, **pro)
-        ctx.save_for_backward(x, weight, alpha)
+        K.pw_gemm(B=B, M=Cout, K=Cin, T=n_frames, ldt=ldt, A=weight, X=x, Y=y, bias=bias, a_amax=a_amax, **pro)
+        ctx.save_for_backward(x, weight, alpha, a_amax)
         ctx.meta = (B, Cin, Cout, n_frames, ldt, bias is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         K = backend()
-        x, weight, alpha = ctx.saved_tensors
+        x, weight, alpha, a_amax = ctx.saved_tensors
         B, Cin, Cout, F, ldt, has_bias = ctx.meta
         f32 = dict(device=x.device, dtype=x.dtype)
         dy = dy.contiguous()
         dx = torch.empty(B, Cin, ldt, **f32)
         dalpha = None
         if alpha is None:
-            K.pw_gemm(B=B, M=Cin, K=Cout, T=F, ldt=ldt, trans_a=1, A=weight, X=dy, Y=dx)
+            K.pw_gemm(B=B, M=Cin, K=Cout, T=F, ldt=ldt, trans_a=1, A=weight, X=dy, Y=dx, a_amax=a_amax)
             part, pb, ns = _net._wgrad(K, B, F, ldt, 0.0, f32, Cout, Cin, dy, x, True)
         else:
             slot = torch.zeros(1, device=x.device, dtype=torch.float64)
             K.pw_gemm(B=B, M=Cin, K=Cout, T=F, ldt=ldt, trans_a=1, A=weight, X=dy, Y=dx, epi_flags=_net.EPI_PRELU_BWD, epi_aux=x,
-                      epi_alpha=alpha, epi_dalpha=slot)
+                      epi_alpha=alpha, epi_dalpha=slot, a_amax=a_amax)
             part, pb, ns = _net._wgrad(K, B, F, ldt, 0.0, f32, Cout, Cin, dy, x, True, x_mode=_net.PRO_PRELU, x_alpha=alpha)
             dalpha = torch.empty_like(alpha)
             K.f64_to_f32(slot, dalpha, 1, 0)
         dW, db = torch.empty_like(weight), torch.empty(Cout, **f32)
         K.reduce_slabs([(part, 0, dW, Cout * Cin, ns, Cout * Cin, 0, 1.0), (pb, 0, db, Cout, ns, Cout, 0, 1.0)])
-        return dx, None, dW, (db if has_bias else None), dalpha
+        return dx, None, dW, (db if has_bias else None), dalpha, None
 
 
 class MaskDecodeFn(torch.autograd.Function):
@@ -216,8 +218,8 @@ class PaddedCLNFn(torch.autograd.Function):
         f32 = dict(device=x.device, dtype=x.dtype)
         g1, b1 = gamma.reshape(-1).contiguous(), beta.reshape(-1).contiguous()
         y = torch.empty(B, C, ldt, **f32)
-        mean, rstd = torch.empty(B, n_frames, **f32), torch.empty(B, n_frames, **f32)
-        ws = torch.empty(B, 2, n_frames, device=x.device, dtype=torch.float64)
+        mean, rstd = torch.empty(B, ldt, **f32), torch.empty(B, ldt, **f32)
+        ws = torch.empty(B, 2, ldt, device=x.device, dtype=torch.float64)
         K.cln_fwd(x, g1, b1, y, mean, rstd, ws, B, C, n_frames, ldt, eps, alpha=alpha)
         ctx.save_for_backward(x, g1, mean, rstd, alpha)
         ctx.meta = (B, C, n_frames, ldt, eps, gamma.shape, beta.shape)
@@ -232,7 +234,7 @@ class PaddedCLNFn(torch.autograd.Function):
         dx = torch.empty(B, C, ldt, **f32)
         pg, pb = torch.empty(B, C, **f32), torch.empty(B, C, **f32)
         pa = torch.empty(B, C, **f32) if alpha is not None else None
-        ws = torch.empty(B, 2, F, device=x.device, dtype=torch.float64)
+        ws = torch.empty(B, 2, ldt, device=x.device, dtype=torch.float64)
         K.cln_bwd(dy.contiguous(), x, g1, mean, rstd, dx, pg, pb, ws, B, C, F, ldt, eps, alpha=alpha, dalpha_part=pa)
         dgamma, dbeta = torch.empty(C, **f32), torch.empty(C, **f32)
         segs = [(pg, 0, dgamma, C, B, C, 0, 1.0), (pb, 0, dbeta, C, B, C, 0, 1.0)]

@@ -300,8 +300,9 @@ int sep_softmax_ch_bwd(const float* y, float* g, int B, int C, int T, int ldt, s
 
 /* Cumulative layer norm (causal cLN), CumulativeLayerNorm1d of reference src/modules/norm.py:42-101 and its autograd backward:
  *   y = (x - m_t) / (sqrt(v_t) + eps) * gamma_c + beta_c with the mean / biased variance of all channels and frames <= t.
- * x, y, dy, dx: (B, C, ldt) fp32, frames contiguous, ldt % 4 == 0, frames >= T written as zeros; mean, rstd: (B, T) fp32, written
- * by the forward and read by the backward; ws: (B, 2, T) fp64 scratch (column sums, then their prefix / suffix sums);
+ * x, y, dy, dx: (B, C, ldt) fp32, frames contiguous, ldt % 4 == 0, frames >= T written as zeros; mean, rstd: (B, ldt) fp32 (ABI 20: rows of
+ * ldt, entries >= T untouched), written by the forward and read by the backward; ws: (B, 2, ldt) fp64 scratch (column sums, then their
+ * prefix / suffix sums);
  * dgamma_part, dbeta_part: (B, C) per-sample sums, to be added over the samples (sep_reduce_slabs).
  * alpha (ABI 20; may be NULL): the single slope of a PReLU in FRONT of the norm (tdcn.py:113-116, 182-186: nonlinear1d then norm1d): the
  * kernels normalise u = PReLU(x; alpha), dx is the gradient at x, and dalpha_part (B, C) receives sum_t du * x * [x <= 0] per row. */

@@ -407,10 +407,10 @@ class EmuBackend:
         m = v.sum(1).cumsum(1) / n
         var = ((v * v).sum(1).cumsum(1) / n - m * m).clamp_min(0)
         r = 1.0 / (var.sqrt() + eps)
-        mean.reshape(B, T).copy_(m.to(mean.dtype))           # fp32 on the device; the fp64 emulator runs of the CPU tests keep fp64
-        rstd.reshape(B, T).copy_(r.to(rstd.dtype))
+        mean.reshape(B, ldt)[:, :T] = m.to(mean.dtype)           # rows of ldt; fp32 on the device; the fp64 emulator runs of the CPU tests keep fp64
+        rstd.reshape(B, ldt)[:, :T] = r.to(rstd.dtype)
         out = torch.zeros(B, C, ldt, dtype=x.dtype)
-        mf, rf = mean.reshape(B, 1, T), rstd.reshape(B, 1, T)
+        mf, rf = mean.reshape(B, 1, ldt)[:, :, :T], rstd.reshape(B, 1, ldt)[:, :, :T]
         out[:, :, :T] = (x.reshape(B, C, ldt)[:, :, :T] - mf) * rf * gamma.view(1, C, 1) + beta.view(1, C, 1)
         y.reshape(B, C, ldt).copy_(out)
 
@@ -418,7 +418,7 @@ class EmuBackend:
         g = dy.reshape(B, C, ldt)[:, :, :T].double()
         x_pre = x.reshape(B, C, ldt)[:, :, :T].double()
         v = _prelu(x_pre, alpha) if alpha is not None else x_pre
-        m, r = mean.reshape(B, 1, T).double(), rstd.reshape(B, 1, T).double()
+        m, r = mean.reshape(B, 1, ldt)[:, :, :T].double(), rstd.reshape(B, 1, ldt)[:, :, :T].double()
         gh = g * gamma.view(1, C, 1).double()
         A, Bq = gh.sum(1), (gh * (v - m)).sum(1)
         n = torch.arange(1, T + 1, dtype=torch.float64) * C

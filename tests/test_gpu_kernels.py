@@ -696,6 +696,22 @@ def test_depthwise_generic(Kw, stride, pad, dil, Tin):
     both("depthwise_bwd_weight", [dy, x, nan(B, C, Kw + 1), B, C, Tin, Tout, Kw, stride, pad, dil])
 
 
+@pytest.mark.parametrize("Kw,dil,ldt,causal", [(3, 1, 384, True), (3, 2, 384, True), (3, 4, 512, True), (3, 128, 4096, True), (3, 64, 1024, False), (3, 1, 256, False),
+                                                 (5, 2, 384, True), (3, 3, 260, True)])
+def test_depthwise_tcn_geometry(Kw, dil, ldt, causal):
+    """sep_depthwise_* the way the TCN layers of the staged (causal) path call them: rows of the workspace stride, Tout = Tin, all the
+    zero padding in front ((Kw - 1) d, causal) or the smaller half of it.  Kw = 3 takes the float4 row kernels (aligned taps for d % 4 == 0,
+    the row through LDS otherwise), Kw = 5 the generic ones."""
+    B, C = 2, 24
+    pad = (Kw - 1) * dil if causal else (Kw - 1) * dil // 2
+    x, w, bias = rnd(B, C, ldt), rnd(C, 1, Kw), rnd(C)
+    both("depthwise_fwd", [x, w, bias, nan(B, C, ldt), B, C, ldt, ldt, Kw, 1, pad, dil])
+    both("depthwise_fwd", [x, w, None, nan(B, C, ldt), B, C, ldt, ldt, Kw, 1, pad, dil])
+    dy = rnd(B, C, ldt)
+    both("depthwise_bwd_input", [dy, w, nan(B, C, ldt), B, C, ldt, ldt, Kw, 1, pad, dil])
+    both("depthwise_bwd_weight", [dy, x, nan(B, C, Kw + 1), B, C, ldt, ldt, Kw, 1, pad, dil])
+
+
 @pytest.mark.parametrize("nq,ntile", [(2, 8), (8, 4), (8, 1), (2, 64)])
 def test_gln_bwd_finalize(nq, ntile):
     B, C = 3, 96
@@ -809,8 +825,8 @@ def test_cln_fwd_bwd(B, C, T):
     y64 = (x64 - m.unsqueeze(1)) / (v.sqrt().unsqueeze(1) + eps) * g64.view(1, C, 1) + b64.view(1, C, 1)
     (y64 * dy[..., :T].double()).sum().backward()
     f32 = dict(device=device_name(), dtype=torch.float32)
-    y, mean, rstd = torch.full((B, C, ldt), float("nan"), **f32), torch.empty(B, T, **f32), torch.empty(B, T, **f32)
-    ws = torch.empty(B, 2, T, device=device_name(), dtype=torch.float64)
+    y, mean, rstd = torch.full((B, C, ldt), float("nan"), **f32), torch.empty(B, ldt, **f32), torch.empty(B, ldt, **f32)
+    ws = torch.empty(B, 2, ldt, device=device_name(), dtype=torch.float64)
     HIP.cln_fwd(to_device(x), to_device(gamma), to_device(beta), y, mean, rstd, ws, B, C, T, ldt, eps)
     dx, pg, pb = torch.full((B, C, ldt), float("nan"), **f32), torch.empty(B, C, **f32), torch.empty(B, C, **f32)
     HIP.cln_bwd(to_device(dy), to_device(x), to_device(gamma), mean, rstd, dx, pg, pb, ws, B, C, T, ldt, eps)
@@ -818,13 +834,13 @@ def test_cln_fwd_bwd(B, C, T):
     y, dx = y.cpu(), dx.cpu()
     assert torch.isfinite(y).all() and torch.isfinite(dx).all()
     assert (y[..., T:] == 0).all() and (dx[..., T:] == 0).all()
-    assert (mean.cpu().double() - m.detach()).abs().max() <= 2e-6 * (1 + m.detach().abs().max())
+    assert (mean.cpu().double()[:, :T] - m.detach()).abs().max() <= 2e-6 * (1 + m.detach().abs().max())
     assert (y[..., :T].double() - y64.detach()).abs().max() <= 2e-5 * y64.detach().abs().max()
     assert (dx[..., :T].double() - x64.grad).abs().max() <= 5e-5 * x64.grad.abs().max()
     assert (pg.cpu().double().sum(0) - g64.grad).abs().max() <= 5e-5 * g64.grad.abs().max()
     assert (pb.cpu().double().sum(0) - b64.grad).abs().max() <= 5e-5 * b64.grad.abs().max()
     # and the emulator's restatement of the same contract
-    ye, me, re_ = torch.empty(B, C, ldt), torch.empty(B, T), torch.empty(B, T)
+    ye, me, re_ = torch.empty(B, C, ldt), torch.empty(B, ldt), torch.empty(B, ldt)
     EMU.cln_fwd(x, gamma, beta, ye, me, re_, None, B, C, T, ldt, eps)
     assert (ye - y).abs().max() <= 2e-5 * ye.abs().max()
     dxe, pge, pbe = torch.empty(B, C, ldt), torch.empty(B, C), torch.empty(B, C)
@@ -853,8 +869,8 @@ def test_prelu_cln_fwd_bwd(B, C, T, a):
     y64 = (u64 - m.unsqueeze(1)) / (v.sqrt().unsqueeze(1) + eps) * g64.view(1, C, 1) + b64.view(1, C, 1)
     (y64 * dy[..., :T].double()).sum().backward()
     f32 = dict(device=device_name(), dtype=torch.float32)
-    y, mean, rstd = torch.full((B, C, ldt), float("nan"), **f32), torch.empty(B, T, **f32), torch.empty(B, T, **f32)
-    ws = torch.empty(B, 2, T, device=device_name(), dtype=torch.float64)
+    y, mean, rstd = torch.full((B, C, ldt), float("nan"), **f32), torch.empty(B, ldt, **f32), torch.empty(B, ldt, **f32)
+    ws = torch.empty(B, 2, ldt, device=device_name(), dtype=torch.float64)
     HIP.cln_fwd(to_device(x), to_device(gamma), to_device(beta), y, mean, rstd, ws, B, C, T, ldt, eps, alpha=to_device(alpha))
     dx, pg, pb, pa = torch.full((B, C, ldt), float("nan"), **f32), torch.empty(B, C, **f32), torch.empty(B, C, **f32), torch.empty(B, C, **f32)
     HIP.cln_bwd(to_device(dy), to_device(x), to_device(gamma), mean, rstd, dx, pg, pb, ws, B, C, T, ldt, eps, alpha=to_device(alpha), dalpha_part=pa)
@@ -866,7 +882,7 @@ def test_prelu_cln_fwd_bwd(B, C, T, a):
     assert (pg.cpu().double().sum(0) - g64.grad).abs().max() <= 5e-5 * g64.grad.abs().max()
     assert (pb.cpu().double().sum(0) - b64.grad).abs().max() <= 5e-5 * b64.grad.abs().max()
     assert abs(pa.cpu().double().sum().item() - a64.grad.item()) <= 2e-4 * (x64.grad.abs() * x64.detach().abs()).sum().item() / max(1, B * C) ** 0.5 + 1e-6
-    ye, me, re_ = torch.empty(B, C, ldt), torch.empty(B, T), torch.empty(B, T)
+    ye, me, re_ = torch.empty(B, C, ldt), torch.empty(B, ldt), torch.empty(B, ldt)
     EMU.cln_fwd(x, gamma, beta, ye, me, re_, None, B, C, T, ldt, eps, alpha=alpha)
     assert (ye - y).abs().max() <= 2e-5 * ye.abs().max()
     dxe, pge, pbe, pae = torch.empty(B, C, ldt), torch.empty(B, C), torch.empty(B, C), torch.empty(B, C)

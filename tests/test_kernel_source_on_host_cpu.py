@@ -26,7 +26,8 @@ pytestmark = pytest.mark.skipif(hostsim.compiler() is None, reason="needs clang+
 CASES = [
     ("test_encoder_and_unfold", [(1, 16, 8, 0, 0), (1, 16, 8, 1, 3), (2, 20, 10, 1, 4), (1, 2, 1, 0, 0)]),
     ("test_dwconv_fwd_bwd", [(300, 8), (1030, 64), (2100, 256), (700, 2), (5000, 1)]),
-    ("test_depthwise_generic", [(5, 2, 4, 2, 130), (4, 4, 0, 1, 64)]),
+    ("test_depthwise_generic", [(5, 2, 4, 2, 130), (4, 4, 0, 1, 64), (3, 1, 8, 8, 1000)]),
+    ("test_depthwise_tcn_geometry", [(3, 1, 384, True), (3, 4, 512, True), (3, 64, 1024, False), (5, 2, 384, True)]),
     ("test_gln_bwd_finalize", [(2, 8), (8, 1)]),
     ("test_gln_bwd_finalize_batch", [()]),
     ("test_head_bwd", [(0,), (1,)]),

@@ -548,8 +548,13 @@ def _dual_path_workloads():
     from models.dptnet import DPTNet
     from models.galrnet import GALRNet
     from models.sepformer import SepFormer
+    from models.conv_tasnet import ConvTasNet
     tr = dict(enc_basis="trainable", dec_basis="trainable")
     return {
+        # the reference constructor's default family (causal=True: cLN, all padding on the left) at the paper-best sizes: runs layer by layer
+        # on this library's kernels (models/conv_tasnet.py::_run_staged), batch 16 like the headline
+        "causal": (ConvTasNet, dict(PAPER, causal=True), 16, dict(lr=1e-3), None,
+                   "Conv-TasNet paper-best sizes, CAUSAL (cLN, left padding: reference tdcn.py:98,125-127), staged kernel path"),
         # BASELINE.json configs[3]: egs/wsj0-mix/dprnn-tasnet/train.sh:28-37
         "dprnn": (DPRNNTasNet, dict(n_basis=64, kernel_size=2, stride=1, enc_nonlinear=None, sep_hidden_channels=128, sep_bottleneck_channels=64,
                                     sep_chunk_size=250, sep_hop_size=125, sep_num_blocks=6, sep_norm=True, mask_nonlinear="sigmoid", causal=False,
@@ -589,6 +594,8 @@ def bench_dual_path(args):
     model = cls(**cfg).to(dev)
     problems = model.kernel_path_problems() if hasattr(model, "kernel_path_problems") else []
     assert not problems, problems
+    if args.config == "causal":
+        assert model.staged, model.staged_reason
     crit = PIT1d(NegSISDR(), n_sources=2)
     opt = torch.optim.Adam(model.parameters(), **adam)
     B = recipe_batch if args.batch is None else args.batch
@@ -656,7 +663,7 @@ def bench_dual_path(args):
                     "what": "algorithmic fp32 FLOP of fwd + bwd ({:.0f} GFLOP per utterance, SURVEY.md 8d) / step time vs the dense fp32 MFMA peak".format(gflop)}
         note = "{:.0f} GFLOP per utterance (SURVEY.md 8d): {:.1f} TFLOP/s achieved".format(gflop, tf)
     print(json.dumps({
-        "metric": "separated audio frames/sec (fwd+bwd), {} 2-spk 4s@8kHz".format("DPRNN-TasNet" if args.config == "dprnn" else cls.__name__) +
+        "metric": "separated audio frames/sec (fwd+bwd), {} 2-spk 4s@8kHz".format("DPRNN-TasNet" if args.config == "dprnn" else "causal Conv-TasNet" if args.config == "causal" else cls.__name__) +
                   (" (BASELINE configs[3])" if args.config == "dprnn" else ""), "value": B * F * args.steps / el, "unit": "frames/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": config, "roofline": roofline, "roofline_note": note,
