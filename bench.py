@@ -128,6 +128,10 @@ def main():
                     help="convtasnet2 (default) = BASELINE.json configs[1]/[2], the headline; sinkpit4 = configs[4] (paper-best Conv-TasNet, "
                          "4 speakers, SinkPIT(NegSI-SDR, coldness 1, 200 iterations)); dprnn = configs[3] (DPRNN-TasNet N64 L2 F64 H128 K250 P125 B6, batch 2); dptnet / galrnet / sepformer = the reference recipes' "
                          "own sizes of those separators (SURVEY.md section 8 row f4)")
+    ap.add_argument("--basis", default="trainable", choices=["trainable", "fourier", "pinv"],
+                    help="convtasnet2 only: the filterbank -- trainable / trainable (the headline), Fourier / Fourier with the recipe's two-sided real-valued "
+                         "latent, or trainable / pseudo-inverse (the reference README's other two published rows): linear filterbanks run the fused "
+                         "kernel sequence on bases derived from their parameters")
     ap.add_argument("--sink-iters", type=int, default=200, help="sinkpit4: Sinkhorn iterations (the tutorial recipe uses 200; the paper's ablation 10)")
     args = ap.parse_args()
     if args.config in ("causal", "dprnn", "dptnet", "galrnet", "sepformer"):
@@ -189,7 +193,12 @@ def main():
         crit = SinkPIT(NegSISDR(), n_sources=4, coldness=1.0, iteration=args.sink_iters)
     else:
         crit = PIT1d(NegSISDR(), n_sources=2)
+    if args.basis == "fourier":
+        cfg_model.update(enc_basis="Fourier", dec_basis="Fourier", window_fn="hann", enc_onesided=0, enc_return_complex=0)
+    elif args.basis == "pinv":
+        cfg_model.update(dec_basis="pinv")
     model = ConvTasNet(**cfg_model).to(dev)
+    assert args.basis == "trainable" or model.fused_derived
     step = FusedTrainStep(model, crit, lr=1e-3, max_norm=5.0, time_collectives=world > 1 and not dry)   # recipe defaults: adam 1e-3, clip 5 (train.sh:50-57)
     g = torch.Generator().manual_seed(111 + rank)
     sources = (0.1 * torch.randn(args.batch, n_src, t_samples, generator=g)).to(dev)
@@ -292,6 +301,8 @@ def main():
         paper_name = "Conv-TasNet paper-best (N=512,L=16,B=128,H=512,Sc=128,P=3,X=8,R=3)"
         if args.config == "convtasnet2":
             workload = "{} 2-spk, 4 s @ 8 kHz synthetic mixtures, {} utterances/GPU, fwd + PIT(NegSI-SDR) + bwd + clip(5) + Adam".format(paper_name, args.batch)
+            if args.basis != "trainable":
+                workload += " -- filterbank: " + {"fourier": "Fourier / Fourier (two-sided, real-valued latent)", "pinv": "trainable / pseudo-inverse"}[args.basis]
         else:
             workload = ("{} 4-spk, softmax mask, 4 s @ 8 kHz synthetic mixtures, {} utterances/GPU, fwd + SinkPIT(NegSI-SDR, coldness 1, "
                         "{} iterations) + bwd + clip(5) + Adam").format(paper_name, args.batch, args.sink_iters)

@@ -54,10 +54,13 @@ class _FusedConvTasNetFn(torch.autograd.Function):
             return (None, None, None, None, None) + tuple(None for _ in params)
         # one flat gradient buffer with the same packing as ConvTasNet._flatten_parameters
         offs, total = _layout([(n, p.numel()) for n, p in zip(names, params)])
-        flat = ctx.grad_sink
+        placed = ctx.grad_sink if isinstance(ctx.grad_sink, dict) else None      # derived-basis models: name -> where that gradient goes
+        flat = None if placed is not None else ctx.grad_sink
         if flat is None or flat.numel() != total:
             flat = torch.empty(total, device=d_est.device, dtype=d_est.dtype)
         G = {n: flat[offs[n]:offs[n] + p.numel()].view(p.shape) for n, p in zip(names, params)}
+        if placed is not None:
+            G.update(placed)
         hook = ctx.bucket_hook if flat is ctx.grad_sink else None
         on_ready = None
         if hook is not None:
@@ -72,7 +75,7 @@ class _FusedConvTasNetFn(torch.autograd.Function):
         if hook is not None:
             hook(0, starts[1] if ctx.cfg["sep_num_blocks"] > 1 else total)
         ctx.sv = None
-        grads = tuple(G[n] for n in names)
+        grads = tuple(None if (placed is not None and n in placed) else G[n] for n in names)      # placed: already where the caller wants them
         G = None
         return (None, None, None, None, None) + grads
 
@@ -177,13 +180,20 @@ class ConvTasNet(nn.Module):
         # PReLU + cLN in sep_cln_*, the dilated depthwise taps in sep_depthwise_*, encoder / mask / decoder as in the fused path -- on
         # (B, C, ldt) workspace rows throughout.  Not one fused sequence (each norm is a pass of its own), no torch convolution either.
         self.staged, self.staged_reason = self._staged_supported()
+        # ... and the LINEAR filterbanks other than the learned pair -- Fourier bases (fixed / trainable frequencies / trainable phase) with a
+        # real-valued two-sided latent, the pseudo-inverse decoder: the reference recipe's settings for its published "Fourier / Fourier" and
+        # "trainable / pseudo-inverse" rows (egs/wsj0-mix/conv-tasnet/train.sh:21-26, README rows 3-4) -- are a convolution with SOME analysis
+        # matrix and a transposed convolution with SOME synthesis matrix: the fused kernel sequence runs them unchanged on bases that torch
+        # forms from the filterbank's parameters each pass (a few hundred kilobytes), and autograd carries the kernels' basis gradients back
+        # into frequency / phase / window / encoder weight.  `fused_derived`.
+        self.fused_derived = (not self.fused) and self._derived_supported()
         self._flatten_parameters()
 
     # ------------------------------------------------------------------ parameter storage
     def _flatten_parameters(self):
         """Re-home every parameter as a view of one flat buffer (see _layout).  Idempotent; called after
         construction and after every .to()/.cuda()/.float() (nn.Module._apply)."""
-        named = [(n, p) for n, p in self.named_parameters()]
+        named = [(n, p) for n, p in self.named_parameters() if p.is_floating_point()]      # (a Fourier basis keeps an integer `time_seq`: not part of the buffer)
         if not named:
             return
         dev, dt = named[0][1].device, named[0][1].dtype
@@ -211,7 +221,7 @@ class ConvTasNet(nn.Module):
         if self._flat is None:
             return None
         for n, p in self.named_parameters():   # cheap sanity: views still intact?
-            if p.data_ptr() != self._flat.data_ptr() + 4 * self._offsets[n]:
+            if p.is_floating_point() and p.data_ptr() != self._flat.data_ptr() + self._flat.element_size() * self._offsets[n]:
                 self._flatten_parameters()
                 break
         return self._flat
@@ -246,6 +256,11 @@ class ConvTasNet(nn.Module):
         cfg = self.get_config()
         if mixture.size(1) != self.in_channels:
             raise ValueError("input has {} channels, the model was built with in_channels={}".format(mixture.size(1), self.in_channels))
+        if self.fused_derived and ((mixture.is_cuda and mixture.dtype == torch.float32) or _net.backend().name != "hip"):
+            est, latent = self._run_fused_derived(mixture.contiguous(), want_latent)
+            if n_dims == 3:
+                est = est.view(batch_size, self.n_sources, T)
+            return est, latent
         if not self.fused and self.staged and ((mixture.is_cuda and mixture.dtype == torch.float32) or _net.backend().name != "hip"):
             est, latent = self._run_staged(mixture.contiguous(), want_latent)
             if n_dims == 3:
@@ -295,6 +310,69 @@ class ConvTasNet(nn.Module):
             raise RuntimeError("ConvTasNet has no parameters to run with (a module replica without `_former_parameters`?); for "
                                "multi-GPU training use one process per GPU with sepkernels.train.FusedTrainStep")
         return out
+
+    _FOURIER_BASES = ("Fourier", "trainableFourier", "trainableFourierTrainablePhase")
+
+    def _derived_cfg(self):
+        return dict(self.get_config(), enc_basis="trainable", dec_basis="trainable", enc_nonlinear=None)
+
+    def _derived_supported(self):
+        enc, dec = self.enc_basis, self.dec_basis
+        fourier = self._FOURIER_BASES
+        if enc == "trainable" and dec == "trainable":
+            return False                                         # the fused family proper (or outside it for another reason)
+        if enc not in ("trainable",) + fourier or dec not in ("trainable", "pinv") + fourier:
+            return False                                         # gated encoder: not linear
+        if (enc in fourier or dec in fourier) and (self.enc_onesided or self.enc_return_complex):
+            return False                                         # complex latent (magnitude masked, phase kept) / one-sided (N + 2 rows: not a multiple of 16)
+        if enc == "trainable" and self.enc_nonlinear:
+            return False
+        try:
+            _net.check_supported(self._derived_cfg())
+        except NotImplementedError:
+            return False
+        return True
+
+    def _derived_bases(self):
+        """(E, D): analysis basis (N, in_channels, L) and synthesis basis (N, in_channels, L) of this model's filterbank, differentiable in
+        its parameters.  Row order = the reference's channel order: Fourier [real parts of all bins | imaginary parts], reference
+        src/models/filterbank.py:60-113 (encoder), :160-203 (decoder), :253-323 (pseudo-inverse)."""
+        from models.filterbank import FourierEncoder, FourierDecoder, PinvDecoder, _all_bins
+        enc, dec = self.encoder, self.decoder
+        if isinstance(enc, FourierEncoder):
+            E = enc.get_basis().unsqueeze(1)                     # [window cos ; -window sin] over all bins
+        else:
+            E = enc.conv1d.weight
+
+        def synthesis(mod, window):                              # est = convT(xr, br) - convT(xi, bi): one transposed convolution with [br ; -bi]
+            ang = mod._angles()
+            n = mod.n_basis
+            br, bi = _all_bins(torch.cos(ang), n, 0, 1.0), _all_bins(torch.sin(ang), n, 0, -1.0)
+            return torch.cat([window * br / n, -(window * bi / n)], 0).unsqueeze(1)
+        if isinstance(dec, FourierDecoder):
+            D = synthesis(dec, dec.optimal_window)
+        elif isinstance(dec, PinvDecoder):
+            D = synthesis(enc, enc.window) if isinstance(enc, FourierEncoder) else dec.get_basis()
+        else:
+            D = dec.conv_transpose1d.weight
+        return E.contiguous(), D.contiguous()
+
+    def _run_fused_derived(self, mixture, want_latent):
+        cfg = self._derived_cfg()
+        E, D = self._derived_bases()
+        sep = [(n, p) for n, p in self._named_tensors() if n.startswith("separator.")]
+        names = ("encoder.conv1d.weight",) + tuple(n for n, _ in sep) + ("decoder.conv_transpose1d.weight",)
+        # inside FusedTrainStep the separator's gradients go straight to their places in the step's flat buffer (no per-tensor .grad copies);
+        # only the two bases' gradients travel through autograd into the filterbank's few parameters
+        sink, placed = getattr(self, "_grad_sink", None), None
+        if sink is not None and self._flat is not None and sink.numel() == self._flat.numel():
+            placed = {n: sink[self._offsets[n]:self._offsets[n] + p.numel()].view(p.shape) for n, p in sep}
+            self._sink_placed = True
+        out = _FusedConvTasNetFn.apply(mixture.float() if _net.backend().name == "hip" else mixture, cfg, names, want_latent, placed, E, *[p for _, p in sep], D)
+        if want_latent:
+            est, latent = out
+            return est, latent[..., :_net.Geometry(mixture.shape[-1], self.kernel_size, self.stride).F]
+        return out, None
 
     def _staged_supported(self):
         cfg = self.get_config()

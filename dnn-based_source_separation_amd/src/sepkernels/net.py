@@ -95,15 +95,22 @@ class Saved:
 
 
 def amax_over(ts):
-    """(1,) tensor >= max|t| over the tensors ts: ONE reduction when they are views of one buffer (spans it, alignment gaps
-    included -- they are zero), else one per tensor."""
-    lo = min(ts, key=lambda t: t.data_ptr())
-    hi = max(ts, key=lambda t: t.data_ptr())
-    n = (hi.data_ptr() - lo.data_ptr()) // lo.element_size() + hi.numel()
-    same = all(t.untyped_storage().data_ptr() == lo.untyped_storage().data_ptr() and t.dtype == lo.dtype for t in ts)
-    if same and lo.is_contiguous() and n <= 4 * sum(t.numel() for t in ts):
-        return lo.detach().as_strided((n,), (1,)).abs().amax().reshape(1)
-    return torch.stack([t.detach().abs().amax().float() for t in ts]).amax().reshape(1)
+    """(1,) tensor >= max|t| over the tensors ts.  Tensors that are views of ONE buffer take one reduction over the span they cover
+    (alignment gaps included -- they are zero); a model whose parameters live in one flat buffer plus a few derived tensors (the bases of a
+    Fourier / pseudo-inverse filterbank) takes one reduction per buffer, not one per tensor (that was ~300 launches per pass)."""
+    groups = {}
+    for t in ts:
+        groups.setdefault((t.untyped_storage().data_ptr(), t.dtype), []).append(t)
+    parts = []
+    for g in groups.values():
+        lo = min(g, key=lambda t: t.data_ptr())
+        hi = max(g, key=lambda t: t.data_ptr())
+        n = (hi.data_ptr() - lo.data_ptr()) // lo.element_size() + hi.numel()
+        if lo.is_contiguous() and n <= 4 * sum(t.numel() for t in g):
+            parts.append(lo.detach().as_strided((n,), (1,)).abs().amax().float())
+        else:
+            parts.extend(t.detach().abs().amax().float() for t in g)
+    return (parts[0] if len(parts) == 1 else torch.stack(parts).amax()).reshape(1)
 
 
 def _weights_amax(P):

@@ -63,12 +63,12 @@ class FusedTrainStep:
         """None when every parameter trains (the usual case: nothing extra runs), else a 0 / 1 vector over the flat buffer, rebuilt when the
         set of frozen parameters changes.  Frozen parameters (requires_grad = False) get a zero gradient before the norm is taken, and their
         values / moments are put back after the fused Adam (which would otherwise apply weight decay to them); alignment gaps hold zeros."""
-        key = tuple(p.requires_grad for p in self.model.parameters())
+        key = tuple(p.requires_grad for p in self._params())
         if all(key):
             return None
         if getattr(self, "_mask_key", None) != key or self._mask.device != self.flat.device:
             mask = torch.zeros_like(self.flat)
-            for (off, n, _), p in zip(self._spans(), self.model.parameters()):
+            for (off, n, _), p in zip(self._spans(), self._params()):
                 if p.requires_grad:
                     mask[off:off + n] = 1.0
             self._mask, self._mask_key = mask, key
@@ -149,6 +149,7 @@ class FusedTrainStep:
             self._rebind()
         self.zero_grad()
         model._grad_sink = self.gflat                 # backward writes every gradient straight into the flat buffer
+        model._sink_placed = False
         works = []
         self.last_bucket_bytes = []
         count_work = None
@@ -169,6 +170,25 @@ class FusedTrainStep:
         finally:
             model._grad_sink = None
             model._grad_bucket_hook = None
+        if not getattr(model, "fused", True):
+            # the module-by-module / staged / derived-basis paths of ConvTasNet leave their gradients in .grad like any torch module: put
+            # them where the flat step reads them (a parameter without a gradient -- a fixed Fourier basis, a frozen tensor -- contributes
+            # zeros).  The derived-basis path has written the separator's gradients in place already (_sink_placed): only the rest moves.
+            placed = bool(getattr(model, "_sink_placed", False))
+            model._sink_placed = False
+            if not placed:
+                self.gflat.zero_()
+            dst, src = [], []
+            for (off, n, _), (name, q) in zip(self._spans(), [(k, v) for k, v in model.named_parameters() if v.is_floating_point()]):
+                if placed and name.startswith("separator."):
+                    continue
+                if q.grad is not None:
+                    dst.append(self.gflat[off:off + n])
+                    src.append(q.grad.reshape(-1))
+                elif placed:
+                    self.gflat[off:off + n].zero_()
+            if dst:
+                torch._foreach_copy_(dst, src)
         self.last_buckets = len(works)
         grad_scale = 1.0 / self.world
         if self.world > 1:
@@ -214,10 +234,14 @@ class FusedTrainStep:
 
     # ---- optimizer state in torch.optim.Adam's state_dict layout (checkpoint interchange with the reference's
     #      driver.py:208-226 / 51-68: `optim_dict`) ---------------------------------------------------------
+    def _params(self):
+        """the parameters that live in the flat buffer: every floating-point one (a Fourier basis carries an integer `time_seq`)"""
+        return [p for p in self.model.parameters() if p.is_floating_point()]
+
     def _spans(self):
         base = self.flat.data_ptr()
         spans = []
-        for p in self.model.parameters():
+        for p in self._params():
             off = (p.data_ptr() - base) // self.flat.element_size()
             if off < 0 or off + p.numel() > self.flat.numel():
                 raise RuntimeError("parameter is not a view of the flat buffer")

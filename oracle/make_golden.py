@@ -90,14 +90,26 @@ CONFIGS = {
                          enc_onesided=0, enc_return_complex=0, sep_hidden_channels=48, sep_bottleneck_channels=32, sep_skip_channels=32,
                          sep_kernel_size=3, sep_num_blocks=1, sep_num_layers=2, dilated=True, separable=True, causal=False, sep_nonlinear="prelu",
                          sep_norm=True, mask_nonlinear="sigmoid", n_sources=2),
+    # the reference recipe's settings for its published "Fourier / Fourier" row (train.sh:21-26: two-sided, real-valued latent) and the same
+    # with trainable frequencies and phases on both sides: linear filterbanks -> the fused kernel sequence on derived bases
+    "fourier_real": dict(n_basis=64, kernel_size=16, stride=8, enc_basis="Fourier", dec_basis="Fourier", enc_nonlinear=None, window_fn="hann",
+                         enc_onesided=0, enc_return_complex=0, sep_hidden_channels=64, sep_bottleneck_channels=32, sep_skip_channels=32,
+                         sep_kernel_size=3, sep_num_blocks=1, sep_num_layers=3, dilated=True, separable=True, causal=False, sep_nonlinear="prelu",
+                         sep_norm=True, mask_nonlinear="sigmoid", n_sources=2),
+    "fourier_phase_real": dict(n_basis=32, kernel_size=32, stride=16, enc_basis="trainableFourierTrainablePhase", dec_basis="trainableFourierTrainablePhase",
+                               enc_nonlinear=None, window_fn="hamming", enc_onesided=0, enc_return_complex=0, sep_hidden_channels=48,
+                               sep_bottleneck_channels=32, sep_skip_channels=32, sep_kernel_size=3, sep_num_blocks=1, sep_num_layers=2, dilated=True,
+                               separable=True, causal=False, sep_nonlinear="prelu", sep_norm=True, mask_nonlinear="softmax", n_sources=3),
     "pinv": dict(n_basis=64, kernel_size=16, stride=8, enc_basis="trainable", dec_basis="pinv", enc_nonlinear=None, sep_hidden_channels=48,
                  sep_bottleneck_channels=32, sep_skip_channels=32, sep_kernel_size=3, sep_num_blocks=1, sep_num_layers=2, dilated=True,
                  separable=True, causal=False, sep_nonlinear="prelu", sep_norm=True, mask_nonlinear="sigmoid", n_sources=2),
 }
 SHAPES = {"tiny": (1, 4000), "mid": (2, 3203), "softmax": (2, 2500),   # (batch, samples); 3203 / 2500 exercise the input padding branch
           "causal": (2, 2403), "causal16": (2, 2403), "causal16_p5": (3, 1500), "plainconv": (2, 2000), "nodil": (1, 1607),
-          "fourier": (2, 1603), "fourier_phase": (2, 1603), "fourier_pinv": (1, 1603), "pinv": (2, 1603)}
-COMPOSED = ("causal", "plainconv", "nodil", "fourier", "fourier_phase", "fourier_pinv", "pinv")
+          "fourier": (2, 1603), "fourier_phase": (2, 1603), "fourier_pinv": (1, 1603), "pinv": (2, 1603), "fourier_real": (2, 1603),
+          "fourier_phase_real": (2, 1603)}
+COMPOSED = ("causal", "plainconv", "nodil", "fourier", "fourier_phase", "fourier_pinv", "pinv", "fourier_real", "fourier_phase_real")
+DERIVED = ("fourier_pinv", "pinv", "fourier_real", "fourier_phase_real")      # linear filterbanks: the fused sequence on bases formed from their parameters
 STAGED = ("causal16", "causal16_p5")      # causal, on kernels layer by layer
 
 

@@ -12,7 +12,7 @@ import torch
 
 import sepkernels
 from emulator import EmuBackend
-from oracle.make_golden import CONFIGS, COMPOSED, STAGED
+from oracle.make_golden import CONFIGS, COMPOSED, STAGED, DERIVED
 from models.conv_tasnet import ConvTasNet
 from models.tdcn import TimeDilatedConvNet, ResidualBlock1d
 from modules.norm import CumulativeLayerNorm1d
@@ -40,6 +40,7 @@ def _load(golden_dir, name, dtype=torch.float64):
 def test_composed_path_matches_the_reference(golden_dir, name, emu):
     g, model = _load(golden_dir, name)
     assert not model.fused and model.fused_reason          # decided at construction, with the reason on record
+    assert model.fused_derived == (name in DERIVED)        # linear filterbanks run the fused sequence on derived bases
     assert model.num_parameters == int(g["num_parameters"])
     mixture, sources = torch.from_numpy(g["mixture"]).double(), torch.from_numpy(g["sources"]).double()
     est, latent = model.extract_latent(mixture)

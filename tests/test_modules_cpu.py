@@ -343,3 +343,33 @@ def test_checkpoints_load_through_the_safe_unpickler(tmp_path):
     with pytest.raises(RuntimeError):
         load_checkpoint(bad)
     assert load_checkpoint(bad, trust_pickle=True)["thing"] == fractions.Fraction(1, 3)
+
+
+def test_fused_train_step_moves_the_parameters_of_non_fused_models(emu):
+    """FusedTrainStep on a ConvTasNet outside the fused family (staged causal, derived-basis Fourier): their gradients arrive in .grad, the
+    flat step has to pick them up -- one step must equal torch.optim.Adam on the same gradients."""
+    import copy
+    from oracle.make_golden import CONFIGS
+    from sepkernels.train import FusedTrainStep
+    from criterion.sdr import NegSISDR
+    from criterion.pit import PIT1d
+    for name in ("causal16_p5", "fourier_phase_real"):
+        torch.manual_seed(5)
+        model = ConvTasNet(**CONFIGS[name]).double()
+        assert not model.fused
+        ref = copy.deepcopy(model)
+        start = {k: q.detach().clone() for k, q in model.named_parameters()}
+        src = 0.1 * torch.randn(2, CONFIGS[name]["n_sources"], 900, dtype=torch.float64)
+        mix = src.sum(1, keepdim=True)
+        crit = PIT1d(NegSISDR(), n_sources=CONFIGS[name]["n_sources"])
+        step = FusedTrainStep(model, crit, lr=1e-3, max_norm=5.0)
+        step(mix, src)
+        opt = torch.optim.Adam([q for q in ref.parameters() if q.requires_grad], lr=1e-3)
+        crit(ref(mix), src)[0].backward()
+        torch.nn.utils.clip_grad_norm_([q for q in ref.parameters() if q.requires_grad], 5.0)
+        opt.step()
+        moved = 0.0
+        for (k, q), (_, r) in zip(model.named_parameters(), ref.named_parameters()):
+            assert (q - r).abs().max() <= 1e-9 * max(1.0, r.abs().max().item()), k
+            moved = max(moved, (q.detach() - start[k]).abs().max().item())
+        assert moved > 0
