@@ -401,10 +401,10 @@ class ConvTasNet(nn.Module):
         this library's kernels on (B, C, ldt) rows, autograd through sepkernels.functional:
             encoder (+ReLU)                  EncodeFn                         sep_encoder_fwd
             cLN, 1x1 bottleneck              PaddedCLNFn, PaddedPointwiseFn   sep_cln_*, sep_pw_gemm
-            per layer  1x1 -> PReLU+cLN -> depthwise (left padding (P-1) d) -> PReLU+cLN -> 1x1 output (+ residual) / 1x1 skip
-                                             PaddedPointwiseFn, PaddedCLNFn, PaddedDepthwiseFn
+            per layer  1x1 -> PReLU+cLN -> depthwise (left padding (P-1) d) -> PReLU+cLN -> [1x1 output + residual ; 1x1 skip, summed]
+                                             PaddedPointwiseFn, PaddedCLNFn, PaddedDepthwiseFn, PaddedHeadsFn
             PReLU + 1x1 mask, sigmoid | softmax, mask * w -> decoder -> crop     PaddedPointwiseFn, torch elementwise, MaskDecodeFn"""
-        from sepkernels.functional import EncodeFn, PaddedPointwiseFn, PaddedCLNFn, PaddedDepthwiseFn, MaskDecodeFn
+        from sepkernels.functional import EncodeFn, PaddedPointwiseFn, PaddedCLNFn, PaddedDepthwiseFn, PaddedHeadsFn, MaskDecodeFn
         B, Cin, T = mixture.shape
         sep = self.separator
         geo = _net.Geometry(T, self.kernel_size, self.stride)
@@ -422,10 +422,9 @@ class ConvTasNet(nn.Module):
                 v1 = PaddedCLNFn.apply(a, F_, layer.nonlinear1d.weight, layer.norm1d.gamma, layer.norm1d.beta, layer.norm1d.eps)
                 z = PaddedDepthwiseFn.apply(v1, F_, dw.depthwise_conv1d.weight, dw.depthwise_conv1d.bias, d, (P - 1) * d)
                 v2 = PaddedCLNFn.apply(z, F_, dw.nonlinear1d.weight, dw.norm1d.gamma, dw.norm1d.beta, dw.norm1d.eps)
-                skip = PaddedPointwiseFn.apply(v2, F_, dw.skip_pointwise_conv1d.weight, dw.skip_pointwise_conv1d.bias, None, wa)
-                total = skip if total is None else total + skip
-                if dw.dual_head:
-                    x = PaddedPointwiseFn.apply(v2, F_, dw.output_pointwise_conv1d.weight, dw.output_pointwise_conv1d.bias, None, wa) + x
+                out = dw.output_pointwise_conv1d if dw.dual_head else None
+                x, total = PaddedHeadsFn.apply(v2, F_, out.weight if out is not None else None, out.bias if out is not None else None,
+                                               dw.skip_pointwise_conv1d.weight, dw.skip_pointwise_conv1d.bias, x, total, wa)
         m = PaddedPointwiseFn.apply(total, F_, sep.mask_conv1d.weight, sep.mask_conv1d.bias, sep.prelu.weight, wa)
         m = torch.sigmoid(m) if self.mask_nonlinear == "sigmoid" else torch.softmax(m, dim=1)
         out = MaskDecodeFn.apply(w, m, self.decoder.conv_transpose1d.weight, self.stride, T, want_latent)

@@ -243,6 +243,77 @@ class PaddedCLNFn(torch.autograd.Function):
         return dx, None, dalpha, dgamma.view(gshape), dbeta.view(bshape), None
 
 
+class PaddedHeadsFn(torch.autograd.Function):
+    """The two 1x1 heads of a TCN layer on workspace rows in ONE pass over their input (reference tdcn.py:188-196 + :145-147 + the skip sum
+    of :36-41, 70-75): out = Wo v + bo + x_res, total += Ws v + bs.  v (B, H, ldt); x_res (B, Bn, ldt); total (B, Sc, ldt) or None (first
+    layer: created) -- UPDATED IN PLACE and returned; Wo / bo None for a layer without the output head.  With Bn % 128 == 0 and the two
+    weight matrices adjacent in memory (ConvTasNet's flat parameter buffer keeps them so) it is one product over [Wo; Ws] with the residual
+    and the accumulation in its epilogue, and one product [Wo; Ws]^T [d out; d total] backward -- instead of two products, two additions
+    forward and two products plus the addition of two H-tensors backward."""
+
+    @staticmethod
+    def forward(ctx, v, n_frames, Wo, bo, Ws, bs, x_res, total, a_amax=None):
+        K = backend()
+        v = v.contiguous()
+        B, H, ldt = v.shape
+        Sc = Ws.shape[0]
+        Bn = Wo.shape[0] if Wo is not None else 0
+        f32 = dict(device=v.device, dtype=v.dtype)
+        first = total is None
+        if first:
+            total = torch.empty(B, Sc, ldt, **f32)
+        else:
+            ctx.mark_dirty(total)
+        xo = torch.empty(B, Bn, ldt, **f32) if Wo is not None else None
+        joint = Wo is not None and Bn % 128 == 0 and _net._adjacent(Wo, Ws) and _net._adjacent(bo, bs)
+        if joint:
+            K.pw_gemm(B=B, M=Bn + Sc, K=H, T=n_frames, ldt=ldt, A=Wo.as_strided((Bn + Sc, H), (H, 1)), X=v, Y=xo, Y2=total, m_split=Bn,
+                      bias=bo.as_strided((Bn + Sc,), (1,)), accumulate=int(not first), epi_flags=_net.EPI_RESIDUAL, epi_res=x_res, a_amax=a_amax)
+        else:
+            if Wo is not None:
+                K.pw_gemm(B=B, M=Bn, K=H, T=n_frames, ldt=ldt, A=Wo, X=v, Y=xo, bias=bo, epi_flags=_net.EPI_RESIDUAL, epi_res=x_res, a_amax=a_amax)
+            K.pw_gemm(B=B, M=Sc, K=H, T=n_frames, ldt=ldt, A=Ws, X=v, Y=total, bias=bs, accumulate=int(not first), a_amax=a_amax)
+        ctx.save_for_backward(v, Wo, Ws, a_amax)
+        ctx.meta = (B, H, Bn, Sc, n_frames, ldt, first)
+        ctx.set_materialize_grads(False)
+        return (xo, total) if Wo is not None else (None, total)
+
+    @staticmethod
+    def backward(ctx, d_out, d_total):
+        K = backend()
+        v, Wo, Ws, a_amax = ctx.saved_tensors
+        B, H, Bn, Sc, F, ldt, first = ctx.meta
+        f32 = dict(device=v.device, dtype=v.dtype)
+        if d_total is None:
+            d_total = torch.zeros(B, Sc, ldt, **f32)
+        d_total = d_total.contiguous()
+        have_o = Wo is not None and d_out is not None
+        if have_o:
+            d_out = d_out.contiguous()
+        dv = torch.empty(B, H, ldt, **f32)
+        if have_o:
+            K.pw_gemm(B=B, M=H, K=Bn + Sc, T=F, ldt=ldt, trans_a=1, A=Wo, A2=Ws, X=d_out, X2=d_total, k_split=Bn, Y=dv, a_amax=a_amax)
+        else:
+            K.pw_gemm(B=B, M=H, K=Sc, T=F, ldt=ldt, trans_a=1, A=Ws, X=d_total, Y=dv, a_amax=a_amax)
+        segs = []
+        dWo = dbo = None
+        dWs, dbs = torch.empty_like(Ws), torch.empty(Sc, **f32)
+        if have_o and Bn % 128 == 0:
+            dWo, dbo = torch.empty_like(Wo), torch.empty(Bn, **f32)
+            part, pb, ns = _net._wgrad(K, B, F, ldt, 0.0, f32, Bn + Sc, H, d_out, v, True, G2=d_total, g_split=Bn)
+            segs += [(part, 0, dWo, Bn * H, ns, (Bn + Sc) * H, 0, 1.0), (part, Bn * H, dWs, Sc * H, ns, (Bn + Sc) * H, 0, 1.0),
+                     (pb, 0, dbo, Bn, ns, Bn + Sc, 0, 1.0), (pb, Bn, dbs, Sc, ns, Bn + Sc, 0, 1.0)]
+        else:
+            if have_o:
+                dWo, dbo = torch.empty_like(Wo), torch.empty(Bn, **f32)
+                part, pb, ns = _net._wgrad(K, B, F, ldt, 0.0, f32, Bn, H, d_out, v, True)
+                segs += [(part, 0, dWo, Bn * H, ns, Bn * H, 0, 1.0), (pb, 0, dbo, Bn, ns, Bn, 0, 1.0)]
+            part2, pb2, ns2 = _net._wgrad(K, B, F, ldt, 0.0, f32, Sc, H, d_total, v, True)
+            segs += [(part2, 0, dWs, Sc * H, ns2, Sc * H, 0, 1.0), (pb2, 0, dbs, Sc, ns2, Sc, 0, 1.0)]
+        K.reduce_slabs(segs)
+        return dv, None, dWo, dbo, dWs, dbs, (d_out if have_o else None), (None if first else d_total), None
+
+
 class PaddedDepthwiseFn(torch.autograd.Function):
     """nn.Conv1d(C, C, k, dilation=d, groups=C) of a TCN layer on rows that carry the workspace stride, with the layer's zero padding folded
     in: `left` zeros in front (causal: (k - 1) d, all of it; else the smaller half -- reference tdcn.py:118-129), the output has the input's

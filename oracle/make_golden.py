@@ -66,6 +66,11 @@ CONFIGS = {
                         sep_hidden_channels=64, sep_bottleneck_channels=32, sep_skip_channels=48, sep_kernel_size=5,
                         sep_num_blocks=1, sep_num_layers=4, dilated=True, separable=True, causal=True, sep_nonlinear="prelu",
                         sep_norm=True, mask_nonlinear="sigmoid", n_sources=2),
+    # a 128-row bottleneck: the two heads of a layer run as ONE product over [Wo; Ws] (sepkernels.functional.PaddedHeadsFn)
+    "causal16_joint": dict(n_basis=32, kernel_size=16, stride=8, enc_basis="trainable", dec_basis="trainable", enc_nonlinear=None,
+                           sep_hidden_channels=64, sep_bottleneck_channels=128, sep_skip_channels=32, sep_kernel_size=3,
+                           sep_num_blocks=2, sep_num_layers=2, dilated=True, separable=True, causal=True, sep_nonlinear="prelu",
+                           sep_norm=True, mask_nonlinear="sigmoid", n_sources=2),
     # full (non-separable) 5-tap convolutions, channel counts off the multiples of 16
     "plainconv": dict(n_basis=60, kernel_size=20, stride=10, enc_basis="trainable", dec_basis="trainable", enc_nonlinear=None,
                       sep_hidden_channels=72, sep_bottleneck_channels=36, sep_skip_channels=28, sep_kernel_size=5,
@@ -105,12 +110,12 @@ CONFIGS = {
                  separable=True, causal=False, sep_nonlinear="prelu", sep_norm=True, mask_nonlinear="sigmoid", n_sources=2),
 }
 SHAPES = {"tiny": (1, 4000), "mid": (2, 3203), "softmax": (2, 2500),   # (batch, samples); 3203 / 2500 exercise the input padding branch
-          "causal": (2, 2403), "causal16": (2, 2403), "causal16_p5": (3, 1500), "plainconv": (2, 2000), "nodil": (1, 1607),
+          "causal": (2, 2403), "causal16": (2, 2403), "causal16_p5": (3, 1500), "causal16_joint": (2, 1203), "plainconv": (2, 2000), "nodil": (1, 1607),
           "fourier": (2, 1603), "fourier_phase": (2, 1603), "fourier_pinv": (1, 1603), "pinv": (2, 1603), "fourier_real": (2, 1603),
           "fourier_phase_real": (2, 1603)}
 COMPOSED = ("causal", "plainconv", "nodil", "fourier", "fourier_phase", "fourier_pinv", "pinv", "fourier_real", "fourier_phase_real")
 DERIVED = ("fourier_pinv", "pinv", "fourier_real", "fourier_phase_real")      # linear filterbanks: the fused sequence on bases formed from their parameters
-STAGED = ("causal16", "causal16_p5")      # causal, on kernels layer by layer
+STAGED = ("causal16", "causal16_p5", "causal16_joint")      # causal, on kernels layer by layer
 
 
 def perturb(model, seed):

@@ -79,6 +79,8 @@ def test_staged_causal_path_matches_the_reference(golden_dir, name, emu):
     est, latent = model.extract_latent(mixture)
     nl = CONFIGS[name]["sep_num_blocks"] * CONFIGS[name]["sep_num_layers"]
     assert calls.count("cln_fwd") == 2 * nl + 1 and calls.count("depthwise_fwd") == nl          # the staged path ran, not the torch composition
+    if name == "causal16_joint":          # 128-row bottleneck, adjacent weights: ONE product per layer for both heads (+ conv1; + bottleneck, mask)
+        assert calls.count("pw_gemm") == 2 * nl + 2, calls.count("pw_gemm")
     ref = torch.from_numpy(g["output_f64"])
     assert (est - ref).abs().max() <= 1e-9 * ref.abs().max()
     assert abs(latent.sum().item() - float(g["latent_f64_sum"])) <= 1e-8 * float(g["latent_f64_abs_sum"])

@@ -176,12 +176,12 @@ def case_norms(R):
     GK.both("gln_apply", [x, GK.stats_of(x, T), GK.rnd(C) + 1, GK.rnd(C), GK.nan(B, C, ldt), B, C, T, ldt, C * float(T), 1e-12])
     if C >= 3:          # (one channel: the first frame has zero variance and 1 / (sigma + eps) = 1e12 either way -- nothing to compare)
         xs = x * 2 + 0.1 * (x != 0)
-        ye, me, re_ = GK.nan(B, C, ldt), torch.empty(B, T), torch.empty(B, T)
-        ys, ms, rs = GK.nan(B, C, ldt), torch.empty(B, T), torch.empty(B, T)
+        ye, me, re_ = GK.nan(B, C, ldt), torch.zeros(B, ldt), torch.zeros(B, ldt)          # ABI 20: the per-frame statistics in rows of ldt
+        ys, ms, rs = GK.nan(B, C, ldt), torch.zeros(B, ldt), torch.zeros(B, ldt)
         gamma, beta = GK.rnd(C) + 1, GK.rnd(C)
-        GK.EMU.cln_fwd(xs, gamma, beta, ye, me, re_, torch.empty(B, 2, T, dtype=torch.float64), B, C, T, ldt, 1e-12)
-        GK.HIP.cln_fwd(xs.clone(), gamma.clone(), beta.clone(), ys, ms, rs, torch.empty(B, 2, T, dtype=torch.float64), B, C, T, ldt, 1e-12)   # the workspace is scratch
-        assert torch.isfinite(ys).all() and (ys - ye).abs().max() <= 5e-4 * ye.abs().max() and (ms - me).abs().max() <= 1e-5 * (1 + me.abs().max())
+        GK.EMU.cln_fwd(xs, gamma, beta, ye, me, re_, torch.empty(B, 2, ldt, dtype=torch.float64), B, C, T, ldt, 1e-12)
+        GK.HIP.cln_fwd(xs.clone(), gamma.clone(), beta.clone(), ys, ms, rs, torch.empty(B, 2, ldt, dtype=torch.float64), B, C, T, ldt, 1e-12)   # the workspace is scratch
+        assert torch.isfinite(ys).all() and (ys - ye).abs().max() <= 5e-4 * ye.abs().max() and (ms[:, :T] - me[:, :T]).abs().max() <= 1e-5 * (1 + me.abs().max())
     return "norms B={} C={} T={}".format(B, C, T)
 
 
