@@ -371,6 +371,50 @@ def paper_b16_golden(ConvTasNet, NegSISDR, PIT1d):
     np.savez_compressed(os.path.join(OUT, "convtasnet_paper_b16.npz"), **blob)
     print("paper-best B=16 fp64 reference: loss", loss64.item(), "in {:.0f} s".format(time.time() - t0))
 
+
+# The reference's TRAINING STEP, several times over (egs/wsj0-mix/common/src/driver.py:141-157: zero_grad, model(mixture), pit_criterion,
+# backward, clip_grad_norm_(max_norm), optimizer.step with torch.optim.Adam -- local/train.py:103-118), on seeded batches, in fp32 as shipped
+# and in fp64: the loss of every step and a fingerprint of the parameters afterwards.  The GPU tier runs the recipe's own step
+# (sepkernels.train.FusedTrainStep, what recipes.trainer.Trainer drives) on the same batches and has to stay on this trajectory.
+TRAJ_CFG = dict(n_basis=64, kernel_size=16, stride=8, enc_basis="trainable", dec_basis="trainable", enc_nonlinear="relu",
+                sep_hidden_channels=128, sep_bottleneck_channels=64, sep_skip_channels=64, sep_kernel_size=3, sep_num_blocks=2,
+                sep_num_layers=3, dilated=True, separable=True, causal=False, sep_nonlinear="prelu", sep_norm=True,
+                mask_nonlinear="sigmoid", n_sources=2)
+TRAJ = dict(model_seed=31, data_seed=32, steps=8, batch=4, samples=4000, lr=1e-3, max_norm=5.0)
+
+
+def traj_batches():
+    g = torch.Generator().manual_seed(TRAJ["data_seed"])
+    out = []
+    for _ in range(TRAJ["steps"]):
+        sources = 0.1 * torch.randn(TRAJ["batch"], 2, TRAJ["samples"], generator=g) * torch.exp(0.5 * torch.randn(TRAJ["batch"], 2, 1, generator=g))
+        out.append((sources.sum(1, keepdim=True), sources))
+    return out
+
+
+def train_trajectory_golden(ConvTasNet, NegSISDR, PIT1d):
+    blob = {}
+    for name, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        torch.manual_seed(TRAJ["model_seed"])
+        model = ConvTasNet(**TRAJ_CFG).to(dt)
+        crit = PIT1d(NegSISDR(), n_sources=2)
+        opt = torch.optim.Adam(model.parameters(), lr=TRAJ["lr"])
+        losses = []
+        for mixture, sources in traj_batches():
+            opt.zero_grad()
+            loss, _ = crit(model(mixture.to(dt)), sources.to(dt))
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), TRAJ["max_norm"])
+            opt.step()
+            losses.append(loss.item())
+        blob["loss_" + name] = np.array(losses)
+        if name == "f64":
+            for k, v in model.state_dict().items():
+                blob["pfp/" + k] = np.array([v.double().sum().item(), v.double().abs().sum().item(), v.double().abs().max().item()])
+    np.savez_compressed(os.path.join(OUT, "train_trajectory.npz"), **blob)
+    print("training trajectory (reference step x {}): fp64 losses".format(TRAJ["steps"]), [round(v, 5) for v in blob["loss_f64"]], "fp32 - fp64",
+          float(np.abs(blob["loss_f32"] - blob["loss_f64"]).max()))
+
 # DPTNet / GALRNet / SepFormer: small configurations, channel counts in multiples of 16 so that the
 # product runs them on its kernel path, plus one with odd widths (composition path).  403 samples -> 201 frames: both the
 # waveform padding and the chunk padding (1 frame left, 2 right) are exercised.
@@ -476,4 +520,6 @@ if __name__ == "__main__":
         dprnn_full_golden(NegSISDR, PIT1d)
     if not only or "paper_b16" in only:
         paper_b16_golden(ConvTasNet, NegSISDR, PIT1d)
+    if not only or "trajectory" in only:
+        train_trajectory_golden(ConvTasNet, NegSISDR, PIT1d)
     print("golden vectors written to", OUT)

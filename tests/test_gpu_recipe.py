@@ -56,3 +56,27 @@ def test_train_validate_checkpoint_test_on_gpu(tmp_path):
     targs = argparse.Namespace(sample_rate=SR, n_sources=2, out_dir=str(tmp_path / "out"), model_path=os.path.join(tmp_path, "model", "best.pth"))
     res = Tester(ConvTasNet(**CFG).cuda(), TestDataLoader(WaveTestDataset(root, lst), batch_size=1), crit, targs).run()
     assert all(math.isfinite(v) for v in res.values())
+
+
+def test_training_trajectory_follows_the_reference_trainer(golden_dir):
+    """The recipe's own step (sepkernels.train.FusedTrainStep: what recipes.trainer.Trainer drives -- fused forward / PIT / backward, clip and
+    Adam on flat buffers) against the REFERENCE's training step (driver.py:141-157 with torch.optim.Adam and clip_grad_norm_, run by
+    oracle/make_golden.py::train_trajectory_golden on the unmodified reference classes in fp64): the same seeded model, the same eight
+    batches -- every step's loss within 1e-3, the parameters afterwards within 1e-3 of their scale."""
+    import numpy as np
+    from oracle.make_golden import TRAJ, TRAJ_CFG, traj_batches
+    from sepkernels.train import FusedTrainStep
+    fx = np.load(os.path.join(golden_dir, "train_trajectory.npz"))
+    torch.manual_seed(TRAJ["model_seed"])
+    model = ConvTasNet(**TRAJ_CFG).cuda()
+    assert model.fused
+    step = FusedTrainStep(model, PIT1d(NegSISDR(), n_sources=2), lr=TRAJ["lr"], max_norm=TRAJ["max_norm"])
+    losses = [step(mix.cuda(), src.cuda()).item() for mix, src in traj_batches()]
+    ref = fx["loss_f64"]
+    rel = np.abs(np.array(losses) - ref) / np.abs(ref)
+    assert rel.max() <= 1e-3, (losses, ref.tolist())
+    assert rel[0] <= 1e-5                                               # the first step is a pure forward comparison
+    for k, v in model.state_dict().items():
+        want = fx["pfp/" + k]
+        got = np.array([v.double().sum().item(), v.double().abs().sum().item(), v.double().abs().max().item()])
+        assert abs(got[1] - want[1]) <= 1e-3 * want[1] + 1e-9 and abs(got[2] - want[2]) <= 1e-3 * want[2] + 1e-9, k

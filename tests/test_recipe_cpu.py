@@ -191,3 +191,20 @@ def test_tester_variable_length_inference(tmp_path, wav_tree, emu):
     res = Tester(model, loader, PIT1d(NegSISDR(), n_sources=2), args).run()
     assert all(math.isfinite(v) for v in res.values())
     assert os.path.exists(os.path.join(tmp_path, "out", "utt_c_2-estimated.wav"))
+
+
+def test_training_trajectory_follows_the_reference_trainer_through_the_emulator(golden_dir, emu):
+    """CPU form of tests/test_gpu_recipe.py::test_training_trajectory_follows_the_reference_trainer: the same eight steps of the recipe's
+    step through the C-ABI emulator in fp64 against the reference's fp64 trajectory (1e-7: Adam amplifies nothing in eight steps)."""
+    import numpy as np
+    from oracle.make_golden import TRAJ, TRAJ_CFG, traj_batches
+    from sepkernels.train import FusedTrainStep
+    fx = np.load(os.path.join(golden_dir, "train_trajectory.npz"))
+    torch.manual_seed(TRAJ["model_seed"])
+    model = ConvTasNet(**TRAJ_CFG).double()
+    step = FusedTrainStep(model, PIT1d(NegSISDR(), n_sources=2), lr=TRAJ["lr"], max_norm=TRAJ["max_norm"])
+    losses = [step(mix.double(), src.double()).item() for mix, src in traj_batches()]
+    assert np.abs(np.array(losses) - fx["loss_f64"]).max() <= 1e-7 * np.abs(fx["loss_f64"]).max(), losses
+    for k, v in model.state_dict().items():
+        want = fx["pfp/" + k]
+        assert abs(v.double().sum().item() - want[0]) <= 1e-6 * want[1] + 1e-12, k
