@@ -1273,6 +1273,93 @@ __global__ __launch_bounds__(256) void depthwise_bwd_weight_kernel(const float* 
     }
 }
 
+// =====================================================================================
+// Global layer norm on TOKEN-MAJOR rows: x (nseq, L, C) with the features contiguous -- the layout the dual-path separators keep between
+// their attention / LSTM / Linear layers (DPTNet's and GALRNet's blocks: reference src/models/dptnet.py:505-560, `norm1d(x.permute(1, 2, 0))`).
+// Statistics over all L*C values of a sequence (nn.GroupNorm(1, C) on (batch, C, L): mean, biased variance, eps inside the root), gain and
+// shift per feature.  One workgroup per sequence, float4 per thread and trip; the second pass over the sequence's <= a few hundred KB
+// comes out of L2.  With the features innermost the channel-major sep_gln_* kernels would need two transposing copies per norm
+// (DPTNet: 96 of its 244 strided copies per step).  C must divide 1024 (a thread's four lanes keep their features across trips).
+//   forward : y = (x - mu) rstd gamma_c + beta_c ; stats[s] = {mu, rstd}
+//   backward: dx = rstd (g gamma_c - m1 - xhat m2), m1 = mean(g gamma), m2 = mean(g gamma xhat) ; part[s] = {sum_t g xhat [C] | sum_t g [C]}
+// =====================================================================================
+__global__ __launch_bounds__(256) void gln_tokens_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ y, float* __restrict__ stats, int n, int C, float eps) {
+    __shared__ double red[4];
+    const float* xs = x + (size_t)blockIdx.x * n;
+    float* ys = y + (size_t)blockIdx.x * n;
+    double s = 0.0, ss = 0.0;
+    for (int i = 4 * threadIdx.x; i < n; i += 1024) {
+        const float4 v = ld4(xs + i);
+        s += (double)((v.x + v.y) + (v.z + v.w));
+        ss += (double)(fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w));
+    }
+    const double ts = block_sum_256<double>(s, red), tss = block_sum_256<double>(ss, red);
+    const double m = ts / n;
+    double var = tss / n - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mu = (float)m, rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (threadIdx.x == 0) { stats[2 * blockIdx.x] = mu; stats[2 * blockIdx.x + 1] = rstd; }
+    const int c0 = (4 * threadIdx.x) % C;
+    const float4 g4 = ld4(gamma + c0), b4 = ld4(beta + c0);
+    for (int i = 4 * threadIdx.x; i < n; i += 1024) {
+        const float4 v = ld4(xs + i);
+        st4(ys + i, make_float4(fmaf((v.x - mu) * rstd, g4.x, b4.x), fmaf((v.y - mu) * rstd, g4.y, b4.y),
+                                fmaf((v.z - mu) * rstd, g4.z, b4.z), fmaf((v.w - mu) * rstd, g4.w, b4.w)));
+    }
+}
+
+__global__ __launch_bounds__(256) void gln_tokens_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ stats, float* __restrict__ dx, float* __restrict__ part,
+                                                             int n, int C) {
+    __shared__ double red[4];
+    __shared__ float pc[256][8];
+    const float* xs = x + (size_t)blockIdx.x * n;
+    const float* gs = dy + (size_t)blockIdx.x * n;
+    float* ds = dx + (size_t)blockIdx.x * n;
+    const float mu = stats[2 * blockIdx.x], rstd = stats[2 * blockIdx.x + 1];
+    const int c0 = (4 * threadIdx.x) % C;
+    const float4 g4 = ld4(gamma + c0);
+    const float ga[4] = {g4.x, g4.y, g4.z, g4.w};
+    double s1 = 0.0, s2 = 0.0;
+    float pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 4 * threadIdx.x; i < n; i += 1024) {
+        const float4 v = ld4(xs + i), g = ld4(gs + i);
+        const float xv[4] = {v.x, v.y, v.z, v.w}, gv[4] = {g.x, g.y, g.z, g.w};
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (xv[e] - mu) * rstd, gg = gv[e] * ga[e];
+            a1 += gg; a2 = fmaf(gg, xh, a2);
+            pg[e] = fmaf(gv[e], xh, pg[e]); pb[e] += gv[e];
+        }
+        s1 += (double)a1; s2 += (double)a2;
+    }
+    const double t1 = block_sum_256<double>(s1, red), t2 = block_sum_256<double>(s2, red);
+    const float m1 = (float)(t1 / n), m2 = (float)(t2 / n);
+    for (int i = 4 * threadIdx.x; i < n; i += 1024) {
+        const float4 v = ld4(xs + i), g = ld4(gs + i);
+        const float xv[4] = {v.x, v.y, v.z, v.w}, gv[4] = {g.x, g.y, g.z, g.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (xv[e] - mu) * rstd;
+            o[e] = rstd * (gv[e] * ga[e] - m1 - xh * m2);
+        }
+        st4(ds + i, make_float4(o[0], o[1], o[2], o[3]));
+    }
+    // per-feature partials: thread t holds features (4 t) % C .. + 3; the threads of a feature are C / 4 apart
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { pc[threadIdx.x][e] = pg[e]; pc[threadIdx.x][4 + e] = pb[e]; }
+    __syncthreads();
+    float* ps = part + (size_t)blockIdx.x * 2 * C;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float tg = 0.f, tb = 0.f;
+        for (int t = c / 4; t < 256; t += C / 4) { tg += pc[t][c & 3]; tb += pc[t][4 + (c & 3)]; }
+        ps[c] = tg; ps[C + c] = tb;
+    }
+}
+
 // ---- the TCN layers' own depthwise geometry (stride 1, three taps, Tin = Tout = the workspace stride, `pad` zeros in front: (P - 1) d when
 // causal), one (b, c) row per workgroup, a float4 of frames per thread and trip.  Tap k sits at t + k d - pad.  For shifts that are multiples
 // of 4 the taps are aligned float4 loads; for the others (d = 1, 2: the first two layers of a block) the row goes through LDS once.
@@ -1651,6 +1738,23 @@ extern "C" int sep_softmax_ch_bwd(const float* y, float* g, int B, int C, int T,
     SEP_REQUIRE(y && g && B > 0 && B <= 65535 && C > 0 && T > 0 && ldt % 64 == 0 && ldt >= T, "sep_softmax_ch_bwd: bad arguments");
     hipLaunchKernelGGL((softmax_ch_kernel<true>), dim3(ldt / 64, B), dim3(256), 0, (hipStream_t)stream, const_cast<float*>(y), g, C, T, ldt);
     SEP_CHECK_LAUNCH("sep_softmax_ch_bwd");
+    return 0;
+}
+
+extern "C" int sep_gln_tokens_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, int nseq, int L, int C, float eps,
+                                  sep_stream_t stream) {
+    SEP_REQUIRE(x && gamma && beta && y && stats && nseq > 0 && L > 0 && C >= 4 && 1024 % C == 0, "sep_gln_tokens_fwd: bad arguments (C must divide 1024, C >= 4)");
+    SEP_REQUIRE((long)L * C <= 0x7fffffffL, "sep_gln_tokens_fwd: sequence too long");
+    hipLaunchKernelGGL(gln_tokens_fwd_kernel, dim3((unsigned)nseq), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, stats, L * C, C, eps);
+    SEP_CHECK_LAUNCH("sep_gln_tokens_fwd");
+    return 0;
+}
+
+extern "C" int sep_gln_tokens_bwd(const float* dy, const float* x, const float* gamma, const float* stats, float* dx, float* part, int nseq, int L,
+                                  int C, sep_stream_t stream) {
+    SEP_REQUIRE(dy && x && gamma && stats && dx && part && nseq > 0 && L > 0 && C >= 4 && 1024 % C == 0, "sep_gln_tokens_bwd: bad arguments (C must divide 1024, C >= 4)");
+    hipLaunchKernelGGL(gln_tokens_bwd_kernel, dim3((unsigned)nseq), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, stats, dx, part, L * C, C);
+    SEP_CHECK_LAUNCH("sep_gln_tokens_bwd");
     return 0;
 }
 

@@ -7,7 +7,10 @@ recurrence of the feed-forward sub-block: the LSTM sweep kernels; layer norms: t
 import torch.nn as nn
 import torch.nn.functional as F
 
-from sepkernels.functional import OverlapAddFn, PaddedPointwiseFn, SegmentFn, linear_apply, lstm_apply
+import torch
+
+from sepkernels.functional import (ChunkToTokensFn, OverlapAddFn, PaddedPointwiseFn, SegmentFn, TokenGLNFn, TokensToChunkFn, dense_apply, linear_apply,
+                                   lstm_apply, token_gln_ok)
 from utils.model import choose_nonlinear, choose_rnn
 from utils.tasnet import choose_layer_norm
 from models.gtu import GTU1d
@@ -95,7 +98,42 @@ class DualPathTransformer(nn.Module):
 
     def forward(self, input):
         """(batch_size, num_features, S, chunk_size) -> same shape"""
+        if self._tokens_ok(input):
+            return self._forward_tokens(input)
         return self.net(input)
+
+    def _tokens_ok(self, input):
+        """every norm of the stack a gLN (a causal model's inter-chunk path carries cLN: cumulative along the sequence, another kernel), a
+        feature count sep_gln_tokens_* takes, tensors the backend takes"""
+        probe = input.new_empty(1, 1, input.shape[1])
+        for block in self.net:
+            for tr in (block.intra_chunk_block.transformer, block.inter_chunk_block.transformer):
+                for sub in (tr.multihead_attn_block, tr.subnet):
+                    if sub.norm and not token_gln_ok(probe, sub.norm1d):
+                        return False
+        return token_gln_ok(probe, _ANY_GLN)
+
+    def _forward_tokens(self, input):
+        """The same stack with the features innermost from end to end: (B, C, S, K) -> tokens (B*S, K, C) once (sep_chunk_to_tokens), every
+        sub-block on token-major rows (attention projections and the Linear on csrc/linear.hip, the LSTM sweeps, gLN on sep_gln_tokens_*),
+        one transposing copy between the intra- and the inter-chunk path, back once (sep_tokens_to_chunk).  The module-by-module form
+        above makes ~10 strided copies per transformer and direction (244 per step at the recipe's size)."""
+        B, C, S, K = input.shape
+        x = ChunkToTokensFn.apply(input, False)                                  # (B*S, K, C): a sequence per (b, s)
+        for block in self.net:
+            x = block.intra_chunk_block.transformer.forward_tokens(x)
+            x = x.view(B, S, K, C).transpose(1, 2).contiguous().view(B * K, S, C)    # a sequence per (b, k)
+            x = block.inter_chunk_block.transformer.forward_tokens(x)
+            x = x.view(B, K, S, C).transpose(1, 2).contiguous().view(B * S, K, C)
+        return TokensToChunkFn.apply(x, (B, C, S, K), False)
+
+
+class _AnyGLN:
+    pass
+
+
+_AnyGLN.__name__ = "GlobalLayerNorm"
+_ANY_GLN = _AnyGLN()
 
 
 class DualPathTransformerBlock(nn.Module):
@@ -156,6 +194,10 @@ class ImprovedTransformer(nn.Module):
     def forward(self, input):
         return self.subnet(self.multihead_attn_block(input))
 
+    def forward_tokens(self, x):
+        """x (nseq, L, C), features contiguous -> the same shape"""
+        return self.subnet.forward_tokens(self.multihead_attn_block.forward_tokens(x))
+
 
 def _norm_time_first(norm1d, x):
     """layer norm of the TasNet family, defined on (batch_size, C, T), applied to (T, batch_size, C)"""
@@ -181,6 +223,22 @@ class MultiheadAttentionBlock(nn.Module):
             x = self.dropout1d(x)
         return _norm_time_first(self.norm1d, x) if self.norm else x
 
+    def forward_tokens(self, x):
+        """(nseq, L, embed_dim) -> same shape.  nn.MultiheadAttention's arithmetic (torch/nn/functional.py multi_head_attention_forward: packed
+        input projection in the order q, k, v; head h = features h*d .. (h+1)*d - 1; scores scaled by 1/sqrt(d); softmax; output projection; no
+        mask, no attention dropout) on batch-first rows: the projections on csrc/linear.hip, the core on scaled_dot_product_attention."""
+        mha = self.multihead_attn
+        N, L, C = x.shape
+        h = mha.num_heads
+        qkv = dense_apply(x, mha.in_proj_weight, mha.in_proj_bias).view(N, L, 3, h, C // h)
+        q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))                # (N, h, L, d) views
+        o = torch.nn.functional.scaled_dot_product_attention(q, k, v)             # (N, h, L, d)
+        o = o.transpose(1, 2).reshape(N, L, C)
+        y = dense_apply(o, mha.out_proj.weight, mha.out_proj.bias) + x
+        if self.dropout:
+            y = self.dropout1d(y)
+        return TokenGLNFn.apply(y, self.norm1d.norm.weight, self.norm1d.norm.bias, self.norm1d.eps) if self.norm else y
+
 
 class FeedForwardBlock(nn.Module):
     def __init__(self, num_features, hidden_channels, norm=True, nonlinear="relu", causal=False, eps=EPS):
@@ -197,6 +255,11 @@ class FeedForwardBlock(nn.Module):
         h = lstm_apply(input.transpose(0, 1), self.rnn).transpose(0, 1)          # the sweep kernels run sequence-major per batch row
         x = linear_apply(self.nonlinear1d(h), self.fc) + input
         return _norm_time_first(self.norm1d, x) if self.norm else x
+
+    def forward_tokens(self, x):
+        """(nseq, L, num_features) -> same shape, batch-first: no transposes around the recurrence"""
+        y = linear_apply(self.nonlinear1d(lstm_apply(x, self.rnn)), self.fc) + x
+        return TokenGLNFn.apply(y, self.norm1d.norm.weight, self.norm1d.norm.bias, self.norm1d.eps) if self.norm else y
 
 
 from sepkernels.shadowed import fall_through as _fall_through      # names of the reference's same-named module this tree does not define

@@ -734,6 +734,48 @@ def lstm_bidirectional(x, rnn):
 LSTM_KERNEL_HIDDEN = (16, 32, 64, 128)
 
 
+class TokenGLNFn(torch.autograd.Function):
+    """Global layer norm of token-major rows: x (nseq, L, C), features contiguous -> the same shape; statistics over the L * C values of a
+    sequence, gain / shift per feature (GlobalLayerNorm applied to x.permute(0, 2, 1): what the dual-path transformer blocks of the reference
+    do around every attention / feed-forward sub-block, dptnet.py:505-560) without the two transposing copies.  sep_gln_tokens_fwd / bwd."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        K = backend()
+        x = x.contiguous()
+        nseq, L, C = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty(nseq, 2, device=x.device, dtype=x.dtype)
+        K.gln_tokens_fwd(x, gamma, beta, y, stats, nseq, L, C, eps)
+        ctx.save_for_backward(x, gamma, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        K = backend()
+        x, gamma, stats = ctx.saved_tensors
+        nseq, L, C = x.shape
+        dx = torch.empty_like(x)
+        part = torch.empty(nseq, 2, C, device=x.device, dtype=x.dtype)
+        K.gln_tokens_bwd(dy.contiguous(), x, gamma, stats, dx, part, nseq, L, C)
+        tot = part.sum(0)
+        return dx, tot[0], tot[1], None
+
+
+def token_gln_ok(x, norm1d):
+    """can `norm1d` (a modules.norm.GlobalLayerNorm) run on token-major rows x (nseq, L, C) through TokenGLNFn?"""
+    C = x.shape[-1]
+    return (type(norm1d).__name__ == "GlobalLayerNorm" and x.dim() == 3 and C >= 4 and 1024 % C == 0 and takes(x)
+            and (backend().name != "hip" or x.dtype == torch.float32))
+
+
+def dense_apply(x, weight, bias):
+    """x (..., K) @ weight^T + bias with weight (N, K): csrc/linear.hip for the widths it takes, torch's BLAS otherwise"""
+    if _dense_ok(weight.shape[1], weight.shape[0]) and takes(x):
+        return DenseFn.apply(x, weight, bias)
+    return torch.nn.functional.linear(x, weight, bias)
+
+
 def takes(x):
     """can this tensor go to libsepkernels as it is?  (fp32 on the GPU; the CPU stand-in of the tests takes any real dtype)"""
     if backend().name != "hip":

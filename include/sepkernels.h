@@ -312,6 +312,16 @@ int sep_cln_bwd(const float* dy, const float* x, const float* gamma, const float
                 float* dgamma_part, float* dbeta_part, double* ws, int B, int C, int T, int ldt, float eps, const float* alpha,
                 float* dalpha_part, sep_stream_t stream);
 
+/* gLN on TOKEN-MAJOR rows (ABI 20): x, y, dy, dx (nseq, L, C) with the C features contiguous -- the layout between the attention / LSTM /
+ * Linear layers of the dual-path separators (dptnet.py:505-560 `norm1d(x.permute(1, 2, 0))`): statistics over the L*C values of a sequence
+ * (biased variance, eps inside the root, as nn.GroupNorm(1, C)), gain / shift per feature.  C must divide 1024, C >= 4, (L*C) % 4 == 0.
+ * stats (nseq, 2) = {mean, rstd}, written forward, read backward; part (nseq, 2, C) = {sum_t dy*xhat | sum_t dy} per sequence: summed over
+ * the sequences they are d(gamma), d(beta). */
+int sep_gln_tokens_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, int nseq, int L, int C, float eps,
+                       sep_stream_t stream);
+int sep_gln_tokens_bwd(const float* dy, const float* x, const float* gamma, const float* stats, float* dx, float* part, int nseq, int L, int C,
+                       sep_stream_t stream);
+
 /* Stand-alone gLN (modules/norm.py:11-35) for callers outside the fused network. */
 int sep_gln_stats(const float* x, double* stats, int B, int C, int T, int ldt, sep_stream_t stream);
 int sep_gln_apply(const float* x, const double* stats, const float* gamma, const float* beta, float* y, int B, int C,

@@ -437,6 +437,27 @@ class EmuBackend:
         dgamma_part.reshape(B, C).copy_((g * (v - m) * r).sum(2).to(dgamma_part.dtype))
         dbeta_part.reshape(B, C).copy_(g.sum(2).to(dbeta_part.dtype))
 
+    # ------------------------------------------------------------------ gLN on token-major rows
+    def gln_tokens_fwd(self, x, gamma, beta, y, stats, nseq, L, C, eps):
+        v = x.reshape(nseq, L * C).double()
+        m = v.mean(1, keepdim=True)
+        r = 1.0 / torch.sqrt((v * v).mean(1, keepdim=True) - m * m + eps)
+        stats.reshape(nseq, 2)[:, 0] = m[:, 0].to(stats.dtype)
+        stats.reshape(nseq, 2)[:, 1] = r[:, 0].to(stats.dtype)
+        mu, rs = stats.reshape(nseq, 2)[:, 0].view(nseq, 1, 1), stats.reshape(nseq, 2)[:, 1].view(nseq, 1, 1)
+        y.reshape(nseq, L, C).copy_((x.reshape(nseq, L, C) - mu) * rs * gamma.view(1, 1, C) + beta.view(1, 1, C))
+
+    def gln_tokens_bwd(self, dy, x, gamma, stats, dx, part, nseq, L, C):
+        mu, rs = stats.reshape(nseq, 2)[:, 0].view(nseq, 1, 1), stats.reshape(nseq, 2)[:, 1].view(nseq, 1, 1)
+        g = dy.reshape(nseq, L, C)
+        xh = (x.reshape(nseq, L, C) - mu) * rs
+        gg = g * gamma.view(1, 1, C)
+        m1, m2 = gg.double().mean((1, 2), keepdim=True).to(g.dtype), (gg * xh).double().mean((1, 2), keepdim=True).to(g.dtype)
+        dx.reshape(nseq, L, C).copy_(rs * (gg - m1 - xh * m2))
+        p = part.reshape(nseq, 2, C)
+        p[:, 0] = (g * xh).sum(1)
+        p[:, 1] = g.sum(1)
+
     # ------------------------------------------------------------------ stand-alone gLN
     def gln_stats(self, x, stats, B, C, T, ldt):
         v = x.reshape(B, C, ldt)[:, :, :T]

@@ -890,6 +890,36 @@ def test_prelu_cln_fwd_bwd(B, C, T, a):
     assert (dxe - dx).abs().max() <= 5e-5 * dxe.abs().max() and (pae - pa.cpu()).abs().max() <= 2e-4 * pae.abs().max() + 1e-5
 
 
+@pytest.mark.parametrize("nseq,L,C", [(3, 250, 64), (5, 37, 16), (2, 100, 128), (1, 7, 1024), (4, 258, 64)])
+def test_gln_tokens_fwd_bwd(nseq, L, C):
+    """sep_gln_tokens_fwd / bwd: gLN on token-major (nseq, L, C) rows against nn.functional.group_norm on the transposed tensor in float64
+    (what the reference computes: dptnet.py:505-560, norm1d(x.permute(1, 2, 0)) with modules/norm.py:11-29)."""
+    torch.manual_seed(nseq * 100 + C)
+    x = torch.randn(nseq, L, C) * 1.7 + 0.3
+    gamma, beta, dy = torch.randn(C) + 1, torch.randn(C), torch.randn(nseq, L, C)
+    eps = 1e-12
+    x64 = x.double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    y64 = torch.nn.functional.group_norm(x64.permute(0, 2, 1), 1, g64, b64, eps).permute(0, 2, 1)
+    (y64 * dy.double()).sum().backward()
+    f32 = dict(device=device_name(), dtype=torch.float32)
+    y, stats = torch.full((nseq, L, C), float("nan"), **f32), torch.empty(nseq, 2, **f32)
+    HIP.gln_tokens_fwd(to_device(x), to_device(gamma), to_device(beta), y, stats, nseq, L, C, eps)
+    dx, part = torch.full((nseq, L, C), float("nan"), **f32), torch.full((nseq, 2, C), float("nan"), **f32)
+    HIP.gln_tokens_bwd(to_device(dy), to_device(x), to_device(gamma), stats, dx, part, nseq, L, C)
+    device_sync()
+    assert (y.cpu().double() - y64.detach()).abs().max() <= 2e-5 * y64.detach().abs().max()
+    assert (dx.cpu().double() - x64.grad).abs().max() <= 5e-5 * x64.grad.abs().max()
+    assert (part.cpu().double()[:, 0].sum(0) - g64.grad).abs().max() <= 5e-5 * g64.grad.abs().max()
+    assert (part.cpu().double()[:, 1].sum(0) - b64.grad).abs().max() <= 5e-5 * b64.grad.abs().max()
+    ye, se = torch.empty(nseq, L, C), torch.empty(nseq, 2)
+    EMU.gln_tokens_fwd(x, gamma, beta, ye, se, nseq, L, C, eps)
+    dxe, pe = torch.empty(nseq, L, C), torch.empty(nseq, 2, C)
+    EMU.gln_tokens_bwd(dy, x, gamma, se, dxe, pe, nseq, L, C)
+    assert (ye - y.cpu()).abs().max() <= 2e-5 * ye.abs().max() and (dxe - dx.cpu()).abs().max() <= 5e-5 * dxe.abs().max()
+    assert (pe - part.cpu()).abs().max() <= 5e-5 * pe.abs().max()
+
+
 # ------------------------------------------------------------------------------------------- losses / optimiser
 @pytest.mark.parametrize("n,all_pairs", [(1, 0), (2, 1), (4, 1), (3, 0)])
 def test_sisdr_kernels(n, all_pairs):

@@ -1,7 +1,7 @@
 """CPU: the HIP kernel files' OWN SOURCE executed on the host.  tools/hostsim.py compiles every file of csrc/ as plain C++ against a
 stand-in for the pieces of the HIP programming model they use (one host thread per lane, pthread barriers for workgroup and wave;
 shuffles, DPP, ballots and the MFMA instructions as collective operations of a wave; LDS-DMA as a wave-wide copy; the GEMM files' few
-inline-assembly helpers get a C++ body in the compiled copy) into a library with the same C ABI -- all 49 entry points -- and the kernel
+inline-assembly helpers get a C++ body in the compiled copy) into a library with the same C ABI -- all 51 entry points -- and the kernel
 cases of tests/test_gpu_kernels.py -- the very functions that run on the MI355X -- are run against it here: encoder / unfold, depthwise forward / backward, gLN statistics / apply / backward pieces, head backward,
 decoder forward / backward, channel softmax, cLN, SI-SDR, PIT search, Sinkhorn, row distances, squared norm + Adam, chunking /
 overlap-add, the LSTM sweeps (both kernels: sixteen and four sequences per workgroup, forced per call),
@@ -37,6 +37,7 @@ CASES = [
     ("test_gln_standalone_and_repack", [()]),
     ("test_cln_fwd_bwd", [(2, 24, 203), (3, 128, 3999)]),
     ("test_prelu_cln_fwd_bwd", [(2, 24, 203, 0.25), (1, 48, 1030, 0.0)]),
+    ("test_gln_tokens_fwd_bwd", [(3, 250, 64), (5, 37, 16), (1, 7, 1024)]),
     ("test_sisdr_kernels", [(1, 0), (2, 1), (3, 0)]),
     ("test_pit_search", [(2, 0, 1), (3, 1, 1), (4, 0, 0)]),
     ("test_sinkhorn", [(3, 10, 1.0), (5, 200, 1.0), (10, 5, 0.5)]),
