@@ -53,25 +53,64 @@ class GloballyAttentiveBlockBase(nn.Module):
         angle = position / base ** index
         return torch.cat([torch.sin(angle), torch.cos(angle)], dim=1)
 
-    def _position_code(self, S, Q, C, like):
+    def _position_code(self, S, Q, C, like, tokens=False):
         """(C, S, Q) code on the device / in the dtype of `like`, built once per shape: forming it on the host and copying it
         over in every forward would stall the launch queue once per block"""
         # The code depends on the shape only, not on the block: one module-level LRU (not an attribute: deepcopy / state_dict must not
         # carry device tensors along; not keyed by id(self): nn.DataParallel replicas are fresh objects every forward and destroyed
         # models would leave their entries behind).
         cache = _POSITION_CODES
-        key = (S, Q, C, like.device, like.dtype)
+        key = (S, Q, C, like.device, like.dtype, bool(tokens))           # tokens: the same code laid out (Q, S, C) for token-major rows
         code = cache.pop(key, None)
         if code is None:
             if len(cache) >= _POSITION_CODES_MAX:            # a few shapes stay resident (training length, validation utterances): least recently used goes
                 cache.pop(next(iter(cache)))
             code = self.positional_encoding(length=S * Q, dimension=C).t().reshape(C, S, Q).to(device=like.device, dtype=like.dtype)
+            if tokens:
+                code = code.permute(2, 1, 0).contiguous()
         cache[key] = code                                    # (re-)inserted last = most recently used
         return code
+
+    def _attend_tokens(self, x):
+        """_attend with the features innermost from end to end: (B, C, S, Q) -> one sequence per (b, q) as token-major rows (B*Q, S, C)
+        (sep_chunk_to_tokens), the channel norm on the rows as they are, the attention batch-first with its projections on csrc/linear.hip,
+        gLN over a sample's (Q, S, C) block on sep_gln_tokens_*, back (sep_tokens_to_chunk): two tiled transposes instead of six strided
+        copies per block and direction."""
+        from sepkernels.functional import ChunkToTokensFn, TokensToChunkFn, TokenGLNFn, dense_apply
+        B, C, S, Q = x.size()
+        t = ChunkToTokensFn.apply(x, True)                                       # (B*Q, S, C)
+        if self.norm:
+            ln = self.norm2d_in.norm
+            t = torch.nn.functional.layer_norm(t, (C,), ln.weight, ln.bias, ln.eps)
+        seq = (t.view(B, Q, S, C) + self._position_code(S, Q, C, x, tokens=True)).view(B * Q, S, C)
+        mha = self.multihead_attn
+        h = mha.num_heads
+        qkv = dense_apply(seq, mha.in_proj_weight, mha.in_proj_bias).view(B * Q, S, 3, h, C // h)
+        q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
+        y = torch.nn.functional.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B * Q, S, C)
+        y = dense_apply(y, mha.out_proj.weight, mha.out_proj.bias)
+        if self.dropout:
+            y = self.dropout1d(y)
+        y = y + seq
+        if self.norm:
+            gn = self.norm2d_out
+            y = TokenGLNFn.apply(y.view(B, Q * S, C), gn.norm.weight, gn.norm.bias, gn.eps).view(B * Q, S, C)
+        return TokensToChunkFn.apply(y, (B, C, S, Q), True)
+
+    def _tokens_ok(self, x):
+        """the token-major route: the kernels' tensors, the layout pair's grid limits, and -- with norms -- gLN over features that
+        sep_gln_tokens_* takes (the causal cLN stays on the strided route)"""
+        from sepkernels.functional import takes, token_gln_ok
+        B, C, S, Q = x.size()
+        if not takes(x) or S > 65535 or B * ((C + 31) // 32) > 65535:
+            return False
+        return not self.norm or token_gln_ok(x.new_empty(1, 1, C), self.norm2d_out)
 
     def _attend(self, x):
         """x (batch_size, num_features, S, Q): [channel norm ->] + position code -> attention over S -> [dropout] + its input
         -> [gLN / cLN].  The position code runs over the FLATTENED (S, Q) index, as the reference's does."""
+        if self._tokens_ok(x):
+            return self._attend_tokens(x)
         B, C, S, Q = x.size()
         if self.norm:
             x = self.norm2d_in(x)

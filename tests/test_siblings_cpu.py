@@ -72,6 +72,10 @@ def test_sibling_separator_matches_the_reference(golden_dir, name, emu):
     assert ("decoder_fwd" in emu.used and "encoder_fwd" in emu.used) == on_kernels           # the path under test is the one that ran
     if name == "dptnet":              # features a power of two, gLN everywhere: the token-major stack (models/dptnet.py::_forward_tokens)
         assert "gln_tokens_fwd" in emu.used and "chunk_to_tokens" in emu.used
+    if name == "galrnet":             # its global attention runs token-major too (models/galr.py::_attend_tokens); the causal one does not
+        assert "gln_tokens_fwd" in emu.used
+    if name == "galrnet_causal":
+        assert "gln_tokens_fwd" not in emu.used
     ref = torch.from_numpy(g["output_f64"])
     assert est.shape == ref.shape
     assert (est - ref).abs().max() <= 1e-9 * ref.abs().max()
