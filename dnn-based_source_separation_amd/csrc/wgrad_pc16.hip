@@ -104,6 +104,38 @@ __device__ __forceinline__ int w16_next_exp(const float m, const int cur) {
     return ex2 + cur > 14 ? 9 - ex : cur;
 }
 
+// The DMA pieces of a chunk pair (8 rows x 128 B each, 4096 B apart in LDS) in ONE statement.  Issued one by one (glds16_asm) every piece
+// costs six scalar issue slots -- M0 saved, set, a wait state, the load, M0 restored, the address add -- and a pointer of its own to
+// advance; the SIMD issues about one instruction per four cycles whatever its kind, and the producers' ~110 scalar instructions per chunk
+// were a quarter of the chunk's time (SQ counters: profiles/r05x_*).  Here M0 is saved once and advanced once per TWO pieces: the
+// instruction's immediate offset (-4096) reaches the piece in front -- it moves the LDS and the global address alike, so the even pieces'
+// lane offsets carry +4096 (voffc) --, and the pieces share one base pointer per source tensor (pa: pieces 0-3, pb: 4-7).
+// lds1: LDS byte address of piece 1.
+__device__ __forceinline__ void w16_dma_pieces8(const float* pa, const float* pb, const unsigned (&voffc)[8], unsigned lds1) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %11\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %9 offset:-4096\n\tglobal_load_lds_dwordx4 %2, %9\n\t"
+                 "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %3, %9 offset:-4096\n\tglobal_load_lds_dwordx4 %4, %9\n\t"
+                 "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %5, %10 offset:-4096\n\tglobal_load_lds_dwordx4 %6, %10\n\t"
+                 "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %7, %10 offset:-4096\n\tglobal_load_lds_dwordx4 %8, %10\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voffc[0]), "v"(voffc[1]), "v"(voffc[2]), "v"(voffc[3]), "v"(voffc[4]), "v"(voffc[5]), "v"(voffc[6]), "v"(voffc[7]), "s"(pa), "s"(pb), "s"(lds1)
+                 : "memory", "scc");
+}
+__device__ __forceinline__ void w16_dma_pieces4(const float* pa, const unsigned (&voffc)[4], unsigned lds1) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %5 offset:-4096\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+                 "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %3, %5 offset:-4096\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voffc[0]), "v"(voffc[1]), "v"(voffc[2]), "v"(voffc[3]), "s"(pa), "s"(lds1) : "memory", "scc");
+}
+
 template <int WR, int WC, int XMODE>
 __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_desc d) {
     constexpr bool X_GLN = XMODE == SEP_PRO_GLN || XMODE == SEP_PRO_GLN_PRELU;
@@ -157,53 +189,43 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
         const int ptid = tid - 256;
         const int Mg1 = d.g_split ? d.g_split : d.M;
         const int r8 = lane >> 3, slot = lane & 7;       // a DMA instruction: 8 rows x 8 granules, lane-linear in LDS = [row][32 frames]
-        unsigned voffG[PG], voffX[PX];
-        const float* srcG[PG];
-        int MgOf[PG];
+        static_assert(PG == 8 && PX == 4, "w16_dma_pieces8 / 4");
+        unsigned voffG[PG], voffX[PX];                                           // (the even pieces' carry +4096: see w16_dma_pieces8)
+        // g_split is a multiple of 128 and m0 of 256: pieces 0-3 (rows < 128 of the tile) and pieces 4-7 each come from ONE tensor
+        const bool secA = d.g_split && m0 >= d.g_split, secB = d.g_split && m0 + 128 >= d.g_split;
+        const int MgA = secA ? d.M - d.g_split : Mg1, MgB = secB ? d.M - d.g_split : Mg1;
 #pragma unroll
         for (int q = 0; q < PG; ++q) {
             const int rowt = 8 * (pw + 4 * q) + r8;                                     // row of the tile
-            const bool second = d.g_split && (m0 + 8 * (pw + 4 * q)) >= d.g_split;     // wave-uniform
-            srcG[q] = second ? d.G2 : d.G;
-            MgOf[q] = second ? d.M - d.g_split : Mg1;
-            voffG[q] = 4u * (unsigned)((m0 + rowt - (second ? d.g_split : 0)) * d.ldt + 4 * (slot ^ w16_f8(rowt)));
+            const bool second = q < 4 ? secA : secB;
+            voffG[q] = 4u * (unsigned)((m0 + rowt - (second ? d.g_split : 0)) * d.ldt + 4 * (slot ^ w16_f8(rowt))) + ((q & 1) ? 0u : 4096u);
         }
 #pragma unroll
         for (int q = 0; q < PX; ++q) {
             const int rowt = 8 * (pw + 4 * q) + r8;
-            voffX[q] = 4u * (unsigned)((n0 + rowt) * d.ldt + 4 * (slot ^ w16_f8(rowt)));
+            voffX[q] = 4u * (unsigned)((n0 + rowt) * d.ldt + 4 * (slot ^ w16_f8(rowt))) + ((q & 1) ? 0u : 4096u);
         }
-        // Source pointers of the NEXT pair to fetch, one per DMA piece, advanced by 32 frames per pair (or to the next sample's rows): formed
-        // afresh from (sample, chunk) for every piece, the 64-bit scalar multiplies made the DMA instructions of a pair cost 1300 - 2300
-        // cycles of one producer wave, with the consumers waiting at the barrier behind it (s_memtime stamps, tools/wpc16_prof.py).
+        // Source pointers of the NEXT pair to fetch, one per source tensor, advanced by 32 frames per pair (or to the next sample's rows).
         // G runs one pair ahead of X (three raw G stages, two raw X stages).
         const int pps = cps_t / 2;                                               // pairs per sample
         int itG = (int)(c_begin % cps_t) / 2, itX = itG;
         int ciG = 0, ciX = 0, gst = 0, xst = 0;
-        const float* pG[PG];
-        long wrapG[PG];
-#pragma unroll
-        for (int q = 0; q < PG; ++q) {
-            pG[q] = srcG[q] + (size_t)(c_begin / cps_t) * MgOf[q] * d.ldt + itG * RL;
-            wrapG[q] = (long)MgOf[q] * d.ldt - (long)(pps - 1) * RL;
-        }
+        const float* pGa = (secA ? d.G2 : d.G) + (size_t)(c_begin / cps_t) * MgA * d.ldt + itG * RL;
+        const float* pGb = (secB ? d.G2 : d.G) + (size_t)(c_begin / cps_t) * MgB * d.ldt + itG * RL;
+        const long wrapGa = (long)MgA * d.ldt - (long)(pps - 1) * RL, wrapGb = (long)MgB * d.ldt - (long)(pps - 1) * RL;
         const float* pX = d.X + (size_t)(c_begin / cps_t) * d.N * d.ldt + itX * RL;
         const long wrapX = (long)d.N * d.ldt - (long)(pps - 1) * RL;
         auto issueG = [&]() {
-#pragma unroll
-            for (int q = 0; q < PG; ++q)
-                glds16_asm(pG[q], voffG[q], lds_addr(&sm.Gr[gst][8 * (pw + 4 * q) * RL]));
+            w16_dma_pieces8(pGa, pGb, voffG, lds_addr(&sm.Gr[gst][8 * (pw + 4) * RL]));
             const bool wrap = ++itG >= pps;                                      // the next pair is the first of the next sample
             if (wrap) itG = 0;
-#pragma unroll
-            for (int q = 0; q < PG; ++q) pG[q] += wrap ? wrapG[q] : (long)RL;
+            pGa += wrap ? wrapGa : (long)RL;
+            pGb += wrap ? wrapGb : (long)RL;
             ++ciG;
             gst = gst + 1 == W16NGP ? 0 : gst + 1;
         };
         auto issueX = [&]() {
-#pragma unroll
-            for (int q = 0; q < PX; ++q)
-                glds16_asm(pX, voffX[q], lds_addr(&sm.Xr[xst][8 * (pw + 4 * q) * RL]));
+            w16_dma_pieces4(pX, voffX, lds_addr(&sm.Xr[xst][8 * (pw + 4) * RL]));
             const bool wrap = ++itX >= pps;
             if (wrap) itX = 0;
             pX += wrap ? wrapX : (long)RL;
@@ -548,6 +570,7 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
             }
     }
 }
+
 
 template <int WR, int WC, int XMODE>
 void launch_w16(const sep_wgrad_desc& d, hipStream_t stream) {

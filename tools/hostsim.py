@@ -44,7 +44,11 @@ _HELPERS = {
     "wgrad_pc16.hip": [
         ("w16_max_halves", "static inline float w16_max_halves(const float m) { const float o = sim_read_lane(m, (threadIdx.x & 63) ^ 32); return m > o ? m : o; }\n"),
         ("w16_max_neighbour", "static inline float w16_max_neighbour(const float m) { const float o = sim_read_lane(m, (threadIdx.x & 63) ^ 1); return m > o ? m : o; }\n"),
-        ("w16_split2_pair", _SPLIT2.format(n="w16_split2_pair"))],
+        ("w16_split2_pair", _SPLIT2.format(n="w16_split2_pair")),
+        ("w16_dma_pieces8", "static inline void w16_dma_pieces8(const float* pa, const float* pb, const unsigned (&voffc)[8], unsigned lds1) { for (int q = 0; q < 8; ++q) "
+                            "sim_glds16((const char*)(q < 4 ? pa : pb) + voffc[q] - ((q & 1) ? 0 : 4096), lds1 + 4096 * (q - 1)); }\n"),
+        ("w16_dma_pieces4", "static inline void w16_dma_pieces4(const float* pa, const unsigned (&voffc)[4], unsigned lds1) { for (int q = 0; q < 4; ++q) "
+                            "sim_glds16((const char*)pa + voffc[q] - ((q & 1) ? 0 : 4096), lds1 + 4096 * (q - 1)); }\n")],
     "gemm_coop.hip": [
         ("co_vmax", "static inline float co_vmax(const float a, const float b) { return a > b ? a : b; }\n"),
         ("co_quad_max", "static inline float co_quad_max(const float m) { float o = sim_read_lane(m, (threadIdx.x & 63) ^ 1); const float t = m > o ? m : o; "
