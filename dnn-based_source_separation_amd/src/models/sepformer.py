@@ -156,8 +156,67 @@ class _ChunkPathEncoder(nn.Module):
                                            batch_first=False, norm_first=norm_first)
         self.transformer = nn.TransformerEncoder(layer, num_layers=num_layers, norm=final, enable_nested_tensor=False)
 
+    def _tokens_ok(self, input):
+        """the token-major route: the kernels' tensors, the layout pair's grid limits, no final norm or a gLN that sep_gln_tokens_* takes
+        (the causal inter path's cLN stays on the strided route)"""
+        from sepkernels.functional import takes, token_gln_ok
+        B, C, S, K = input.size()
+        if not takes(input) or max(S, K) > 65535 or B * ((C + 31) // 32) > 65535:
+            return False
+        final = self.transformer.norm
+        return final is None or token_gln_ok(input.new_empty(1, 1, C), final.norm1d)
+
+    @staticmethod
+    def _layer_tokens(layer, x):
+        """one nn.TransformerEncoderLayer (torch/nn/modules/transformer.py: post-norm, or pre-norm with norm_first) on batch-first rows
+        (N, L, C): the four dense layers on csrc/linear.hip -- hipBLASLt's picks for these fp32 shapes (32 K tokens x 256 x 1024) run at a
+        third of the fp32 MFMA rate, profiles/r05zc_sepformer_kernel_stats.md --, the core on scaled_dot_product_attention with the
+        layer's attention dropout."""
+        from sepkernels.functional import dense_apply
+        sa = layer.self_attn
+        N, L, C = x.shape
+        h = sa.num_heads
+
+        def attend(u):
+            qkv = dense_apply(u, sa.in_proj_weight, sa.in_proj_bias).view(N, L, 3, h, C // h)
+            q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
+            o = F.scaled_dot_product_attention(q, k, v, dropout_p=sa.dropout if layer.training else 0.0)
+            return layer.dropout1(dense_apply(o.transpose(1, 2).reshape(N, L, C), sa.out_proj.weight, sa.out_proj.bias))
+
+        def feed(u):
+            f = layer.dropout(layer.activation(dense_apply(u, layer.linear1.weight, layer.linear1.bias)))
+            return layer.dropout2(dense_apply(f, layer.linear2.weight, layer.linear2.bias))
+
+        def ln(norm, u):
+            return F.layer_norm(u, (C,), norm.weight, norm.bias, norm.eps)
+
+        if layer.norm_first:
+            x = x + attend(ln(layer.norm1, x))
+            return x + feed(ln(layer.norm2, x))
+        x = ln(layer.norm1, x + attend(x))
+        return ln(layer.norm2, x + feed(x))
+
+    def _forward_tokens(self, input):
+        """forward with the features innermost: one tiled transpose in (sep_chunk_to_tokens), the stack on (sequences, steps, C) rows, the
+        final gLN on sep_gln_tokens_*, one tiled transpose out"""
+        from sepkernels.functional import ChunkToTokensFn, TokensToChunkFn, TokenGLNFn
+        B, C, S, K = input.size()
+        inter = self.SEQ_AXIS == 2
+        t = ChunkToTokensFn.apply(input, inter)                                   # (B*S, K, C) | (B*K, S, C)
+        pe = self.positional_encoding
+        x = t + pe.dropout(t + pe.positional_encoding[:t.size(1), 0])
+        for layer in self.transformer.layers:
+            x = self._layer_tokens(layer, x)
+        final = self.transformer.norm
+        if final is not None:
+            gn = final.norm1d
+            x = TokenGLNFn.apply(x, gn.norm.weight, gn.norm.bias, gn.eps)
+        return TokensToChunkFn.apply(x, (B, C, S, K), inter) + input
+
     def forward(self, input):
         """(batch_size, num_features, S, chunk_size) -> same shape"""
+        if self._tokens_ok(input):
+            return self._forward_tokens(input)
         B, C, S, K = input.size()
         if self.SEQ_AXIS == 3:
             x = input.permute(3, 0, 2, 1).reshape(K, B * S, C)
