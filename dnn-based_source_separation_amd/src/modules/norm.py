@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 
 import sepkernels
+from sepkernels.functional import cln_workspace
 
 EPS = 1e-12
 GRID_ROWS = 65535      # rows one launch of the gLN / cLN kernels takes (grid.y)
@@ -110,7 +111,7 @@ class _CumulativeLayerNormFn(torch.autograd.Function):
             xp = x3
         yp = torch.empty_like(xp)
         mean, rstd = torch.empty(B, ldt, **f32), torch.empty(B, ldt, **f32)      # rows of ldt (ABI 20)
-        ws = torch.empty(B, 2, ldt, device=x.device, dtype=torch.float64)
+        ws = cln_workspace(K, B, C, T, ldt, x.device)
         g1, b1 = gamma.reshape(C).contiguous(), beta.reshape(C).contiguous()
         K.cln_fwd(xp, g1, b1, yp, mean, rstd, ws, B, C, T, ldt, eps)
         if ldt != T:
@@ -136,7 +137,7 @@ class _CumulativeLayerNormFn(torch.autograd.Function):
             dyp = dy3
         dxp = torch.empty_like(xp)
         pg, pb = torch.empty(B, C, **f32), torch.empty(B, C, **f32)
-        ws = torch.empty(B, 2, ldt, device=xp.device, dtype=torch.float64)
+        ws = cln_workspace(K, B, C, T, ldt, xp.device)
         K.cln_bwd(dyp, xp, g1, mean, rstd, dxp, pg, pb, ws, B, C, T, ldt, eps)
         dgamma, dbeta = torch.empty(C, **f32), torch.empty(C, **f32)
         K.reduce_slabs([(pg, 0, dgamma, C, B, C, 0, 1.0), (pb, 0, dbeta, C, B, C, 0, 1.0)])

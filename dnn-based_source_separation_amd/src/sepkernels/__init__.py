@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("SEPKERNELS_LIB", os.path.normpath(os.path.join(_HERE,
 # ---- constants mirrored from include/sepkernels.h -------------------------------------------------
 PRO_NONE, PRO_PRELU, PRO_GLN, PRO_GLN_PRELU, PRO_GLN_BWD = 0, 1, 2, 3, 4
 EPI_STATS_PRELU, EPI_RESIDUAL, EPI_SIGMOID, EPI_PRELU_BWD, EPI_ROWSUMS, EPI_ROWSUMS_PRELU = 1, 2, 4, 8, 16, 32
-ABI_VERSION = 20
+ABI_VERSION = 21
 LSTM_INTERLEAVED = 0x400       # sep_lstm_fwd / sep_lstm_bwd with reverse = 2: h_out / dh_out as one (nseq, L, 2H) buffer
 STATS_SLOTS = 16   # SEP_STATS_SLOTS: gLN statistics are double[B][STATS_SLOTS][2]
 ARRIVE_INTS = 17   # SEP_ARRIVE_INTS: arrival counters of the gLN-backward publishers, int[B][ARRIVE_INTS]
@@ -128,6 +128,7 @@ SIGNATURES = {
     "sep_decoder_bwd": [_vp] * 6 + [_I] * 11 + [_vp],
     "sep_softmax_ch_fwd": [_vp] + [_I] * 4 + [_vp],
     "sep_softmax_ch_bwd": [_vp, _vp] + [_I] * 4 + [_vp],
+    "sep_cln_ws_bytes": [_I] * 4,                                    # returns size_t
     "sep_cln_fwd": [_vp] * 7 + [_I] * 4 + [_F, _vp, _vp],
     "sep_cln_bwd": [_vp] * 9 + [_I] * 4 + [_F, _vp, _vp, _vp],
     "sep_gln_tokens_fwd": [_vp] * 5 + [_I] * 3 + [_F, _vp],
@@ -182,7 +183,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_char_p if name == "sep_last_error" else ctypes.c_int
+        fn.restype = ctypes.c_char_p if name == "sep_last_error" else (ctypes.c_size_t if name == "sep_cln_ws_bytes" else ctypes.c_int)
     if lib.sep_version() != ABI_VERSION:
         raise SepKernelsError("libsepkernels ABI {} != binding ABI {}".format(lib.sep_version(), ABI_VERSION))
     _lib = lib
@@ -356,6 +357,9 @@ class HipBackend:
 
     def softmax_ch_bwd(self, y, g, B, C, T, ldt):
         _check(load().sep_softmax_ch_bwd(_ptr(y, _f32), _ptr(g, _f32), B, C, T, ldt, _stream()), "sep_softmax_ch_bwd")
+
+    def cln_ws_bytes(self, B, C, T, ldt):
+        return int(load().sep_cln_ws_bytes(B, C, T, ldt))
 
     def cln_fwd(self, x, gamma, beta, y, mean, rstd, ws, B, C, T, ldt, eps, alpha=None):
         _check(load().sep_cln_fwd(_ptr(x, _f32), _ptr(gamma, _f32), _ptr(beta, _f32), _ptr(y, _f32), _ptr(mean, _f32), _ptr(rstd, _f32),

@@ -204,6 +204,11 @@ class MaskDecodeFn(torch.autograd.Function):
         return dw, dmask, dD, None, None, None
 
 
+def cln_workspace(K, B, C, T, ldt, device):
+    """the scratch sep_cln_fwd / sep_cln_bwd ask for at this shape (sep_cln_ws_bytes), as fp64 words"""
+    return torch.empty((K.cln_ws_bytes(B, C, T, ldt) + 7) // 8, device=device, dtype=torch.float64)
+
+
 class PaddedCLNFn(torch.autograd.Function):
     """[PReLU ->] CumulativeLayerNorm1d on rows that already carry the workspace stride: x (B, C, ldt) with n_frames valid frames -> the
     same shape, frames beyond zero (reference src/modules/norm.py:58-101, behind nonlinear1d of tdcn.py:113-116 / 182-186 when `alpha` -- the
@@ -219,7 +224,7 @@ class PaddedCLNFn(torch.autograd.Function):
         g1, b1 = gamma.reshape(-1).contiguous(), beta.reshape(-1).contiguous()
         y = torch.empty(B, C, ldt, **f32)
         mean, rstd = torch.empty(B, ldt, **f32), torch.empty(B, ldt, **f32)
-        ws = torch.empty(B, 2, ldt, device=x.device, dtype=torch.float64)
+        ws = cln_workspace(K, B, C, n_frames, ldt, x.device)
         K.cln_fwd(x, g1, b1, y, mean, rstd, ws, B, C, n_frames, ldt, eps, alpha=alpha)
         ctx.save_for_backward(x, g1, mean, rstd, alpha)
         ctx.meta = (B, C, n_frames, ldt, eps, gamma.shape, beta.shape)
@@ -234,7 +239,7 @@ class PaddedCLNFn(torch.autograd.Function):
         dx = torch.empty(B, C, ldt, **f32)
         pg, pb = torch.empty(B, C, **f32), torch.empty(B, C, **f32)
         pa = torch.empty(B, C, **f32) if alpha is not None else None
-        ws = torch.empty(B, 2, ldt, device=x.device, dtype=torch.float64)
+        ws = cln_workspace(K, B, C, F, ldt, x.device)
         K.cln_bwd(dy.contiguous(), x, g1, mean, rstd, dx, pg, pb, ws, B, C, F, ldt, eps, alpha=alpha, dalpha_part=pa)
         dgamma, dbeta = torch.empty(C, **f32), torch.empty(C, **f32)
         segs = [(pg, 0, dgamma, C, B, C, 0, 1.0), (pb, 0, dbeta, C, B, C, 0, 1.0)]

@@ -33,7 +33,7 @@ extern "C" {
 
 typedef void* sep_stream_t; /* hipStream_t */
 
-#define SEP_ABI_VERSION 20
+#define SEP_ABI_VERSION 21
 #define SEP_STATS_SLOTS 16
 #define SEP_ARRIVE_INTS 17 /* arrival counters per sample: one per slot + one for the slots (csrc/common.hpp, gln_bwd_publish) */
 
@@ -301,11 +301,14 @@ int sep_softmax_ch_bwd(const float* y, float* g, int B, int C, int T, int ldt, s
 /* Cumulative layer norm (causal cLN), CumulativeLayerNorm1d of reference src/modules/norm.py:42-101 and its autograd backward:
  *   y = (x - m_t) / (sqrt(v_t) + eps) * gamma_c + beta_c with the mean / biased variance of all channels and frames <= t.
  * x, y, dy, dx: (B, C, ldt) fp32, frames contiguous, ldt % 4 == 0, frames >= T written as zeros; mean, rstd: (B, ldt) fp32 (ABI 20: rows of
- * ldt, entries >= T untouched), written by the forward and read by the backward; ws: (B, 2, ldt) fp64 scratch (column sums, then their
- * prefix / suffix sums);
+ * ldt, entries >= T untouched), written by the forward and read by the backward; ws: scratch of sep_cln_ws_bytes(B, C, T, ldt) bytes, 16-byte
+ * aligned (ABI 21: for C <= 512 one pass each way -- a workgroup holds all channels of a 32-frame tile and takes the prefix / suffix of the
+ * earlier / later tiles from a look-back chain whose records live in ws, with the per-tile partial sums of the parameter gradients behind
+ * them; for wider rows the column sums of three launches: (B, 2, ldt) fp64);
  * dgamma_part, dbeta_part: (B, C) per-sample sums, to be added over the samples (sep_reduce_slabs).
  * alpha (ABI 20; may be NULL): the single slope of a PReLU in FRONT of the norm (tdcn.py:113-116, 182-186: nonlinear1d then norm1d): the
  * kernels normalise u = PReLU(x; alpha), dx is the gradient at x, and dalpha_part (B, C) receives sum_t du * x * [x <= 0] per row. */
+size_t sep_cln_ws_bytes(int B, int C, int T, int ldt);
 int sep_cln_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, double* ws, int B, int C,
                 int T, int ldt, float eps, const float* alpha, sep_stream_t stream);
 int sep_cln_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,

@@ -399,6 +399,9 @@ class EmuBackend:
         g.copy_(v)
 
     # ------------------------------------------------------------------ cumulative layer norm
+    def cln_ws_bytes(self, B, C, T, ldt):
+        return B * 2 * ldt * 8
+
     def cln_fwd(self, x, gamma, beta, y, mean, rstd, ws, B, C, T, ldt, eps, alpha=None):
         if alpha is not None:
             x = _prelu(x, alpha)

@@ -19,7 +19,7 @@ HEADER = os.path.join(ROOT, "include", "sepkernels.h")
 def _declared():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|const char\s*\*)\s+(sep_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(?:int|size_t|const char\s*\*)\s+(sep_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_every_declared_symbol_is_exported_and_bound():
@@ -30,9 +30,9 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(lib, n), "{} declared in sepkernels.h but not exported".format(n)
         assert n in sepkernels.SIGNATURES, "{} has no ctypes signature".format(n)
     assert sorted(sepkernels.SIGNATURES) == names
-    assert lib.sep_version() == sepkernels.ABI_VERSION == 20
+    assert lib.sep_version() == sepkernels.ABI_VERSION == 21
     header = open(HEADER).read()
-    assert "#define SEP_ABI_VERSION 20" in header and "#define SEP_STATS_SLOTS 16" in header
+    assert "#define SEP_ABI_VERSION 21" in header and "#define SEP_STATS_SLOTS 16" in header
     assert sepkernels.STATS_SLOTS == 16
 
 

@@ -826,7 +826,7 @@ def test_cln_fwd_bwd(B, C, T):
     (y64 * dy[..., :T].double()).sum().backward()
     f32 = dict(device=device_name(), dtype=torch.float32)
     y, mean, rstd = torch.full((B, C, ldt), float("nan"), **f32), torch.empty(B, ldt, **f32), torch.empty(B, ldt, **f32)
-    ws = torch.empty(B, 2, ldt, device=device_name(), dtype=torch.float64)
+    ws = torch.empty((HIP.cln_ws_bytes(B, C, T, ldt) + 7) // 8, device=device_name(), dtype=torch.float64)
     HIP.cln_fwd(to_device(x), to_device(gamma), to_device(beta), y, mean, rstd, ws, B, C, T, ldt, eps)
     dx, pg, pb = torch.full((B, C, ldt), float("nan"), **f32), torch.empty(B, C, **f32), torch.empty(B, C, **f32)
     HIP.cln_bwd(to_device(dy), to_device(x), to_device(gamma), mean, rstd, dx, pg, pb, ws, B, C, T, ldt, eps)
@@ -870,7 +870,7 @@ def test_prelu_cln_fwd_bwd(B, C, T, a):
     (y64 * dy[..., :T].double()).sum().backward()
     f32 = dict(device=device_name(), dtype=torch.float32)
     y, mean, rstd = torch.full((B, C, ldt), float("nan"), **f32), torch.empty(B, ldt, **f32), torch.empty(B, ldt, **f32)
-    ws = torch.empty(B, 2, ldt, device=device_name(), dtype=torch.float64)
+    ws = torch.empty((HIP.cln_ws_bytes(B, C, T, ldt) + 7) // 8, device=device_name(), dtype=torch.float64)
     HIP.cln_fwd(to_device(x), to_device(gamma), to_device(beta), y, mean, rstd, ws, B, C, T, ldt, eps, alpha=to_device(alpha))
     dx, pg, pb, pa = torch.full((B, C, ldt), float("nan"), **f32), torch.empty(B, C, **f32), torch.empty(B, C, **f32), torch.empty(B, C, **f32)
     HIP.cln_bwd(to_device(dy), to_device(x), to_device(gamma), mean, rstd, dx, pg, pb, ws, B, C, T, ldt, eps, alpha=to_device(alpha), dalpha_part=pa)

@@ -35,7 +35,7 @@ CASES = [
                               (2, 1, 2, 1, 0, False), (1, 1, 64, 16, 0, False)]),
     ("test_softmax_over_channels", [(2, 128, 300), (3, 50, 64), (2, 7, 1)]),
     ("test_gln_standalone_and_repack", [()]),
-    ("test_cln_fwd_bwd", [(2, 24, 203), (3, 128, 3999)]),
+    ("test_cln_fwd_bwd", [(2, 24, 203), (3, 128, 3999), (2, 300, 150)]),          # the last: 16-wave tiles of the chained backward
     ("test_prelu_cln_fwd_bwd", [(2, 24, 203, 0.25), (1, 48, 1030, 0.0)]),
     ("test_gln_tokens_fwd_bwd", [(3, 250, 64), (5, 37, 16), (1, 7, 1024)]),
     ("test_sisdr_kernels", [(1, 0), (2, 1), (3, 0)]),

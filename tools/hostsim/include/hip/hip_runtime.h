@@ -124,7 +124,10 @@ static inline double atomicAdd(double* p, double v) {
 }
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 #define __HIP_MEMORY_SCOPE_AGENT 4
-#define __hip_atomic_load(p, order, scope) (*(p))
+template <typename T> static inline T sim_atomic_load(const T* p, int order) { T v; __atomic_load(const_cast<T*>(p), &v, order); return v; }
+template <typename T, typename V> static inline void sim_atomic_store(T* p, V v, int order) { T t = (T)v; __atomic_store(p, &t, order); }
+#define __hip_atomic_load(p, order, scope) sim_atomic_load(p, order)
+#define __hip_atomic_store(p, v, order, scope) sim_atomic_store(p, v, order)
 static inline float unsafeAtomicAdd(float* p, float v) { return atomicAdd(p, v); }          // the hardware fp32 atomic of the device build
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }

@@ -180,7 +180,7 @@ def case_norms(R):
         ys, ms, rs = GK.nan(B, C, ldt), torch.zeros(B, ldt), torch.zeros(B, ldt)
         gamma, beta = GK.rnd(C) + 1, GK.rnd(C)
         GK.EMU.cln_fwd(xs, gamma, beta, ye, me, re_, torch.empty(B, 2, ldt, dtype=torch.float64), B, C, T, ldt, 1e-12)
-        GK.HIP.cln_fwd(xs.clone(), gamma.clone(), beta.clone(), ys, ms, rs, torch.empty(B, 2, ldt, dtype=torch.float64), B, C, T, ldt, 1e-12)   # the workspace is scratch
+        GK.HIP.cln_fwd(xs.clone(), gamma.clone(), beta.clone(), ys, ms, rs, torch.empty((GK.HIP.cln_ws_bytes(B, C, T, ldt) + 7) // 8, dtype=torch.float64), B, C, T, ldt, 1e-12)   # the workspace is scratch
         assert torch.isfinite(ys).all() and (ys - ye).abs().max() <= 5e-4 * ye.abs().max() and (ms[:, :T] - me[:, :T]).abs().max() <= 1e-5 * (1 + me.abs().max())
     return "norms B={} C={} T={}".format(B, C, T)
 
