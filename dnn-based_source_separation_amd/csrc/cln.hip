@@ -256,15 +256,15 @@ __device__ __forceinline__ void chain_lookback(const unsigned long long* agg, co
         while (true) {
             have_inc = true;                                                     // before the chain's head: an empty prefix
             bool have = true;
-            if (idx >= 0) {
-                wa = __hip_atomic_load(incl + 2 * idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                wq = __hip_atomic_load(incl + 2 * idx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                have_inc = wa != 0 && wq != 0;
-                if (!have_inc) {
-                    wa = __hip_atomic_load(agg + 2 * idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    wq = __hip_atomic_load(agg + 2 * idx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    have = wa != 0 && wq != 0;
-                }
+            if (idx >= 0) {                                                      // all four words in one round trip
+                const unsigned long long ia = __hip_atomic_load(incl + 2 * idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long iq = __hip_atomic_load(incl + 2 * idx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long ga = __hip_atomic_load(agg + 2 * idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long gq = __hip_atomic_load(agg + 2 * idx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                have_inc = ia != 0 && iq != 0;
+                wa = have_inc ? ia : ga;
+                wq = have_inc ? iq : gq;
+                have = wa != 0 && wq != 0;
             }
             inc = __builtin_amdgcn_ballot_w64(have_inc);
             const unsigned long long ready = __builtin_amdgcn_ballot_w64(have);

@@ -244,7 +244,7 @@ class PaddedCLNFn(torch.autograd.Function):
         dgamma, dbeta = torch.empty(C, **f32), torch.empty(C, **f32)
         segs = [(pg, 0, dgamma, C, B, C, 0, 1.0), (pb, 0, dbeta, C, B, C, 0, 1.0)]
         K.reduce_slabs(segs)
-        dalpha = pa.double().sum().to(x.dtype).view(alpha.shape) if alpha is not None else None      # B*C row partials -> the one slope
+        dalpha = pa.sum(dtype=torch.float64).to(x.dtype).view(alpha.shape) if alpha is not None else None      # B*C row partials -> the one slope
         return dx, None, dalpha, dgamma.view(gshape), dbeta.view(bshape), None
 
 
