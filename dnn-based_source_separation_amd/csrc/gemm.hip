@@ -1607,6 +1607,8 @@ extern "C" int sep_pw_gemm(const sep_gemm_desc* d, sep_stream_t stream) {
         else if (!tr && !sp && pm == SEP_PRO_PRELU && ef == SEP_EPI_SIGMOID) SEP_LD(false, SEP_PRO_PRELU, false, SEP_EPI_SIGMOID);               // mask
         else if (!tr && !sp && pm == SEP_PRO_GLN && ef == 0) SEP_LD(false, SEP_PRO_GLN, false, 0);                                               // bottleneck
         else if (!tr && !sp && pm == SEP_PRO_NONE && ef == 0) SEP_LD(false, SEP_PRO_NONE, false, 0);                                             // plain 1x1 conv
+        else if (!tr && !sp && pm == SEP_PRO_NONE && ef == SEP_EPI_RESIDUAL) SEP_LD(false, SEP_PRO_NONE, false, SEP_EPI_RESIDUAL);               // heads of the staged (causal) layers: input already normalised
+        else if (tr && sp && pm == SEP_PRO_NONE && ef == 0) SEP_LD(true, SEP_PRO_NONE, true, 0);                                                 // ... and their heads^T
         else if (tr && !sp && pm == SEP_PRO_NONE && ef == 0) SEP_LD(true, SEP_PRO_NONE, false, 0);                                               // plain input gradient
         else if (tr && !sp && pm == SEP_PRO_NONE && ef == SEP_EPI_PRELU_BWD) SEP_LD(true, SEP_PRO_NONE, false, SEP_EPI_PRELU_BWD);               // mask^T
         else if (tr && sp && pm == SEP_PRO_NONE && ef == (SEP_EPI_ROWSUMS | SEP_EPI_ROWSUMS_PRELU)) SEP_LD(true, SEP_PRO_NONE, true, SEP_EPI_ROWSUMS | SEP_EPI_ROWSUMS_PRELU);   // heads^T

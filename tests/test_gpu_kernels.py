@@ -222,6 +222,18 @@ def test_gemm_packed_heads_residual_accumulate(arith):
     both("pw_gemm", [], kw)
 
 
+def test_gemm_heads_plain_input_residual_accumulate(arith):
+    """the same joint product on an input that is already normalised (the staged causal layers: cLN is a pass of its own): no prologue,
+    residual on the first m_split rows, accumulation on the rest"""
+    B, Bn, Sc, H, T = 2, 128, 128, 256, 500
+    ldt = 512
+    v = padded(B, H, T, ldt) * 1.5 + 0.2
+    A, bias = rnd(Bn + Sc, H, scale=H ** -0.5), rnd(Bn + Sc)
+    kw = dict(B=B, M=Bn + Sc, K=H, T=T, ldt=ldt, A=A, X=v, Y=nan(B, Bn, ldt), Y2=padded(B, Sc, T, ldt), m_split=Bn, bias=bias, accumulate=1,
+              epi_flags=EPI_RESIDUAL, epi_res=padded(B, Bn, T, ldt))
+    both("pw_gemm", [], kw)
+
+
 def test_gemm_prelu_prologue_sigmoid(arith):
     B, M, K, T = 2, 384, 64, 260
     ldt, X, A, bias = _gemm_common(B, M, K, T)

@@ -65,6 +65,8 @@ GEMM_CASES = [
     ("f16x3-packed", "test_gemm_dgrad_prelu_bwd", ()),
     ("f16x3-packed", "test_gemm_dgrad_two_sources_plain", (512, 700)),
     ("f16x3-packed", "test_gemm_packed_heads_residual_accumulate", ()),
+    ("f16x3", "test_gemm_heads_plain_input_residual_accumulate", ()),           # the staged causal layers' heads and heads^T: the direct kernel, fp32 weights
+    ("f16x3", "test_gemm_dgrad_two_sources_plain", (256, 130)),
     ("f32", "test_gemm_gln_bwd_prologue", (0,)),
     ("bf16x6", "test_wgrad_two_sources_gln_prelu", ()),
     ("f16x3", "test_wgrad_latent_product_and_prelu", ()),
