@@ -1360,6 +1360,148 @@ __global__ __launch_bounds__(256) void gln_tokens_bwd_kernel(const float* __rest
     }
 }
 
+// ---- few, long sequences (GALRNet: one sequence per SAMPLE, ~1 MB each): one workgroup per sequence leaves the chip to nseq compute
+// units (96 / 128 us forward / backward with 4 samples, profiles/r05zj_galrnet_kernel_stats.md).  Split form: grid (nsplit, nseq), slices of
+// whole 1024-float trips (a thread keeps its four features), the slices' partial sums in a workspace, every workgroup adding them up in
+// slice order for itself; two launches each way.
+//   wsd[(s * nsplit + j) * 2 + {0, 1}]            forward: sum, sum of squares of slice j | backward: sum g gamma, sum g gamma xhat
+//   wsf[((s * nsplit + j) * 2 + {0, 1}) * C + c]  backward: slice j's sum_t g xhat, sum_t g of feature c
+__device__ __forceinline__ void gln_tokens_slice(const int n, const int nsplit, int& lo, int& hi) {
+    const int trips = (n + 1023) / 1024, per = (trips + nsplit - 1) / nsplit;
+    lo = blockIdx.x * per * 1024;
+    hi = lo + per * 1024;
+    if (hi > n) hi = n;
+}
+__global__ __launch_bounds__(256) void gln_tokens_part_fwd_kernel(const float* __restrict__ x, double* __restrict__ wsd, int n, int nsplit) {
+    __shared__ double red[4];
+    const float* xs = x + (size_t)blockIdx.y * n;
+    int lo, hi;
+    gln_tokens_slice(n, nsplit, lo, hi);
+    double s = 0.0, ss = 0.0;
+    for (int i = lo + 4 * threadIdx.x; i < hi; i += 1024) {
+        const float4 v = ld4(xs + i);
+        s += (double)((v.x + v.y) + (v.z + v.w));
+        ss += (double)(fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w));
+    }
+    const double ts = block_sum_256<double>(s, red), tss = block_sum_256<double>(ss, red);
+    if (threadIdx.x == 0) {
+        wsd[((size_t)blockIdx.y * nsplit + blockIdx.x) * 2] = ts;
+        wsd[((size_t)blockIdx.y * nsplit + blockIdx.x) * 2 + 1] = tss;
+    }
+}
+__global__ __launch_bounds__(256) void gln_tokens_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   const double* __restrict__ wsd, float* __restrict__ y, float* __restrict__ stats, int n,
+                                                                   int nsplit, int C, float eps) {
+    const float* xs = x + (size_t)blockIdx.y * n;
+    float* ys = y + (size_t)blockIdx.y * n;
+    double ts = 0.0, tss = 0.0;
+    for (int j = 0; j < nsplit; ++j) {
+        ts += wsd[((size_t)blockIdx.y * nsplit + j) * 2];
+        tss += wsd[((size_t)blockIdx.y * nsplit + j) * 2 + 1];
+    }
+    const double m = ts / n;
+    double var = tss / n - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mu = (float)m, rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (blockIdx.x == 0 && threadIdx.x == 0) { stats[2 * blockIdx.y] = mu; stats[2 * blockIdx.y + 1] = rstd; }
+    int lo, hi;
+    gln_tokens_slice(n, nsplit, lo, hi);
+    const int c0 = (4 * threadIdx.x) % C;
+    const float4 g4 = ld4(gamma + c0), b4 = ld4(beta + c0);
+    for (int i = lo + 4 * threadIdx.x; i < hi; i += 1024) {
+        const float4 v = ld4(xs + i);
+        st4(ys + i, make_float4(fmaf((v.x - mu) * rstd, g4.x, b4.x), fmaf((v.y - mu) * rstd, g4.y, b4.y),
+                                fmaf((v.z - mu) * rstd, g4.z, b4.z), fmaf((v.w - mu) * rstd, g4.w, b4.w)));
+    }
+}
+__global__ __launch_bounds__(256) void gln_tokens_part_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ stats, double* __restrict__ wsd, float* __restrict__ wsf, int n,
+                                                                  int nsplit, int C) {
+    __shared__ double red[4];
+    __shared__ float pc[256][8];
+    const float* xs = x + (size_t)blockIdx.y * n;
+    const float* gs = dy + (size_t)blockIdx.y * n;
+    const float mu = stats[2 * blockIdx.y], rstd = stats[2 * blockIdx.y + 1];
+    const int c0 = (4 * threadIdx.x) % C;
+    const float4 g4 = ld4(gamma + c0);
+    const float ga[4] = {g4.x, g4.y, g4.z, g4.w};
+    int lo, hi;
+    gln_tokens_slice(n, nsplit, lo, hi);
+    double s1 = 0.0, s2 = 0.0;
+    float pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = lo + 4 * threadIdx.x; i < hi; i += 1024) {
+        const float4 v = ld4(xs + i), g = ld4(gs + i);
+        const float xv[4] = {v.x, v.y, v.z, v.w}, gv[4] = {g.x, g.y, g.z, g.w};
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (xv[e] - mu) * rstd, gg = gv[e] * ga[e];
+            a1 += gg; a2 = fmaf(gg, xh, a2);
+            pg[e] = fmaf(gv[e], xh, pg[e]); pb[e] += gv[e];
+        }
+        s1 += (double)a1; s2 += (double)a2;
+    }
+    const double t1 = block_sum_256<double>(s1, red), t2 = block_sum_256<double>(s2, red);
+    const size_t rec = (size_t)blockIdx.y * nsplit + blockIdx.x;
+    if (threadIdx.x == 0) { wsd[rec * 2] = t1; wsd[rec * 2 + 1] = t2; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { pc[threadIdx.x][e] = pg[e]; pc[threadIdx.x][4 + e] = pb[e]; }
+    __syncthreads();
+    float* ps = wsf + rec * 2 * C;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float tg = 0.f, tb = 0.f;
+        for (int t = c / 4; t < 256; t += C / 4) { tg += pc[t][c & 3]; tb += pc[t][4 + (c & 3)]; }
+        ps[c] = tg; ps[C + c] = tb;
+    }
+}
+__global__ __launch_bounds__(256) void gln_tokens_apply_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ stats, const double* __restrict__ wsd, const float* __restrict__ wsf,
+                                                                   float* __restrict__ dx, float* __restrict__ part, int n, int nsplit, int C) {
+    const float* xs = x + (size_t)blockIdx.y * n;
+    const float* gs = dy + (size_t)blockIdx.y * n;
+    float* ds = dx + (size_t)blockIdx.y * n;
+    const float mu = stats[2 * blockIdx.y], rstd = stats[2 * blockIdx.y + 1];
+    double t1 = 0.0, t2 = 0.0;
+    for (int j = 0; j < nsplit; ++j) {
+        t1 += wsd[((size_t)blockIdx.y * nsplit + j) * 2];
+        t2 += wsd[((size_t)blockIdx.y * nsplit + j) * 2 + 1];
+    }
+    const float m1 = (float)(t1 / n), m2 = (float)(t2 / n);
+    if (blockIdx.x == 0) {                                                       // the per-feature sums of the sequence, slices in order
+        float* ps = part + (size_t)blockIdx.y * 2 * C;
+        for (int c = threadIdx.x; c < 2 * C; c += 256) {
+            float t = 0.f;
+            for (int j = 0; j < nsplit; ++j) t += wsf[((size_t)blockIdx.y * nsplit + j) * 2 * C + c];
+            ps[c] = t;
+        }
+    }
+    int lo, hi;
+    gln_tokens_slice(n, nsplit, lo, hi);
+    const int c0 = (4 * threadIdx.x) % C;
+    const float4 g4 = ld4(gamma + c0);
+    const float ga[4] = {g4.x, g4.y, g4.z, g4.w};
+    for (int i = lo + 4 * threadIdx.x; i < hi; i += 1024) {
+        const float4 v = ld4(xs + i), g = ld4(gs + i);
+        const float xv[4] = {v.x, v.y, v.z, v.w}, gv[4] = {g.x, g.y, g.z, g.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (xv[e] - mu) * rstd;
+            o[e] = rstd * (gv[e] * ga[e] - m1 - xh * m2);
+        }
+        st4(ds + i, make_float4(o[0], o[1], o[2], o[3]));
+    }
+}
+// slices per sequence: none while the sequences alone fill the chip; otherwise ~512 workgroups, at least 16 trips each
+static int gln_tokens_nsplit(int nseq, long n) {
+    if (nseq >= 128) return 1;
+    const long trips = (n + 1023) / 1024;
+    long ns = (512 + nseq - 1) / nseq;
+    if (ns > trips / 16) ns = trips / 16;
+    if (ns > 64) ns = 64;
+    return ns < 2 ? 1 : (int)ns;
+}
+
 // ---- the TCN layers' own depthwise geometry (stride 1, three taps, Tin = Tout = the workspace stride, `pad` zeros in front: (P - 1) d when
 // causal), one (b, c) row per workgroup, a float4 of frames per thread and trip.  Tap k sits at t + k d - pad.  For shifts that are multiples
 // of 4 the taps are aligned float4 loads; for the others (d = 1, 2: the first two layers of a block) the row goes through LDS once.
@@ -1741,19 +1883,42 @@ extern "C" int sep_softmax_ch_bwd(const float* y, float* g, int B, int C, int T,
     return 0;
 }
 
-extern "C" int sep_gln_tokens_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, int nseq, int L, int C, float eps,
-                                  sep_stream_t stream) {
+extern "C" size_t sep_gln_tokens_ws_bytes(int nseq, int L, int C) {
+    if (nseq <= 0 || L <= 0 || C <= 0) return 0;
+    const int ns = gln_tokens_nsplit(nseq, (long)L * C);
+    return ns == 1 ? 0 : (size_t)nseq * ns * 2 * (sizeof(double) + (size_t)C * sizeof(float));
+}
+
+extern "C" int sep_gln_tokens_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, void* ws, int nseq, int L, int C,
+                                  float eps, sep_stream_t stream) {
     SEP_REQUIRE(x && gamma && beta && y && stats && nseq > 0 && L > 0 && C >= 4 && 1024 % C == 0, "sep_gln_tokens_fwd: bad arguments (C must divide 1024, C >= 4)");
-    SEP_REQUIRE((long)L * C <= 0x7fffffffL, "sep_gln_tokens_fwd: sequence too long");
-    hipLaunchKernelGGL(gln_tokens_fwd_kernel, dim3((unsigned)nseq), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, stats, L * C, C, eps);
+    SEP_REQUIRE((long)L * C <= 0x7fffffffL && nseq <= 65535, "sep_gln_tokens_fwd: sequence too long / too many sequences");
+    const int ns = gln_tokens_nsplit(nseq, (long)L * C);
+    if (ns > 1) {
+        SEP_REQUIRE(ws != nullptr, "sep_gln_tokens_fwd: this shape needs the workspace of sep_gln_tokens_ws_bytes");
+        hipLaunchKernelGGL(gln_tokens_part_fwd_kernel, dim3(ns, nseq), dim3(256), 0, (hipStream_t)stream, x, (double*)ws, L * C, ns);
+        hipLaunchKernelGGL(gln_tokens_apply_fwd_kernel, dim3(ns, nseq), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (const double*)ws, y, stats, L * C, ns, C, eps);
+    } else {
+        hipLaunchKernelGGL(gln_tokens_fwd_kernel, dim3((unsigned)nseq), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, stats, L * C, C, eps);
+    }
     SEP_CHECK_LAUNCH("sep_gln_tokens_fwd");
     return 0;
 }
 
-extern "C" int sep_gln_tokens_bwd(const float* dy, const float* x, const float* gamma, const float* stats, float* dx, float* part, int nseq, int L,
-                                  int C, sep_stream_t stream) {
+extern "C" int sep_gln_tokens_bwd(const float* dy, const float* x, const float* gamma, const float* stats, float* dx, float* part, void* ws, int nseq,
+                                  int L, int C, sep_stream_t stream) {
     SEP_REQUIRE(dy && x && gamma && stats && dx && part && nseq > 0 && L > 0 && C >= 4 && 1024 % C == 0, "sep_gln_tokens_bwd: bad arguments (C must divide 1024, C >= 4)");
-    hipLaunchKernelGGL(gln_tokens_bwd_kernel, dim3((unsigned)nseq), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, stats, dx, part, L * C, C);
+    SEP_REQUIRE((long)L * C <= 0x7fffffffL && nseq <= 65535, "sep_gln_tokens_bwd: sequence too long / too many sequences");
+    const int ns = gln_tokens_nsplit(nseq, (long)L * C);
+    if (ns > 1) {
+        SEP_REQUIRE(ws != nullptr, "sep_gln_tokens_bwd: this shape needs the workspace of sep_gln_tokens_ws_bytes");
+        double* wsd = (double*)ws;
+        float* wsf = (float*)(wsd + (size_t)nseq * ns * 2);
+        hipLaunchKernelGGL(gln_tokens_part_bwd_kernel, dim3(ns, nseq), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, stats, wsd, wsf, L * C, ns, C);
+        hipLaunchKernelGGL(gln_tokens_apply_bwd_kernel, dim3(ns, nseq), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, stats, (const double*)wsd, (const float*)wsf, dx, part, L * C, ns, C);
+    } else {
+        hipLaunchKernelGGL(gln_tokens_bwd_kernel, dim3((unsigned)nseq), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, stats, dx, part, L * C, C);
+    }
     SEP_CHECK_LAUNCH("sep_gln_tokens_bwd");
     return 0;
 }

@@ -131,8 +131,9 @@ SIGNATURES = {
     "sep_cln_ws_bytes": [_I] * 4,                                    # returns size_t
     "sep_cln_fwd": [_vp] * 7 + [_I] * 4 + [_F, _vp, _vp],
     "sep_cln_bwd": [_vp] * 9 + [_I] * 4 + [_F, _vp, _vp, _vp],
-    "sep_gln_tokens_fwd": [_vp] * 5 + [_I] * 3 + [_F, _vp],
-    "sep_gln_tokens_bwd": [_vp] * 6 + [_I] * 3 + [_vp],
+    "sep_gln_tokens_ws_bytes": [_I] * 3,                             # returns size_t
+    "sep_gln_tokens_fwd": [_vp] * 6 + [_I] * 3 + [_F, _vp],
+    "sep_gln_tokens_bwd": [_vp] * 7 + [_I] * 3 + [_vp],
     "sep_gln_stats": [_vp, _vp, _I, _I, _I, _I, _vp],
     "sep_gln_apply": [_vp] * 5 + [_I] * 4 + [_D, _F, _vp],
     "sep_gln_bwd_rowsums": [_vp, _vp, _vp, _I, _I, _I, _I, _vp],
@@ -183,7 +184,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_char_p if name == "sep_last_error" else (ctypes.c_size_t if name == "sep_cln_ws_bytes" else ctypes.c_int)
+        fn.restype = ctypes.c_char_p if name == "sep_last_error" else (ctypes.c_size_t if name in ("sep_cln_ws_bytes", "sep_gln_tokens_ws_bytes") else ctypes.c_int)
     if lib.sep_version() != ABI_VERSION:
         raise SepKernelsError("libsepkernels ABI {} != binding ABI {}".format(lib.sep_version(), ABI_VERSION))
     _lib = lib
@@ -370,13 +371,16 @@ class HipBackend:
                                   _ptr(dgamma_part, _f32), _ptr(dbeta_part, _f32), _ptr(ws, _f64), B, C, T, ldt, eps, _ptr(alpha, _f32),
                                   _ptr(dalpha_part, _f32), _stream()), "sep_cln_bwd")
 
-    def gln_tokens_fwd(self, x, gamma, beta, y, stats, nseq, L, C, eps):
-        _check(load().sep_gln_tokens_fwd(_ptr(x, _f32), _ptr(gamma, _f32), _ptr(beta, _f32), _ptr(y, _f32), _ptr(stats, _f32), nseq, L, C, eps,
-                                         _stream()), "sep_gln_tokens_fwd")
+    def gln_tokens_ws_bytes(self, nseq, L, C):
+        return int(load().sep_gln_tokens_ws_bytes(nseq, L, C))
 
-    def gln_tokens_bwd(self, dy, x, gamma, stats, dx, part, nseq, L, C):
+    def gln_tokens_fwd(self, x, gamma, beta, y, stats, nseq, L, C, eps, ws=None):
+        _check(load().sep_gln_tokens_fwd(_ptr(x, _f32), _ptr(gamma, _f32), _ptr(beta, _f32), _ptr(y, _f32), _ptr(stats, _f32), _ptr(ws, _f64), nseq, L, C,
+                                         eps, _stream()), "sep_gln_tokens_fwd")
+
+    def gln_tokens_bwd(self, dy, x, gamma, stats, dx, part, nseq, L, C, ws=None):
         _check(load().sep_gln_tokens_bwd(_ptr(dy, _f32), _ptr(x, _f32), _ptr(gamma, _f32), _ptr(stats, _f32), _ptr(dx, _f32), _ptr(part, _f32),
-                                         nseq, L, C, _stream()), "sep_gln_tokens_bwd")
+                                         _ptr(ws, _f64), nseq, L, C, _stream()), "sep_gln_tokens_bwd")
 
     def gln_stats(self, x, stats, B, C, T, ldt):
         _check(load().sep_gln_stats(_ptr(x, _f32), _ptr(stats, _f64), B, C, T, ldt, _stream()), "sep_gln_stats")

@@ -739,6 +739,12 @@ def lstm_bidirectional(x, rnn):
 LSTM_KERNEL_HIDDEN = (16, 32, 64, 128)
 
 
+def _gln_tokens_ws(K, nseq, L, C, device):
+    """the scratch sep_gln_tokens_* ask for at this shape (few long sequences are cut into slices), or None"""
+    nbytes = K.gln_tokens_ws_bytes(nseq, L, C)
+    return torch.empty((nbytes + 7) // 8, device=device, dtype=torch.float64) if nbytes else None
+
+
 class TokenGLNFn(torch.autograd.Function):
     """Global layer norm of token-major rows: x (nseq, L, C), features contiguous -> the same shape; statistics over the L * C values of a
     sequence, gain / shift per feature (GlobalLayerNorm applied to x.permute(0, 2, 1): what the dual-path transformer blocks of the reference
@@ -751,7 +757,7 @@ class TokenGLNFn(torch.autograd.Function):
         nseq, L, C = x.shape
         y = torch.empty_like(x)
         stats = torch.empty(nseq, 2, device=x.device, dtype=x.dtype)
-        K.gln_tokens_fwd(x, gamma, beta, y, stats, nseq, L, C, eps)
+        K.gln_tokens_fwd(x, gamma, beta, y, stats, nseq, L, C, eps, ws=_gln_tokens_ws(K, nseq, L, C, x.device))
         ctx.save_for_backward(x, gamma, stats)
         return y
 
@@ -762,7 +768,7 @@ class TokenGLNFn(torch.autograd.Function):
         nseq, L, C = x.shape
         dx = torch.empty_like(x)
         part = torch.empty(nseq, 2, C, device=x.device, dtype=x.dtype)
-        K.gln_tokens_bwd(dy.contiguous(), x, gamma, stats, dx, part, nseq, L, C)
+        K.gln_tokens_bwd(dy.contiguous(), x, gamma, stats, dx, part, nseq, L, C, ws=_gln_tokens_ws(K, nseq, L, C, x.device))
         tot = part.sum(0)
         return dx, tot[0], tot[1], None
 

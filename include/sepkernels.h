@@ -319,11 +319,14 @@ int sep_cln_bwd(const float* dy, const float* x, const float* gamma, const float
  * Linear layers of the dual-path separators (dptnet.py:505-560 `norm1d(x.permute(1, 2, 0))`): statistics over the L*C values of a sequence
  * (biased variance, eps inside the root, as nn.GroupNorm(1, C)), gain / shift per feature.  C must divide 1024, C >= 4, (L*C) % 4 == 0.
  * stats (nseq, 2) = {mean, rstd}, written forward, read backward; part (nseq, 2, C) = {sum_t dy*xhat | sum_t dy} per sequence: summed over
- * the sequences they are d(gamma), d(beta). */
-int sep_gln_tokens_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, int nseq, int L, int C, float eps,
+ * the sequences they are d(gamma), d(beta).  ws (ABI 21): scratch of sep_gln_tokens_ws_bytes(nseq, L, C) bytes, 8-byte aligned; 0 bytes (ws may
+ * be NULL) while the sequences alone fill the chip -- few long sequences (GALRNet normalises one per sample) are cut into slices whose
+ * partial sums meet there. */
+size_t sep_gln_tokens_ws_bytes(int nseq, int L, int C);
+int sep_gln_tokens_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, void* ws, int nseq, int L, int C, float eps,
                        sep_stream_t stream);
-int sep_gln_tokens_bwd(const float* dy, const float* x, const float* gamma, const float* stats, float* dx, float* part, int nseq, int L, int C,
-                       sep_stream_t stream);
+int sep_gln_tokens_bwd(const float* dy, const float* x, const float* gamma, const float* stats, float* dx, float* part, void* ws, int nseq, int L,
+                       int C, sep_stream_t stream);
 
 /* Stand-alone gLN (modules/norm.py:11-35) for callers outside the fused network. */
 int sep_gln_stats(const float* x, double* stats, int B, int C, int T, int ldt, sep_stream_t stream);

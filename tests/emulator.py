@@ -441,7 +441,10 @@ class EmuBackend:
         dbeta_part.reshape(B, C).copy_(g.sum(2).to(dbeta_part.dtype))
 
     # ------------------------------------------------------------------ gLN on token-major rows
-    def gln_tokens_fwd(self, x, gamma, beta, y, stats, nseq, L, C, eps):
+    def gln_tokens_ws_bytes(self, nseq, L, C):
+        return 0
+
+    def gln_tokens_fwd(self, x, gamma, beta, y, stats, nseq, L, C, eps, ws=None):
         v = x.reshape(nseq, L * C).double()
         m = v.mean(1, keepdim=True)
         r = 1.0 / torch.sqrt((v * v).mean(1, keepdim=True) - m * m + eps)
@@ -450,7 +453,7 @@ class EmuBackend:
         mu, rs = stats.reshape(nseq, 2)[:, 0].view(nseq, 1, 1), stats.reshape(nseq, 2)[:, 1].view(nseq, 1, 1)
         y.reshape(nseq, L, C).copy_((x.reshape(nseq, L, C) - mu) * rs * gamma.view(1, 1, C) + beta.view(1, 1, C))
 
-    def gln_tokens_bwd(self, dy, x, gamma, stats, dx, part, nseq, L, C):
+    def gln_tokens_bwd(self, dy, x, gamma, stats, dx, part, nseq, L, C, ws=None):
         mu, rs = stats.reshape(nseq, 2)[:, 0].view(nseq, 1, 1), stats.reshape(nseq, 2)[:, 1].view(nseq, 1, 1)
         g = dy.reshape(nseq, L, C)
         xh = (x.reshape(nseq, L, C) - mu) * rs

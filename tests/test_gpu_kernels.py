@@ -902,7 +902,7 @@ def test_prelu_cln_fwd_bwd(B, C, T, a):
     assert (dxe - dx).abs().max() <= 5e-5 * dxe.abs().max() and (pae - pa.cpu()).abs().max() <= 2e-4 * pae.abs().max() + 1e-5
 
 
-@pytest.mark.parametrize("nseq,L,C", [(3, 250, 64), (5, 37, 16), (2, 100, 128), (1, 7, 1024), (4, 258, 64)])
+@pytest.mark.parametrize("nseq,L,C", [(3, 250, 64), (5, 37, 16), (2, 100, 128), (1, 7, 1024), (4, 258, 64), (2, 1500, 64), (3, 4100, 16)])      # the last two: sliced sequences
 def test_gln_tokens_fwd_bwd(nseq, L, C):
     """sep_gln_tokens_fwd / bwd: gLN on token-major (nseq, L, C) rows against nn.functional.group_norm on the transposed tensor in float64
     (what the reference computes: dptnet.py:505-560, norm1d(x.permute(1, 2, 0)) with modules/norm.py:11-29)."""
@@ -916,9 +916,11 @@ def test_gln_tokens_fwd_bwd(nseq, L, C):
     (y64 * dy.double()).sum().backward()
     f32 = dict(device=device_name(), dtype=torch.float32)
     y, stats = torch.full((nseq, L, C), float("nan"), **f32), torch.empty(nseq, 2, **f32)
-    HIP.gln_tokens_fwd(to_device(x), to_device(gamma), to_device(beta), y, stats, nseq, L, C, eps)
+    nws = HIP.gln_tokens_ws_bytes(nseq, L, C)
+    ws = torch.empty((nws + 7) // 8, device=device_name(), dtype=torch.float64) if nws else None
+    HIP.gln_tokens_fwd(to_device(x), to_device(gamma), to_device(beta), y, stats, nseq, L, C, eps, ws=ws)
     dx, part = torch.full((nseq, L, C), float("nan"), **f32), torch.full((nseq, 2, C), float("nan"), **f32)
-    HIP.gln_tokens_bwd(to_device(dy), to_device(x), to_device(gamma), stats, dx, part, nseq, L, C)
+    HIP.gln_tokens_bwd(to_device(dy), to_device(x), to_device(gamma), stats, dx, part, nseq, L, C, ws=ws)
     device_sync()
     assert (y.cpu().double() - y64.detach()).abs().max() <= 2e-5 * y64.detach().abs().max()
     assert (dx.cpu().double() - x64.grad).abs().max() <= 5e-5 * x64.grad.abs().max()
