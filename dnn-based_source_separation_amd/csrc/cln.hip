@@ -383,7 +383,7 @@ __global__ __launch_bounds__(512) void cln_chain_fwd_kernel(const float* __restr
 
 // backward: the chain runs from the LAST tile of a sample to the first (suffix sums); parts[(b * nt + tile) * 3 * C + {0, 1, 2} * C + c] =
 // the tile's contributions to d(gamma_c), d(beta_c), d(alpha)
-// NW waves per workgroup (16 for C > 256: the tile's two tensors in 64 registers per thread left one workgroup per compute unit)
+// NW waves per workgroup
 template <int R, int NW>
 __global__ __launch_bounds__(64 * NW) void cln_chain_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ alpha, float* __restrict__ dx, float* __restrict__ parts,
@@ -486,6 +486,12 @@ __global__ __launch_bounds__(64 * NW) void cln_chain_bwd_kernel(const float* __r
         }
     }
     __syncthreads();
+    // (the products formed for the column sums -- PReLU(x), g gamma -- are formed AGAIN below: kept alive across the chain they cost 64
+    //  registers and an occupancy step; the empty asm hides the equality from the compiler)
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(xv[j][e]), "+v"(gv[j][e]));
     const float4 P4 = ld4(&pq[0][4 * fl]), Q4 = ld4(&pq[1][4 * fl]);
     const float Ps[4] = {P4.x, P4.y, P4.z, P4.w}, Qs[4] = {Q4.x, Q4.y, Q4.z, Q4.w};
     float* prow = parts + (size_t)(b * nt + tile) * 3 * C;
@@ -612,7 +618,9 @@ extern "C" int sep_cln_bwd(const float* dy, const float* x, const float* gamma, 
         const ChainWs cw = chain_ws(ws, B, C, nt);
         SEP_REQUIRE(hipMemsetAsync(ws, 0, cw.clear_bytes, stream) == hipSuccess, "sep_cln: clearing the chain records failed");
 #define SEP_CLB(RR, NW) hipLaunchKernelGGL((cln_chain_bwd_kernel<RR, NW>), dim3(B * nt), dim3(64 * NW), 0, stream, dy, x, mean, rstd, gamma, alpha, dx, cw.parts, cw.ticket, cw.agg, cw.incl, B, C, T, ldt, nt, eps)
-        if (C <= 64) SEP_CLB(1, 8); else if (C <= 128) SEP_CLB(2, 8); else if (C <= 256) SEP_CLB(4, 8); else SEP_CLB(4, 16);
+        // C > 256: 8 waves x 8 rounds (124 registers: two workgroups per compute unit, one walks its chain while the other streams) beat
+        // 16 waves x 4 rounds (88 registers but one workgroup per CU): 118 against 143 us at B = 16, C = 512 (profiles/r05ze_cln_chain.txt)
+        if (C <= 64) SEP_CLB(1, 8); else if (C <= 128) SEP_CLB(2, 8); else if (C <= 256) SEP_CLB(4, 8); else SEP_CLB(8, 8);
 #undef SEP_CLB
         hipLaunchKernelGGL(cln_chain_parts_kernel, dim3(ceil_div(C, 64), 3, B), dim3(1024), 0, stream, (const float*)cw.parts, dgamma_part, dbeta_part, dalpha_part, B, C, nt);
         SEP_CHECK_LAUNCH("sep_cln_bwd");
