@@ -1605,6 +1605,7 @@ extern "C" int sep_pw_gemm(const sep_gemm_desc* d, sep_stream_t stream) {
         else if (!tr && !sp && pm == SEP_PRO_GLN_PRELU && ef == SEP_EPI_RESIDUAL) SEP_LD(false, SEP_PRO_GLN_PRELU, false, SEP_EPI_RESIDUAL);     // heads
         else if (!tr && !sp && pm == SEP_PRO_GLN_PRELU && ef == 0) SEP_LD(false, SEP_PRO_GLN_PRELU, false, 0);                                   // last layer: skip head only
         else if (!tr && !sp && pm == SEP_PRO_PRELU && ef == SEP_EPI_SIGMOID) SEP_LD(false, SEP_PRO_PRELU, false, SEP_EPI_SIGMOID);               // mask
+        else if (!tr && !sp && pm == SEP_PRO_PRELU && ef == 0) SEP_LD(false, SEP_PRO_PRELU, false, 0);                                           // mask without its activation (softmax over channels, staged layers)
         else if (!tr && !sp && pm == SEP_PRO_GLN && ef == 0) SEP_LD(false, SEP_PRO_GLN, false, 0);                                               // bottleneck
         else if (!tr && !sp && pm == SEP_PRO_NONE && ef == 0) SEP_LD(false, SEP_PRO_NONE, false, 0);                                             // plain 1x1 conv
         else if (!tr && !sp && pm == SEP_PRO_NONE && ef == SEP_EPI_RESIDUAL) SEP_LD(false, SEP_PRO_NONE, false, SEP_EPI_RESIDUAL);               // heads of the staged (causal) layers: input already normalised
