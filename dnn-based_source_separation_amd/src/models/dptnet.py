@@ -9,7 +9,7 @@ import torch.nn.functional as F
 
 import torch
 
-from sepkernels.functional import (ChunkToTokensFn, OverlapAddFn, PaddedPointwiseFn, SegmentFn, TokenGLNFn, TokensToChunkFn, dense_apply, linear_apply,
+from sepkernels.functional import (attention_core, ChunkToTokensFn, OverlapAddFn, PaddedPointwiseFn, SegmentFn, TokenGLNFn, TokensToChunkFn, dense_apply, linear_apply,
                                    lstm_apply, token_gln_ok)
 from utils.model import choose_nonlinear, choose_rnn
 from utils.tasnet import choose_layer_norm
@@ -226,14 +226,12 @@ class MultiheadAttentionBlock(nn.Module):
     def forward_tokens(self, x):
         """(nseq, L, embed_dim) -> same shape.  nn.MultiheadAttention's arithmetic (torch/nn/functional.py multi_head_attention_forward: packed
         input projection in the order q, k, v; head h = features h*d .. (h+1)*d - 1; scores scaled by 1/sqrt(d); softmax; output projection; no
-        mask, no attention dropout) on batch-first rows: the projections on csrc/linear.hip, the core on scaled_dot_product_attention."""
+        mask, no attention dropout) on batch-first rows: the projections on csrc/linear.hip, the core on csrc/attn.hip (sep_attn_*)."""
         mha = self.multihead_attn
         N, L, C = x.shape
         h = mha.num_heads
         qkv = dense_apply(x, mha.in_proj_weight, mha.in_proj_bias).view(N, L, 3, h, C // h)
-        q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))                # (N, h, L, d) views
-        o = torch.nn.functional.scaled_dot_product_attention(q, k, v)             # (N, h, L, d)
-        o = o.transpose(1, 2).reshape(N, L, C)
+        o = attention_core(qkv)                                                   # (N, L, C): csrc/attn.hip, or SDPA for long sequences / wide heads
         y = dense_apply(o, mha.out_proj.weight, mha.out_proj.bias) + x
         if self.dropout:
             y = self.dropout1d(y)

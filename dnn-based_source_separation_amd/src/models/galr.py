@@ -73,10 +73,10 @@ class GloballyAttentiveBlockBase(nn.Module):
 
     def _attend_tokens(self, x):
         """_attend with the features innermost from end to end: (B, C, S, Q) -> one sequence per (b, q) as token-major rows (B*Q, S, C)
-        (sep_chunk_to_tokens), the channel norm on the rows as they are, the attention batch-first with its projections on csrc/linear.hip,
+        (sep_chunk_to_tokens), the channel norm on the rows as they are, the attention batch-first with its projections on csrc/linear.hip and its core on csrc/attn.hip,
         gLN over a sample's (Q, S, C) block on sep_gln_tokens_*, back (sep_tokens_to_chunk): two tiled transposes instead of six strided
         copies per block and direction."""
-        from sepkernels.functional import ChunkToTokensFn, TokensToChunkFn, TokenGLNFn, dense_apply
+        from sepkernels.functional import attention_core, ChunkToTokensFn, TokensToChunkFn, TokenGLNFn, dense_apply
         B, C, S, Q = x.size()
         t = ChunkToTokensFn.apply(x, True)                                       # (B*Q, S, C)
         if self.norm:
@@ -86,9 +86,7 @@ class GloballyAttentiveBlockBase(nn.Module):
         mha = self.multihead_attn
         h = mha.num_heads
         qkv = dense_apply(seq, mha.in_proj_weight, mha.in_proj_bias).view(B * Q, S, 3, h, C // h)
-        q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
-        y = torch.nn.functional.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B * Q, S, C)
-        y = dense_apply(y, mha.out_proj.weight, mha.out_proj.bias)
+        y = dense_apply(attention_core(qkv), mha.out_proj.weight, mha.out_proj.bias)
         if self.dropout:
             y = self.dropout1d(y)
         y = y + seq

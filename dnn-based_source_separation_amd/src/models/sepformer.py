@@ -170,18 +170,17 @@ class _ChunkPathEncoder(nn.Module):
     def _layer_tokens(layer, x):
         """one nn.TransformerEncoderLayer (torch/nn/modules/transformer.py: post-norm, or pre-norm with norm_first) on batch-first rows
         (N, L, C): the four dense layers on csrc/linear.hip -- hipBLASLt's picks for these fp32 shapes (32 K tokens x 256 x 1024) run at a
-        third of the fp32 MFMA rate, profiles/r05zc_sepformer_kernel_stats.md --, the core on scaled_dot_product_attention with the
-        layer's attention dropout."""
-        from sepkernels.functional import dense_apply
+        third of the fp32 MFMA rate, profiles/r05zc_sepformer_kernel_stats.md --, the core on csrc/attn.hip (sep_attn_*) with the layer's
+        attention dropout."""
+        from sepkernels.functional import attention_core, dense_apply
         sa = layer.self_attn
         N, L, C = x.shape
         h = sa.num_heads
 
         def attend(u):
             qkv = dense_apply(u, sa.in_proj_weight, sa.in_proj_bias).view(N, L, 3, h, C // h)
-            q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
-            o = F.scaled_dot_product_attention(q, k, v, dropout_p=sa.dropout if layer.training else 0.0)
-            return layer.dropout1(dense_apply(o.transpose(1, 2).reshape(N, L, C), sa.out_proj.weight, sa.out_proj.bias))
+            o = attention_core(qkv, sa.dropout if layer.training else 0.0)
+            return layer.dropout1(dense_apply(o, sa.out_proj.weight, sa.out_proj.bias))
 
         def feed(u):
             f = layer.dropout(layer.activation(dense_apply(u, layer.linear1.weight, layer.linear1.bias)))

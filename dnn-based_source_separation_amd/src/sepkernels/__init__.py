@@ -131,6 +131,8 @@ SIGNATURES = {
     "sep_cln_ws_bytes": [_I] * 4,                                    # returns size_t
     "sep_cln_fwd": [_vp] * 7 + [_I] * 4 + [_F, _vp, _vp],
     "sep_cln_bwd": [_vp] * 9 + [_I] * 4 + [_F, _vp, _vp, _vp],
+    "sep_attn_fwd": [_vp] * 3 + [_I] * 4 + [_F, _F, ctypes.c_ulonglong, _vp],
+    "sep_attn_bwd": [_vp] * 6 + [_I] * 4 + [_F, _F, ctypes.c_ulonglong, _vp],
     "sep_gln_tokens_ws_bytes": [_I] * 3,                             # returns size_t
     "sep_gln_tokens_fwd": [_vp] * 6 + [_I] * 3 + [_F, _vp],
     "sep_gln_tokens_bwd": [_vp] * 7 + [_I] * 3 + [_vp],
@@ -370,6 +372,13 @@ class HipBackend:
         _check(load().sep_cln_bwd(_ptr(dy, _f32), _ptr(x, _f32), _ptr(gamma, _f32), _ptr(mean, _f32), _ptr(rstd, _f32), _ptr(dx, _f32),
                                   _ptr(dgamma_part, _f32), _ptr(dbeta_part, _f32), _ptr(ws, _f64), B, C, T, ldt, eps, _ptr(alpha, _f32),
                                   _ptr(dalpha_part, _f32), _stream()), "sep_cln_bwd")
+
+    def attn_fwd(self, qkv, o, lse, N, L, H, D, scale, p_drop=0.0, seed=0):
+        _check(load().sep_attn_fwd(_ptr(qkv, _f32), _ptr(o, _f32), _ptr(lse, _f32), N, L, H, D, scale, p_drop, seed, _stream()), "sep_attn_fwd")
+
+    def attn_bwd(self, qkv, o, dout, lse, delta, dqkv, N, L, H, D, scale, p_drop=0.0, seed=0):
+        _check(load().sep_attn_bwd(_ptr(qkv, _f32), _ptr(o, _f32), _ptr(dout, _f32), _ptr(lse, _f32), _ptr(delta, _f32), _ptr(dqkv, _f32), N, L, H, D,
+                                   scale, p_drop, seed, _stream()), "sep_attn_bwd")
 
     def gln_tokens_ws_bytes(self, nseq, L, C):
         return int(load().sep_gln_tokens_ws_bytes(nseq, L, C))

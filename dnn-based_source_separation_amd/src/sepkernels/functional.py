@@ -739,6 +739,53 @@ def lstm_bidirectional(x, rnn):
 LSTM_KERNEL_HIDDEN = (16, 32, 64, 128)
 
 
+def attn_core_ok(x, L, head_dim):
+    """should csrc/attn.hip take this attention?  Heads 8 / 16 / 32 wide, fp32 on the device, and sequences of at most 256 steps: the kernels
+    go to 320, but at 257 (three query tiles, the last with one query; nine key blocks) torch's memory-efficient kernel is faster -- 634
+    against 463 us forward + backward at DPTNet's inter-chunk shape, profiles/r05zo_attention.txt"""
+    return L <= 256 and head_dim in (8, 16, 32) and takes(x) and (backend().name != "hip" or x.dtype == torch.float32)
+
+
+class AttnCoreFn(torch.autograd.Function):
+    """O = dropout(softmax(Q K^T / sqrt(d))) V on the packed projection qkv (N, L, 3, H, d) -> (N, L, H * d): the core of nn.MultiheadAttention
+    (torch/nn/functional.py multi_head_attention_forward; reference models/dptnet.py:505-527, galr.py:160-226, sepformer.py's encoder layers)
+    on sep_attn_fwd / sep_attn_bwd -- no transposes on either side, no L x L tensor, dropout decided by a hash of (seed, n, h, q, key)."""
+
+    @staticmethod
+    def forward(ctx, qkv, p_drop):
+        K = backend()
+        qkv = qkv.contiguous()
+        N, L, three, H, D = qkv.shape
+        o = torch.empty(N, L, H, D, device=qkv.device, dtype=qkv.dtype)
+        lse = torch.empty(N, H, L, device=qkv.device, dtype=qkv.dtype)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p_drop > 0 else 0         # the CPU generator: torch.manual_seed reaches it, no device sync
+        scale = float(D) ** -0.5
+        K.attn_fwd(qkv, o, lse, N, L, H, D, scale, float(p_drop), seed)
+        ctx.save_for_backward(qkv, o, lse)
+        ctx.meta = (scale, float(p_drop), seed)
+        return o.view(N, L, H * D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        K = backend()
+        qkv, o, lse = ctx.saved_tensors
+        N, L, three, H, D = qkv.shape
+        scale, p_drop, seed = ctx.meta
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty_like(lse)
+        K.attn_bwd(qkv, o, dout.contiguous(), lse, delta, dqkv, N, L, H, D, scale, p_drop, seed)
+        return dqkv, None
+
+
+def attention_core(qkv, p_drop=0.0):
+    """qkv (N, L, 3, H, d) -> (N, L, H * d): csrc/attn.hip where it applies, torch's scaled_dot_product_attention otherwise"""
+    N, L, three, H, D = qkv.shape
+    if attn_core_ok(qkv, L, D):
+        return AttnCoreFn.apply(qkv, float(p_drop))
+    q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
+    return torch.nn.functional.scaled_dot_product_attention(q, k, v, dropout_p=float(p_drop)).transpose(1, 2).reshape(N, L, H * D)
+
+
 def _gln_tokens_ws(K, nseq, L, C, device):
     """the scratch sep_gln_tokens_* ask for at this shape (few long sequences are cut into slices), or None"""
     nbytes = K.gln_tokens_ws_bytes(nseq, L, C)

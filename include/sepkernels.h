@@ -328,6 +328,17 @@ int sep_gln_tokens_fwd(const float* x, const float* gamma, const float* beta, fl
 int sep_gln_tokens_bwd(const float* dy, const float* x, const float* gamma, const float* stats, float* dx, float* part, void* ws, int nseq, int L,
                        int C, sep_stream_t stream);
 
+/* Scaled dot-product attention of the dual-path separators' transformer blocks (ABI 21): O = dropout(softmax(scale Q K^T)) V per (sequence,
+ * head) -- the core of nn.MultiheadAttention as the reference calls it (models/dptnet.py:505-527, models/galr.py:160-226, the
+ * nn.TransformerEncoderLayer of models/sepformer.py:395-520) and its autograd backward, fp32 on the matrix pipe.
+ * qkv, dqkv: (N, L, 3, H, D) -- the packed input projection's output as it is; o, dout: (N, L, H, D); lse, delta: (N, H, L) (lse written
+ * forward, read backward; delta is scratch of the backward).  L <= 320, D in {8, 16, 32}.  p_drop: dropout rate on the probabilities
+ * (0: none); the mask is a function of (seed, n, h, query, key), so forward and backward must be given the same seed. */
+int sep_attn_fwd(const float* qkv, float* o, float* lse, int N, int L, int H, int D, float scale, float p_drop, unsigned long long seed,
+                 sep_stream_t stream);
+int sep_attn_bwd(const float* qkv, const float* o, const float* dout, const float* lse, float* delta, float* dqkv, int N, int L, int H, int D,
+                 float scale, float p_drop, unsigned long long seed, sep_stream_t stream);
+
 /* Stand-alone gLN (modules/norm.py:11-35) for callers outside the fused network. */
 int sep_gln_stats(const float* x, double* stats, int B, int C, int T, int ldt, sep_stream_t stream);
 int sep_gln_apply(const float* x, const double* stats, const float* gamma, const float* beta, float* y, int B, int C,

@@ -440,6 +440,55 @@ class EmuBackend:
         dgamma_part.reshape(B, C).copy_((g * (v - m) * r).sum(2).to(dgamma_part.dtype))
         dbeta_part.reshape(B, C).copy_(g.sum(2).to(dbeta_part.dtype))
 
+    # ------------------------------------------------------------------ attention core (csrc/attn.hip)
+    @staticmethod
+    def _attn_keep(N, L, H, p_drop, seed):
+        """the dropout decision of csrc/attn.hip: a hash of (seed, n, h, query, key), 32-bit arithmetic"""
+        if not p_drop > 0:
+            return None, 1.0
+        M = 0xFFFFFFFF
+        thr = max(1, min(int(p_drop * 4294967296.0), M))
+        s0, s1 = seed & M, (seed >> 32) & M
+        n, h, q, k = torch.meshgrid(torch.arange(N), torch.arange(H), torch.arange(L), torch.arange(L), indexing="ij")
+        x = ((((n * H + h) * L + q) * L + k) & M) ^ s0
+        x = (x * 0x9E3779B1) & M
+        x = x ^ (x >> 15)
+        x = (x * 0x85EBCA6B) & M
+        x = x ^ (x >> 13)
+        x = (x + s1) & M
+        x = (x * 0xC2B2AE35) & M
+        x = x ^ (x >> 16)
+        return x >= thr, 1.0 / (1.0 - p_drop)
+
+    def attn_fwd(self, qkv, o, lse, N, L, H, D, scale, p_drop=0.0, seed=0):
+        t = qkv.reshape(N, L, 3, H, D).double()
+        q, k, v = (t[:, :, i].permute(0, 2, 1, 3) for i in range(3))                   # (N, H, L, D)
+        s = scale * q @ k.transpose(-1, -2)
+        ls = torch.logsumexp(s, dim=-1)
+        pr = torch.exp(s - ls.unsqueeze(-1))
+        keep, kinv = self._attn_keep(N, L, H, p_drop, seed)
+        pd = pr if keep is None else torch.where(keep, pr * kinv, torch.zeros_like(pr))
+        o.reshape(N, L, H, D).copy_((pd @ v).permute(0, 2, 1, 3).to(o.dtype))
+        lse.reshape(N, H, L).copy_(ls.to(lse.dtype))
+
+    def attn_bwd(self, qkv, o, dout, lse, delta, dqkv, N, L, H, D, scale, p_drop=0.0, seed=0):
+        t = qkv.reshape(N, L, 3, H, D).double()
+        q, k, v = (t[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        g = dout.reshape(N, L, H, D).double().permute(0, 2, 1, 3)
+        oo = o.reshape(N, L, H, D).double().permute(0, 2, 1, 3)
+        pr = torch.exp(scale * q @ k.transpose(-1, -2) - lse.reshape(N, H, L, 1).double())
+        keep, kinv = self._attn_keep(N, L, H, p_drop, seed)
+        dl = (g * oo).sum(-1, keepdim=True)
+        dpd = g @ v.transpose(-1, -2)
+        if keep is None:
+            pd, dp = pr, dpd
+        else:
+            pd, dp = torch.where(keep, pr * kinv, torch.zeros_like(pr)), torch.where(keep, dpd * kinv, torch.zeros_like(dpd))
+        ds = pr * (dp - dl)
+        out = torch.stack([scale * ds @ k, scale * ds.transpose(-1, -2) @ q, pd.transpose(-1, -2) @ g], dim=0)      # (3, N, H, L, D)
+        dqkv.reshape(N, L, 3, H, D).copy_(out.permute(1, 3, 0, 2, 4).to(dqkv.dtype))
+        delta.reshape(N, H, L).copy_(dl[..., 0].to(delta.dtype))
+
     # ------------------------------------------------------------------ gLN on token-major rows
     def gln_tokens_ws_bytes(self, nseq, L, C):
         return 0

@@ -902,6 +902,44 @@ def test_prelu_cln_fwd_bwd(B, C, T, a):
     assert (dxe - dx).abs().max() <= 5e-5 * dxe.abs().max() and (pae - pa.cpu()).abs().max() <= 2e-4 * pae.abs().max() + 1e-5
 
 
+@pytest.mark.parametrize("N,L,H,D,p_drop", [(3, 250, 4, 16, 0.0), (2, 257, 2, 32, 0.0), (1, 320, 1, 16, 0.0), (5, 37, 8, 8, 0.0), (2, 100, 4, 16, 0.25), (1, 130, 2, 32, 0.1)])
+def test_attention_core_fwd_bwd(N, L, H, D, p_drop):
+    """sep_attn_fwd / sep_attn_bwd on the packed projection (N, L, 3, H, D): against torch's float64 softmax(q k^T / sqrt(d)) v and its autograd
+    gradients (what nn.MultiheadAttention computes between its projections: reference dptnet.py:505-527), sequences that are not multiples of
+    32 or 128 (more than 256 steps: the kernels' second size), more than 320 is refused; with dropout against the same composition under the mask the emulator derives from the seed."""
+    torch.manual_seed(N * 100 + L)
+    qkv = torch.randn(N, L, 3, H, D) * 1.3
+    dout = torch.randn(N, L, H, D)
+    scale, seed = D ** -0.5, 0x1234ABCD5678
+    t = qkv.double().requires_grad_(True)
+    q, k, v = (t[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    pr = torch.softmax(scale * q @ k.transpose(-1, -2), dim=-1)
+    keep, kinv = EMU._attn_keep(N, L, H, p_drop, seed)
+    if keep is not None:
+        assert abs(keep.double().mean().item() - (1 - p_drop)) < 0.02
+        pr = torch.where(keep, pr * kinv, torch.zeros_like(pr))
+    o64 = (pr @ v).permute(0, 2, 1, 3)
+    (o64 * dout.double()).sum().backward()
+    f32 = dict(device=device_name(), dtype=torch.float32)
+    o, lse = torch.full((N, L, H, D), float("nan"), **f32), torch.full((N, H, L), float("nan"), **f32)
+    dq, delta = torch.full((N, L, 3, H, D), float("nan"), **f32), torch.empty(N, H, L, **f32)
+    gq = to_device(qkv)
+    HIP.attn_fwd(gq, o, lse, N, L, H, D, scale, p_drop, seed)
+    HIP.attn_bwd(gq, o, to_device(dout), lse, delta, dq, N, L, H, D, scale, p_drop, seed)
+    device_sync()
+    o, dq = o.cpu().double(), dq.cpu().double()
+    assert torch.isfinite(o).all() and torch.isfinite(dq).all()
+    assert (o - o64.detach()).abs().max() <= 2e-5 * o64.detach().abs().max()
+    assert (dq - t.grad).abs().max() <= 5e-5 * t.grad.abs().max()
+    oe, le, dqe, de = torch.empty(N, L, H, D), torch.empty(N, H, L), torch.empty(N, L, 3, H, D), torch.empty(N, H, L)
+    EMU.attn_fwd(qkv, oe, le, N, L, H, D, scale, p_drop, seed)
+    EMU.attn_bwd(qkv, oe, dout, le, de, dqe, N, L, H, D, scale, p_drop, seed)
+    assert (oe.double() - o).abs().max() <= 2e-5 * o.abs().max() and (le - lse.cpu()).abs().max() <= 2e-5 * (1 + le.abs().max())
+    assert (dqe.double() - dq).abs().max() <= 5e-5 * dq.abs().max()
+    with pytest.raises(Exception):
+        HIP.attn_fwd(gq, o, lse, N, 321, H, D, scale, 0.0, 0)
+
+
 @pytest.mark.parametrize("nseq,L,C", [(3, 250, 64), (5, 37, 16), (2, 100, 128), (1, 7, 1024), (4, 258, 64), (2, 1500, 64), (3, 4100, 16)])      # the last two: sliced sequences
 def test_gln_tokens_fwd_bwd(nseq, L, C):
     """sep_gln_tokens_fwd / bwd: gLN on token-major (nseq, L, C) rows against nn.functional.group_norm on the transposed tensor in float64

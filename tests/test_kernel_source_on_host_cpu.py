@@ -37,6 +37,7 @@ CASES = [
     ("test_gln_standalone_and_repack", [()]),
     ("test_cln_fwd_bwd", [(2, 24, 203), (3, 128, 3999), (2, 300, 150)]),          # the last: 16-wave tiles of the chained backward
     ("test_prelu_cln_fwd_bwd", [(2, 24, 203, 0.25), (1, 48, 1030, 0.0)]),
+    ("test_attention_core_fwd_bwd", [(2, 70, 2, 16, 0.0), (1, 37, 2, 8, 0.0), (1, 130, 1, 32, 0.2), (1, 257, 1, 16, 0.0)]),
     ("test_gln_tokens_fwd_bwd", [(3, 250, 64), (5, 37, 16), (1, 7, 1024), (2, 1500, 64)]),          # the last: sliced sequences
     ("test_sisdr_kernels", [(1, 0), (2, 1), (3, 0)]),
     ("test_pit_search", [(2, 0, 1), (3, 1, 1), (4, 0, 0)]),

@@ -72,6 +72,7 @@ def test_sibling_separator_matches_the_reference(golden_dir, name, emu):
     assert ("decoder_fwd" in emu.used and "encoder_fwd" in emu.used) == on_kernels           # the path under test is the one that ran
     if name == "dptnet":              # features a power of two, gLN everywhere: the token-major stack (models/dptnet.py::_forward_tokens)
         assert "gln_tokens_fwd" in emu.used and "chunk_to_tokens" in emu.used
+        assert "attn_fwd" in emu.used                                         # ... and the attention core on sep_attn_* (csrc/attn.hip)
     if name == "galrnet":             # its global attention runs token-major too (models/galr.py::_attend_tokens); the causal one does not
         assert "gln_tokens_fwd" in emu.used
     if name == "sepformer":           # both transformer stacks on token-major rows (models/sepformer.py::_forward_tokens)
