@@ -150,9 +150,23 @@ class LowDimensionGloballyAttentiveBlock(GloballyAttentiveBlockBase):
         self._make_core(num_features, num_heads, causal, norm, dropout, eps)
         self.fc_inv = nn.Linear(down_chunk_size, chunk_size)
 
+    @staticmethod
+    def _along_chunk(x, fc):
+        """nn.Linear along the chunk axis (100 -> 32 -> 100 at the recipe's sizes).  The library's pick for 20 736 rows x 100 x 32 in fp32 runs
+        82 us (profiles/r05zj_galrnet_kernel_stats.md: 1 ms of the step for 0.13 GFLOP); on csrc/linear.hip with both widths padded with
+        zeros to its multiples of 64 the product and the two small copies take a third of that."""
+        from sepkernels.functional import DenseFn, takes
+        K_in, N_out = fc.in_features, fc.out_features
+        if not takes(x) or (K_in % 64 == 0 and N_out % 64 == 0) or max(K_in, N_out) > 256:
+            return fc(x)
+        Kp, Np = -(-K_in // 64) * 64, -(-N_out // 64) * 64
+        F = torch.nn.functional
+        y = DenseFn.apply(F.pad(x, (0, Kp - K_in)), F.pad(fc.weight, (0, Kp - K_in, 0, Np - N_out)), F.pad(fc.bias, (0, Np - N_out)))
+        return y[..., :N_out]
+
     def forward(self, input):
         """(batch_size, num_features, S, K) -> same shape; attention runs on K squeezed to Q = down_chunk_size positions"""
-        return self.fc_inv(self._attend(self.fc_map(input))) + input
+        return self._along_chunk(self._attend(self._along_chunk(input, self.fc_map)), self.fc_inv) + input
 
 
 class LayerNormAlongChannel(nn.Module):
