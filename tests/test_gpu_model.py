@@ -114,7 +114,9 @@ def _golden_case(golden_dir, name):
             rel = (q.grad.double().cpu() - r).abs().max().item() / (r.abs().max().item() + 1e-30)
             assert rel <= 5e-3, "{}: {:.3e}".format(k, rel)
     else:
-        assert worst[1] <= 2e-2, "per-tensor worst {}".format(worst)
+        # the module-by-module composition (torch convolutions around the library's norms): every tensor at the bar of the forward; measured
+        # worst 1.5e-6 ... 4.7e-6 over the five configurations (tools/print_composed_worst.py, profiles/r05zp_composed_worst.txt)
+        assert worst[1] <= 1e-3, "per-tensor worst {}".format(worst)
 
 
 def test_paper_best_against_oracle():
