@@ -1502,28 +1502,57 @@ constexpr int RMAXSEG = 64;
 struct ReduceArgs {
     sep_reduce_seg seg[RMAXSEG];
     int blk_start[RMAXSEG + 1];
+    unsigned char phased[RMAXSEG];      // 1: 64 outputs per workgroup, four slab phases per output
     int nseg;
 };
 
+// Two forms per segment, both with a fixed summation order (bit-stable run to run).  Launches that stream (the Conv-TasNet step's batched weight
+// gradients: dozens of segments of 64 - 128 slabs of 64 K ... 128 K values, 0.5 GB per launch) keep one thread per output and four chains.  Short ones -- the
+// dual-path models' dense layers: 170 slabs of 12 K values took 20 us, latency, 54 launches per DPTNet step -- get 64 outputs per
+// workgroup and four threads per output: thread (i, g) adds the slabs k = g, g + 4, ... in four chains of its own (sixteen loads in flight
+// per output), the four phases meet in LDS.
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceArgs a) {
+    __shared__ float ph[4][64];
     int sgi = 0;
     while (sgi + 1 < a.nseg && (int)blockIdx.x >= a.blk_start[sgi + 1]) ++sgi;
     const sep_reduce_seg sg = a.seg[sgi];
-    const int i = ((int)blockIdx.x - a.blk_start[sgi]) * 256 + threadIdx.x;
-    if (i >= sg.n) return;
-    // fixed summation order -> bit-stable run to run; 4 independent chains hide load latency
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int k = 0;
-    for (; k + 3 < sg.nslab; k += 4) {
-        s0 += sg.src[(size_t)(k + 0) * sg.stride + i];
-        s1 += sg.src[(size_t)(k + 1) * sg.stride + i];
-        s2 += sg.src[(size_t)(k + 2) * sg.stride + i];
-        s3 += sg.src[(size_t)(k + 3) * sg.stride + i];
+    if (!a.phased[sgi]) {
+        const int i = ((int)blockIdx.x - a.blk_start[sgi]) * 256 + threadIdx.x;
+        if (i >= sg.n) return;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int k = 0;
+        for (; k + 3 < sg.nslab; k += 4) {
+            s0 += sg.src[(size_t)(k + 0) * sg.stride + i];
+            s1 += sg.src[(size_t)(k + 1) * sg.stride + i];
+            s2 += sg.src[(size_t)(k + 2) * sg.stride + i];
+            s3 += sg.src[(size_t)(k + 3) * sg.stride + i];
+        }
+        for (; k < sg.nslab; ++k) s0 += sg.src[(size_t)k * sg.stride + i];
+        float v = ((s0 + s1) + (s2 + s3)) * sg.scale;
+        if (sg.accumulate) v += sg.dst[i];
+        sg.dst[i] = v;
+        return;
     }
-    for (; k < sg.nslab; ++k) s0 += sg.src[(size_t)k * sg.stride + i];
-    float v = ((s0 + s1) + (s2 + s3)) * sg.scale;
-    if (sg.accumulate) v += sg.dst[i];
-    sg.dst[i] = v;
+    const int g = threadIdx.x >> 6, li = threadIdx.x & 63;
+    const int i = ((int)blockIdx.x - a.blk_start[sgi]) * 64 + li;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < sg.n) {
+        int k = g;
+        for (; k + 12 < sg.nslab; k += 16) {
+            s0 += sg.src[(size_t)(k + 0) * sg.stride + i];
+            s1 += sg.src[(size_t)(k + 4) * sg.stride + i];
+            s2 += sg.src[(size_t)(k + 8) * sg.stride + i];
+            s3 += sg.src[(size_t)(k + 12) * sg.stride + i];
+        }
+        for (; k < sg.nslab; k += 4) s0 += sg.src[(size_t)k * sg.stride + i];
+    }
+    ph[g][li] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && i < sg.n) {
+        float v = ((ph[0][li] + ph[1][li]) + (ph[2][li] + ph[3][li])) * sg.scale;
+        if (sg.accumulate) v += sg.dst[i];
+        sg.dst[i] = v;
+    }
 }
 
 __global__ void f64_to_f32_kernel(const double* src, float* dst, int n, int accumulate) {
@@ -1699,11 +1728,15 @@ extern "C" int sep_reduce_slabs(const sep_reduce_seg* segs, int nseg, sep_stream
     SEP_REQUIRE(segs && nseg >= 1 && nseg <= RMAXSEG, "sep_reduce_slabs: 1..64 segments per launch (got %d)", nseg);
     ReduceArgs a;
     int blocks = 0;
+    double launch_bytes = 0.0;                       // a launch that moves more than this streams: one thread per output is the faster form there
+    for (int i = 0; i < nseg; ++i) launch_bytes += 4.0 * (double)segs[i].n * (double)segs[i].nslab;
+    const bool streams = launch_bytes > 64e6;
     for (int i = 0; i < nseg; ++i) {
         SEP_REQUIRE(segs[i].src && segs[i].dst && segs[i].n > 0 && segs[i].nslab > 0, "sep_reduce_slabs: bad segment %d", i);
         a.seg[i] = segs[i];
         a.blk_start[i] = blocks;
-        blocks += ceil_div(segs[i].n, 256);
+        a.phased[i] = !streams && segs[i].nslab >= 16;
+        blocks += ceil_div(segs[i].n, a.phased[i] ? 64 : 256);
     }
     a.blk_start[nseg] = blocks;
     a.nseg = nseg;
