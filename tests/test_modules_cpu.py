@@ -373,3 +373,37 @@ def test_fused_train_step_moves_the_parameters_of_non_fused_models(emu):
             assert (q - r).abs().max() <= 1e-9 * max(1.0, r.abs().max().item()), k
             moved = max(moved, (q.detach() - start[k]).abs().max().item())
         assert moved > 0
+
+
+@pytest.mark.parametrize("N,L,H,D", [(3, 50, 4, 16), (2, 33, 2, 8), (1, 300, 2, 16), (2, 20, 2, 24)])
+def test_attention_core_is_nn_multihead_attention_between_its_projections(emu, N, L, H, D):
+    """sepkernels.functional.attention_core on the packed projection (through the C-ABI contract as the emulator restates it, or torch's SDPA
+    for the shapes csrc/attn.hip leaves alone: more than 256 steps, head widths other than 8 / 16 / 32) against nn.MultiheadAttention's own
+    arithmetic in float64: outputs and the gradient at the projection."""
+    from sepkernels.functional import attention_core, attn_core_ok
+    torch.manual_seed(N + L)
+    C = H * D
+    mha = torch.nn.MultiheadAttention(C, H, batch_first=True).double()
+    x = torch.randn(N, L, C, dtype=torch.float64)
+    qkv = torch.nn.functional.linear(x, mha.in_proj_weight, mha.in_proj_bias).view(N, L, 3, H, D).detach().requires_grad_(True)
+    calls = []
+    K = sepkernels.backend()
+    orig = K.attn_fwd
+    K.attn_fwd = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        o = attention_core(qkv)
+    finally:
+        del K.attn_fwd
+    assert bool(calls) == attn_core_ok(qkv, L, D) == (L <= 256 and D in (8, 16, 32))
+    q, k, v = (qkv.detach()[:, :, i].reshape(N, L, C) for i in range(3))
+    # the module's own path from ready-made projections: identity input projection, its output projection applied by hand below
+    ref_qkv = qkv.detach().clone().requires_grad_(True)
+    rq, rk, rv = (ref_qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    ref = (torch.softmax(rq @ rk.transpose(-1, -2) / D ** 0.5, dim=-1) @ rv).permute(0, 2, 1, 3).reshape(N, L, C)
+    assert (o - ref).abs().max() <= 1e-12 * ref.abs().max()
+    w = torch.randn(N, L, C, dtype=torch.float64)
+    (o * w).sum().backward()
+    (ref * w).sum().backward()
+    assert (qkv.grad - ref_qkv.grad).abs().max() <= 1e-11 * ref_qkv.grad.abs().max()
+    full, _ = mha(x, x, x, need_weights=False)
+    assert (torch.nn.functional.linear(o, mha.out_proj.weight, mha.out_proj.bias) - full).abs().max() <= 1e-12 * full.abs().max()
