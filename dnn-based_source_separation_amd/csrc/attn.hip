@@ -26,7 +26,9 @@ typedef float att_f32x16 __attribute__((ext_vector_type(16)));
 constexpr int ATT_MAXL = 320;          // (two sizes of every kernel: tiles for 256 and for 320 steps)
 
 __device__ __forceinline__ float4 ald4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ float att_exp(const float x) { return __builtin_amdgcn_exp2f(1.4426950408889634f * x); }      // v_exp_f32
+constexpr float ATT_LOG2E = 1.4426950408889634f, ATT_LN2 = 0.6931471805599453f;
+// the scores are kept in units of log 2 (q, or k, is scaled by scale * log2(e) on load): v_exp_f32 with nothing in front of it
+__device__ __forceinline__ float att_exp2(const float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ int att_row(const int r, const int lk) { return (r & 3) + 8 * (r >> 2) + 4 * lk; }      // row of result register r
 __device__ __forceinline__ unsigned att_hash(const unsigned idx, const unsigned s0, const unsigned s1) {
     unsigned x = idx ^ s0;
@@ -82,7 +84,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const att_args p) {
     for (int j = 0; j < DH / 4; ++j) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q < L) v = ald4(base + (size_t)q * RS + lk * DH + 4 * j);
-        qv[4 * j] = v.x * p.scale; qv[4 * j + 1] = v.y * p.scale; qv[4 * j + 2] = v.z * p.scale; qv[4 * j + 3] = v.w * p.scale;
+        const float sc = p.scale * ATT_LOG2E;
+        qv[4 * j] = v.x * sc; qv[4 * j + 1] = v.y * sc; qv[4 * j + 2] = v.z * sc; qv[4 * j + 3] = v.w * sc;
     }
     constexpr int NB = ML / 32;
     att_f32x16 s[NB];
@@ -105,26 +108,32 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const att_args p) {
     // softmax over the keys: this lane's registers hold the keys {kb * 32 + row(r, lk)}, lane ^ 32 the others
     float m = -INFINITY;
 #pragma unroll
-    for (int kb = 0; kb < NB; ++kb)
+    for (int kb = 0; kb < NB; ++kb) {
+        if (kb + 1 < nkb) {                                  // only the last block has dead keys
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const bool live = kb < nkb && kb * 32 + att_row(r, lk) < L;
-            s[kb][r] = live ? s[kb][r] : -INFINITY;
-            m = fmaxf(m, s[kb][r]);
+            for (int r = 0; r < 16; ++r) m = fmaxf(m, s[kb][r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool live = kb < nkb && kb * 32 + att_row(r, lk) < L;
+                s[kb][r] = live ? s[kb][r] : -INFINITY;
+                m = fmaxf(m, s[kb][r]);
+            }
         }
+    }
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     float sum = 0.f;
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float e = att_exp(s[kb][r] - m);          // exp(-inf) = 0 for the dead keys
+            const float e = att_exp2(s[kb][r] - m);         // 2^-inf = 0 for the dead keys
             s[kb][r] = e;
             sum += e;
         }
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.f / sum;
-    if (lk == 0 && q < L) p.lse[((size_t)n * H + h) * L + q] = m + logf(sum);
+    if (lk == 0 && q < L) p.lse[((size_t)n * H + h) * L + q] = m * ATT_LN2 + logf(sum);
     const unsigned ebase = (unsigned)((((size_t)n * H + h) * L + q) * (size_t)L);
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb)
@@ -182,7 +191,8 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const att_args p) {
             g = ald4(p.dout + ((size_t)n * L + q) * OS + (size_t)h * D + lk * DH + 4 * j);
             oo = ald4(p.o + ((size_t)n * L + q) * OS + (size_t)h * D + lk * DH + 4 * j);
         }
-        qv[4 * j] = v.x * p.scale; qv[4 * j + 1] = v.y * p.scale; qv[4 * j + 2] = v.z * p.scale; qv[4 * j + 3] = v.w * p.scale;
+        const float sc = p.scale * ATT_LOG2E;
+        qv[4 * j] = v.x * sc; qv[4 * j + 1] = v.y * sc; qv[4 * j + 2] = v.z * sc; qv[4 * j + 3] = v.w * sc;
         dov[4 * j] = g.x; dov[4 * j + 1] = g.y; dov[4 * j + 2] = g.z; dov[4 * j + 3] = g.w;
         dl += (g.x * oo.x + g.y * oo.y) + (g.z * oo.z + g.w * oo.w);
     }
@@ -190,7 +200,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const att_args p) {
     const size_t sidx = ((size_t)n * H + h) * L + q;
     float lse = 0.f;
     if (q < L) {
-        lse = p.lse_in[sidx];
+        lse = p.lse_in[sidx] * ATT_LOG2E;
         if (lk == 0) p.lse[sidx] = dl;
     }
     const unsigned ebase = (unsigned)(sidx * (size_t)L);
@@ -218,7 +228,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const att_args p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = kb * 32 + att_row(r, lk);
-            const float pr = key < L ? att_exp(s[r] - lse) : 0.f;
+            const float pr = key < L ? att_exp2(s[r] - lse) : 0.f;
             float dpv = dp[r];
             if (p.thr != 0u) dpv = att_hash(ebase + (unsigned)key, p.s0, p.s1) >= p.thr ? dpv * p.keep_inv : 0.f;
             s[r] = pr * (dpv - dl);                          // dS
@@ -254,7 +264,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const att_args p) {
     att_fill<D>(Qr, base, RS, L, Lp);
     att_fill<D>(Gr, p.dout + (size_t)n * L * OS + (size_t)h * D, OS, L, Lp);
     for (int i = threadIdx.x; i < Lp; i += 256) {
-        lse_s[i] = i < L ? p.lse_in[((size_t)n * H + h) * L + i] : 0.f;
+        lse_s[i] = i < L ? p.lse_in[((size_t)n * H + h) * L + i] * ATT_LOG2E : 0.f;
         del_s[i] = i < L ? p.delta_in[((size_t)n * H + h) * L + i] : 0.f;
     }
     __syncthreads();
@@ -267,7 +277,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const att_args p) {
             a = ald4(base + (size_t)key * RS + (size_t)H * D + lk * DH + 4 * j);
             c = ald4(base + (size_t)key * RS + (size_t)2 * H * D + lk * DH + 4 * j);
         }
-        kv[4 * j] = a.x * p.scale; kv[4 * j + 1] = a.y * p.scale; kv[4 * j + 2] = a.z * p.scale; kv[4 * j + 3] = a.w * p.scale;
+        const float sc = p.scale * ATT_LOG2E;
+        kv[4 * j] = a.x * sc; kv[4 * j + 1] = a.y * sc; kv[4 * j + 2] = a.z * sc; kv[4 * j + 3] = a.w * sc;
         vv[4 * j] = c.x; vv[4 * j + 1] = c.y; vv[4 * j + 2] = c.z; vv[4 * j + 3] = c.w;
     }
     const size_t hbase = ((size_t)n * H + h) * L;
@@ -296,7 +307,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const att_args p) {
         for (int r = 0; r < 16; ++r) {
             const int qq = qb * 32 + att_row(r, lk);
             const bool live = qq < L && key < L;
-            const float pr = live ? att_exp(s[r] - lse_s[qq]) : 0.f;
+            const float pr = live ? att_exp2(s[r] - lse_s[qq]) : 0.f;
             float pd = pr, dpv = dp[r];
             if (p.thr != 0u) {
                 const bool keep = att_hash((unsigned)((hbase + qq) * (size_t)L) + (unsigned)key, p.s0, p.s1) >= p.thr;
