@@ -108,19 +108,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const att_args p) {
     // softmax over the keys: this lane's registers hold the keys {kb * 32 + row(r, lk)}, lane ^ 32 the others
     float m = -INFINITY;
 #pragma unroll
-    for (int kb = 0; kb < NB; ++kb) {
-        if (kb + 1 < nkb) {                                  // only the last block has dead keys
+    for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) m = fmaxf(m, s[kb][r]);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const bool live = kb < nkb && kb * 32 + att_row(r, lk) < L;
-                s[kb][r] = live ? s[kb][r] : -INFINITY;
-                m = fmaxf(m, s[kb][r]);
-            }
+        for (int r = 0; r < 16; ++r) {
+            const bool live = kb < nkb && kb * 32 + att_row(r, lk) < L;
+            s[kb][r] = live ? s[kb][r] : -INFINITY;
+            m = fmaxf(m, s[kb][r]);
         }
-    }
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     float sum = 0.f;
 #pragma unroll
