@@ -264,7 +264,29 @@ def case_test_functions(R):
     return "cln fwd+bwd {} {} {}".format(B, C, T)
 
 
-CASES = [case_gemm, case_gemm, case_gemm_forms, case_gemm_forms, case_wgrad, case_wgrad, case_codec, case_norms, case_chunks, case_lstm, case_dense, case_dense,
+def case_round4(R):
+    """the kernels of round 4: attention core (with and without dropout), gLN over tokens in both forms, the chained cLN with PReLU"""
+    pick = R.randint(0, 3)
+    if pick == 0:
+        N, L, H, D = R.randint(1, 3), R.randint(1, 140), R.randint(1, 3), R.choice([8, 16, 32])
+        p = R.choice([0.0, 0.0, 0.3]) if N * L * L * H >= 20000 else 0.0
+        GK.test_attention_core_fwd_bwd(N, L, H, D, p)
+        return "attention {} {} {} {} {}".format(N, L, H, D, p)
+    if pick == 1:
+        nseq, L, C = R.randint(1, 6), R.randint(1, 400), R.choice([4, 16, 64, 256, 1024])
+        GK.test_gln_tokens_fwd_bwd(nseq, L, C)
+        return "gln_tokens {} {} {}".format(nseq, L, C)
+    if pick == 2:
+        nseq, C = R.randint(1, 3), R.choice([16, 64])
+        L = R.randint(16 * 1024 // C * 2, 16 * 1024 // C * 5)           # long enough for the sliced form
+        GK.test_gln_tokens_fwd_bwd(nseq, L, C)
+        return "gln_tokens sliced {} {} {}".format(nseq, L, C)
+    B, C, T, a = R.randint(1, 3), R.choice([5, 24, 64, 100, 200, 300]), R.randint(1, 500), R.choice([0.25, -0.3, 0.0])
+    GK.test_prelu_cln_fwd_bwd(B, C, T, a)
+    return "prelu_cln {} {} {} {}".format(B, C, T, a)
+
+
+CASES = [case_round4, case_round4, case_gemm, case_gemm, case_gemm_forms, case_gemm_forms, case_wgrad, case_wgrad, case_codec, case_norms, case_chunks, case_lstm, case_dense, case_dense,
          case_test_functions, case_test_functions]
 
 
