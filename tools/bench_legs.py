@@ -612,6 +612,15 @@ def bench_dual_path(args):
         opt.step()
         return loss.detach()
     launch = "eager (one launch per kernel)"
+    if args.config == "causal" and os.environ.get("SEPK_TORCH_ADAM", "0") != "1":
+        # Conv-TasNet keeps its parameters in one flat buffer: clip + Adam as the headline's step takes them (sepkernels.train.FusedTrainStep:
+        # gradients gathered into the flat buffer, one norm kernel, one fused Adam) instead of torch's foreach passes
+        from sepkernels.train import FusedTrainStep
+        fused = FusedTrainStep(model, crit, lr=adam.get("lr", 1e-3), max_norm=5.0)
+
+        def step():      # noqa: F811
+            return fused(mix, src)
+        launch = "eager (one launch per kernel), fused clip + Adam"
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
