@@ -183,6 +183,8 @@ class _ChunkPathEncoder(nn.Module):
             return layer.dropout1(dense_apply(o, sa.out_proj.weight, sa.out_proj.bias))
 
         def feed(u):
+            if _ff_on_conv_kernels(layer, u):
+                return layer.dropout2(_feed_forward_channel_major(layer, u))
             f = layer.dropout(layer.activation(dense_apply(u, layer.linear1.weight, layer.linear1.bias)))
             return layer.dropout2(dense_apply(f, layer.linear2.weight, layer.linear2.bias))
 
@@ -224,6 +226,42 @@ class _ChunkPathEncoder(nn.Module):
             x = input.permute(2, 0, 3, 1).reshape(S, B * K, C)
             y = self.transformer(x + self.positional_encoding(x)).view(S, B, K, C).permute(1, 3, 0, 2)
         return y + input
+
+
+def _ff_on_conv_kernels(layer, u):
+    """the feed-forward pair on the 1x1-convolution kernels?  Widths in multiples of 128 (their tiles), the two-part fp16 arithmetic, the
+    device (the CPU stand-in of the tests takes the route too, so that the fixtures exercise it)"""
+    import sepkernels
+    from sepkernels.functional import takes
+    C, Fd = layer.linear1.in_features, layer.linear1.out_features
+    on_device = sepkernels.backend().name == "hip"
+    return (takes(u) and C % 128 == 0 and Fd % 128 == 0 and (not on_device or sepkernels.gemm_arith() == sepkernels.ARITH_F16X3)
+            and layer.linear1.bias is not None and layer.linear2.bias is not None)
+
+
+def _feed_forward_channel_major(layer, u):
+    """linear2(dropout(activation(linear1(u)))) of an nn.TransformerEncoderLayer on tokens u (N, L, C), computed CHANNEL-MAJOR on the 1x1-
+    convolution kernels (sep_pw_gemm / sep_pw_wgrad through PaddedPointwiseFn): all N L tokens are the frames of one (C, frames) sample.
+    At SepFormer's sizes (33 K tokens, 256 <-> 1024) the two products are compute-bound; the dense kernel multiplies on the fp32 MFMA
+    (210 + 241 us forward, 444 + 353 backward), its two-part fp16 form is load-bound at the 128 x 128 tile
+    (profiles/r05zy_linear16_experiment.md), the convolution kernels' 256-row tiles are not -- at the price of two tiled transposes (34 MB
+    each) around the pair.  ReLU without dropout rides the second product's prologue (PReLU with slope 0)."""
+    from sepkernels.functional import ChunkToTokensFn, TokensToChunkFn, PaddedPointwiseFn
+    from sepkernels import net as _net
+    N, L, C = u.shape
+    ntok = N * L
+    ldt = -(-ntok // 128) * 128
+    t = F.pad(u.reshape(ntok, C), (0, 0, 0, ldt - ntok))                                          # rows of zeros up to the kernels' frame stride
+    x = TokensToChunkFn.apply(t.view(1, ldt, C), (1, C, 1, ldt), False).view(1, C, ldt)
+    w1, w2 = layer.linear1.weight, layer.linear2.weight
+    wa = _net._weights_amax({"w1": w1, "w2": w2})
+    h = PaddedPointwiseFn.apply(x, ntok, w1, layer.linear1.bias, None, wa)
+    drop = layer.training and layer.dropout.p > 0
+    if layer.activation is F.relu and not drop:
+        y = PaddedPointwiseFn.apply(h, ntok, w2, layer.linear2.bias, u.new_zeros(1), wa)
+    else:
+        y = PaddedPointwiseFn.apply(layer.dropout(layer.activation(h)), ntok, w2, layer.linear2.bias, None, wa)
+    return ChunkToTokensFn.apply(y.view(1, C, 1, ldt), False).view(ldt, C)[:ntok].view(N, L, C)
 
 
 class IntraTransformer(_ChunkPathEncoder):

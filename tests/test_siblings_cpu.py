@@ -211,3 +211,26 @@ def test_gradient_with_respect_to_the_mixture(golden_dir, emu, name):
     with torch.no_grad():
         est_k = model(mixture.detach())              # the kernel path (through the emulator) on the same input
     assert (est_k - est.detach()).abs().max() <= 1e-9 * est.detach().abs().max()
+
+
+@pytest.mark.parametrize("training,p", [(False, 0.0), (True, 0.0)])
+def test_sepformer_feed_forward_on_the_convolution_kernels(emu, training, p):
+    """the feed-forward pair of an encoder layer on the 1x1-convolution kernels (widths in multiples of 128: models/sepformer.py::
+    _feed_forward_channel_major) against nn.TransformerEncoderLayer's own forward in float64, outputs and every gradient"""
+    from models.sepformer import _ChunkPathEncoder, _ff_on_conv_kernels
+    torch.manual_seed(3)
+    layer = torch.nn.TransformerEncoderLayer(128, 4, 256, dropout=p, activation="relu", batch_first=False).double()
+    layer.train(training)
+    x = torch.randn(3, 37, 128, dtype=torch.float64, requires_grad=True)             # (N, L, C): 111 tokens, not a multiple of 128
+    assert _ff_on_conv_kernels(layer, x)
+    y = _ChunkPathEncoder._layer_tokens(layer, x)
+    assert "pw_gemm" in emu.used and "pw_wgrad" not in emu.used
+    xr = x.detach().clone().requires_grad_(True)
+    ref = layer(xr.transpose(0, 1)).transpose(0, 1)                                   # torch's own (T, batch, C) route
+    assert (y - ref).abs().max() <= 1e-11 * ref.abs().max()
+    w = torch.randn_like(y)
+    grads = torch.autograd.grad((y * w).sum(), [x] + list(layer.parameters()))
+    refs = torch.autograd.grad((ref * w).sum(), [xr] + list(layer.parameters()))
+    assert "pw_wgrad" in emu.used
+    for g, r in zip(grads, refs):
+        assert (g - r).abs().max() <= 1e-10 * max(r.abs().max().item(), 1e-12)
