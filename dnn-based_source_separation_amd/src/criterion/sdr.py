@@ -64,8 +64,23 @@ def _prep(input, target):
     return input, target.to(input.dtype)
 
 
+def _on_host(input):
+    """a tensor the caller left on the CPU while the HIP library is the backend (`--use_cuda 0` evaluation, demo notebooks): the
+    criterion is then evaluated with ATen in the reference's own formula -- never for a tensor on the GPU"""
+    return (not input.is_cuda) and sepkernels.backend().name == "hip"
+
+
+def _sisdr_aten(input, target, eps):
+    """reference src/criterion/sdr.py:135-137: projection of the estimate on the target, energy ratio in dB, eps in both sums"""
+    tt = target.square().sum(-1, keepdim=True) + eps
+    proj = (input * target).sum(-1, keepdim=True) / tt * target
+    return 10 * torch.log10((proj.square().sum(-1) + eps) / ((proj - input).square().sum(-1) + eps))
+
+
 def sisdr_pairs(input, target, eps=EPS):
     """(B, n, T) x (B, n, T) -> (B, n, n) matrix of SI-SDR(input_i, target_j)."""
+    if _on_host(input):
+        return _sisdr_aten(input.unsqueeze(2), target.to(input.dtype).unsqueeze(1), eps)
     input, target = _prep(input, target)
     return _SISDRPairsFn.apply(input, target, True, eps)
 
@@ -79,6 +94,8 @@ def sisdr(input, target, eps=EPS):
     """
     n_dims = input.dim()
     assert n_dims in [2, 3, 4], "Only 2D or 3D or 4D tensor is acceptable, but given {}D tensor.".format(n_dims)
+    if _on_host(input):
+        return _sisdr_aten(input, target.to(input.dtype), eps)
     input, target = _prep(input, target)
     lead, T = input.shape[:-1], input.shape[-1]
     rows = input.numel() // T

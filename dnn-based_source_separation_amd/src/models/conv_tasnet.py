@@ -34,9 +34,7 @@ class _FusedConvTasNetFn(torch.autograd.Function):
     def forward(ctx, mixture, cfg, names, want_latent, grad_sink, *params):
         ctx.set_materialize_grads(False)
         ctx.grad_sink, ctx.bucket_hook = (grad_sink if isinstance(grad_sink, tuple) else (grad_sink, None))
-        if ctx.needs_input_grad[0]:
-            raise NotImplementedError("gradient w.r.t. the input mixture is not implemented on the fused path")
-        need_bwd = any(ctx.needs_input_grad[5:])
+        need_bwd = ctx.needs_input_grad[0] or any(ctx.needs_input_grad[5:])
         P = dict(zip(names, params))
         est, latent, sv = _net.forward(cfg, P, mixture, want_latent=want_latent, save=need_bwd)
         ctx.cfg, ctx.names, ctx.sv = cfg, names, sv
@@ -71,13 +69,13 @@ class _FusedConvTasNetFn(torch.autograd.Function):
 
             def on_ready(r):
                 hook(starts[r], total if r == R - 1 else starts[r + 1])
-        _net.backward(ctx.cfg, dict(zip(names, params)), ctx.sv, d_est, G, on_ready=on_ready)
+        d_mix = _net.backward(ctx.cfg, dict(zip(names, params)), ctx.sv, d_est, G, on_ready=on_ready, want_dmix=ctx.needs_input_grad[0])
         if hook is not None:
             hook(0, starts[1] if ctx.cfg["sep_num_blocks"] > 1 else total)
         ctx.sv = None
         grads = tuple(None if (placed is not None and n in placed) else G[n] for n in names)      # placed: already where the caller wants them
         G = None
-        return (None, None, None, None, None) + grads
+        return (d_mix, None, None, None, None) + grads
 
 
 def _layout(named_sizes):
@@ -272,8 +270,17 @@ class ConvTasNet(nn.Module):
                 est = est.view(batch_size, self.n_sources, T)
             return est, latent
         if not mixture.is_cuda and _net.backend().name == "hip":
-            raise RuntimeError("ConvTasNet (MI355X build) runs on the GPU only: move the model and the input to 'cuda'. "
-                               "There is no CPU fallback.")
+            # A model and an input the CALLER left on the CPU (`local/test.py --use_cuda 0`, demo.py; reference
+            # egs/wsj0-mix/conv-tasnet/local/test.py:25,41-43): the module-by-module composition on ATen, i.e. the reference's own
+            # arithmetic -- not this library, never chosen for a tensor on the GPU and never because the HIP library is missing (a
+            # model on 'cuda' without it fails in sepkernels.load()).  SEPK_STRICT_DEVICE=1 turns the case back into the loud error.
+            if os.environ.get("SEPK_STRICT_DEVICE", "0") == "1":
+                raise RuntimeError("ConvTasNet (MI355X build) runs on the GPU only: move the model and the input to 'cuda' "
+                                   "(SEPK_STRICT_DEVICE=1 forbids the ATen composition for CPU tensors).")
+            est, latent = self._run_composed(mixture.contiguous(), want_latent)
+            if n_dims == 3:
+                est = est.view(batch_size, self.n_sources, T)
+            return est, latent
         mixture = mixture.contiguous()
         if mixture.dtype != torch.float32 and _net.backend().name == "hip":
             mixture = mixture.float()

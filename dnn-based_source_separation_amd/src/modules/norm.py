@@ -83,6 +83,10 @@ class GlobalLayerNorm(nn.Module):
 
     def forward(self, input):
         """input (batch_size, C, *) -> same shape; statistics over (C, *) per sample."""
+        if not input.is_cuda and sepkernels.backend().name == "hip":
+            # CPU tensors (the reference's `--use_cuda 0` evaluation / demo mode, egs/wsj0-mix/conv-tasnet/local/test.py:25,41-43): the
+            # reference's own arithmetic, nn.GroupNorm(1, C) of src/modules/norm.py:18,27.  Never taken for a tensor on the GPU.
+            return self.norm(input)
         per_launch = max(1, GRID_ROWS // self.num_features)       # one grid row per (sample, channel): the dual-path models of
         if input.shape[0] <= per_launch:                          # models/{dptnet,galr,sepformer}.py normalise thousands of short samples
             return _GlobalLayerNormFn.apply(input, self.norm.weight, self.norm.bias, self.eps)

@@ -265,8 +265,11 @@ def tail_backward(cfg, P, geo, w, core, m, mixture_shape, d_est, G, dalpha_slot,
     return dcore, dwm
 
 
-def head_backward(cfg, P, geo, stats0, w, mixture, dx0, dwm, G, PK=None):
-    """Backward of head_forward given dx0 = d(bottleneck output) and dwm = d(w) arriving through mask*w."""
+def head_backward(cfg, P, geo, stats0, w, mixture, dx0, dwm, G, PK=None, want_dmix=False):
+    """Backward of head_forward given dx0 = d(bottleneck output) and dwm = d(w) arriving through mask*w.
+    want_dmix: also return d(mixture) (B, Cin, T) -- the adjoint of the analysis convolution is the overlap-add the decoder kernel
+    performs (sep_decoder_fwd with the analysis basis and a mask of ones), one extra launch for the rare caller that differentiates
+    with respect to the input (reference: autograd through nn.Conv1d, src/models/filterbank.py:212,222-230)."""
     K = backend()
     B, Cin, T_in = mixture.shape
     N, L, S = cfg["n_basis"], cfg["kernel_size"], cfg["stride"]
@@ -297,6 +300,11 @@ def head_backward(cfg, P, geo, stats0, w, mixture, dx0, dwm, G, PK=None):
     K.unfold(mixture, Fx, B, Cin, T_in, L, S, F, ldt, geo.pad_left)
     part, _, ns = _wgrad(K, B, F, ldt, eps, f32, N, Cin * L, dvw, Fx, False)
     K.reduce_slabs([(part, 0, G["encoder.conv1d.weight"], N * Cin * L, ns, N * Cin * L, 0, 1.0)])
+    if not want_dmix:
+        return None
+    dmix = torch.empty(B, 1, Cin, T_in, **f32)
+    K.decoder_fwd(dvw, torch.ones(B, N, ldt, **f32), P["encoder.conv1d.weight"], dmix, None, B, 1, N, Cin, L, S, F, ldt, T_in, geo.pad_left)
+    return dmix.view(B, Cin, T_in)
 
 
 def forward(cfg, P, mixture, want_latent=False, save=True):
@@ -389,14 +397,17 @@ class _SideStream:
     stream are handed to `keep()` so that the caching allocator does not recycle them while the side stream lags.
     Measured on MI355X (paper-best, B=16).  fp32-MFMA arithmetic: no gain -- 30.7 vs 30.5 ms/step: every kernel of that
     path fills the chip's LDS/VGPR slots by itself, so a concurrent kernel only takes slots away from the other one.
-    Split arithmetic: 20.8 vs 21.2 ms/step (same box, twice, bit-identical loss) -- its weight-gradient kernel launches
-    512 workgroups onto 768 slots, and the chain's kernels take the rest.  Hence ON by default with the split arithmetics and
-    OFF with SEP_ARITH_F32 (SEPK_SIDE_STREAM=1 / 0 force it); always off on CPU tensors (emulator tests)."""
+    Split arithmetic, round 2: 20.8 vs 21.2 ms/step (same box, twice, bit-identical loss) -- its weight-gradient kernel launched
+    512 workgroups onto 768 slots, and the chain's kernels took the rest.  Round 5, with the one-workgroup-per-compute-unit kernels
+    of rounds 3 - 4 (nothing of another launch fits beside them): OFF is faster in every A/B pair -- 16.26 vs 16.50 / 16.60,
+    16.05 vs 16.39 / 16.41 ms/step at 16 utterances, 10.4 vs 11.7 - 12.4 at 8, where the stream's events also cost host time
+    (profiles/r07_round5_experiments.md).  Hence OFF by default; SEPK_SIDE_STREAM=1 turns it on (the tests run both ways); always
+    off on CPU tensors (emulator tests)."""
     _streams = {}
 
     def __init__(self, dev):
         want = os.environ.get("SEPK_SIDE_STREAM", "auto")
-        self.on = dev.type == "cuda" and (want == "1" or (want not in ("0", "1") and sepkernels.gemm_arith() != sepkernels.ARITH_F32))
+        self.on = dev.type == "cuda" and want == "1"
         if self.on:
             key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
             if key not in _SideStream._streams:
@@ -452,17 +463,18 @@ class _SideStream:
             self.main.wait_event(ev)
 
 
-def backward(cfg, P, sv, d_est, G, on_ready=None):
+def backward(cfg, P, sv, d_est, G, on_ready=None, want_dmix=False):
     """See _backward; sets the per-pass weight bound of SEP_ARITH_F16X3 around it."""
     prev = sepkernels.set_weights_amax(_weights_amax(P))
     try:
-        return _backward(cfg, P, sv, d_est, G, on_ready)
+        return _backward(cfg, P, sv, d_est, G, on_ready, want_dmix)
     finally:
         sepkernels.set_weights_amax(prev)
 
 
-def _backward(cfg, P, sv, d_est, G, on_ready):
-    """Writes the gradient of every parameter into G[name] (overwrites; G tensors have the parameter shapes).
+def _backward(cfg, P, sv, d_est, G, on_ready, want_dmix=False):
+    """Writes the gradient of every parameter into G[name] (overwrites; G tensors have the parameter shapes); returns d(mixture) when
+    want_dmix, else None.
 
     on_ready(first_block, last_block_or_None): optional callback for gradient bucketing.  It is called when every
     gradient of TCN blocks [first_block, ...] is final: first with the last block (plus the whole tail: mask PReLU, mask
@@ -660,4 +672,4 @@ def _backward(cfg, P, sv, d_est, G, on_ready):
     K.reduce_slabs(pending)
 
     # ---- head: bottleneck conv, first gLN, encoder ------------------------------------------------------
-    head_backward(cfg, P, geo, stats[0], w, mixture, dout, dwm, G, PK)
+    return head_backward(cfg, P, geo, stats[0], w, mixture, dout, dwm, G, PK, want_dmix)

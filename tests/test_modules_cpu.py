@@ -71,8 +71,12 @@ def test_error_behaviour():
         model(torch.zeros(4000))                                  # bad rank -> ValueError like the reference
     with pytest.raises(AssertionError):
         model(torch.zeros(1, 2, 4000))                            # C_in must be 1
-    with pytest.raises(RuntimeError):
-        model(torch.zeros(1, 1, 4000))                            # CPU tensor on the HIP build: loud failure, no fallback
+    os.environ["SEPK_STRICT_DEVICE"] = "1"
+    try:
+        with pytest.raises(RuntimeError):
+            model(torch.zeros(1, 1, 4000))                        # CPU tensor on the HIP build, strict mode: loud failure
+    finally:
+        del os.environ["SEPK_STRICT_DEVICE"]
     with pytest.raises(AssertionError):                              # one-sided complex Fourier basis needs an odd feature count (reference utils/filterbank.py:50-66)
         ConvTasNet(64, 16, enc_basis="Fourier", dec_basis="Fourier", enc_nonlinear=None, window_fn="hann",
                    enc_onesided=True, enc_return_complex=True)
@@ -407,3 +411,58 @@ def test_attention_core_is_nn_multihead_attention_between_its_projections(emu, N
     assert (qkv.grad - ref_qkv.grad).abs().max() <= 1e-11 * ref_qkv.grad.abs().max()
     full, _ = mha(x, x, x, need_weights=False)
     assert (torch.nn.functional.linear(o, mha.out_proj.weight, mha.out_proj.bias) - full).abs().max() <= 1e-12 * full.abs().max()
+
+
+@pytest.mark.parametrize("relu", ["relu", None])
+def test_gradient_with_respect_to_the_mixture_on_the_fused_path(emu, relu):
+    """d loss / d mixture of a fused-family model (round-4 verdict item 6: the reference's autograd gives it for free; here it is one
+    more overlap-add launch behind the head's backward) against autograd through the fp64 oracle, parameter gradients alongside."""
+    from oracle import convtasnet_oracle as O
+    cfg = dict(CONFIGS["tiny"], enc_nonlinear=relu)
+    torch.manual_seed(5)
+    model = ConvTasNet(**cfg).double()
+    assert model.fused
+    sources = 0.1 * torch.randn(2, 2, 1003, dtype=torch.float64)
+    mixture = sources.sum(1, keepdim=True).clone().requires_grad_(True)
+    crit = PIT1d(NegSISDR(), n_sources=2)
+    loss, _ = crit(model(mixture), sources)
+    loss.backward()
+    p = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    xm = mixture.detach().clone().requires_grad_(True)
+    out, _ = O.conv_tasnet(xm, p, model.get_config())
+    ref, _ = O.pit(O.neg_sisdr, out, sources)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 1e-10 * abs(ref.item())
+    assert mixture.grad.shape == xm.grad.shape and xm.grad.abs().max() > 0
+    assert (mixture.grad - xm.grad).abs().max() <= 1e-9 * xm.grad.abs().max()
+    for k, q in model.named_parameters():
+        assert (q.grad - p[k].grad).abs().max() <= 1e-8 * max(p[k].grad.abs().max().item(), 1e-9), k
+    # the mixture alone (frozen parameters): same input gradient
+    for q in model.parameters():
+        q.requires_grad_(False)
+    m2 = mixture.detach().clone().requires_grad_(True)
+    crit(model(m2), sources)[0].backward()
+    assert (m2.grad - xm.grad).abs().max() <= 1e-9 * xm.grad.abs().max()
+
+
+def test_cpu_tensors_on_the_product_backend_run_the_aten_composition(golden_dir):
+    """`--use_cuda 0` / demo.py (reference egs/wsj0-mix/conv-tasnet/local/test.py:25,41-43): a fused-family model the caller left on the
+    CPU, with the PRODUCT's backend object in place (no emulator), runs the module-by-module composition on ATen -- the reference's own
+    arithmetic -- and agrees with the golden vectors of the unmodified reference; SEPK_STRICT_DEVICE=1 keeps the loud error."""
+    assert sepkernels.backend().name == "hip"
+    for name in ("tiny", "softmax"):
+        g = _golden(golden_dir, name)
+        model = ConvTasNet(**CONFIGS[name])
+        model.load_state_dict({k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param/")})
+        assert model.fused
+        with torch.no_grad():
+            est = model(torch.from_numpy(g["mixture"]))
+            est2, latent = model.extract_latent(torch.from_numpy(g["mixture"]))
+        ref = torch.from_numpy(g["output_f32"])
+        assert est.shape == ref.shape and (est - ref).abs().max() <= 1e-4 * ref.abs().max()
+        assert torch.equal(est, est2) and latent.shape[:3] == (ref.shape[0], model.n_sources, model.n_basis)
+    # gradients flow too (the reference's demo notebooks fine-tune on the CPU)
+    model.train()
+    out = model(torch.from_numpy(g["mixture"]))
+    out.square().mean().backward()
+    assert all(q.grad is not None and torch.isfinite(q.grad).all() for q in model.parameters())
