@@ -88,8 +88,12 @@ def compact_line(detail):
     out["config"] = {k: c[k] for k in ("workload", "global_batch", "per_gpu_batch", "parallelism", "rccl_ranks", "launch", "final_loss") if k in c}
     r = detail.get("roofline")
     if r:
-        out["roofline"] = {k: _r(r.get(k)) for k in ("kernel", "launch_class", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic",
-                                                      "avg_launch_us", "launches_per_step", "share_of_kernel_time", "algorithmic_bytes_per_launch")}
+        out["roofline"] = {k: _r(r.get(k)) for k in ("kernel", "launch_class", "family", "bound", "achieved", "peak", "unit", "frac", "family_frac", "family_share", "traffic",
+                                                      "traffic_over_algorithmic", "avg_launch_us", "launches_per_step", "share_of_kernel_time",
+                                                      "algorithmic_bytes_per_launch")}
+    rf = detail.get("roofline_family")
+    if rf:
+        out["roofline_family"] = {k: {"frac": _r(v["frac"]), "share": _r(v["share"])} for k, v in rf.items()}
     s = detail.get("step_roofline")
     if s:
         out["step_roofline"] = {k: _r(s.get(k)) for k in ("hbm_frac", "matrix_pipe_frac", "traffic_GB_per_step", "traffic_over_algorithmic")}
@@ -361,6 +365,7 @@ def main():
             dom = legs.dominant_kernel_roofline(by_kernel, arith_name)
             if dom is not None:
                 detail["roofline"] = dom
+            detail["roofline_family"] = legs.roofline_family(by_kernel)
             detail["slowest_kernels"] = legs.furthest_from_roof(by_kernel)
         if world == 1 and args.config == "convtasnet2" and not args.no_stock:
             detail["inference"] = legs.inference_leg(model, dev)

@@ -26,7 +26,7 @@ import sepkernels
 
 class FusedTrainStep:
     def __init__(self, model, criterion, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=5.0,
-                 process_group=None, distributed=None, uneven_batches=False, time_collectives=False):
+                 process_group=None, distributed=None, uneven_batches=False, time_collectives=False, exercise_collectives=False):
         self.model, self.criterion = model, criterion
         self.lr, self.betas, self.eps, self.weight_decay, self.max_norm = lr, betas, eps, weight_decay, max_norm
         self.group = process_group
@@ -36,7 +36,11 @@ class FusedTrainStep:
         if flat is None:
             raise RuntimeError("FusedTrainStep needs the model's parameters co-located in one flat buffer")
         self.flat = flat
-        if self.distributed and self.world > 1:
+        # exercise_collectives: take the exchange path (broadcast, bucketed asynchronous all-reduces from inside backward, their waits and
+        # event brackets) ALSO in a process group of one rank, where every collective is the identity: the RCCL call sequence of the N-GPU
+        # step then runs on the single GPU a test box has (tests/test_gpu_model.py) instead of for the first time on the 8-GPU node
+        self.comm = self.distributed and (self.world > 1 or bool(exercise_collectives))
+        if self.comm:
             dist.broadcast(self.flat, src=0, group=process_group)      # replaces DataParallel's per-forward replicate
         self.gflat = torch.zeros_like(flat)
         self.m = torch.zeros_like(flat)
@@ -103,7 +107,7 @@ class FusedTrainStep:
         """Record one step on inputs of this shape.  `warmup` eager steps run first on a side stream (allocator and lazy
         initialisation settle there, as torch.cuda.graphs asks for); they ARE training steps.  Returns the loss of the captured step
         (which is executed too)."""
-        if self.world > 1:
+        if self.comm:
             raise RuntimeError("graph capture of the train step is single-process only (the gradient all-reduce stays eager)")
         dev = self.flat.device
         self._static = (torch.empty_like(mixture), torch.empty_like(sources))
@@ -153,10 +157,10 @@ class FusedTrainStep:
         works = []
         self.last_bucket_bytes = []
         count_work = None
-        if self.world > 1 and self.uneven:
+        if self.comm and self.uneven:
             count = torch.tensor([float(mixture.shape[0])], device=self.gflat.device, dtype=torch.float32)
             count_work = (dist.all_reduce(count, op=dist.ReduceOp.SUM, group=self.group, async_op=True), count)
-        if self.world > 1 and self.bucketed:
+        if self.comm and self.bucketed:
             # one asynchronous RCCL all-reduce per TCN block, issued as soon as the block's gradients are final, so the
             # exchange of the late layers travels under the differentiation of the early ones (3 buckets at paper-best)
             def bucket_ready(lo, hi):
@@ -191,7 +195,7 @@ class FusedTrainStep:
                 torch._foreach_copy_(dst, src)
         self.last_buckets = len(works)
         grad_scale = 1.0 / self.world
-        if self.world > 1:
+        if self.comm:
             timed = self.time_collectives and self.gflat.is_cuda
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -248,15 +252,21 @@ class FusedTrainStep:
             spans.append((off, p.numel(), tuple(p.shape)))
         return spans
 
+    def _state_indices(self):
+        """position of every flat-buffer parameter in model.parameters() -- torch.optim.Adam(model.parameters()) numbers ALL of them, also
+        the integer `time_seq` a Fourier basis carries, so the state of a checkpoint the reference wrote (or will read) is keyed by these"""
+        return [i for i, p in enumerate(self.model.parameters()) if p.is_floating_point()]
+
     def optim_state_dict(self):
         state = {}
-        for i, (off, n, shape) in enumerate(self._spans()):
+        for i, (off, n, shape) in zip(self._state_indices(), self._spans()):
             state[i] = {"step": torch.tensor(float(self.step_count)),
                         "exp_avg": self.m[off:off + n].detach().reshape(shape).cpu().clone(),
                         "exp_avg_sq": self.v[off:off + n].detach().reshape(shape).cpu().clone()}
+        n_all = sum(1 for _ in self.model.parameters())
         group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
                  "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
-                 "fused": None, "params": list(range(len(state)))}
+                 "fused": None, "params": list(range(n_all))}
         return {"state": state, "param_groups": [group]}
 
     def load_optim_state_dict(self, sd):
@@ -270,10 +280,12 @@ class FusedTrainStep:
             self.weight_decay = g.get("weight_decay", self.weight_decay)
         state = sd.get("state", {})
         steps = []
-        for i, (off, n, _) in enumerate(spans):
+        for i, (off, n, _) in zip(self._state_indices(), spans):
             st = state.get(i, state.get(str(i)))
             if st is None:
                 continue
+            if st["exp_avg"].numel() != n:
+                raise ValueError("optimizer state {} has {} elements, the parameter at that position {}".format(i, st["exp_avg"].numel(), n))
             self.m[off:off + n].copy_(st["exp_avg"].reshape(-1).to(self.m.device, self.m.dtype))
             self.v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1).to(self.v.device, self.v.dtype))
             steps.append(int(float(st["step"])))

@@ -182,6 +182,36 @@ def test_torch_adam_state_resumes_the_fused_step(emu):
         assert (pa - pc).abs().max() <= 1e-6 * (1 + pa.abs().max()), k
 
 
+def test_adam_state_of_a_fourier_model_round_trips_with_torch_adam(emu):
+    """round-4 advisor finding: a Fourier filterbank carries integer `time_seq` parameters that torch.optim.Adam(model.parameters()) counts
+    in its state indices; the fused step's optim_dict has to use the same numbering in both directions."""
+    cfg = dict(TINY, enc_basis="trainableFourierTrainablePhase", dec_basis="trainableFourierTrainablePhase", enc_nonlinear=None, window_fn="hann",
+               enc_onesided=False, enc_return_complex=False)
+    torch.manual_seed(4)
+    a = ConvTasNet(**cfg)
+    n_all = len(list(a.parameters()))
+    n_float = len([p for p in a.parameters() if p.is_floating_point()])
+    assert n_all > n_float                                           # the integer parameters exist in this configuration
+    crit = PIT1d(NegSISDR(), n_sources=2)
+    mix, src = 0.3 * torch.randn(2, 1, 200), 0.3 * torch.randn(2, 2, 200)
+    fused = FusedTrainStep(a, crit, lr=1e-3, max_norm=5.0)
+    fused(mix, src)
+    sd = fused.optim_state_dict()
+    assert sd["param_groups"][0]["params"] == list(range(n_all)) and len(sd["state"]) == n_float
+    # torch's optimizer over ALL parameters accepts it ...
+    opt = torch.optim.Adam(a.parameters(), lr=1e-3)
+    opt.load_state_dict(sd)
+    params = list(a.parameters())
+    for i, st in opt.state_dict()["state"].items():
+        assert params[i].is_floating_point() and st["exp_avg"].shape == params[i].shape
+    # ... and what torch writes comes back to the same moments
+    b = ConvTasNet(**cfg)
+    b.load_state_dict(a.state_dict())
+    fused_b = FusedTrainStep(b, crit, lr=1e-3, max_norm=5.0)
+    fused_b.load_optim_state_dict(opt.state_dict())
+    assert fused_b.step_count == 1 and torch.equal(fused_b.m, fused.m) and torch.equal(fused_b.v, fused.v)
+
+
 def test_tester_variable_length_inference(tmp_path, wav_tree, emu):
     root, lst = wav_tree
     torch.manual_seed(2)

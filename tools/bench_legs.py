@@ -203,15 +203,46 @@ def attach_kernel_instances(by_kernel, per_kernel_traffic):
             e["traffic_over_algorithmic"] = (t[1] + t[2]) / (e["algorithmic_MB_per_launch"] * 1e6)
 
 
+def family_of(cls):
+    """launch class -> kernel family: the 1x1-convolution products (forward + input gradient), their weight gradients (with the slab
+    reductions they need), everything else that streams tensors once (depthwise, encoder / decoder, head backward)"""
+    if cls.startswith("gemm "):
+        return "gemm"
+    if cls.startswith("wgrad ") or cls in ("reduce_slabs", "gln sums from wgrad"):
+        return "wgrad"
+    return "streaming"
+
+
+def roofline_family(by_kernel):
+    """{family: {frac, share, ms_per_step, launches_per_step}}: time-weighted fraction of the HBM roof (sum of the launches' algorithmic bytes /
+    sum of their durations / 8 TB/s; launch classes without a byte count -- latency-bound tails -- add time only) and share of the step's
+    kernel time, per family.  The per-class table (`roofline_by_kernel`) decides nothing by a 0.02 % tie this way (round-4 verdict item 3)."""
+    fam = {}
+    for cls, e in by_kernel.items():
+        f = fam.setdefault(family_of(cls), {"ms": 0.0, "bytes": 0.0, "share": 0.0, "n": 0.0})
+        f["ms"] += e["ms_per_step"]
+        f["share"] += e["share_of_kernel_time"]
+        f["n"] += e["launches_per_step"]
+        if "algorithmic_MB_per_launch" in e:
+            f["bytes"] += e["algorithmic_MB_per_launch"] * 1e6 * e["launches_per_step"]
+    return {k: {"frac": v["bytes"] / (v["ms"] * 1e-3) / (HBM_PEAK_TBS * 1e12) if v["ms"] > 0 else None, "share": v["share"],
+                "ms_per_step": v["ms"], "launches_per_step": v["n"]} for k, v in fam.items()}
+
+
 def dominant_kernel_roofline(by_kernel, arith_name):
-    """`roofline` of the bench line: the launch class with the largest share of the step's kernel time, i.e. ONE kernel template instance"""
-    cands = [(e["ms_per_step"], cls) for cls, e in by_kernel.items() if "hbm_frac" in e]
+    """`roofline` of the bench line: ONE kernel template instance -- the largest launch class of the FAMILY with the largest share of the step's
+    kernel time (the families' own fractions travel beside it as `roofline_family`)"""
+    fams = roofline_family(by_kernel)
+    top = max(fams, key=lambda k: fams[k]["share"]) if fams else None
+    cands = [(e["ms_per_step"], cls) for cls, e in by_kernel.items() if "hbm_frac" in e and family_of(cls) == top]
+    if not cands:
+        cands = [(e["ms_per_step"], cls) for cls, e in by_kernel.items() if "hbm_frac" in e]
     if not cands:
         return None
     cls = max(cands)[1]
     e = by_kernel[cls]
     hbm = e["bound"] == "hbm"
-    out = {"kernel": e.get("kernel_instance", cls), "launch_class": cls, "bound": e["bound"],
+    out = {"kernel": e.get("kernel_instance", cls), "launch_class": cls, "family": family_of(cls), "bound": e["bound"],
            "achieved": e["GBps"] if hbm else e["tflops_equiv"], "peak": HBM_PEAK_TBS * 1e3 if hbm else MFMA_PER_PRODUCT[arith_name][1] / MFMA_PER_PRODUCT[arith_name][0],
            "unit": "GB/s" if hbm else "TFLOP/s", "frac": e["hbm_frac"] if hbm else e["matrix_pipe_frac"],
            "traffic": e["traffic_MB_per_launch"] * 1e6 if "traffic_MB_per_launch" in e else None, "traffic_unit": "bytes/launch",
@@ -223,6 +254,8 @@ def dominant_kernel_roofline(by_kernel, arith_name):
                        "FETCH_SIZE x2 + WRITE_SIZE of the same instance"}
     if "matrix_pipe_frac" in e:
         out["matrix_pipe_frac"] = e["matrix_pipe_frac"]
+    if top is not None and family_of(cls) == top:
+        out["family_frac"], out["family_share"] = fams[top]["frac"], fams[top]["share"]      # the family's time-weighted figure beside its largest instance
     return out
 
 
@@ -543,7 +576,9 @@ def hipified_baseline(mixture, sources, steps=5):
 
 
 def _dual_path_workloads():
-    """--config name -> (class, constructor arguments, recipe batch size, Adam arguments, GFLOP/utterance or None, what runs where)"""
+    """--config name -> (class, constructor arguments, recipe batch size, Adam arguments, GFLOP per utterance forward + backward, what runs
+    where).  The GFLOP figures are counted on the unmodified reference modules by oracle/count_flops.py (every matrix product / convolution /
+    attention product of one forward pass of a 4-s utterance, LSTM gate products included, x 3; DPRNN-TasNet's 980.07 is SURVEY.md 8d's)."""
     from models.dprnn_tasnet import DPRNNTasNet
     from models.dptnet import DPTNet
     from models.galrnet import GALRNet
@@ -553,7 +588,7 @@ def _dual_path_workloads():
     return {
         # the reference constructor's default family (causal=True: cLN, all padding on the left) at the paper-best sizes: runs layer by layer
         # on this library's kernels (models/conv_tasnet.py::_run_staged), batch 16 like the headline
-        "causal": (ConvTasNet, dict(PAPER, causal=True), 16, dict(lr=1e-3), None,
+        "causal": (ConvTasNet, dict(PAPER, causal=True), 16, dict(lr=1e-3), 117.84,
                    "Conv-TasNet paper-best sizes, CAUSAL (cLN, left padding: reference tdcn.py:98,125-127), staged kernel path"),
         # BASELINE.json configs[3]: egs/wsj0-mix/dprnn-tasnet/train.sh:28-37
         "dprnn": (DPRNNTasNet, dict(n_basis=64, kernel_size=2, stride=1, enc_nonlinear=None, sep_hidden_channels=128, sep_bottleneck_channels=64,
@@ -563,16 +598,16 @@ def _dual_path_workloads():
         # SURVEY.md section 8 row f4, the reference recipes' own sizes: egs/wsj0-mix/{dptnet,galrnet,sepformer}/train.sh
         "dptnet": (DPTNet, dict(n_basis=64, kernel_size=2, stride=1, enc_nonlinear=None, sep_bottleneck_channels=64, sep_hidden_channels=128,
                                 sep_chunk_size=250, sep_hop_size=125, sep_num_blocks=6, sep_num_heads=4, sep_norm=True, sep_nonlinear="relu",
-                                sep_dropout=0, mask_nonlinear="relu", causal=False, n_sources=2, **tr), 1, dict(lr=1e-3), None,
+                                sep_dropout=0, mask_nonlinear="relu", causal=False, n_sources=2, **tr), 1, dict(lr=1e-3), 1206.76,
                    "DPTNet N=64 L=2 F=64 d_ff=128 K=250 P=125 B=6 h=4 (egs/wsj0-mix/dptnet/train.sh:28-44)"),
         "galrnet": (GALRNet, dict(n_basis=64, kernel_size=16, stride=8, enc_nonlinear=None, sep_hidden_channels=128, sep_chunk_size=100,
                                   sep_hop_size=50, sep_down_chunk_size=32, sep_num_blocks=6, sep_num_heads=8, sep_norm=True, sep_dropout=1e-1,
-                                  mask_nonlinear="relu", causal=False, n_sources=2, low_dimension=True, **tr), 4, dict(lr=1e-3, weight_decay=1e-6), None,
+                                  mask_nonlinear="relu", causal=False, n_sources=2, low_dimension=True, **tr), 4, dict(lr=1e-3, weight_decay=1e-6), 64.81,
                     "GALRNet D=64 M=16 H=128 K=100 P=50 Q=32 N=6 J=8 (egs/wsj0-mix/galrnet/train.sh:28-42)"),
         "sepformer": (SepFormer, dict(n_basis=256, kernel_size=16, stride=8, enc_nonlinear="relu", sep_bottleneck_channels=256, sep_chunk_size=250,
                                       sep_hop_size=125, sep_num_blocks=2, sep_num_layers_intra=8, sep_num_layers_inter=8, sep_num_heads_intra=8,
                                       sep_num_heads_inter=8, sep_d_ff_intra=1024, sep_d_ff_inter=1024, sep_norm=True, sep_nonlinear="relu",
-                                      sep_dropout=1e-1, mask_nonlinear="relu", causal=False, n_sources=2, **tr), 4, dict(lr=15e-5), None,
+                                      sep_dropout=1e-1, mask_nonlinear="relu", causal=False, n_sources=2, **tr), 4, dict(lr=15e-5), 1184.66,
                       "SepFormer F=256 L=16 B=256 C=250 P=125 N=2 K=8+8 h=8 d_ff=1024 (egs/wsj0-mix/sepformer/train.sh:27-47)"),
     }
 
@@ -660,17 +695,27 @@ def bench_dual_path(args):
                   label, B, " (recipe default)" if B == recipe_batch else " (recipe default: {})".format(recipe_batch)),
               "global_batch": B, "frames_per_utterance": F, "parallelism": "dp1", "utt_per_s": B * args.steps / el, "final_loss": float(loss),
               "parameters": model.num_parameters, "launch": launch}
-    note = "no roofline: library GEMM / attention calls between this library's kernels, none of which dominates"
-    roofline = None
-    if gflop is not None:
-        config["algorithmic_gflop_per_utterance_fwd_bwd"] = gflop
-        tf = gflop * 1e9 * B * args.steps / el / 1e12
-        # the step's arithmetic is fp32 throughout (the LSTM recurrences on v_mfma_f32_16x16x4 / 4x4x1, projections on rocBLAS fp32): matrix-pipe roof
-        roofline = {"kernel": "whole step (sep_lstm_fwd / sep_lstm_bwd sweeps + the dense layers of csrc/linear.hip; per-kernel: profiles/r04e_dprnn_kernel_stats.md)",
+    config["algorithmic_gflop_per_utterance_fwd_bwd"] = gflop
+    tf = gflop * 1e9 * B * args.steps / el / 1e12
+    if args.config == "causal":
+        # same tensors and products as the headline (cLN instead of gLN): whole step against the HBM roof with SURVEY.md 8d's bytes per frame, the
+        # matrix-pipe fraction of its f16x3 products beside it
+        by_frame = 3 * bytes_per_frame(PAPER)
+        per, pipe = MFMA_PER_PRODUCT["f16x3"]
+        gbs = B * F * args.steps / el * by_frame / 1e9
+        roofline = {"kernel": "whole step (staged sequence: sep_pw_gemm, sep_cln_*, sep_depthwise_*; per-kernel: profiles/r05zm_causal_kernel_stats.md)",
+                    "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s", "frac": gbs / (HBM_PEAK_TBS * 1e3), "traffic": None,
+                    "matrix_pipe_frac": tf / (pipe / per),
+                    "what": "algorithmic bytes of fwd + bwd ({} B per frame, SURVEY.md 8d: the fused non-causal sequence's minimum) x frames/s vs 8 TB/s".format(by_frame)}
+        note = "{:.2f} GFLOP per utterance, {} B per frame (SURVEY.md 8d)".format(gflop, by_frame)
+    else:
+        # these steps' arithmetic is fp32 throughout (LSTM recurrences on v_mfma_f32_16x16x4 / 4x4x1, dense layers of csrc/linear.hip and the
+        # attention core on the fp32 MFMA): matrix-pipe roof
+        roofline = {"kernel": "whole step (LSTM sweeps, dense layers of csrc/linear.hip, attention core of csrc/attn.hip; per-kernel: profiles/*_{}_kernel_stats.md)".format(args.config),
                     "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                    "what": "algorithmic fp32 FLOP of fwd + bwd ({:.0f} GFLOP per utterance, SURVEY.md 8d) / step time vs the dense fp32 MFMA peak".format(gflop)}
-        note = "{:.0f} GFLOP per utterance (SURVEY.md 8d): {:.1f} TFLOP/s achieved".format(gflop, tf)
+                    "what": "algorithmic fp32 FLOP of fwd + bwd ({:.2f} GFLOP per utterance: oracle/count_flops.py on the reference modules) / step time vs the dense fp32 MFMA peak".format(gflop)}
+        note = "{:.2f} GFLOP per utterance (oracle/count_flops.py): {:.1f} TFLOP/s achieved".format(gflop, tf)
     print(json.dumps({
         "metric": "separated audio frames/sec (fwd+bwd), {} 2-spk 4s@8kHz".format("DPRNN-TasNet" if args.config == "dprnn" else "causal Conv-TasNet" if args.config == "causal" else cls.__name__) +
                   (" (BASELINE configs[3])" if args.config == "dprnn" else ""), "value": B * F * args.steps / el, "unit": "frames/s",
