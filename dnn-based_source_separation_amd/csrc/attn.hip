@@ -30,11 +30,13 @@ constexpr float ATT_LOG2E = 1.4426950408889634f, ATT_LN2 = 0.6931471805599453f;
 // the scores are kept in units of log 2 (q, or k, is scaled by scale * log2(e) on load): v_exp_f32 with nothing in front of it
 __device__ __forceinline__ float att_exp2(const float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ int att_row(const int r, const int lk) { return (r & 3) + 8 * (r >> 2) + 4 * lk; }      // row of result register r
-__device__ __forceinline__ unsigned att_hash(const unsigned idx, const unsigned s0, const unsigned s1) {
-    unsigned x = idx ^ s0;
+// idx: the element's 64-bit index ((n H + h) L + q) L + key -- beyond 2^32 probabilities (N H L^2) the high word enters the hash too, so the
+// mask does not repeat; below that it is zero and changes nothing
+__device__ __forceinline__ unsigned att_hash(const unsigned long long idx, const unsigned s0, const unsigned s1) {
+    unsigned x = (unsigned)idx ^ s0;
     x *= 0x9E3779B1u; x ^= x >> 15;
     x *= 0x85EBCA6Bu; x ^= x >> 13;
-    x += s1;
+    x += s1 + (unsigned)(idx >> 32) * 0x9E3779B1u;
     x *= 0xC2B2AE35u; x ^= x >> 16;
     return x;
 }
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const att_args p) {
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.f / sum;
     if (lk == 0 && q < L) p.lse[((size_t)n * H + h) * L + q] = m * ATT_LN2 + logf(sum);
-    const unsigned ebase = (unsigned)((((size_t)n * H + h) * L + q) * (size_t)L);
+    const unsigned long long ebase = (((unsigned long long)n * H + h) * L + q) * (unsigned long long)L;
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const att_args p) {
         lse = p.lse_in[sidx] * ATT_LOG2E;
         if (lk == 0) p.lse[sidx] = dl;
     }
-    const unsigned ebase = (unsigned)(sidx * (size_t)L);
+    const unsigned long long ebase = (unsigned long long)sidx * (unsigned long long)L;
     att_f32x16 dq;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[r] = 0.f;
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const att_args p) {
             const float pr = live ? att_exp2(s[r] - lse_s[qq]) : 0.f;
             float pd = pr, dpv = dp[r];
             if (p.thr != 0u) {
-                const bool keep = att_hash((unsigned)((hbase + qq) * (size_t)L) + (unsigned)key, p.s0, p.s1) >= p.thr;
+                const bool keep = att_hash((unsigned long long)(hbase + qq) * (unsigned long long)L + (unsigned)key, p.s0, p.s1) >= p.thr;
                 pd = keep ? pr * p.keep_inv : 0.f;
                 dpv = keep ? dpv * p.keep_inv : 0.f;
             }

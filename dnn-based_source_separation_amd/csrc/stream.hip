@@ -1581,7 +1581,7 @@ __global__ __launch_bounds__(256) void depthwise3_wgrad_row_kernel(const float* 
 // the row kernels take the TCN layers' geometry: stride 1, three taps, rows of a multiple of 4 frames that fit the LDS
 static inline bool depthwise3_rows(int Tin, int Tout, int Kw, int stride) {
     static const bool off = getenv("SEPK_DEPTHWISE_ROWS") != nullptr && atoi(getenv("SEPK_DEPTHWISE_ROWS")) == 0;
-    return !off && Kw == 3 && stride == 1 && Tin == Tout && Tin % 4 == 0 && Tin <= 32768;
+    return !off && Kw == 3 && stride == 1 && Tin == Tout && Tin % 4 == 0 && (size_t)Tin * sizeof(float) <= 128 * 1024;      // one row of LDS: 128 of gfx950's 160 KB
 }
 
 }  // namespace
@@ -2007,7 +2007,10 @@ extern "C" int sep_depthwise_fwd(const float* x, const float* w, const float* bi
                                  int Kw, int stride, int pad, int dil, sep_stream_t stream) {
     SEP_REQUIRE(x && w && y && B > 0 && C > 0 && Tin > 0 && Tout > 0 && Kw > 0 && stride > 0 && dil > 0 && pad >= 0, "sep_depthwise_fwd: bad arguments");
     if (depthwise3_rows(Tin, Tout, Kw, stride)) {
-        hipLaunchKernelGGL((depthwise3_row_kernel<0>), dim3((unsigned)((long)B * C)), dim3(256), (size_t)Tin * sizeof(float), (hipStream_t)stream, x, w, bias, y, C, Tin, dil, pad);
+        // the LDS row is only touched when a tap's shift is not a multiple of 4 frames (the kernel's `aligned`): none is asked for otherwise,
+        // which is every dilation >= 4 of the TCN -- 128 KB per workgroup at the longest row would leave one workgroup per compute unit
+        const bool al = ((pad | (dil - pad) | (2 * dil - pad)) & 3) == 0;
+        hipLaunchKernelGGL((depthwise3_row_kernel<0>), dim3((unsigned)((long)B * C)), dim3(256), al ? (size_t)0 : (size_t)Tin * sizeof(float), (hipStream_t)stream, x, w, bias, y, C, Tin, dil, pad);
         SEP_CHECK_LAUNCH("sep_depthwise_fwd");
         return 0;
     }
@@ -2021,7 +2024,8 @@ extern "C" int sep_depthwise_bwd_input(const float* dy, const float* w, float* d
                                        int stride, int pad, int dil, sep_stream_t stream) {
     SEP_REQUIRE(dy && w && dx && B > 0 && C > 0 && stride > 0, "sep_depthwise_bwd_input: bad arguments");
     if (depthwise3_rows(Tin, Tout, Kw, stride)) {
-        hipLaunchKernelGGL((depthwise3_row_kernel<1>), dim3((unsigned)((long)B * C)), dim3(256), (size_t)Tin * sizeof(float), (hipStream_t)stream, dy, w, (const float*)nullptr, dx, C, Tin, dil, pad);
+        const bool al = ((pad | (pad - dil) | (pad - 2 * dil)) & 3) == 0;          // (see sep_depthwise_fwd)
+        hipLaunchKernelGGL((depthwise3_row_kernel<1>), dim3((unsigned)((long)B * C)), dim3(256), al ? (size_t)0 : (size_t)Tin * sizeof(float), (hipStream_t)stream, dy, w, (const float*)nullptr, dx, C, Tin, dil, pad);
         SEP_CHECK_LAUNCH("sep_depthwise_bwd_input");
         return 0;
     }

@@ -105,6 +105,9 @@ class DualPathTransformer(nn.Module):
     def _tokens_ok(self, input):
         """every norm of the stack a gLN (a causal model's inter-chunk path carries cLN: cumulative along the sequence, another kernel), a
         feature count sep_gln_tokens_* takes, tensors the backend takes"""
+        B, C, S, K = input.shape
+        if max(S, K) > 65535 or B * ((C + 31) // 32) > 65535 or B * max(S, K) > 65535:      # grid limits of sep_chunk_to_tokens / sep_gln_tokens_* / sep_attn_*
+            return False
         probe = input.new_empty(1, 1, input.shape[1])
         for block in self.net:
             for tr in (block.intra_chunk_block.transformer, block.inter_chunk_block.transformer):

@@ -270,7 +270,7 @@ class PaddedHeadsFn(torch.autograd.Function):
         else:
             ctx.mark_dirty(total)
         xo = torch.empty(B, Bn, ldt, **f32) if Wo is not None else None
-        joint = Wo is not None and Bn % 128 == 0 and _net._adjacent(Wo, Ws) and _net._adjacent(bo, bs)
+        joint = Wo is not None and bo is not None and bs is not None and Bn % 128 == 0 and _net._adjacent(Wo, Ws) and _net._adjacent(bo, bs)
         if joint:
             K.pw_gemm(B=B, M=Bn + Sc, K=H, T=n_frames, ldt=ldt, A=Wo.as_strided((Bn + Sc, H), (H, 1)), X=v, Y=xo, Y2=total, m_split=Bn,
                       bias=bo.as_strided((Bn + Sc,), (1,)), accumulate=int(not first), epi_flags=_net.EPI_RESIDUAL, epi_res=x_res, a_amax=a_amax)
@@ -743,7 +743,8 @@ def attn_core_ok(x, L, head_dim):
     """should csrc/attn.hip take this attention?  Heads 8 / 16 / 32 wide, fp32 on the device, and sequences of at most 256 steps: the kernels
     go to 320, but at 257 (three query tiles, the last with one query; nine key blocks) torch's memory-efficient kernel is faster -- 634
     against 463 us forward + backward at DPTNet's inter-chunk shape, profiles/r05zo_attention.txt"""
-    return L <= 256 and head_dim in (8, 16, 32) and takes(x) and (backend().name != "hip" or x.dtype == torch.float32)
+    # (x.shape[0] sequences ride a 16-bit grid dimension in sep_attn_*: longer batches -- DPTNet at stride 1 on a long recording -- keep torch's kernel)
+    return L <= 256 and head_dim in (8, 16, 32) and x.shape[0] <= 65535 and takes(x) and (backend().name != "hip" or x.dtype == torch.float32)
 
 
 class AttnCoreFn(torch.autograd.Function):
@@ -758,7 +759,15 @@ class AttnCoreFn(torch.autograd.Function):
         N, L, three, H, D = qkv.shape
         o = torch.empty(N, L, H, D, device=qkv.device, dtype=qkv.dtype)
         lse = torch.empty(N, H, L, device=qkv.device, dtype=qkv.dtype)
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p_drop > 0 else 0         # the CPU generator: torch.manual_seed reaches it, no device sync
+        seed = 0
+        if p_drop > 0:
+            if qkv.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("attention dropout takes its seed on the host: a captured step would replay ONE mask (use p = 0 or launch eagerly)")
+            # the CPU generator (torch.manual_seed reaches it, no device sync), with the rank and the device folded in: data-parallel ranks
+            # seeded alike must not drop the same elements
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+            seed = (seed ^ (0x9E3779B97F4A7C15 * (1 + rank + 1024 * (qkv.device.index or 0)))) & (2 ** 62 - 1)
         scale = float(D) ** -0.5
         K.attn_fwd(qkv, o, lse, N, L, H, D, scale, float(p_drop), seed)
         ctx.save_for_backward(qkv, o, lse)
@@ -823,8 +832,8 @@ class TokenGLNFn(torch.autograd.Function):
 def token_gln_ok(x, norm1d):
     """can `norm1d` (a modules.norm.GlobalLayerNorm) run on token-major rows x (nseq, L, C) through TokenGLNFn?"""
     C = x.shape[-1]
-    return (type(norm1d).__name__ == "GlobalLayerNorm" and x.dim() == 3 and C >= 4 and 1024 % C == 0 and takes(x)
-            and (backend().name != "hip" or x.dtype == torch.float32))
+    return (type(norm1d).__name__ == "GlobalLayerNorm" and x.dim() == 3 and C >= 4 and 1024 % C == 0 and x.shape[0] <= 65535 and takes(x)
+            and (backend().name != "hip" or x.dtype == torch.float32))      # (nseq rides a 16-bit grid dimension in sep_gln_tokens_*)
 
 
 def dense_apply(x, weight, bias):

@@ -450,12 +450,13 @@ class EmuBackend:
         thr = max(1, min(int(p_drop * 4294967296.0), M))
         s0, s1 = seed & M, (seed >> 32) & M
         n, h, q, k = torch.meshgrid(torch.arange(N), torch.arange(H), torch.arange(L), torch.arange(L), indexing="ij")
-        x = ((((n * H + h) * L + q) * L + k) & M) ^ s0
+        idx = ((n * H + h) * L + q) * L + k                                             # 64-bit element index: the high word enters the hash too
+        x = (idx & M) ^ s0
         x = (x * 0x9E3779B1) & M
         x = x ^ (x >> 15)
         x = (x * 0x85EBCA6B) & M
         x = x ^ (x >> 13)
-        x = (x + s1) & M
+        x = (x + s1 + (((idx >> 32) & M) * 0x9E3779B1)) & M
         x = (x * 0xC2B2AE35) & M
         x = x ^ (x >> 16)
         return x >= thr, 1.0 / (1.0 - p_drop)

@@ -1177,28 +1177,16 @@ def test_tcn_layer_kernel_by_kernel_against_the_oracle(B, Bn, H, Sc, T, d):
         Wcat, bcat = rnd(Bn + Sc, H, scale=H ** -0.5), rnd(Bn + Sc, scale=0.1)
         dout, dS = padded(B, Bn, T, ldt), padded(B, Sc, T, ldt)
 
-        # ---- the oracle, fp64, with every intermediate kept -------------------------------------------------------------------------
-        dd = lambda t: t.double().clone().requires_grad_(True)
-        ox = dd(x[..., :T])
-        oW1, ob1, oal1, oal2, og1, obe1, og2, obe2, owd, obd, oWc, obc = (dd(t) for t in (W1, b1, al1, al2, g1, be1, g2, be2, wd, bd, Wcat, bcat))
-        oa = O.pointwise_conv(ox, oW1, ob1)
-        ou1 = O.prelu(oa, oal1)
-        ov1 = O.gln(ou1, og1, obe1, eps)
-        oz = O.depthwise_conv(ov1, owd, obd, d)
-        ou2 = O.prelu(oz, oal2)
-        ov2 = O.gln(ou2, og2, obe2, eps)
-        oo = O.pointwise_conv(ov2, oWc[:Bn].unsqueeze(-1), obc[:Bn]) + ox
-        osk = O.pointwise_conv(ov2, oWc[Bn:].unsqueeze(-1), obc[Bn:])
-        for t in (oa, ov1, oz, ov2):
-            t.retain_grad()
-        ((oo * dout[..., :T].double()).sum() + (osk * dS[..., :T].double()).sum()).backward()
-
         def close(got, ref, tol, what):
             got = got.detach().cpu().double()
             ref = ref.detach().double()
             assert torch.isfinite(got).all(), what
-            err = (got - ref).abs().max().item()
-            assert err <= tol * (ref.abs().max().item() + 1e-30), "{}: max err {:.3e} vs scale {:.3e}".format(what, err, ref.abs().max().item())
+            diff = (got - ref).abs()
+            err = diff.max().item()
+            where = tuple(int(i) for i in torch.unravel_index(diff.argmax(), diff.shape)) if diff.dim() else ()
+            nbad = int((diff > tol * ref.abs().max()).sum())
+            assert err <= tol * (ref.abs().max().item() + 1e-30), "{}: max err {:.3e} vs scale {:.3e} at {} ({} of {} elements above the bound)".format(
+                what, err, ref.abs().max().item(), where, nbad, diff.numel())
 
         dev = lambda t: to_device(t)
         f32 = dict(device=device_name(), dtype=torch.float32)
@@ -1210,20 +1198,46 @@ def test_tcn_layer_kernel_by_kernel_against_the_oracle(B, Bn, H, Sc, T, d):
         a = dev(nan(B, H, ldt))
         K.pw_gemm(B=B, M=H, K=Bn, T=F, ldt=ldt, A=gW1, A_pk=pk[0], X=X, Y=a, bias=gb1, epi_flags=EPI_STATS_PRELU, epi_alpha=gal1, epi_stats=st[1], eps=eps)
         device_sync()
-        close(a[..., :T], oa, 2e-4, "conv1")
         assert a[..., T:].abs().max().item() == 0.0
         s1 = st[1].cpu().sum(1)
-        sq = (ou1.detach() ** 2).sum((1, 2))
-        assert (s1[:, 1] - sq).abs().max() <= 1e-4 * sq.abs().max()                     # the statistics the epilogue adds up: sum of PReLU(a)^2
-        assert (s1[:, 0] - ou1.detach().sum((1, 2))).abs().max() <= 1e-4 * sq.sqrt().max() * (H * T) ** 0.5
         z = dev(nan(B, H, ldt))
         K.dwconv_fwd(a, st[1], gg1, gbe1, gal1, gwd, gbd, gal2, z, st[2], B, H, F, ldt, d, eps)
         device_sync()
-        close(z[..., :T], oz, 2e-4, "depthwise forward")
         xo, skip = dev(nan(B, Bn, ldt)), dev(nan(B, Sc, ldt))
         K.pw_gemm(B=B, M=Bn + Sc, K=H, T=F, ldt=ldt, A=gWc, A_pk=pk[2], X=z, Y=xo, Y2=skip, m_split=Bn, bias=gbc, accumulate=0, epi_flags=EPI_RESIDUAL,
                   epi_res=X, pro_mode=PRO_GLN_PRELU, pro_stats=st[2], pro_gamma=gg2, pro_beta=gbe2, pro_alpha=gal2, count=cnt, eps=eps)
         device_sync()
+        # ---- the oracle, fp64, with every intermediate kept.  PReLU is not differentiable at 0: where a pre-activation of the device (fp32
+        # products) and of the oracle (fp64) fall on different sides of it -- a handful of the 4 M elements, |value| ~ 1e-6 -- the two slopes
+        # differ by 1 - alpha and the gradients behind that element (three taps, or a whole frame of dx) are O(1) apart with nothing wrong on
+        # either side.  The oracle therefore takes its PReLU BRANCH from the device's pre-activations (checked below to differ from its own
+        # only where the value is within rounding of zero); every value and every other operation is its own.
+        dd = lambda t: t.double().clone().requires_grad_(True)
+        ox = dd(x[..., :T])
+        oW1, ob1, oal1, oal2, og1, obe1, og2, obe2, owd, obd, oWc, obc = (dd(t) for t in (W1, b1, al1, al2, g1, be1, g2, be2, wd, bd, Wcat, bcat))
+        oa = O.pointwise_conv(ox, oW1, ob1)
+        a_dev, z_dev = a[..., :T].cpu().double(), None
+        flip = (a_dev > 0) != (oa.detach() > 0)
+        assert not flip.any() or oa.detach()[flip].abs().max() <= 1e-4 * oa.detach().abs().max()
+        ou1 = torch.where(a_dev > 0, oa, oal1.reshape(()) * oa)
+        assert (ou1.detach() - O.prelu(oa.detach(), oal1.detach())).abs().max() <= 1e-4 * oa.detach().abs().max()
+        ov1 = O.gln(ou1, og1, obe1, eps)
+        oz = O.depthwise_conv(ov1, owd, obd, d)
+        z_dev = z[..., :T].cpu().double()
+        flip = (z_dev > 0) != (oz.detach() > 0)
+        assert not flip.any() or oz.detach()[flip].abs().max() <= 1e-4 * oz.detach().abs().max()
+        ou2 = torch.where(z_dev > 0, oz, oal2.reshape(()) * oz)
+        ov2 = O.gln(ou2, og2, obe2, eps)
+        oo = O.pointwise_conv(ov2, oWc[:Bn].unsqueeze(-1), obc[:Bn]) + ox
+        osk = O.pointwise_conv(ov2, oWc[Bn:].unsqueeze(-1), obc[Bn:])
+        for t in (oa, ov1, oz, ov2):
+            t.retain_grad()
+        ((oo * dout[..., :T].double()).sum() + (osk * dS[..., :T].double()).sum()).backward()
+        close(a[..., :T], oa, 2e-4, "conv1")
+        sq = (ou1.detach() ** 2).sum((1, 2))
+        assert (s1[:, 1] - sq).abs().max() <= 1e-4 * sq.abs().max()                     # the statistics the epilogue adds up: sum of PReLU(a)^2
+        assert (s1[:, 0] - ou1.detach().sum((1, 2))).abs().max() <= 1e-4 * sq.sqrt().max() * (H * T) ** 0.5
+        close(z[..., :T], oz, 2e-4, "depthwise forward")
         close(xo[..., :T], oo, 2e-4, "heads: output + residual")
         close(skip[..., :T], osk, 2e-4, "heads: skip")
         # ---- backward: heads weight gradient + gLN2 sums, heads^T, depthwise backward, conv1^T, conv1 weight gradient ------------------

@@ -51,7 +51,7 @@ CASES = [
     ("test_lstm_sweeps_interleaved_output", [("sixteen",), ("four",)]),
     ("test_chunk_tokens_layout_pair", [(2, 64, 5, 250), (1, 48, 3, 33), (3, 7, 2, 1)]),
     ("test_linear_forward_and_input_gradient", [(1000, 64, 512), (777, 256, 64), (130, 128, 128)]),
-    ("test_tcn_layer_kernel_by_kernel_against_the_oracle", [(1, 128, 128, 128, 300, 2)]),
+    ("test_tcn_layer_kernel_by_kernel_against_the_oracle", [(1, 128, 128, 128, 300, 2), (2, 128, 128, 128, 300, 4)]),
     ("test_linear_weight_gradient", [(32, 20, 64, 512, 0, 7), (9, 31, 128, 512, -1, 3), (9, 31, 128, 512, 1, 5), (3, 7, 64, 64, -1, 1), (5, 250, 256, 64, 0, 40)]),
 ]
 
