@@ -242,13 +242,23 @@ def main():
             os.environ["SEPK_SIDE_STREAM"] = side_prev
         return el
 
-    # SEPK_GRAPH=1 (N = 1): the step is captured once into a hipGraph and replayed.  Measured (profiles/r02d_graph_vs_eager.md): no
-    # faster than the eager two-stream step, so the capture is opt-in.
-    use_graph = world == 1 and not dry and not args.no_graph and os.environ.get("SEPK_GRAPH", "0") == "1"
+    # N = 1: the step (forward + PIT + backward + clip + Adam, one stream) is captured once into a hipGraph and replayed; --no-graph or
+    # SEPK_GRAPH=0 launches eagerly.  Round 2 measured the replay no faster than the eager TWO-stream step of that time
+    # (profiles/r02d_graph_vs_eager.md); with everything on one stream (round 5) it is: 15.70 / 15.73 against 15.89 / 16.00 ms per step at
+    # 16 utterances, 7.2 against 11.7 at 4, where the Python launch wrappers bound the eager step (profiles/r07_round5_experiments.md).
+    # A capture that fails falls back to eager launches and says so in the line.
+    use_graph = world == 1 and not dry and not args.no_graph and os.environ.get("SEPK_GRAPH", "1") == "1" and os.environ.get("SEPK_SIDE_STREAM", "0") != "1"
+    graph_note = None
     done = 0
     if use_graph:
-        loss = step.capture(mixture, sources)
-        done = 4
+        try:
+            loss = step.capture(mixture, sources)
+            done = 4
+        except Exception as e:                               # noqa: BLE001 -- reported in the line, the measurement goes on eagerly
+            graph_note = "eager (hipGraph capture failed: {}: {})".format(type(e).__name__, str(e)[:120])
+            print("bench.py: " + graph_note, file=sys.stderr)
+            use_graph = False
+            step._graph = None
     for _ in range(max(0, args.warmup - done)):
         loss = step(mixture, sources)
     elapsed, loss = timed_steps(args.steps)              # THE timed region: K steps, nothing else in it
@@ -322,7 +332,7 @@ def main():
             "config": {"workload": workload, "global_batch": world * args.batch, "per_gpu_batch": args.batch, "frames_per_utterance": F,
                        "parallelism": "dp{}".format(world), "rccl_ranks": world if backend_name == "nccl" else 0,
                        "utt_per_s": value / F, "samples_per_s": value / F * t_samples, "final_loss": float(loss),
-                       "launch": "hipGraph replay" if use_graph else "eager", "gemm_arith": arith_name},
+                       "launch": "hipGraph replay" if use_graph else (graph_note or "eager"), "gemm_arith": arith_name},
             "step_roofline": {"hbm_frac": value / world * by_frame / (HBM_PEAK_TBS * 1e12),
                               "matrix_pipe_frac": value / world * fl_frame / (pipe / per * 1e12),
                               "matrix_pipe_peak_tflops_equiv": pipe / per,

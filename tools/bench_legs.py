@@ -324,7 +324,7 @@ def measure_pmc_traffic(batch, timeout_s=150):
     if exe is None:
         return None, "rocprofv3 not found"
     res = {}
-    env = dict(os.environ, SEPK_SIDE_STREAM="0", TMPDIR="/tmp")
+    env = dict(os.environ, SEPK_SIDE_STREAM="0", SEPK_GRAPH="0", TMPDIR="/tmp")      # (eager launches: one dispatch record per launch for the counters)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
