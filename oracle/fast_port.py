@@ -91,3 +91,14 @@ def train_step(p, cfg, mixture, sources, dtype=torch.float32):
     loss, pattern = neg_sisdr_pit(out, sources.to(dtype))
     loss.backward()
     return out.detach(), loss.detach(), pattern, {k: v.grad for k, v in pp.items()}
+
+
+def forward_loss(p, cfg, mixture, sources, dtype=torch.float32):
+    """Forward + PIT(NegSI-SDR) only (no autograd tape): (output, loss, permutation) -- for full-batch forward comparisons where the
+    gradients are judged elsewhere (tests/test_gpu_model.py::test_batch16_each_utterance_against_the_oracle)."""
+    with torch.no_grad():
+        q = {k: v.to(dtype) for k, v in p.items()}
+        out, _ = conv_tasnet(mixture.to(dtype), q, cfg)
+        loss, pattern = neg_sisdr_pit(out, sources.to(dtype))
+    return out, loss, pattern
+

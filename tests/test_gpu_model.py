@@ -183,15 +183,11 @@ def test_full_size_properties():
 
 
 def test_batch16_each_utterance_against_the_oracle():
-    """BASELINE configs[1] at its real batch: ONE B=16 forward/backward on the GPU against ONE run of the oracle on the same batch
-    (CPU port, pinned to the live reference at this configuration by tests/test_oracle_vs_reference_cpu.py): every utterance's
-    outputs to 1e-3, its PIT loss and permutation, the batch loss, and every parameter gradient.  The oracle runs in fp32 here
-    (its fp64 run of this batch takes 4.5 minutes of host time on the GPU box, the fp32 one 20 s): its forward is good to 1e-6, its
-    gradients carry the reference's own fp32 noise (2e-4 on the flat vector, up to 2.6e-3 on a PReLU slope), so the
-    gradient gates are fp32-vs-fp32 ones -- flat rel-inf 2e-3, per tensor 1e-2.  The scalar PReLU slopes are judged on the flat
-    vector only: each is a signed sum over 33 M terms, and on this batch the ORACLE's fp32 value of one of them is 8 % away from
-    its own fp64 value (this path: 1.2 %).  The fp64 gradient comparison at this configuration is test_paper_best_against_oracle
-    (B = 1) and the noise-floor gates of the golden cases."""
+    """BASELINE configs[1] at its real batch: ONE B = 16 forward on the GPU against ONE run of the oracle on the same batch (CPU port, pinned
+    to the live reference at this configuration by tests/test_oracle_vs_reference_cpu.py; fp32: its forward is good to 1e-6): every
+    utterance's outputs to 1e-3, its PIT loss and permutation, and the batch loss, on utterances and speakers of different level.  The
+    GRADIENTS of this configuration and batch are judged against the reference itself in fp64 by the fixture test below (round-4 verdict:
+    the fp32-vs-fp32 gradient gates this test used to carry -- 2e-3 flat, 1e-2 per tensor -- added nothing beside it and are gone)."""
     B, T = 16, 32000
     torch.manual_seed(111)
     model = ConvTasNet(**PAPER)
@@ -204,25 +200,18 @@ def test_batch16_each_utterance_against_the_oracle():
     sources = 0.1 * torch.randn(B, 2, T, generator=g) * torch.exp(0.7 * torch.randn(B, 2, 1, generator=g))     # utterances / speakers of different level
     mixture = sources.sum(1, keepdim=True)
     model.cuda()
-    est = model(mixture.cuda())
     crit = PIT1d(NegSISDR(), n_sources=2)
-    loss, pattern = crit(est, sources.cuda())
-    per_utt, _ = crit(est.detach(), sources.cuda(), batch_mean=False)
-    loss.backward()
-    o, l, pat, ref = FP.train_step(p, PAPER, mixture, sources, dtype=torch.float32)
+    with torch.no_grad():
+        est = model(mixture.cuda())
+        loss, pattern = crit(est, sources.cuda())
+        per_utt, _ = crit(est, sources.cuda(), batch_mean=False)
+        o, l, pat = FP.forward_loss(p, PAPER, mixture, sources, dtype=torch.float32)
     assert abs(loss.item() - l.item()) <= TOL * max(abs(l.item()), 1.0)
     assert torch.equal(pattern.cpu(), torch.as_tensor(pat))
     for b in range(B):
-        assert _rel(est[b].detach(), o[b]) <= TOL, b
+        assert _rel(est[b], o[b]) <= TOL, b
         lb, _ = FP.neg_sisdr_pit(o[b:b + 1].double(), sources[b:b + 1].double())
         assert abs(per_utt[b].item() - lb.item()) <= TOL * max(abs(lb.item()), 1.0), b
-    flat_rel, worst = _grad_report(model, ref)
-    assert flat_rel <= 2e-3, "flat gradient rel-inf {:.3e}, worst tensor {}".format(flat_rel, worst)
-    for k, q in model.named_parameters():
-        r = ref[k].double()
-        rel = (q.grad.double().cpu() - r).abs().max().item() / (r.abs().max().item() + 1e-30)
-        if not (k.endswith("nonlinear1d.weight") or k.endswith("prelu.weight")):
-            assert rel <= 1e-2, "{}: {:.3e}".format(k, rel)
 
 
 def test_batch16_against_the_fp64_reference_fixture(golden_dir):
