@@ -656,14 +656,8 @@ def bench_dual_path(args):
         def step():      # noqa: F811
             return fused(mix, src)
         launch = "eager (one launch per kernel), fused clip + Adam"
-        if os.environ.get("SEPK_GRAPH", "1") == "1" and not args.no_graph and os.environ.get("SEPK_SIDE_STREAM", "0") != "1":
-            # the staged sequence is ~1200 launches per step: replayed as one hipGraph like the headline (a failed capture keeps the eager step)
-            try:
-                fused.capture(mix, src)
-                launch = "hipGraph replay, fused clip + Adam"
-            except Exception as e:                               # noqa: BLE001
-                fused._graph = None
-                launch += " (hipGraph capture failed: {}: {})".format(type(e).__name__, str(e)[:100])
+        # (replaying this step as a hipGraph was tried in round 5: the replay of the staged sequence faults -- Memory access fault by GPU node,
+        #  profiles/r07_round5_experiments.md -- so the causal line keeps eager launches)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
