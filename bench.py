@@ -247,7 +247,7 @@ def main():
     # (profiles/r02d_graph_vs_eager.md); with everything on one stream (round 5) it is: 15.70 / 15.73 against 15.89 / 16.00 ms per step at
     # 16 utterances, 7.2 against 11.7 at 4, where the Python launch wrappers bound the eager step (profiles/r07_round5_experiments.md).
     # A capture that fails falls back to eager launches and says so in the line.
-    use_graph = world == 1 and not dry and not args.no_graph and os.environ.get("SEPK_GRAPH", "1") == "1" and os.environ.get("SEPK_SIDE_STREAM", "0") != "1"
+    use_graph = world == 1 and not dry and not args.no_graph and os.environ.get("SEPK_GRAPH", "1") == "1" and os.environ.get("SEPK_SIDE_STREAM", "0") != "1" and bool(getattr(model, "fused", False))
     graph_note = None
     done = 0
     if use_graph:

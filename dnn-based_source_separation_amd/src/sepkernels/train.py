@@ -109,6 +109,11 @@ class FusedTrainStep:
         (which is executed too)."""
         if self.comm:
             raise RuntimeError("graph capture of the train step is single-process only (the gradient all-reduce stays eager)")
+        if not getattr(self.model, "fused", True):
+            # measured (profiles/r07_round5_experiments.md, r07k): the staged causal sequence records, but its replay ends in a GPU memory
+            # access fault -- the layer-by-layer autograd Functions own workspaces the capture does not pin.  Refused instead of offered.
+            raise RuntimeError("graph capture is offered for the fused kernel sequence only; this model runs the {} path".format(
+                "derived-basis" if getattr(self.model, "fused_derived", False) else "staged" if getattr(self.model, "staged", False) else "composed"))
         dev = self.flat.device
         self._static = (torch.empty_like(mixture), torch.empty_like(sources))
         self._static[0].copy_(mixture)
