@@ -253,7 +253,7 @@ def test_gemm_dgrad_two_sources_rowsums(arith):
     both("pw_gemm", [], kw)
 
 
-@pytest.mark.parametrize("H,T", [(512, 700), (256, 130)])
+@pytest.mark.parametrize("H,T", [(512, 700), (256, 130), (512, 1000)])      # the last: heads^T on the persistent producer / consumer kernel (packed weights)
 def test_gemm_dgrad_two_sources_plain(H, T, arith):
     """dv2 = Wo^T dout + Ws^T dS with a plain epilogue: the heads^T product of the step since its gLN sums come from the weight gradient
     (H = 512: the 128-row-per-wave form of the cooperative kernel when SEPK_COOP_MI=4)"""
