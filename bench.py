@@ -242,18 +242,19 @@ def main():
             os.environ["SEPK_SIDE_STREAM"] = side_prev
         return el
 
-    # N = 1: the step (forward + PIT + backward + clip + Adam, one stream) is captured once into a hipGraph and replayed; --no-graph or
-    # SEPK_GRAPH=0 launches eagerly.  Round 2 measured the replay no faster than the eager TWO-stream step of that time
-    # (profiles/r02d_graph_vs_eager.md); with everything on one stream (round 5) it is: 15.70 / 15.73 against 15.89 / 16.00 ms per step at
-    # 16 utterances, 7.2 against 11.7 at 4, where the Python launch wrappers bound the eager step (profiles/r07_round5_experiments.md).
-    # A capture that fails falls back to eager launches and says so in the line.
-    use_graph = world == 1 and not dry and not args.no_graph and os.environ.get("SEPK_GRAPH", "1") == "1" and os.environ.get("SEPK_SIDE_STREAM", "0") != "1" and bool(getattr(model, "fused", False))
+    # SEPK_GRAPH=1 (N = 1, opt-in): the step (forward + PIT + backward + clip + Adam, one stream) captured once into a hipGraph and replayed.
+    # NOT the default: replays of this full-size step are 0.0 - 0.3 ms faster than eager launches (15.70 vs 15.89 ms on one box, 15.73 vs
+    # 15.77 on another) but END WITH WRONG LOSSES in about half the runs on this stack (inf / 49.98 instead of 0.0812 in 5 of 10 runs, twice:
+    # profiles/r07_round5_experiments.md, r07m) -- a replay hazard the small-configuration test of FusedTrainStep.capture does not show.
+    # A number from a step that does not train is not a measurement.
+    use_graph = world == 1 and not dry and not args.no_graph and os.environ.get("SEPK_GRAPH", "0") == "1" and os.environ.get("SEPK_SIDE_STREAM", "0") != "1" and bool(getattr(model, "fused", False))
     graph_note = None
     done = 0
     if use_graph:
         try:
-            loss = step.capture(mixture, sources)
-            done = 4
+            w = max(1, args.warmup - 1)                      # w eager steps + the recorded one (which is executed too) = the W warm-up steps
+            loss = step.capture(mixture, sources, warmup=w)
+            done = w + 1
         except Exception as e:                               # noqa: BLE001 -- reported in the line, the measurement goes on eagerly
             graph_note = "eager (hipGraph capture failed: {}: {})".format(type(e).__name__, str(e)[:120])
             print("bench.py: " + graph_note, file=sys.stderr)
@@ -263,6 +264,7 @@ def main():
         loss = step(mixture, sources)
     elapsed, loss = timed_steps(args.steps)              # THE timed region: K steps, nothing else in it
     my_elapsed = elapsed
+    final_loss = float(loss)                             # NOW: a replayed step returns a tensor of the graph's pool, which a later re-capture (fp32 pass) recycles
 
     arith_name = sepkernels.gemm_arith_name()
     by_kernel = roof_g = roof_w = None
@@ -331,7 +333,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "global_batch": world * args.batch, "per_gpu_batch": args.batch, "frames_per_utterance": F,
                        "parallelism": "dp{}".format(world), "rccl_ranks": world if backend_name == "nccl" else 0,
-                       "utt_per_s": value / F, "samples_per_s": value / F * t_samples, "final_loss": float(loss),
+                       "utt_per_s": value / F, "samples_per_s": value / F * t_samples, "final_loss": final_loss,
                        "launch": "hipGraph replay" if use_graph else (graph_note or "eager"), "gemm_arith": arith_name},
             "step_roofline": {"hbm_frac": value / world * by_frame / (HBM_PEAK_TBS * 1e12),
                               "matrix_pipe_frac": value / world * fl_frame / (pipe / per * 1e12),
