@@ -109,7 +109,8 @@ class FusedTrainStep:
         (which is executed too).
         EXPERIMENTAL on this stack (ROCm 7.0 / torch 2.10): the replayed step equals the eager one on the small configurations of the
         tests, but replays of the paper-best step at 16 utterances ended with wrong losses (inf, 49.98 for 0.0812) in about half of 20 runs
-        (profiles/r07_round5_experiments.md, r07m); the eager step is the product's step, and bench.py's default."""
+        (profiles/r07_round5_experiments.md, r07m) -- the runtime's pre-built graph packets: with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 every replay is
+        right to the last bit and no faster than eager launches (r07o).  The eager step is the product's step, and bench.py's default."""
         if self.comm:
             raise RuntimeError("graph capture of the train step is single-process only (the gradient all-reduce stays eager)")
         if not getattr(self.model, "fused", True):
