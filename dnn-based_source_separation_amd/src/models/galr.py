@@ -76,12 +76,11 @@ class GloballyAttentiveBlockBase(nn.Module):
         (sep_chunk_to_tokens), the channel norm on the rows as they are, the attention batch-first with its projections on csrc/linear.hip and its core on csrc/attn.hip,
         gLN over a sample's (Q, S, C) block on sep_gln_tokens_*, back (sep_tokens_to_chunk): two tiled transposes instead of six strided
         copies per block and direction."""
-        from sepkernels.functional import attention_core, ChunkToTokensFn, TokensToChunkFn, TokenGLNFn, dense_apply
+        from sepkernels.functional import attention_core, ChunkToTokensFn, TokensToChunkFn, TokenGLNFn, dense_apply, residual_layer_norm
         B, C, S, Q = x.size()
         t = ChunkToTokensFn.apply(x, True)                                       # (B*Q, S, C)
         if self.norm:
-            ln = self.norm2d_in.norm
-            t = torch.nn.functional.layer_norm(t, (C,), ln.weight, ln.bias, ln.eps)
+            t = residual_layer_norm(t, None, self.norm2d_in.norm)                 # the channel norm on sep_rownorm_*
         seq = (t.view(B, Q, S, C) + self._position_code(S, Q, C, x, tokens=True)).view(B * Q, S, C)
         mha = self.multihead_attn
         h = mha.num_heads

@@ -172,7 +172,7 @@ class _ChunkPathEncoder(nn.Module):
         (N, L, C): the four dense layers on csrc/linear.hip -- hipBLASLt's picks for these fp32 shapes (32 K tokens x 256 x 1024) run at a
         third of the fp32 MFMA rate, profiles/r05zc_sepformer_kernel_stats.md --, the core on csrc/attn.hip (sep_attn_*) with the layer's
         attention dropout."""
-        from sepkernels.functional import attention_core, dense_apply
+        from sepkernels.functional import attention_core, dense_apply, relu_dropout, residual_layer_norm
         sa = layer.self_attn
         N, L, C = x.shape
         h = sa.num_heads
@@ -180,22 +180,24 @@ class _ChunkPathEncoder(nn.Module):
         def attend(u):
             qkv = dense_apply(u, sa.in_proj_weight, sa.in_proj_bias).view(N, L, 3, h, C // h)
             o = attention_core(qkv, sa.dropout if layer.training else 0.0)
-            return layer.dropout1(dense_apply(o, sa.out_proj.weight, sa.out_proj.bias))
+            return dense_apply(o, sa.out_proj.weight, sa.out_proj.bias)
 
         def feed(u):
             if _ff_on_conv_kernels(layer, u):
-                return layer.dropout2(_feed_forward_channel_major(layer, u))
-            f = layer.dropout(layer.activation(dense_apply(u, layer.linear1.weight, layer.linear1.bias)))
-            return layer.dropout2(dense_apply(f, layer.linear2.weight, layer.linear2.bias))
+                return _feed_forward_channel_major(layer, u)
+            f = dense_apply(u, layer.linear1.weight, layer.linear1.bias)
+            f = relu_dropout(f, rate(layer.dropout)) if layer.activation is F.relu else layer.dropout(layer.activation(f))
+            return dense_apply(f, layer.linear2.weight, layer.linear2.bias)
 
-        def ln(norm, u):
-            return F.layer_norm(u, (C,), norm.weight, norm.bias, norm.eps)
+        def rate(drop):
+            return drop.p if layer.training else 0.0
 
         if layer.norm_first:
-            x = x + attend(ln(layer.norm1, x))
-            return x + feed(ln(layer.norm2, x))
-        x = ln(layer.norm1, x + attend(x))
-        return ln(layer.norm2, x + feed(x))
+            x = x + layer.dropout1(attend(residual_layer_norm(x, None, layer.norm1)))
+            return x + layer.dropout2(feed(residual_layer_norm(x, None, layer.norm2)))
+        # post-norm (the reference's layers): dropout of the branch, residual sum and layer norm in one pass each way (sep_rownorm_*)
+        x = residual_layer_norm(x, attend(x), layer.norm1, rate(layer.dropout1))
+        return residual_layer_norm(x, feed(x), layer.norm2, rate(layer.dropout2))
 
     def _forward_tokens(self, input):
         """forward with the features innermost: one tiled transpose in (sep_chunk_to_tokens), the stack on (sequences, steps, C) rows, the
@@ -246,7 +248,7 @@ def _feed_forward_channel_major(layer, u):
     (210 + 241 us forward, 444 + 353 backward), its two-part fp16 form is load-bound at the 128 x 128 tile
     (profiles/r05zy_linear16_experiment.md), the convolution kernels' 256-row tiles are not -- at the price of two tiled transposes (34 MB
     each) around the pair.  ReLU without dropout rides the second product's prologue (PReLU with slope 0)."""
-    from sepkernels.functional import ChunkToTokensFn, TokensToChunkFn, PaddedPointwiseFn
+    from sepkernels.functional import ChunkToTokensFn, TokensToChunkFn, PaddedPointwiseFn, relu_dropout
     from sepkernels import net as _net
     N, L, C = u.shape
     ntok = N * L
@@ -259,6 +261,8 @@ def _feed_forward_channel_major(layer, u):
     drop = layer.training and layer.dropout.p > 0
     if layer.activation is F.relu and not drop:
         y = PaddedPointwiseFn.apply(h, ntok, w2, layer.linear2.bias, u.new_zeros(1), wa)
+    elif layer.activation is F.relu:
+        y = PaddedPointwiseFn.apply(relu_dropout(h, layer.dropout.p), ntok, w2, layer.linear2.bias, None, wa)     # one pass each way: sep_relu_drop_*
     else:
         y = PaddedPointwiseFn.apply(layer.dropout(layer.activation(h)), ntok, w2, layer.linear2.bias, None, wa)
     return ChunkToTokensFn.apply(y.view(1, C, 1, ldt), False).view(ldt, C)[:ntok].view(N, L, C)

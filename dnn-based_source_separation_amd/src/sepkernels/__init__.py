@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("SEPKERNELS_LIB", os.path.normpath(os.path.join(_HERE,
 # ---- constants mirrored from include/sepkernels.h -------------------------------------------------
 PRO_NONE, PRO_PRELU, PRO_GLN, PRO_GLN_PRELU, PRO_GLN_BWD = 0, 1, 2, 3, 4
 EPI_STATS_PRELU, EPI_RESIDUAL, EPI_SIGMOID, EPI_PRELU_BWD, EPI_ROWSUMS, EPI_ROWSUMS_PRELU = 1, 2, 4, 8, 16, 32
-ABI_VERSION = 21
+ABI_VERSION = 22
 LSTM_INTERLEAVED = 0x400       # sep_lstm_fwd / sep_lstm_bwd with reverse = 2: h_out / dh_out as one (nseq, L, 2H) buffer
 STATS_SLOTS = 16   # SEP_STATS_SLOTS: gLN statistics are double[B][STATS_SLOTS][2]
 ARRIVE_INTS = 17   # SEP_ARRIVE_INTS: arrival counters of the gLN-backward publishers, int[B][ARRIVE_INTS]
@@ -136,6 +136,11 @@ SIGNATURES = {
     "sep_gln_tokens_ws_bytes": [_I] * 3,                             # returns size_t
     "sep_gln_tokens_fwd": [_vp] * 6 + [_I] * 3 + [_F, _vp],
     "sep_gln_tokens_bwd": [_vp] * 7 + [_I] * 3 + [_vp],
+    "sep_rownorm_parts": [_L, _I],
+    "sep_rownorm_fwd": [_vp] * 7 + [_L, _I, _F, _F, ctypes.c_ulonglong, _vp],
+    "sep_rownorm_bwd": [_vp] * 7 + [_L, _I, _F, ctypes.c_ulonglong, _vp],
+    "sep_relu_drop_fwd": [_vp, _vp, _L, _F, ctypes.c_ulonglong, _vp],
+    "sep_relu_drop_bwd": [_vp, _vp, _vp, _L, _F, _vp],
     "sep_gln_stats": [_vp, _vp, _I, _I, _I, _I, _vp],
     "sep_gln_apply": [_vp] * 5 + [_I] * 4 + [_D, _F, _vp],
     "sep_gln_bwd_rowsums": [_vp, _vp, _vp, _I, _I, _I, _I, _vp],
@@ -379,6 +384,23 @@ class HipBackend:
     def attn_bwd(self, qkv, o, dout, lse, delta, dqkv, N, L, H, D, scale, p_drop=0.0, seed=0):
         _check(load().sep_attn_bwd(_ptr(qkv, _f32), _ptr(o, _f32), _ptr(dout, _f32), _ptr(lse, _f32), _ptr(delta, _f32), _ptr(dqkv, _f32), N, L, H, D,
                                    scale, p_drop, seed, _stream()), "sep_attn_bwd")
+
+    def rownorm_parts(self, rows, C):
+        return int(load().sep_rownorm_parts(rows, C))
+
+    def rownorm_fwd(self, x, res, gamma, beta, s, y, stat, rows, C, eps, p_drop=0.0, seed=0):
+        _check(load().sep_rownorm_fwd(_ptr(x, _f32), _ptr(res, _f32), _ptr(gamma, _f32), _ptr(beta, _f32), _ptr(s, _f32), _ptr(y, _f32), _ptr(stat, _f32),
+                                      rows, C, eps, p_drop, seed, _stream()), "sep_rownorm_fwd")
+
+    def rownorm_bwd(self, dy, s, gamma, stat, ds, dres, part, rows, C, p_drop=0.0, seed=0):
+        _check(load().sep_rownorm_bwd(_ptr(dy, _f32), _ptr(s, _f32), _ptr(gamma, _f32), _ptr(stat, _f32), _ptr(ds, _f32), _ptr(dres, _f32), _ptr(part, _f32),
+                                      rows, C, p_drop, seed, _stream()), "sep_rownorm_bwd")
+
+    def relu_drop_fwd(self, h, a, n, p_drop=0.0, seed=0):
+        _check(load().sep_relu_drop_fwd(_ptr(h, _f32), _ptr(a, _f32), n, p_drop, seed, _stream()), "sep_relu_drop_fwd")
+
+    def relu_drop_bwd(self, dy, a, dh, n, p_drop=0.0):
+        _check(load().sep_relu_drop_bwd(_ptr(dy, _f32), _ptr(a, _f32), _ptr(dh, _f32), n, p_drop, _stream()), "sep_relu_drop_bwd")
 
     def gln_tokens_ws_bytes(self, nseq, L, C):
         return int(load().sep_gln_tokens_ws_bytes(nseq, L, C))

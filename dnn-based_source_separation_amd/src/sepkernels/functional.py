@@ -759,15 +759,7 @@ class AttnCoreFn(torch.autograd.Function):
         N, L, three, H, D = qkv.shape
         o = torch.empty(N, L, H, D, device=qkv.device, dtype=qkv.dtype)
         lse = torch.empty(N, H, L, device=qkv.device, dtype=qkv.dtype)
-        seed = 0
-        if p_drop > 0:
-            if qkv.is_cuda and torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("attention dropout takes its seed on the host: a captured step would replay ONE mask (use p = 0 or launch eagerly)")
-            # the CPU generator (torch.manual_seed reaches it, no device sync), with the rank and the device folded in: data-parallel ranks
-            # seeded alike must not drop the same elements
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-            rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
-            seed = (seed ^ (0x9E3779B97F4A7C15 * (1 + rank + 1024 * (qkv.device.index or 0)))) & (2 ** 62 - 1)
+        seed = _dropout_seed(qkv) if p_drop > 0 else 0
         scale = float(D) ** -0.5
         K.attn_fwd(qkv, o, lse, N, L, H, D, scale, float(p_drop), seed)
         ctx.save_for_backward(qkv, o, lse)
@@ -827,6 +819,99 @@ class TokenGLNFn(torch.autograd.Function):
         K.gln_tokens_bwd(dy.contiguous(), x, gamma, stats, dx, part, nseq, L, C, ws=_gln_tokens_ws(K, nseq, L, C, x.device))
         tot = part.sum(0)
         return dx, tot[0], tot[1], None
+
+
+def _dropout_seed(t):
+    """a 62-bit seed for a hash-masked dropout (sep_attn_*, sep_rownorm_*): drawn on the host from the CPU generator (torch.manual_seed
+    reaches it, no device sync), with the rank and the device folded in -- data-parallel ranks seeded alike must not drop the same elements"""
+    if t.is_cuda and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("this dropout takes its seed on the host: a captured step would replay ONE mask (use p = 0 or launch eagerly)")
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+    return (seed ^ (0x9E3779B97F4A7C15 * (1 + rank + 1024 * (t.device.index or 0)))) & (2 ** 62 - 1)
+
+
+class RowNormFn(torch.autograd.Function):
+    """y = LayerNorm_C(x + dropout(res)) on token-major rows (..., C): the tail of both sub-blocks of a post-norm nn.TransformerEncoderLayer
+    (torch/nn/modules/transformer.py `norm1(x + _sa_block(x))`, `norm2(x + _ff_block(x))`; reference models/sepformer.py:395-520), one pass each
+    way on sep_rownorm_fwd / bwd instead of dropout, add, layer norm and their three backward kernels.  res None: y = LayerNorm_C(x)
+    (GALRNet's channel norm, models/galr.py:172-190).  The dropout mask is a hash of (seed, element), formed again in the backward pass."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps, p_drop):
+        K = backend()
+        x = x.contiguous()
+        C = x.shape[-1]
+        rows = x.numel() // C
+        if res is not None:
+            res = res.contiguous()
+        p_drop = float(p_drop) if res is not None else 0.0
+        seed = _dropout_seed(x) if p_drop > 0 else 0
+        s = torch.empty_like(x) if res is not None else None
+        y = torch.empty_like(x)
+        stat = torch.empty(rows, 2, device=x.device, dtype=x.dtype)
+        K.rownorm_fwd(x, res, gamma, beta, s, y, stat, rows, C, float(eps), p_drop, seed)
+        ctx.save_for_backward(x if s is None else s, gamma, stat)
+        ctx.meta = (rows, C, p_drop, seed, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        K = backend()
+        s, gamma, stat = ctx.saved_tensors
+        rows, C, p_drop, seed, has_res = ctx.meta
+        ds = torch.empty_like(s)
+        dres = torch.empty_like(s) if p_drop > 0 else None
+        part = torch.empty(K.rownorm_parts(rows, C), 2, C, device=s.device, dtype=s.dtype)
+        K.rownorm_bwd(dy.contiguous(), s, gamma, stat, ds, dres, part, rows, C, p_drop, seed)
+        tot = part.sum(0)
+        return ds, ((dres if dres is not None else ds) if has_res else None), tot[0], tot[1], None, None
+
+
+def rownorm_ok(x, norm):
+    """can `norm` (an nn.LayerNorm over the last axis, with gain and shift) run on sep_rownorm_* for rows x (..., C)?"""
+    C = x.shape[-1]
+    return (isinstance(norm, torch.nn.LayerNorm) and tuple(norm.normalized_shape) == (C,) and norm.weight is not None and norm.bias is not None
+            and C % 4 == 0 and 4 <= C <= 1024 and x.numel() > 0 and takes(x))
+
+
+def residual_layer_norm(x, res, norm, p_drop=0.0):
+    """norm(x + dropout(res, p_drop)) (res None: norm(x)): sep_rownorm_* where it applies, torch's kernels otherwise"""
+    if rownorm_ok(x, norm) and (res is None or (res.shape == x.shape and res.dtype == x.dtype)):
+        return RowNormFn.apply(x, res, norm.weight, norm.bias, norm.eps, p_drop)
+    if res is not None:
+        x = x + torch.nn.functional.dropout(res, p_drop, training=p_drop > 0)
+    return torch.nn.functional.layer_norm(x, norm.normalized_shape, norm.weight, norm.bias, norm.eps)
+
+
+class ReluDropFn(torch.autograd.Function):
+    """dropout(relu(h), p) between the two Linear layers of a transformer layer's feed-forward sub-block: one pass each way on sep_relu_drop_*
+    instead of four torch kernels; the backward pass reads the mask off the forward's output (zero exactly where the gradient is)."""
+
+    @staticmethod
+    def forward(ctx, h, p_drop):
+        K = backend()
+        h = h.contiguous()
+        a = torch.empty_like(h)
+        K.relu_drop_fwd(h, a, h.numel(), float(p_drop), _dropout_seed(h) if p_drop > 0 else 0)
+        ctx.save_for_backward(a)
+        ctx.p_drop = float(p_drop)
+        return a
+
+    @staticmethod
+    def backward(ctx, dy):
+        K = backend()
+        a, = ctx.saved_tensors
+        dh = torch.empty_like(a)
+        K.relu_drop_bwd(dy.contiguous(), a, dh, a.numel(), ctx.p_drop)
+        return dh, None
+
+
+def relu_dropout(h, p_drop):
+    """dropout(relu(h), p_drop) -- sep_relu_drop_* where they apply (p_drop = 0: a plain ReLU)"""
+    if takes(h) and h.numel() > 0 and h.numel() % 4 == 0 and 0 <= p_drop < 1:
+        return ReluDropFn.apply(h, p_drop)
+    return torch.nn.functional.dropout(torch.relu(h), p_drop, training=p_drop > 0)
 
 
 def token_gln_ok(x, norm1d):

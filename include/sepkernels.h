@@ -33,7 +33,7 @@ extern "C" {
 
 typedef void* sep_stream_t; /* hipStream_t */
 
-#define SEP_ABI_VERSION 21
+#define SEP_ABI_VERSION 22
 #define SEP_STATS_SLOTS 16
 #define SEP_ARRIVE_INTS 17 /* arrival counters per sample: one per slot + one for the slots (csrc/common.hpp, gln_bwd_publish) */
 
@@ -338,6 +338,28 @@ int sep_attn_fwd(const float* qkv, float* o, float* lse, int N, int L, int H, in
                  sep_stream_t stream);
 int sep_attn_bwd(const float* qkv, const float* o, const float* dout, const float* lse, float* delta, float* dqkv, int N, int L, int H, int D,
                  float scale, float p_drop, unsigned long long seed, sep_stream_t stream);
+
+/* Layer norm over the features of token-major rows with the residual sum in front of it (ABI 22): nn.LayerNorm(C) as the post-norm
+ * nn.TransformerEncoderLayer of SepFormer applies it (reference models/sepformer.py:395-520: `norm1(x + dropout1(self_attention(x)))`,
+ * `norm2(x + dropout2(feed_forward(x)))`) and GALRNet's channel norm (models/galr.py:172-190 LayerNormAlongChannel), one pass each way.
+ *   forward : s = x + drop(res) ; y = (s - mu) rstd gamma + beta with mu / biased variance of the row's C values, eps inside the root
+ *   backward: ds = the gradient at s (it is the gradient at x AND at drop(res)) ; dres = the gradient at res
+ * x, res, s, y, dy, ds, dres: (rows, C) fp32, features contiguous, C a multiple of 4 and <= 1024.  res and s come together (both NULL: y = LN(x),
+ * and the backward is given x as s).  stat (rows, 2) = {mu, rstd}, written forward, read backward.  p_drop: rate of the inverted dropout on
+ * res (0: none; then dres must be NULL -- ds serves both); the mask is a function of (seed, element index), the hash of sep_attn_*, so the
+ * backward must be given the forward's seed.  part: (sep_rownorm_parts(rows, C), 2, C) = {sum dy * xhat | sum dy} over each workgroup's rows:
+ * summed over the slabs they are d(gamma), d(beta). */
+int sep_rownorm_parts(long rows, int C);
+int sep_rownorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* s, float* y, float* stat, long rows, int C,
+                    float eps, float p_drop, unsigned long long seed, sep_stream_t stream);
+int sep_rownorm_bwd(const float* dy, const float* s, const float* gamma, const float* stat, float* ds, float* dres, float* part, long rows, int C,
+                    float p_drop, unsigned long long seed, sep_stream_t stream);
+
+/* ReLU + inverted dropout between the two Linear layers of the transformer layers' feed-forward sub-block (ABI 22; torch/nn/modules/
+ * transformer.py _ff_block as models/sepformer.py:395-520 instantiates it): a = keep ? max(h, 0) / (1 - p) : 0 with the mask of sep_rownorm_*
+ * (hash of (seed, element index)); backward dh = a != 0 ? dy / (1 - p) : 0 -- from the forward's OUTPUT, no mask, no seed.  n a multiple of 4. */
+int sep_relu_drop_fwd(const float* h, float* a, long n, float p_drop, unsigned long long seed, sep_stream_t stream);
+int sep_relu_drop_bwd(const float* dy, const float* a, float* dh, long n, float p_drop, sep_stream_t stream);
 
 /* Stand-alone gLN (modules/norm.py:11-35) for callers outside the fused network. */
 int sep_gln_stats(const float* x, double* stats, int B, int C, int T, int ldt, sep_stream_t stream);

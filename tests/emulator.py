@@ -514,6 +514,76 @@ class EmuBackend:
         p[:, 0] = (g * xh).sum(1)
         p[:, 1] = g.sum(1)
 
+    # ------------------------------------------------------------------ residual sum + layer norm over the features of rows (csrc/rownorm.hip)
+    @staticmethod
+    def _rownorm_keep(n, p_drop, seed):
+        """the dropout decision of csrc/rownorm.hip: the hash of csrc/attn.hip on the flat element index"""
+        if not p_drop > 0:
+            return None, 1.0
+        M = 0xFFFFFFFF
+        thr = max(1, min(int(p_drop * 4294967296.0), M))
+        s0, s1 = seed & M, (seed >> 32) & M
+        idx = torch.arange(n)
+        x = (idx & M) ^ s0
+        x = (x * 0x9E3779B1) & M
+        x = x ^ (x >> 15)
+        x = (x * 0x85EBCA6B) & M
+        x = x ^ (x >> 13)
+        x = (x + s1 + (((idx >> 32) & M) * 0x9E3779B1)) & M
+        x = (x * 0xC2B2AE35) & M
+        x = x ^ (x >> 16)
+        return x >= thr, 1.0 / (1.0 - p_drop)
+
+    def rownorm_parts(self, rows, C):
+        return min((rows + 3) // 4, 2048)
+
+    def rownorm_fwd(self, x, res, gamma, beta, s, y, stat, rows, C, eps, p_drop=0.0, seed=0):
+        assert (res is None) == (s is None) and (p_drop == 0 or res is not None)
+        v = x.reshape(rows, C)
+        if res is not None:
+            q = res.reshape(rows, C)
+            keep, kinv = self._rownorm_keep(rows * C, p_drop, seed)
+            if keep is not None:
+                q = torch.where(keep.view(rows, C).to(q.device), q * kinv, torch.zeros_like(q))
+            v = v + q
+            s.reshape(rows, C).copy_(v)
+        d = v.double()
+        m = d.mean(1, keepdim=True)
+        r = 1.0 / torch.sqrt(((d - m) ** 2).mean(1, keepdim=True) + eps)
+        st = stat.reshape(rows, 2)
+        st[:, 0] = m[:, 0].to(st.dtype)
+        st[:, 1] = r[:, 0].to(st.dtype)
+        y.reshape(rows, C).copy_((v - st[:, :1]) * st[:, 1:] * gamma.view(1, C) + beta.view(1, C))
+
+    def rownorm_bwd(self, dy, s, gamma, stat, ds, dres, part, rows, C, p_drop=0.0, seed=0):
+        assert (p_drop > 0) == (dres is not None)
+        st = stat.reshape(rows, 2)
+        g = dy.reshape(rows, C)
+        xh = (s.reshape(rows, C) - st[:, :1]) * st[:, 1:]
+        gg = g * gamma.view(1, C)
+        m1, m2 = gg.double().mean(1, keepdim=True).to(g.dtype), (gg * xh).double().mean(1, keepdim=True).to(g.dtype)
+        o = st[:, 1:] * (gg - m1 - xh * m2)
+        ds.reshape(rows, C).copy_(o)
+        if dres is not None:
+            keep, kinv = self._rownorm_keep(rows * C, p_drop, seed)
+            dres.reshape(rows, C).copy_(torch.where(keep.view(rows, C).to(o.device), o * kinv, torch.zeros_like(o)))
+        # the slabs as the kernel cuts them: workgroup w takes rows 4 w + wave + 4 nparts k
+        nparts = self.rownorm_parts(rows, C)
+        p = part.reshape(nparts, 2, C)
+        p.zero_()
+        owner = (torch.arange(rows) // 4) % nparts
+        p[:, 0].index_add_(0, owner.to(p.device), g * xh)
+        p[:, 1].index_add_(0, owner.to(p.device), g)
+
+    def relu_drop_fwd(self, h, a, n, p_drop=0.0, seed=0):
+        keep, kinv = self._rownorm_keep(n, p_drop, seed)
+        v = torch.clamp(h.reshape(n), min=0)
+        a.reshape(n).copy_(v if keep is None else torch.where(keep.to(v.device), v * kinv, torch.zeros_like(v)))
+
+    def relu_drop_bwd(self, dy, a, dh, n, p_drop=0.0):
+        g = dy.reshape(n)
+        dh.reshape(n).copy_(torch.where(a.reshape(n) != 0, g * (1.0 / (1.0 - p_drop)), torch.zeros_like(g)))
+
     # ------------------------------------------------------------------ stand-alone gLN
     def gln_stats(self, x, stats, B, C, T, ldt):
         v = x.reshape(B, C, ldt)[:, :, :T]

@@ -30,9 +30,9 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(lib, n), "{} declared in sepkernels.h but not exported".format(n)
         assert n in sepkernels.SIGNATURES, "{} has no ctypes signature".format(n)
     assert sorted(sepkernels.SIGNATURES) == names
-    assert lib.sep_version() == sepkernels.ABI_VERSION == 21
+    assert lib.sep_version() == sepkernels.ABI_VERSION == 22
     header = open(HEADER).read()
-    assert "#define SEP_ABI_VERSION 21" in header and "#define SEP_STATS_SLOTS 16" in header
+    assert "#define SEP_ABI_VERSION 22" in header and "#define SEP_STATS_SLOTS 16" in header
     assert sepkernels.STATS_SLOTS == 16
 
 

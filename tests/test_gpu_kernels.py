@@ -972,6 +972,87 @@ def test_gln_tokens_fwd_bwd(nseq, L, C):
     assert (pe - part.cpu()).abs().max() <= 5e-5 * pe.abs().max()
 
 
+@pytest.mark.parametrize("rows,C,with_res,p_drop", [(1000, 256, True, 0.0), (33, 256, True, 0.1), (517, 64, False, 0.0), (9, 1024, True, 0.5),
+                                                    (130, 300, True, 0.25), (5, 4, True, 0.0), (9000, 128, True, 0.1)])
+def test_rownorm_fwd_bwd(rows, C, with_res, p_drop):
+    """sep_rownorm_fwd / bwd: LayerNorm_C(x + dropout(res)) on token-major rows against nn.functional.layer_norm in float64 (what the
+    reference's nn.TransformerEncoderLayer computes: sepformer.py:395-520, `norm1(x + dropout1(...))`), the dropout mask taken from the
+    kernel's own hash (tests/emulator.py::_rownorm_keep); then the emulator call by call."""
+    torch.manual_seed(rows + C)
+    seed = 0x1234567 * (rows + 1) + (C << 40)
+    x = torch.randn(rows, C) * 1.7 + 0.3
+    res = torch.randn(rows, C) * 0.8 if with_res else None
+    gamma, beta, dy = torch.randn(C) + 1, torch.randn(C), torch.randn(rows, C)
+    eps = 1e-5
+    x64 = x.double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    s64 = x64
+    if with_res:
+        r64 = res.double().requires_grad_(True)
+        keep, kinv = EMU._rownorm_keep(rows * C, p_drop, seed)
+        # (the kernel scales in fp32: res * fp32(1 / (1 - p)))
+        s64 = x64 + (r64 if keep is None else torch.where(keep.view(rows, C), r64 * float(torch.tensor(kinv, dtype=torch.float32)), torch.zeros_like(r64)))
+        if keep is not None and rows * C >= 4096:
+            assert abs(keep.double().mean().item() - (1 - p_drop)) < 0.03
+    y64 = torch.nn.functional.layer_norm(s64, (C,), g64, b64, eps)
+    (y64 * dy.double()).sum().backward()
+    f32 = dict(device=device_name(), dtype=torch.float32)
+    nparts = HIP.rownorm_parts(rows, C)
+    assert nparts == EMU.rownorm_parts(rows, C)
+    y, stat = torch.full((rows, C), float("nan"), **f32), torch.full((rows, 2), float("nan"), **f32)
+    s = torch.full((rows, C), float("nan"), **f32) if with_res else None
+    HIP.rownorm_fwd(to_device(x), to_device(res) if with_res else None, to_device(gamma), to_device(beta), s, y, stat, rows, C, eps, p_drop, seed)
+    ds, part = torch.full((rows, C), float("nan"), **f32), torch.full((nparts, 2, C), float("nan"), **f32)
+    dres = torch.full((rows, C), float("nan"), **f32) if p_drop > 0 else None
+    HIP.rownorm_bwd(to_device(dy), s if with_res else to_device(x), to_device(gamma), stat, ds, dres, part, rows, C, p_drop, seed)
+    device_sync()
+    assert (y.cpu().double() - y64.detach()).abs().max() <= 2e-5 * y64.detach().abs().max()
+    assert (ds.cpu().double() - x64.grad).abs().max() <= 5e-5 * x64.grad.abs().max()
+    if with_res:
+        assert (s.cpu().double() - s64.detach()).abs().max() <= 1e-6 * s64.detach().abs().max()
+        got = dres if p_drop > 0 else ds
+        assert (got.cpu().double() - r64.grad).abs().max() <= 5e-5 * r64.grad.abs().max()
+    assert (part.cpu().double()[:, 0].sum(0) - g64.grad).abs().max() <= 5e-5 * max(g64.grad.abs().max().item(), rows ** 0.5)
+    assert (part.cpu().double()[:, 1].sum(0) - b64.grad).abs().max() <= 5e-5 * max(b64.grad.abs().max().item(), rows ** 0.5)
+    ye, se, sse = torch.empty(rows, C), torch.empty(rows, 2), (torch.empty(rows, C) if with_res else None)
+    EMU.rownorm_fwd(x, res, gamma, beta, sse, ye, se, rows, C, eps, p_drop, seed)
+    dse, pe, dre = torch.empty(rows, C), torch.empty(nparts, 2, C), (torch.empty(rows, C) if p_drop > 0 else None)
+    EMU.rownorm_bwd(dy, sse if with_res else x, gamma, se, dse, dre, pe, rows, C, p_drop, seed)
+    assert (ye - y.cpu()).abs().max() <= 2e-5 * ye.abs().max() and (dse - ds.cpu()).abs().max() <= 5e-5 * dse.abs().max()
+    assert (se - stat.cpu()).abs().max() <= 2e-5 * se.abs().max()
+    assert (pe - part.cpu()).abs().max() <= 5e-5 * max(pe.abs().max().item(), 1.0)
+    if p_drop > 0:
+        assert torch.equal(dre == 0, dres.cpu() == 0) and (dre - dres.cpu()).abs().max() <= 5e-5 * dre.abs().max()
+    with pytest.raises(Exception):
+        HIP.rownorm_fwd(to_device(x), None, to_device(gamma), to_device(beta), None, y, stat, rows, C, eps, 0.5, seed)      # dropout without a branch
+
+
+@pytest.mark.parametrize("n,p_drop", [(4096, 0.0), (1028, 0.1), (4, 0.5), (3000000, 0.1)])
+def test_relu_drop_fwd_bwd(n, p_drop):
+    """sep_relu_drop_fwd / bwd: dropout(relu(h)) of the feed-forward sub-block against the emulator's restatement (same hash), the rate of the
+    mask, and the backward pass reading the mask off the forward's output"""
+    torch.manual_seed(n)
+    seed = 0xABCDEF0123 + n
+    h, dy = torch.randn(n), torch.randn(n)
+    f32 = dict(device=device_name(), dtype=torch.float32)
+    a, dh = torch.full((n,), float("nan"), **f32), torch.full((n,), float("nan"), **f32)
+    HIP.relu_drop_fwd(to_device(h), a, n, p_drop, seed)
+    HIP.relu_drop_bwd(to_device(dy), a, dh, n, p_drop)
+    device_sync()
+    ae, dhe = torch.empty(n), torch.empty(n)
+    EMU.relu_drop_fwd(h, ae, n, p_drop, seed)
+    EMU.relu_drop_bwd(dy, ae, dhe, n, p_drop)
+    assert torch.equal(ae == 0, a.cpu() == 0) and (ae - a.cpu()).abs().max() <= 1e-6 * ae.abs().max()
+    assert torch.equal(dhe == 0, dh.cpu() == 0) and (dhe - dh.cpu()).abs().max() <= 1e-6 * dhe.abs().max()
+    kinv = 1.0 / (1.0 - p_drop)
+    kept = a.cpu() != 0
+    assert torch.all(h[kept] > 0) and (a.cpu()[kept] - h[kept] * kinv).abs().max() <= 1e-6 * h.abs().max() * kinv
+    if n >= 4096:
+        assert abs(kept.double().sum().item() / (h > 0).double().sum().item() - (1 - p_drop)) < 0.03
+    with pytest.raises(Exception):
+        HIP.relu_drop_fwd(to_device(h), a, n + 1, p_drop, seed)
+
+
 # ------------------------------------------------------------------------------------------- losses / optimiser
 @pytest.mark.parametrize("n,all_pairs", [(1, 0), (2, 1), (4, 1), (3, 0)])
 def test_sisdr_kernels(n, all_pairs):

@@ -523,6 +523,44 @@ def test_widths_in_odd_multiples_of_16_against_oracle(widths):
     assert flat_rel <= 2e-3, "flat gradient rel-inf {:.3e}, worst tensor {}".format(flat_rel, worst)
 
 
+def test_sepformer_encoder_stack_token_route_against_torch_layers_and_with_dropout():
+    """SepFormer's intra-chunk stack at its recipe widths (256 features, 8 heads, 1024 hidden: reference sepformer.py:395-470) on the device:
+    the token-major route (csrc/linear.hip, csrc/attn.hip, the feed-forward pair on the convolution kernels, residual sum + LayerNorm on
+    sep_rownorm_*) against torch's own nn.TransformerEncoder on the strided route in float64 (evaluation mode); then training mode with the
+    recipe's dropout 0.1: finite, different from the evaluation output by about what 10 % dropout does, and every parameter gets a gradient."""
+    from models.sepformer import IntraTransformer
+    torch.manual_seed(21)
+    net = IntraTransformer(256, num_layers=2, num_heads=8, d_ff=1024, norm=True, dropout=0.1)
+    x = 0.5 * torch.randn(2, 256, 5, 50)
+    ref_net = IntraTransformer(256, num_layers=2, num_heads=8, d_ff=1024, norm=True, dropout=0.1).double()
+    ref_net.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+    ref_net.eval()
+    ref_net._tokens_ok = lambda t: False                                      # torch's layers, module by module
+    x64 = x.double().requires_grad_(True)
+    ref = ref_net(x64)
+    w = torch.randn(x.shape)
+    (ref * w.double()).sum().backward()
+    net.cuda().eval()
+    xd = x.cuda().requires_grad_(True)
+    assert net._tokens_ok(xd)
+    y = net(xd)
+    (y * w.cuda()).sum().backward()
+    assert _rel(y, ref.detach()) <= TOL and _rel(xd.grad, x64.grad) <= 2e-3
+    for (k, p), q in zip(net.named_parameters(), ref_net.parameters()):
+        assert _rel(p.grad, q.grad) <= 2e-3, k
+    net.train()
+    net.zero_grad()
+    torch.manual_seed(5)
+    yt = net(xd)
+    assert torch.isfinite(yt).all()
+    d = (yt - y).abs().mean().item() / y.abs().mean().item()
+    assert 0.01 < d < 1.0, d
+    (yt * w.cuda()).sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().max() > 0 for p in net.parameters())
+    torch.manual_seed(5)
+    assert torch.equal(net(xd), yt)                                           # the masks are functions of the host generator's state
+
+
 def test_dptnet_full_width_step():
     """DPTNet at the widths of its paper (N = 64, L = 2, 64 bottleneck channels, chunks of 100 frames) on 4 x 2 s @ 8 kHz:
     320 chunks per utterance, i.e. 1280 x 64 rows in every intra-chunk gLN -- more than one launch takes (the module splits the

@@ -74,9 +74,10 @@ def test_sibling_separator_matches_the_reference(golden_dir, name, emu):
         assert "gln_tokens_fwd" in emu.used and "chunk_to_tokens" in emu.used
         assert "attn_fwd" in emu.used                                         # ... and the attention core on sep_attn_* (csrc/attn.hip)
     if name == "galrnet":             # its global attention runs token-major too (models/galr.py::_attend_tokens); the causal one does not
-        assert "gln_tokens_fwd" in emu.used
+        assert "gln_tokens_fwd" in emu.used and "rownorm_fwd" in emu.used      # (the channel norm in front of it: sep_rownorm_*)
     if name == "sepformer":           # both transformer stacks on token-major rows (models/sepformer.py::_forward_tokens)
         assert "gln_tokens_fwd" in emu.used and "chunk_to_tokens" in emu.used
+        assert "rownorm_fwd" in emu.used                                      # ... their layer norms with the residual sums on sep_rownorm_*
     if name == "galrnet_causal":
         assert "gln_tokens_fwd" not in emu.used
     ref = torch.from_numpy(g["output_f64"])

@@ -17,7 +17,7 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "dnn-based_source_separation_amd", "csrc")
-FILES = ("stream", "cln", "loss", "lstm", "linear", "attn", "gemm", "gemm_coop", "gemm_pc", "wgrad_pc", "wgrad_pc16")
+FILES = ("stream", "cln", "loss", "lstm", "linear", "attn", "rownorm", "gemm", "gemm_coop", "gemm_pc", "wgrad_pc", "wgrad_pc16")
 _DYN = re.compile(r"extern __shared__ (?:__attribute__\(\(aligned\(\d+\)\)\) )?(\w+) (\w+)\[\];")
 
 # The GEMM files: helper functions whose bodies are inline assembly (or address-space casts) get a C++ body in the compiled copies.

@@ -1,7 +1,8 @@
 """Per-kernel summary (calls, total, average, share) of a rocprofv3 run from its SQLite database (`-o name` -> name_results.db):
 the same table `--stats` prints, for runs whose CSV post-processing did not finish inside the box's time limit.
 
-    python tools/rocpd_summary.py gpurun_out/prof_galr/galr_results.db profiles/r02k_galrnet_kernel_stats.md [steps]
+    python tools/rocpd_summary.py gpurun_out/prof_galr/galr_results.db profiles/r02k_galrnet_kernel_stats.md [steps] [name-filter]
+With a name filter: one line per (kernel, grid) of the kernels whose name contains it -- launches of one template at different shapes apart.
 """
 import sqlite3
 import sys
@@ -22,6 +23,16 @@ def main():
             short = name if len(name) <= 110 else name[:107] + "..."
             f.write("| `{}` | {} | {:.3f} | {:.1f} | {:.1f} | {:.1f} | {:.1f} % |\n".format(short.replace("|", "\\|"), calls, tot / 1e6, avg / 1e3,
                                                                                      lo / 1e3, hi / 1e3, 100.0 * tot / total))
+        if len(sys.argv) > 4:
+            cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
+            gcols = [k for k in cols if "grid" in k.lower()]
+            f.write("\nlaunches of kernels matching `{}` by grid ({}):\n\n| kernel | grid | calls | avg us | min us | max us |\n|---|---|---:|---:|---:|---:|\n".format(
+                sys.argv[4], ", ".join(gcols)))
+            q = "select name, {g}, count(*), avg(end - start), min(end - start), max(end - start) from kernels where name like ? group by name, {g} order by 1, 4 desc".format(
+                g=", ".join(gcols))
+            for r in c.execute(q, ("%" + sys.argv[4] + "%",)):
+                name, grid, (calls, avg, lo, hi) = r[0], r[1:1 + len(gcols)], r[1 + len(gcols):]
+                f.write("| `{}` | {} | {} | {:.1f} | {:.1f} | {:.1f} |\n".format(name[:60], " x ".join(map(str, grid)), calls, avg / 1e3, lo / 1e3, hi / 1e3))
     print("wrote", out, "kernel ms/step", total / 1e6 / steps)
 
 
