@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const att_args p) {
     att_fill<D>(Kr, base + (size_t)H * D, RS, L, Lp);
     att_fill<D>(Vr, base + (size_t)2 * H * D, RS, L, Lp);
     __syncthreads();
+    if (q0 + 32 * w >= L) return;                           // a wave without a live query (short sequences): it has helped to fill, no barrier follows
     const int q = q0 + 32 * w + l31;
     float qv[DH];
 #pragma unroll
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const att_args p) {
     att_fill<D>(Kr, base + (size_t)H * D, RS, L, Lp);
     att_fill<D>(Vr, base + (size_t)2 * H * D, RS, L, Lp);
     __syncthreads();
+    if (q0 + 32 * w >= L) return;                           // (as in the forward kernel)
     const int q = q0 + 32 * w + l31;
     float qv[DH], dov[DH];
     float dl = 0.f;
@@ -264,6 +266,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const att_args p) {
         del_s[i] = i < L ? p.delta_in[((size_t)n * H + h) * L + i] : 0.f;
     }
     __syncthreads();
+    if (k0 + 32 * w >= L) return;                           // a wave without a live key
     const int key = k0 + 32 * w + l31;
     float kv[DH], vv[DH];
 #pragma unroll
@@ -364,7 +367,9 @@ extern "C" int sep_attn_fwd(const float* qkv, float* o, float* lse, int N, int L
     const dim3 grid((L + 127) / 128, H, N);
 #define SEP_ATF(DD)                                                                                                   \
     do {                                                                                                              \
-        if (L <= 256) hipLaunchKernelGGL((attn_fwd_kernel<DD, 256>), grid, dim3(256), 0, (hipStream_t)stream, a);     \
+        if (L <= 64) hipLaunchKernelGGL((attn_fwd_kernel<DD, 64>), grid, dim3(256), 0, (hipStream_t)stream, a);       \
+        else if (L <= 128) hipLaunchKernelGGL((attn_fwd_kernel<DD, 128>), grid, dim3(256), 0, (hipStream_t)stream, a); \
+        else if (L <= 256) hipLaunchKernelGGL((attn_fwd_kernel<DD, 256>), grid, dim3(256), 0, (hipStream_t)stream, a); \
         else hipLaunchKernelGGL((attn_fwd_kernel<DD, 320>), grid, dim3(256), 0, (hipStream_t)stream, a);              \
     } while (0)
     if (D == 8) SEP_ATF(8); else if (D == 16) SEP_ATF(16); else SEP_ATF(32);
@@ -383,7 +388,13 @@ extern "C" int sep_attn_bwd(const float* qkv, const float* o, const float* dout,
     const dim3 grid((L + 127) / 128, H, N);
 #define SEP_ATB(DD)                                                                                                       \
     do {                                                                                                                  \
-        if (L <= 256) {                                                                                                   \
+        if (L <= 64) {                                                                                                    \
+            hipLaunchKernelGGL((attn_bwd_q_kernel<DD, 64>), grid, dim3(256), 0, (hipStream_t)stream, a);                  \
+            hipLaunchKernelGGL((attn_bwd_kv_kernel<DD, 64>), grid, dim3(256), 0, (hipStream_t)stream, a);                 \
+        } else if (L <= 128) {                                                                                            \
+            hipLaunchKernelGGL((attn_bwd_q_kernel<DD, 128>), grid, dim3(256), 0, (hipStream_t)stream, a);                 \
+            hipLaunchKernelGGL((attn_bwd_kv_kernel<DD, 128>), grid, dim3(256), 0, (hipStream_t)stream, a);                \
+        } else if (L <= 256) {                                                                                            \
             hipLaunchKernelGGL((attn_bwd_q_kernel<DD, 256>), grid, dim3(256), 0, (hipStream_t)stream, a);                 \
             hipLaunchKernelGGL((attn_bwd_kv_kernel<DD, 256>), grid, dim3(256), 0, (hipStream_t)stream, a);                \
         } else {                                                                                                          \
