@@ -55,10 +55,10 @@ struct att_args {
 
 // rows [0, Lp) of (sequence n, head h) of one of q / k / v or of a (N, L, H, D) tensor -- `src` points at row 0, rows `row_stride` apart -- into a
 // row-major LDS tile; rows >= L are zeros
-template <int D>
+template <int D, int NT>
 __device__ __forceinline__ void att_fill(float* tile, const float* src, const size_t row_stride, const int L, const int Lp) {
     constexpr int KLD = D + 4;
-    for (int i = threadIdx.x; i < Lp * (D / 4); i += 256) {
+    for (int i = threadIdx.x; i < Lp * (D / 4); i += NT) {
         const int row = i / (D / 4), d4 = i % (D / 4);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < L) v = ald4(src + (size_t)row * row_stride + 4 * d4);
@@ -67,18 +67,23 @@ __device__ __forceinline__ void att_fill(float* tile, const float* src, const si
 }
 
 // ------------------------------------------------------------------------------------------------------------------------ forward
-template <int D, int ML>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const att_args p) {
+// One pass over the key blocks with a running maximum and sum per query (the scores of ONE block in registers: 16): the round-4 kernel held
+// all blocks' scores at once -- 256 + 125 registers at 256 steps, one wave per SIMD, 174 us at SepFormer's intra-chunk shape
+// (profiles/r07t_attention.txt).  A block whose maximum raises the running one rescales what has been accumulated: the accumulator's
+// register r is query row(r, lk), whose factor lives in that LANE -- sixteen lane reads (ds_bpermute) per block, against sixteen
+// MFMAs for a second pass over the scores.  NW waves of 32 queries share the K / V tiles of a (sequence, head).
+template <int D, int ML, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const att_args p) {
     constexpr int DH = D / 2, KLD = D + 4;
     __shared__ __attribute__((aligned(16))) float Kr[ML * KLD + 32];
     __shared__ __attribute__((aligned(16))) float Vr[ML * KLD + 32];
     const int L = p.L, H = p.H, Lp = (L + 31) & ~31, nkb = Lp >> 5;
-    const int n = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+    const int n = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 32 * NW;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l31 = lane & 31, lk = lane >> 5;
     const size_t RS = (size_t)3 * H * D;
     const float* base = p.qkv + (size_t)n * L * RS + (size_t)h * D;
-    att_fill<D>(Kr, base + (size_t)H * D, RS, L, Lp);
-    att_fill<D>(Vr, base + (size_t)2 * H * D, RS, L, Lp);
+    att_fill<D, 64 * NW>(Kr, base + (size_t)H * D, RS, L, Lp);
+    att_fill<D, 64 * NW>(Vr, base + (size_t)2 * H * D, RS, L, Lp);
     __syncthreads();
     if (q0 + 32 * w >= L) return;                           // a wave without a live query (short sequences): it has helped to fill, no barrier follows
     const int q = q0 + 32 * w + l31;
@@ -90,92 +95,79 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const att_args p) {
         const float sc = p.scale * ATT_LOG2E;
         qv[4 * j] = v.x * sc; qv[4 * j + 1] = v.y * sc; qv[4 * j + 2] = v.z * sc; qv[4 * j + 3] = v.w * sc;
     }
-    constexpr int NB = ML / 32;
-    att_f32x16 s[NB];
-#pragma unroll
-    for (int kb = 0; kb < NB; ++kb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-        if (kb < nkb) {
-            const float* kp = &Kr[(kb * 32 + l31) * KLD + lk * DH];
-#pragma unroll
-            for (int j = 0; j < DH / 4; ++j) {
-                const float4 a = ald4(kp + 4 * j);
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qv[4 * j], s[kb], 0, 0, 0);
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qv[4 * j + 1], s[kb], 0, 0, 0);
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qv[4 * j + 2], s[kb], 0, 0, 0);
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qv[4 * j + 3], s[kb], 0, 0, 0);
-            }
-        }
-    }
-    // softmax over the keys: this lane's registers hold the keys {kb * 32 + row(r, lk)}, lane ^ 32 the others
-    float m = -INFINITY;
-#pragma unroll
-    for (int kb = 0; kb < NB; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const bool live = kb < nkb && kb * 32 + att_row(r, lk) < L;
-            s[kb][r] = live ? s[kb][r] : -INFINITY;
-            m = fmaxf(m, s[kb][r]);
-        }
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < NB; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float e = att_exp2(s[kb][r] - m);         // 2^-inf = 0 for the dead keys
-            s[kb][r] = e;
-            sum += e;
-        }
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.f / sum;
-    if (lk == 0 && q < L) p.lse[((size_t)n * H + h) * L + q] = m * ATT_LN2 + logf(sum);
     const unsigned long long ebase = (((unsigned long long)n * H + h) * L + q) * (unsigned long long)L;
-#pragma unroll
-    for (int kb = 0; kb < NB; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float v = s[kb][r] * inv;
-            if (p.thr != 0u) v = att_hash(ebase + (unsigned)(kb * 32 + att_row(r, lk)), p.s0, p.s1) >= p.thr ? v * p.keep_inv : 0.f;
-            s[kb][r] = v;
-        }
-    // O = P V: A = the probabilities as they are (lane = query, k slot lk <-> key row(r, lk)), B = V[that key][dd = l31]
+    float m = -INFINITY, sum = 0.f;                          // running maximum (common to lane and lane ^ 32) and this lane's part of the sum
     att_f32x16 oacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+    for (int kb = 0; kb < nkb; ++kb) {
+        att_f32x16 s;
 #pragma unroll
-    for (int kb = 0; kb < NB; ++kb) {
-        if (kb < nkb) {
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        const float* kp = &Kr[(kb * 32 + l31) * KLD + lk * DH];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float b = Vr[(kb * 32 + att_row(r, lk)) * KLD + l31];          // (columns >= D: the next row's values -- their results are not stored)
-                oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(s[kb][r], b, oacc, 0, 0, 0);
-            }
+        for (int j = 0; j < DH / 4; ++j) {
+            const float4 a = ald4(kp + 4 * j);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qv[4 * j], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qv[4 * j + 1], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qv[4 * j + 2], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qv[4 * j + 3], s, 0, 0, 0);
         }
-    }
-    if (l31 < D) {
+        // this lane's registers hold the keys {kb * 32 + row(r, lk)}, lane ^ 32 the others
+        float bm = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int qq = q0 + 32 * w + att_row(r, lk);
-            if (qq < L) p.out[(((size_t)n * L + qq) * H + h) * D + l31] = oacc[r];
+            s[r] = kb * 32 + att_row(r, lk) < L ? s[r] : -INFINITY;
+            bm = fmaxf(bm, s[r]);
         }
+        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+        const float mn = fmaxf(m, bm);                       // finite: every block has a live key
+        const float alpha = att_exp2(m - mn);                // (first block: 2^-inf = 0, and there is nothing to rescale)
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float e = att_exp2(s[r] - mn);                   // 2^-inf = 0 for the dead keys
+            ps += e;
+            if (p.thr != 0u) e = att_hash(ebase + (unsigned)(kb * 32 + att_row(r, lk)), p.s0, p.s1) >= p.thr ? e * p.keep_inv : 0.f;
+            s[r] = e;
+        }
+        sum = fmaf(sum, alpha, ps);
+        m = mn;
+        if (kb > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[r] *= __shfl(alpha, att_row(r, lk), 64);
+        }
+        // O += P V: A = the (unnormalised) probabilities as they are (lane = query, k slot lk <-> key row(r, lk)), B = V[that key][dd = l31]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float b = Vr[(kb * 32 + att_row(r, lk)) * KLD + l31];              // (columns >= D: the next row's values -- their results are not stored)
+            oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(s[r], b, oacc, 0, 0, 0);
+        }
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+    if (lk == 0 && q < L) p.lse[((size_t)n * H + h) * L + q] = m * ATT_LN2 + logf(sum);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float f = __shfl(inv, att_row(r, lk), 64);
+        const int qq = q0 + 32 * w + att_row(r, lk);
+        if (l31 < D && qq < L) p.out[(((size_t)n * L + qq) * H + h) * D + l31] = oacc[r] * f;
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------ backward (a): dQ, delta
-template <int D, int ML>
-__global__ __launch_bounds__(256) void attn_bwd_q_kernel(const att_args p) {
+template <int D, int ML, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_q_kernel(const att_args p) {
     constexpr int DH = D / 2, KLD = D + 4;
     __shared__ __attribute__((aligned(16))) float Kr[ML * KLD + 32];
     __shared__ __attribute__((aligned(16))) float Vr[ML * KLD + 32];
     const int L = p.L, H = p.H, Lp = (L + 31) & ~31, nkb = Lp >> 5;
-    const int n = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+    const int n = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 32 * NW;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l31 = lane & 31, lk = lane >> 5;
     const size_t RS = (size_t)3 * H * D, OS = (size_t)H * D;
     const float* base = p.qkv + (size_t)n * L * RS + (size_t)h * D;
-    att_fill<D>(Kr, base + (size_t)H * D, RS, L, Lp);
-    att_fill<D>(Vr, base + (size_t)2 * H * D, RS, L, Lp);
+    att_fill<D, 64 * NW>(Kr, base + (size_t)H * D, RS, L, Lp);
+    att_fill<D, 64 * NW>(Vr, base + (size_t)2 * H * D, RS, L, Lp);
     __syncthreads();
     if (q0 + 32 * w >= L) return;                           // (as in the forward kernel)
     const int q = q0 + 32 * w + l31;
@@ -247,21 +239,21 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const att_args p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------ backward (b): dK, dV
-template <int D, int ML>
-__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const att_args p) {
+template <int D, int ML, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_kv_kernel(const att_args p) {
     constexpr int DH = D / 2, KLD = D + 4;
     __shared__ __attribute__((aligned(16))) float Qr[ML * KLD + 32];
     __shared__ __attribute__((aligned(16))) float Gr[ML * KLD + 32];      // dO
     __shared__ __attribute__((aligned(16))) float lse_s[ML];
     __shared__ __attribute__((aligned(16))) float del_s[ML];
     const int L = p.L, H = p.H, Lp = (L + 31) & ~31, nqb = Lp >> 5;
-    const int n = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 128;
+    const int n = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 32 * NW;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l31 = lane & 31, lk = lane >> 5;
     const size_t RS = (size_t)3 * H * D, OS = (size_t)H * D;
     const float* base = p.qkv + (size_t)n * L * RS + (size_t)h * D;
-    att_fill<D>(Qr, base, RS, L, Lp);
-    att_fill<D>(Gr, p.dout + (size_t)n * L * OS + (size_t)h * D, OS, L, Lp);
-    for (int i = threadIdx.x; i < Lp; i += 256) {
+    att_fill<D, 64 * NW>(Qr, base, RS, L, Lp);
+    att_fill<D, 64 * NW>(Gr, p.dout + (size_t)n * L * OS + (size_t)h * D, OS, L, Lp);
+    for (int i = threadIdx.x; i < Lp; i += 64 * NW) {
         lse_s[i] = i < L ? p.lse_in[((size_t)n * H + h) * L + i] * ATT_LOG2E : 0.f;
         del_s[i] = i < L ? p.delta_in[((size_t)n * H + h) * L + i] : 0.f;
     }
@@ -364,15 +356,17 @@ extern "C" int sep_attn_fwd(const float* qkv, float* o, float* lse, int N, int L
     SEP_REQUIRE(att_shape_ok(N, L, H, D), "sep_attn_fwd: N=%d L=%d H=%d D=%d (L <= 320, D in {8, 16, 32})", N, L, H, D);
     SEP_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "sep_attn_fwd: dropout rate %g", (double)p_drop);
     const att_args a = att_make(qkv, nullptr, nullptr, nullptr, nullptr, o, lse, L, H, scale, p_drop, seed);
-    const dim3 grid((L + 127) / 128, H, N);
-#define SEP_ATF(DD)                                                                                                   \
-    do {                                                                                                              \
-        if (L <= 64) hipLaunchKernelGGL((attn_fwd_kernel<DD, 64>), grid, dim3(256), 0, (hipStream_t)stream, a);       \
-        else if (L <= 128) hipLaunchKernelGGL((attn_fwd_kernel<DD, 128>), grid, dim3(256), 0, (hipStream_t)stream, a); \
-        else if (L <= 256) hipLaunchKernelGGL((attn_fwd_kernel<DD, 256>), grid, dim3(256), 0, (hipStream_t)stream, a); \
-        else hipLaunchKernelGGL((attn_fwd_kernel<DD, 320>), grid, dim3(256), 0, (hipStream_t)stream, a);              \
+    /* waves per workgroup = 32-query blocks that share one K / V fill: all of a sequence up to 256 steps */
+#define SEP_ATF_ONE(DD, MLL, NWW) hipLaunchKernelGGL((attn_fwd_kernel<DD, MLL, NWW>), dim3((L + 32 * NWW - 1) / (32 * NWW), H, N), dim3(64 * NWW), 0, (hipStream_t)stream, a)
+#define SEP_ATF(DD)                                  \
+    do {                                             \
+        if (L <= 64) SEP_ATF_ONE(DD, 64, 2);         \
+        else if (L <= 128) SEP_ATF_ONE(DD, 128, 4);  \
+        else if (L <= 256) SEP_ATF_ONE(DD, 256, 8);  \
+        else SEP_ATF_ONE(DD, 320, 8);                \
     } while (0)
     if (D == 8) SEP_ATF(8); else if (D == 16) SEP_ATF(16); else SEP_ATF(32);
+#undef SEP_ATF_ONE
 #undef SEP_ATF
     SEP_CHECK_LAUNCH("sep_attn_fwd");
     return 0;
@@ -385,24 +379,21 @@ extern "C" int sep_attn_bwd(const float* qkv, const float* o, const float* dout,
     SEP_REQUIRE(att_shape_ok(N, L, H, D), "sep_attn_bwd: N=%d L=%d H=%d D=%d (L <= 320, D in {8, 16, 32})", N, L, H, D);
     SEP_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "sep_attn_bwd: dropout rate %g", (double)p_drop);
     const att_args a = att_make(qkv, o, dout, lse, delta, dqkv, delta, L, H, scale, p_drop, seed);
-    const dim3 grid((L + 127) / 128, H, N);
-#define SEP_ATB(DD)                                                                                                       \
-    do {                                                                                                                  \
-        if (L <= 64) {                                                                                                    \
-            hipLaunchKernelGGL((attn_bwd_q_kernel<DD, 64>), grid, dim3(256), 0, (hipStream_t)stream, a);                  \
-            hipLaunchKernelGGL((attn_bwd_kv_kernel<DD, 64>), grid, dim3(256), 0, (hipStream_t)stream, a);                 \
-        } else if (L <= 128) {                                                                                            \
-            hipLaunchKernelGGL((attn_bwd_q_kernel<DD, 128>), grid, dim3(256), 0, (hipStream_t)stream, a);                 \
-            hipLaunchKernelGGL((attn_bwd_kv_kernel<DD, 128>), grid, dim3(256), 0, (hipStream_t)stream, a);                \
-        } else if (L <= 256) {                                                                                            \
-            hipLaunchKernelGGL((attn_bwd_q_kernel<DD, 256>), grid, dim3(256), 0, (hipStream_t)stream, a);                 \
-            hipLaunchKernelGGL((attn_bwd_kv_kernel<DD, 256>), grid, dim3(256), 0, (hipStream_t)stream, a);                \
-        } else {                                                                                                          \
-            hipLaunchKernelGGL((attn_bwd_q_kernel<DD, 320>), grid, dim3(256), 0, (hipStream_t)stream, a);                 \
-            hipLaunchKernelGGL((attn_bwd_kv_kernel<DD, 320>), grid, dim3(256), 0, (hipStream_t)stream, a);                \
-        }                                                                                                                 \
+#define SEP_ATB_ONE(DD, MLL, NWW)                                                                                                                             \
+    do {                                                                                                                                                      \
+        const dim3 grid((L + 32 * NWW - 1) / (32 * NWW), H, N);                                                                                               \
+        hipLaunchKernelGGL((attn_bwd_q_kernel<DD, MLL, NWW>), grid, dim3(64 * NWW), 0, (hipStream_t)stream, a);                                               \
+        hipLaunchKernelGGL((attn_bwd_kv_kernel<DD, MLL, NWW>), grid, dim3(64 * NWW), 0, (hipStream_t)stream, a);                                              \
+    } while (0)
+#define SEP_ATB(DD)                                  \
+    do {                                             \
+        if (L <= 64) SEP_ATB_ONE(DD, 64, 2);         \
+        else if (L <= 128) SEP_ATB_ONE(DD, 128, 4);  \
+        else if (L <= 256) SEP_ATB_ONE(DD, 256, 8);  \
+        else SEP_ATB_ONE(DD, 320, 8);                \
     } while (0)
     if (D == 8) SEP_ATB(8); else if (D == 16) SEP_ATB(16); else SEP_ATB(32);
+#undef SEP_ATB_ONE
 #undef SEP_ATB
     SEP_CHECK_LAUNCH("sep_attn_bwd");
     return 0;
