@@ -1,0 +1,44 @@
+"""Development tool (device): random shapes through the kernels added or rewritten in round 5 -- residual sum + LayerNorm over features
+(sep_rownorm_*), ReLU + dropout (sep_relu_drop_*), the one-pass attention forward with its 64 / 128 / 256 / 320-step tiles and workgroups of
+2 .. 8 waves (all step counts, every head width, with and without dropout) -- each against torch's float64 autograd and the emulator, through
+the kernel tests' own checks.
+    python tools/gpu_fuzz_round5.py [seconds]"""
+import os, sys, time, random
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "dnn-based_source_separation_amd", "src"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import torch
+import test_gpu_kernels as GK
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = random.Random(20260928)
+t0, n = time.time(), 0
+first = [("attn", (2, L, 2, D, 0.0)) for L in (1, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 288, 319, 320) for D in (8, 32)]
+first += [("rownorm", (70000, 256, True, 0.1)), ("rownorm", (3, 1024, True, 0.0)), ("relu_drop", (40000000, 0.1))]
+while time.time() - t0 < budget:
+    if first:
+        kind, args = first.pop(0)
+    else:
+        kind = rng.choice(["attn", "attn", "rownorm", "rownorm", "relu_drop"])
+        if kind == "attn":
+            args = (rng.randint(1, 40), rng.randint(1, 320), rng.randint(1, 8), rng.choice([8, 16, 32]), rng.choice([0.0, 0.0, 0.1, 0.5]))
+            if args[4] > 0 and args[0] * args[1] * args[1] * args[2] < 20000:      # (the test checks the kept fraction: needs a sample of some size)
+                args = args[:4] + (0.0,)
+        elif kind == "rownorm":
+            C = 4 * rng.randint(1, 256)
+            res = rng.random() < 0.7
+            args = (rng.randint(1, 20000), C, res, rng.choice([0.0, 0.1, 0.5]) if res else 0.0)
+        else:
+            args = (4 * rng.randint(1, 2000000), rng.choice([0.0, 0.1, 0.3]))
+    fn = {"attn": GK.test_attention_core_fwd_bwd, "rownorm": GK.test_rownorm_fwd_bwd, "relu_drop": GK.test_relu_drop_fwd_bwd}[kind]
+    try:
+        fn(*args)
+    except Exception as e:
+        import traceback
+        traceback.print_exc()
+        print("FAILED", kind, args, repr(e)[:300])
+        sys.exit(1)
+    n += 1
+    if n <= 6 or n % 25 == 0:
+        print("case {:3d} {} {} ok".format(n, kind, args), flush=True)
+print("{} cases in {:.0f} s, all within the kernel tests' tolerances".format(n, time.time() - t0))
