@@ -903,7 +903,8 @@ def test_prelu_cln_fwd_bwd(B, C, T, a):
 
 
 @pytest.mark.parametrize("N,L,H,D,p_drop", [(3, 250, 4, 16, 0.0), (2, 257, 2, 32, 0.0), (1, 320, 1, 16, 0.0), (5, 37, 8, 8, 0.0), (2, 100, 4, 16, 0.25), (1, 130, 2, 32, 0.1),
-                                            (4, 33, 8, 32, 0.1), (2, 64, 2, 16, 0.0), (2, 128, 2, 8, 0.1), (3, 1, 2, 8, 0.0), (2, 31, 1, 32, 0.0), (2, 65, 2, 32, 0.0)])      # tiles for 64 / 128 steps
+                                            (4, 33, 8, 32, 0.1), (2, 64, 2, 16, 0.0), (2, 128, 2, 8, 0.1), (3, 1, 2, 8, 0.0), (2, 31, 1, 32, 0.0), (2, 65, 2, 32, 0.0),      # tiles for 64 / 128 steps
+                                            (3, 31, 8, 32, 0.1), (2, 20, 4, 16, 0.0), (2, 50, 3, 8, 0.0), (5, 32, 12, 8, 0.0)])      # short sequences, many heads, an odd head count
 def test_attention_core_fwd_bwd(N, L, H, D, p_drop):
     """sep_attn_fwd / sep_attn_bwd on the packed projection (N, L, 3, H, D): against torch's float64 softmax(q k^T / sqrt(d)) v and its autograd
     gradients (what nn.MultiheadAttention computes between its projections: reference dptnet.py:505-527), sequences that are not multiples of

@@ -37,7 +37,7 @@ CASES = [
     ("test_gln_standalone_and_repack", [()]),
     ("test_cln_fwd_bwd", [(2, 24, 203), (3, 128, 3999), (2, 300, 150)]),          # the last: 16-wave tiles of the chained backward
     ("test_prelu_cln_fwd_bwd", [(2, 24, 203, 0.25), (1, 48, 1030, 0.0)]),
-    ("test_attention_core_fwd_bwd", [(2, 70, 2, 16, 0.0), (1, 37, 2, 8, 0.0), (1, 130, 1, 32, 0.2), (1, 257, 1, 16, 0.0), (2, 33, 2, 32, 0.1), (1, 64, 1, 16, 0.0)]),
+    ("test_attention_core_fwd_bwd", [(2, 70, 2, 16, 0.0), (1, 37, 2, 8, 0.0), (1, 130, 1, 32, 0.2), (1, 257, 1, 16, 0.0), (2, 33, 2, 32, 0.1), (1, 64, 1, 16, 0.0), (2, 31, 4, 32, 0.1), (1, 20, 8, 8, 0.0)]),
     ("test_gln_tokens_fwd_bwd", [(3, 250, 64), (5, 37, 16), (1, 7, 1024), (2, 1500, 64)]),          # the last: sliced sequences
     ("test_rownorm_fwd_bwd", [(100, 256, True, 0.0), (33, 256, True, 0.1), (51, 64, False, 0.0), (9, 1024, True, 0.5), (13, 300, True, 0.25), (5, 4, True, 0.0)]),
     ("test_relu_drop_fwd_bwd", [(4096, 0.0), (1028, 0.1), (4, 0.5)]),

@@ -13,7 +13,7 @@ import test_gpu_kernels as GK
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = random.Random(20260928)
 t0, n = time.time(), 0
-first = [("attn", (2, L, 2, D, 0.0)) for L in (1, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 288, 319, 320) for D in (8, 32)]
+first = [("attn", (2, L, H, D, 0.0)) for H in (2, 4) for L in (1, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 288, 319, 320) for D in (8, 32)]
 first += [("rownorm", (70000, 256, True, 0.1)), ("rownorm", (3, 1024, True, 0.0)), ("relu_drop", (40000000, 0.1))]
 while time.time() - t0 < budget:
     if first:
