@@ -218,7 +218,7 @@ extern "C" int sep_rownorm_parts(long rows, int C) {
 extern "C" int sep_rownorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* s, float* y, float* stat, long rows,
                                int C, float eps, float p_drop, unsigned long long seed, sep_stream_t stream) {
     SEP_REQUIRE(x && gamma && beta && y && stat && rn_shape_ok(rows, C), "sep_rownorm_fwd: bad arguments (C a multiple of 4, at most 1024)");
-    SEP_REQUIRE((res != nullptr) == (s != nullptr), "sep_rownorm_fwd: the residual branch and the place for the sum come together");
+    SEP_REQUIRE(res != nullptr || s == nullptr, "sep_rownorm_fwd: a place for the sum without a residual branch");      // (s may be NULL with a branch: inference)
     SEP_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || res), "sep_rownorm_fwd: 0 <= p_drop < 1, and only on a residual branch");
     const rn_drop d = rn_make_drop(p_drop, seed);
     const int grid = sep_rownorm_parts(rows, C), nj = (C + 255) / 256;

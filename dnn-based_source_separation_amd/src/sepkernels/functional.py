@@ -847,11 +847,12 @@ class RowNormFn(torch.autograd.Function):
             res = res.contiguous()
         p_drop = float(p_drop) if res is not None else 0.0
         seed = _dropout_seed(x) if p_drop > 0 else 0
-        s = torch.empty_like(x) if res is not None else None
+        keep = res is not None and any(ctx.needs_input_grad[:4])      # the sum is the backward pass's operand: not written under no_grad
+        s = torch.empty_like(x) if keep else None
         y = torch.empty_like(x)
         stat = torch.empty(rows, 2, device=x.device, dtype=x.dtype)
         K.rownorm_fwd(x, res, gamma, beta, s, y, stat, rows, C, float(eps), p_drop, seed)
-        ctx.save_for_backward(x if s is None else s, gamma, stat)
+        ctx.save_for_backward(x if res is None else s, gamma, stat)
         ctx.meta = (rows, C, p_drop, seed, res is not None)
         return y
 

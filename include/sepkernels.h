@@ -344,8 +344,8 @@ int sep_attn_bwd(const float* qkv, const float* o, const float* dout, const floa
  * `norm2(x + dropout2(feed_forward(x)))`) and GALRNet's channel norm (models/galr.py:172-190 LayerNormAlongChannel), one pass each way.
  *   forward : s = x + drop(res) ; y = (s - mu) rstd gamma + beta with mu / biased variance of the row's C values, eps inside the root
  *   backward: ds = the gradient at s (it is the gradient at x AND at drop(res)) ; dres = the gradient at res
- * x, res, s, y, dy, ds, dres: (rows, C) fp32, features contiguous, C a multiple of 4 and <= 1024.  res and s come together (both NULL: y = LN(x),
- * and the backward is given x as s).  stat (rows, 2) = {mu, rstd}, written forward, read backward.  p_drop: rate of the inverted dropout on
+ * x, res, s, y, dy, ds, dres: (rows, C) fp32, features contiguous, C a multiple of 4 and <= 1024.  res NULL: y = LN(x), s must be NULL and the
+ * backward is given x as s; s NULL with a branch: the sum is not kept (inference).  stat (rows, 2) = {mu, rstd}, written forward, read backward.  p_drop: rate of the inverted dropout on
  * res (0: none; then dres must be NULL -- ds serves both); the mask is a function of (seed, element index), the hash of sep_attn_*, so the
  * backward must be given the forward's seed.  part: (sep_rownorm_parts(rows, C), 2, C) = {sum dy * xhat | sum dy} over each workgroup's rows:
  * summed over the slabs they are d(gamma), d(beta). */

@@ -538,7 +538,7 @@ class EmuBackend:
         return min((rows + 3) // 4, 2048)
 
     def rownorm_fwd(self, x, res, gamma, beta, s, y, stat, rows, C, eps, p_drop=0.0, seed=0):
-        assert (res is None) == (s is None) and (p_drop == 0 or res is not None)
+        assert (res is not None or s is None) and (p_drop == 0 or res is not None)
         v = x.reshape(rows, C)
         if res is not None:
             q = res.reshape(rows, C)
@@ -546,7 +546,8 @@ class EmuBackend:
             if keep is not None:
                 q = torch.where(keep.view(rows, C).to(q.device), q * kinv, torch.zeros_like(q))
             v = v + q
-            s.reshape(rows, C).copy_(v)
+            if s is not None:
+                s.reshape(rows, C).copy_(v)
         d = v.double()
         m = d.mean(1, keepdim=True)
         r = 1.0 / torch.sqrt(((d - m) ** 2).mean(1, keepdim=True) + eps)

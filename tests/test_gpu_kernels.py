@@ -1028,8 +1028,15 @@ def test_rownorm_fwd_bwd(rows, C, with_res, p_drop):
         dropped = ~EMU._rownorm_keep(rows * C, p_drop, seed)[0].view(rows, C)
         assert (dres.cpu()[dropped] == 0).all() and (dre[dropped] == 0).all()
         assert (dre - dres.cpu()).abs().max() <= 5e-5 * dre.abs().max()
+    if with_res:                                               # inference: the sum is not kept
+        y2, stat2 = torch.full((rows, C), float("nan"), **f32), torch.full((rows, 2), float("nan"), **f32)
+        HIP.rownorm_fwd(to_device(x), to_device(res), to_device(gamma), to_device(beta), None, y2, stat2, rows, C, eps, p_drop, seed)
+        device_sync()
+        assert torch.equal(y2.cpu(), y.cpu()) and torch.equal(stat2.cpu(), stat.cpu())
     with pytest.raises(Exception):
         HIP.rownorm_fwd(to_device(x), None, to_device(gamma), to_device(beta), None, y, stat, rows, C, eps, 0.5, seed)      # dropout without a branch
+    with pytest.raises(Exception):
+        HIP.rownorm_fwd(to_device(x), None, to_device(gamma), to_device(beta), ds, y, stat, rows, C, eps, 0.0, seed)        # a place for the sum without a branch
 
 
 @pytest.mark.parametrize("n,p_drop", [(4096, 0.0), (1028, 0.1), (4, 0.5), (3000000, 0.1)])

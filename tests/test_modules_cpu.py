@@ -458,6 +458,9 @@ def test_residual_layer_norm_is_nn_layer_norm_of_the_sum(emu, shape, with_res, p
     ref = norm(x + branch if with_res else x)
     (ref * w).sum().backward()
     assert (y - ref).abs().max() <= 1e-12 * ref.abs().max()
+    if p_drop == 0:
+        with torch.no_grad():                                      # inference: the same values, the sum is not kept
+            assert torch.equal(residual_layer_norm(x, res, norm, 0.0), y.detach())
     want = [x.grad, res.grad if with_res else None, norm.weight.grad, norm.bias.grad]
     for a, b in zip(got, want):
         if b is not None:
