@@ -50,6 +50,7 @@ def main():
     torch.cuda.synchronize()
     st = pstats.Stats(pr)
     st.sort_stats("tottime").print_stats(28)
+    st.sort_stats("cumulative").print_stats("dnn-based_source_separation_amd|torch/nn/functional|torch/autograd/function", 45)
 
 
 if __name__ == "__main__":

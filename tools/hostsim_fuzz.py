@@ -286,7 +286,25 @@ def case_round4(R):
     return "prelu_cln {} {} {} {}".format(B, C, T, a)
 
 
-CASES = [case_round4, case_round4, case_gemm, case_gemm, case_gemm_forms, case_gemm_forms, case_wgrad, case_wgrad, case_codec, case_norms, case_chunks, case_lstm, case_dense, case_dense,
+def case_round5(R):
+    """the kernels of round 5: residual sum + LayerNorm over features, ReLU + dropout, the one-pass attention forward at every tile size"""
+    pick = R.randint(0, 2)
+    if pick == 0:
+        C = 4 * R.randint(1, 256)
+        rows, res = R.randint(1, 60), R.random() < 0.7
+        p = (R.choice([0.0, 0.1, 0.5]) if rows * C >= 4096 else 0.0) if res else 0.0
+        GK.test_rownorm_fwd_bwd(rows, C, res, p)
+        return "rownorm {} {} {} {}".format(rows, C, res, p)
+    if pick == 1:
+        n, p = 4 * R.randint(1, 3000), R.choice([0.0, 0.1, 0.3])
+        GK.test_relu_drop_fwd_bwd(n, p if n >= 4096 else 0.0)
+        return "relu_drop {} {}".format(n, p)
+    N, L, H, D = R.randint(1, 2), R.choice([1, 31, 32, 33, 64, 65, 128, 129, 200, 256, 257, 300, 320]), R.randint(1, 2), R.choice([8, 16, 32])
+    GK.test_attention_core_fwd_bwd(N, L, H, D, 0.0)
+    return "attention {} {} {} {}".format(N, L, H, D)
+
+
+CASES = [case_round5, case_round5, case_round4, case_round4, case_gemm, case_gemm, case_gemm_forms, case_gemm_forms, case_wgrad, case_wgrad, case_codec, case_norms, case_chunks, case_lstm, case_dense, case_dense,
          case_test_functions, case_test_functions]
 
 
