@@ -831,6 +831,12 @@ def _dropout_seed(t):
     return (seed ^ (0x9E3779B97F4A7C15 * (1 + rank + 1024 * (t.device.index or 0)))) & (2 ** 62 - 1)
 
 
+def _aligned16(t):
+    """float4 accesses: the kernels of csrc/rownorm.hip read rows from the tensor's first byte (a contiguous view that starts inside another
+    tensor's row may not be 16-byte aligned; such a caller keeps torch's kernels)"""
+    return (t.data_ptr() if t.is_contiguous() else 0) % 16 == 0
+
+
 class RowNormFn(torch.autograd.Function):
     """y = LayerNorm_C(x + dropout(res)) on token-major rows (..., C): the tail of both sub-blocks of a post-norm nn.TransformerEncoderLayer
     (torch/nn/modules/transformer.py `norm1(x + _sa_block(x))`, `norm2(x + _ff_block(x))`; reference models/sepformer.py:395-520), one pass each
@@ -873,12 +879,12 @@ def rownorm_ok(x, norm):
     """can `norm` (an nn.LayerNorm over the last axis, with gain and shift) run on sep_rownorm_* for rows x (..., C)?"""
     C = x.shape[-1]
     return (isinstance(norm, torch.nn.LayerNorm) and tuple(norm.normalized_shape) == (C,) and norm.weight is not None and norm.bias is not None
-            and C % 4 == 0 and 4 <= C <= 1024 and x.numel() > 0 and takes(x))
+            and C % 4 == 0 and 4 <= C <= 1024 and x.numel() > 0 and takes(x) and _aligned16(x))
 
 
 def residual_layer_norm(x, res, norm, p_drop=0.0):
     """norm(x + dropout(res, p_drop)) (res None: norm(x)): sep_rownorm_* where it applies, torch's kernels otherwise"""
-    if rownorm_ok(x, norm) and (res is None or (res.shape == x.shape and res.dtype == x.dtype)):
+    if rownorm_ok(x, norm) and (res is None or (res.shape == x.shape and res.dtype == x.dtype and _aligned16(res))):
         return RowNormFn.apply(x, res, norm.weight, norm.bias, norm.eps, p_drop)
     if res is not None:
         x = x + torch.nn.functional.dropout(res, p_drop, training=p_drop > 0)
@@ -910,7 +916,7 @@ class ReluDropFn(torch.autograd.Function):
 
 def relu_dropout(h, p_drop):
     """dropout(relu(h), p_drop) -- sep_relu_drop_* where they apply (p_drop = 0: a plain ReLU)"""
-    if takes(h) and h.numel() > 0 and h.numel() % 4 == 0 and 0 <= p_drop < 1:
+    if takes(h) and h.numel() > 0 and h.numel() % 4 == 0 and 0 <= p_drop < 1 and _aligned16(h):
         return ReluDropFn.apply(h, p_drop)
     return torch.nn.functional.dropout(torch.relu(h), p_drop, training=p_drop > 0)
 

@@ -461,6 +461,12 @@ def test_residual_layer_norm_is_nn_layer_norm_of_the_sum(emu, shape, with_res, p
     if p_drop == 0:
         with torch.no_grad():                                      # inference: the same values, the sum is not kept
             assert torch.equal(residual_layer_norm(x, res, norm, 0.0), y.detach())
+            # rows that do not start on a 16-byte boundary (a contiguous view into a larger buffer) stay on torch's kernels
+            buf = torch.zeros(x.numel() + 1, dtype=x.dtype)
+            buf[1:] = x.detach().reshape(-1)
+            odd = buf[1:].view(x.shape)
+            assert odd.is_contiguous() and odd.data_ptr() % 16 != 0 and not rownorm_ok(odd, norm)
+            assert (residual_layer_norm(odd, res, norm, 0.0) - y.detach()).abs().max() <= 1e-12 * y.detach().abs().max()
     want = [x.grad, res.grad if with_res else None, norm.weight.grad, norm.bias.grad]
     for a, b in zip(got, want):
         if b is not None:
