@@ -156,13 +156,19 @@ import test_gpu_kernels as GK
 import test_kernel_source_on_host_cpu as H
 with hostsim.HostSimBackend({so!r}) as K:
     GK.HIP, GK.to_device, GK.device_sync, GK.device_name = K, (lambda t: t.clone()), (lambda: None), (lambda: "cpu")
+    import os
+    only = [o for o in os.environ.get("HOSTSIM_ONLY", "").split(",") if o]        # python tools/hostsim.py --tsan --only rownorm,relu_drop,attention
     for name, params in H.CASES:
+        if only and not any(o in name for o in only):
+            continue
         for p in params:
             t0 = time.time()
             getattr(GK, name)(*p)
             print("  {{:34s}} {{:28s}} {{:5.1f}} s".format(name, str(p), time.time() - t0), flush=True)
     import sepkernels
     for arith, name, args in H.GEMM_CASES:
+        if only and not any(o in name for o in only):
+            continue
         t0 = time.time()
         if arith is None:
             getattr(GK, name)(*args)
@@ -235,6 +241,8 @@ def main():
     with tempfile.TemporaryDirectory() as d:
         so = build(d, sanitize="address" if kind == "asan" else "thread")
         paths = [os.path.join(ROOT, "tools"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "dnn-based_source_separation_amd", "src"), ROOT]
+        if "--only" in sys.argv:
+            os.environ["HOSTSIM_ONLY"] = sys.argv[sys.argv.index("--only") + 1]
         env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:halt_on_error=0", TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0")
         r = subprocess.run([sys.executable, "-c", _SANITIZED_CHILD.format(paths=paths, so=so)], env=env, capture_output=True, text=True)
     reports = r.stderr.count(marker)
