@@ -299,7 +299,7 @@ def case_round5(R):
         n, p = 4 * R.randint(1, 3000), R.choice([0.0, 0.1, 0.3])
         GK.test_relu_drop_fwd_bwd(n, p if n >= 4096 else 0.0)
         return "relu_drop {} {}".format(n, p)
-    N, L, H, D = R.randint(1, 2), R.choice([1, 31, 32, 33, 64, 65, 128, 129, 200, 256, 257, 300, 320]), R.randint(1, 2), R.choice([8, 16, 32])
+    N, L, H, D = 1, R.choice([1, 31, 32, 33, 64, 65, 100, 128, 129]), R.randint(1, 2), R.choice([8, 16, 32])      # (longer sequences: the fixed cases of the CPU tier)
     GK.test_attention_core_fwd_bwd(N, L, H, D, 0.0)
     return "attention {} {} {} {}".format(N, L, H, D)
 
