@@ -1233,9 +1233,9 @@ def test_lstm_sweeps_interleaved_output(kernel):
 
 
 @pytest.mark.parametrize("kernel", sorted(LSTM_KERNELS))
-def test_lstm_sweeps_both_directions_one_launch(kernel):
-    """reverse = 2: two slabs per buffer, grid.y = direction."""
-    H, nseq, L = 128, 21, 40
+def test_lstm_sweeps_both_directions_one_launch(kernel, nseq=21, L=40):
+    """reverse = 2: two slabs per buffer, grid.y = direction.  (nseq, L: the host simulation of the CPU tier runs a shorter case)"""
+    H = 128
     two = 2 | LSTM_KERNELS[kernel]
     xg = rnd(2, nseq, L, 4 * H)
     w_hh = rnd(2, 4 * H, H, scale=H ** -0.5)
