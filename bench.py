@@ -37,7 +37,7 @@ from bench_legs import (PAPER, T_SAMPLES, PER_GPU_BATCH, HBM_PEAK_TBS, MFMA_PER_
 
 # the launcher / rendezvous / timing plumbing on a box without a GPU (tests/test_distributed_cpu.py): tiny Conv-TasNet on the tests'
 # CPU emulator of the kernels, flagged in the line; never a measurement
-DRY_CFG = dict(PAPER, n_basis=64, sep_hidden_channels=128, sep_bottleneck_channels=64, sep_skip_channels=64, sep_num_blocks=1, sep_num_layers=2)
+DRY_CFG = dict(PAPER, n_basis=64, sep_hidden_channels=128, sep_bottleneck_channels=64, sep_skip_channels=64, sep_num_blocks=3, sep_num_layers=1)      # three TCN blocks = three gradient buckets, like the paper-best model
 DRY_T = 4000
 
 
@@ -86,9 +86,11 @@ def compact_line(detail):
     out = {k: detail[k] for k in keep}
     c = detail["config"]
     out["config"] = {k: c[k] for k in ("workload", "global_batch", "per_gpu_batch", "parallelism", "rccl_ranks", "launch", "final_loss") if k in c}
+    if detail.get("ranks") and detail["n_gpus"] > 1:
+        out["config"]["ddp_buckets"] = detail["ranks"].get("ddp_buckets")
     r = detail.get("roofline")
     if r:
-        out["roofline"] = {k: _r(r.get(k)) for k in ("kernel", "launch_class", "family", "bound", "achieved", "peak", "unit", "frac", "family_frac", "family_share", "traffic",
+        out["roofline"] = {k: _r(r.get(k)) for k in ("kernel", "launch_class", "family", "bound", "achieved", "peak", "unit", "frac", "frac_8d", "family_frac", "family_share", "traffic",
                                                       "traffic_over_algorithmic", "avg_launch_us", "launches_per_step", "share_of_kernel_time",
                                                       "algorithmic_bytes_per_launch")}
     rf = detail.get("roofline_family")
@@ -127,7 +129,8 @@ def main():
     ap.add_argument("--no-f32-pass", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic (N = 1 only)")
     ap.add_argument("--no-stock", action="store_true", help="skip the hipified_baseline leg (stock torch.nn modules on the same device)")
-    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured step (N = 1)")
+    ap.add_argument("--eager", "--no-graph", dest="eager", action="store_true",
+                    help="launch every kernel from Python instead of replaying the recorded launch sequence (N = 1; same as SEPK_SEQUENCE=0)")
     ap.add_argument("--config", default="convtasnet2", choices=["convtasnet2", "sinkpit4", "causal", "dprnn", "dptnet", "galrnet", "sepformer"],
                     help="convtasnet2 (default) = BASELINE.json configs[1]/[2], the headline; sinkpit4 = configs[4] (paper-best Conv-TasNet, "
                          "4 speakers, SinkPIT(NegSI-SDR, coldness 1, 200 iterations)); dprnn = configs[3] (DPRNN-TasNet N64 L2 F64 H128 K250 P125 B6, batch 2); dptnet / galrnet / sepformer = the reference recipes' "
@@ -229,42 +232,41 @@ def main():
         would time the overlap, not the kernel."""
         side_prev = os.environ.get("SEPK_SIDE_STREAM")
         os.environ["SEPK_SIDE_STREAM"] = "0"
-        graph, step._graph = step._graph, None            # the event brackets live in the Python launch wrappers: eager for this pass
+        seq, step._seq = step._seq, None                  # the event brackets live in the Python launch wrappers: eager for this pass
+        auto, step.auto_record = step.auto_record, False
         step(mixture, sources)
         timed.reset()
         timed.enabled = True
         el, _ = timed_steps(n)
         timed.enabled = False
-        step._graph = graph
+        step._seq, step.auto_record = seq, auto
         if side_prev is None:
             del os.environ["SEPK_SIDE_STREAM"]
         else:
             os.environ["SEPK_SIDE_STREAM"] = side_prev
         return el
 
-    # SEPK_GRAPH=1 (N = 1, opt-in): the step (forward + PIT + backward + clip + Adam, one stream) captured once into a hipGraph and replayed.
-    # NOT the default: replays of this full-size step are 0.0 - 0.3 ms faster than eager launches (15.70 vs 15.89 ms on one box, 15.73 vs
-    # 15.77 on another) but END WITH WRONG LOSSES in about half the runs on this stack (inf / 49.98 instead of 0.0812 in 5 of 10 runs, twice:
-    # profiles/r07_round5_experiments.md, r07m) -- a replay hazard the small-configuration test of FusedTrainStep.capture does not show.
-    # A number from a step that does not train is not a measurement.
-    use_graph = world == 1 and not dry and not args.no_graph and os.environ.get("SEPK_GRAPH", "0") == "1" and os.environ.get("SEPK_SIDE_STREAM", "0") != "1" and bool(getattr(model, "fused", False))
-    graph_note = None
+    # N = 1: the step is recorded ONCE (sepkernels.Sequence: every launch of forward + PIT + backward + clip + Adam through the library's own
+    # entry points, no hipGraph) and replayed by one sep_run_sequence call per step -- the launches leave a C loop instead of ~360 Python
+    # wrappers.  Same kernels, same arguments, same order as the eager step (losses agree to the last bit: tests/test_gpu_model.py).
+    # SEPK_SEQUENCE=0 or --eager: the eager step.  N > 1: eager (the bucketed all-reduces are issued from inside backward).
+    use_seq = (world == 1 and not dry and not args.eager and os.environ.get("SEPK_SEQUENCE", "1") != "0" and step.recordable() is None)
+    seq_note = None
     done = 0
-    if use_graph:
+    if use_seq:
         try:
-            w = max(1, args.warmup - 1)                      # w eager steps + the recorded one (which is executed too) = the W warm-up steps
-            loss = step.capture(mixture, sources, warmup=w)
-            done = w + 1
+            loss = step.record(mixture, sources)             # a training step: the first of the W warm-up steps
+            done = 1
         except Exception as e:                               # noqa: BLE001 -- reported in the line, the measurement goes on eagerly
-            graph_note = "eager (hipGraph capture failed: {}: {})".format(type(e).__name__, str(e)[:120])
-            print("bench.py: " + graph_note, file=sys.stderr)
-            use_graph = False
-            step._graph = None
+            seq_note = "eager (recording failed: {}: {})".format(type(e).__name__, str(e)[:120])
+            print("bench.py: " + seq_note, file=sys.stderr)
+            use_seq = False
+            step._seq = None
     for _ in range(max(0, args.warmup - done)):
         loss = step(mixture, sources)
     elapsed, loss = timed_steps(args.steps)              # THE timed region: K steps, nothing else in it
     my_elapsed = elapsed
-    final_loss = float(loss)                             # NOW: a replayed step returns a tensor of the graph's pool, which a later re-capture (fp32 pass) recycles
+    final_loss = float(loss)                             # NOW: a replayed step returns the recorded step's loss buffer, which a later recording (fp32 pass) replaces
 
     arith_name = sepkernels.gemm_arith_name()
     by_kernel = roof_g = roof_w = None
@@ -280,9 +282,9 @@ def main():
     f32_pass = None
     if world == 1 and arith_name != "f32" and not args.no_f32_pass:
         sepkernels.set_gemm_arith("f32")
-        step._graph = None
-        if use_graph:
-            step.capture(mixture, sources)                 # the captured launches carry the arithmetic: record the step again
+        step._seq = None
+        if use_seq:
+            step.record(mixture, sources)                  # the recorded launches carry the arithmetic: record the step again
         else:
             step(mixture, sources)
         el_f32, _ = timed_steps(args.steps)
@@ -291,7 +293,7 @@ def main():
                     "frac": v32 * fl_frame / (FP32_MFMA_PEAK_TFLOPS * 1e12), "frac_of": "step FLOP x frames/s / 157.3 TFLOP/s (dense fp32 MFMA)",
                     "what": "same process, same K steps, SEP_ARITH_F32 (v_mfma_f32_32x32x2_f32) for every sep_pw_gemm / sep_pw_wgrad"}
         sepkernels.set_gemm_arith(arith_name)
-        step._graph = None
+        step._seq = None
 
     rank_ms = [1e3 * my_elapsed / args.steps]
     comm_ms = [None]
@@ -334,7 +336,8 @@ def main():
             "config": {"workload": workload, "global_batch": world * args.batch, "per_gpu_batch": args.batch, "frames_per_utterance": F,
                        "parallelism": "dp{}".format(world), "rccl_ranks": world if backend_name == "nccl" else 0,
                        "utt_per_s": value / F, "samples_per_s": value / F * t_samples, "final_loss": final_loss,
-                       "launch": "hipGraph replay" if use_graph else (graph_note or "eager"), "gemm_arith": arith_name},
+                       "launch": "recorded sequence, one sep_run_sequence call per step" if use_seq else (seq_note or "eager (one Python call per launch)"),
+                       "gemm_arith": arith_name},
             "step_roofline": {"hbm_frac": value / world * by_frame / (HBM_PEAK_TBS * 1e12),
                               "matrix_pipe_frac": value / world * fl_frame / (pipe / per * 1e12),
                               "matrix_pipe_peak_tflops_equiv": pipe / per,
@@ -351,7 +354,7 @@ def main():
         if dry:
             detail["dry_run"] = ("NOT a measurement: no GPU on this box; tiny Conv-TasNet on the tests' CPU emulator, T = {} -- exercises the launcher, "
                                  "rendezvous, barrier and max-over-ranks timing only").format(t_samples)
-            detail["config"]["workload"] = "dry run (launcher test): tiny Conv-TasNet (N=64,B=64,H=128,Sc=64,X=2,R=1) on the CPU emulator, {} utterances/rank".format(args.batch)
+            detail["config"]["workload"] = "dry run (launcher test): tiny Conv-TasNet (N=64,B=64,H=128,Sc=64,X=1,R=3) on the CPU emulator, {} utterances/rank".format(args.batch)
         if f32_pass is not None:
             detail["fp32_mfma_pass"] = f32_pass
         per_kernel_traffic = None

@@ -34,7 +34,10 @@ class _FusedConvTasNetFn(torch.autograd.Function):
     def forward(ctx, mixture, cfg, names, want_latent, grad_sink, *params):
         ctx.set_materialize_grads(False)
         ctx.grad_sink, ctx.bucket_hook = (grad_sink if isinstance(grad_sink, tuple) else (grad_sink, None))
-        need_bwd = ctx.needs_input_grad[0] or any(ctx.needs_input_grad[5:])
+        # want_latent may arrive as (want_latent, grad mode of the caller): inside Function.forward the grad mode is always off and
+        # needs_input_grad ignores torch.no_grad(), so the caller says whether anything will be differentiated
+        want_latent, grad_on = want_latent if isinstance(want_latent, tuple) else (want_latent, True)
+        need_bwd = grad_on and (ctx.needs_input_grad[0] or any(ctx.needs_input_grad[5:]))
         P = dict(zip(names, params))
         est, latent, sv = _net.forward(cfg, P, mixture, want_latent=want_latent, save=need_bwd)
         ctx.cfg, ctx.names, ctx.sv = cfg, names, sv
@@ -289,7 +292,7 @@ class ConvTasNet(nn.Module):
         params = tuple(p for _, p in named)
         sink = getattr(self, "_grad_sink", None)
         hook = getattr(self, "_grad_bucket_hook", None)
-        out = _FusedConvTasNetFn.apply(mixture, cfg, names, want_latent, (sink, hook) if hook is not None else sink, *params)
+        out = _FusedConvTasNetFn.apply(mixture, cfg, names, (want_latent, torch.is_grad_enabled()), (sink, hook) if hook is not None else sink, *params)
         if want_latent:
             est, latent = out
             F = _net.Geometry(T, self.kernel_size, self.stride).F
@@ -375,7 +378,8 @@ class ConvTasNet(nn.Module):
         if sink is not None and self._flat is not None and sink.numel() == self._flat.numel():
             placed = {n: sink[self._offsets[n]:self._offsets[n] + p.numel()].view(p.shape) for n, p in sep}
             self._sink_placed = True
-        out = _FusedConvTasNetFn.apply(mixture.float() if _net.backend().name == "hip" else mixture, cfg, names, want_latent, placed, E, *[p for _, p in sep], D)
+        out = _FusedConvTasNetFn.apply(mixture.float() if _net.backend().name == "hip" else mixture, cfg, names, (want_latent, torch.is_grad_enabled()), placed, E,
+                                       *[p for _, p in sep], D)
         if want_latent:
             est, latent = out
             return est, latent[..., :_net.Geometry(mixture.shape[-1], self.kernel_size, self.stride).F]

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("SEPKERNELS_LIB", os.path.normpath(os.path.join(_HERE,
 # ---- constants mirrored from include/sepkernels.h -------------------------------------------------
 PRO_NONE, PRO_PRELU, PRO_GLN, PRO_GLN_PRELU, PRO_GLN_BWD = 0, 1, 2, 3, 4
 EPI_STATS_PRELU, EPI_RESIDUAL, EPI_SIGMOID, EPI_PRELU_BWD, EPI_ROWSUMS, EPI_ROWSUMS_PRELU = 1, 2, 4, 8, 16, 32
-ABI_VERSION = 22
+ABI_VERSION = 23
 LSTM_INTERLEAVED = 0x400       # sep_lstm_fwd / sep_lstm_bwd with reverse = 2: h_out / dh_out as one (nseq, L, 2H) buffer
 STATS_SLOTS = 16   # SEP_STATS_SLOTS: gLN statistics are double[B][STATS_SLOTS][2]
 ARRIVE_INTS = 17   # SEP_ARRIVE_INTS: arrival counters of the gLN-backward publishers, int[B][ARRIVE_INTS]
@@ -106,6 +106,17 @@ class ReduceSeg(ctypes.Structure):
                 ("accumulate", _i32), ("scale", ctypes.c_float)]
 
 
+SEQ_MAX_ARGS = 26
+
+
+class SeqArg(ctypes.Union):
+    _fields_ = [("i", ctypes.c_int64), ("f", ctypes.c_double), ("p", _vp)]
+
+
+class SeqOp(ctypes.Structure):
+    _fields_ = [("fn", _i32), ("nargs", _i32), ("args", SeqArg * SEQ_MAX_ARGS)]
+
+
 # name -> argtypes (restype is always int unless noted); also the list the symbol-export test checks
 _I, _F, _D, _L = ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_int64
 SIGNATURES = {
@@ -169,7 +180,17 @@ SIGNATURES = {
     "sep_linear_bwd_weight": [_vp, _vp, _L, _vp, _vp, _L] + [_I] * 5 + [_vp],
     "sep_chunk_to_tokens": [_vp, _vp] + [_I] * 5 + [_vp],
     "sep_tokens_to_chunk": [_vp, _vp] + [_I] * 5 + [_vp],
+    "sep_seq_count": [],
+    "sep_seq_lookup": [ctypes.c_char_p],
+    "sep_seq_name": [_I],                                            # returns const char*
+    "sep_seq_nargs": [_I],
+    "sep_run_sequence": [ctypes.POINTER(SeqOp), _I, _vp],
+    "sep_memset": [_vp, _I, ctypes.c_size_t, _vp],
+    "sep_absmax": [_vp, _L, _vp, _vp],
+    "sep_pit_finish": [_vp, _vp, _vp, _I, _I, _I, _F, _F, _vp, _vp, _vp, _vp],
 }
+_RESTYPES = {"sep_last_error": ctypes.c_char_p, "sep_seq_name": ctypes.c_char_p, "sep_cln_ws_bytes": ctypes.c_size_t,
+             "sep_gln_tokens_ws_bytes": ctypes.c_size_t}
 
 _lib = None
 
@@ -182,7 +203,7 @@ def load():
     """Load libsepkernels.so (once).  Fails loudly -- there is no fallback implementation."""
     global _lib
     if _lib is not None:
-        return _lib
+        return _lib if _recording is None else _RecordingLib(_lib, _recording)
     if not os.path.exists(LIB_PATH):
         raise SepKernelsError(
             "libsepkernels.so not found at {} -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -191,16 +212,131 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_char_p if name == "sep_last_error" else (ctypes.c_size_t if name in ("sep_cln_ws_bytes", "sep_gln_tokens_ws_bytes") else ctypes.c_int)
+        fn.restype = _RESTYPES.get(name, ctypes.c_int)
     if lib.sep_version() != ABI_VERSION:
         raise SepKernelsError("libsepkernels ABI {} != binding ABI {}".format(lib.sep_version(), ABI_VERSION))
     _lib = lib
-    return lib
+    return lib if _recording is None else _RecordingLib(lib, _recording)
+
+
+# ---- recorded launch sequences (include/sepkernels.h, ABI 23) --------------------------------------------------------------------------
+_recording = None          # the Sequence being recorded (every successful launch through load() is appended to it), or None
+
+
+class Sequence:
+    """The launches of one pass, recorded once and replayed by ONE call of sep_run_sequence (a C loop over the same entry points; no
+    hipGraph).  Keeps alive everything the ops point at: the device tensors that went through the binding while recording (their
+    addresses are in the ops) and the host-side descriptors / segment arrays."""
+
+    def __init__(self):
+        self.ops = []           # (name, fn id, [(kind, value)])
+        self.keep = []
+        self._arr = None
+
+    def __len__(self):
+        return len(self.ops)
+
+    def add(self, lib, name, args):
+        types = SIGNATURES[name][:-1]
+        if len(types) > SEQ_MAX_ARGS:
+            raise SepKernelsError("{} has {} arguments, a recorded op holds {}".format(name, len(types), SEQ_MAX_ARGS))
+        fn = lib.sep_seq_lookup(name.encode())
+        if fn < 0:
+            raise SepKernelsError("{} cannot be recorded into a sequence".format(name))
+        conv = []
+        for ty, a in zip(types, args):
+            if ty is _vp:
+                conv.append(("p", int(a) if a else 0))
+            elif isinstance(ty, type) and issubclass(ty, ctypes._Pointer):
+                obj = getattr(a, "_obj", a)                # ctypes.byref(struct) -> the struct; an array instance is passed as it is
+                self.keep.append(obj)
+                conv.append(("p", ctypes.addressof(obj)))
+            elif ty in (_F, _D):
+                conv.append(("f", float(a)))
+            else:
+                conv.append(("i", int(a)))
+        self.ops.append((name, fn, conv))
+        self._arr = None
+
+    def names(self):
+        return [o[0] for o in self.ops]
+
+    def _array(self):
+        if self._arr is None:
+            arr = (SeqOp * max(1, len(self.ops)))()
+            for k, (_, fn, conv) in enumerate(self.ops):
+                arr[k].fn, arr[k].nargs = fn, len(conv)
+                for q, (kind, v) in enumerate(conv):
+                    setattr(arr[k].args[q], kind, v)
+            self._arr = arr
+        return self._arr
+
+    def run(self, first=0, last=None):
+        """replay ops [first, last) on the current stream"""
+        last = len(self.ops) if last is None else last
+        if last <= first:
+            return
+        arr = self._array()
+        base = ctypes.cast(ctypes.byref(arr, first * ctypes.sizeof(SeqOp)), ctypes.POINTER(SeqOp))
+        lib = _lib if _lib is not None else load()
+        _check(lib.sep_run_sequence(base, last - first, _stream()), "sep_run_sequence")
+
+
+class _RecordingLib:
+    """what load() hands out while a Sequence is being recorded: every entry point runs as usual and, when it succeeded and takes a
+    stream, is appended to the sequence"""
+
+    def __init__(self, lib, seq):
+        self._lib, self._seq = lib, seq
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        sig = SIGNATURES.get(name)
+        if not sig or sig[-1] is not _vp or name in ("sep_run_sequence",) or name in _RESTYPES:
+            return fn
+        lib, seq = self._lib, self._seq
+
+        def call(*args):
+            rc = fn(*args)
+            if rc == 0:
+                seq.add(lib, name, args)
+            return rc
+        return call
+
+
+class recording:
+    """with sepkernels.recording(seq): ... -- the launches issued inside go into `seq` (and are executed).  Not re-entrant."""
+
+    def __init__(self, seq):
+        self.seq = seq
+
+    def __enter__(self):
+        global _recording
+        if _recording is not None:
+            raise SepKernelsError("a sequence is already being recorded")
+        _recording = self.seq
+        return self.seq
+
+    def __exit__(self, *exc):
+        global _recording
+        _recording = None
+        return False
+
+
+def is_recording():
+    return _recording is not None
+
+
+def _keep(*tensors):
+    if _recording is not None:
+        _recording.keep.extend(t for t in tensors if t is not None)
 
 
 def _ptr(t, dtype=None):
     if t is None:
         return None
+    if _recording is not None:
+        _recording.keep.append(t)
     if not t.is_cuda:
         raise SepKernelsError("sepkernels is HIP-only: got a {} tensor (no CPU fallback exists)".format(t.device))
     if dtype is not None and t.dtype != dtype:
@@ -273,6 +409,7 @@ class HipBackend:
         data = torch.empty(total + 8, device=dev, dtype=_f32)
         off0 = (-data.data_ptr() // 4) % 8                       # 32-byte alignment of the first segment; sizes are multiples of 8
         rsc = torch.empty(rows_total, device=dev, dtype=_f32)
+        _keep(data, rsc)
         arr = (PackSeg * len(specs))()
         out = []
         off, roff = off0, 0
@@ -518,6 +655,24 @@ class HipBackend:
         _ptr(x[:1], _f32)                                     # device / dtype checks on a (contiguous) row of it
         _check(load().sep_linear_bwd_weight(_ptr(dy, _f32), x.data_ptr(), ldx, _ptr(partial, _f32), _ptr(partial_bias, _f32), ntok, K, N, L, shift,
                                             nslab, _stream()), "sep_linear_bwd_weight")
+
+    def memset(self, t, value=0):
+        _check(load().sep_memset(_ptr(t), int(value), t.numel() * t.element_size(), _stream()), "sep_memset")
+
+    def zeros(self, *shape, device, dtype):
+        """torch.zeros, except while a Sequence is being recorded: the clearing is then a launch of the sequence (sep_memset)"""
+        if _recording is None:
+            return torch.zeros(*shape, device=device, dtype=dtype)
+        t = torch.empty(*shape, device=device, dtype=dtype)
+        self.memset(t, 0)
+        return t
+
+    def absmax(self, x, out, n):
+        _check(load().sep_absmax(_ptr(x, _f32), n, _ptr(out, _f32), _stream()), "sep_absmax")
+
+    def pit_finish(self, best_val, best_idx, perms, P, n, B, sign, scale, loss, gw, pattern):
+        _check(load().sep_pit_finish(_ptr(best_val, _f32), _ptr(best_idx, torch.int64), _ptr(perms, torch.int32), P, n, B, sign, scale,
+                                     _ptr(loss, _f32), _ptr(gw, _f32), _ptr(pattern, torch.int64), _stream()), "sep_pit_finish")
 
     def adam_step(self, p, g, m, v, sqnorm, n, lr, beta1, beta2, eps, weight_decay, max_norm, grad_scale, step):
         _check(load().sep_adam_step(_ptr(p, _f32), _ptr(g, _f32), _ptr(m, _f32), _ptr(v, _f32), _ptr(sqnorm, _f64), n, lr, beta1,

@@ -821,14 +821,31 @@ class TokenGLNFn(torch.autograd.Function):
         return dx, tot[0], tot[1], None
 
 
+_seed_state = {"gen": None, "key": None, "counter": 0, "rank": None}
+
+
 def _dropout_seed(t):
-    """a 62-bit seed for a hash-masked dropout (sep_attn_*, sep_rownorm_*): drawn on the host from the CPU generator (torch.manual_seed
-    reaches it, no device sync), with the rank and the device folded in -- data-parallel ranks seeded alike must not drop the same elements"""
-    if t.is_cuda and torch.cuda.is_current_stream_capturing():
-        raise RuntimeError("this dropout takes its seed on the host: a captured step would replay ONE mask (use p = 0 or launch eagerly)")
-    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-    rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
-    return (seed ^ (0x9E3779B97F4A7C15 * (1 + rank + 1024 * (t.device.index or 0)))) & (2 ** 62 - 1)
+    """a 62-bit seed for a hash-masked dropout (sep_attn_*, sep_rownorm_*).  ONE draw from the global CPU generator per (torch.manual_seed
+    state seen at the first site of a process / after a re-seed) starts a dedicated generator; every site then takes the next value of
+    that generator: no .item() on the global stream per site (a SepFormer step has ~50 sites: that shifted the data shuffling against the
+    reference for the same manual_seed and cost host time on a launch-bound step).  The rank (cached) and the device are folded in --
+    data-parallel ranks seeded alike must not drop the same elements."""
+    st = _seed_state
+    key = torch.initial_seed()
+    if st["gen"] is None or st["key"] != key:
+        st["gen"] = torch.Generator().manual_seed(int(torch.randint(0, 2 ** 62, (1,)).item()) ^ (key & (2 ** 62 - 1)))
+        st["key"], st["counter"] = key, 0
+    if st["rank"] is None or st["counter"] % 4096 == 0:
+        st["rank"] = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+    st["counter"] += 1
+    seed = int(torch.randint(0, 2 ** 62, (1,), generator=st["gen"]).item())
+    return (seed ^ (0x9E3779B97F4A7C15 * (1 + st["rank"] + 1024 * (t.device.index or 0)))) & (2 ** 62 - 1)
+
+
+def _contiguous16(t):
+    """contiguous AND 16-byte aligned (an incoming gradient may be an offset view of a larger buffer): the float4 kernels' operand form"""
+    t = t.contiguous()
+    return t if t.data_ptr() % 16 == 0 else t.clone()
 
 
 def _aligned16(t):
@@ -844,7 +861,7 @@ class RowNormFn(torch.autograd.Function):
     (GALRNet's channel norm, models/galr.py:172-190).  The dropout mask is a hash of (seed, element), formed again in the backward pass."""
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, eps, p_drop):
+    def forward(ctx, x, res, gamma, beta, eps, p_drop, keep=True):
         K = backend()
         x = x.contiguous()
         C = x.shape[-1]
@@ -853,7 +870,9 @@ class RowNormFn(torch.autograd.Function):
             res = res.contiguous()
         p_drop = float(p_drop) if res is not None else 0.0
         seed = _dropout_seed(x) if p_drop > 0 else 0
-        keep = res is not None and any(ctx.needs_input_grad[:4])      # the sum is the backward pass's operand: not written under no_grad
+        # keep: the sum x + dropout(res) is the backward pass's operand -- decided by the CALLER (residual_layer_norm), where the grad mode
+        # is still visible: inside Function.forward it is always off and needs_input_grad ignores torch.no_grad()
+        keep = res is not None and bool(keep)
         s = torch.empty_like(x) if keep else None
         y = torch.empty_like(x)
         stat = torch.empty(rows, 2, device=x.device, dtype=x.dtype)
@@ -870,22 +889,25 @@ class RowNormFn(torch.autograd.Function):
         ds = torch.empty_like(s)
         dres = torch.empty_like(s) if p_drop > 0 else None
         part = torch.empty(K.rownorm_parts(rows, C), 2, C, device=s.device, dtype=s.dtype)
-        K.rownorm_bwd(dy.contiguous(), s, gamma, stat, ds, dres, part, rows, C, p_drop, seed)
+        if s is None:
+            raise RuntimeError("RowNormFn: the forward pass ran without keeping its sum (keep=False) and cannot be differentiated")
+        K.rownorm_bwd(_contiguous16(dy), s, gamma, stat, ds, dres, part, rows, C, p_drop, seed)
         tot = part.sum(0)
-        return ds, ((dres if dres is not None else ds) if has_res else None), tot[0], tot[1], None, None
+        return ds, ((dres if dres is not None else ds) if has_res else None), tot[0], tot[1], None, None, None
 
 
 def rownorm_ok(x, norm):
     """can `norm` (an nn.LayerNorm over the last axis, with gain and shift) run on sep_rownorm_* for rows x (..., C)?"""
     C = x.shape[-1]
     return (isinstance(norm, torch.nn.LayerNorm) and tuple(norm.normalized_shape) == (C,) and norm.weight is not None and norm.bias is not None
-            and C % 4 == 0 and 4 <= C <= 1024 and x.numel() > 0 and takes(x) and _aligned16(x))
+            and C % 4 == 0 and 4 <= C <= 1024 and x.numel() > 0 and takes(x) and _aligned16(x) and _aligned16(norm.weight) and _aligned16(norm.bias))
 
 
 def residual_layer_norm(x, res, norm, p_drop=0.0):
     """norm(x + dropout(res, p_drop)) (res None: norm(x)): sep_rownorm_* where it applies, torch's kernels otherwise"""
     if rownorm_ok(x, norm) and (res is None or (res.shape == x.shape and res.dtype == x.dtype and _aligned16(res))):
-        return RowNormFn.apply(x, res, norm.weight, norm.bias, norm.eps, p_drop)
+        keep = torch.is_grad_enabled() and (x.requires_grad or (res is not None and res.requires_grad) or norm.weight.requires_grad or norm.bias.requires_grad)
+        return RowNormFn.apply(x, res, norm.weight, norm.bias, norm.eps, p_drop, keep)
     if res is not None:
         x = x + torch.nn.functional.dropout(res, p_drop, training=p_drop > 0)
     return torch.nn.functional.layer_norm(x, norm.normalized_shape, norm.weight, norm.bias, norm.eps)
@@ -910,7 +932,7 @@ class ReluDropFn(torch.autograd.Function):
         K = backend()
         a, = ctx.saved_tensors
         dh = torch.empty_like(a)
-        K.relu_drop_bwd(dy.contiguous(), a, dh, a.numel(), ctx.p_drop)
+        K.relu_drop_bwd(_contiguous16(dy), a, dh, a.numel(), ctx.p_drop)
         return dh, None
 
 

@@ -94,6 +94,12 @@ class Saved:
     pass
 
 
+def _zeros(K, *shape, **kw):
+    """torch.zeros through the backend: while a launch sequence is being recorded (sepkernels.Sequence) the clearing has to be one of its ops"""
+    z = getattr(K, "zeros", None)
+    return z(*shape, **kw) if z is not None else torch.zeros(*shape, **kw)
+
+
 def amax_over(ts):
     """(1,) tensor >= max|t| over the tensors ts.  Tensors that are views of ONE buffer take one reduction over the span they cover
     (alignment gaps included -- they are zero); a model whose parameters live in one flat buffer plus a few derived tensors (the bases of a
@@ -334,7 +340,7 @@ def _forward(cfg, P, mixture, want_latent, save):
     nl = len(layers)
     f32 = dict(device=dev, dtype=mixture.dtype)   # always fp32 in the product; the CPU emulator tests also run fp64
 
-    stats = torch.zeros(2 * nl + 1, B, STATS_SLOTS, 2, device=dev, dtype=torch.float64)
+    stats = _zeros(K, 2 * nl + 1, B, STATS_SLOTS, 2, device=dev, dtype=torch.float64)
     PK = pack_weights(cfg, P, need_bwd=save)
     geo, w, x = head_forward(cfg, P, mixture, stats[0], PK)
 
@@ -497,7 +503,7 @@ def _backward(cfg, P, sv, d_est, G, on_ready, want_dmix=False):
     f32 = dict(device=dev, dtype=mixture.dtype)   # always fp32 in the product; the CPU emulator tests also run fp64
     chunks = B * (ldt // 32)
     nt64, nt1024 = ldt // 64, (ldt + 1023) // 1024
-    dalpha = torch.zeros(nl + 1, device=dev, dtype=torch.float64)   # [layer alpha1 ..., mask prelu]
+    dalpha = _zeros(K, nl + 1, device=dev, dtype=torch.float64)   # [layer alpha1 ..., mask prelu]
     # gLN backward needs two per-sample means of the incoming gradient g -- mean(gamma g), mean(gamma g xhat) -- before any element of the
     # input gradient can be formed.  Inside the TCN layers the kernel that PRODUCES g's sums finishes them: its workgroups add their
     # gamma-weighted totals to fp64 slots (bacc, laid out like `stats`: [1 + 2 li] / [2 + 2 li] = gLN1 / gLN2 of layer li), count their
@@ -506,8 +512,8 @@ def _backward(cfg, P, sv, d_est, G, on_ready, want_dmix=False):
     # thousands of short workgroups -- only adds to the slots and one thread per workgroup of the conv1^T product forms the means
     # (pro_bacc): the arrival protocol cost that kernel +10 us per launch.  sep_gln_bwd_finalize still turns gLN1's row partials into
     # parameter gradients, as a leaf.
-    bacc = torch.zeros(2 * nl + 1, B, STATS_SLOTS, 2, device=dev, dtype=torch.float64)
-    arrive = torch.zeros(2 * nl + 1, B, ARRIVE_INTS, device=dev, dtype=torch.int32)
+    bacc = _zeros(K, 2 * nl + 1, B, STATS_SLOTS, 2, device=dev, dtype=torch.float64)
+    arrive = _zeros(K, 2 * nl + 1, B, ARRIVE_INTS, device=dev, dtype=torch.int32)
     bsum = torch.empty(2 * nl + 1, B, 2, **f32)
     def wgrad(M, Nn, Gt, Xt, dW, dbias=None, Bq=B, weps=None, **kw):
         return _wgrad(K, B, F, ldt, eps, f32, M, Nn, Gt, Xt, dbias is not None, Bq=Bq, weps=weps, **kw)

@@ -10,11 +10,15 @@ reference's single-process result.  The collective is 19.9 MB per step (4,984,88
 bandwidth-bound on 7 x 153 GB/s xGMI links; it is issued in three asynchronous pieces (one per TCN block, last block
 first) so that most of it hides under the rest of backward (SEPK_DDP_BUCKETS=0: one call after backward).
 
-hipGraph: a step is ~400 kernel launches with fixed shapes, and the gaps between them were 10-17 % of the profiled wall time
-(profiles/r02c_kernel_stats.md).  `capture(mixture, sources)` records ONE step -- forward, criterion, backward on both streams,
-clip, Adam -- into a graph over static input buffers and the caching allocator's private pool; later calls with the same shapes
-copy their batch in and replay it.  The two scalars that change from step to step (Adam's step count, the learning rate) live in
-device memory for that (sep_adam_step_dev).  Single-process only: the RCCL all-reduce stays eager.
+One call per pass: a step is ~360 kernel launches of fixed shapes, and driven from Python each costs ~30 us of interpreter time -- below
+~10 utterances per GPU (the recipes train with 2 - 4) the eager step is bound by that, not by the GPU.  `record(mixture, sources)` runs ONE
+step through the ordinary entry points while the binding records every launch (sepkernels.Sequence: entry point + arguments, forward,
+criterion, backward, clip, Adam -- all of it library entry points, no torch kernel in between); later calls with the same shapes copy
+their batch into the recorded input buffers and hand the list to sep_run_sequence, a C loop over the same entry points (include/sepkernels.h,
+ABI 23).  The two scalars that change from step to step (Adam's step count, the learning rate) live in device memory for that
+(sep_adam_step_dev).  No hipGraph: replays of the captured full-size step were measured wrong in half the runs on this stack
+(profiles/r07_round5_experiments.md, r07m) and that path (FusedTrainStep.capture, GraphedStep) is gone.  Single-process only so far: with
+ranks > 1 the step stays eager (the bucketed all-reduces are issued from inside backward).
 """
 import os
 
@@ -26,8 +30,11 @@ import sepkernels
 
 class FusedTrainStep:
     def __init__(self, model, criterion, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=5.0,
-                 process_group=None, distributed=None, uneven_batches=False, time_collectives=False, exercise_collectives=False):
+                 process_group=None, distributed=None, uneven_batches=False, time_collectives=False, exercise_collectives=False, auto_record=None):
         self.model, self.criterion = model, criterion
+        # auto_record: the first call on a GPU batch records the step (record()), later calls of that shape replay it; other shapes, other
+        # criteria and ranks > 1 step eagerly.  Default: the SEPK_SEQUENCE switch (off unless SEPK_SEQUENCE=1).
+        self.auto_record = (os.environ.get("SEPK_SEQUENCE", "0") == "1") if auto_record is None else bool(auto_record)
         self.lr, self.betas, self.eps, self.weight_decay, self.max_norm = lr, betas, eps, weight_decay, max_norm
         self.group = process_group
         self.distributed = dist.is_available() and dist.is_initialized() if distributed is None else distributed
@@ -57,8 +64,8 @@ class FusedTrainStep:
         self.time_collectives = bool(time_collectives)
         self.last_comm = None
         self.last_bucket_bytes = []
-        # graph state (see capture())
-        self._graph = None
+        # recorded-sequence state (see record())
+        self._seq = None
         self._static = None
         self._step_dev = None
         self._lr_dev = None
@@ -100,66 +107,137 @@ class FusedTrainStep:
         self.flat = flat
         self.gflat, self.m, self.v = (t.to(flat.device) for t in (self.gflat, self.m, self.v))
         self.sqnorm = self.sqnorm.to(flat.device)
-        self._graph = None          # a captured step writes through the OLD buffers' addresses: it has to be recorded again
+        self._seq = None            # a recorded step writes through the OLD buffers' addresses: it has to be recorded again
 
-    # ---- hipGraph of the whole step -----------------------------------------------------------------------------------
-    def capture(self, mixture, sources, warmup=3):
-        """Record one step on inputs of this shape.  `warmup` eager steps run first on a side stream (allocator and lazy
-        initialisation settle there, as torch.cuda.graphs asks for); they ARE training steps.  Returns the loss of the captured step
-        (which is executed too).
-        EXPERIMENTAL on this stack (ROCm 7.0 / torch 2.10): the replayed step equals the eager one on the small configurations of the
-        tests, but replays of the paper-best step at 16 utterances ended with wrong losses (inf, 49.98 for 0.0812) in about half of 20 runs
-        (profiles/r07_round5_experiments.md, r07m) -- the runtime's pre-built graph packets: with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 every replay is
-        right to the last bit and no faster than eager launches (r07o).  The eager step is the product's step, and bench.py's default."""
+    # ---- the whole step as one recorded launch sequence ---------------------------------------------------------------------
+    def recordable(self):
+        """None when record() can take this step, else the reason it cannot"""
+        from criterion.pit import PIT
+        from criterion.sdr import SISDR, NegSISDR
         if self.comm:
-            raise RuntimeError("graph capture of the train step is single-process only (the gradient all-reduce stays eager)")
-        if not getattr(self.model, "fused", True):
-            # measured (profiles/r07_round5_experiments.md, r07k): the staged causal sequence records, but its replay ends in a GPU memory
-            # access fault -- the layer-by-layer autograd Functions own workspaces the capture does not pin.  Refused instead of offered.
-            raise RuntimeError("graph capture is offered for the fused kernel sequence only; this model runs the {} path".format(
-                "derived-basis" if getattr(self.model, "fused_derived", False) else "staged" if getattr(self.model, "staged", False) else "composed"))
+            return "ranks > 1: the bucketed gradient all-reduces are issued from inside backward (eager)"
+        if not getattr(self.model, "fused", False):
+            return "the recorded step is offered for the fused kernel sequence only; this model runs the {} path".format(
+                "derived-basis" if getattr(self.model, "fused_derived", False) else "staged" if getattr(self.model, "staged", False) else "composed")
+        c = self.criterion
+        if not (isinstance(c, PIT) and type(c.criterion) in (SISDR, NegSISDR) and c.criterion.reduction in ("mean", "sum")):
+            return "the recorded step implements PIT over SI-SDR / NegSI-SDR (criterion.pit.PIT1d(NegSISDR())); other criteria run eagerly"
+        if self._trainable_mask() is not None:
+            return "frozen parameters (requires_grad = False) are handled by the eager step"
+        if os.environ.get("SEPK_SIDE_STREAM", "0") == "1":
+            return "SEPK_SIDE_STREAM=1 puts the weight gradients on a second stream: eager only"
+        if getattr(self.model, "in_channels", 1) != 1:
+            return "multi-channel input: the recorded criterion scores (B, n_sources, T) estimates"
+        return None
+
+    def record(self, mixture, sources):
+        """Run ONE training step on this batch while recording every launch, and keep the list: later calls with batches of the same shape
+        replay it through sep_run_sequence (one C-ABI call per step).  Returns the loss of the recorded step (it IS a training step).
+        The step is the eager one's arithmetic, launch for launch; only the glue differs: clearing of accumulators by sep_memset, the
+        weight bound by sep_absmax, the tail of PIT (batch mean, gradient weights of the chosen permutation) by sep_pit_finish instead of
+        torch kernels.  reference: egs/wsj0-mix/common/src/driver.py:141-157."""
+        from . import net as _net
+        from criterion.sdr import NegSISDR
+        why = self.recordable()
+        if why is not None:
+            raise RuntimeError("FusedTrainStep.record: " + why)
+        self._rebind()
+        K = sepkernels.backend()
+        model, crit = self.model, self.criterion.criterion
         dev = self.flat.device
-        self._static = (torch.empty_like(mixture), torch.empty_like(sources))
+        B, n_src, T = sources.shape
+        if tuple(mixture.shape) != (B, 1, T) or n_src != model.n_sources:
+            raise ValueError("record: mixture {} / sources {} do not fit a {}-source model".format(tuple(mixture.shape), tuple(sources.shape), model.n_sources))
+        f32 = dict(device=dev, dtype=torch.float32)
+        self._static = (mixture.detach().to(**f32).contiguous().clone(), sources.detach().to(**f32).contiguous().clone())
+        mix, src = self._static
+        self._lr_dev = torch.tensor([self.lr], **f32)
+        self._lr_host = self.lr
+        self._step_dev = torch.tensor([self.step_count], device=dev, dtype=torch.int32)
+        named = model._named_tensors()
+        P = {k: v.detach() for k, v in named}
+        offs, total = model._offsets, self.gflat.numel()
+        G = {k: self.gflat[offs[k]:offs[k] + v.numel()].view(v.shape) for k, v in named}
+        cfg = model.get_config()
+        patterns = self.criterion.patterns
+        Pn = patterns.size(0)
+        perms32 = patterns.to(device=dev, dtype=torch.int32).contiguous()
+        sign = -1.0 if isinstance(crit, NegSISDR) else 1.0
+        scale = 1.0 / (B * n_src) if crit.reduction == "mean" else 1.0 / B
+        self.zero_grad()
+        seq = sepkernels.Sequence()
+        out = {}
+        with torch.no_grad(), sepkernels.recording(seq):
+            amax = None
+            if sepkernels.gemm_arith() == sepkernels.ARITH_F16X3 and hasattr(K, "absmax"):
+                amax = torch.empty(1, **f32)
+                K.absmax(self.flat, amax, self.flat.numel())          # (alignment gaps of the flat buffer hold zeros)
+            prev = sepkernels.set_weights_amax(amax)
+            try:
+                est, _, sv = _net._forward(cfg, P, mix, False, True)
+                est3 = est.view(B, n_src, T)
+                # PIT over the SI-SDR pair matrix (criterion/pit.py::_fused_pit, criterion/sdr.py::_SISDRPairsFn), launch for launch
+                dots = K.zeros(B, n_src, n_src, device=dev, dtype=torch.float64)
+                tt = K.zeros(B, n_src, device=dev, dtype=torch.float64)
+                xx = K.zeros(B, n_src, device=dev, dtype=torch.float64)
+                val = torch.empty(B, n_src, n_src, **f32)
+                K.sisdr_dots(est3, src, dots, tt, xx, B, n_src, T, True)
+                K.sisdr_from_dots(dots, tt, xx, val, B, n_src, True, crit.eps)
+                best_val = torch.empty(B, **f32)
+                best_idx = torch.empty(B, device=dev, dtype=torch.int64)
+                K.pit_search(val, perms32, Pn, n_src, B, True, crit.reduction == "mean", best_val, best_idx)      # max SI-SDR = min NegSI-SDR
+                loss = torch.empty(1, **f32)
+                gw = torch.empty(B, n_src, n_src, **f32)
+                pattern = torch.empty(B, n_src, device=dev, dtype=torch.int64)
+                K.pit_finish(best_val, best_idx, perms32, Pn, n_src, B, sign, scale, loss, gw, pattern)
+                d_est = torch.empty_like(est3)
+                K.sisdr_bwd(est3, src, dots, tt, xx, gw, d_est, B, n_src, T, True, crit.eps)
+                _net._backward(cfg, P, sv, d_est.view(B, n_src, 1, T), G, None, False)
+            finally:
+                sepkernels.set_weights_amax(prev)
+            n = self.gflat.numel()
+            K.memset(self.sqnorm, 0)
+            if self.max_norm and self.max_norm > 0:
+                K.sqnorm(self.gflat, self.sqnorm, n)
+            K.adam_step_dev(self.flat, self.gflat, self.m, self.v, self.sqnorm, n, self._lr_dev, self._step_dev, self.betas[0], self.betas[1],
+                            self.eps, self.weight_decay, float(self.max_norm or 0.0), 1.0)
+            out["loss"], out["pattern"] = loss, pattern
+        self.step_count += 1
+        self._seq = seq
+        self._seq_loss, self.last_pattern = out["loss"].view(()), out["pattern"]
+        self._seq_key = (tuple(mixture.shape), tuple(sources.shape), tuple(self.betas), self.eps, self.weight_decay, self.max_norm,
+                         sepkernels.gemm_arith(), id(self.criterion))
+        return self._seq_loss
+
+    def _seq_valid(self, mixture, sources):
+        return self._seq is not None and self._seq_key == (tuple(mixture.shape), tuple(sources.shape), tuple(self.betas), self.eps, self.weight_decay,
+                                                           self.max_norm, sepkernels.gemm_arith(), id(self.criterion))
+
+    def _replay(self, mixture, sources):
+        if self.model.flat_parameters() is not self.flat:      # model.to() / .float() since the recording: the list is stale
+            self._seq = None
+            return self._eager(mixture, sources)
         self._static[0].copy_(mixture)
         self._static[1].copy_(sources)
-        self._lr_dev = torch.tensor([self.lr], device=dev, dtype=torch.float32)
-        s = torch.cuda.Stream(device=dev)
-        s.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(s):
-            for _ in range(warmup):
-                self._eager(*self._static)
-        torch.cuda.current_stream(dev).wait_stream(s)
-        self._step_dev = torch.tensor([self.step_count], device=dev, dtype=torch.int32)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._static_loss = self._eager(*self._static, graph=True)
-        self._graph = g
-        self._graph_shapes = (tuple(mixture.shape), tuple(sources.shape))
-        self._graph_hyper = (tuple(self.betas), self.eps, self.weight_decay)
-        # capture only records: run the step it recorded once, so that the caller sees warmup + 1 steps done
-        return self._replay()
-
-    def _replay(self):
-        if self.model.flat_parameters() is not self.flat:      # model.to() / .float() since the capture: the graph is stale
-            self._graph = None
-            return self._eager(*self._static)
-        self._lr_dev.fill_(self.lr)
-        self._graph.replay()
+        if self._lr_host != self.lr:
+            self._lr_dev.fill_(self.lr)
+            self._lr_host = self.lr
+        self._seq.run()
         self.step_count += 1
-        return self._static_loss
+        return self._seq_loss
 
     def __call__(self, mixture, sources):
-        if self._graph is not None and (tuple(mixture.shape), tuple(sources.shape)) == self._graph_shapes:
-            self._static[0].copy_(mixture)
-            self._static[1].copy_(sources)
-            return self._replay()
+        if self._seq is not None:
+            if self._seq_valid(mixture, sources):
+                return self._replay(mixture, sources)
+        elif self.auto_record and mixture.is_cuda and self.recordable() is None:
+            return self.record(mixture, sources)
         return self._eager(mixture, sources)
 
-    def _eager(self, mixture, sources, graph=False):
+    def _eager(self, mixture, sources):
         K = sepkernels.backend()
         model = self.model
-        if not graph:
-            self._rebind()
+        self._rebind()
         self.zero_grad()
         model._grad_sink = self.gflat                 # backward writes every gradient straight into the flat buffer
         model._sink_placed = False
@@ -230,15 +308,11 @@ class FusedTrainStep:
         self.sqnorm.zero_()
         if self.max_norm and self.max_norm > 0:
             K.sqnorm(self.gflat, self.sqnorm, n)
-        if graph:
-            K.adam_step_dev(self.flat, self.gflat, self.m, self.v, self.sqnorm, n, self._lr_dev, self._step_dev, self.betas[0], self.betas[1],
-                            self.eps, self.weight_decay, float(self.max_norm or 0.0), grad_scale)
-        else:
-            self.step_count += 1
-            if self._step_dev is not None:
-                self._step_dev.fill_(self.step_count)          # an eager step between replays (other shapes) keeps the device count in step
-            K.adam_step(self.flat, self.gflat, self.m, self.v, self.sqnorm, n, self.lr, self.betas[0], self.betas[1], self.eps,
-                        self.weight_decay, float(self.max_norm or 0.0), grad_scale, self.step_count)
+        self.step_count += 1
+        if self._step_dev is not None:
+            self._step_dev.fill_(self.step_count)          # an eager step between replays (other shapes) keeps the device count in step
+        K.adam_step(self.flat, self.gflat, self.m, self.v, self.sqnorm, n, self.lr, self.betas[0], self.betas[1], self.eps,
+                    self.weight_decay, float(self.max_norm or 0.0), grad_scale, self.step_count)
         if frozen is not None:
             self.flat.mul_(mask).add_(frozen)
             self.m.mul_(mask)
@@ -302,99 +376,7 @@ class FusedTrainStep:
             if len(set(steps)) != 1:
                 raise ValueError("per-parameter Adam step counts differ; the fused step keeps one")
             self.step_count = steps[0]
-        # a captured step carries betas / eps / weight_decay as launch constants and the step count in device memory: refresh the count,
-        # and drop the graph if any of the constants moved (capture() records it again)
+        # a recorded step carries betas / eps / weight_decay as launch constants (its key: a change makes __call__ step eagerly until
+        # record() is called again) and the step count in device memory: refresh the count
         if self._step_dev is not None:
             self._step_dev.fill_(self.step_count)
-        if self._graph is not None and getattr(self, "_graph_hyper", None) != (tuple(self.betas), self.eps, self.weight_decay):
-            self._graph = None
-
-
-
-class GraphedStep:
-    """forward + criterion + backward [+ clip] + optimizer step of ANY separator of this tree, recorded once into a hipGraph and replayed.
-
-    For separators whose parameters are ordinary tensors (DPRNN-TasNet, DPTNet ...; ConvTasNet has FusedTrainStep.capture): shapes are
-    fixed and nothing in these steps reads back to the host, so the whole step can be one graph launch.  `optimizer` must keep its state
-    on the device and step without a host sync (torch.optim.Adam(..., capturable=True)).  Measured on MI355X (profiles/r04d_dual.txt):
-    replay equals the eager step to 1e-4 (tests/test_gpu_model.py) and takes the SAME time at the recipes' sizes (DPRNN-TasNet 36.9 ms
-    either way: the step is bound by its kernels) -- it pays where the launches are the bottleneck (small batches, short utterances).
-    Models with dropout diverged under replay on this stack (GALRNet, SepFormer: loss inf): use it for dropout-free configurations.
-
-        step = GraphedStep(model, criterion, optimizer, max_norm=5.0)
-        loss = step(mixture, sources)          # first call: three eager steps on a side stream (allocator warm-up), capture, then replay
-
-    The warm-up and the recording run real optimizer steps; `restore=True` (default) puts parameters, gradients-free, and the Adam
-    moments / step counts back IN PLACE afterwards (the graph holds their addresses), so that the first replay is the first step.
-    Batches of another shape need another GraphedStep.  reference: egs/wsj0-mix/common/src/driver.py:132-164 (the eager step)."""
-
-    def __init__(self, model, criterion, optimizer, max_norm=None, warmup=3, restore=True):
-        for g in optimizer.param_groups:
-            if not g.get("capturable", False):
-                raise ValueError("GraphedStep needs an optimizer that steps on the device: torch.optim.Adam(..., capturable=True)")
-        self.model, self.criterion, self.optimizer = model, criterion, optimizer
-        self.max_norm, self.warmup, self.restore = max_norm, int(warmup), bool(restore)
-        self._graph = self._static = self._loss = None
-
-    def _eager(self, mixture, sources):
-        self.optimizer.zero_grad(set_to_none=False)
-        out = self.criterion(self.model(mixture), sources)
-        loss = out[0] if isinstance(out, (tuple, list)) else out
-        loss.backward()
-        if self.max_norm is not None:
-            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_norm)
-        self.optimizer.step()
-        return loss.detach()
-
-    def capture(self, mixture, sources):
-        # Recorded dropout diverges on this stack (GALRNet / SepFormer at their recipe sizes: loss inf after the first replays,
-        # profiles/r04d_dual.txt -- the philox offset of the captured native_dropout does not advance as the eager one does): refuse
-        # rather than train on it.
-        live = [n for n, m in self.model.named_modules() if isinstance(m, torch.nn.modules.dropout._DropoutNd) and m.training and m.p > 0]
-        if live:
-            raise RuntimeError("GraphedStep: active dropout ({}{}) is not supported under hipGraph replay on this stack -- use the eager "
-                               "step, model.eval(), or dropout 0".format(", ".join(live[:3]), " ..." if len(live) > 3 else ""))
-        params = [p for p in self.model.parameters()]
-        saved = [p.detach().clone() for p in params] if self.restore else None
-        # optimizer state that exists ALREADY (continue_from / load_state_dict / earlier eager steps) is put back after the recording;
-        # only state born during the warm-up starts from zero
-        saved_state = {}
-        if self.restore:
-            for p, st in self.optimizer.state.items():
-                saved_state[p] = {k: v.detach().clone() for k, v in st.items() if torch.is_tensor(v)}
-        self._static = (mixture.clone(), sources.clone())
-        for p in params:                                   # gradients must exist (and keep their addresses) before the recording
-            if p.grad is None and p.requires_grad:
-                p.grad = torch.zeros_like(p)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(self.warmup):
-                self._eager(*self._static)
-        torch.cuda.current_stream().wait_stream(side)
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            self._loss = self._eager(*self._static)
-        if self.restore:
-            with torch.no_grad():
-                for p, s in zip(params, saved):
-                    p.copy_(s)
-                for p, st in self.optimizer.state.items():
-                    old = saved_state.get(p, {})
-                    for k, v in st.items():
-                        if torch.is_tensor(v):
-                            if k in old:
-                                v.copy_(old[k])            # in place: the graph holds the addresses
-                            else:
-                                v.zero_()                  # Adam-family state born in the warm-up starts at zero
-        return self
-
-    def __call__(self, mixture, sources):
-        if self._graph is None:
-            self.capture(mixture, sources)
-        elif mixture.shape != self._static[0].shape or sources.shape != self._static[1].shape:
-            raise ValueError("GraphedStep was recorded for batches of shape {} / {}".format(tuple(self._static[0].shape), tuple(self._static[1].shape)))
-        self._static[0].copy_(mixture)
-        self._static[1].copy_(sources)
-        self._graph.replay()
-        return self._loss

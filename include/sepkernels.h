@@ -33,7 +33,7 @@ extern "C" {
 
 typedef void* sep_stream_t; /* hipStream_t */
 
-#define SEP_ABI_VERSION 22
+#define SEP_ABI_VERSION 23
 #define SEP_STATS_SLOTS 16
 #define SEP_ARRIVE_INTS 17 /* arrival counters per sample: one per slot + one for the slots (csrc/common.hpp, gln_bwd_publish) */
 
@@ -493,6 +493,44 @@ int sep_linear_bwd_weight(const float* dy, const float* x, long ldx, float* part
  *   sep_tokens_to_chunk   the reverse, x (B, F, S, K) contiguous. */
 int sep_chunk_to_tokens(const float* x, float* y, int B, int F, int S, int K, int inter, sep_stream_t stream);
 int sep_tokens_to_chunk(const float* y, float* x, int B, int F, int S, int K, int inter, sep_stream_t stream);
+
+/* ---- recorded launch sequences (ABI 23) ------------------------------------------------------------------------------------
+ * One C-ABI call per pass instead of one Python call per kernel.  The host runs a step ONCE through the ordinary entry points while it
+ * records every call as a sep_seq_op -- the entry point's id (sep_seq_lookup) and its arguments in order, WITHOUT the trailing stream:
+ * pointers (device buffers, and HOST descriptors / segment arrays the caller keeps alive and unchanged) in .p, integers in .i, float /
+ * double parameters in .f.  sep_run_sequence then calls the same entry points again, in order, on `stream`; it stops at the first op that
+ * fails and returns that op's code (sep_last_error names the op).  The buffers named by the ops must stay allocated at the recorded
+ * addresses; values that change between runs live in device memory (sep_adam_step_dev's step count and learning rate, the input batch).
+ * Replaces the per-launch Python of the train step of reference egs/wsj0-mix/common/src/driver.py:141-157 (model(mixture) ->
+ * pit_criterion -> backward -> clip_grad_norm_ -> optimizer.step()); there is no FFI there to cite: the reference issues the same work as
+ * ~900 ATen launches from the interpreter. */
+#define SEP_SEQ_MAX_ARGS 26
+typedef union sep_seq_arg {
+    int64_t i;
+    double f;
+    const void* p;
+} sep_seq_arg;
+typedef struct sep_seq_op {
+    int32_t fn;    /* sep_seq_lookup(name) */
+    int32_t nargs; /* must equal sep_seq_nargs(fn) */
+    sep_seq_arg args[SEP_SEQ_MAX_ARGS];
+} sep_seq_op;
+int sep_seq_count(void);              /* number of recordable entry points: ids are 0 .. count-1 */
+int sep_seq_lookup(const char* name); /* id of the entry point `name`, -1 if it cannot be recorded (queries without a stream) */
+const char* sep_seq_name(int fn);
+int sep_seq_nargs(int fn); /* parameters of the entry point minus the stream */
+int sep_run_sequence(const sep_seq_op* ops_host, int n, sep_stream_t stream);
+
+/* What a fully recorded step needs where the eager step used torch kernels:
+ *   sep_memset      hipMemsetAsync on the stream (statistics slots, fp64 accumulators, arrival counters: `torch.zeros` in the eager step)
+ *   sep_absmax      out[0] = max |x[i]|: the A-operand bound a_amax of SEP_ARITH_F16X3 over the flat parameter buffer
+ *   sep_pit_finish  tail of PIT (criterion/pit.py:33-44) behind sep_pit_search, and its backward: loss[0] = sign * mean_b best_val[b];
+ *                   gw[b][i][j] = sign * scale if j == perms[best_idx[b]][i] else 0 (the dL/d sisdr matrix sep_sisdr_bwd takes: scale =
+ *                   1 / (B n) for a mean over sources and batch); pattern[b][i] = perms[best_idx[b]][i] (int64).  loss, gw, pattern may be NULL. */
+int sep_memset(void* dst, int value, size_t bytes, sep_stream_t stream);
+int sep_absmax(const float* x, int64_t n, float* out, sep_stream_t stream);
+int sep_pit_finish(const float* best_val, const int64_t* best_idx, const int32_t* perms, int P, int n, int B, float sign, float scale,
+                   float* loss, float* gw, int64_t* pattern, sep_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -259,6 +259,27 @@ def test_bench_gpus_flag_starts_the_ranks():
         assert k in out
 
 
+def test_bench_eight_ranks_dry_run_has_the_driver_run_shape():
+    """`python bench.py --gpus 8 --steps K --warmup W` exactly as the driver's scaling run issues it (default batch: 16 utterances per
+    rank), on this GPU-less box as the gloo dry run: eight ranks rendezvous on 127.0.0.1, every rank steps its own shard, the gradient
+    exchange goes out in three buckets (one per TCN block), the timing is the max over ranks, and stdout carries ONE JSON line -- rank 0's
+    -- with the whole-job figures (global batch 128).  So that the first real `--gpus 8` cannot fail on plumbing; no curve is claimed."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SEPK_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    json_lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(json_lines) == 1 and r.stdout.strip().splitlines()[-1] == json_lines[0]
+    out = json.loads(json_lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["parallelism"] == "dp8" and out["config"]["global_batch"] == 128 and out["config"]["per_gpu_batch"] == 16
+    assert out["config"]["ddp_buckets"] == 3 and out["scaling"] == "weak" and out["dry_run"]
+    assert out["steps"] == 2 and out["warmup"] == 1 and out["value"] > 0
+    assert abs(out["value"] - 128 * 499 / (out["ms_per_step"] * 1e-3)) <= 1e-3 * out["value"]      # whole-job frames (T = 4000 -> 499 frames) / the max-over-ranks step time
+
+
 def test_bench_without_gpu_fails_loudly():
     """no GPU, no dry-run switch: the bench refuses instead of measuring a fallback"""
     import subprocess

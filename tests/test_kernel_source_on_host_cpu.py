@@ -1,7 +1,7 @@
 """CPU: the HIP kernel files' OWN SOURCE executed on the host.  tools/hostsim.py compiles every file of csrc/ as plain C++ against a
 stand-in for the pieces of the HIP programming model they use (one host thread per lane, pthread barriers for workgroup and wave;
 shuffles, DPP, ballots and the MFMA instructions as collective operations of a wave; LDS-DMA as a wave-wide copy; the GEMM files' few
-inline-assembly helpers get a C++ body in the compiled copy) into a library with the same C ABI -- all 51 entry points -- and the kernel
+inline-assembly helpers get a C++ body in the compiled copy) into a library with the same C ABI -- every entry point -- and the kernel
 cases of tests/test_gpu_kernels.py -- the very functions that run on the MI355X -- are run against it here: encoder / unfold, depthwise forward / backward, gLN statistics / apply / backward pieces, head backward,
 decoder forward / backward, channel softmax, cLN, SI-SDR, PIT search, Sinkhorn, row distances, squared norm + Adam, chunking /
 overlap-add, the LSTM sweeps (both kernels: sixteen and four sequences per workgroup, forced per call),
@@ -176,6 +176,56 @@ def test_whole_fused_conv_tasnet_through_the_kernel_sources(on_host, golden_dir,
         r = torch.from_numpy(g["grad/" + k]).double()
         worst, scale = max(worst, (p.grad.double() - r).abs().max().item()), max(scale, r.abs().max().item())
     assert worst <= 1e-4 * scale, (worst, scale)
+
+
+def test_recorded_train_step_replays_through_sep_run_sequence(on_host):
+    """ABI 23 end to end on the kernel sources: FusedTrainStep.record runs one training step of the tiny Conv-TasNet (forward, PIT over the
+    SI-SDR pair matrix, backward, clip, Adam) while the binding records every launch; the next two steps are ONE sep_run_sequence call
+    each (the C loop of csrc/sequence.hip over the recorded ops, a learning-rate change in between through device memory).  Three eager
+    steps from the same start give the same losses to the last bit and the same parameters to an ulp: same entry points, same
+    arguments, same order -- and sep_memset / sep_absmax / sep_pit_finish do what the eager step's torch kernels do."""
+    import sepkernels
+    from oracle.make_golden import CONFIGS
+    from models.conv_tasnet import ConvTasNet
+    from criterion.sdr import NegSISDR
+    from criterion.pit import PIT1d
+    from sepkernels.train import FusedTrainStep
+
+    class Named:
+        name = "hostsim"
+
+        def __getattr__(self, attr):
+            return getattr(on_host, attr)
+    g = torch.Generator().manual_seed(5)
+    batches = [0.1 * torch.randn(2, 2, 1203, generator=g) for _ in range(3)]
+    old = sepkernels._set_backend_for_tests(Named())
+    runs = []
+    try:
+        for recorded in (False, True):
+            torch.manual_seed(1)
+            model = ConvTasNet(**CONFIGS["tiny"])
+            step = FusedTrainStep(model, PIT1d(NegSISDR(), n_sources=2), lr=1e-3, max_norm=5.0)
+            losses = []
+            for i, src in enumerate(batches):
+                mix = src.sum(1, keepdim=True).contiguous()
+                if i == 2:
+                    step.lr = 5e-4
+                if recorded and i == 0:
+                    losses.append(float(step.record(mix, src)))
+                    names = step._seq.names()
+                    assert names[0] == "sep_absmax" and names[-1] == "sep_adam_step_dev" and names.count("sep_pit_finish") == 1
+                    assert "sep_pw_gemm" in names and "sep_pw_wgrad" in names and "sep_memset" in names
+                else:
+                    losses.append(float(step(mix, src)))
+                    assert (step._seq is not None) == recorded
+            assert step.step_count == 3 and (not recorded or int(step._step_dev.item()) == 3)
+            runs.append((losses, model.flat_parameters().detach().clone(), step.last_pattern if recorded else None))
+    finally:
+        sepkernels._set_backend_for_tests(old)
+    (l0, p0, _), (l1, p1, pattern) = runs
+    assert l0 == l1 and l0[0] != l0[2], (l0, l1)
+    assert (p0 - p1).abs().max().item() <= 2e-7 * p0.abs().max().item()
+    assert pattern.shape == (2, 2) and sorted(pattern[0].tolist()) == [0, 1]
 
 
 def test_random_small_shapes_through_the_kernel_sources(on_host):

@@ -249,6 +249,8 @@ def dominant_kernel_roofline(by_kernel, arith_name):
            "traffic_over_algorithmic": e.get("traffic_over_algorithmic"),
            "avg_launch_us": e["avg_us"], "launches_per_step": e["launches_per_step"], "share_of_kernel_time": e["share_of_kernel_time"],
            "algorithmic_bytes_per_launch": e["algorithmic_MB_per_launch"] * 1e6,
+           # the same launch on SURVEY.md 8d's byte count (no `da` store-back, no re-read the fused minimum does not contain): the strictest of the figures
+           "frac_8d": e.get("hbm_frac_8d"), "bytes_8d_per_launch": e["survey_8d_MB_per_launch"] * 1e6 if "survey_8d_MB_per_launch" in e else None,
            "measured": "HIP events around every launch of this class on the launch stream (second pass of the same steps, one stream); achieved = "
                        "algorithmic bytes of the launch (every operand tensor once, fp32, valid frames) / average duration; traffic = rocprofv3 --pmc "
                        "FETCH_SIZE x2 + WRITE_SIZE of the same instance"}
@@ -324,7 +326,7 @@ def measure_pmc_traffic(batch, timeout_s=150):
     if exe is None:
         return None, "rocprofv3 not found"
     res = {}
-    env = dict(os.environ, SEPK_SIDE_STREAM="0", SEPK_GRAPH="0", TMPDIR="/tmp")      # (eager launches: one dispatch record per launch for the counters)
+    env = dict(os.environ, SEPK_SIDE_STREAM="0", SEPK_SEQUENCE="0", TMPDIR="/tmp")      # (eager launches: one dispatch record per launch for the counters)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -668,31 +670,6 @@ def bench_dual_path(args):
     el = time.perf_counter() - t0
     L, S = cfg["kernel_size"], cfg["stride"]
     F = (T_SAMPLES + (S - (T_SAMPLES - L) % S) % S - L) // S + 1
-    # Optional second leg (SEPK_GRAPH=1): the same step recorded into a hipGraph and replayed (sepkernels.train.GraphedStep).  Measured
-    # (profiles/r04d_dual.txt): replay = eager within 1 % for DPRNN-TasNet and DPTNet (36.9 vs 36.9, 45.2 vs 43.3 ms) -- these steps are
-    # bound by their kernels, not by the Python launches -- and the models with dropout (GALRNet, SepFormer) diverge under replay on this
-    # stack (loss inf), so the leg is off by default and flags itself invalid there.
-    graph_leg = None
-    if os.environ.get("SEPK_GRAPH", "0") == "1" and not args.no_graph:
-        try:
-            from sepkernels.train import GraphedStep
-            gopt = torch.optim.Adam(model.parameters(), capturable=True, **adam)
-            gstep = GraphedStep(model, crit, gopt, max_norm=5.0)
-            gstep.capture(mix, src)
-            for _ in range(args.warmup):
-                gstep(mix, src)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                gl = gstep(mix, src)
-            torch.cuda.synchronize()
-            gel = time.perf_counter() - t0
-            gl = float(gl)
-            graph_leg = {"ms_per_step": 1e3 * gel / args.steps, "value": B * F * args.steps / gel, "unit": "frames/s", "final_loss": gl,
-                         "valid": gl == gl and abs(gl) != float("inf"),
-                         "what": "the same step (fresh Adam state, parameters where the eager leg left them) as ONE hipGraph launch per step"}
-        except Exception as e:                                   # noqa: BLE001 -- a leg that cannot be recorded is reported, not fatal
-            graph_leg = {"error": "{}: {}".format(type(e).__name__, e)}
     config = {"workload": "{}, 2 spk, 4 s @ 8 kHz synthetic mixtures, batch {}{}, fwd + PIT(NegSI-SDR) + bwd + clip(5) + Adam".format(
                   label, B, " (recipe default)" if B == recipe_batch else " (recipe default: {})".format(recipe_batch)),
               "global_batch": B, "frames_per_utterance": F, "parallelism": "dp1", "utt_per_s": B * args.steps / el, "final_loss": float(loss),
@@ -707,6 +684,7 @@ def bench_dual_path(args):
         gbs = B * F * args.steps / el * by_frame / 1e9
         roofline = {"kernel": "whole step (staged sequence: sep_pw_gemm, sep_cln_*, sep_depthwise_*; per-kernel: profiles/r05zm_causal_kernel_stats.md)",
                     "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s", "frac": gbs / (HBM_PEAK_TBS * 1e3), "traffic": None,
+                    "frac_is": "of_fused_minimum (the staged sequence itself moves more bytes than SURVEY.md 8d's count: not comparable with a per-kernel frac)",
                     "matrix_pipe_frac": tf / (pipe / per),
                     "what": "algorithmic bytes of fwd + bwd ({} B per frame, SURVEY.md 8d: the fused non-causal sequence's minimum) x frames/s vs 8 TB/s".format(by_frame)}
         note = "{:.2f} GFLOP per utterance, {} B per frame (SURVEY.md 8d)".format(gflop, by_frame)
@@ -723,4 +701,4 @@ def bench_dual_path(args):
                   (" (BASELINE configs[3])" if args.config == "dprnn" else ""), "value": B * F * args.steps / el, "unit": "frames/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": config, "roofline": roofline, "roofline_note": note,
-        "peak_memory_GB": torch.cuda.max_memory_allocated() / 2 ** 30, "graph_replay": graph_leg}), flush=True)
+        "peak_memory_GB": torch.cuda.max_memory_allocated() / 2 ** 30}), flush=True)

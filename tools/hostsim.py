@@ -17,7 +17,7 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "dnn-based_source_separation_amd", "csrc")
-FILES = ("stream", "cln", "loss", "lstm", "linear", "attn", "rownorm", "gemm", "gemm_coop", "gemm_pc", "wgrad_pc", "wgrad_pc16")
+FILES = ("stream", "cln", "loss", "lstm", "linear", "attn", "rownorm", "gemm", "gemm_coop", "gemm_pc", "wgrad_pc", "wgrad_pc16", "sequence")
 _DYN = re.compile(r"extern __shared__ (?:__attribute__\(\(aligned\(\d+\)\)\) )?(\w+) (\w+)\[\];")
 
 # The GEMM files: helper functions whose bodies are inline assembly (or address-space casts) get a C++ body in the compiled copies.
@@ -130,13 +130,14 @@ class HostSimBackend:
             fn = getattr(lib, name, None)
             if fn is not None:                         # the GEMM entry points do not exist here
                 fn.argtypes = argtypes
-                fn.restype = ctypes.c_char_p if name == "sep_last_error" else ctypes.c_int
+                fn.restype = sepkernels._RESTYPES.get(name, ctypes.c_int)
         self._saved = (sepkernels._lib, sepkernels._ptr, sepkernels._stream)
 
         def ptr(t, dtype=None):
             if t is None:
                 return None
             assert not t.is_cuda and t.is_contiguous() and (dtype is None or t.dtype == dtype), (t.device, t.dtype, dtype)
+            sepkernels._keep(t)                        # (a Sequence being recorded keeps what its ops point at)
             return t.data_ptr()
         sepkernels._lib, sepkernels._ptr, sepkernels._stream = lib, ptr, (lambda: None)
         return sepkernels.HipBackend()

@@ -131,6 +131,11 @@ template <typename T, typename V> static inline void sim_atomic_store(T* p, V v,
 static inline float unsafeAtomicAdd(float* p, float v) { return atomicAdd(p, v); }          // the hardware fp32 atomic of the device build
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicMax(unsigned* p, unsigned v) {
+    unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }          // only used on wave-uniform values
