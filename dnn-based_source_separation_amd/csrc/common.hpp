@@ -152,3 +152,4 @@ int sep_pw_gemm_pc(const sep_gemm_desc* d, hipStream_t stream);
 int sep_pw_wgrad_pc(const sep_wgrad_desc* d, hipStream_t stream);
 // wgrad_pc16.hip: the same in the scaled two-part fp16 arithmetic (SEP_ARITH_F16X3; same contract)
 int sep_pw_wgrad_pc16(const sep_wgrad_desc* d, hipStream_t stream);
+int sep_pw_wgrad_pc16_batch(const sep_wgrad_desc* ds, int n, hipStream_t stream);

@@ -1724,6 +1724,38 @@ extern "C" int sep_pw_wgrad(const sep_wgrad_desc* d, sep_stream_t stream) {
     return 0;
 }
 
+extern "C" int sep_pw_wgrad_batch(const sep_wgrad_desc* ds, int n, sep_stream_t stream) {
+    SEP_REQUIRE(ds != nullptr && n >= 1 && n <= 8, "sep_pw_wgrad_batch: 1..8 products per call (got %d)", n);
+    bool same = true;
+    for (int k = 1; k < n; ++k) {
+        const sep_wgrad_desc &a = ds[0], &b = ds[k];
+        same = same && a.B == b.B && a.M == b.M && a.N == b.N && a.T == b.T && a.ldt == b.ldt && a.g_split == b.g_split && a.g_mul == b.g_mul &&
+               a.g_div == b.g_div && a.x_mode == b.x_mode && a.x_div == b.x_div && a.nsplit == b.nsplit && a.arith == b.arith && a.eps == b.eps &&
+               a.count == b.count && a.Gaux == b.Gaux && a.x_alpha == b.x_alpha && a.x_stats == b.x_stats && a.x_gamma == b.x_gamma &&
+               a.x_beta == b.x_beta && (a.G2 == nullptr) == (b.G2 == nullptr) && (a.partial_bias == nullptr) == (b.partial_bias == nullptr);
+    }
+    SEP_REQUIRE(same, "sep_pw_wgrad_batch: the products must agree in everything but G, G2, X, partial, partial_bias");
+    // one grid for all of them where the producer / consumer fp16 kernel takes the shape (checked like sep_pw_wgrad does, on the first)
+    const sep_wgrad_desc* d = &ds[0];
+    const bool plain_ok = d->B > 0 && d->M > 0 && d->N > 0 && d->T > 0 && d->ldt % 128 == 0 && d->ldt >= d->T && d->nsplit > 0 &&
+                          (long)d->nsplit <= (long)d->B * (d->ldt / DK) && !d->g_mul && d->x_div == 1 && d->arith == SEP_ARITH_F16X3 &&
+                          (!d->g_split || (d->g_split % BM == 0 && d->g_split < d->M)) && d->x_mode >= 0 && d->x_mode <= SEP_PRO_GLN_PRELU;
+    bool ptrs_ok = plain_ok;
+    for (int k = 0; k < n && ptrs_ok; ++k)
+        ptrs_ok = ds[k].G && ds[k].X && ds[k].partial && (!d->g_split || ds[k].G2);
+    if (ptrs_ok && (d->x_mode == SEP_PRO_NONE || ((d->x_mode == SEP_PRO_PRELU || d->x_mode == SEP_PRO_GLN_PRELU ? d->x_alpha != nullptr : true) &&
+                                                   (d->x_mode >= SEP_PRO_GLN ? (d->x_stats && d->x_gamma && d->x_beta && d->count > 0) : true))) &&
+        n > 1 && getenv("SEPK_WGRAD_BATCH_OFF") == nullptr && sep_pw_wgrad_pc16_batch(ds, n, (hipStream_t)stream)) {
+        SEP_CHECK_LAUNCH("sep_pw_wgrad_batch (pc16)");
+        return 0;
+    }
+    for (int k = 0; k < n; ++k) {               // any other shape / arithmetic: one launch per product, same results
+        const int rc = sep_pw_wgrad(&ds[k], stream);
+        if (rc != 0) return rc;
+    }
+    return 0;
+}
+
 extern "C" int sep_reduce_slabs(const sep_reduce_seg* segs, int nseg, sep_stream_t stream) {
     SEP_REQUIRE(segs && nseg >= 1 && nseg <= RMAXSEG, "sep_reduce_slabs: 1..64 segments per launch (got %d)", nseg);
     ReduceArgs a;

@@ -49,7 +49,7 @@ struct seq_entry { const char* name; seq_thunk call; int nargs; };
 
 // every entry point of include/sepkernels.h whose last parameter is the stream (the queries without one are not launches)
 const seq_entry SEQ_TABLE[] = {
-    SEQ_FN(sep_pw_gemm), SEQ_FN(sep_pack_weights), SEQ_FN(sep_pw_wgrad), SEQ_FN(sep_reduce_slabs), SEQ_FN(sep_f64_to_f32),
+    SEQ_FN(sep_pw_gemm), SEQ_FN(sep_pack_weights), SEQ_FN(sep_pw_wgrad), SEQ_FN(sep_pw_wgrad_batch), SEQ_FN(sep_reduce_slabs), SEQ_FN(sep_f64_to_f32),
     SEQ_FN(sep_encoder_fwd), SEQ_FN(sep_unfold), SEQ_FN(sep_dwconv_fwd), SEQ_FN(sep_dwconv_bwd), SEQ_FN(sep_gln_bwd_finalize),
     SEQ_FN(sep_gln_bwd_finalize_batch), SEQ_FN(sep_gln_bwd_from_wgrad), SEQ_FN(sep_head_bwd), SEQ_FN(sep_decoder_fwd),
     SEQ_FN(sep_decoder_bwd), SEQ_FN(sep_softmax_ch_fwd), SEQ_FN(sep_softmax_ch_bwd), SEQ_FN(sep_cln_fwd), SEQ_FN(sep_cln_bwd),

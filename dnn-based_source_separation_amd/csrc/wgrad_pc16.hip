@@ -136,8 +136,10 @@ __device__ __forceinline__ void w16_dma_pieces4(const float* pa, const unsigned 
                  : "=&s"(keep) : "v"(voffc[0]), "v"(voffc[1]), "v"(voffc[2]), "v"(voffc[3]), "s"(pa), "s"(lds1) : "memory", "scc");
 }
 
+// The kernel's body.  `bid` is the workgroup's index within ITS product: the single-product kernel passes blockIdx.x, the batched kernel
+// (several products of identical shape in one launch, see below) the index within the product's share of the grid.
 template <int WR, int WC, int XMODE>
-__global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_desc d) {
+__device__ __forceinline__ void w16_body(const sep_wgrad_desc& d, const int bid) {
     constexpr bool X_GLN = XMODE == SEP_PRO_GLN || XMODE == SEP_PRO_GLN_PRELU;
     constexpr bool X_PRELU = XMODE == SEP_PRO_PRELU || XMODE == SEP_PRO_GLN_PRELU;
     using Smem = W16Smem<WR, WC>;
@@ -154,7 +156,6 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
 
     const int ntm = d.M / TM, ntn = d.N / TN;
     const int ntiles = ntm * ntn;
-    const int bid = blockIdx.x;
     const int xcd = bid & 7, jj = bid >> 3;
     const int tile = jj % ntiles;
     const int s = (jj / ntiles) * 8 + xcd;
@@ -571,12 +572,44 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_d
     }
 }
 
+template <int WR, int WC, int XMODE>
+__global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_desc d) {
+    w16_body<WR, WC, XMODE>(d, (int)blockIdx.x);
+}
+
+// Several weight gradients of IDENTICAL shape and prologue in one launch (sep_pw_wgrad_batch): the conv1 weight gradients of consecutive TCN
+// layers are leaves of the backward pass -- nothing waits for them -- so the host holds them back and issues L of them together.  The
+// grid stays one workgroup per compute unit, so every product gets 1/L of the slabs: L times longer contractions per workgroup (the
+// first-chunk prologue and the 128 KiB slab store of a workgroup are paid once per L times as many chunks) and 1/L of the slab
+// traffic behind them (written here, read by sep_reduce_slabs).  Workgroups [k * per, (k + 1) * per) work on product k.
+constexpr int W16_MAXBATCH = 8;
+struct W16Batch {
+    sep_wgrad_desc d;                       // the common shape / prologue; its operand pointers are replaced per product
+    int per;                                // workgroups per product (a multiple of 8: the XCD decode of the body sees bid & 7 = blockIdx & 7)
+    const float* G[W16_MAXBATCH];
+    const float* G2[W16_MAXBATCH];
+    const float* X[W16_MAXBATCH];
+    float* partial[W16_MAXBATCH];
+    float* partial_bias[W16_MAXBATCH];
+};
+template <int WR, int WC, int XMODE>
+__global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_batch_kernel(const W16Batch b) {
+    const int k = (int)blockIdx.x / b.per;
+    sep_wgrad_desc d = b.d;
+    d.G = b.G[k]; d.G2 = b.G2[k]; d.X = b.X[k]; d.partial = b.partial[k]; d.partial_bias = b.partial_bias[k];
+    w16_body<WR, WC, XMODE>(d, (int)blockIdx.x - k * b.per);
+}
 
 template <int WR, int WC, int XMODE>
 void launch_w16(const sep_wgrad_desc& d, hipStream_t stream) {
     const int ntiles = (d.M / (64 * WR)) * (d.N / (128 * WC));
     const int grid = 8 * ntiles * ceil_div(d.nsplit, 8);
     hipLaunchKernelGGL((pw_wgrad_pc16_kernel<WR, WC, XMODE>), dim3(grid), dim3(512), 0, stream, d);
+}
+
+template <int WR, int WC, int XMODE>
+void launch_w16_batch(const W16Batch& b, int n, hipStream_t stream) {
+    hipLaunchKernelGGL((pw_wgrad_pc16_batch_kernel<WR, WC, XMODE>), dim3(n * b.per), dim3(512), 0, stream, b);
 }
 
 }  // namespace
@@ -603,4 +636,34 @@ int sep_pw_wgrad_pc16(const sep_wgrad_desc* d, hipStream_t stream) {
     }
 #undef SEP_LW
     return 0;
+}
+
+static bool w16_takes(const sep_wgrad_desc* d) {
+    static const bool off = getenv("SEPK_WGRAD_F16") != nullptr && atoi(getenv("SEPK_WGRAD_F16")) == 0;
+    if (off || d->arith != SEP_ARITH_F16X3 || d->g_mul || d->x_div != 1 || d->B > W16MAXB || d->g_split % 128 != 0) return false;
+    if (d->M % 256 != 0 || d->N % 128 != 0) return false;
+    if ((size_t)d->M * d->ldt * 4 >= (1ull << 32) || (size_t)d->N * d->ldt * 4 >= (1ull << 32)) return false;
+    if ((long)d->nsplit > (long)d->B * (d->ldt / DK)) return false;
+    return true;
+}
+
+// Called by sep_pw_wgrad_batch (gemm.hip): n products whose descriptors differ in G, G2, X, partial, partial_bias only (the caller has checked
+// that).  Returns 1 when they were launched here as ONE grid.
+int sep_pw_wgrad_pc16_batch(const sep_wgrad_desc* ds, int n, hipStream_t stream) {
+    if (n < 1 || n > W16_MAXBATCH || !w16_takes(&ds[0])) return 0;
+    W16Batch b;
+    b.d = ds[0];
+    const int ntiles = (ds[0].M / 256) * (ds[0].N / 128);
+    b.per = 8 * ntiles * ceil_div(ds[0].nsplit, 8);
+    for (int k = 0; k < W16_MAXBATCH; ++k) {
+        const sep_wgrad_desc& q = ds[k < n ? k : 0];
+        b.G[k] = q.G; b.G2[k] = q.G2; b.X[k] = q.X; b.partial[k] = q.partial; b.partial_bias[k] = q.partial_bias;
+    }
+    switch (ds[0].x_mode) {
+        case SEP_PRO_NONE: launch_w16_batch<4, 1, SEP_PRO_NONE>(b, n, stream); break;
+        case SEP_PRO_PRELU: launch_w16_batch<4, 1, SEP_PRO_PRELU>(b, n, stream); break;
+        case SEP_PRO_GLN: launch_w16_batch<4, 1, SEP_PRO_GLN>(b, n, stream); break;
+        default: launch_w16_batch<4, 1, SEP_PRO_GLN_PRELU>(b, n, stream); break;
+    }
+    return 1;
 }

@@ -125,6 +125,7 @@ SIGNATURES = {
     "sep_pw_gemm": [ctypes.POINTER(GemmDesc), _vp],
     "sep_pack_weights": [ctypes.POINTER(PackSeg), _I, _vp],
     "sep_pw_wgrad": [ctypes.POINTER(WgradDesc), _vp],
+    "sep_pw_wgrad_batch": [ctypes.POINTER(WgradDesc), _I, _vp],
     "sep_reduce_slabs": [ctypes.POINTER(ReduceSeg), _I, _vp],
     "sep_f64_to_f32": [_vp, _vp, _I, _I, _vp],
     "sep_encoder_fwd": [_vp, _vp, _vp, _vp] + [_I] * 10 + [_vp],
@@ -433,6 +434,19 @@ class HipBackend:
                       X=_ptr(X, _f32), x_alpha=_ptr(x_alpha, _f32), x_stats=_ptr(x_stats, _f64), x_gamma=_ptr(x_gamma, _f32),
                       x_beta=_ptr(x_beta, _f32), partial=_ptr(partial, _f32), partial_bias=_ptr(partial_bias, _f32))
         _check(load().sep_pw_wgrad(ctypes.byref(d), _stream()), "sep_pw_wgrad")
+
+    def pw_wgrad_batch(self, calls):
+        """calls: list (<= 8) of pw_wgrad keyword dicts that agree in everything but G, G2, X, partial, partial_bias: one launch"""
+        arr = (WgradDesc * len(calls))()
+        for k, c in enumerate(calls):
+            c = dict(c)
+            g = lambda name, default=None: c.get(name, default)
+            arr[k] = WgradDesc(B=c["B"], M=c["M"], N=c["N"], T=c["T"], ldt=c["ldt"], g_split=g("g_split", 0), g_mul=g("g_mul", 0), g_div=g("g_div", 1),
+                               x_mode=g("x_mode", PRO_NONE), x_div=g("x_div", 1), nsplit=c["nsplit"], arith=gemm_arith() if g("arith") is None else c["arith"],
+                               eps=g("eps", 1e-12), count=float(g("count", 0.0)), G=_ptr(c["G"], _f32), G2=_ptr(g("G2"), _f32), Gaux=_ptr(g("Gaux"), _f32),
+                               X=_ptr(c["X"], _f32), x_alpha=_ptr(g("x_alpha"), _f32), x_stats=_ptr(g("x_stats"), _f64), x_gamma=_ptr(g("x_gamma"), _f32),
+                               x_beta=_ptr(g("x_beta"), _f32), partial=_ptr(c["partial"], _f32), partial_bias=_ptr(g("partial_bias"), _f32))
+        _check(load().sep_pw_wgrad_batch(arr, len(calls), _stream()), "sep_pw_wgrad_batch")
 
     def reduce_slabs(self, segs):
         """segs: list of (src, src_offset_elems, dst, n, nslab, stride, accumulate, scale)"""

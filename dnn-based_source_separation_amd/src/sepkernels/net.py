@@ -530,6 +530,33 @@ def _backward(cfg, P, sv, d_est, G, on_ready, want_dmix=False):
     # after the loop instead of ~100 tiny launches inside it (each costs a ~5 us dispatch bubble on the critical path).
     # Price: the slabs of all layers stay alive until the flush (~1.6 GB at B=16 paper-best; HBM is 288 GB).
     pending = []
+    W1_BATCH = max(1, min(8, int(os.environ.get("SEPK_WGRAD_BATCH", "4"))))
+    w1_held = []                   # (da, x, parameter prefix) of layers whose conv1 weight gradient has not been issued yet
+
+    def flush_w1():
+        """the held conv1 weight gradients as one launch (side stream when that is on)"""
+        if not w1_held:
+            return
+        held = list(w1_held)
+        del w1_held[:]
+        with side:
+            ns = _nsplit(H, Bn, chunks, target_blocks=max(8, 512 // len(held)))
+            calls, segs = [], []
+            for da_k, x_k, pre_k in held:
+                part = torch.empty(ns, H, Bn, **f32)
+                pb = torch.empty(ns, H, **f32)
+                calls.append(dict(B=B, M=H, N=Bn, T=F, ldt=ldt, G=da_k, X=x_k, partial=part, partial_bias=pb, nsplit=ns, eps=eps))
+                segs += [(part, 0, G[pre_k + "bottleneck_conv1d.weight"], H * Bn, ns, H * Bn, 0, 1.0),
+                         (pb, 0, G[pre_k + "bottleneck_conv1d.bias"], H, ns, H, 0, 1.0)]
+            if len(calls) > 1 and hasattr(K, "pw_wgrad_batch"):
+                K.pw_wgrad_batch(calls)
+            else:
+                for c in calls:
+                    K.pw_wgrad(**c)
+            if side.on:
+                K.reduce_slabs(segs)
+            else:
+                pending.extend(segs)        # (side off: one stream, one pool -- nothing to lend)
     deferred = []                  # leaves of the layer just differentiated, queued on the side stream behind the next layer's hand-off
     finals = []                    # queued sep_gln_bwd_finalize calls (flushed with `pending`, in front of it)
     flushed_from = nl + 1          # dalpha entries [flushed_from, nl] are already converted (bucketed mode)
@@ -628,17 +655,11 @@ def _backward(cfg, P, sv, d_est, G, on_ready, want_dmix=False):
         # second stage of gLN1's backward (parameter gradients only: a leaf): queued, all layers of a flush go out in one launch per stage
         finals.append((rp1, nt1024, 8, st1, g1, cnt, teps, None, pbeta1, pgamma1, pextra, B, H))
 
-        def conv1_leaves(da=da, x=x, pre=pre):
-            """this layer's leaf on the side stream: the conv1 weight gradient"""
-            with side:
-                part, pb, ns = wgrad(H, Bn, da, x, True, True)
-                segs = [(part, 0, G[pre + "bottleneck_conv1d.weight"], H * Bn, ns, H * Bn, 0, 1.0),
-                        (pb, 0, G[pre + "bottleneck_conv1d.bias"], H, ns, H, 0, 1.0)]
-                if side.on:
-                    K.reduce_slabs(segs)
-                else:
-                    pending.extend(segs)        # (side off: one stream, one pool -- nothing to lend)
-        deferred.append(conv1_leaves)
+        # this layer's leaf: the conv1 weight gradient.  Nothing waits for it, so it is held back and issued together with its neighbours'
+        # (sep_pw_wgrad_batch: W1_BATCH products in one launch, each with 1 / W1_BATCH of the slabs; da and x stay alive until then)
+        w1_held.append((da, x, pre))
+        if len(w1_held) >= W1_BATCH:
+            deferred.append(flush_w1)
         dout = dx
         X_layers = cfg["sep_num_layers"]
         if on_ready is not None and li % X_layers == 0 and li > 0:
@@ -647,6 +668,7 @@ def _backward(cfg, P, sv, d_est, G, on_ready, want_dmix=False):
             for leaf in deferred:
                 leaf()
             deferred = []
+            flush_w1()
             side.join()
             blk = li // X_layers
             hi = nl + 1 if blk == cfg["sep_num_blocks"] - 1 else (blk + 1) * X_layers     # the last block also owns the mask PReLU slope
@@ -664,6 +686,7 @@ def _backward(cfg, P, sv, d_est, G, on_ready, want_dmix=False):
             on_ready(blk)
     for leaf in deferred:
         leaf()
+    flush_w1()
     side.join()
     # PReLU slope gradients were accumulated in fp64 (one scalar per layer + the mask PReLU): one conversion, then
     # scattered into the parameter gradients by the same flush

@@ -174,6 +174,12 @@ typedef struct sep_wgrad_desc {
 } sep_wgrad_desc;
 
 int sep_pw_wgrad(const sep_wgrad_desc* d, sep_stream_t stream);
+/* n <= 8 weight gradients that agree in EVERYTHING but G, G2, X, partial, partial_bias (e.g. the conv1 weight gradients of consecutive TCN layers,
+ * which nothing in the backward pass waits for), as ONE launch where the fp16 producer / consumer kernel takes the shape: the grid stays one
+ * workgroup per compute unit, so the caller gives every product 1/n of the slabs it would give a single call (nsplit of the descriptors) and
+ * gets n times longer contractions per workgroup and 1/n of the slab traffic.  Other shapes / arithmetics: n calls of sep_pw_wgrad.
+ * Same results as n separate calls with the same nsplit.  (ABI 23; reference: the same convolutions' weight gradients, tdcn.py:86.) */
+int sep_pw_wgrad_batch(const sep_wgrad_desc* descs_host, int n, sep_stream_t stream);
 
 /* dst[i] (+)= scale * sum_s src[s*stride + i] for up to 64 independent segments in one launch
  * (deterministic second stage of every split reduction). */

@@ -54,6 +54,8 @@ CASES = [
     ("test_chunk_tokens_layout_pair", [(2, 64, 5, 250), (1, 48, 3, 33), (3, 7, 2, 1)]),
     ("test_linear_forward_and_input_gradient", [(1000, 64, 512), (777, 256, 64), (130, 128, 128)]),
     ("test_tcn_layer_kernel_by_kernel_against_the_oracle", [(1, 128, 128, 128, 300, 2), (2, 128, 128, 128, 300, 4)]),
+    ("test_head_and_tail_kernel_by_kernel_against_the_oracle", [(1, 128, 128, 128, 2, 1203, True), (2, 128, 128, 128, 3, 1205, False)]),
+    ("test_criterion_kernels_against_the_oracle", [(2, 4, 8000), (4, 3, 4001)]),
     ("test_linear_weight_gradient", [(32, 20, 64, 512, 0, 7), (9, 31, 128, 512, -1, 3), (9, 31, 128, 512, 1, 5), (3, 7, 64, 64, -1, 1), (5, 250, 256, 64, 0, 40)]),
 ]
 
@@ -93,6 +95,8 @@ GEMM_CASES = [
     (None, "test_wgrad_f16_adversarial_operands", ("zero_rows_then_signal",)),
     ("f16x3", "test_wgrad_plain", (2, 512, 128, 999, 7)),                      # the scaled two-part fp16 weight-gradient kernel
     ("f16x3", "test_wgrad_two_sources_gln_prelu", ()),
+    ("f16x3", "test_wgrad_batch_equals_separate_calls", (1, 256, 128, 300, 2, 3)),   # the batched grid of the fp16 producer / consumer kernel
+    ("f32", "test_wgrad_batch_equals_separate_calls", (2, 64, 32, 201, 2, 2)),       # ... and the entry point's n-calls fallback
     (None, "test_pack_weights_reproduces_the_weights", ()),
     (None, "test_reduce_slabs_and_f64", ()),
 ]

@@ -90,6 +90,9 @@ class TimedBackend:
                 "mask" if kw.get("x_mode", 0) == 1 else "bottleneck" if kw.get("x_mode", 0) == 2 else "conv1" if M > N and N >= 64 else "basis / other"
             rows = M + N + (M if kw.get("g_mul") else 0) // max(1, kw.get("g_div", 1))
             return "wgrad " + cls, 2.0 * M * N * B * T, rows * col, (M + N) * col
+        if name == "pw_wgrad_batch":
+            rows = [TimedBackend._classify("pw_wgrad", (), c) for c in a[0]]
+            return rows[0][0], sum(r[1] for r in rows), sum(r[2] for r in rows), sum(r[3] for r in rows)
         if name == "dwconv_fwd":
             B, C, T = a[10], a[11], a[12]
             return "depthwise fwd", None, 2.0 * C * 4 * B * T, 2.0 * C * 4 * B * T
