@@ -530,7 +530,7 @@ def _backward(cfg, P, sv, d_est, G, on_ready, want_dmix=False):
     # after the loop instead of ~100 tiny launches inside it (each costs a ~5 us dispatch bubble on the critical path).
     # Price: the slabs of all layers stay alive until the flush (~1.6 GB at B=16 paper-best; HBM is 288 GB).
     pending = []
-    W1_BATCH = max(1, min(8, int(os.environ.get("SEPK_WGRAD_BATCH", "4"))))
+    W1_BATCH = max(1, min(8, int(os.environ.get("SEPK_WGRAD_BATCH", "8"))))      # measured on one box (profiles/r08b_wgrad_batch.txt): 15.81 / 15.60 / 15.42 / 15.40 ms per step at 1 / 2 / 4 / 8
     w1_held = []                   # (da, x, parameter prefix) of layers whose conv1 weight gradient has not been issued yet
 
     def flush_w1():
