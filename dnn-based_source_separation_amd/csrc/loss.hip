@@ -435,7 +435,7 @@ extern "C" int sep_rowdiff_bwd(const float* x, const float* t, const float* c_ab
 extern "C" int sep_sqnorm(const float* g, double* sqnorm, int64_t n, sep_stream_t stream) {
     SEP_REQUIRE(g && sqnorm && n > 0, "sep_sqnorm: bad arguments");
     int64_t blocks = (n + 1023) / 1024;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 256) blocks = 256;      // one fp64 atomic per workgroup on ONE address: 2048 of them serialised into ~30 us (profiles/r08a: 33 us for 20 MB)
     hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, sqnorm, n);
     SEP_CHECK_LAUNCH("sep_sqnorm");
     return 0;

@@ -556,7 +556,7 @@ def _backward(cfg, P, sv, d_est, G, on_ready, want_dmix=False):
             if side.on:
                 K.reduce_slabs(segs)
             else:
-                pending.extend(segs)        # (side off: one stream, one pool -- nothing to lend)
+                pending.extend(segs)        # (main stream: one pool -- nothing to lend)
     deferred = []                  # leaves of the layer just differentiated, queued on the side stream behind the next layer's hand-off
     finals = []                    # queued sep_gln_bwd_finalize calls (flushed with `pending`, in front of it)
     flushed_from = nl + 1          # dalpha entries [flushed_from, nl] are already converted (bucketed mode)
