@@ -484,7 +484,9 @@ __global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
         // z is not read: the row of v1 = gLN1(PReLU1(a)) goes to a second LDS row and z = bd + the three taps is formed again exactly as
         // dwconv_fwd_direct_kernel formed it (same expression, zero outside [0, T)) -- a quarter of the kernel's HBM bytes for 8 B of LDS
         // traffic per frame
-        float* v1s = lds + ldt;
+        // v1s and dzs are never live together (v1 is dead once every thread has formed its z): ONE LDS row serves both, behind one more
+        // barrier -- 16 KiB per workgroup at ldt = 4096 instead of 32: six workgroups per compute unit (the register limit) instead of four
+        float* v1s = lds;
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
             const int q = threadIdx.x + 256 * k;
@@ -520,6 +522,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
                 zv[k] = make_float4(o[0], o[1], o[2], o[3]);
             }
         }
+        __syncthreads();                                  // every neighbour read of v1 is done: the row becomes dz
     }
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
@@ -1662,7 +1665,7 @@ extern "C" int sep_dwconv_bwd(const float* dv2, const float* z, const float* a, 
     if (!force_tiles && ldt <= 8192 && (long)B * C <= 0x7fffffffL) {        // the row (ldt floats of LDS, ldt / 1024 float4 triples in registers)
         // with the depthwise bias at hand z is formed again from `a` instead of being read (two LDS rows): 3 streams of HBM instead of 4
         const bool recomp = bd != nullptr && !no_recompute;
-        const size_t rsmem = (size_t)ldt * sizeof(float) * (recomp ? 2 : 1);
+        const size_t rsmem = (size_t)ldt * sizeof(float);      // (the recomputing form's v1 row and the dz row share it)
         const dim3 grid((unsigned)((long)B * C));
 #define SEP_DWB(AL, NIT, RC) hipLaunchKernelGGL((dwconv_bwd_row_kernel<AL, NIT, RC>), grid, dim3(256), rsmem, (hipStream_t)stream, dv2, z, bd, a, stats1, gamma1, beta1, alpha1, stats2, gamma2, alpha2, bsum2, wd, dv1, rowpart, bacc1, arrive1, bsum1, C, T, ldt, dilation, eps)
 #define SEP_DWB2(AL, NIT) do { if (recomp) SEP_DWB(AL, NIT, true); else SEP_DWB(AL, NIT, false); } while (0)
