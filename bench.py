@@ -249,8 +249,9 @@ def main():
     # N = 1: the step is recorded ONCE (sepkernels.Sequence: every launch of forward + PIT + backward + clip + Adam through the library's own
     # entry points, no hipGraph) and replayed by one sep_run_sequence call per step -- the launches leave a C loop instead of ~360 Python
     # wrappers.  Same kernels, same arguments, same order as the eager step (losses agree to the last bit: tests/test_gpu_model.py).
-    # SEPK_SEQUENCE=0 or --eager: the eager step.  N > 1: eager (the bucketed all-reduces are issued from inside backward).
-    use_seq = (world == 1 and not dry and not args.eager and os.environ.get("SEPK_SEQUENCE", "1") != "0" and step.recordable() is None)
+    # SEPK_SEQUENCE=0 or --eager: the eager step.  N > 1: the same list in segments, one per gradient bucket, the bucket's asynchronous
+    # all-reduce issued between them (FusedTrainStep._replay).
+    use_seq = (not dry and not args.eager and os.environ.get("SEPK_SEQUENCE", "1") != "0" and step.recordable() is None)
     seq_note = None
     done = 0
     if use_seq:

@@ -417,6 +417,9 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(
 // =====================================================================================
 // the neighbours at distance d of the four frames t .. t + 3 of an LDS row: DM 0: d % 4 == 0 (two aligned float4 reads), 1 / 2: d = 1 / 2 (the
 // two neighbouring float4s and register selects, as dwconv_fwd_direct_kernel does with global loads), 3: any d (eight scalar reads)
+#ifndef DWB_WAVES
+#define DWB_WAVES 6      // waves per SIMD the depthwise backward row kernel is compiled for (79 registers, no spills; 8 would spill 34)
+#endif
 template <int DM>
 __device__ __forceinline__ void dw_row_neighbours(const float* row, const float4 c, const int t, const int d, const int ldt, float (&lft)[4], float (&rgt)[4]) {
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -444,7 +447,7 @@ __device__ __forceinline__ void dw_row_neighbours(const float* row, const float4
 }
 
 template <int DM, int NIT, bool RECOMP>
-__global__ __launch_bounds__(256) void dwconv_bwd_row_kernel(
+__global__ __launch_bounds__(256, NIT <= 4 ? DWB_WAVES : 3) void dwconv_bwd_row_kernel(
     const float* __restrict__ dv2, const float* __restrict__ z, const float* __restrict__ bd, const float* __restrict__ a,
     const double* __restrict__ stats1, const float* __restrict__ gamma1, const float* __restrict__ beta1,
     const float* __restrict__ alpha1, const double* __restrict__ stats2, const float* __restrict__ gamma2,

@@ -63,8 +63,11 @@ class Trainer:
             refuse = bool(flag.item())
         if refuse:
             raise ValueError("{} already exists. If you continue to run, set --overwrite to be True.".format(best))
+        # auto_record: the first batch of the training shape records the step's launch list, every later batch of that shape is ONE C-ABI call
+        # (sep_run_sequence) -- at the recipes' batch sizes (2 - 4 utterances) the eager step is bound by its ~360 Python launches (7.1 against
+        # 9.6 ms per step at 4).  Other shapes (a short last batch), other criteria and CPU tensors step eagerly.  SEPK_SEQUENCE=0 turns it off.
         self.step = FusedTrainStep(model, pit_criterion, lr=args.lr, weight_decay=getattr(args, "weight_decay", 0.0),
-                                   max_norm=args.max_norm or 0.0)
+                                   max_norm=args.max_norm or 0.0, auto_record=os.environ.get("SEPK_SEQUENCE", "1") != "0")
         self.reshard = getattr(args, "reshard", None)       # callable(epoch) -> this rank's train loader for that epoch, or None
         self.train_loss = torch.empty(self.epochs)
         self.valid_loss = torch.empty(self.epochs)

@@ -17,8 +17,9 @@ criterion, backward, clip, Adam -- all of it library entry points, no torch kern
 their batch into the recorded input buffers and hand the list to sep_run_sequence, a C loop over the same entry points (include/sepkernels.h,
 ABI 23).  The two scalars that change from step to step (Adam's step count, the learning rate) live in device memory for that
 (sep_adam_step_dev).  No hipGraph: replays of the captured full-size step were measured wrong in half the runs on this stack
-(profiles/r07_round5_experiments.md, r07m) and that path (FusedTrainStep.capture, GraphedStep) is gone.  Single-process only so far: with
-ranks > 1 the step stays eager (the bucketed all-reduces are issued from inside backward).
+(profiles/r07_round5_experiments.md, r07m) and that path (FusedTrainStep.capture, GraphedStep) is gone.  With ranks > 1 the gradient buckets
+cut the recorded list into segments: a replayed step runs a segment, issues that bucket's asynchronous all-reduce, runs the next segment ...,
+waits for the exchange, then runs clip + Adam (`_seq_marks`).
 """
 import os
 
@@ -114,8 +115,8 @@ class FusedTrainStep:
         """None when record() can take this step, else the reason it cannot"""
         from criterion.pit import PIT
         from criterion.sdr import SISDR, NegSISDR
-        if self.comm:
-            return "ranks > 1: the bucketed gradient all-reduces are issued from inside backward (eager)"
+        if self.comm and self.uneven:
+            return "uneven_batches weights the loss by a count that is all-reduced under the forward pass: eager only"
         if not getattr(self.model, "fused", False):
             return "the recorded step is offered for the fused kernel sequence only; this model runs the {} path".format(
                 "derived-basis" if getattr(self.model, "fused_derived", False) else "staged" if getattr(self.model, "staged", False) else "composed")
@@ -167,6 +168,21 @@ class FusedTrainStep:
         self.zero_grad()
         seq = sepkernels.Sequence()
         out = {}
+        # ranks > 1: the gradient buckets of the eager step (one per TCN block, last block first, then block 0 + the head: _FusedConvTasNetFn.backward)
+        # cut the list into segments -- `marks` holds (ops recorded when the bucket became final, first float, one past the last float); a
+        # replay runs a segment, issues that bucket's asynchronous all-reduce, runs the next segment ...
+        marks, works = [], []
+        self.last_bucket_bytes = []
+        R = cfg["sep_num_blocks"]
+        starts = {r: offs["separator.tdcn.net.{}.net.0.bottleneck_conv1d.weight".format(r)] for r in range(R)}
+
+        def bucket(lo, hi):
+            marks.append((len(seq), lo, hi))
+            works.append(self._bucket_allreduce(lo, hi))
+
+        def on_ready(r):
+            bucket(starts[r], total if r == R - 1 else starts[r + 1])
+        bucketed = self.comm and self.bucketed
         with torch.no_grad(), sepkernels.recording(seq):
             amax = None
             if sepkernels.gemm_arith() == sepkernels.ARITH_F16X3 and hasattr(K, "absmax"):
@@ -192,18 +208,25 @@ class FusedTrainStep:
                 K.pit_finish(best_val, best_idx, perms32, Pn, n_src, B, sign, scale, loss, gw, pattern)
                 d_est = torch.empty_like(est3)
                 K.sisdr_bwd(est3, src, dots, tt, xx, gw, d_est, B, n_src, T, True, crit.eps)
-                _net._backward(cfg, P, sv, d_est.view(B, n_src, 1, T), G, None, False)
+                _net._backward(cfg, P, sv, d_est.view(B, n_src, 1, T), G, on_ready if bucketed else None, False)
+                if bucketed:
+                    bucket(0, starts[1] if R > 1 else total)
+                elif self.comm:
+                    bucket(0, total)
             finally:
                 sepkernels.set_weights_amax(prev)
+            self._wait_buckets(works)
             n = self.gflat.numel()
             K.memset(self.sqnorm, 0)
             if self.max_norm and self.max_norm > 0:
                 K.sqnorm(self.gflat, self.sqnorm, n)
             K.adam_step_dev(self.flat, self.gflat, self.m, self.v, self.sqnorm, n, self._lr_dev, self._step_dev, self.betas[0], self.betas[1],
-                            self.eps, self.weight_decay, float(self.max_norm or 0.0), 1.0)
+                            self.eps, self.weight_decay, float(self.max_norm or 0.0), 1.0 / self.world)
             out["loss"], out["pattern"] = loss, pattern
         self.step_count += 1
         self._seq = seq
+        self._seq_marks = marks
+        self.last_buckets = len(marks)
         self._seq_loss, self.last_pattern = out["loss"].view(()), out["pattern"]
         self._seq_key = (tuple(mixture.shape), tuple(sources.shape), tuple(self.betas), self.eps, self.weight_decay, self.max_norm,
                          sepkernels.gemm_arith(), id(self.criterion))
@@ -222,15 +245,44 @@ class FusedTrainStep:
         if self._lr_host != self.lr:
             self._lr_dev.fill_(self.lr)
             self._lr_host = self.lr
-        self._seq.run()
+        if not self._seq_marks:
+            self._seq.run()
+        else:
+            pos, works = 0, []
+            self.last_bucket_bytes = []
+            for upto, lo, hi in self._seq_marks:
+                self._seq.run(pos, upto)
+                works.append(self._bucket_allreduce(lo, hi))
+                pos = upto
+            self._wait_buckets(works)
+            self._seq.run(pos, len(self._seq))
         self.step_count += 1
         return self._seq_loss
+
+    def _bucket_allreduce(self, lo, hi):
+        self.last_bucket_bytes.append(4 * (hi - lo))
+        return dist.all_reduce(self.gflat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _wait_buckets(self, works):
+        """the compute stream waits for the gradient exchange (HIP events around the waits when time_collectives is on)"""
+        if not works:
+            return
+        timed = self.time_collectives and self.gflat.is_cuda
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        for w in works:
+            w.wait()
+        if timed:
+            e1.record()
+            self.last_comm = (e0, e1)
 
     def __call__(self, mixture, sources):
         if self._seq is not None:
             if self._seq_valid(mixture, sources):
                 return self._replay(mixture, sources)
-        elif self.auto_record and mixture.is_cuda and self.recordable() is None:
+        elif (self.auto_record and mixture.is_cuda and mixture.dim() == 3 and sources.dim() == 3 and mixture.shape[1] == 1
+              and sources.shape[0] == mixture.shape[0] and sources.shape[2] == mixture.shape[2] and self.recordable() is None):
             return self.record(mixture, sources)
         return self._eager(mixture, sources)
 

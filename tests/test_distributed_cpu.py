@@ -85,6 +85,76 @@ def test_two_rank_step_matches_single_process(tmp_path):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
+# The recorded launch sequence (ABI 23) under data parallelism: the gradient buckets cut the recorded list into segments, a replayed step
+# runs segment / all-reduce / segment ... / waits / clip + Adam.  Kernels: the kernel SOURCES on the host simulation (tools/hostsim.py) --
+# the emulator has no C ABI to record.  Two ranks, three steps each way (eager; recorded + two replays): same losses, same parameters.
+def _recorded_worker(rank, world, port, out_dir, so):
+    _setup_paths()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    import hostsim
+    import sepkernels
+    from sepkernels.train import FusedTrainStep
+    from models.conv_tasnet import ConvTasNet
+    from criterion.sdr import NegSISDR
+    from criterion.pit import PIT1d
+    g = torch.Generator().manual_seed(7)
+    batches = [0.1 * torch.randn(2, 2, 1203, generator=g) for _ in range(3)]          # (both ranks draw the same stream; each takes its utterance)
+    out = {}
+    with hostsim.HostSimBackend(so) as K:
+        class Named:
+            name = "hostsim"
+
+            def __getattr__(self, attr):
+                return getattr(K, attr)
+        sepkernels._set_backend_for_tests(Named())
+        for recorded in (False, True):
+            torch.manual_seed(111)
+            model = ConvTasNet(**dict(CFG, sep_num_layers=1))
+            step = FusedTrainStep(model, PIT1d(NegSISDR(), n_sources=2), lr=1e-3, max_norm=5.0, distributed=True)
+            losses = []
+            for i, src in enumerate(batches):
+                src = src[rank:rank + 1]
+                mix = src.sum(1, keepdim=True).contiguous()
+                if recorded and i == 0:
+                    assert step.recordable() is None
+                    losses.append(float(step.record(mix, src)))
+                    assert [m[1:] for m in step._seq_marks][-1][0] == 0 and len(step._seq_marks) == 3
+                    assert all(a[0] < b[0] for a, b in zip(step._seq_marks, step._seq_marks[1:])) and step._seq_marks[-1][0] < len(step._seq)
+                else:
+                    losses.append(float(step(mix, src)))
+                assert step.last_buckets == 3 and sum(step.last_bucket_bytes) == 4 * step.gflat.numel()
+            assert (step._seq is not None) == recorded
+            out[recorded] = (losses, model.flat_parameters().detach().clone())
+    torch.save(out, os.path.join(out_dir, "rec_rank{}.pt".format(rank)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_recorded_step_matches_the_eager_two_rank_step(tmp_path):
+    import pytest
+    _setup_paths()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import hostsim
+    if hostsim.compiler() is None:
+        pytest.skip("needs clang++ for the host simulation of the kernel sources")
+    so = hostsim.build(str(tmp_path))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_recorded_worker, args=(2, port, str(tmp_path), so), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "rec_rank0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "rec_rank1.pt"))
+    for r in (r0, r1):
+        (le, pe), (lr, pr) = r[False], r[True]
+        assert le == lr and le[0] != le[2], (le, lr)                # the recorded step is the eager step, launch for launch
+        assert (pe - pr).abs().max() <= 2e-7 * pe.abs().max()
+    assert torch.equal(r0[True][1], r1[True][1])                   # replicas stay in lock-step
+    assert r0[True][0] != r1[True][0]                              # (on different utterances)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
 # The dual-path separators shard the same way (one process per GPU, utterances split across ranks); their parameters are ordinary
 # tensors, so the gradient exchange is torch's DistributedDataParallel (RCCL on the GPUs, gloo here) around the module whose
 # 1x1 convolutions / chunking / norms / recurrences are custom autograd Functions on the C ABI.

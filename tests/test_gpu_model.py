@@ -868,11 +868,26 @@ def test_rccl_single_rank_runs_the_exchange_path_of_the_train_step():
             plain = FusedTrainStep(a, crit, lr=1e-3, max_norm=5.0, distributed=False)
             comm = FusedTrainStep(b, crit, lr=1e-3, max_norm=5.0, time_collectives=True, exercise_collectives=True)
             assert comm.distributed and comm.world == 1 and comm.comm and not plain.comm
+            rec = None
+            if side == "0":     # round 6: the RECORDED step under the exchange path -- segments of the launch list between the buckets' all-reduces
+                c = ConvTasNet(**cfg).cuda()
+                c.load_state_dict(a.state_dict())
+                rec = FusedTrainStep(c, crit, lr=1e-3, max_norm=5.0, time_collectives=True, exercise_collectives=True, auto_record=True)
+                assert rec.comm and rec.recordable() is None
             for src in batches:
                 src = src.cuda()
                 mix = src.sum(1, keepdim=True).contiguous()
                 la, lb = plain(mix, src), comm(mix, src)
                 assert abs(la.item() - lb.item()) <= 1e-5 * abs(la.item())      # (fp64 atomics of the statistics: the last bits may differ run to run)
+                if rec is not None:
+                    lc = rec(mix, src)
+                    assert abs(la.item() - lc.item()) <= 1e-5 * abs(la.item())
+            if rec is not None:
+                assert rec._seq is not None and len(rec._seq_marks) == cfg["sep_num_blocks"] and rec.last_buckets == cfg["sep_num_blocks"]
+                assert sum(rec.last_bucket_bytes) == 4 * rec.gflat.numel() and rec.step_count == len(batches)
+                ms = rec.exposed_comm_ms()
+                assert ms is not None and np.isfinite(ms) and ms >= 0.0
+                assert (a.flat_parameters() - c.flat_parameters()).abs().max().item() <= 1e-5 * a.flat_parameters().abs().max().item()
             assert comm.last_buckets == cfg["sep_num_blocks"] and sum(comm.last_bucket_bytes) == 4 * comm.gflat.numel()
             ms = comm.exposed_comm_ms()
             assert ms is not None and np.isfinite(ms) and ms >= 0.0
