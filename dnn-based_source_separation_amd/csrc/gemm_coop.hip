@@ -465,6 +465,9 @@ void launch_coop(const sep_gemm_desc& d, const int ns, hipStream_t stream) {
 
 // Called by sep_pw_gemm (gemm.hip) for SEP_ARITH_F16X3 descriptors that carry packed weights.  Returns 1 when the call was
 // launched here, 0 when the shape / flag combination is not one of the packed kernel's (the caller then uses A / A2).
+#ifndef SEP_COOP_MI4_DEFAULT
+#define SEP_COOP_MI4_DEFAULT 2      // heads^T on the 512 x 64 tile (every [dout; dS] value split once for all 512 outputs): -0.1 ms per step; conv1 gains nothing from it (r08g)
+#endif
 int sep_pw_gemm_packed(const sep_gemm_desc* d, hipStream_t stream) {
     static const bool off = getenv("SEPK_COOP") != nullptr && atoi(getenv("SEPK_COOP")) == 0;
     // SEPK_GEMM_KERNEL = auto (default): the producer / consumer kernel where it wins (long contractions), the cooperative
@@ -491,9 +494,13 @@ int sep_pw_gemm_packed(const sep_gemm_desc* d, hipStream_t stream) {
     const int ns = env_ns == 2 || env_ns == 3 ? env_ns : 2;
     // 128-row waves (a 512 x 64 workgroup tile: every value of X is split ONCE for 512 outputs instead of once per 256): the write-heavy
     // short-contraction shapes with M % 512 == 0 -- TCN conv1, heads^T, skip^T (SEPK_COOP_MI=4 while it is being measured)
-    if (force_mi == 4 && d->M % 512 == 0 && !sp && pm == SEP_PRO_NONE && ef == SEP_EPI_STATS_PRELU) { launch_coop<4, SEP_PRO_NONE, false, SEP_EPI_STATS_PRELU>(*d, ns, stream); return 1; }
-    if (force_mi == 4 && d->M % 512 == 0 && sp && pm == SEP_PRO_NONE && ef == 0) { launch_coop<4, SEP_PRO_NONE, true, 0>(*d, ns, stream); return 1; }
-    if (force_mi == 4 && d->M % 512 == 0 && !sp && pm == SEP_PRO_NONE && ef == 0) { launch_coop<4, SEP_PRO_NONE, false, 0>(*d, ns, stream); return 1; }
+    // SEPK_COOP_MI4: bit 0 = conv1, bit 1 = heads^T / skip^T (two sources), bit 2 = the plain product; SEPK_COOP_MI=4 = all three.
+    // Measured, recorded sequence (profiles/r08f_kernel_choice_toggles.txt, r08g_coop_tile_per_shape.txt): none 15.29, conv1 15.33, heads^T 15.19, all 15.22 ms per step
+    // (means of three alternating runs on one box).
+    static const int mi4 = force_mi == 4 ? 7 : getenv("SEPK_COOP_MI4") ? atoi(getenv("SEPK_COOP_MI4")) : SEP_COOP_MI4_DEFAULT;
+    if ((mi4 & 1) && force_mi != 1 && force_mi != 2 && d->M % 512 == 0 && !sp && pm == SEP_PRO_NONE && ef == SEP_EPI_STATS_PRELU) { launch_coop<4, SEP_PRO_NONE, false, SEP_EPI_STATS_PRELU>(*d, ns, stream); return 1; }
+    if ((mi4 & 2) && force_mi != 1 && force_mi != 2 && d->M % 512 == 0 && sp && pm == SEP_PRO_NONE && ef == 0) { launch_coop<4, SEP_PRO_NONE, true, 0>(*d, ns, stream); return 1; }
+    if ((mi4 & 4) && force_mi != 1 && force_mi != 2 && d->M % 512 == 0 && !sp && pm == SEP_PRO_NONE && ef == 0) { launch_coop<4, SEP_PRO_NONE, false, 0>(*d, ns, stream); return 1; }
 #define SEP_LC(P, S, E)                                              \
     do {                                                             \
         if (mi == 2) launch_coop<2, P, S, E>(*d, ns, stream);        \

@@ -821,24 +821,34 @@ class TokenGLNFn(torch.autograd.Function):
         return dx, tot[0], tot[1], None
 
 
-_seed_state = {"gen": None, "key": None, "counter": 0, "rank": None}
+_seed_rank = {"rank": None, "calls": 0}
+
+
+def _mix64(x):
+    """splitmix64 finaliser: a 64-bit hash of a 64-bit integer"""
+    x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return x ^ (x >> 31)
 
 
 def _dropout_seed(t):
-    """a 62-bit seed for a hash-masked dropout (sep_attn_*, sep_rownorm_*).  ONE draw from the global CPU generator per (torch.manual_seed
-    state seen at the first site of a process / after a re-seed) starts a dedicated generator; every site then takes the next value of
-    that generator: no .item() on the global stream per site (a SepFormer step has ~50 sites: that shifted the data shuffling against the
-    reference for the same manual_seed and cost host time on a launch-bound step).  The rank (cached) and the device are folded in --
-    data-parallel ranks seeded alike must not drop the same elements."""
-    st = _seed_state
-    key = torch.initial_seed()
-    if st["gen"] is None or st["key"] != key:
-        st["gen"] = torch.Generator().manual_seed(int(torch.randint(0, 2 ** 62, (1,)).item()) ^ (key & (2 ** 62 - 1)))
-        st["key"], st["counter"] = key, 0
-    if st["rank"] is None or st["counter"] % 4096 == 0:
+    """a 62-bit seed for a hash-masked dropout (sep_attn_*, sep_rownorm_*, sep_relu_drop_*).  For a tensor on the GPU it is a hash of the
+    device generator's (seed, offset), and the offset is advanced -- what torch's own dropout kernels do with that generator: the masks
+    are a function of torch.manual_seed(), NOTHING is drawn from the global CPU generator (which the data loaders' shuffling shares with the
+    reference) and no .item() costs a launch-bound step host time.  CPU tensors (the tests' stand-in) draw from the CPU generator.
+    The rank (cached) and the device are folded in -- data-parallel ranks seeded alike must not drop the same elements."""
+    st = _seed_rank
+    if st["rank"] is None or st["calls"] % 4096 == 0:
         st["rank"] = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
-    st["counter"] += 1
-    seed = int(torch.randint(0, 2 ** 62, (1,), generator=st["gen"]).item())
+    st["calls"] += 1
+    if t.is_cuda:
+        gen = torch.cuda.default_generators[t.device.index if t.device.index is not None else torch.cuda.current_device()]
+        base, off = gen.initial_seed(), gen.get_offset()
+        gen.set_offset(off + 4)
+        seed = _mix64((base & 0xFFFFFFFFFFFFFFFF) ^ _mix64(off))
+    else:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
     return (seed ^ (0x9E3779B97F4A7C15 * (1 + st["rank"] + 1024 * (t.device.index or 0)))) & (2 ** 62 - 1)
 
 
