@@ -540,7 +540,11 @@ def _backward(cfg, P, sv, d_est, G, on_ready, want_dmix=False):
         held = list(w1_held)
         del w1_held[:]
         with side:
-            ns = _nsplit(H, Bn, chunks, target_blocks=max(8, 512 // len(held)))
+            # one grid for all of them only where sep_pw_wgrad_batch has a batched kernel (the fp16 producer / consumer form: f16x3, 256 x 128 tiles);
+            # otherwise the entry point issues one launch per product and every product needs the slabs of a launch of its own
+            batched = (len(held) > 1 and hasattr(K, "pw_wgrad_batch") and sepkernels.gemm_arith() == sepkernels.ARITH_F16X3
+                       and H % 256 == 0 and Bn % 128 == 0)
+            ns = _nsplit(H, Bn, chunks, target_blocks=max(8, 512 // len(held)) if batched else 512)
             calls, segs = [], []
             for da_k, x_k, pre_k in held:
                 part = torch.empty(ns, H, Bn, **f32)
@@ -548,7 +552,7 @@ def _backward(cfg, P, sv, d_est, G, on_ready, want_dmix=False):
                 calls.append(dict(B=B, M=H, N=Bn, T=F, ldt=ldt, G=da_k, X=x_k, partial=part, partial_bias=pb, nsplit=ns, eps=eps))
                 segs += [(part, 0, G[pre_k + "bottleneck_conv1d.weight"], H * Bn, ns, H * Bn, 0, 1.0),
                          (pb, 0, G[pre_k + "bottleneck_conv1d.bias"], H, ns, H, 0, 1.0)]
-            if len(calls) > 1 and hasattr(K, "pw_wgrad_batch"):
+            if batched:
                 K.pw_wgrad_batch(calls)
             else:
                 for c in calls:

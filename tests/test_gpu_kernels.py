@@ -1598,3 +1598,20 @@ def test_criterion_kernels_against_the_oracle(n, B, T):
         assert (sl.cpu().double() - osl.detach()).abs().max() <= 1e-4 * osl.detach().abs().max()
         assert (sP.cpu().double() - oP.detach()).abs().max() <= 1e-4
         assert (dC.cpu().double() - oC.grad).abs().max() <= 2e-4 * oC.grad.abs().max()
+
+
+@pytest.mark.parametrize("n", [1, 1000, 4984881])
+def test_absmax_and_memset(n):
+    """sep_absmax (the A-operand bound of the split arithmetic over the flat parameter buffer in a recorded step) and sep_memset"""
+    x = rnd(n)
+    x[n // 2] = -7.5 if n > 1 else 0.25
+    gx, out = to_device(x), to_device(nan(1))
+    HIP.absmax(gx, out, n)
+    device_sync()
+    assert out.cpu().item() == x.abs().max().item()
+    buf = to_device(rnd(n))
+    HIP.memset(buf, 0)
+    device_sync()
+    assert buf.cpu().abs().max().item() == 0.0
+    z = HIP.zeros(3, 5, device=device_name(), dtype=torch.float64)
+    assert z.shape == (3, 5) and z.dtype == torch.float64 and z.abs().max().item() == 0.0

@@ -56,6 +56,7 @@ CASES = [
     ("test_tcn_layer_kernel_by_kernel_against_the_oracle", [(1, 128, 128, 128, 300, 2), (2, 128, 128, 128, 300, 4)]),
     ("test_head_and_tail_kernel_by_kernel_against_the_oracle", [(1, 128, 128, 128, 2, 1203, True), (2, 128, 128, 128, 3, 1205, False)]),
     ("test_criterion_kernels_against_the_oracle", [(2, 4, 8000), (4, 3, 4001)]),
+    ("test_absmax_and_memset", [(1,), (1000,), (70001,)]),
     ("test_linear_weight_gradient", [(32, 20, 64, 512, 0, 7), (9, 31, 128, 512, -1, 3), (9, 31, 128, 512, 1, 5), (3, 7, 64, 64, -1, 1), (5, 250, 256, 64, 0, 40)]),
 ]
 
