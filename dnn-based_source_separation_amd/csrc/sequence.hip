@@ -60,7 +60,7 @@ const seq_entry SEQ_TABLE[] = {
     SEQ_FN(sep_sisdr_from_dots), SEQ_FN(sep_sisdr_bwd), SEQ_FN(sep_pit_search), SEQ_FN(sep_sinkhorn_fwd), SEQ_FN(sep_sinkhorn_bwd),
     SEQ_FN(sep_rowdiff_sums), SEQ_FN(sep_rowdiff_bwd), SEQ_FN(sep_sqnorm), SEQ_FN(sep_adam_step), SEQ_FN(sep_adam_step_dev),
     SEQ_FN(sep_lstm_fwd), SEQ_FN(sep_lstm_bwd), SEQ_FN(sep_linear_fwd), SEQ_FN(sep_linear_bwd_input), SEQ_FN(sep_linear_bwd_weight),
-    SEQ_FN(sep_chunk_to_tokens), SEQ_FN(sep_tokens_to_chunk), SEQ_FN(sep_memset), SEQ_FN(sep_absmax), SEQ_FN(sep_pit_finish),
+    SEQ_FN(sep_chunk_to_tokens), SEQ_FN(sep_tokens_to_chunk), SEQ_FN(sep_memset), SEQ_FN(sep_absmax), SEQ_FN(sep_pit_finish), SEQ_FN(sep_axpby),
 };
 constexpr int SEQ_COUNT = (int)(sizeof(SEQ_TABLE) / sizeof(SEQ_TABLE[0]));
 
@@ -89,12 +89,19 @@ __global__ __launch_bounds__(256) void pit_finish_kernel(const float* __restrict
     for (int b = threadIdx.x; b < B; b += 256) acc += (double)best_val[b];
     const double tot = block_sum_256<double>(acc, red);
     if (threadIdx.x == 0 && loss) loss[0] = (float)((double)sign * tot / (double)B);
+    if (!gw && !pattern) return;
     for (int e = threadIdx.x; e < B * n * n; e += 256) {
         const int b = e / (n * n), i = (e / n) % n, j = e % n;
         const int sel = perms[(size_t)best_idx[b] * n + i];
         if (gw) gw[e] = j == sel ? sign * scale : 0.f;
         if (pattern && j == 0) pattern[(size_t)b * n + i] = sel;
     }
+}
+
+// out[i] = a * x[i] + b * y[i] (y may be NULL): the sign flips and sums between criterion kernels that the eager step leaves to torch
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x, const float a, const float* __restrict__ y, const float b,
+                                                    float* __restrict__ out, const int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = y ? a * x[i] + b * y[i] : a * x[i];
 }
 
 }  // namespace
@@ -150,8 +157,17 @@ extern "C" int sep_absmax(const float* x, int64_t n, float* out, sep_stream_t st
 
 extern "C" int sep_pit_finish(const float* best_val, const int64_t* best_idx, const int32_t* perms, int P, int n, int B, float sign,
                               float scale, float* loss, float* gw, int64_t* pattern, sep_stream_t stream) {
-    SEP_REQUIRE(best_val && best_idx && perms && P > 0 && n > 0 && B > 0 && (loss || gw || pattern), "sep_pit_finish: bad arguments");
+    SEP_REQUIRE(best_val && n > 0 && B > 0 && (loss || gw || pattern), "sep_pit_finish: bad arguments");
+    SEP_REQUIRE((best_idx && perms && P > 0) || (!gw && !pattern), "sep_pit_finish: gw / pattern need best_idx and perms");
     hipLaunchKernelGGL(pit_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, best_val, best_idx, perms, B, n, sign, scale, loss, gw, pattern);
     SEP_CHECK_LAUNCH("sep_pit_finish");
+    return 0;
+}
+
+extern "C" int sep_axpby(const float* x, float a, const float* y, float b, float* out, int64_t n, sep_stream_t stream) {
+    SEP_REQUIRE(x && out && n > 0, "sep_axpby: bad arguments");
+    const int64_t want = (n + 255) / 256;
+    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)(want > 2048 ? 2048 : want)), dim3(256), 0, (hipStream_t)stream, x, a, y, b, out, n);
+    SEP_CHECK_LAUNCH("sep_axpby");
     return 0;
 }

@@ -189,6 +189,7 @@ SIGNATURES = {
     "sep_memset": [_vp, _I, ctypes.c_size_t, _vp],
     "sep_absmax": [_vp, _L, _vp, _vp],
     "sep_pit_finish": [_vp, _vp, _vp, _I, _I, _I, _F, _F, _vp, _vp, _vp, _vp],
+    "sep_axpby": [_vp, _F, _vp, _F, _vp, _L, _vp],
 }
 _RESTYPES = {"sep_last_error": ctypes.c_char_p, "sep_seq_name": ctypes.c_char_p, "sep_cln_ws_bytes": ctypes.c_size_t,
              "sep_gln_tokens_ws_bytes": ctypes.c_size_t}
@@ -687,6 +688,9 @@ class HipBackend:
     def pit_finish(self, best_val, best_idx, perms, P, n, B, sign, scale, loss, gw, pattern):
         _check(load().sep_pit_finish(_ptr(best_val, _f32), _ptr(best_idx, torch.int64), _ptr(perms, torch.int32), P, n, B, sign, scale,
                                      _ptr(loss, _f32), _ptr(gw, _f32), _ptr(pattern, torch.int64), _stream()), "sep_pit_finish")
+
+    def axpby(self, x, a, y, b, out, n):
+        _check(load().sep_axpby(_ptr(x, _f32), a, _ptr(y, _f32), b, _ptr(out, _f32), n, _stream()), "sep_axpby")
 
     def adam_step(self, p, g, m, v, sqnorm, n, lr, beta1, beta2, eps, weight_decay, max_norm, grad_scale, step):
         _check(load().sep_adam_step(_ptr(p, _f32), _ptr(g, _f32), _ptr(m, _f32), _ptr(v, _f32), _ptr(sqnorm, _f64), n, lr, beta1,

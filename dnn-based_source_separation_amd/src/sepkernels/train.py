@@ -120,9 +120,13 @@ class FusedTrainStep:
         if not getattr(self.model, "fused", False):
             return "the recorded step is offered for the fused kernel sequence only; this model runs the {} path".format(
                 "derived-basis" if getattr(self.model, "fused_derived", False) else "staged" if getattr(self.model, "staged", False) else "composed")
+        from criterion.pit import SinkPIT
         c = self.criterion
-        if not (isinstance(c, PIT) and type(c.criterion) in (SISDR, NegSISDR) and c.criterion.reduction in ("mean", "sum")):
-            return "the recorded step implements PIT over SI-SDR / NegSI-SDR (criterion.pit.PIT1d(NegSISDR())); other criteria run eagerly"
+        pit_ok = isinstance(c, PIT) and type(c.criterion) in (SISDR, NegSISDR) and c.criterion.reduction in ("mean", "sum")
+        sink_ok = type(c) is SinkPIT and type(c.criterion) in (SISDR, NegSISDR) and c.iteration >= 0 and c.coldness != 0
+        if not (pit_ok or sink_ok):
+            return ("the recorded step implements PIT and SinkPIT over SI-SDR / NegSI-SDR (criterion.pit.PIT1d(NegSISDR()), "
+                    "criterion.pit.SinkPIT(NegSISDR(), ...)); other criteria run eagerly")
         if self._trainable_mask() is not None:
             return "frozen parameters (requires_grad = False) are handled by the eager step"
         if os.environ.get("SEPK_SIDE_STREAM", "0") == "1":
@@ -144,7 +148,9 @@ class FusedTrainStep:
             raise RuntimeError("FusedTrainStep.record: " + why)
         self._rebind()
         K = sepkernels.backend()
+        from criterion.pit import SinkPIT
         model, crit = self.model, self.criterion.criterion
+        sink = type(self.criterion) is SinkPIT
         dev = self.flat.device
         B, n_src, T = sources.shape
         if tuple(mixture.shape) != (B, 1, T) or n_src != model.n_sources:
@@ -160,11 +166,12 @@ class FusedTrainStep:
         offs, total = model._offsets, self.gflat.numel()
         G = {k: self.gflat[offs[k]:offs[k] + v.numel()].view(v.shape) for k, v in named}
         cfg = model.get_config()
-        patterns = self.criterion.patterns
-        Pn = patterns.size(0)
-        perms32 = patterns.to(device=dev, dtype=torch.int32).contiguous()
+        if not sink:
+            patterns = self.criterion.patterns
+            Pn = patterns.size(0)
+            perms32 = patterns.to(device=dev, dtype=torch.int32).contiguous()
+            scale = 1.0 / (B * n_src) if crit.reduction == "mean" else 1.0 / B
         sign = -1.0 if isinstance(crit, NegSISDR) else 1.0
-        scale = 1.0 / (B * n_src) if crit.reduction == "mean" else 1.0 / B
         self.zero_grad()
         seq = sepkernels.Sequence()
         out = {}
@@ -199,13 +206,30 @@ class FusedTrainStep:
                 val = torch.empty(B, n_src, n_src, **f32)
                 K.sisdr_dots(est3, src, dots, tt, xx, B, n_src, T, True)
                 K.sisdr_from_dots(dots, tt, xx, val, B, n_src, True, crit.eps)
-                best_val = torch.empty(B, **f32)
-                best_idx = torch.empty(B, device=dev, dtype=torch.int64)
-                K.pit_search(val, perms32, Pn, n_src, B, True, crit.reduction == "mean", best_val, best_idx)      # max SI-SDR = min NegSI-SDR
                 loss = torch.empty(1, **f32)
                 gw = torch.empty(B, n_src, n_src, **f32)
-                pattern = torch.empty(B, n_src, device=dev, dtype=torch.int64)
-                K.pit_finish(best_val, best_idx, perms32, Pn, n_src, B, sign, scale, loss, gw, pattern)
+                if not sink:
+                    best_val = torch.empty(B, **f32)
+                    best_idx = torch.empty(B, device=dev, dtype=torch.int64)
+                    K.pit_search(val, perms32, Pn, n_src, B, True, crit.reduction == "mean", best_val, best_idx)      # max SI-SDR = min NegSI-SDR
+                    pattern = torch.empty(B, n_src, device=dev, dtype=torch.int64)
+                    K.pit_finish(best_val, best_idx, perms32, Pn, n_src, B, sign, scale, loss, gw, pattern)
+                else:
+                    # Sinkhorn PIT (criterion/pit.py::sinkpit): costs C = -SI-SDR for both criterion classes, per-item losses from the log-domain
+                    # iterations, their batch mean (sign flipped for a maximised criterion), and back: dL/dC through every iteration, dL/d SI-SDR = -dL/dC
+                    iters, cold = int(self.criterion.iteration), float(self.criterion.coldness)
+                    C = torch.empty(B, n_src, n_src, **f32)
+                    K.axpby(val, -1.0, None, 0.0, C, B * n_src * n_src)
+                    zwork = torch.empty(B, 2 * iters + 1, n_src, n_src, device=dev, dtype=torch.float64)
+                    item_loss, Pm = torch.empty(B, **f32), torch.empty(B, n_src, n_src, **f32)
+                    K.sinkhorn_fwd(C, zwork, item_loss, Pm, B, n_src, cold, iters)
+                    lsign = -1.0 if bool(crit.maximize) else 1.0
+                    K.pit_finish(item_loss, None, None, 0, n_src, B, lsign, 0.0, loss, None, None)
+                    dloss = torch.full((B,), lsign / B, **f32)                   # written once, before the recording's first launch reads it
+                    dC = torch.empty(B, n_src, n_src, **f32)
+                    K.sinkhorn_bwd(C, zwork, dloss, dC, B, n_src, cold, iters)
+                    K.axpby(dC, -1.0, None, 0.0, gw, B * n_src * n_src)
+                    pattern = Pm                                                 # (the soft assignment; last_pattern takes its argmax on demand)
                 d_est = torch.empty_like(est3)
                 K.sisdr_bwd(est3, src, dots, tt, xx, gw, d_est, B, n_src, T, True, crit.eps)
                 _net._backward(cfg, P, sv, d_est.view(B, n_src, 1, T), G, on_ready if bucketed else None, False)
@@ -227,10 +251,18 @@ class FusedTrainStep:
         self._seq = seq
         self._seq_marks = marks
         self.last_buckets = len(marks)
-        self._seq_loss, self.last_pattern = out["loss"].view(()), out["pattern"]
+        self._seq_loss, self._seq_pattern = out["loss"].view(()), out["pattern"]
         self._seq_key = (tuple(mixture.shape), tuple(sources.shape), tuple(self.betas), self.eps, self.weight_decay, self.max_norm,
                          sepkernels.gemm_arith(), id(self.criterion))
         return self._seq_loss
+
+    @property
+    def last_pattern(self):
+        """(B, n_sources) int64 permutation of the last recorded / replayed step (PIT: the chosen one; SinkPIT: argmax of the soft assignment)"""
+        p = getattr(self, "_seq_pattern", None)
+        if p is None:
+            return None
+        return p if p.dtype == torch.int64 else torch.argmax(p, dim=2)
 
     def _seq_valid(self, mixture, sources):
         return self._seq is not None and self._seq_key == (tuple(mixture.shape), tuple(sources.shape), tuple(self.betas), self.eps, self.weight_decay,

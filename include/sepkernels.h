@@ -537,6 +537,10 @@ int sep_memset(void* dst, int value, size_t bytes, sep_stream_t stream);
 int sep_absmax(const float* x, int64_t n, float* out, sep_stream_t stream);
 int sep_pit_finish(const float* best_val, const int64_t* best_idx, const int32_t* perms, int P, int n, int B, float sign, float scale,
                    float* loss, float* gw, int64_t* pattern, sep_stream_t stream);
+/*   sep_axpby       out[i] = a x[i] + b y[i] (y may be NULL; out may alias x or y): the sign flips between criterion kernels the eager step leaves to
+ *                   torch -- SinkPIT's cost matrix C = -SI-SDR and dL / d SI-SDR = -dL / dC (criterion/pit.py:143-146).  With best_idx = perms = NULL
+ *                   sep_pit_finish only forms loss[0] = sign * mean_b best_val[b] (the batch mean of SinkPIT's per-item losses, pit.py:155-156). */
+int sep_axpby(const float* x, float a, const float* y, float b, float* out, int64_t n, sep_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -362,14 +362,38 @@ def test_recorded_step_at_paper_best_sixteen_utterances_trains_like_the_eager_st
     assert (diff > 1e-5).float().mean().item() <= 1e-3 and diff.max().item() <= 2.1e-2, ((diff > 1e-5).float().mean().item(), diff.max().item())
 
 
+def test_recorded_sinkpit_step_equals_eager_steps():
+    """BASELINE configs[4]'s criterion in the recorded step: SinkPIT(NegSI-SDR, coldness 1, 20 iterations) on a 4-speaker softmax-mask model,
+    recording + three replays against four eager steps (sep_axpby for C = -SI-SDR and dL/dSI-SDR = -dL/dC, sep_pit_finish for the batch mean)."""
+    from sepkernels.train import FusedTrainStep
+    cfg = dict(CONFIGS["mid"], n_sources=4, mask_nonlinear="softmax")
+    g = torch.Generator().manual_seed(4)
+    batches = [0.1 * torch.randn(3, 4, 3203, generator=g).cuda() for _ in range(4)]
+    runs = []
+    for recorded in (False, True):
+        torch.manual_seed(1)
+        model = ConvTasNet(**cfg).cuda()
+        step = FusedTrainStep(model, SinkPIT(NegSISDR(), n_sources=4, coldness=1.0, iteration=20), lr=1e-3, max_norm=5.0, auto_record=recorded)
+        losses = [step(src.sum(1, keepdim=True).contiguous(), src).item() for src in batches]
+        torch.cuda.synchronize()
+        assert (step._seq is not None) == recorded and step.step_count == 4
+        if recorded:
+            assert "sep_sinkhorn_fwd" in step._seq.names() and step.last_pattern.shape == (3, 4)
+        runs.append((losses, model.flat_parameters().detach().clone()))
+    (l0, p0), (l1, p1) = runs
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 1e-5 * abs(a), (l0, l1)
+    assert (p0 - p1).abs().max().item() <= 1e-5 * p0.abs().max().item()
+
+
 def test_record_refuses_what_it_does_not_implement():
     from sepkernels.train import FusedTrainStep
-    from criterion.pit import SinkPIT
+    from criterion.sdr import ClippedNegSISDR
     model = ConvTasNet(**CONFIGS["tiny"]).cuda()
     src = 0.1 * torch.randn(2, 2, 2000).cuda()
-    step = FusedTrainStep(model, SinkPIT(NegSISDR(), n_sources=2), auto_record=True)
-    assert "PIT over SI-SDR" in step.recordable()
-    with pytest.raises(RuntimeError, match="PIT over SI-SDR"):
+    step = FusedTrainStep(model, PIT1d(ClippedNegSISDR(min=-30), n_sources=2), auto_record=True)
+    assert "over SI-SDR" in step.recordable()
+    with pytest.raises(RuntimeError, match="over SI-SDR"):
         step.record(src.sum(1, keepdim=True), src)
     step(src.sum(1, keepdim=True).contiguous(), src)                  # auto_record falls back to the eager step
     assert step._seq is None and step.step_count == 1
