@@ -234,7 +234,23 @@ class GatedEncoder(nn.Module):
 
     def forward(self, input):
         x = input / (torch.linalg.norm(input, dim=2, keepdim=True) + self.eps)
+        if self._on_kernels(x):
+            # both analysis convolutions on sep_encoder_fwd (the ReLU of U inside the kernel), their basis gradients on sep_unfold + sep_pw_wgrad
+            # (sepkernels.functional.EncodeFn); the gate itself is two elementwise torch kernels.  Frames come back in rows of the workspace
+            # stride: the valid ones are a view.
+            from sepkernels.functional import EncodeFn
+            n_frames = (x.shape[-1] - self.kernel_size) // self.stride + 1
+            u = EncodeFn.apply(x, self.conv1d_U.weight, self.stride, True)[..., :n_frames]
+            v = EncodeFn.apply(x, self.conv1d_V.weight, self.stride, False)[..., :n_frames]
+            return u * torch.sigmoid(v)
         return self.relu(self.conv1d_U(x)) * self.sigmoid(self.conv1d_V(x))
+
+    def _on_kernels(self, x):
+        """the kernels take the TasNet geometry they were written for: the input already padded to whole frames (the TasNet forwards pad
+        before the encoder, conv_tasnet.py:145-149), a kernel that is a multiple of its stride, no gradient with respect to the input"""
+        from sepkernels.functional import takes
+        return (takes(x) and not x.requires_grad and x.dim() == 3 and self.kernel_size % self.stride == 0
+                and x.shape[-1] >= self.kernel_size and (x.shape[-1] - self.kernel_size) % self.stride == 0)
 
 
 from sepkernels.shadowed import fall_through as _fall_through      # names of the reference's same-named module this tree does not define

@@ -208,3 +208,26 @@ def test_cln_kernel_contract_via_emulator():
         assert (m32(x4).double() - m64(x4.double())).abs().max() < 2e-5
     finally:
         sepkernels._set_backend_for_tests(old)
+
+
+def test_gated_encoder_on_the_encoder_kernels_equals_the_convolutions(emu):
+    """models.filterbank.GatedEncoder (reference src/models/filterbank.py:325-346): relu(U x) * sigmoid(V x) with both analysis convolutions on
+    sep_encoder_fwd / sep_unfold + sep_pw_wgrad (sepkernels.functional.EncodeFn; here the emulator of the C ABI in fp64) against the same module
+    on nn.Conv1d: output and both basis gradients; an input that is not whole frames, or that needs a gradient, keeps the convolutions."""
+    from models.filterbank import GatedEncoder
+    torch.manual_seed(4)
+    enc = GatedEncoder(1, 32, kernel_size=16, stride=8).double()
+    x = torch.randn(3, 1, 16 + 8 * 40, dtype=torch.float64)
+    assert enc._on_kernels(x) and not enc._on_kernels(x[..., :-3]) and not enc._on_kernels(x.clone().requires_grad_(True))
+    y = enc(x)
+    w = torch.randn_like(y)
+    gU, gV = torch.autograd.grad((y * w).sum(), [enc.conv1d_U.weight, enc.conv1d_V.weight])
+    xn = x / (torch.linalg.norm(x, dim=2, keepdim=True) + enc.eps)
+    ref = torch.relu(enc.conv1d_U(xn)) * torch.sigmoid(enc.conv1d_V(xn))
+    rU, rV = torch.autograd.grad((ref * w).sum(), [enc.conv1d_U.weight, enc.conv1d_V.weight])
+    assert y.shape == ref.shape == (3, 32, 41)
+    assert (y - ref).abs().max() <= 1e-12 * ref.abs().max()
+    assert (gU - rU).abs().max() <= 1e-10 * rU.abs().max() and (gV - rV).abs().max() <= 1e-10 * rV.abs().max()
+    xs = x[..., :-3]
+    xsn = xs / (torch.linalg.norm(xs, dim=2, keepdim=True) + enc.eps)
+    assert torch.equal(enc(xs), torch.relu(enc.conv1d_U(xsn)) * torch.sigmoid(enc.conv1d_V(xsn)))

@@ -386,6 +386,25 @@ def test_recorded_sinkpit_step_equals_eager_steps():
     assert (p0 - p1).abs().max().item() <= 1e-5 * p0.abs().max().item()
 
 
+def test_gated_encoder_on_the_device():
+    """models.filterbank.GatedEncoder on sep_encoder_fwd / sep_unfold + sep_pw_wgrad against nn.Conv1d in fp64 (reference filterbank.py:325-346)"""
+    from models.filterbank import GatedEncoder
+    torch.manual_seed(4)
+    enc = GatedEncoder(1, 512, kernel_size=16, stride=8)
+    ref = GatedEncoder(1, 512, kernel_size=16, stride=8).double()
+    ref.load_state_dict({k: v.double() for k, v in enc.state_dict().items()})
+    x = torch.randn(4, 1, 16 + 8 * 3998)
+    w = torch.randn(4, 512, 3999)
+    yr = ref(x.double())                                            # CPU tensors: the convolutions
+    rU, rV = torch.autograd.grad((yr * w.double()).sum(), [ref.conv1d_U.weight, ref.conv1d_V.weight])
+    enc.cuda()
+    assert enc._on_kernels(x.cuda())
+    y = enc(x.cuda())
+    gU, gV = torch.autograd.grad((y * w.cuda()).sum(), [enc.conv1d_U.weight, enc.conv1d_V.weight])
+    assert y.shape == (4, 512, 3999) and _rel(y, yr.detach()) <= 1e-5
+    assert _rel(gU, rU) <= 1e-4 and _rel(gV, rV) <= 1e-4
+
+
 def test_record_refuses_what_it_does_not_implement():
     from sepkernels.train import FusedTrainStep
     from criterion.sdr import ClippedNegSISDR
