@@ -87,7 +87,7 @@ def test_two_rank_step_matches_single_process(tmp_path):
 # ---------------------------------------------------------------------------------------------------------------------------
 # The recorded launch sequence (ABI 23) under data parallelism: the gradient buckets cut the recorded list into segments, a replayed step
 # runs segment / all-reduce / segment ... / waits / clip + Adam.  Kernels: the kernel SOURCES on the host simulation (tools/hostsim.py) --
-# the emulator has no C ABI to record.  Two ranks, three steps each way (eager; recorded + two replays): same losses, same parameters.
+# the emulator has no C ABI to record.  Two ranks, two steps each way (eager; recorded + one replay): same losses, same parameters.
 def _recorded_worker(rank, world, port, out_dir, so):
     _setup_paths()
     sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -101,7 +101,7 @@ def _recorded_worker(rank, world, port, out_dir, so):
     from criterion.sdr import NegSISDR
     from criterion.pit import PIT1d
     g = torch.Generator().manual_seed(7)
-    batches = [0.1 * torch.randn(2, 2, 1203, generator=g) for _ in range(3)]          # (both ranks draw the same stream; each takes its utterance)
+    batches = [0.1 * torch.randn(2, 2, 803, generator=g) for _ in range(2)]           # (both ranks draw the same stream; each takes its utterance)
     out = {}
     with hostsim.HostSimBackend(so) as K:
         class Named:
@@ -148,7 +148,7 @@ def test_two_rank_recorded_step_matches_the_eager_two_rank_step(tmp_path):
     r1 = torch.load(os.path.join(tmp_path, "rec_rank1.pt"))
     for r in (r0, r1):
         (le, pe), (lr, pr) = r[False], r[True]
-        assert le == lr and le[0] != le[2], (le, lr)                # the recorded step is the eager step, launch for launch
+        assert le == lr and le[0] != le[1], (le, lr)                # the recorded step is the eager step, launch for launch
         assert (pe - pr).abs().max() <= 2e-7 * pe.abs().max()
     assert torch.equal(r0[True][1], r1[True][1])                   # replicas stay in lock-step
     assert r0[True][0] != r1[True][0]                              # (on different utterances)

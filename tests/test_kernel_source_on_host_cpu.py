@@ -204,7 +204,7 @@ def test_recorded_train_step_replays_through_sep_run_sequence(on_host, kind):
             return getattr(on_host, attr)
     make = (lambda: PIT1d(NegSISDR(), n_sources=2)) if kind == "pit" else (lambda: SinkPIT(NegSISDR(), n_sources=2, coldness=1.0, iteration=7))
     g = torch.Generator().manual_seed(5)
-    batches = [0.1 * torch.randn(2, 2, 1203, generator=g) for _ in range(3)]
+    batches = [0.1 * torch.randn(2, 2, 1203 if kind == "pit" else 803, generator=g) for _ in range(3)]
     old = sepkernels._set_backend_for_tests(Named())
     runs = []
     try:
