@@ -58,17 +58,24 @@ __device__ __forceinline__ int w16_f8(const int row) { return ((row >> 1) & 1) |
 __device__ __forceinline__ f32x16 w16_mfma(const u32x4_t a, const u32x4_t b, const f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
 }
+// W16_CEILING_PROBE (tools/call_r08n.sh only): the main loop WITHOUT its workgroup barriers -- wrong results, no hang (nothing spins): the time such
+// a build takes bounds what a flag protocol instead of the barrier per chunk could gain
+#ifdef W16_CEILING_PROBE
+#define W16_BARRIER() do { } while (0)
+#else
+#define W16_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
 template <int N>
 __device__ __forceinline__ void w16_wait_barrier() {      // vmcnt(N) lgkmcnt(0), then the workgroup barrier
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0x0070 | (N & 15) | ((N >> 4) << 14));
-    __builtin_amdgcn_s_barrier();
+    W16_BARRIER();
     asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ void w16_lgkm0_barrier() {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_s_barrier();
+    W16_BARRIER();
     asm volatile("" ::: "memory");
 }
 // Single-instruction forms (see gemm_pc.hip): the maximum with the lane 32 away as one v_permlane32_swap (no LDS round trip in the middle
