@@ -344,6 +344,11 @@ __global__ __launch_bounds__(512, 2) void pw_gemm_pc_kernel(const sep_gemm_desc 
                             w[e] = x;
                         }
                     }
+#ifdef PCD_PROBE_NOSPLIT      // ceiling probe (tools/call_r08o.sh): X as if it arrived pre-split -- WRONG results, timing only
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { hi[cc][q] = __builtin_bit_cast(unsigned, w[2 * q]); lo[cc][q] = __builtin_bit_cast(unsigned, w[2 * q + 1]); }
+                    continue;
+#endif
                     float m = fmaxf(fmaxf(fmaxf(fmaxf(fabsf(w[0]), fabsf(w[1])), fabsf(w[2])), fmaxf(fmaxf(fabsf(w[3]), fabsf(w[4])), fabsf(w[5]))),
                                     fmaxf(fabsf(w[6]), fabsf(w[7])));
                     // the column's other 8 contraction rows sit in the neighbouring lane (quad_perm [1,0,3,2])
