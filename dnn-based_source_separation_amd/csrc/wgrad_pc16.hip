@@ -381,8 +381,11 @@ __device__ __forceinline__ void w16_body(const sep_wgrad_desc& d, const int bid)
         // micro-steps of the split of row block mi: (A) the row's new scale exponent; (B q) values 2q, 2q+1 scaled and split
         auto split_exp = [&](auto mic, const bool live) __attribute__((always_inline)) {
             constexpr int mi = decltype(mic)::value;
-#ifdef W16_PROBE_NOSPLIT      // ceiling probe (tools/call_r08o.sh): G as if it arrived pre-split -- WRONG results, timing only
-            (void)live; gdelta[mi] = 0; W16_SB(); return;
+#if defined(W16_PROBE_NOSPLIT) || defined(W16_PROBE_NOSPLIT_MI1)      // ceiling probes (tools/call_r08o.sh, r08r): G (or the second row block of every wave) as if it arrived pre-split -- WRONG results, timing only
+#ifdef W16_PROBE_NOSPLIT_MI1
+            if (mi == 1)
+#endif
+            { (void)live; gdelta[mi] = 0; W16_SB(); return; }
 #endif
             const float rsum = ((ra[mi][0] + ra[mi][1]) + (ra[mi][2] + ra[mi][3])) + ((ra[mi][4] + ra[mi][5]) + (ra[mi][6] + ra[mi][7]));
             bias_acc[mi] += (do_bias && live) ? rsum : 0.f;
@@ -397,8 +400,11 @@ __device__ __forceinline__ void w16_body(const sep_wgrad_desc& d, const int bid)
         auto split_pair = [&](auto parc, auto mic, auto qc) __attribute__((always_inline)) {      // straight into the operand registers of set `par`
             constexpr int par = decltype(parc)::value, mi = decltype(mic)::value, q = decltype(qc)::value;
             unsigned hi, lo;
-#ifdef W16_PROBE_NOSPLIT
+#if defined(W16_PROBE_NOSPLIT)
             hi = __builtin_bit_cast(unsigned, ra[mi][2 * q]); lo = __builtin_bit_cast(unsigned, ra[mi][2 * q + 1]);
+#elif defined(W16_PROBE_NOSPLIT_MI1)
+            if (mi == 1) { hi = __builtin_bit_cast(unsigned, ra[mi][2 * q]); lo = __builtin_bit_cast(unsigned, ra[mi][2 * q + 1]); }
+            else w16_split2_pair(__builtin_ldexpf(ra[mi][2 * q], gexp[mi]), __builtin_ldexpf(ra[mi][2 * q + 1], gexp[mi]), hi, lo);
 #else
             w16_split2_pair(__builtin_ldexpf(ra[mi][2 * q], gexp[mi]), __builtin_ldexpf(ra[mi][2 * q + 1], gexp[mi]), hi, lo);
 #endif
