@@ -60,7 +60,7 @@ const seq_entry SEQ_TABLE[] = {
     SEQ_FN(sep_sisdr_from_dots), SEQ_FN(sep_sisdr_bwd), SEQ_FN(sep_pit_search), SEQ_FN(sep_sinkhorn_fwd), SEQ_FN(sep_sinkhorn_bwd),
     SEQ_FN(sep_rowdiff_sums), SEQ_FN(sep_rowdiff_bwd), SEQ_FN(sep_sqnorm), SEQ_FN(sep_adam_step), SEQ_FN(sep_adam_step_dev),
     SEQ_FN(sep_lstm_fwd), SEQ_FN(sep_lstm_bwd), SEQ_FN(sep_linear_fwd), SEQ_FN(sep_linear_bwd_input), SEQ_FN(sep_linear_bwd_weight),
-    SEQ_FN(sep_chunk_to_tokens), SEQ_FN(sep_tokens_to_chunk), SEQ_FN(sep_memset), SEQ_FN(sep_absmax), SEQ_FN(sep_pit_finish), SEQ_FN(sep_axpby),
+    SEQ_FN(sep_chunk_to_tokens), SEQ_FN(sep_tokens_to_chunk), SEQ_FN(sep_memset), SEQ_FN(sep_absmax), SEQ_FN(sep_pit_finish), SEQ_FN(sep_axpby), SEQ_FN(sep_split_rows),
 };
 constexpr int SEQ_COUNT = (int)(sizeof(SEQ_TABLE) / sizeof(SEQ_TABLE[0]));
 

@@ -2053,3 +2053,96 @@ extern "C" int sep_depthwise_bwd_weight(const float* dy, const float* x, float* 
     SEP_CHECK_LAUNCH("sep_depthwise_bwd_weight");
     return 0;
 }
+
+
+// =====================================================================================
+// sep_split_rows: rows of an activation tensor split once into the {hi, lo} fp16 operand form of the fp16 weight-gradient kernel's G operand
+// (wgrad_pc16.hip, G2_pre): the skip gradient dS is the second G source of all 24 heads' weight gradients of a Conv-TasNet step (reference
+// src/models/tdcn.py:173,175: the skip / output pointwise convolutions), so its half of the split arithmetic is done here once per step.
+// One workgroup per (sample, row); the row (ldt <= 8192 floats) stays in registers between the maximum and the split.
+// =====================================================================================
+namespace {
+constexpr int SPLIT_MAXK = 8;
+typedef __fp16 split_h2_t __attribute__((ext_vector_type(2)));
+template <int NIT>
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, unsigned* __restrict__ out, int* __restrict__ exps,
+                                                         float* __restrict__ sums, int C, int T, int ldt, int k) {
+    __shared__ float red[4][SPLIT_MAXK + 1];
+    const int row = blockIdx.x;                       // b * C + r
+    const int b = row / C, r = row % C;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nq4 = ldt / 4, per = ldt / k;
+    float4 v[NIT];
+    float m = 0.f;
+    float rs[SPLIT_MAXK];
+#pragma unroll
+    for (int q = 0; q < SPLIT_MAXK; ++q) rs[q] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int q = threadIdx.x + 256 * i;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < nq4) {
+            v[i] = ld4(x + (size_t)row * ldt + 4 * q);
+            const float e4[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+            float s4 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float val = 4 * q + e < T ? e4[e] : 0.f;
+                m = fmaxf(m, fabsf(val));
+                s4 += val;
+            }
+            const int range = (4 * q) / per;              // per is a multiple of 32: the four frames lie in one range
+#pragma unroll
+            for (int qq = 0; qq < SPLIT_MAXK; ++qq) rs[qq] += qq == range ? s4 : 0.f;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+#pragma unroll
+    for (int qq = 0; qq < SPLIT_MAXK; ++qq) rs[qq] = wave_sum(rs[qq]);
+    if (lane == 0) {
+        red[wv][SPLIT_MAXK] = m;
+#pragma unroll
+        for (int qq = 0; qq < SPLIT_MAXK; ++qq) red[wv][qq] = rs[qq];
+    }
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0][SPLIT_MAXK], red[1][SPLIT_MAXK]), fmaxf(red[2][SPLIT_MAXK], red[3][SPLIT_MAXK]));
+    const int ex = m > 0.f ? 13 - __builtin_amdgcn_frexp_expf(m) : 0;      // m = f 2^e', f in [0.5, 1): the maximum lands in [2^12, 2^13)
+    if (threadIdx.x == 0) exps[row] = ex;
+    if (sums && (int)threadIdx.x < k) sums[((size_t)b * k + threadIdx.x) * C + r] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    unsigned* orow = out + (size_t)row * ldt;          // the row in 32-bit words: 32 words per 32-frame line = 16 words of hi pairs, 16 of lo pairs
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int q = threadIdx.x + 256 * i;
+        if (q < nq4) {
+            const int t = 4 * q;
+            const float e4[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+            float w4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w4[e] = t + e < T ? __builtin_ldexpf(e4[e], ex) : 0.f;
+            unsigned hi[2], lo[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const split_h2_t hh = __builtin_amdgcn_cvt_pkrtz(w4[2 * h], w4[2 * h + 1]);
+                hi[h] = __builtin_bit_cast(unsigned, hh);
+                const float l0 = w4[2 * h] - (float)hh.x, l1 = w4[2 * h + 1] - (float)hh.y;      // exact in fp32
+                lo[h] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l0, l1));
+            }
+            unsigned* line = orow + (t / 32) * 32;        // 128 bytes per 32 frames
+            const int w0 = (t % 32) / 2;                  // word of the frame pair inside the hi half
+            line[w0] = hi[0]; line[w0 + 1] = hi[1];
+            line[16 + w0] = lo[0]; line[16 + w0 + 1] = lo[1];
+        }
+    }
+}
+}  // namespace
+
+extern "C" int sep_split_rows(const float* x, void* out, int32_t* exps, float* sums, int B, int C, int T, int ldt, int k, sep_stream_t stream) {
+    SEP_REQUIRE(x && out && exps && B > 0 && C > 0 && T > 0 && ldt >= T && ldt % 128 == 0 && ldt <= 8192, "sep_split_rows: bad sizes (ldt <= 8192)");
+    SEP_REQUIRE(k >= 1 && k <= SPLIT_MAXK && ldt % (32 * k) == 0 && (long)B * C <= 0x7fffffffL, "sep_split_rows: k = %d must divide ldt / 32 (<= %d)", k, SPLIT_MAXK);
+    const dim3 grid((unsigned)((long)B * C));
+    if (ldt <= 4096) hipLaunchKernelGGL(split_rows_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, reinterpret_cast<unsigned*>(out), exps, sums, C, T, ldt, k);
+    else hipLaunchKernelGGL(split_rows_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, x, reinterpret_cast<unsigned*>(out), exps, sums, C, T, ldt, k);
+    SEP_CHECK_LAUNCH("sep_split_rows");
+    return 0;
+}

@@ -145,7 +145,7 @@ __device__ __forceinline__ void w16_dma_pieces4(const float* pa, const unsigned 
 
 // The kernel's body.  `bid` is the workgroup's index within ITS product: the single-product kernel passes blockIdx.x, the batched kernel
 // (several products of identical shape in one launch, see below) the index within the product's share of the grid.
-template <int WR, int WC, int XMODE>
+template <int WR, int WC, int XMODE, bool G2PRE = false>
 __device__ __forceinline__ void w16_body(const sep_wgrad_desc& d, const int bid) {
     constexpr bool X_GLN = XMODE == SEP_PRO_GLN || XMODE == SEP_PRO_GLN_PRELU;
     constexpr bool X_PRELU = XMODE == SEP_PRO_PRELU || XMODE == SEP_PRO_GLN_PRELU;
@@ -361,26 +361,34 @@ __device__ __forceinline__ void w16_body(const sep_wgrad_desc& d, const int bid)
         float ra[2][8];                                                          // raw G: [mi][frame 8*lk + e] of row 64*wr + 32*mi + l31
         float bias_acc[2] = {0.f, 0.f};
         int gexp[2] = {W16UNSET, W16UNSET};                                      // running scale exponents of this lane's two G rows
+        if (G2PRE) gexp[1] = d.g2_exps[(size_t)(c_begin / cps_t) * (d.M - d.g_split) + (m0 + 128 - d.g_split) + 32 * wr + l31];      // (the slab lies in ONE sample: checked by the launcher)
         int gdelta[2] = {0, 0};                                                  // their change with the chunk split last: applied to the accumulators
                                                                                  // before that chunk's first MFMA
         int bcur[2][2] = {{W16UNSET, W16UNSET}, {W16UNSET, W16UNSET}};           // scale the accumulators of column block (h, n) are in
         int en[2][2];
         const int g_f = w16_f8(l31);
-        const int g_off = (64 * wr + l31) * RL;
+        // Row blocks of the 256-row tile by wave: block mi = 0 of wave wr is rows 32 wr + [0, 32), block mi = 1 rows 128 + 32 wr + [0, 32) -- with a two-source G
+        // (g_split = 128: [dout; dS] of the heads) every wave owns 32 rows of each source, so that a PRE-SPLIT second source (G2PRE) halves the split
+        // arithmetic of EVERY consumer wave instead of freeing two of the four
+        const int g_off = (32 * wr + l31) * RL;
         const int b_off = (128 * wcc + l31) * 4 + lk * 2 * TN * 4;               // + (64 * h + 32 * n) * 4 + part * TN * 4
 #define W16_SB() __builtin_amdgcn_sched_barrier(0)
         // raw G rows of block mi of chunk `par` of the pair in stage gstage
         auto read_raw_mi = [&](const int gstage, auto parc, auto mic) __attribute__((always_inline)) {
             constexpr int par = decltype(parc)::value, mi = decltype(mic)::value;
-            const float* Gb = sm.Gr[gstage] + g_off + mi * 32 * RL;
-            const float4 x = ld4(Gb + 4 * ((4 * par + 2 * lk) ^ g_f));
-            const float4 y = ld4(Gb + 4 * ((4 * par + 2 * lk + 1) ^ g_f));
+            const float* Gb = sm.Gr[gstage] + g_off + mi * 128 * RL;
+            // raw fp32: frames 8 lk .. 8 lk + 7 of chunk `par` are granules 4 par + 2 lk, + 1 of the row's 128-byte line; a pre-split line holds
+            // {32 hi | 32 lo} fp16: the eight hi values are granule 2 par + lk, the eight lo values granule 4 + 2 par + lk
+            constexpr bool pre = G2PRE && mi == 1;
+            const float4 x = ld4(Gb + 4 * ((pre ? 2 * par + lk : 4 * par + 2 * lk) ^ g_f));
+            const float4 y = ld4(Gb + 4 * ((pre ? 4 + 2 * par + lk : 4 * par + 2 * lk + 1) ^ g_f));
             ra[mi][0] = x.x; ra[mi][1] = x.y; ra[mi][2] = x.z; ra[mi][3] = x.w; ra[mi][4] = y.x; ra[mi][5] = y.y; ra[mi][6] = y.z; ra[mi][7] = y.w;
             W16_SB();
         };
         // micro-steps of the split of row block mi: (A) the row's new scale exponent; (B q) values 2q, 2q+1 scaled and split
         auto split_exp = [&](auto mic, const bool live) __attribute__((always_inline)) {
             constexpr int mi = decltype(mic)::value;
+            if constexpr (G2PRE && mi == 1) { (void)live; gdelta[mi] = 0; W16_SB(); return; }      // one scale per row and sample, fixed by sep_split_rows
 #if defined(W16_PROBE_NOSPLIT) || defined(W16_PROBE_NOSPLIT_MI1)      // ceiling probes (tools/call_r08o.sh, r08r): G (or the second row block of every wave) as if it arrived pre-split -- WRONG results, timing only
 #ifdef W16_PROBE_NOSPLIT_MI1
             if (mi == 1)
@@ -400,6 +408,13 @@ __device__ __forceinline__ void w16_body(const sep_wgrad_desc& d, const int bid)
         auto split_pair = [&](auto parc, auto mic, auto qc) __attribute__((always_inline)) {      // straight into the operand registers of set `par`
             constexpr int par = decltype(parc)::value, mi = decltype(mic)::value, q = decltype(qc)::value;
             unsigned hi, lo;
+            if constexpr (G2PRE && mi == 1) {                                    // the registers hold the operand halves already
+                sa[par][mi][0][q] = __builtin_bit_cast(unsigned, ra[mi][q]);
+                sa[par][mi][1][q] = __builtin_bit_cast(unsigned, ra[mi][4 + q]);
+                asm volatile("" : "+v"(sa[par][mi][0]), "+v"(sa[par][mi][1]));
+                W16_SB();
+                return;
+            }
 #if defined(W16_PROBE_NOSPLIT)
             hi = __builtin_bit_cast(unsigned, ra[mi][2 * q]); lo = __builtin_bit_cast(unsigned, ra[mi][2 * q + 1]);
 #elif defined(W16_PROBE_NOSPLIT_MI1)
@@ -556,8 +571,9 @@ __device__ __forceinline__ void w16_body(const sep_wgrad_desc& d, const int bid)
         if (do_bias && wcc == 0) {
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
-                const float tot = bias_acc[mi] + __shfl_xor(bias_acc[mi], 32, 64);     // the two lane halves own different frames
-                if (lk == 0) d.partial_bias[(size_t)s * d.M + m0 + 64 * wr + 32 * mi + l31] = tot;
+                float tot = bias_acc[mi] + __shfl_xor(bias_acc[mi], 32, 64);           // the two lane halves own different frames
+                if (G2PRE && mi == 1) tot = d.g2_sums[(size_t)s * (d.M - d.g_split) + (m0 + 128 - d.g_split) + 32 * wr + l31];      // summed once by sep_split_rows
+                if (lk == 0) d.partial_bias[(size_t)s * d.M + m0 + 128 * mi + 32 * wr + l31] = tot;
             }
         }
     }
@@ -570,7 +586,7 @@ __device__ __forceinline__ void w16_body(const sep_wgrad_desc& d, const int bid)
         const int ewr = ewid / WC, ewc = ewid % WC, elk = (etid >> 5) & 1, el31 = etid & 31, elane = etid & 63;
         float* Tw = reinterpret_cast<float*>(&sm) + ewid * EPI_WAVE_FLOATS;
         const int rsub = elane >> 4, c4 = elane & 15;
-        float* out = d.partial + (size_t)es * d.M * d.N + (size_t)(em0 + ewr * 64) * d.N + en0 + ewc * 128 + 4 * c4;
+        float* out = d.partial + (size_t)es * d.M * d.N + (size_t)(em0 + ewr * 32) * d.N + en0 + ewc * 128 + 4 * c4;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -585,16 +601,16 @@ __device__ __forceinline__ void w16_body(const sep_wgrad_desc& d, const int bid)
 #pragma unroll
                 for (int p8 = 0; p8 < 8; ++p8) {
                     const int row = 4 * p8 + rsub;
-                    st4(out + (size_t)(mi * 32 + row) * d.N + h * 64, ld4(Tw + row * EPI_LD + 4 * c4));
+                    st4(out + (size_t)(mi * 128 + row) * d.N + h * 64, ld4(Tw + row * EPI_LD + 4 * c4));
                 }
                 __builtin_amdgcn_wave_barrier();
             }
     }
 }
 
-template <int WR, int WC, int XMODE>
+template <int WR, int WC, int XMODE, bool G2PRE = false>
 __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_kernel(const sep_wgrad_desc d) {
-    w16_body<WR, WC, XMODE>(d, (int)blockIdx.x);
+    w16_body<WR, WC, XMODE, G2PRE>(d, (int)blockIdx.x);
 }
 
 // Several weight gradients of IDENTICAL shape and prologue in one launch (sep_pw_wgrad_batch): the conv1 weight gradients of consecutive TCN
@@ -620,11 +636,11 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_pc16_batch_kernel(const W16Ba
     w16_body<WR, WC, XMODE>(d, (int)blockIdx.x - k * b.per);
 }
 
-template <int WR, int WC, int XMODE>
+template <int WR, int WC, int XMODE, bool G2PRE = false>
 void launch_w16(const sep_wgrad_desc& d, hipStream_t stream) {
     const int ntiles = (d.M / (64 * WR)) * (d.N / (128 * WC));
     const int grid = 8 * ntiles * ceil_div(d.nsplit, 8);
-    hipLaunchKernelGGL((pw_wgrad_pc16_kernel<WR, WC, XMODE>), dim3(grid), dim3(512), 0, stream, d);
+    hipLaunchKernelGGL((pw_wgrad_pc16_kernel<WR, WC, XMODE, G2PRE>), dim3(grid), dim3(512), 0, stream, d);
 }
 
 template <int WR, int WC, int XMODE>
@@ -643,6 +659,21 @@ int sep_pw_wgrad_pc16(const sep_wgrad_desc* d, hipStream_t stream) {
     if (d->M % 256 != 0 || d->N % 128 != 0) return 0;
     if ((size_t)d->M * d->ldt * 4 >= (1ull << 32) || (size_t)d->N * d->ldt * 4 >= (1ull << 32)) return 0;      // 32-bit DMA offsets
     if ((long)d->nsplit > (long)d->B * (d->ldt / DK)) return 0;
+    // second G source handed over PRE-SPLIT (sep_split_rows): the heads' [dout; dS] with dS split once per step for all layers.  One 256-row tile
+    // (M = 256, g_split = 128), slabs inside one sample (the row scales are per sample), the bias partials of those rows come with it.
+    if (d->G2_pre != nullptr) {
+        const long cps_t = d->ldt / DK, chunks_total = (long)d->B * cps_t;
+        long cper = (chunks_total + d->nsplit - 1) / d->nsplit;
+        cper += cper & 1;
+        if (!(d->M == 256 && d->g_split == 128 && d->g2_exps && (d->g2_sums || !d->partial_bias) && cps_t % cper == 0 &&
+              (d->x_mode == SEP_PRO_PRELU || d->x_mode == SEP_PRO_NONE)))
+            return 0;
+        sep_wgrad_desc q = *d;
+        q.G2 = reinterpret_cast<const float*>(d->G2_pre);      // same row pitch and line size as the fp32 tensor: the DMA does not change
+        if (d->x_mode == SEP_PRO_PRELU) launch_w16<4, 1, SEP_PRO_PRELU, true>(q, stream);
+        else launch_w16<4, 1, SEP_PRO_NONE, true>(q, stream);
+        return 1;
+    }
 #define SEP_LW(XM)                                           \
     do {                                                     \
         launch_w16<4, 1, XM>(*d, stream);                    \

@@ -79,7 +79,7 @@ class GemmDesc(ctypes.Structure):
 class WgradDesc(ctypes.Structure):
     _fields_ = [(n, _i32) for n in ("B", "M", "N", "T", "ldt", "g_split", "g_mul", "g_div", "x_mode", "x_div", "nsplit", "arith")] + \
                [("eps", ctypes.c_float), ("count", ctypes.c_double)] + \
-               [(n, _vp) for n in ("G", "G2", "Gaux", "X", "x_alpha", "x_stats", "x_gamma", "x_beta", "partial", "partial_bias")]
+               [(n, _vp) for n in ("G", "G2", "Gaux", "X", "x_alpha", "x_stats", "x_gamma", "x_beta", "partial", "partial_bias", "G2_pre", "g2_exps", "g2_sums")]
 
 
 class PackSeg(ctypes.Structure):
@@ -190,6 +190,7 @@ SIGNATURES = {
     "sep_absmax": [_vp, _L, _vp, _vp],
     "sep_pit_finish": [_vp, _vp, _vp, _I, _I, _I, _F, _F, _vp, _vp, _vp, _vp],
     "sep_axpby": [_vp, _F, _vp, _F, _vp, _L, _vp],
+    "sep_split_rows": [_vp, _vp, _vp, _vp, _I, _I, _I, _I, _I, _vp],
 }
 _RESTYPES = {"sep_last_error": ctypes.c_char_p, "sep_seq_name": ctypes.c_char_p, "sep_cln_ws_bytes": ctypes.c_size_t,
              "sep_gln_tokens_ws_bytes": ctypes.c_size_t}
@@ -429,12 +430,24 @@ class HipBackend:
 
     def pw_wgrad(self, *, B, M, N, T, ldt, G, X, partial, nsplit, G2=None, g_split=0, Gaux=None, g_mul=0, g_div=1,
                  x_mode=PRO_NONE, x_div=1, eps=1e-12, count=0.0, x_alpha=None, x_stats=None, x_gamma=None, x_beta=None,
-                 partial_bias=None, arith=None):
+                 partial_bias=None, arith=None, G2_pre=None):
+        """G2_pre: (planes, exps, sums) of the second G source as sep_split_rows wrote them (split_rows below), or None"""
         d = WgradDesc(B=B, M=M, N=N, T=T, ldt=ldt, g_split=g_split, g_mul=g_mul, g_div=g_div, x_mode=x_mode, x_div=x_div,
                       nsplit=nsplit, arith=gemm_arith() if arith is None else arith, eps=eps, count=float(count), G=_ptr(G, _f32), G2=_ptr(G2, _f32), Gaux=_ptr(Gaux, _f32),
                       X=_ptr(X, _f32), x_alpha=_ptr(x_alpha, _f32), x_stats=_ptr(x_stats, _f64), x_gamma=_ptr(x_gamma, _f32),
-                      x_beta=_ptr(x_beta, _f32), partial=_ptr(partial, _f32), partial_bias=_ptr(partial_bias, _f32))
+                      x_beta=_ptr(x_beta, _f32), partial=_ptr(partial, _f32), partial_bias=_ptr(partial_bias, _f32),
+                      G2_pre=_ptr(G2_pre[0], _f32) if G2_pre else None, g2_exps=_ptr(G2_pre[1], torch.int32) if G2_pre else None,
+                      g2_sums=_ptr(G2_pre[2], _f32) if G2_pre else None)
         _check(load().sep_pw_wgrad(ctypes.byref(d), _stream()), "sep_pw_wgrad")
+
+    def split_rows(self, x, T, k):
+        """x (B, C, ldt) -> (planes (B, C, ldt) holding {32 hi | 32 lo} fp16 per 32 frames, exps (B, C) int32, sums (B * k, C)): sep_split_rows"""
+        B, C, ldt = x.shape
+        planes = torch.empty_like(x)
+        exps = torch.empty(B, C, device=x.device, dtype=torch.int32)
+        sums = torch.empty(B * k, C, device=x.device, dtype=x.dtype)
+        _check(load().sep_split_rows(_ptr(x, _f32), _ptr(planes, _f32), _ptr(exps, torch.int32), _ptr(sums, _f32), B, C, T, ldt, k, _stream()), "sep_split_rows")
+        return planes, exps, sums
 
     def pw_wgrad_batch(self, calls):
         """calls: list (<= 8) of pw_wgrad keyword dicts that agree in everything but G, G2, X, partial, partial_bias: one launch"""

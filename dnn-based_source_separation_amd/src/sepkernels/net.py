@@ -522,6 +522,16 @@ def _backward(cfg, P, sv, d_est, G, on_ready, want_dmix=False):
     PK = getattr(sv, "packs", None) or {}
     dS, dwm = tail_backward(cfg, P, geo, w, skip, m, mixture.shape, d_est, G, dalpha[nl:nl + 1], PK)
 
+    # The skip gradient dS is the second G source of EVERY layer's heads weight gradient: its half of that kernel's operand split is done once here
+    # (sep_split_rows: {hi, lo} fp16 lines, one scale per sample and row, the bias partials of its rows) instead of 24 times inside the kernels'
+    # consumer waves (profiles/r08_round6_experiments.md, r08r: 83 -> 70 us per launch).  The fp16 kernel's shape only: [Wo;Ws] as one 256-row product.
+    dS_pre = None
+    if (hasattr(K, "split_rows") and sepkernels.gemm_arith() == sepkernels.ARITH_F16X3 and Bn == 128 and Sc == 128 and H % 128 == 0
+            and os.environ.get("SEPK_WGRAD_PRESPLIT", "1") != "0" and ldt <= 8192):
+        k_heads = _nsplit_aligned(Bn + Sc, H, B, ldt) // B
+        if (ldt // 32) % k_heads == 0 and k_heads <= 8:
+            dS_pre = K.split_rows(dS, F, k_heads)
+
     # ---- TCN layers, reversed -----------------------------------------------------------------------
     side = _SideStream(dev)
     side.fork()   # dS exists
@@ -601,7 +611,8 @@ def _backward(cfg, P, sv, d_est, G, on_ready, want_dmix=False):
         side.keep(pbeta2, pgamma2, *dWbs)
         with side:
             for hi, (Gt, G2t, gsp, rows, Wmat, wnames, bnames) in enumerate(heads):
-                part, pb, ns = wgrad(rows, H, Gt, z, True, True, G2=G2t, g_split=gsp, **xkw)
+                pre_kw = dict(G2_pre=dS_pre) if (dS_pre is not None and G2t is dS and gsp == Bn and rows == Bn + Sc) else {}
+                part, pb, ns = wgrad(rows, H, Gt, z, True, True, G2=G2t, g_split=gsp, **pre_kw, **xkw)
                 side.lend(pb)           # reduced on the MAIN stream by the flush of `pending`
                 K.gln_bwd_from_wgrad(part, pb, Wmat, st2, g2, b2, cnt, teps, dWbs[hi], pbeta2, pgamma2, bacc[2 + 2 * li], arrive[2 + 2 * li],
                                      bsum[2 + 2 * li], B, rows, H, ns // B, accumulate=int(hi > 0), products=len(heads))

@@ -171,6 +171,13 @@ typedef struct sep_wgrad_desc {
     const float* x_beta;
     float* partial;      /* [nsplit][M][N] */
     float* partial_bias; /* [nsplit][M] or NULL */
+    /* ABI 23: the second G source PRE-SPLIT by sep_split_rows (NULL: not used).  With M = 256, g_split = 128 and slabs that lie inside one sample the fp16
+     * weight-gradient kernel takes rows m >= g_split as ready {hi, lo} operands (no split arithmetic for them in any layer that reads the same tensor:
+     * the skip gradient dS of the Conv-TasNet step is the second source of all 24 heads' weight gradients); G2 must still be given (other kernels,
+     * other shapes fall back to it). */
+    const void* G2_pre;    /* [B][M - g_split][ldt / 32] lines of 128 bytes: 32 hi then 32 lo fp16 of x * 2^e */
+    const int32_t* g2_exps; /* [B][M - g_split]: e */
+    const float* g2_sums;  /* [nsplit][M - g_split]: sum over the slab's frames (the bias partials of those rows), or NULL with partial_bias == NULL */
 } sep_wgrad_desc;
 
 int sep_pw_wgrad(const sep_wgrad_desc* d, sep_stream_t stream);
@@ -180,6 +187,13 @@ int sep_pw_wgrad(const sep_wgrad_desc* d, sep_stream_t stream);
  * gets n times longer contractions per workgroup and 1/n of the slab traffic.  Other shapes / arithmetics: n calls of sep_pw_wgrad.
  * Same results as n separate calls with the same nsplit.  (ABI 23; reference: the same convolutions' weight gradients, tdcn.py:86.) */
 int sep_pw_wgrad_batch(const sep_wgrad_desc* descs_host, int n, sep_stream_t stream);
+/* Rows of an activation tensor split ONCE for every weight gradient that takes them as (second) G operand: for row r of sample b
+ *   e = 13 - exponent(max_t |x[b][r][t]|)   (the row's maximum lands in [2^12, 2^13); an all-zero row: e = 0)
+ *   out line (b, r, p) = { hi[32] | lo[32] } fp16 of x[b][r][32 p .. 32 p + 31] * 2^e,  hi = fp16 toward zero, lo = fp16(x 2^e - hi)
+ *   sums[(b * k + q) * C + r] = sum of x[b][r][t] over the q-th of k equal frame ranges of the row (k slabs per sample: the bias partials)
+ * out has the shape and row pitch of x (B, C, ldt floats).  ldt % (32 k) == 0.  (ABI 23; no reference counterpart: it is half of the operand split
+ * of the heads' weight gradient, reference src/models/tdcn.py:173,175, hoisted out of the 24 layers.) */
+int sep_split_rows(const float* x, void* out, int32_t* exps, float* sums, int B, int C, int T, int ldt, int k, sep_stream_t stream);
 
 /* dst[i] (+)= scale * sum_s src[s*stride + i] for up to 64 independent segments in one launch
  * (deterministic second stage of every split reduction). */

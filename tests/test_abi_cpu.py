@@ -43,7 +43,7 @@ def test_descriptor_layouts_match_the_header():
     assert ctypes.sizeof(sepkernels.GemmDesc) == 64 + 25 * 8
     assert sepkernels.GemmDesc.A_pk.offset == 64 + 23 * 8 and ctypes.sizeof(sepkernels.PackSeg) == 40
     assert sepkernels.WgradDesc.arith.offset == 44 and sepkernels.WgradDesc.count.offset == 56 and sepkernels.WgradDesc.G.offset == 64
-    assert ctypes.sizeof(sepkernels.WgradDesc) == 64 + 10 * 8
+    assert ctypes.sizeof(sepkernels.WgradDesc) == 64 + 13 * 8 and sepkernels.WgradDesc.G2_pre.offset == 64 + 10 * 8      # (ABI 23: G2_pre, g2_exps, g2_sums)
     assert ctypes.sizeof(sepkernels.ReduceSeg) == 40
 
 

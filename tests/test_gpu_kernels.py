@@ -567,6 +567,52 @@ def test_wgrad_batch_equals_separate_calls(B, M, N, T, ns, n, arith):
         HIP.pw_wgrad_batch([calls[0], dict(calls[1], nsplit=ns + 1)])
 
 
+@pytest.mark.parametrize("B,N,T,k", [(2, 128, 999, 4), (1, 512, 3999, 4), (3, 128, 300, 1)])
+def test_wgrad_with_a_presplit_second_source(B, N, T, k):
+    """sep_split_rows + sep_wgrad_desc.G2_pre (round 6): the heads' weight gradient with its second G source -- the skip gradient dS, the same
+    tensor in all 24 layers -- handed over as {hi, lo} fp16 operand lines with one scale per (sample, row), split ONCE.  The split is exact to
+    2^-22 of the row's maximum, its per-slab row sums are the bias partials, and the weight gradient equals the fp64 product as closely as the
+    form that splits dS inside the kernel does (both against |G||X| per output)."""
+    prev = sepkernels.set_gemm_arith("f16x3")
+    try:
+        M, gs = 256, 128
+        ldt = (T + 127) // 128 * 128
+        while (ldt // 32) % k:
+            ldt += 128
+        dout, dS, z = padded(B, gs, T, ldt), padded(B, M - gs, T, ldt, scale=3.0), padded(B, N, T, ldt)
+        dS[:, 5] *= 1e-6                                    # rows of very different scale; a silent row
+        dS[:, 7] = 0
+        al = torch.tensor([0.2])
+        gdout, gdS, gz, gal = (to_device(t) for t in (dout, dS, z, al))
+        planes, exps, sums = HIP.split_rows(gdS, T, k)
+        device_sync()
+        # the planes decode to dS * 2^e: per 32-frame line 32 hi then 32 lo fp16
+        raw = planes.cpu().contiguous().view(torch.float16).view(B, M - gs, ldt // 32, 2, 32).float()
+        rec = (raw[:, :, :, 0] + raw[:, :, :, 1]).reshape(B, M - gs, ldt).double() * torch.pow(2.0, -exps.cpu().double()).unsqueeze(-1)
+        rowmax = dS[..., :T].abs().amax(-1, keepdim=True).double()
+        assert ((rec - dS.double()).abs() <= 2.0 ** -21 * rowmax + 1e-30).all()
+        assert (rec[..., T:] == 0).all() and exps.cpu()[:, 7].abs().max() == 0
+        want = dS[..., :ldt].double().view(B, M - gs, k, ldt // k).sum(-1).permute(0, 2, 1).reshape(B * k, M - gs)
+        assert (sums.cpu().double() - want).abs().max() <= 1e-5 * want.abs().max()
+        ns = B * k
+        outs = []
+        for pre in (None, (planes, exps, sums)):
+            part, pb = to_device(nan(ns, M, N)), to_device(nan(ns, M))
+            HIP.pw_wgrad(B=B, M=M, N=N, T=T, ldt=ldt, G=gdout, G2=gdS, g_split=gs, X=gz, x_mode=PRO_PRELU, x_alpha=gal, partial=part, partial_bias=pb,
+                         nsplit=ns, G2_pre=pre)
+            device_sync()
+            outs.append((part.cpu().double().sum(0), pb.cpu().double().sum(0)))
+        u = torch.where(z > 0, z, al * z).double()
+        G = torch.cat([dout, dS], 1).double()
+        ref = torch.einsum("bmt,bnt->mn", G, u)
+        bound = torch.einsum("bmt,bnt->mn", G.abs(), u.abs())
+        for (w, bsum), name in zip(outs, ("split in the kernel", "pre-split")):
+            assert ((w - ref).abs() <= 2e-6 * bound + 1e-30).all(), name
+            assert (bsum - G.sum((0, 2))).abs().max() <= 1e-5 * G.abs().sum((0, 2)).max(), name
+    finally:
+        sepkernels.set_gemm_arith(prev)
+
+
 @pytest.mark.parametrize("B,M,N,T,k", [(2, 256, 128, 999, 4), (3, 128, 256, 300, 3), (2, 64, 48, 130, 1), (1, 256, 512, 1000, 8), (3, 32, 20, 500, 2)])
 def test_wgrad_sample_aligned_slabs_and_gln_sums_from_them(B, M, N, T, k, arith):
     """The heads' weight gradient as the model's backward takes it: against u = PReLU(z) on nsplit = B * k sample-aligned slabs, then

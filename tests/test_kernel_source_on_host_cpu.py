@@ -96,6 +96,7 @@ GEMM_CASES = [
     (None, "test_wgrad_f16_adversarial_operands", ("zero_rows_then_signal",)),
     ("f16x3", "test_wgrad_plain", (2, 512, 128, 999, 7)),                      # the scaled two-part fp16 weight-gradient kernel
     ("f16x3", "test_wgrad_two_sources_gln_prelu", ()),
+    (None, "test_wgrad_with_a_presplit_second_source", (2, 128, 300, 2)),            # sep_split_rows + the G2_pre form of the fp16 weight-gradient kernel
     ("f16x3", "test_wgrad_batch_equals_separate_calls", (1, 256, 128, 300, 2, 3)),   # the batched grid of the fp16 producer / consumer kernel
     ("f32", "test_wgrad_batch_equals_separate_calls", (2, 64, 32, 201, 2, 2)),       # ... and the entry point's n-calls fallback
     (None, "test_pack_weights_reproduces_the_weights", ()),

@@ -46,6 +46,8 @@ cases = {
 wcases = {
     "W2 conv1 wgrad   512x128": dict(M=H, N=Bn, G=xH, X=xB, nsplit=128),
     "W3 heads wgrad   256x512 gLNPReLU": dict(M=Bn + Sc, N=H, G=xB, G2=xS, g_split=Bn, X=xH, nsplit=64, x_mode=PRO_GLN_PRELU, x_stats=st(), x_gamma=f(H), x_beta=f(H), x_alpha=al, count=H * T),
+    "W3u heads wgrad  256x512 PReLU aligned": dict(M=Bn + Sc, N=H, G=xB, G2=xS, g_split=Bn, X=xH, nsplit=64, x_mode=PRO_PRELU, x_alpha=al),
+    "W3p heads wgrad  256x512 PReLU aligned, dS pre-split": dict(M=Bn + Sc, N=H, G=xB, G2=xS, g_split=Bn, X=xH, nsplit=64, x_mode=PRO_PRELU, x_alpha=al, G2_pre="split"),
     "W4 mask wgrad   1024x128 PReLU": dict(M=ns * N, N=Sc, G=xM, X=xS, nsplit=64, x_mode=PRO_PRELU, x_alpha=al),
     "W1 bneck wgrad   128x512 gLN": dict(M=Bn, N=N, G=xB, X=xN, nsplit=128, x_mode=PRO_GLN, x_stats=st(), x_gamma=f(N), x_beta=f(N), count=N * T),
     "WE enc wgrad     512x16": dict(M=N, N=16, G=xN, X=f(B, 16, ldt), nsplit=128),
@@ -87,6 +89,8 @@ for name, kw in wcases.items():
         continue
     kw = dict(kw, nsplit=int(round(kw["nsplit"] * args.nsplit_scale)))
     ns_ = kw["nsplit"]
+    if kw.get("G2_pre") == "split":
+        kw["G2_pre"] = K.split_rows(kw["G2"], T, ns_ // B)
     part = torch.empty(ns_, kw["M"], kw["N"], device=dev)
     pb = torch.empty(ns_, kw["M"], device=dev)
     ms = timeit(lambda: K.pw_wgrad(B=B, T=T, ldt=ldt, eps=1e-12, partial=part, partial_bias=pb, **kw))
