@@ -180,7 +180,7 @@ KERNEL_OF_CLASS = {
     "gemm heads^T": "pw_gemm_coop_kernel<4, 0, true, 0, 2>",
     "gemm heads": "pw_gemm_pc_kernel<4, 1, 3, false, 2, 4, 4>",
     "gemm conv1": "pw_gemm_coop_kernel<2, 0, false, 1, 2>",
-    "wgrad heads": "pw_wgrad_pc16_kernel<4, 1, 1>",
+    "wgrad heads": "pw_wgrad_pc16_kernel<4, 1, 1, true>",
     "wgrad conv1": "pw_wgrad_pc16_batch_kernel<4, 1, 0>",
     "depthwise fwd": "dwconv_fwd_direct_kernel<0, 2>",
     "depthwise bwd": "dwconv_bwd_row_kernel<0, 4, true>",
