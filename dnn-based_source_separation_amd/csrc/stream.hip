@@ -2062,7 +2062,7 @@ extern "C" int sep_depthwise_bwd_weight(const float* dy, const float* x, float* 
 // One workgroup per (sample, row); the row (ldt <= 8192 floats) stays in registers between the maximum and the split.
 // =====================================================================================
 namespace {
-constexpr int SPLIT_MAXK = 8;
+constexpr int SPLIT_MAXK = 64;      // slabs per sample (small batches: one sample is cut into up to 64 slabs so that the weight gradient still fills the chip)
 typedef __fp16 split_h2_t __attribute__((ext_vector_type(2)));
 template <int NIT>
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, unsigned* __restrict__ out, int* __restrict__ exps,

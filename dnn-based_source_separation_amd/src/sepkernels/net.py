@@ -529,7 +529,7 @@ def _backward(cfg, P, sv, d_est, G, on_ready, want_dmix=False):
     if (hasattr(K, "split_rows") and sepkernels.gemm_arith() == sepkernels.ARITH_F16X3 and Bn == 128 and Sc == 128 and H % 128 == 0
             and os.environ.get("SEPK_WGRAD_PRESPLIT", "1") != "0" and ldt <= 8192):
         k_heads = _nsplit_aligned(Bn + Sc, H, B, ldt) // B
-        if (ldt // 32) % k_heads == 0 and k_heads <= 8:
+        if (ldt // 32) % k_heads == 0 and k_heads <= 64:
             dS_pre = K.split_rows(dS, F, k_heads)
 
     # ---- TCN layers, reversed -----------------------------------------------------------------------

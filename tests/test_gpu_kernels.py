@@ -567,7 +567,7 @@ def test_wgrad_batch_equals_separate_calls(B, M, N, T, ns, n, arith):
         HIP.pw_wgrad_batch([calls[0], dict(calls[1], nsplit=ns + 1)])
 
 
-@pytest.mark.parametrize("B,N,T,k", [(2, 128, 999, 4), (1, 512, 3999, 4), (3, 128, 300, 1)])
+@pytest.mark.parametrize("B,N,T,k", [(2, 128, 999, 4), (1, 512, 3999, 4), (3, 128, 300, 1), (1, 128, 3999, 32)])
 def test_wgrad_with_a_presplit_second_source(B, N, T, k):
     """sep_split_rows + sep_wgrad_desc.G2_pre (round 6): the heads' weight gradient with its second G source -- the skip gradient dS, the same
     tensor in all 24 layers -- handed over as {hi, lo} fp16 operand lines with one scale per (sample, row), split ONCE.  The split is exact to
